@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""ODE steps/sec of the full-graph GRAND-nl diffusion solve (BASELINE.json metric).
+
+One "step" = one rk4 (3/8 rule) solver step = 4 evaluations of f(t,x) = alpha (A(x) x - x) + beta x0 on
+the synthetic ogbn-arxiv-shaped graph (169,343 nodes, ~2.48 M edges incl. self-loops, d = 128,
+attention_dim 16 / 4 heads, softmax over rows, add_source) -- BASELINE.json configs[2].  The K timed
+steps are ONE launch of the hipGraph-captured native solver (T = K, step_size = 1), state resident in HBM.
+
+  python bench.py --gpus 1 --steps 100 --warmup 10
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row-partitioned, RCCL halo)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the CSR aggregation
+spmm_rows_kernel): algorithmic bytes of DESIGN.md section "Kernels" divided by its average launch duration,
+measured here with HIP events on the launch stream over the four rk4-stage variants the solver runs.
+`cpu_baseline` times the CPU oracle (the reference's op sequence) on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--graph', default='arxiv', choices=['arxiv', 'cora', 'rmat'])
+  ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the metric)')
+  ap.add_argument('--att-dim', type=int, default=None)
+  ap.add_argument('--heads', type=int, default=None)
+  ap.add_argument('--function', default='transformer', choices=['transformer', 'laplacian'])
+  ap.add_argument('--no-graph', action='store_true', help='launch the solver eagerly instead of via hipGraph')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-evals', type=int, default=8)
+  ap.add_argument('--seed', type=int, default=0)
+  return ap.parse_args()
+
+
+def build_opt(cfg, args):
+  return dict(heads=args.heads or cfg['heads'], attention_dim=args.att_dim or cfg['att_dim'],
+              attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+              beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True,
+              no_alpha_sigmoid=False, mix_features=False, hidden_dim=cfg['d'], augment=False, adjoint=False,
+              tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
+              function=args.function, time=float(args.steps))
+
+
+class _Data(object):
+  pass
+
+
+def make_block(G, opt, ei, n, x, dev, T, seed):
+  data = _Data()
+  data.x, data.edge_index, data.edge_attr, data.num_nodes = x, ei, None, n
+  fcls = G.ODEFuncTransformerAtt if opt['function'] == 'transformer' else G.LaplacianODEFunc
+  block = G.ConstantODEblock(fcls, [], dict(opt, time=T), data, dev, t=torch.tensor([0, T])).to(dev)
+  g = torch.Generator().manual_seed(seed + 1)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if p.dim() >= 2 and 'multihead_att_layer' in name:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))  # Q/K ~ N(0, 1/d)
+      elif name.endswith('.bias'):
+        p.zero_()
+    for f in (block.odefunc, block.reg_odefunc.odefunc):
+      f.alpha_train.fill_(0.0)   # sigmoid -> 0.5
+      f.beta_train.fill_(0.1)
+  block.eval()
+  return block
+
+
+def spmm_kernel_time(G, block, x, reps=10):
+  """Average duration of one launch of the aggregation kernel over the 4 rk4 stage epilogues, HIP events on
+  the launch stream (torch's current stream, which is the stream the C ABI is handed)."""
+  from gnpde_amd import ops, _lib
+  f = block.odefunc
+  graph = f._graph(x)
+  d = x.shape[1]
+  dev = x.device
+  w = torch.rand(max(graph.e, 1), device=dev) / 16
+  bufs = [torch.randn_like(x) for _ in range(7)]
+  y, k1, k2, k3, ua, ub, x0 = bufs
+  alpha = ops._scalar_dev(f.alpha_train, x)
+  beta = ops._scalar_dev(f.beta_train, x)
+  stages = [dict(stage=_lib.STAGE_RK1, y=y, out_k=k1, out_y=ua, u=y),
+            dict(stage=_lib.STAGE_RK2, y=y, k1=k1, out_k=k2, out_y=ub, u=ua),
+            dict(stage=_lib.STAGE_RK3, y=y, k1=k1, k2=k2, out_k=k3, out_y=ua, u=ub),
+            dict(stage=_lib.STAGE_RK4, y=y, k1=k1, k2=k2, k3=k3, out_y=y, u=ua)]
+
+  def once():
+    for st in stages:
+      kw = dict(st)
+      u = kw.pop('u')
+      ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
+  once()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    once()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e-3 / (reps * 4), graph
+
+
+def cpu_baseline(block, x_cpu, evals):
+  """Reference op sequence (oracle) on the host cores: a bounded number of full-size evaluations of f."""
+  from oracle import restate as R
+  f = block.odefunc
+  cpu = lambda t: t.detach().cpu()
+  edge = cpu(f.edge_index)
+  if hasattr(f, 'multihead_att_layer'):
+    lay = f.multihead_att_layer
+    args = (cpu(lay.Q.weight), cpu(lay.Q.bias), cpu(lay.K.weight), cpu(lay.K.bias), lay.h)
+    rhs = lambda y: R.rhs_transformer(y, edge, *args, cpu(f.alpha_train), cpu(f.beta_train), x_cpu, False, True)
+  else:
+    w = cpu(f.edge_weight)
+    rhs = lambda y: R.rhs_laplacian(y, edge, w, cpu(f.alpha_train), cpu(f.beta_train), x_cpu, False, True)
+  torch.set_num_threads(os.cpu_count())
+  with torch.no_grad():
+    out = rhs(x_cpu)  # warm-up, also the parity reference
+    t0 = time.perf_counter()
+    for _ in range(evals):
+      rhs(x_cpu)
+    dt = (time.perf_counter() - t0) / evals
+  return dt, out
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus != world:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+  import gnpde_amd as G
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
+  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(dev)
+  if world > 1:
+    from gnpde_amd import distributed as D
+    return D.bench_main(args, rank, world, dev)
+
+  cfg = G.synthetic.CONFIGS[args.graph]
+  ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
+  opt = build_opt(cfg, args)
+  d = cfg['d']
+  x_cpu = torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed))
+  x = x_cpu.to(dev)
+  ei = ei_cpu.to(dev)
+  K, W = args.steps, args.warmup
+  use_graph = not args.no_graph
+
+  main_block = make_block(G, opt, ei, n, x, dev, float(K), args.seed)
+  main_block.set_x0(x)
+  with torch.no_grad():
+    if W > 0:
+      warm_block = make_block(G, opt, ei, n, x, dev, float(W), args.seed)
+      warm_block.set_x0(x)
+      if not use_graph:
+        import functools
+        warm_block.test_integrator = functools.partial(G.odeint, use_graph=False)
+      warm_block(x)                       # W untimed warm-up steps
+      del warm_block
+    if not use_graph:
+      import functools
+      main_block.test_integrator = functools.partial(G.odeint, use_graph=False)
+    main_block(x)                          # untimed: instantiates the K-step hipGraph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z = main_block(x)                      # EXACTLY K steps
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+  assert torch.isfinite(z).all()
+  steps_per_s = K / elapsed
+  f = main_block.odefunc
+  E = int(f.edge_index.shape[1])
+  A, h = opt['attention_dim'], opt['heads']
+
+  # roofline of the dominant kernel (B_spmm = E (4 + 4 + 4d) + N (4 + 8d) + 4dN with add_source)
+  t_spmm, graph = spmm_kernel_time(G, main_block, x)
+  bytes_spmm = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n
+  achieved = bytes_spmm / t_spmm / 1e9
+  traffic = None
+  tpath = os.path.join(ROOT, 'profiles', 'spmm_hbm_traffic.json')
+  if os.path.exists(tpath):
+    try:
+      traffic = json.load(open(tpath)).get('%s_d%d' % (args.graph, d))
+    except Exception:
+      traffic = None
+  bytes_eval_nl = E * (4 + 4 * A + 4 * d) + n * (4 + 12 * A + 12 * d) + 4 * d * n
+  bytes_eval = bytes_eval_nl if args.function == 'transformer' else bytes_spmm
+  out = {
+    'metric': 'ODE steps/sec (full-graph diffusion), ogbn-arxiv d=128 rk4',
+    'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
+    'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+    'dtype': 'f32', 'data': 'synthetic',
+    'config': {'workload': 'synthetic ogbn-arxiv-shaped graph (power-law, shuffled ids), GRAND-%s %s, rk4 3/8-rule, '
+                           'step_size 1, T=%d, hipGraph-captured solver' % (
+                             'nl scaled_dot softmax attention' if args.function == 'transformer' else 'l',
+                             'add_source', K),
+               'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
+               'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
+               'long_rows': graph.n_long_rows, 'algorithmic_bytes_per_rhs_eval': bytes_eval,
+               'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
+    'roofline': {'kernel': 'spmm_rows_kernel (CSR aggregation + fused epilogue / rk4 stage)', 'bound': 'hbm',
+                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                 'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2)},
+  }
+  if not args.no_cpu_baseline:
+    t_eval, ref = cpu_baseline(main_block, x_cpu, args.cpu_evals)
+    with torch.no_grad():
+      f.x0 = x
+      got = f(0.0, x)
+    from oracle import restate as R
+    e_inf, e_2 = R.parity_error(got, ref)
+    out['cpu_baseline'] = {'value': round(1.0 / (4 * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                           'kind': 'port',
+                           'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload with the '
+                                     'reference op sequence (oracle/restate.py, torch CPU); steps/s = 1 / (4 t_eval)'
+                                     % (args.cpu_evals, args.cpu_evals / 4.0),
+                           'ms_per_rhs_eval': round(t_eval * 1e3, 2)}
+    out['parity_vs_oracle_one_eval'] = {'rel_max': e_inf, 'rel_l2': e_2}
+    out['speedup_vs_cpu'] = round(steps_per_s / out['cpu_baseline']['value'], 1)
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

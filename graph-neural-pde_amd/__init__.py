@@ -1,0 +1,25 @@
+"""gnpde_amd -- MI355X-native ODE right-hand side for GRAND / BLEND graph neural diffusion.
+
+Same operator surface as the reference's src/ modules of the same names (ODEFunc / ODEblock and the
+function_* / block_* classes); every arithmetic step of f(t,x) and of the fixed-step solver loop
+runs in csrc/libgnpde_hip.so (hand-written gfx950 kernels, C ABI in include/gnpde.h)."""
+from . import _lib
+from ._lib import GnpdeError, build, lib
+from .graph import CSRGraph, graph_of, partition_rows
+from . import ops
+from .utils import MaxNFEException, get_rw_adj, gcn_norm_fill_val, add_remaining_self_loops, DummyData, DummyDataset
+from .odeint import odeint, odeint_adjoint, time_grid
+from .base_classes import ODEFunc, ODEblock, RegularizedODEfunc
+from .function_laplacian_diffusion import LaplacianODEFunc
+from .function_transformer_attention import ODEFuncTransformerAtt, SpGraphTransAttentionLayer
+from .function_GAT_attention import ODEFuncAtt, SpGraphAttentionLayer
+from .block_constant import ConstantODEblock
+from .block_transformer_attention import AttODEblock
+from .model_configurations import set_block, set_function, BlockNotDefined, FunctionNotDefined
+from . import synthetic
+
+__all__ = ['GnpdeError', 'build', 'lib', 'CSRGraph', 'graph_of', 'partition_rows', 'ops', 'MaxNFEException',
+           'get_rw_adj', 'gcn_norm_fill_val', 'add_remaining_self_loops', 'odeint', 'odeint_adjoint', 'time_grid',
+           'ODEFunc', 'ODEblock', 'LaplacianODEFunc', 'ODEFuncTransformerAtt', 'SpGraphTransAttentionLayer',
+           'ODEFuncAtt', 'SpGraphAttentionLayer', 'ConstantODEblock', 'AttODEblock', 'set_block', 'set_function',
+           'synthetic']

@@ -1,0 +1,151 @@
+"""ctypes binding of libgnpde_hip.so (include/gnpde.h).  There is no CPU fallback: if the library
+is missing, or a tensor is not on a HIP device, the product path raises."""
+import ctypes
+import os
+import subprocess
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libgnpde_hip.so')
+_lib = None
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int32)
+c_vp = ctypes.c_void_p
+
+LONG_ROW = 512
+
+STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
+ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
+RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
+METHOD_EULER, METHOD_RK4 = range(2)
+
+ATT_TYPES = {'scaled_dot': ATT_SCALED_DOT, 'cosine_sim': ATT_COSINE, 'pearson': ATT_PEARSON,
+             'exp_kernel': ATT_EXP_KERNEL}
+
+
+class GraphStruct(ctypes.Structure):
+  _fields_ = [('n', ctypes.c_int32), ('e', ctypes.c_int32),
+              ('rowptr', c_vp), ('colidx', c_vp), ('rowidx', c_vp), ('perm', c_vp),
+              ('cscptr', c_vp), ('cscpos', c_vp),
+              ('n_long_rows', ctypes.c_int32), ('n_long_chunks', ctypes.c_int32),
+              ('long_rows', c_vp), ('long_chunk_ptr', c_vp), ('long_chunk_row', c_vp),
+              ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp)]
+
+
+class EpilogueStruct(ctypes.Structure):
+  _fields_ = [('alpha', c_vp), ('beta', c_vp), ('x0', c_vp),
+              ('alpha_sigmoid', ctypes.c_int32), ('stage', ctypes.c_int32), ('dt', ctypes.c_float),
+              ('y', c_vp), ('k1', c_vp), ('k2', c_vp), ('k3', c_vp), ('out_k', c_vp), ('out_y', c_vp)]
+
+
+class AttentionStruct(ctypes.Structure):
+  _fields_ = [('type', ctypes.c_int32), ('heads', ctypes.c_int32), ('att_dim', ctypes.c_int32),
+              ('norm_idx', ctypes.c_int32), ('square_plus', ctypes.c_int32), ('leaky_slope', ctypes.c_float),
+              ('q', c_vp), ('k', c_vp), ('ldqk', ctypes.c_int32),
+              ('gat_a', c_vp), ('output_var', c_vp), ('lengthscale', c_vp), ('edge_w_csr', c_vp)]
+
+
+class RhsStruct(ctypes.Structure):
+  _fields_ = [('kind', ctypes.c_int32), ('graph', ctypes.POINTER(GraphStruct)),
+              ('d', ctypes.c_int32), ('ld', ctypes.c_int32),
+              ('alpha', c_vp), ('beta', c_vp), ('x0', c_vp), ('alpha_sigmoid', ctypes.c_int32),
+              ('w_csr', c_vp),
+              ('proj_w', c_vp), ('proj_b', c_vp), ('proj_m', ctypes.c_int32),
+              ('att', AttentionStruct)]
+
+
+# name -> (restype, argtypes); every symbol include/gnpde.h declares
+PROTOTYPES = {
+  'gnpde_abi_version': (ctypes.c_int, []),
+  'gnpde_last_error': (ctypes.c_char_p, []),
+  'gnpde_graph_count_long': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, c_int_p, c_int_p]),
+  'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 11),
+  'gnpde_partition_rows': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_uint64, c_vp]),
+  'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),
+  'gnpde_spmm_rhs': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
+                                    ctypes.POINTER(EpilogueStruct), c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_spmm': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
+                                c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_linear': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32,
+                                  ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_attention_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),
+  'gnpde_edge_attention': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct),
+                                          c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_edge_to_csr_mean': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_solver_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
+  'gnpde_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.c_int32,
+                                         c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
+  'gnpde_solver_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_rhs_eval': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_rhs_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct)]),
+  'gnpde_solver_num_rhs_evals': (ctypes.c_int, [c_vp]),
+  'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_gather_rows': (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,
+                                       ctypes.c_int32, c_vp]),
+}
+
+
+def build(verbose=False):
+  """Compile csrc/*.hip for gfx950 into csrc/libgnpde_hip.so (hipcc cross-compiles without a GPU)."""
+  script = os.path.join(_HERE, 'csrc', 'build.sh')
+  res = subprocess.run(['bash', script], capture_output=True, text=True)
+  if verbose or res.returncode != 0:
+    print(res.stdout)
+    print(res.stderr)
+  if res.returncode != 0:
+    raise RuntimeError('building libgnpde_hip.so failed')
+  return LIB_PATH
+
+
+def lib():
+  """The loaded library; raises if it has not been built (no fallback path exists)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError('libgnpde_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"`. '
+                         'There is no CPU / PyTorch fallback for the ODE right-hand side.' % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+      fn = getattr(handle, name)
+      fn.restype = res
+      fn.argtypes = args
+    if handle.gnpde_abi_version() != 1:
+      raise RuntimeError('libgnpde_hip.so ABI version mismatch')
+    _lib = handle
+  return _lib
+
+
+class GnpdeError(RuntimeError):
+  pass
+
+
+def check(rc):
+  if rc != 0:
+    msg = lib().gnpde_last_error().decode(errors='replace')
+    raise GnpdeError('libgnpde_hip error %d: %s' % (rc, msg))
+
+
+def ptr(t):
+  """Device (or host) address of a tensor, None -> NULL."""
+  if t is None:
+    return None
+  return ctypes.c_void_p(t.data_ptr())
+
+
+def require_hip(*tensors):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise GnpdeError('the ODE right-hand side runs only on a HIP device (got a %s tensor); there is no CPU fallback'
+                       % t.device.type)
+
+
+def f32c(t, name='tensor'):
+  if t.dtype != torch.float32:
+    raise GnpdeError('%s must be float32 (got %s)' % (name, t.dtype))
+  return t if t.is_contiguous() else t.contiguous()
+
+
+def stream_of(t):
+  return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

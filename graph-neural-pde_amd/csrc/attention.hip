@@ -1,0 +1,353 @@
+// Edge attention: per-edge multi-head scores -> per-node (row or column) softmax / squareplus ->
+// head-mean weights in CSR order (+ the reference's [E,h] outputs in the caller's edge order).
+//
+// Replaces SpGraphTransAttentionLayer.forward (reference src/function_transformer_attention.py:
+// 190-213), SpGraphAttentionLayer.forward (src/function_GAT_attention.py:111-114),
+// torch_geometric.utils.softmax [3P] and utils.squareplus (src/utils.py:179-208).  The reference
+// materialises q[edge[0]] and k[edge[1]] as two [E,d_k,h] tensors, their product, and runs
+// scatter_max / scatter_add (atomics) per head; here a lane owns one (edge, head) pair, gathers its
+// d_k-slice of q and k straight from the [N,A] projections (16-byte loads), and the segment
+// statistics are wave reductions over the CSR (norm_idx=0) or CSC (norm_idx=1) segment -- no atomics
+// except one order-independent max per block for squareplus' global maximum.
+//
+// Pass 1  scores[p,h]   (CSR order)            edge-parallel, balanced regardless of degree skew
+// Pass 2  seg stats     m[seg,h], den[seg,h]   one wavefront per segment
+// Pass 3  normalise     w[p] = mean_h att      edge-parallel; optional scatter to edge order
+#include <cmath>
+#include "common.h"
+
+namespace gnpde {
+namespace {
+
+struct AttArgs {
+  int n, e, h, dk, type, norm_idx, square_plus;
+  float inv_sqrt_dk_den;  // sqrt(d_k), divisor of the scaled dot product
+  float leaky_slope;
+  const int* __restrict__ rowidx;
+  const int* __restrict__ colidx;
+  const int* __restrict__ perm;
+  const int* __restrict__ segptr;   // rowptr or cscptr
+  const int* __restrict__ segpos;   // nullptr (rows: positions are contiguous) or cscpos
+  const float* __restrict__ q;
+  const float* __restrict__ k;
+  int ldqk;
+  const float* __restrict__ gat_terms;  // [n, 2h]: src terms then dst terms
+  const float* __restrict__ output_var;
+  const float* __restrict__ lengthscale;
+  const float* __restrict__ edge_w;
+  float* scores;      // [e,h]
+  float* seg_m;       // [n,h]
+  float* seg_den;     // [n,h]
+  unsigned* gmax;     // ordered-uint encoding of the global max score
+  float* w_mean;      // [e] or null
+  float* att_edge;    // [E,h] or null
+  float* prods_edge;  // [E,h] or null
+};
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// ---- pass 0 (GAT): per-node terms  src[i,h] = sum_c a[c] h_i[c,head],  dst[i,h] = sum_c a[d_k+c] h_i[c,head]
+__global__ __launch_bounds__(kBlock) void gat_terms_kernel(const float* __restrict__ wx, int ld, const float* __restrict__ a,
+                                                          int n, int h, int dk, float* __restrict__ terms) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<long long>(n) * h) return;
+  const int i = static_cast<int>(idx / h), head = static_cast<int>(idx % h);
+  const float* row = wx + static_cast<size_t>(i) * ld + head * dk;
+  float s = 0.f, t = 0.f;
+  for (int c = 0; c < dk; ++c) {
+    const float v = row[c];
+    s = fmaf(a[c], v, s);
+    t = fmaf(a[dk + c], v, t);
+  }
+  terms[static_cast<size_t>(i) * 2 * h + head] = s;
+  terms[static_cast<size_t>(i) * 2 * h + h + head] = t;
+}
+
+// ---- pass 1: one lane per (CSR position, head)
+template <int TYPE, bool VEC4>
+__global__ __launch_bounds__(kBlock) void scores_kernel(const AttArgs a) {
+  const long long total = static_cast<long long>(a.e) * a.h;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  float lmax = -INFINITY;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int p = static_cast<int>(idx / a.h);
+    const int head = static_cast<int>(idx - static_cast<long long>(p) * a.h);
+    const int r = a.rowidx[p], c = a.colidx[p];
+    float s;
+    if constexpr (TYPE == GNPDE_ATT_GAT) {
+      const float v = a.gat_terms[static_cast<size_t>(r) * 2 * a.h + head] +
+                      a.gat_terms[static_cast<size_t>(c) * 2 * a.h + a.h + head];
+      s = v > 0.f ? v : v * a.leaky_slope;
+    } else {
+      const float* qp = a.q + static_cast<size_t>(r) * a.ldqk + head * a.dk;
+      const float* kp = a.k + static_cast<size_t>(c) * a.ldqk + head * a.dk;
+      float mq = 0.f, mk = 0.f;
+      if constexpr (TYPE == GNPDE_ATT_PEARSON) {
+        for (int j = 0; j < a.dk; ++j) { mq += qp[j]; mk += kp[j]; }
+        mq = mq / static_cast<float>(a.dk);
+        mk = mk / static_cast<float>(a.dk);
+      }
+      float dot = 0.f, nq = 0.f, nk = 0.f;
+      auto term = [&](float qv, float kv) {
+        if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
+          dot = fmaf(qv, kv, dot);
+        } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
+          const float df = qv - kv;
+          dot = fmaf(df, df, dot);
+        } else {
+          qv -= mq; kv -= mk;
+          dot = fmaf(qv, kv, dot);
+          nq = fmaf(qv, qv, nq);
+          nk = fmaf(kv, kv, nk);
+        }
+      };
+      if constexpr (VEC4) {
+        for (int j = 0; j < a.dk; j += 4) {
+          const float4 qv = *reinterpret_cast<const float4*>(qp + j);
+          const float4 kv = *reinterpret_cast<const float4*>(kp + j);
+          term(qv.x, kv.x); term(qv.y, kv.y); term(qv.z, kv.z); term(qv.w, kv.w);
+        }
+      } else {
+        for (int j = 0; j < a.dk; ++j) term(qp[j], kp[j]);
+      }
+      if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
+        s = dot / a.inv_sqrt_dk_den;
+      } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
+        const float ov = *a.output_var, ls = *a.lengthscale;
+        s = (ov * ov) * expf(-(dot / (2.0f * (ls * ls))));
+      } else {  // cosine / pearson: x1.x2 / sqrt(max(|x1|^2 |x2|^2, eps^2)), eps = 1e-5
+        s = dot / sqrtf(fmaxf(nq * nk, 1e-10f));
+      }
+    }
+    if (a.edge_w != nullptr) s = s * a.edge_w[p];
+    a.scores[idx] = s;
+    lmax = fmaxf(lmax, s);
+  }
+  if (a.square_plus) {  // block max -> one order-independent atomic
+    __shared__ float smax[kWavesPerBlock];
+    lmax = wave_max(lmax);
+    if ((threadIdx.x & (kWave - 1)) == 0) smax[threadIdx.x >> 6] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = smax[0];
+      for (int i = 1; i < kWavesPerBlock; ++i) m = fmaxf(m, smax[i]);
+      atomicMax(a.gmax, f2ord(m));
+    }
+  }
+}
+
+__device__ __forceinline__ float squareplus_num(float s, float gmax) {
+  const float z = s - gmax;
+  return (z + sqrtf(z * z + 4.0f)) / 2.0f;
+}
+
+// ---- pass 2: one wavefront per segment, heads in an outer loop
+__global__ __launch_bounds__(kBlock) void seg_stats_kernel(const AttArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+  if (seg >= a.n) return;
+  const int b = a.segptr[seg], e = a.segptr[seg + 1];
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  for (int head = 0; head < a.h; ++head) {
+    float m = 0.f, den;
+    if (a.square_plus) {
+      float sum = 0.f;
+      for (int t = b + lane; t < e; t += kWave) {
+        const int p = a.segpos ? a.segpos[t] : t;
+        sum += squareplus_num(a.scores[static_cast<size_t>(p) * a.h + head], gmax);
+      }
+      den = wave_sum(sum) + 1e-16f;
+    } else {
+      float mx = -INFINITY;
+      for (int t = b + lane; t < e; t += kWave) {
+        const int p = a.segpos ? a.segpos[t] : t;
+        mx = fmaxf(mx, a.scores[static_cast<size_t>(p) * a.h + head]);
+      }
+      mx = wave_max(mx);
+      m = (e > b) ? mx : 0.f;
+      float sum = 0.f;
+      for (int t = b + lane; t < e; t += kWave) {
+        const int p = a.segpos ? a.segpos[t] : t;
+        sum += expf(a.scores[static_cast<size_t>(p) * a.h + head] - m);
+      }
+      den = wave_sum(sum) + 1e-16f;
+    }
+    if (lane == 0) {
+      a.seg_m[static_cast<size_t>(seg) * a.h + head] = m;
+      a.seg_den[static_cast<size_t>(seg) * a.h + head] = den;
+    }
+  }
+}
+
+// ---- pass 3: one lane per CSR position, heads serial (same order as attention.mean(dim=1))
+__global__ __launch_bounds__(kBlock) void normalise_kernel(const AttArgs a) {
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  for (long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.e; p += stride) {
+    const int seg = a.norm_idx == 0 ? a.rowidx[p] : a.colidx[p];
+    const long long dst = (a.att_edge || a.prods_edge) ? static_cast<long long>(a.perm[p]) * a.h : 0;
+    float acc = 0.f;
+    for (int head = 0; head < a.h; ++head) {
+      const float s = a.scores[p * a.h + head];
+      const float den = a.seg_den[static_cast<size_t>(seg) * a.h + head];
+      float v;
+      if (a.square_plus) v = squareplus_num(s, gmax) / den;
+      else v = expf(s - a.seg_m[static_cast<size_t>(seg) * a.h + head]) / den;
+      acc += v;
+      if (a.att_edge) a.att_edge[dst + head] = v;
+      if (a.prods_edge) a.prods_edge[dst + head] = s;
+    }
+    if (a.w_mean) a.w_mean[p] = acc / static_cast<float>(a.h);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_to_csr_mean_kernel(const int* __restrict__ perm, const float* __restrict__ src,
+                                                                 int h, int e, float* __restrict__ w) {
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; p < e; p += stride) {
+    const float* s = src + static_cast<size_t>(perm[p]) * h;
+    if (h == 1) {
+      w[p] = s[0];
+    } else {
+      float acc = 0.f;
+      for (int j = 0; j < h; ++j) acc += s[j];
+      w[p] = acc / static_cast<float>(h);
+    }
+  }
+}
+
+inline unsigned stream_grid(long long work_items) {
+  long long blocks = (work_items + kBlock - 1) / kBlock;
+  const long long cap = 256LL * 8;  // 256 CUs x 8 blocks, grid-stride beyond
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+struct AttLayout {
+  size_t scores, seg_m, seg_den, gmax, gat, total;
+};
+AttLayout att_layout(int n, int e, int h, bool gat) {
+  AttLayout L{};
+  size_t off = 0;
+  L.scores = off; off += align_up(static_cast<size_t>(e) * h * 4, 256);
+  L.seg_m = off;  off += align_up(static_cast<size_t>(n) * h * 4, 256);
+  L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
+  L.gmax = off; off += 256;
+  L.gat = off; if (gat) off += align_up(static_cast<size_t>(n) * 2 * h * 4, 256);
+  L.total = off;
+  return L;
+}
+
+template <int TYPE>
+void launch_scores(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s) {
+  if (vec4) hipLaunchKernelGGL((scores_kernel<TYPE, true>), dim3(grid), dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL((scores_kernel<TYPE, false>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+}  // namespace
+
+int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream) {
+  GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
+  GNPDE_CHECK_ARG(w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
+  GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
+                  "edge_attention: heads (%d) must be a factor of the attention dimension (%d)", at->heads, at->att_dim);
+  GNPDE_CHECK_ARG(at->type >= GNPDE_ATT_SCALED_DOT && at->type <= GNPDE_ATT_GAT, GNPDE_EINVAL, "edge_attention: bad type %d", at->type);
+  GNPDE_CHECK_ARG(at->norm_idx == 0 || at->norm_idx == 1, GNPDE_EINVAL, "edge_attention: attention_norm_idx must be 0 or 1");
+  GNPDE_CHECK_ARG(at->q && at->k && at->ldqk >= at->att_dim, GNPDE_EINVAL, "edge_attention: bad q/k");
+  GNPDE_CHECK_ARG(at->type != GNPDE_ATT_GAT || at->gat_a, GNPDE_EINVAL, "edge_attention: GAT needs the vector a");
+  GNPDE_CHECK_ARG(at->type != GNPDE_ATT_EXP_KERNEL || (at->output_var && at->lengthscale), GNPDE_EINVAL,
+                  "edge_attention: exp_kernel needs output_var and lengthscale");
+  GNPDE_CHECK_ARG(at->norm_idx == 0 || (g->cscptr && g->cscpos), GNPDE_EINVAL, "edge_attention: norm_idx=1 needs the CSC view");
+  GNPDE_CHECK_ARG(g->rowidx && g->perm, GNPDE_EINVAL, "edge_attention: graph lacks rowidx/perm");
+  if (g->e == 0 || g->n == 0) return 0;
+  const bool gat = at->type == GNPDE_ATT_GAT;
+  const AttLayout L = att_layout(g->n, g->e, at->heads, gat);
+  GNPDE_CHECK_ARG(ws && ws_bytes >= L.total, GNPDE_EWS, "edge_attention: workspace %zu < %zu bytes", ws_bytes, L.total);
+  GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0, GNPDE_EINVAL, "edge_attention: workspace must be 16-byte aligned");
+  char* base = static_cast<char*>(ws);
+
+  AttArgs a{};
+  a.n = g->n; a.e = g->e; a.h = at->heads; a.dk = at->att_dim / at->heads;
+  a.type = at->type; a.norm_idx = at->norm_idx; a.square_plus = at->square_plus ? 1 : 0;
+  a.inv_sqrt_dk_den = static_cast<float>(std::sqrt(static_cast<double>(a.dk)));
+  a.leaky_slope = at->leaky_slope;
+  a.rowidx = g->rowidx; a.colidx = g->colidx; a.perm = g->perm;
+  a.segptr = at->norm_idx == 0 ? g->rowptr : g->cscptr;
+  a.segpos = at->norm_idx == 0 ? nullptr : g->cscpos;
+  a.q = at->q; a.k = at->k; a.ldqk = at->ldqk;
+  a.output_var = at->output_var; a.lengthscale = at->lengthscale; a.edge_w = at->edge_w_csr;
+  a.scores = reinterpret_cast<float*>(base + L.scores);
+  a.seg_m = reinterpret_cast<float*>(base + L.seg_m);
+  a.seg_den = reinterpret_cast<float*>(base + L.seg_den);
+  a.gmax = reinterpret_cast<unsigned*>(base + L.gmax);
+  a.gat_terms = reinterpret_cast<float*>(base + L.gat);
+  a.w_mean = w_mean_csr; a.att_edge = att_edge; a.prods_edge = prods_edge;
+
+  if (a.square_plus) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
+  if (gat) {
+    const long long items = static_cast<long long>(g->n) * a.h;
+    hipLaunchKernelGGL(gat_terms_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       at->q, at->ldqk, at->gat_a, g->n, a.h, a.dk, reinterpret_cast<float*>(base + L.gat));
+    GNPDE_LAUNCH_CHECK();
+  }
+  const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(a.k) % 16 == 0);
+  const unsigned sgrid = stream_grid(static_cast<long long>(a.e) * a.h);
+  switch (a.type) {
+    case GNPDE_ATT_SCALED_DOT: launch_scores<GNPDE_ATT_SCALED_DOT>(a, vec4, sgrid, stream); break;
+    case GNPDE_ATT_COSINE: launch_scores<GNPDE_ATT_COSINE>(a, vec4, sgrid, stream); break;
+    case GNPDE_ATT_PEARSON: launch_scores<GNPDE_ATT_PEARSON>(a, vec4, sgrid, stream); break;
+    case GNPDE_ATT_EXP_KERNEL: launch_scores<GNPDE_ATT_EXP_KERNEL>(a, vec4, sgrid, stream); break;
+    default: launch_scores<GNPDE_ATT_GAT>(a, false, sgrid, stream); break;
+  }
+  GNPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_stats_kernel, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, stream, a);
+  GNPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(normalise_kernel, dim3(stream_grid(a.e)), dim3(kBlock), 0, stream, a);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t attention_workspace_bytes(int n, int e, int h, bool gat) { return att_layout(n, e, h, gat).total; }
+
+}  // namespace gnpde
+
+extern "C" size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a) {
+  if (!g || !a || a->heads < 1) return 0;
+  return gnpde::attention_workspace_bytes(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT);
+}
+
+extern "C" int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a, float* w_mean_csr, float* att_edge,
+                                    float* prods_edge, void* workspace, size_t workspace_bytes, void* stream) {
+  return gnpde::launch_edge_attention(g, a, w_mean_csr, att_edge, prods_edge, workspace, workspace_bytes,
+                                      static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnpde_edge_to_csr_mean(const gnpde_graph_t* g, const float* src_edge, int32_t h, float* w_csr, void* stream) {
+  GNPDE_CHECK_ARG(g && g->perm && src_edge && w_csr && h >= 1, GNPDE_EINVAL, "edge_to_csr_mean: bad arguments");
+  if (g->e == 0) return 0;
+  hipLaunchKernelGGL(gnpde::edge_to_csr_mean_kernel, dim3(gnpde::stream_grid(g->e)), dim3(gnpde::kBlock), 0,
+                     static_cast<hipStream_t>(stream), g->perm, src_edge, h, g->e, w_csr);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}

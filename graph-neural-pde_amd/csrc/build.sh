@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libgnpde_hip.so (gfx950 only) next to the sources.  Called by __graft_entry__.build().
+set -e
+cd "$(dirname "$0")"
+ROOT="$(cd ../.. && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I${ROOT}/include -I. -Wall -Wno-unused-function"
+mkdir -p build
+objs=""
+for f in error.cpp graph_prep.cpp spmm.hip linear.hip attention.hip solver.hip misc.hip; do
+  o="build/${f%.*}.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ "${ROOT}/include/gnpde.h" -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+  fi
+  objs="$objs $o"
+done
+wait
+for o in $objs; do [ -f "$o" ] || { echo "missing $o" >&2; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $objs -o libgnpde_hip.so
+echo "built $(pwd)/libgnpde_hip.so"

@@ -1,0 +1,67 @@
+// Internal helpers shared by the translation units of libgnpde_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "gnpde.h"
+
+namespace gnpde {
+
+void set_error(const char* fmt, ...);
+
+#define GNPDE_CHECK_ARG(cond, code, ...)            \
+  do {                                              \
+    if (!(cond)) {                                  \
+      ::gnpde::set_error(__VA_ARGS__);              \
+      return (code);                                \
+    }                                               \
+  } while (0)
+
+#define GNPDE_HIP(call)                                                                   \
+  do {                                                                                    \
+    hipError_t _e = (call);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::gnpde::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                       \
+      return static_cast<int>(_e);                                                        \
+    }                                                                                     \
+  } while (0)
+
+// launch check that does not synchronise (valid inside stream capture)
+#define GNPDE_LAUNCH_CHECK()                                                              \
+  do {                                                                                    \
+    hipError_t _e = hipGetLastError();                                                    \
+    if (_e != hipSuccess) {                                                               \
+      ::gnpde::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),       \
+                         __FILE__, __LINE__);                                             \
+      return static_cast<int>(_e);                                                        \
+    }                                                                                     \
+  } while (0)
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 wavefronts, one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Grid rounded to a multiple of the XCD count so that the swizzle below is a bijection.
+inline unsigned xcd_grid(long long blocks) {
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>((blocks + kXcds - 1) / kXcds * kXcds);
+}
+
+// Blocks that land on one XCD (b % 8 equal) get a CONTIGUOUS range of work items, so rows that
+// are neighbours in the (locality-ordered) graph share that XCD's 4 MiB L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
+  const unsigned per = nblocks / kXcds;
+  return (b % kXcds) * per + (b / kXcds);
+}
+
+// internal launchers used by the solver (defined in the kernel translation units)
+int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
+                    const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
+                    hipStream_t stream);
+
+}  // namespace gnpde

@@ -1,0 +1,191 @@
+// Host-side graph preparation: COO (any order, duplicates allowed) -> CSR + stable permutation,
+// CSC view, long-row chunk list; balanced k-way row partition for the multi-GPU path.
+//
+// Replaces the implicit COO handling inside torch_sparse.spmm / torch_scatter that the reference
+// relies on (reference src/function_transformer_attention.py:35,190-191,213;
+// src/function_laplacian_diffusion.py:31-35).  The stable counting sort keeps duplicates and the
+// within-row edge order of the caller, so `perm` maps every CSR position back to exactly one edge
+// of the reference's edge list (attention is returned in that order).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <queue>
+#include <vector>
+#include "common.h"
+
+using namespace gnpde;
+
+extern "C" int gnpde_graph_count_long(const int64_t* row, int64_t n_edges, int32_t n_nodes,
+                                      int32_t* n_long_rows, int32_t* n_long_chunks) {
+  GNPDE_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (int64_t(1) << 31), GNPDE_EINVAL,
+                  "graph_count_long: bad sizes n=%d e=%lld", n_nodes, (long long)n_edges);
+  GNPDE_CHECK_ARG((row || n_edges == 0) && n_long_rows && n_long_chunks, GNPDE_EINVAL,
+                  "graph_count_long: null pointer");
+  std::vector<int32_t> deg(static_cast<size_t>(n_nodes), 0);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    const int64_t r = row[e];
+    GNPDE_CHECK_ARG(r >= 0 && r < n_nodes, GNPDE_EINVAL, "graph_count_long: row index %lld out of range",
+                    (long long)r);
+    ++deg[r];
+  }
+  int32_t lr = 0, lc = 0;
+  for (int32_t i = 0; i < n_nodes; ++i) {
+    if (deg[i] > GNPDE_LONG_ROW) {
+      ++lr;
+      lc += (deg[i] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+    }
+  }
+  *n_long_rows = lr;
+  *n_long_chunks = lc;
+  return 0;
+}
+
+extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
+                                 int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
+                                 int32_t* cscptr, int32_t* cscpos, int32_t* long_rows,
+                                 int32_t* long_chunk_ptr, int32_t* long_chunk_row,
+                                 int32_t* long_chunk_begin, int32_t* long_chunk_end) {
+  GNPDE_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (int64_t(1) << 31), GNPDE_EINVAL,
+                  "graph_build: bad sizes n=%d e=%lld", n_nodes, (long long)n_edges);
+  GNPDE_CHECK_ARG(rowptr && (n_edges == 0 || (row && col && colidx && perm && rowidx)), GNPDE_EINVAL,
+                  "graph_build: null pointer");
+  const size_t n = static_cast<size_t>(n_nodes);
+  std::fill(rowptr, rowptr + n + 1, 0);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    const int64_t r = row[e], c = col[e];
+    GNPDE_CHECK_ARG(r >= 0 && r < n_nodes && c >= 0 && c < n_nodes, GNPDE_EINVAL,
+                    "graph_build: edge %lld = (%lld,%lld) outside [0,%d)", (long long)e, (long long)r,
+                    (long long)c, n_nodes);
+    ++rowptr[r + 1];
+  }
+  for (size_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+  {
+    std::vector<int32_t> cur(rowptr, rowptr + n);
+    for (int64_t e = 0; e < n_edges; ++e) {
+      const int32_t r = static_cast<int32_t>(row[e]);
+      const int32_t p = cur[r]++;
+      colidx[p] = static_cast<int32_t>(col[e]);
+      perm[p] = static_cast<int32_t>(e);
+      rowidx[p] = r;
+    }
+  }
+  if (cscptr && cscpos) {
+    std::fill(cscptr, cscptr + n + 1, 0);
+    for (int64_t p = 0; p < n_edges; ++p) ++cscptr[colidx[p] + 1];
+    for (size_t i = 0; i < n; ++i) cscptr[i + 1] += cscptr[i];
+    std::vector<int32_t> cur(cscptr, cscptr + n);
+    for (int64_t p = 0; p < n_edges; ++p) cscpos[cur[colidx[p]]++] = static_cast<int32_t>(p);
+  }
+  int32_t lr = 0, lc = 0;
+  for (int32_t i = 0; i < n_nodes; ++i) {
+    const int32_t b = rowptr[i], e = rowptr[i + 1];
+    if (e - b > GNPDE_LONG_ROW) {
+      GNPDE_CHECK_ARG(long_rows && long_chunk_ptr && long_chunk_row && long_chunk_begin && long_chunk_end,
+                      GNPDE_EINVAL, "graph_build: long rows present but chunk arrays are null");
+      long_rows[lr] = i;
+      long_chunk_ptr[lr] = lc;
+      for (int32_t s = b; s < e; s += GNPDE_LONG_ROW) {
+        long_chunk_row[lc] = i;
+        long_chunk_begin[lc] = s;
+        long_chunk_end[lc] = std::min(e, s + GNPDE_LONG_ROW);
+        ++lc;
+      }
+      ++lr;
+    }
+  }
+  if (long_chunk_ptr) long_chunk_ptr[lr] = lc;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-way row partition.  Phase 1 grows parts by BFS until each holds ~1/k of the work (work of a row
+// = its nnz + 1, i.e. balance on EDGES, which is what the SpMM time follows).  Phase 2 is a
+// balance-constrained label propagation that moves a row to the part most of its neighbours live in.
+// ------------------------------------------------------------------------------------------------
+extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes,
+                                    int32_t n_parts, int32_t refine_iters, uint64_t seed, int32_t* part) {
+  GNPDE_CHECK_ARG(rowptr && part && n_nodes >= 0 && n_parts >= 1, GNPDE_EINVAL, "partition_rows: bad args");
+  GNPDE_CHECK_ARG(colidx || rowptr[n_nodes] == 0, GNPDE_EINVAL, "partition_rows: null colidx");
+  const int32_t n = n_nodes, P = n_parts;
+  if (P == 1 || n == 0) {
+    std::fill(part, part + n, 0);
+    return 0;
+  }
+  auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + 1; };
+  int64_t total = 0;
+  for (int32_t v = 0; v < n; ++v) total += work(v);
+  std::fill(part, part + n, -1);
+  std::vector<int64_t> load(P, 0);
+  int32_t next_unassigned = 0;
+  int64_t assigned_work = 0;
+  uint64_t rng = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+  (void)rng;
+  for (int32_t p = 0; p < P; ++p) {
+    const int64_t target = (total - assigned_work) / (P - p);
+    std::queue<int32_t> q;
+    while (load[p] < target || p == P - 1) {
+      if (q.empty()) {
+        while (next_unassigned < n && part[next_unassigned] != -1) ++next_unassigned;
+        if (next_unassigned >= n) break;
+        part[next_unassigned] = p;
+        load[p] += work(next_unassigned);
+        q.push(next_unassigned);
+        continue;
+      }
+      const int32_t v = q.front();
+      q.pop();
+      for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+        const int32_t u = colidx[e];
+        if (part[u] == -1 && (load[p] < target || p == P - 1)) {
+          part[u] = p;
+          load[p] += work(u);
+          q.push(u);
+        }
+      }
+    }
+    assigned_work += load[p];
+  }
+  for (int32_t v = 0; v < n; ++v) {
+    if (part[v] < 0) {  // cannot happen (last part sweeps the rest) but keep the output total
+      part[v] = P - 1;
+      load[P - 1] += work(v);
+    }
+  }
+  const double avg = double(total) / P;
+  const int64_t hi = static_cast<int64_t>(avg * 1.03) + 1, lo = static_cast<int64_t>(avg * 0.97);
+  std::vector<int32_t> cnt(P, 0), touched;
+  touched.reserve(64);
+  for (int32_t it = 0; it < refine_iters; ++it) {
+    int64_t moved = 0;
+    for (int32_t v = 0; v < n; ++v) {
+      const int32_t from = part[v];
+      touched.clear();
+      for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+        const int32_t u = colidx[e];
+        if (u == v) continue;
+        if (cnt[part[u]]++ == 0) touched.push_back(part[u]);
+      }
+      int32_t best = from, best_cnt = cnt[from];
+      for (int32_t p : touched) {
+        if (cnt[p] > best_cnt || (cnt[p] == best_cnt && p != from && load[p] < load[best])) {
+          if (p != from) {
+            best = p;
+            best_cnt = cnt[p];
+          }
+        }
+      }
+      for (int32_t p : touched) cnt[p] = 0;
+      if (best != from) {
+        const int64_t w = work(v);
+        if (load[best] + w <= hi && load[from] - w >= lo) {
+          part[v] = best;
+          load[best] += w;
+          load[from] -= w;
+          ++moved;
+        }
+      }
+    }
+    if (moved == 0) break;
+  }
+  return 0;
+}

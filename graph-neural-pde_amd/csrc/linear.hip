@@ -1,0 +1,138 @@
+// out[n, m] = x[n, d] * W[m, d]^T + b[m]  on the fp32 matrix cores.
+//
+// The only GEMM-shaped work on the path: nn.Linear Q and K of SpGraphTransAttentionLayer
+// (reference src/function_transformer_attention.py:174-175, fused into one [N,d]x[d,2A] product;
+// V is skipped, its result is dead when mix_features is false, :34-35) and torch.mm(x, W) of the
+// GAT layer (src/function_GAT_attention.py:106).  Tall-skinny: N = 1e5..1e6 rows, d and m <= 256,
+// so it is bound by reading x once; v_mfma_f32_16x16x4_f32 is exact fp32 (bit-equal to an fmaf
+// chain) and keeps the VALU free.
+//
+// One wavefront owns 16 consecutive rows and all m output columns (m/16 accumulators).  Every lane
+// loads ONE float4 of x per 16-wide K block -- x[row0 + (l&15)][kb + 4*(l>>4) .. +3] -- and uses its
+// i-th component as the A operand of the i-th MFMA of that block; the matching B operand is the i-th
+// component of the float4 W[col0 + (l&15)][kb + 4*(l>>4) .. +3].  The k index of an MFMA step is thus
+// {kb+i, kb+4+i, kb+8+i, kb+12+i}: a permutation of the K order, which a dot product does not care
+// about, and it makes both operand loads 16-byte vector loads straight from row-major memory with no
+// LDS transpose.
+#include "common.h"
+
+namespace gnpde {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool ALIGNED>
+__device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ base, int k, int kmax, bool row_ok) {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (!row_ok) return r;
+  if constexpr (ALIGNED) {
+    if (k + 3 < kmax) {
+      const float4 t = *reinterpret_cast<const float4*>(base + k);
+      r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+      return r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (k + i < kmax) r[i] = base[k + i];
+  return r;
+}
+
+// MT = number of 16-column output tiles kept in registers by one wave.
+template <int MT, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int n, int d, int ldx,
+                                                        const float* __restrict__ W, int m, int ldw,
+                                                        const float* __restrict__ b, float* __restrict__ out,
+                                                        int ldo, int col_base) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
+  const int row0 = static_cast<int>(tile * 16);
+  if (row0 >= n) return;
+  const int r = lane & 15;       // row within the tile (A operand) / column within a 16-col tile (B)
+  const int kq = lane >> 4;      // which 4-wide K quarter of the 16-wide K block
+  const int arow = row0 + r;
+  const bool arow_ok = arow < n;
+  const float* xrow = x + static_cast<size_t>(arow_ok ? arow : 0) * ldx;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < d; kb += 16) {
+    const int k = kb + 4 * kq;
+    const f32x4 av = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
+    f32x4 bv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int col = col_base + t * 16 + r;
+      const bool ok = col < m;
+      bv[t] = load4_guard<ALIGNED>(W + static_cast<size_t>(ok ? col : 0) * ldw, k, d, ok);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t][i], acc[t], 0, 0, 0);
+  }
+
+  // C/D layout of the 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int col = col_base + t * 16 + r;
+    if (col >= m) continue;
+    const float bias = b != nullptr ? b[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int orow = row0 + 4 * kq + i;
+      if (orow < n) out[static_cast<size_t>(orow) * ldo + col] = acc[t][i] + bias;
+    }
+  }
+}
+
+template <bool ALIGNED>
+void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                   int ldo, hipStream_t s) {
+  const long long tiles = (static_cast<long long>(n) + 15) / 16;
+  const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  int col = 0;
+  while (col < m) {
+    const int rem = (m - col + 15) / 16;
+    if (rem >= 8) {
+      hipLaunchKernelGGL((linear_kernel<8, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      col += 128;
+    } else if (rem >= 4) {
+      hipLaunchKernelGGL((linear_kernel<4, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      col += 64;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL((linear_kernel<2, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      col += 32;
+    } else {
+      hipLaunchKernelGGL((linear_kernel<1, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      col += 16;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                      int ldo, hipStream_t s) {
+  GNPDE_CHECK_ARG(x && W && out, GNPDE_EINVAL, "linear: null pointer");
+  GNPDE_CHECK_ARG(n >= 0 && d >= 1 && m >= 1 && ldx >= d && ldw >= d && ldo >= m, GNPDE_EINVAL,
+                  "linear: bad shape n=%d d=%d m=%d ldx=%d ldw=%d ldo=%d", n, d, m, ldx, ldw, ldo);
+  if (n == 0) return 0;
+  const bool al = (ldx % 4 == 0) && (ldw % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                  (reinterpret_cast<uintptr_t>(W) % 16 == 0);
+  if (al) launch_linear<true>(x, n, d, ldx, W, m, ldw, b, out, ldo, s);
+  else launch_linear<false>(x, n, d, ldx, W, m, ldw, b, out, ldo, s);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gnpde
+
+extern "C" int gnpde_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,
+                            const float* b, float* out, int32_t ldo, void* stream) {
+  return gnpde::launch_linear_any(x, n, d, ldx, W, m, ldw, b, out, ldo, static_cast<hipStream_t>(stream));
+}

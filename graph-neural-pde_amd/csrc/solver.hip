@@ -1,0 +1,271 @@
+// One right-hand-side evaluation f(u) composed from the kernels of this library, and the
+// fixed-step solver loop (torchdiffeq 0.2.1 `euler` / `rk4` == 3/8 rule) with the stage algebra
+// fused into the aggregation epilogue and the whole time grid captured in ONE hipGraph.
+//
+// Replaces ODEFunc.forward (reference src/function_laplacian_diffusion.py:38-51,
+// src/function_transformer_attention.py:38-53, src/function_GAT_attention.py:45-65) and the Python
+// solver loop reached from ODEblock.forward (src/block_constant.py:57-62,
+// src/block_transformer_attention.py:58-63): ~30 launches + ~10 elementwise launches per stage there,
+// 1 (GRAND-l) or 5 (GRAND-nl) launches per stage here and a single graph launch per forward pass.
+#include <vector>
+#include "common.h"
+
+namespace gnpde {
+
+int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                      int ldo, hipStream_t s);
+int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t attention_workspace_bytes(int n, int e, int h, bool gat);
+
+namespace {
+
+struct RhsLayout {
+  size_t proj, wmean, att, spmm, total;
+  size_t att_bytes, spmm_bytes;
+};
+
+RhsLayout rhs_layout(const gnpde_rhs_t& r) {
+  RhsLayout L{};
+  const gnpde_graph_t& g = *r.graph;
+  size_t off = 0;
+  L.spmm = off;
+  L.spmm_bytes = gnpde_spmm_workspace_bytes(&g, r.d);
+  off += align_up(L.spmm_bytes, 256);
+  if (r.kind != GNPDE_RHS_LAPLACIAN) {
+    L.proj = off;  off += align_up(static_cast<size_t>(g.n) * r.proj_m * 4, 256);
+    L.wmean = off; off += align_up(static_cast<size_t>(g.e) * 4, 256);
+    L.att = off;
+    L.att_bytes = attention_workspace_bytes(g.n, g.e, r.att.heads, r.kind == GNPDE_RHS_GAT);
+    off += align_up(L.att_bytes, 256);
+  }
+  L.total = off;
+  return L;
+}
+
+int check_rhs(const gnpde_rhs_t* r) {
+  GNPDE_CHECK_ARG(r && r->graph, GNPDE_EINVAL, "rhs: null descriptor");
+  GNPDE_CHECK_ARG(r->kind >= GNPDE_RHS_LAPLACIAN && r->kind <= GNPDE_RHS_GAT, GNPDE_EINVAL, "rhs: bad kind %d", r->kind);
+  GNPDE_CHECK_ARG(r->d >= 1 && r->ld >= r->d, GNPDE_EINVAL, "rhs: bad d/ld");
+  GNPDE_CHECK_ARG(r->alpha != nullptr, GNPDE_EINVAL, "rhs: alpha is null");
+  GNPDE_CHECK_ARG(r->x0 == nullptr || r->beta != nullptr, GNPDE_EINVAL, "rhs: x0 without beta");
+  if (r->kind == GNPDE_RHS_LAPLACIAN) {
+    GNPDE_CHECK_ARG(r->w_csr != nullptr || r->graph->e == 0, GNPDE_EINVAL, "rhs: laplacian needs w_csr");
+  } else {
+    GNPDE_CHECK_ARG(r->proj_w != nullptr && r->proj_m >= 1, GNPDE_EINVAL, "rhs: projection weights missing");
+    const int need = r->kind == GNPDE_RHS_TRANSFORMER ? 2 * r->att.att_dim : r->att.att_dim;
+    GNPDE_CHECK_ARG(r->proj_m == need, GNPDE_EINVAL, "rhs: proj_m=%d but attention needs %d", r->proj_m, need);
+  }
+  return 0;
+}
+
+// Enqueue f(u) with the given epilogue.  `ws` follows rhs_layout.
+int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, char* ws, const RhsLayout& L,
+                hipStream_t s) {
+  const gnpde_graph_t* g = r.graph;
+  const float* w = r.w_csr;
+  if (r.kind != GNPDE_RHS_LAPLACIAN) {
+    float* proj = reinterpret_cast<float*>(ws + L.proj);
+    float* wmean = reinterpret_cast<float*>(ws + L.wmean);
+    int rc = launch_linear_any(u, g->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.proj_b, proj, r.proj_m, s);
+    if (rc) return rc;
+    gnpde_attention_t at = r.att;
+    at.ldqk = r.proj_m;
+    at.q = proj;
+    at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
+    rc = launch_edge_attention(g, &at, wmean, nullptr, nullptr, ws + L.att, L.att_bytes, s);
+    if (rc) return rc;
+    w = wmean;
+  }
+  return launch_spmm_rhs(g, w, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s);
+}
+
+gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r) {
+  gnpde_epilogue_t e{};
+  e.alpha = r.alpha;
+  e.beta = r.beta;
+  e.x0 = r.x0;
+  e.alpha_sigmoid = r.alpha_sigmoid;
+  return e;
+}
+
+}  // namespace
+}  // namespace gnpde
+
+using namespace gnpde;
+
+struct gnpde_solver {
+  gnpde_rhs_t rhs;
+  gnpde_graph_t graph;
+  int method;
+  std::vector<float> dts;
+  char* ws;
+  size_t ws_bytes;
+  RhsLayout L;
+  size_t off_k1, off_k2, off_k3, off_ua, off_ub, off_rhs;
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph_obj = nullptr;
+  hipGraphExec_t exec = nullptr;
+  float* captured_y = nullptr;
+  int n_evals = 0;
+};
+
+namespace {
+
+size_t solver_layout(const gnpde_rhs_t& r, int method, gnpde_solver* s) {
+  const size_t state = align_up(static_cast<size_t>(r.graph->n) * r.ld * 4, 256);
+  size_t off = 0;
+  size_t k1 = 0, k2 = 0, k3 = 0, ua = 0, ub = 0;
+  ua = off; off += state;
+  if (method == GNPDE_METHOD_RK4) {
+    ub = off; off += state;
+    k1 = off; off += state;
+    k2 = off; off += state;
+    k3 = off; off += state;
+  }
+  const size_t rhs_off = off;
+  off += rhs_layout(r).total;
+  if (s) {
+    s->off_ua = ua; s->off_ub = ub; s->off_k1 = k1; s->off_k2 = k2; s->off_k3 = k3; s->off_rhs = rhs_off;
+  }
+  return off;
+}
+
+int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
+  const gnpde_rhs_t& r = s->rhs;
+  char* rws = s->ws + s->off_rhs;
+  float* ua = reinterpret_cast<float*>(s->ws + s->off_ua);
+  if (s->method == GNPDE_METHOD_EULER) {
+    float* cur = y;
+    float* nxt = ua;
+    for (float dt : s->dts) {
+      gnpde_epilogue_t e = base_epilogue(r);
+      e.stage = GNPDE_STAGE_EULER; e.dt = dt; e.y = cur; e.out_y = nxt;
+      int rc = enqueue_rhs(r, cur, e, rws, s->L, st);
+      if (rc) return rc;
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != y)
+      GNPDE_HIP(hipMemcpyAsync(y, cur, static_cast<size_t>(r.graph->n) * r.ld * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  float* ub = reinterpret_cast<float*>(s->ws + s->off_ub);
+  float* k1 = reinterpret_cast<float*>(s->ws + s->off_k1);
+  float* k2 = reinterpret_cast<float*>(s->ws + s->off_k2);
+  float* k3 = reinterpret_cast<float*>(s->ws + s->off_k3);
+  for (float dt : s->dts) {
+    gnpde_epilogue_t e = base_epilogue(r);
+    e.dt = dt; e.y = y;
+    e.stage = GNPDE_STAGE_RK1; e.out_k = k1; e.out_y = ua;
+    int rc = enqueue_rhs(r, y, e, rws, s->L, st);
+    if (rc) return rc;
+    e.stage = GNPDE_STAGE_RK2; e.k1 = k1; e.out_k = k2; e.out_y = ub;
+    rc = enqueue_rhs(r, ua, e, rws, s->L, st);
+    if (rc) return rc;
+    e.stage = GNPDE_STAGE_RK3; e.k2 = k2; e.out_k = k3; e.out_y = ua;
+    rc = enqueue_rhs(r, ub, e, rws, s->L, st);
+    if (rc) return rc;
+    e.stage = GNPDE_STAGE_RK4; e.k3 = k3; e.out_k = nullptr; e.out_y = y;
+    rc = enqueue_rhs(r, ua, e, rws, s->L, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+void drop_graph(gnpde_solver* s) {
+  if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+  if (s->graph_obj) { (void)hipGraphDestroy(s->graph_obj); s->graph_obj = nullptr; }
+  s->captured_y = nullptr;
+}
+
+}  // namespace
+
+extern "C" size_t gnpde_rhs_workspace_bytes(const gnpde_rhs_t* rhs) {
+  if (check_rhs(rhs)) return 0;
+  return rhs_layout(*rhs).total;
+}
+
+extern "C" int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  int rc = check_rhs(rhs);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(u && out && u != out, GNPDE_EINVAL, "rhs_eval: bad u/out");
+  const RhsLayout L = rhs_layout(*rhs);
+  GNPDE_CHECK_ARG(L.total == 0 || (workspace && workspace_bytes >= L.total), GNPDE_EWS, "rhs_eval: workspace %zu < %zu bytes",
+                  workspace_bytes, L.total);
+  gnpde_epilogue_t e = base_epilogue(*rhs);
+  e.stage = GNPDE_STAGE_RHS;
+  e.out_k = out;
+  return enqueue_rhs(*rhs, u, e, static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t gnpde_solver_workspace_bytes(const gnpde_rhs_t* rhs, int32_t method) {
+  if (check_rhs(rhs)) return 0;
+  if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4) return 0;
+  return solver_layout(*rhs, method, nullptr);
+}
+
+extern "C" int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs, int32_t method, const float* dts,
+                                   int32_t n_steps, void* workspace, size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "solver_create: out is null");
+  *out = nullptr;
+  int rc = check_rhs(rhs);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "solver_create: bad method %d", method);
+  GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "solver_create: bad time grid");
+  gnpde_solver* s = new gnpde_solver();
+  s->rhs = *rhs;
+  s->graph = *rhs->graph;
+  s->rhs.graph = &s->graph;
+  s->method = method;
+  s->dts.assign(dts, dts + n_steps);
+  s->L = rhs_layout(s->rhs);
+  const size_t need = solver_layout(s->rhs, method, s);
+  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
+    set_error("solver_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+    delete s;
+    return GNPDE_EWS;
+  }
+  s->ws = static_cast<char*>(workspace);
+  s->ws_bytes = workspace_bytes;
+  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
+  *out = s;
+  return 0;
+}
+
+extern "C" int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* stream) {
+  GNPDE_CHECK_ARG(s && y, GNPDE_EINVAL, "solver_run: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!use_graph) return enqueue_solve(s, y, st);
+  if (s->exec == nullptr || s->captured_y != y) {
+    drop_graph(s);
+    if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
+    GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_solve(s, y, s->cap_stream);
+    hipGraph_t gobj = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
+    if (rc != 0) {
+      if (gobj) (void)hipGraphDestroy(gobj);
+      return rc;
+    }
+    if (ec != hipSuccess) {
+      set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+      return static_cast<int>(ec);
+    }
+    s->graph_obj = gobj;
+    GNPDE_HIP(hipGraphInstantiate(&s->exec, s->graph_obj, nullptr, nullptr, 0));
+    s->captured_y = y;
+  }
+  GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s) { return s ? s->n_evals : 0; }
+
+extern "C" int gnpde_solver_destroy(gnpde_solver_t* s) {
+  if (!s) return 0;
+  drop_graph(s);
+  if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+  delete s;
+  return 0;
+}

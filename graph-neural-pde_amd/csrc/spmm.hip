@@ -1,0 +1,366 @@
+// Row-parallel CSR aggregation  ax[i] = sum_e w[e] * u[col_e]  fused with the diffusion epilogue
+// f = alpha' (ax - u_i) + beta x0_i  and the fixed-step solver's stage algebra (gnpde.h).
+//
+// Replaces torch_sparse.spmm (index_select -> mul -> scatter_add_ with an [E,d] temporary) plus
+// the elementwise tail of ODEFunc.forward (reference src/function_laplacian_diffusion.py:31-51,
+// src/function_transformer_attention.py:35,46-53) and torchdiffeq's per-stage AXPY chain.
+//
+// Mapping (HBM/L2-gather bound, no MFMA): one 64-lane wavefront per row.  L = lanes that cover one
+// neighbour's feature row (VEC floats each, K column tiles), G = 64/L neighbours are gathered by one
+// wave instruction, U independent gathers are issued before the first FMA so that >= 8 x 16 B loads
+// are in flight per lane.  The G partial sums are combined with an xor butterfly (deterministic, no
+// atomics).  Rows longer than GNPDE_LONG_ROW are processed as independent chunks into a partial
+// buffer and summed by a second small kernel, so a 13k-degree hub does not serialise on one wave.
+#include "common.h"
+
+namespace gnpde {
+namespace {
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+
+struct SpmmArgs {
+  int n, n_long_chunks;
+  const int* __restrict__ rowptr;
+  const int* __restrict__ colidx;
+  const int* __restrict__ lc_row;
+  const int* __restrict__ lc_begin;
+  const int* __restrict__ lc_end;
+  const float* __restrict__ w;
+  const float* __restrict__ u;
+  int d, ld;
+  float* plain_out;      // != nullptr: write ax only (no epilogue)
+  float* partial;        // [n_long_chunks, ldp]
+  int ldp;
+  gnpde_epilogue_t ep;
+};
+
+__device__ __forceinline__ float alpha_of(const gnpde_epilogue_t& ep) {
+  const float a = *ep.alpha;
+  return ep.alpha_sigmoid ? 1.0f / (1.0f + expf(-a)) : a;
+}
+
+// k = alpha (ax - u_i) + beta x0_i, then the stage algebra in torchdiffeq's operation order.
+template <int VEC>
+__device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off,
+                                         const float (&ax)[VEC], const float (&ui)[VEC]) {
+  constexpr float kThird = 1.0f / 3.0f;
+  float k[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) k[v] = alpha * (ax[v] - ui[v]);
+  if (ep.x0 != nullptr) {
+    float s[VEC];
+    load_vec<VEC>(ep.x0 + off, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
+  }
+  const float dt = ep.dt;
+  float y[VEC], a[VEC], b[VEC], c[VEC], o[VEC];
+  switch (ep.stage) {
+    case GNPDE_STAGE_RHS:
+      store_vec<VEC>(ep.out_k + off, k);
+      break;
+    case GNPDE_STAGE_EULER:
+      load_vec<VEC>(ep.y + off, y);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * k[v];
+      store_vec<VEC>(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK1:
+      load_vec<VEC>(ep.y + off, y);
+      store_vec<VEC>(ep.out_k + off, k);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = y[v] + (dt * k[v]) * kThird;
+      store_vec<VEC>(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK2:
+      load_vec<VEC>(ep.y + off, y);
+      load_vec<VEC>(ep.k1 + off, a);
+      store_vec<VEC>(ep.out_k + off, k);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * (k[v] - a[v] * kThird);
+      store_vec<VEC>(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK3:
+      load_vec<VEC>(ep.y + off, y);
+      load_vec<VEC>(ep.k1 + off, a);
+      load_vec<VEC>(ep.k2 + off, b);
+      store_vec<VEC>(ep.out_k + off, k);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * ((a[v] - b[v]) + k[v]);
+      store_vec<VEC>(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK4:
+      load_vec<VEC>(ep.y + off, y);
+      load_vec<VEC>(ep.k1 + off, a);
+      load_vec<VEC>(ep.k2 + off, b);
+      load_vec<VEC>(ep.k3 + off, c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = y[v] + (((a[v] + 3.0f * (b[v] + c[v])) + k[v]) * dt) * 0.125f;
+      store_vec<VEC>(ep.out_y + off, o);
+      break;
+    default:
+      break;
+  }
+}
+
+template <int VEC, int L, int K>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
+  constexpr int G = kWave / L;
+  constexpr int U = (K >= 4) ? 1 : (K >= 2 ? 2 : 4);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blk) * kWavesPerBlock + wave);
+  const int sub = lane / L;   // neighbour slot
+  const int cl = lane % L;    // column lane
+
+  int row, e0, e1;
+  int chunk = -1;
+  if (item < a.n) {
+    row = item;
+    e0 = a.rowptr[row];
+    e1 = a.rowptr[row + 1];
+    if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed below as chunks
+  } else {
+    chunk = item - a.n;
+    if (chunk >= a.n_long_chunks) return;
+    row = a.lc_row[chunk];
+    e0 = a.lc_begin[chunk];
+    e1 = a.lc_end[chunk];
+  }
+
+  float acc[K][VEC];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
+
+  const int last = e1 - 1;
+  for (int j = e0; j < e1; j += G * U) {
+    float vals[U][K][VEC];
+    float ww[U];
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      const int e = j + t * G + sub;
+      const int ec = e < e1 ? e : last;   // clamp: always a valid (cached) neighbour, weight 0
+      const int c = a.colidx[ec];
+      const float wv = a.w[ec];
+      ww[t] = e < e1 ? wv : 0.0f;
+      const float* src = a.u + static_cast<size_t>(c) * a.ld;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int col = (k * L + cl) * VEC;
+        if (col < a.d) {
+          load_vec<VEC>(src + col, vals[t][k]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) vals[t][k][v] = 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[k][v] = fmaf(ww[t], vals[t][k][v], acc[k][v]);
+  }
+
+  // combine the G neighbour slots (lanes with equal column lane)
+#pragma unroll
+  for (int off = L; off < kWave; off <<= 1)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[k][v] += __shfl_xor(acc[k][v], off, kWave);
+
+  if (sub != 0) return;
+
+  if (chunk >= 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int col = (k * L + cl) * VEC;
+      if (col < a.d) store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc[k]);
+    }
+    return;
+  }
+  if (a.plain_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int col = (k * L + cl) * VEC;
+      if (col < a.d) store_vec<VEC>(a.plain_out + static_cast<size_t>(row) * a.ld + col, acc[k]);
+    }
+    return;
+  }
+  const float alpha = alpha_of(a.ep);
+  const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int col = (k * L + cl) * VEC;
+    if (col < a.d) {
+      const size_t off = static_cast<size_t>(row) * a.ld + col;
+      float ui[VEC];
+      load_vec<VEC>(a.u + off, ui);
+      epilogue<VEC>(a.ep, alpha, beta, off, acc[k], ui);
+    }
+  }
+}
+
+// One block per long row: sum its chunk partials in chunk order, then the epilogue.
+__global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(const SpmmArgs a, const int* __restrict__ long_rows,
+                                                                 const int* __restrict__ long_chunk_ptr) {
+  const int lr = blockIdx.x;
+  const int row = long_rows[lr];
+  const int c0 = long_chunk_ptr[lr], c1 = long_chunk_ptr[lr + 1];
+  const bool plain = a.plain_out != nullptr;
+  const float alpha = plain ? 0.0f : alpha_of(a.ep);
+  const float beta = (!plain && a.ep.x0 != nullptr) ? *a.ep.beta : 0.0f;
+  for (int col = threadIdx.x; col < a.d; col += blockDim.x) {
+    float s = 0.0f;
+    for (int c = c0; c < c1; ++c) s += a.partial[static_cast<size_t>(c) * a.ldp + col];
+    const size_t off = static_cast<size_t>(row) * a.ld + col;
+    if (plain) {
+      a.plain_out[off] = s;
+    } else {
+      const float ax[1] = {s};
+      const float ui[1] = {a.u[off]};
+      epilogue<1>(a.ep, alpha, beta, off, ax, ui);
+    }
+  }
+}
+
+template <int VEC, int L, int K>
+void launch_rows(const SpmmArgs& a, hipStream_t s) {
+  const long long items = static_cast<long long>(a.n) + a.n_long_chunks;
+  const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+template <int VEC>
+int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
+  const int slots = (a.d + VEC - 1) / VEC;
+  if (slots <= 8) launch_rows<VEC, 8, 1>(a, s);
+  else if (slots <= 16) launch_rows<VEC, 16, 1>(a, s);
+  else if (slots <= 32) launch_rows<VEC, 32, 1>(a, s);
+  else if (slots <= 64) launch_rows<VEC, 64, 1>(a, s);
+  else if (slots <= 128) launch_rows<VEC, 64, 2>(a, s);
+  else if (slots <= 192) launch_rows<VEC, 64, 3>(a, s);
+  else if (slots <= 256) launch_rows<VEC, 64, 4>(a, s);
+  else {
+    set_error("spmm: feature width d=%d too large for VEC=%d (max %d)", a.d, VEC, 256 * VEC);
+    return GNPDE_ESHAPE;
+  }
+  return 0;
+}
+
+inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
+                    const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  GNPDE_CHECK_ARG(g && u && (w_csr || g->e == 0), GNPDE_EINVAL, "spmm: null pointer");
+  GNPDE_CHECK_ARG(d >= 1 && ld >= d, GNPDE_EINVAL, "spmm: bad d=%d ld=%d", d, ld);
+  GNPDE_CHECK_ARG((epi != nullptr) != (plain_out != nullptr), GNPDE_EINVAL, "spmm: need exactly one of epilogue / plain output");
+  if (g->n == 0) return 0;
+  SpmmArgs a{};
+  a.n = g->n;
+  a.n_long_chunks = g->n_long_chunks;
+  a.rowptr = g->rowptr;
+  a.colidx = g->colidx;
+  a.lc_row = g->long_chunk_row;
+  a.lc_begin = g->long_chunk_begin;
+  a.lc_end = g->long_chunk_end;
+  a.w = w_csr;
+  a.u = u;
+  a.d = d;
+  a.ld = ld;
+  a.plain_out = plain_out;
+  a.ldp = static_cast<int>(align_up(static_cast<size_t>(d), 4));
+  a.partial = static_cast<float*>(ws);
+  if (g->n_long_chunks > 0) {
+    const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
+    GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need, GNPDE_EWS, "spmm: workspace %zu < %zu bytes", ws_bytes, need);
+    GNPDE_CHECK_ARG(g->long_rows && g->long_chunk_ptr && g->long_chunk_row && g->long_chunk_begin && g->long_chunk_end,
+                    GNPDE_EINVAL, "spmm: long-row arrays missing");
+  }
+  bool a16 = (d % 4 == 0) && (ld % 4 == 0) && aligned(u, 16) && aligned(plain_out, 16) && aligned(ws, 16);
+  bool a8 = (d % 2 == 0) && (ld % 2 == 0) && aligned(u, 8) && aligned(plain_out, 8) && aligned(ws, 8);
+  if (epi) {
+    a.ep = *epi;
+    const gnpde_epilogue_t& e = a.ep;
+    GNPDE_CHECK_ARG(e.alpha != nullptr, GNPDE_EINVAL, "spmm: alpha pointer is null");
+    GNPDE_CHECK_ARG(e.x0 == nullptr || e.beta != nullptr, GNPDE_EINVAL, "spmm: x0 given without beta");
+    GNPDE_CHECK_ARG(e.stage >= GNPDE_STAGE_RHS && e.stage <= GNPDE_STAGE_RK4, GNPDE_EINVAL, "spmm: bad stage %d", e.stage);
+    const int st = e.stage;
+    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RK4 || st == GNPDE_STAGE_EULER || e.out_k != nullptr, GNPDE_EINVAL, "spmm: out_k is null");
+    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RHS || (e.out_y != nullptr && e.y != nullptr), GNPDE_EINVAL, "spmm: y/out_y is null");
+    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK2 || e.k1 != nullptr, GNPDE_EINVAL, "spmm: k1 is null");
+    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK3 || e.k2 != nullptr, GNPDE_EINVAL, "spmm: k2 is null");
+    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK4 || e.k3 != nullptr, GNPDE_EINVAL, "spmm: k3 is null");
+    // every row gathers from u while other rows run their epilogue: outputs must not alias u
+    GNPDE_CHECK_ARG(e.out_k != u && e.out_y != u, GNPDE_EINVAL, "spmm: output aliases the gathered operand");
+    const void* ptrs[] = {e.x0, e.y, e.k1, e.k2, e.k3, e.out_k, e.out_y};
+    for (const void* p : ptrs) {
+      a16 = a16 && aligned(p, 16);
+      a8 = a8 && aligned(p, 8);
+    }
+  } else {
+    GNPDE_CHECK_ARG(plain_out != u, GNPDE_EINVAL, "spmm: output aliases the gathered operand");
+  }
+  int rc;
+  if (a16) rc = dispatch_rows<4>(a, stream);
+  else if (a8) rc = dispatch_rows<2>(a, stream);
+  else rc = dispatch_rows<1>(a, stream);
+  if (rc != 0) return rc;
+  GNPDE_LAUNCH_CHECK();
+  if (g->n_long_rows > 0) {
+    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, stream, a, g->long_rows,
+                       g->long_chunk_ptr);
+    GNPDE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace gnpde
+
+extern "C" size_t gnpde_spmm_workspace_bytes(const gnpde_graph_t* g, int32_t d) {
+  if (!g || d < 1) return 0;
+  return static_cast<size_t>(g->n_long_chunks) * gnpde::align_up(static_cast<size_t>(d), 4) * sizeof(float);
+}
+
+extern "C" int gnpde_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,
+                              const gnpde_epilogue_t* epi, void* workspace, size_t workspace_bytes, void* stream) {
+  GNPDE_CHECK_ARG(epi != nullptr, GNPDE_EINVAL, "spmm_rhs: epilogue is null");
+  return gnpde::launch_spmm_rhs(g, w_csr, u, d, ld, epi, nullptr, workspace, workspace_bytes,
+                                static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnpde_spmm(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "spmm: out is null");
+  return gnpde::launch_spmm_rhs(g, w_csr, u, d, ld, nullptr, out, workspace, workspace_bytes,
+                                static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,228 @@
+"""Integrator entry point with torchdiffeq's calling convention
+(`odeint(func, y0, t, method=, options=, atol=, rtol=)` -> tensor [len(t), *y0.shape]), as used by
+the reference's blocks (src/block_constant.py:57-62, src/block_transformer_attention.py:58-63).
+
+Fixed-grid methods (`euler`, `rk4` == torchdiffeq 0.2.1's 3/8-rule rk4_alt_step_func) on one of this
+package's ODEFunc objects run as ONE native solver object whose whole time loop is a captured
+hipGraph (csrc/solver.hip).  Everything else (dopri5, foreign callables, several output times) runs
+the host loops below, which still evaluate f through the native kernels."""
+import math
+import torch
+
+from . import _lib
+
+_THIRD = 1 / 3
+
+
+def time_grid(t, step_size):
+  """torchdiffeq FixedGridODESolver grid: niters = ceil((t1 - t0)/h + 1) points t0 + i h, the last
+  one replaced by t1 (so the final step may be short).  Computed in t's dtype like the original."""
+  t0, t1 = t[0], t[-1]
+  niters = int(torch.ceil((t1 - t0) / step_size + 1).item())
+  grid = torch.arange(0, niters, dtype=t.dtype, device=t.device) * step_size + t0
+  grid[-1] = t1
+  return grid
+
+
+# --------------------------------------------------------------------------------------------------
+# native fixed-step path
+# --------------------------------------------------------------------------------------------------
+def _native_ok(func, y0, t):
+  return (hasattr(func, '_descriptor') and y0.is_cuda and y0.dim() == 2 and y0.dtype == torch.float32
+          and len(t) == 2 and not func._needs_grad(y0))
+
+
+def _solve_native(func, y0, t, method, step_size, use_graph=True):
+  from . import ops
+  grid = time_grid(t.detach().to('cpu'), step_size)
+  dts = (grid[1:] - grid[:-1]).tolist()
+  n_evals = len(dts) * (4 if method == 'rk4' else 1)
+  # NFE guard with the reference's semantics (raise at the first evaluation that finds nfe > max_nfe)
+  room = func.opt['max_nfe'] + 1 - func.nfe
+  if n_evals > room:
+    func.nfe += max(room, 0)
+    from .utils import MaxNFEException
+    raise MaxNFEException
+  st = func.__dict__.setdefault('_solver_state', {})
+  key = (method, tuple(dts), tuple(y0.shape), str(y0.device))
+  ent = st.get(key)
+  y0c = y0.detach()
+  if ent is None:
+    ent = {'y': torch.empty_like(y0c, memory_format=torch.contiguous_format),
+           'x0': torch.empty_like(y0c, memory_format=torch.contiguous_format) if func.opt['add_source'] else None,
+           'solver': None, 'sig': None}
+    st.clear()  # one live solver per function object: buffers are state-sized
+    st[key] = ent
+  ent['y'].copy_(y0c)
+  if ent['x0'] is not None:
+    if func.x0 is None:
+      raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+    ent['x0'].copy_(func.x0)
+  desc = func._descriptor(ent['y'], x0_override=ent['x0'])
+  sig = func._descriptor_signature(desc)
+  if ent['solver'] is None or ent['sig'] != sig:
+    if ent['solver'] is not None:
+      ent['solver'].close()
+    ent['solver'] = ops.FixedStepSolver(desc, method, dts, y0.device)
+    ent['sig'] = sig
+  ent['solver'].run(ent['y'], use_graph=use_graph)
+  func.nfe += n_evals
+  out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+  out[0].copy_(y0c)
+  out[1].copy_(ent['y'])
+  return out
+
+
+# --------------------------------------------------------------------------------------------------
+# host loops (any callable)
+# --------------------------------------------------------------------------------------------------
+def _rk4_38_step(func, t0, dt, t1, y0):
+  k1 = func(t0, y0)
+  k2 = func(t0 + dt * _THIRD, y0 + dt * k1 * _THIRD)
+  k3 = func(t0 + dt * (2 * _THIRD), y0 + dt * (k2 - k1 * _THIRD))
+  k4 = func(t1, y0 + dt * (k1 - k2 + k3))
+  return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+
+
+def _solve_fixed_host(func, y0, t, method, step_size):
+  grid = time_grid(t, step_size)
+  out = torch.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+  out[0] = y0
+  j = 1
+  y = y0
+  for i in range(len(grid) - 1):
+    ta, tb = grid[i], grid[i + 1]
+    dt = tb - ta
+    dy = dt * func(ta, y) if method == 'euler' else _rk4_38_step(func, ta, dt, tb, y)
+    y_next = y + dy
+    while j < len(t) and tb >= t[j]:
+      if t[j] == tb:
+        out[j] = y_next
+      elif t[j] == ta:
+        out[j] = y
+      else:
+        out[j] = y + ((t[j] - ta) / (tb - ta)) * (y_next - y)
+      j += 1
+    y = y_next
+  return out
+
+
+# Dormand-Prince 5(4) coefficients (Shampine's error weights), as used by torchdiffeq's dopri5
+_DP_A = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+_DP_B = ((1 / 5,),
+         (3 / 40, 9 / 40),
+         (44 / 45, -56 / 15, 32 / 9),
+         (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+         (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+         (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84))
+_DP_E = (35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+         -2187 / 6784 + 12231 / 42400, 11 / 84 - 649 / 6300, -1 / 60)
+_DP_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+           187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
+
+
+def _rms(v):
+  return v.pow(2).mean().sqrt()
+
+
+def _combine(y0, ks, coeffs, dt):
+  """y0 + sum_j (c_j * dt) k_j with the coefficients rounded to the state dtype first, as
+  torchdiffeq's k.matmul(beta * dt) does."""
+  acc = None
+  for kj, c in zip(ks, coeffs):
+    if c == 0.0:
+      continue
+    term = kj * (torch.tensor(c, dtype=kj.dtype, device=kj.device) * dt)
+    acc = term if acc is None else acc + term
+  return acc if y0 is None else y0 + acc
+
+
+def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9, ifactor=10.0, dfactor=0.2):
+  """Adaptive Dormand-Prince with torchdiffeq 0.2.1's controller: time and step size in float64,
+  state in y0's dtype, rms error norm, FSAL, quartic-interpolated output."""
+  dev = y0.device
+  f64 = dict(dtype=torch.float64, device=dev)
+  rtol_t, atol_t = torch.as_tensor(rtol, **f64), torch.as_tensor(atol, **f64)
+  tt = t.to(torch.float64)
+  out = torch.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=dev)
+  out[0] = y0
+  f0 = func(tt[0], y0)
+  # initial step (Hairer, Norsett & Wanner), order p = 4
+  scale = atol_t + torch.abs(y0) * rtol_t
+  d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+  h0 = torch.tensor(1e-6, dtype=y0.dtype, device=dev) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+  f1 = func(tt[0].to(y0.dtype) + h0, y0 + h0 * f0)
+  d2 = _rms((f1 - f0) / scale) / h0
+  if d1 <= 1e-15 and d2 <= 1e-15:
+    h1 = torch.max(torch.tensor(1e-6, dtype=y0.dtype, device=dev), h0 * 1e-3)
+  else:
+    h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+  dt = torch.min(100 * h0, h1).to(torch.float64)
+  y, f, t_prev, t_cur = y0, f0, tt[0], tt[0]
+  interp = None
+  for i in range(1, len(t)):
+    n_steps = 0
+    while tt[i] > t_cur:
+      assert n_steps < max_num_steps, 'max_num_steps exceeded'
+      assert t_cur + dt > t_cur, 'underflow in dt {}'.format(float(dt))
+      dty = dt.to(y.dtype)
+      ks = [f]
+      yi = None
+      for a_i, b_i in zip(_DP_A, _DP_B):
+        yi = _combine(y, ks, b_i, dty)
+        ks.append(func(t_cur + dt if a_i == 1.0 else t_cur + a_i * dt, yi))
+      y1, f1 = yi, ks[-1]
+      err = _combine(None, ks, _DP_E, dty)
+      tol = atol_t + rtol_t * torch.max(y.abs(), y1.abs())
+      ratio = _rms(err / tol)
+      accept = bool(ratio <= 1)
+      if accept:
+        y_mid = _combine(y, ks, _DP_MID, dty)
+        interp = (y, y1, y_mid, ks[0], ks[-1], dty, t_cur, t_cur + dt)
+        t_prev, t_cur = t_cur, t_cur + dt
+        y, f = y1, f1
+      # step-size controller
+      if ratio == 0:
+        dt = dt * ifactor
+      else:
+        lo = 1.0 if ratio < 1 else dfactor
+        r = ratio.to(torch.float64)
+        factor = torch.clamp(safety / r ** (1.0 / 5.0), min=lo, max=ifactor)
+        dt = dt * factor
+      n_steps += 1
+    ya, yb, ym, fa, fb, h, ta, tb = interp
+    xfrac = ((tt[i] - ta) / (tb - ta)).to(y0.dtype)
+    ca = 2 * h * (fb - fa) - 8 * (yb + ya) + 16 * ym
+    cb = h * (5 * fa - 3 * fb) + 18 * ya + 14 * yb - 32 * ym
+    cc = h * (fb - 4 * fa) - 11 * ya - 5 * yb + 16 * ym
+    cd = h * fa
+    total = ya + xfrac * cd
+    xp = xfrac
+    for coef in (cc, cb, ca):
+      xp = xp * xfrac
+      total = total + xp * coef
+    out[i] = total
+  return out
+
+
+def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_graph=True, **adjoint_kwargs):
+  """Drop-in for torchdiffeq.odeint on this path.  Unknown options (e.g. `max_iters`, which the
+  reference passes and torchdiffeq ignores with a warning) are ignored."""
+  options = dict(options or {})
+  method = 'dopri5' if method is None else method
+  if method in ('euler', 'rk4'):
+    step_size = options.get('step_size', None)
+    if step_size is None:
+      raise ValueError('fixed-grid methods need options["step_size"]')
+    if _native_ok(func, y0, t):
+      return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
+    return _solve_fixed_host(func, y0, t, method, step_size)
+  if method == 'dopri5':
+    return _solve_dopri5(func, y0, t, rtol, atol)
+  raise ValueError('unsupported method %r (euler, rk4, dopri5)' % (method,))
+
+
+def odeint_adjoint(func, y0, t, **kw):
+  """Forward values of the adjoint integrator equal those of `odeint`; the adjoint backward pass is
+  SURVEY.md section 8f row 1 (next)."""
+  return odeint(func, y0, t, **kw)

@@ -1,0 +1,196 @@
+"""Torch-facing wrappers of the C ABI (include/gnpde.h).  PyTorch is plumbing here: it owns the
+device memory and the stream; every arithmetic step runs in libgnpde_hip.so."""
+import ctypes
+import torch
+
+from . import _lib
+from ._lib import ptr, check, require_hip, f32c, stream_of
+
+
+def _scalar_dev(t, like):
+  """Learnable scalars are read by the kernels from device memory."""
+  t = t.detach()
+  if t.device != like.device or t.dtype != torch.float32:
+    t = t.to(like.device, torch.float32)
+  return t.reshape(-1)
+
+
+def linear(x, weight, bias=None, out=None):
+  """out = x @ weight.T + bias on the fp32 matrix cores (gnpde_linear)."""
+  require_hip(x, weight, bias)
+  x, weight = f32c(x, 'x'), f32c(weight, 'weight')
+  n, d = x.shape
+  m = weight.shape[0]
+  if weight.shape[1] != d:
+    raise _lib.GnpdeError('linear: weight is %s but x has %d features' % (tuple(weight.shape), d))
+  if out is None:
+    out = torch.empty(n, m, dtype=torch.float32, device=x.device)
+  b = None if bias is None else f32c(bias, 'bias')
+  check(_lib.lib().gnpde_linear(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out),
+                                out.stride(0), stream_of(x)))
+  return out
+
+
+def edge_to_csr_mean(graph, src_edge, out=None):
+  """w_csr[p] = mean over heads of src_edge[perm[p]]; src_edge is [E] or [E,h] in edge order."""
+  require_hip(src_edge)
+  src = f32c(src_edge.detach(), 'edge weights')
+  h = 1 if src.dim() == 1 else src.shape[1]
+  if src.shape[0] != graph.e:
+    raise _lib.GnpdeError('edge weights have %d rows but the graph has %d edges' % (src.shape[0], graph.e))
+  if out is None:
+    out = torch.empty(max(graph.e, 1), dtype=torch.float32, device=src.device)
+  check(_lib.lib().gnpde_edge_to_csr_mean(graph.ref(), ptr(src), h, ptr(out), stream_of(src)))
+  return out
+
+
+def make_epilogue(alpha, beta, x0, alpha_sigmoid, stage=_lib.STAGE_RHS, dt=0.0, y=None, k1=None, k2=None, k3=None,
+                  out_k=None, out_y=None):
+  e = _lib.EpilogueStruct()
+  e.alpha, e.beta = alpha.data_ptr(), (beta.data_ptr() if beta is not None else None)
+  e.x0 = x0.data_ptr() if x0 is not None else None
+  e.alpha_sigmoid, e.stage, e.dt = int(alpha_sigmoid), int(stage), float(dt)
+  for name, t in (('y', y), ('k1', k1), ('k2', k2), ('k3', k3), ('out_k', out_k), ('out_y', out_y)):
+    setattr(e, name, t.data_ptr() if t is not None else None)
+  return e
+
+
+def spmm_rhs(graph, w_csr, u, alpha, beta=None, x0=None, alpha_sigmoid=True, out=None, **stage_kw):
+  """f = alpha' (A u - u) + beta x0 with A given by (graph, w_csr); optional fused solver stage."""
+  require_hip(u, w_csr, x0)
+  u = f32c(u, 'u')
+  n, d = u.shape
+  if n != graph.n:
+    raise _lib.GnpdeError('state has %d rows but the graph has %d nodes' % (n, graph.n))
+  alpha_d = _scalar_dev(alpha, u)
+  beta_d = _scalar_dev(beta, u) if x0 is not None else None
+  x0c = f32c(x0, 'x0') if x0 is not None else None
+  if x0c is not None and x0c.shape != u.shape:
+    raise _lib.GnpdeError('x0 shape %s != state shape %s' % (tuple(x0c.shape), tuple(u.shape)))
+  if 'stage' not in stage_kw:
+    if out is None:
+      out = torch.empty_like(u)
+    stage_kw = dict(stage=_lib.STAGE_RHS, out_k=out)
+  epi = make_epilogue(alpha_d, beta_d, x0c, alpha_sigmoid, **stage_kw)
+  L = _lib.lib()
+  ws = graph.workspace('spmm%d' % d, L.gnpde_spmm_workspace_bytes(graph.ref(), d))
+  check(L.gnpde_spmm_rhs(graph.ref(), ptr(w_csr), ptr(u), d, u.stride(0), ctypes.byref(epi), ptr(ws), ws.numel(),
+                         stream_of(u)))
+  return out
+
+
+def spmm(graph, w_csr, u, out=None):
+  """Plain aggregation out = A u."""
+  require_hip(u, w_csr)
+  u = f32c(u, 'u')
+  n, d = u.shape
+  if out is None:
+    out = torch.empty_like(u)
+  L = _lib.lib()
+  ws = graph.workspace('spmm%d' % d, L.gnpde_spmm_workspace_bytes(graph.ref(), d))
+  check(L.gnpde_spmm(graph.ref(), ptr(w_csr), ptr(u), d, u.stride(0), ptr(out), ptr(ws), ws.numel(), stream_of(u)))
+  return out
+
+
+def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=None, ldqk=0, leaky_slope=0.2,
+                     gat_a=None, output_var=None, lengthscale=None, edge_w_csr=None):
+  a = _lib.AttentionStruct()
+  a.type, a.heads, a.att_dim = int(att_type), int(heads), int(att_dim)
+  a.norm_idx, a.square_plus, a.leaky_slope = int(norm_idx), int(bool(square_plus)), float(leaky_slope)
+  a.q = q.data_ptr() if q is not None else None
+  a.k = k.data_ptr() if k is not None else None
+  a.ldqk = int(ldqk)
+  for name, t in (('gat_a', gat_a), ('output_var', output_var), ('lengthscale', lengthscale),
+                  ('edge_w_csr', edge_w_csr)):
+    setattr(a, name, t.data_ptr() if t is not None else None)
+  return a
+
+
+def edge_attention(graph, att, want_w_mean=True, want_att=False, want_prods=False, like=None):
+  """Run the three attention passes.  Returns (w_mean_csr [e] | None, att [E,h] | None, prods [E,h] | None),
+  the [E,h] tensors in the caller's edge order."""
+  dev = like.device
+  L = _lib.lib()
+  ws = graph.workspace('att', L.gnpde_attention_workspace_bytes(graph.ref(), ctypes.byref(att)))
+  w = torch.empty(max(graph.e, 1), dtype=torch.float32, device=dev) if want_w_mean else None
+  a_out = torch.empty(graph.e, att.heads, dtype=torch.float32, device=dev) if want_att else None
+  p_out = torch.empty(graph.e, att.heads, dtype=torch.float32, device=dev) if want_prods else None
+  check(L.gnpde_edge_attention(graph.ref(), ctypes.byref(att), ptr(w), ptr(a_out), ptr(p_out), ptr(ws), ws.numel(),
+                               stream_of(like)))
+  return w, a_out, p_out
+
+
+class RhsDescriptor(object):
+  """Python owner of a gnpde_rhs_t: keeps every tensor the descriptor points to alive."""
+
+  def __init__(self, kind, graph, d, ld, alpha, beta, x0, alpha_sigmoid, w_csr=None, proj_w=None, proj_b=None,
+               att=None):
+    self.graph = graph
+    self.keep = [alpha, beta, x0, w_csr, proj_w, proj_b]
+    r = _lib.RhsStruct()
+    r.kind = int(kind)
+    r.graph = ctypes.pointer(graph.struct)
+    r.d, r.ld = int(d), int(ld)
+    r.alpha = alpha.data_ptr()
+    r.beta = beta.data_ptr() if beta is not None else None
+    r.x0 = x0.data_ptr() if x0 is not None else None
+    r.alpha_sigmoid = int(alpha_sigmoid)
+    r.w_csr = w_csr.data_ptr() if w_csr is not None else None
+    r.proj_w = proj_w.data_ptr() if proj_w is not None else None
+    r.proj_b = proj_b.data_ptr() if proj_b is not None else None
+    r.proj_m = int(proj_w.shape[0]) if proj_w is not None else 0
+    if att is not None:
+      r.att = att
+    self.struct = r
+
+  def ref(self):
+    return ctypes.byref(self.struct)
+
+
+def rhs_eval(desc, u, out=None):
+  """One evaluation f(u) of a descriptor (gnpde_rhs_eval)."""
+  require_hip(u)
+  u = f32c(u, 'u')
+  if out is None:
+    out = torch.empty_like(u)
+  L = _lib.lib()
+  ws = desc.graph.workspace('rhs%d_%d' % (desc.struct.kind, desc.struct.d), L.gnpde_rhs_workspace_bytes(desc.ref()))
+  check(L.gnpde_rhs_eval(desc.ref(), ptr(u), ptr(out), ptr(ws), ws.numel(), stream_of(u)))
+  return out
+
+
+class FixedStepSolver(object):
+  """gnpde_solver_t: euler / rk4 over a fixed grid, the whole loop captured in one hipGraph."""
+
+  def __init__(self, desc, method, dts, device):
+    self.desc = desc
+    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
+    self.dts = [float(v) for v in dts]
+    L = _lib.lib()
+    nbytes = L.gnpde_solver_workspace_bytes(desc.ref(), self.method)
+    self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    arr = (ctypes.c_float * len(self.dts))(*self.dts)
+    handle = ctypes.c_void_p()
+    check(L.gnpde_solver_create(ctypes.byref(handle), desc.ref(), self.method, arr, len(self.dts), ptr(self.ws),
+                                self.ws.numel()))
+    self.handle = handle
+    self.n_rhs_evals = L.gnpde_solver_num_rhs_evals(handle)
+
+  def run(self, y, use_graph=True):
+    """Integrate y in place."""
+    require_hip(y)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+      raise _lib.GnpdeError('solver state must be contiguous float32')
+    check(_lib.lib().gnpde_solver_run(self.handle, ptr(y), int(bool(use_graph)), stream_of(y)))
+    return y
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      try:
+        _lib.lib().gnpde_solver_destroy(self.handle)
+      except Exception:
+        pass
+      self.handle = ctypes.c_void_p()
+
+  def __del__(self):
+    self.close()

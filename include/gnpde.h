@@ -1,0 +1,256 @@
+/*
+ * gnpde.h -- C ABI of libgnpde_hip.so: the MI355X (gfx950) implementation of the GRAND / BLEND
+ * ODE right-hand side f(t,x) = alpha * (A(x) x - x) + beta * x0 and of the fixed-step solver loop
+ * around it.
+ *
+ * The reference (twitter-research/graph-neural-pde) has no FFI: its boundary for this path is the
+ * Python protocol ODEFunc.forward(t, x) / ODEblock.forward(x) (src/base_classes.py:32-95).  The
+ * entry points below are what a binding for that path binds; each cites the reference code it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller; nothing here allocates
+ *     device memory, synchronises the device or touches the default stream (safe inside hipGraph
+ *     capture), except the gnpde_solver_* objects which own their hipGraphExec;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns 0 on success, a hipError_t (> 0) for runtime failures, or a negative
+ *     GNPDE_E* code for bad arguments; gnpde_last_error() returns a thread-local message;
+ *   - all floating point is IEEE fp32 (no fast-math), all device indices int32;
+ *   - learnable scalars (alpha_train, beta_train, ...) are read from DEVICE pointers so that no
+ *     host synchronisation is needed between optimiser steps and solves.
+ */
+#ifndef GNPDE_H
+#define GNPDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNPDE_ABI_VERSION 1
+
+#define GNPDE_EINVAL   (-1)  /* bad argument                                  */
+#define GNPDE_ESHAPE   (-2)  /* shape not supported by any kernel variant     */
+#define GNPDE_EWS      (-3)  /* workspace too small                           */
+#define GNPDE_ESTATE   (-4)  /* object used in the wrong state                */
+
+/* Rows with more than GNPDE_LONG_ROW non-zeros are split into chunks of that many edges so that a
+ * hub node (ogbn-arxiv: degree 13k) is spread over many wavefronts. */
+#define GNPDE_LONG_ROW 512
+
+int         gnpde_abi_version(void);
+const char* gnpde_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph preparation (host, C++).  Replaces the implicit COO handling of torch_sparse.spmm /
+ * torch_scatter (reference call sites: src/function_transformer_attention.py:35,190-191,213;
+ * src/function_laplacian_diffusion.py:31-35): COO int64 [2,E] in ANY order, duplicates allowed
+ * -> CSR with a stable permutation, a CSC view, and the long-row chunk list.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Number of long rows / long-row chunks the edge list produces (sizes of the arrays below). */
+int gnpde_graph_count_long(const int64_t* row, int64_t n_edges, int32_t n_nodes,
+                           int32_t* n_long_rows, int32_t* n_long_chunks);
+
+/* All arrays are HOST memory, caller allocated:
+ *   rowptr[n+1], colidx[E], perm[E] (CSR position -> index into the caller's edge list; stable, so
+ *   duplicates keep their relative order), rowidx[E] (row of each CSR position),
+ *   cscptr[n+1], cscpos[E] (for every column, the CSR positions of its entries, ascending)  -- may
+ *   both be NULL;  long_rows[n_long_rows], long_chunk_ptr[n_long_rows+1],
+ *   long_chunk_row/begin/end[n_long_chunks].
+ * Returns GNPDE_EINVAL if an index is outside [0, n_nodes). */
+int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
+                      int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
+                      int32_t* cscptr, int32_t* cscpos,
+                      int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* long_chunk_row,
+                      int32_t* long_chunk_begin, int32_t* long_chunk_end);
+
+/* Balanced k-way row partition for the multi-GPU path (no METIS offline): BFS-grown parts balanced
+ * on nnz, refined by label propagation.  part[n] receives values in [0, n_parts).  Host only. */
+int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes,
+                         int32_t n_parts, int32_t refine_iters, uint64_t seed, int32_t* part);
+
+/* Device view of a prepared graph (all pointers device memory). */
+typedef struct gnpde_graph {
+  int32_t n;                         /* nodes (square operator)                              */
+  int32_t e;                         /* stored entries                                       */
+  const int32_t* rowptr;             /* [n+1]                                                */
+  const int32_t* colidx;             /* [e]  CSR order                                       */
+  const int32_t* rowidx;             /* [e]  row of each CSR position                        */
+  const int32_t* perm;               /* [e]  CSR position -> caller edge id                  */
+  const int32_t* cscptr;             /* [n+1] or NULL                                        */
+  const int32_t* cscpos;             /* [e]   or NULL                                        */
+  int32_t n_long_rows;
+  int32_t n_long_chunks;
+  const int32_t* long_rows;          /* [n_long_rows]                                        */
+  const int32_t* long_chunk_ptr;     /* [n_long_rows+1]                                      */
+  const int32_t* long_chunk_row;     /* [n_long_chunks]                                      */
+  const int32_t* long_chunk_begin;   /* [n_long_chunks]                                      */
+  const int32_t* long_chunk_end;     /* [n_long_chunks]                                      */
+} gnpde_graph_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Epilogue of one right-hand-side evaluation, optionally fused with the solver's stage algebra.
+ *   k      = alpha' * (A u - u_i) [+ beta * x0_i]      alpha' = sigmoid(*alpha) or *alpha
+ *            (src/function_laplacian_diffusion.py:43-51 == function_transformer_attention.py:46-53
+ *             == function_GAT_attention.py:56-64)
+ * and then, per `stage` (torchdiffeq 0.2.1 fixed-grid solvers, called from
+ * src/block_constant.py:57-62; rk4 == 3/8-rule rk4_alt_step_func, cf. src/early_stop_solver.py:150-155):
+ *   GNPDE_STAGE_RHS    out_k = k
+ *   GNPDE_STAGE_EULER  out_y = y + dt * k                                   (in place on y allowed)
+ *   GNPDE_STAGE_RK1    out_k = k1 ; out_y = y + dt*k1*(1/3)
+ *   GNPDE_STAGE_RK2    out_k = k2 ; out_y = y + dt*(k2 - k1*(1/3))
+ *   GNPDE_STAGE_RK3    out_k = k3 ; out_y = y + dt*(k1 - k2 + k3)
+ *   GNPDE_STAGE_RK4               ; out_y = y + (k1 + 3*(k2+k3) + k4)*dt*0.125   (in place on y)
+ * `u` is the stage input the operator is applied to, `y` the state at the start of the step.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  GNPDE_STAGE_RHS = 0, GNPDE_STAGE_EULER = 1,
+  GNPDE_STAGE_RK1 = 2, GNPDE_STAGE_RK2 = 3, GNPDE_STAGE_RK3 = 4, GNPDE_STAGE_RK4 = 5
+};
+
+typedef struct gnpde_epilogue {
+  const float* alpha;      /* device scalar (alpha_train)                                   */
+  const float* beta;       /* device scalar (beta_train); used iff x0 != NULL               */
+  const float* x0;         /* [n, ld] device or NULL (opt['add_source'] false)              */
+  int32_t alpha_sigmoid;   /* 1: alpha' = sigmoid(alpha)  (opt['no_alpha_sigmoid'] false)   */
+  int32_t stage;           /* GNPDE_STAGE_*                                                 */
+  float   dt;              /* step size for the fused stage algebra                         */
+  const float* y;          /* [n, ld] state at step start (stages != RHS)                   */
+  const float* k1;         /* [n, ld] (RK2..RK4)                                            */
+  const float* k2;         /* [n, ld] (RK3, RK4)                                            */
+  const float* k3;         /* [n, ld] (RK4)                                                 */
+  float* out_k;            /* [n, ld] (RHS, RK1..RK3)                                       */
+  float* out_y;            /* [n, ld] (all but RHS)                                         */
+} gnpde_epilogue_t;
+
+/* Bytes of scratch gnpde_spmm_rhs needs for the long-row partial sums (0 if no long rows). */
+size_t gnpde_spmm_workspace_bytes(const gnpde_graph_t* g, int32_t d);
+
+/* K7+K8 of SURVEY.md: ax[i] = sum_{e in row i} w[e] * u[col_e]  (torch_sparse.spmm, src/
+ * function_laplacian_diffusion.py:31-35, function_transformer_attention.py:35) followed by the
+ * epilogue above.  w is in CSR order.  u, x0, y, k*, out_* are [n, ld] row-major with ld >= d.
+ * Deterministic (no atomics). */
+int gnpde_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,
+                   const gnpde_epilogue_t* epi, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Plain aggregation out[i] = sum_e w[e] * u[col_e] without the diffusion epilogue (GAT
+ * mix_features path, src/function_GAT_attention.py:33-36). */
+int gnpde_spmm(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,
+               float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense feature mixing on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+ *   out[n, m] = x[n, d] * W[m, d]^T + b[m]          (b may be NULL)
+ * Replaces nn.Linear Q and K of SpGraphTransAttentionLayer (src/function_transformer_attention.py:
+ * 174-175; pass W = [Q.weight; K.weight] to get q||k in one pass, V is skipped because its result
+ * is unused when mix_features is false, :34-35) and torch.mm(x, W) of the GAT layer
+ * (src/function_GAT_attention.py:106; pass W^T).
+ * ---------------------------------------------------------------------------------------------- */
+int gnpde_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m,
+                 int32_t ldw, const float* b, float* out, int32_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge attention: per-edge scores -> per-node normalisation -> head-mean weights.
+ * Replaces SpGraphTransAttentionLayer.forward (src/function_transformer_attention.py:190-213),
+ * SpGraphAttentionLayer.forward (src/function_GAT_attention.py:111-114),
+ * torch_geometric.utils.softmax and utils.squareplus (src/utils.py:179-208).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  GNPDE_ATT_SCALED_DOT = 0,  /* sum_c q k / sqrt(d_k)                     (:196)               */
+  GNPDE_ATT_COSINE     = 1,  /* cosine similarity, eps 1e-5               (:198-199)           */
+  GNPDE_ATT_PEARSON    = 2,  /* mean-centred cosine                       (:201-206)           */
+  GNPDE_ATT_EXP_KERNEL = 3,  /* var^2 exp(-|q-k|^2 / (2 l^2))             (:194)               */
+  GNPDE_ATT_GAT        = 4   /* LeakyReLU(a_src.h_i + a_dst.h_j)          (GAT :111-113)       */
+};
+
+typedef struct gnpde_attention {
+  int32_t type;              /* GNPDE_ATT_*                                                    */
+  int32_t heads;             /* h                                                              */
+  int32_t att_dim;           /* A = h * d_k                                                    */
+  int32_t norm_idx;          /* opt['attention_norm_idx']: 0 normalise over row, 1 over column */
+  int32_t square_plus;       /* opt['square_plus']                                             */
+  float   leaky_slope;       /* GAT only                                                       */
+  const float* q;            /* [n, ldqk] device: row-side projection (GAT: h = x W)           */
+  const float* k;            /* [n, ldqk] device: column-side projection (GAT: same as q)      */
+  int32_t ldqk;
+  const float* gat_a;        /* [2*d_k] device (GAT only)                                      */
+  const float* output_var;   /* device scalar (exp_kernel)                                     */
+  const float* lengthscale;  /* device scalar (exp_kernel)                                     */
+  const float* edge_w_csr;   /* [e] CSR order or NULL: opt['reweight_attention'] (:208-209)    */
+} gnpde_attention_t;
+
+/* Scratch: scores [e,h] + segment statistics [n,2h] + global max + GAT node terms [n,2h]. */
+size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a);
+
+/* Outputs (all optional except at least one):
+ *   w_mean_csr [e]    mean over heads of the normalised attention, CSR order (feeds gnpde_spmm_rhs)
+ *   att_edge   [E,h]  attention in the CALLER's edge order (what the reference returns, :214)
+ *   prods_edge [E,h]  un-normalised scores in the caller's edge order (:214)                  */
+int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a,
+                         float* w_mean_csr, float* att_edge, float* prods_edge,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* w_csr[p] = mean_h src[perm[p], :]   (src [E,h] in the caller's edge order; h = 1: plain gather).
+ * Used when a block hands attention_weights / edge_weight in edge order
+ * (src/function_laplacian_diffusion.py:29-35). */
+int gnpde_edge_to_csr_mean(const gnpde_graph_t* g, const float* src_edge, int32_t h, float* w_csr,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fixed-step solver (torchdiffeq `euler` / `rk4` fixed grid, src/block_constant.py:57-62,
+ * src/block_transformer_attention.py:58-63) with the whole time loop captured in one hipGraph.
+ * ---------------------------------------------------------------------------------------------- */
+enum { GNPDE_RHS_LAPLACIAN = 0, GNPDE_RHS_TRANSFORMER = 1, GNPDE_RHS_GAT = 2 };
+enum { GNPDE_METHOD_EULER = 0, GNPDE_METHOD_RK4 = 1 };
+
+typedef struct gnpde_rhs {
+  int32_t kind;               /* GNPDE_RHS_*                                                   */
+  const gnpde_graph_t* graph;
+  int32_t d, ld;              /* state width and leading dimension                             */
+  /* epilogue scalars */
+  const float* alpha; const float* beta; const float* x0; int32_t alpha_sigmoid;
+  /* LAPLACIAN: fixed weights, CSR order */
+  const float* w_csr;
+  /* TRANSFORMER / GAT: projection W [m, d] (+ bias), m = 2A (q||k) or A (GAT), and the attention
+   * descriptor (its q/k/ldqk fields are filled by the solver from its workspace)               */
+  const float* proj_w; const float* proj_b; int32_t proj_m;
+  gnpde_attention_t att;
+} gnpde_rhs_t;
+
+typedef struct gnpde_solver gnpde_solver_t;
+
+/* Workspace (device) the solver needs: stage buffers k1..k3, two stage inputs, projections,
+ * attention scratch, spmm scratch. */
+size_t gnpde_solver_workspace_bytes(const gnpde_rhs_t* rhs, int32_t method);
+
+/* dts[n_steps] are the step sizes of the time grid (host array; the last one may be short).
+ * The descriptor, and the device arrays it points to, must stay alive as long as the solver. */
+int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs, int32_t method,
+                        const float* dts, int32_t n_steps, void* workspace, size_t workspace_bytes);
+
+/* Integrates y (in place, [n, ld]) over the whole grid.  With use_graph != 0 the launches are
+ * captured once into a hipGraph (keyed on the y pointer) and replayed. */
+int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* stream);
+
+/* One un-fused evaluation out = f(u) of the same descriptor (what ODEFunc.forward returns). */
+int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t gnpde_rhs_workspace_bytes(const gnpde_rhs_t* rhs);
+
+int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s);
+int gnpde_solver_destroy(gnpde_solver_t* s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU halo exchange helpers (row-partitioned graph, one process per GPU, RCCL between).
+ * ---------------------------------------------------------------------------------------------- */
+/* dst[i, 0:d] = src[idx[i], 0:d]  for i < count  (pack boundary rows into a send buffer)        */
+int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int32_t count, int32_t d,
+                      float* dst, int32_t ld_dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNPDE_H */

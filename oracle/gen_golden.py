@@ -1,0 +1,246 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (container-only).
+
+Imports /root/reference/src/*.py unmodified (over oracle/shims) and records, for seeded synthetic
+inputs with RANDOM (never the constant-1e-5 init) weights:
+  * one right-hand-side evaluation f(t,x) of each ODEFunc,
+  * attention [E,h] in the reference's edge order (+ raw scores `prods`),
+  * the state after a whole ODEblock.forward (euler / rk4 with a short last step / dopri5),
+  * the rw / sym normalisations, and one end-to-end GNN.forward.
+Each fixture holds its inputs (raw edge_index, x, opt as JSON, the module's full state_dict), so
+the tests on the GPU box need neither the reference nor this script.
+
+Usage (in the build container):  python oracle/gen_golden.py
+"""
+import os
+import sys
+import json
+import copy
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_env  # noqa: E402
+
+ref_env.activate()
+from test_params import OPT  # noqa: E402  (reference test/test_params.py)
+from torch_geometric.data import Data  # noqa: E402  (stand-in)
+from utils import DummyDataset, get_rw_adj, gcn_norm_fill_val  # noqa: E402
+from function_transformer_attention import ODEFuncTransformerAtt, SpGraphTransAttentionLayer  # noqa: E402
+from function_GAT_attention import ODEFuncAtt  # noqa: E402
+from function_laplacian_diffusion import LaplacianODEFunc  # noqa: E402
+from block_constant import ConstantODEblock  # noqa: E402
+from block_transformer_attention import AttODEblock  # noqa: E402
+from GNN import GNN  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+BASE = {**OPT, 'mix_features': False, 'attention_dim': 16, 'heads': 4, 'hidden_dim': 24,
+        'max_nfe': 100000, 'add_source': True, 'block': 'constant', 'function': 'transformer',
+        'method': 'rk4', 'step_size': 1.0, 'time': 2.3, 'self_loop_weight': 1, 'data_norm': 'rw',
+        'tol_scale': 1.0, 'adjoint': False, 'augment': False, 'max_iters': 100}
+
+
+def make_graph(n, avg_deg, seed, with_loops=False):
+  """Random undirected simple graph, both directions listed, edges in shuffled order."""
+  g = torch.Generator().manual_seed(seed)
+  m = n * avg_deg // 2
+  a = torch.randint(0, n, (m,), generator=g)
+  b = torch.randint(0, n, (m,), generator=g)
+  keep = a != b
+  a, b = a[keep], b[keep]
+  key = torch.unique(torch.minimum(a, b) * n + torch.maximum(a, b))
+  a, b = key // n, key % n
+  ei = torch.cat([torch.stack([a, b]), torch.stack([b, a])], dim=1)
+  if with_loops:
+    loops = torch.arange(0, n, 7)
+    ei = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+  ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+  return ei.long()
+
+
+def randomise(module, seed):
+  """Replace every parameter by seeded noise with a sensible scale."""
+  g = torch.Generator().manual_seed(seed)
+  with torch.no_grad():
+    for name, p in module.named_parameters():
+      if p.dim() >= 2:
+        p.copy_(torch.randn(p.shape, generator=g) / np.sqrt(p.shape[-1]) * 1.5)
+      elif name.endswith('alpha_train') or name.endswith('beta_train'):
+        p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+      elif 'lengthscale' in name or 'output_var' in name:
+        p.copy_(1.0 + 0.3 * torch.rand(p.shape, generator=g))
+      else:
+        p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+  # GAT layer keeps W, Wout, a as plain attributes (`nn.Parameter(...).to(device)` on cpu is still a Parameter)
+
+
+def save(name, opt, tensors, module=None):
+  rec = {'opt_json': np.frombuffer(json.dumps(opt, sort_keys=True).encode(), dtype=np.uint8)}
+  for k, v in tensors.items():
+    rec[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+  if module is not None:
+    for k, v in module.state_dict().items():
+      rec['param/' + k] = v.detach().cpu().numpy()
+  path = os.path.join(OUT, name + '.npz')
+  np.savez_compressed(path, **rec)
+  print('%-44s %6.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def data_of(ei, x, edge_attr=None):
+  d = Data(x=x, edge_index=ei, edge_attr=edge_attr)
+  return d
+
+
+def gen_norms():
+  ei = make_graph(50, 6, 11, with_loops=True)
+  g = torch.Generator().manual_seed(12)
+  w = torch.rand(ei.size(1), generator=g) + 0.1
+  rec = {'edge_index': ei, 'edge_weight': w}
+  for fill in (0.0, 0.3, 1.0, 3.2):
+    for nd in (0, 1):
+      e2, w2 = get_rw_adj(ei, edge_weight=w, norm_dim=nd, fill_value=fill, num_nodes=50, dtype=torch.float32)
+      rec['rw_ei_f%g_n%d' % (fill, nd)] = e2
+      rec['rw_w_f%g_n%d' % (fill, nd)] = w2
+    e2, w2 = gcn_norm_fill_val(ei, edge_weight=w, fill_value=fill, num_nodes=50, dtype=torch.float32)
+    rec['gcn_ei_f%g' % fill] = e2
+    rec['gcn_w_f%g' % fill] = w2
+  e2, w2 = get_rw_adj(ei, edge_weight=None, norm_dim=1, fill_value=1.0, num_nodes=50, dtype=torch.float32)
+  rec['rw_ei_unweighted'] = e2
+  rec['rw_w_unweighted'] = w2
+  save('norms', {}, rec)
+
+
+def gen_funcs():
+  n, d = 180, 24
+  ei = make_graph(n, 8, 1, with_loops=True)
+  g = torch.Generator().manual_seed(2)
+  x = torch.randn(n, d, generator=g)
+  x0 = torch.randn(n, d, generator=g)
+  variants = {
+    'sd_softmax_n0': {},
+    'sd_softmax_n1': {'attention_norm_idx': 1},
+    'sd_squareplus_n1': {'attention_norm_idx': 1, 'square_plus': True},
+    'sd_squareplus_n0': {'square_plus': True},
+    'cosine_n0': {'attention_type': 'cosine_sim'},
+    'pearson_n1': {'attention_type': 'pearson', 'attention_norm_idx': 1},
+    'expkernel_n0': {'attention_type': 'exp_kernel'},
+    'sd_rawalpha_nosrc': {'no_alpha_sigmoid': True, 'add_source': False},
+    'sd_h1_A24': {'heads': 1, 'attention_dim': 24},
+    'sd_noloops': {'self_loop_weight': 0},
+  }
+  for i, (name, over) in enumerate(variants.items()):
+    opt = {**BASE, **over}
+    func = ODEFuncTransformerAtt(d, d, opt, data_of(ei, x), torch.device('cpu'))
+    randomise(func, 100 + i)
+    func.x0 = x0
+    with torch.no_grad():
+      att, (v, prods) = func.multihead_att_layer(x, func.edge_index)
+      f = func(0.0, x)
+    save('func_transformer_' + name, opt,
+         {'edge_index': ei, 'x': x, 'x0': x0, 'func_edge_index': func.edge_index,
+          'attention': att, 'prods': prods, 'f': f}, func)
+
+  # layer with reweight_attention (as constructed inside AttODEblock, block_transformer_attention.py:29-30)
+  opt = {**BASE, 'reweight_attention': True}
+  e2, w2 = get_rw_adj(ei, edge_weight=None, norm_dim=1, fill_value=1, num_nodes=n, dtype=torch.float32)
+  layer = SpGraphTransAttentionLayer(d, d, opt, torch.device('cpu'), edge_weights=w2)
+  randomise(layer, 150)
+  with torch.no_grad():
+    att, (v, prods) = layer(x, e2)
+  save('layer_reweight', opt, {'edge_index': ei, 'x': x, 'func_edge_index': e2, 'edge_weight': w2,
+                               'attention': att, 'prods': prods}, layer)
+
+  # GAT
+  for i, (name, over) in enumerate({'n0': {}, 'n1': {'attention_norm_idx': 1},
+                                    'mix': {'mix_features': True},
+                                    'slope': {'leaky_relu_slope': 0.05, 'heads': 2}}.items()):
+    opt = {**BASE, 'function': 'GAT', **over}
+    func = ODEFuncAtt(d, d, opt, data_of(ei, x), torch.device('cpu'))
+    randomise(func, 200 + i)
+    func.x0 = x0
+    with torch.no_grad():
+      att, wx = func.multihead_att_layer(x, func.edge_index)
+      f = func(0.0, x)
+    save('func_gat_' + name, opt, {'edge_index': ei, 'x': x, 'x0': x0, 'func_edge_index': func.edge_index,
+                                   'attention': att, 'wx': wx, 'f': f}, func)
+
+  # Laplacian with each weight source (function_laplacian_diffusion.py:28-36)
+  e2, w2 = get_rw_adj(ei, edge_weight=None, norm_dim=1, fill_value=1, num_nodes=n, dtype=torch.float32)
+  att_h = torch.rand(e2.size(1), 4, generator=g)
+  for i, (name, blk) in enumerate({'constant': 'constant', 'attention': 'attention', 'hard': 'hard_attention'}.items()):
+    opt = {**BASE, 'function': 'laplacian', 'block': blk}
+    func = LaplacianODEFunc(d, d, opt, data_of(ei, x), torch.device('cpu'))
+    randomise(func, 300 + i)
+    func.edge_index, func.edge_weight = e2, w2
+    func.attention_weights = att_h if blk == 'attention' else att_h[:, 0].contiguous()
+    func.x0 = x0
+    with torch.no_grad():
+      f = func(0.0, x)
+    save('func_laplacian_' + name, opt, {'edge_index': ei, 'x': x, 'x0': x0, 'func_edge_index': e2,
+                                         'edge_weight': w2, 'attention_weights': func.attention_weights,
+                                         'f': f}, func)
+
+
+def gen_blocks():
+  n, d = 150, 24
+  ei = make_graph(n, 6, 21)
+  g = torch.Generator().manual_seed(22)
+  x = torch.randn(n, d, generator=g)
+  cases = {
+    'constant_laplacian_euler': dict(block='constant', function='laplacian', method='euler', time=4.0),
+    'constant_laplacian_gcn_rk4': dict(block='constant', function='laplacian', method='rk4', time=3.0, data_norm='gcn'),
+    'constant_transformer_rk4': dict(block='constant', function='transformer', method='rk4', time=2.3),
+    'constant_transformer_sqp_n1_rk4': dict(block='constant', function='transformer', method='rk4', time=3.2948,
+                                            square_plus=True, attention_norm_idx=1),
+    'constant_transformer_euler_h05': dict(block='constant', function='transformer', method='euler', time=2.2,
+                                           step_size=0.5),
+    'constant_gat_rk4': dict(block='constant', function='GAT', method='rk4', time=2.3),
+    'attention_laplacian_euler': dict(block='attention', function='laplacian', method='euler', time=3.0),
+    'attention_laplacian_rk4_sqp': dict(block='attention', function='laplacian', method='rk4', time=2.5,
+                                        square_plus=True, attention_norm_idx=1, reweight_attention=True),
+    'attention_laplacian_dopri5': dict(block='attention', function='laplacian', method='dopri5', time=3.0,
+                                       tol_scale=800.0),
+    'constant_transformer_dopri5': dict(block='constant', function='transformer', method='dopri5', time=2.0,
+                                        tol_scale=100.0),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, **over}
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt, 'GAT': ODEFuncAtt}[opt['function']]
+    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
+    t = torch.tensor([0, opt['time']])
+    block = bcls(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=t)
+    randomise(block, 400 + i)
+    block.eval()
+    block.set_x0(x)
+    with torch.no_grad():
+      z = block(x)
+    save('block_' + name, opt, {'edge_index': ei, 'x': x, 'z': z, 'nfe': np.int64(block.odefunc.nfe)}, block)
+
+
+def gen_gnn():
+  n, feat, classes = 120, 40, 5
+  ei = make_graph(n, 6, 31)
+  g = torch.Generator().manual_seed(32)
+  xin = torch.randn(n, feat, generator=g)
+  for i, (name, over) in enumerate({
+      'constant_transformer_rk4': dict(block='constant', function='transformer', method='rk4', time=2.3),
+      'attention_laplacian_euler': dict(block='attention', function='laplacian', method='euler', time=3.0)}.items()):
+    opt = copy.deepcopy({**BASE, **over})
+    data = data_of(ei, xin)
+    model = GNN(opt, DummyDataset(data, classes), torch.device('cpu'))
+    randomise(model, 500 + i)
+    model.eval()
+    with torch.no_grad():
+      out = model(xin)
+    save('gnn_' + name, opt, {'edge_index': ei, 'x': xin, 'out': out, 'num_classes': np.int64(classes),
+                              'nfe': np.int64(model.getNFE())}, model)
+
+
+if __name__ == '__main__':
+  os.makedirs(OUT, exist_ok=True)
+  torch.manual_seed(0)
+  gen_norms()
+  gen_funcs()
+  gen_blocks()
+  gen_gnn()

@@ -1,0 +1,124 @@
+"""HIP path vs the golden vectors recorded from the reference's own code (oracle/gen_golden.py)."""
+import pytest
+import torch
+
+import gnpde_amd as G
+from helpers import Fixture, fixtures, Data, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}
+BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
+
+
+@pytest.mark.parametrize('name', fixtures('func_transformer_') + fixtures('func_gat_'))
+def test_function_forward(dev, name):
+  fx = Fixture(name)
+  x = fx.t('x', dev)
+  cls = G.ODEFuncTransformerAtt if 'transformer' in name else G.ODEFuncAtt
+  func = cls(x.shape[1], x.shape[1], fx.opt, Data(x, fx.t('edge_index', dev)), dev).to(dev)
+  missing, unexpected = func.load_state_dict(fx.params, strict=True)
+  assert torch.equal(func.edge_index.cpu(), fx.t('func_edge_index')), 'self-loop insertion differs from the reference'
+  func.x0 = fx.t('x0', dev)
+  att, aux = func.multihead_att_layer(x, func.edge_index)
+  assert_parity(att, fx.t('attention'), what=name + ' attention')
+  if 'transformer' in name:
+    assert_parity(aux[1], fx.t('prods'), what=name + ' prods')
+  else:
+    assert_parity(aux, fx.t('wx'), what=name + ' wx')
+  with torch.no_grad():
+    f = func(0.0, x)
+  assert func.nfe == 1
+  assert_parity(f, fx.t('f'), what=name + ' f')
+
+
+def test_layer_reweight(dev):
+  fx = Fixture('layer_reweight')
+  x = fx.t('x', dev)
+  layer = G.SpGraphTransAttentionLayer(x.shape[1], x.shape[1], fx.opt, dev, edge_weights=fx.t('edge_weight', dev)).to(dev)
+  layer.load_state_dict(fx.params, strict=True)
+  att, (v, prods) = layer(x, fx.t('func_edge_index', dev))
+  assert_parity(prods, fx.t('prods'), what='prods')
+  assert_parity(att, fx.t('attention'), what='attention')
+
+
+@pytest.mark.parametrize('name', fixtures('func_laplacian_'))
+def test_laplacian_forward(dev, name):
+  fx = Fixture(name)
+  x = fx.t('x', dev)
+  func = G.LaplacianODEFunc(x.shape[1], x.shape[1], fx.opt, Data(x, fx.t('edge_index', dev)), dev).to(dev)
+  func.load_state_dict(fx.params, strict=True)
+  func.edge_index, func.edge_weight = fx.t('func_edge_index', dev), fx.t('edge_weight', dev)
+  func.attention_weights = fx.t('attention_weights', dev)
+  func.x0 = fx.t('x0', dev)
+  with torch.no_grad():
+    f = func(0.0, x)
+  assert_parity(f, fx.t('f'), what=name)
+
+
+@pytest.mark.parametrize('name', fixtures('block_'))
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_block_forward(dev, name, use_graph):
+  fx = Fixture(name)
+  if fx.opt['method'] == 'dopri5' and not use_graph:
+    pytest.skip('adaptive solver has no graph/eager split')
+  x = fx.t('x', dev)
+  data = Data(x, fx.t('edge_index', dev))
+  block = BLOCKS[fx.opt['block']](FUNCS[fx.opt['function']], [], fx.opt, data, dev,
+                                  t=torch.tensor([0, fx.opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  block.eval()
+  if not use_graph:
+    import functools
+    block.test_integrator = functools.partial(G.odeint, use_graph=False)
+  block.set_x0(x)
+  with torch.no_grad():
+    z = block(x)
+  # dopri5: accept/reject decisions amplify rounding; the solver tolerance itself is >= 1e-5 here
+  tol = 1e-5 if fx.opt['method'] != 'dopri5' else max(1e-5, 20 * fx.opt['tol_scale'] * 1e-7)
+  assert_parity(z, fx.t('z'), tol=tol, what=name)
+  assert block.odefunc.nfe == int(fx.arr['nfe']), 'nfe %d vs reference %d' % (block.odefunc.nfe, int(fx.arr['nfe']))
+  # second forward reuses the captured graph and must reproduce the result bit for bit
+  block.set_x0(x)
+  with torch.no_grad():
+    z2 = block(x)
+  if fx.opt['method'] != 'dopri5':
+    assert torch.equal(z, z2), 'replay is not deterministic'
+
+
+@pytest.mark.parametrize('name', fixtures('gnn_'))
+def test_gnn_end_to_end(dev, name):
+  """Encoder -> ODE block -> decoder as in the reference's GNN.forward (src/GNN.py:17-72, eval mode)."""
+  fx = Fixture(name)
+  xin = fx.t('x', dev)
+  p = {k: v.to(dev) for k, v in fx.params.items()}
+  h = torch.nn.functional.linear(xin, p['m1.weight'], p['m1.bias'])
+  data = Data(xin, fx.t('edge_index', dev))
+  block = BLOCKS[fx.opt['block']](FUNCS[fx.opt['function']], [], fx.opt, data, dev,
+                                  t=torch.tensor([0, fx.opt['time']])).to(dev)
+  block.load_state_dict({k[len('odeblock.'):]: v for k, v in fx.params.items() if k.startswith('odeblock.')}, strict=True)
+  block.eval()
+  block.set_x0(h)
+  with torch.no_grad():
+    z = block(h)
+  out = torch.nn.functional.linear(torch.relu(z), p['m2.weight'], p['m2.bias'])
+  assert_parity(out, fx.t('out'), what=name)
+
+
+def test_max_nfe(dev):
+  fx = Fixture('block_constant_transformer_rk4')
+  opt = dict(fx.opt, max_nfe=5)
+  x = fx.t('x', dev)
+  block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], opt, Data(x, fx.t('edge_index', dev)), dev,
+                             t=torch.tensor([0, opt['time']])).to(dev)
+  block.eval()
+  block.set_x0(x)
+  with torch.no_grad(), pytest.raises(G.MaxNFEException):
+    block(x)
+  f = block.odefunc
+  f.nfe = 0
+  with torch.no_grad():
+    for _ in range(6):
+      f(0.0, x)
+    with pytest.raises(G.MaxNFEException):
+      f(0.0, x)

@@ -1,0 +1,194 @@
+"""Host-side logic that needs no GPU: C-ABI surface, graph preparation, partitioner, normalisation
+helpers, the host integrator loops, parameter-name parity and loud failure without a HIP device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gnpde_amd as G
+from gnpde_amd import _lib
+from oracle import restate as R
+from helpers import Fixture, fixtures, Data, assert_parity, random_graph
+from test_oracle_golden import _block_rhs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, 'include', 'gnpde.h')).read()
+  declared = set(re.findall(r'\b(gnpde_[a-z_0-9]+)\s*\(', header))
+  assert len(declared) >= 20
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  for name in sorted(declared):
+    assert hasattr(lib, name), 'libgnpde_hip.so does not export %s' % name
+  assert declared == set(_lib.PROTOTYPES), 'ctypes prototypes out of sync with gnpde.h'
+  assert G.lib().gnpde_abi_version() == 1
+
+
+def test_structs_match_header_layout():
+  # pointer-sized fields and int32s only: sizes are what the C compiler produces on x86-64
+  assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8
+  assert ctypes.sizeof(_lib.EpilogueStruct) == 3 * 8 + 4 + 4 + 4 + 4 + 6 * 8
+  assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_graph_build_matches_numpy(seed):
+  n = 700
+  ei = random_graph(n, 5, seed=seed, hubs=2, hub_deg=900, isolated=4, dup=30)
+  g = G.CSRGraph(ei, n)
+  row, col = ei[0].numpy(), ei[1].numpy()
+  order = np.argsort(row, kind='stable')
+  assert np.array_equal(g.perm.numpy(), order)
+  assert np.array_equal(g.colidx.numpy(), col[order])
+  assert np.array_equal(g.t['rowidx'][:g.e].numpy(), row[order])
+  assert np.array_equal(g.rowptr.numpy(), np.concatenate([[0], np.cumsum(np.bincount(row, minlength=n))]))
+  # CSC view: positions of each column's entries, ascending
+  cpos = g.t['cscpos'][:g.e].numpy()
+  cptr = g.t['cscptr'].numpy()
+  assert np.array_equal(cptr, np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))]))
+  ccol = g.colidx.numpy()[cpos]
+  assert np.all(np.diff(ccol) >= 0)
+  for c in (0, 5, n - 5):
+    seg = cpos[cptr[c]:cptr[c + 1]]
+    assert np.all(np.diff(seg) > 0) and np.all(g.colidx.numpy()[seg] == c)
+  # long rows
+  deg = np.diff(g.rowptr.numpy())
+  long_rows = np.nonzero(deg > _lib.LONG_ROW)[0]
+  assert g.n_long_rows == len(long_rows) >= 2
+  assert np.array_equal(g.t['long_rows'][:g.n_long_rows].numpy(), long_rows)
+  b, e_ = g.t['long_chunk_begin'][:g.n_long_chunks].numpy(), g.t['long_chunk_end'][:g.n_long_chunks].numpy()
+  assert np.all(e_ - b <= _lib.LONG_ROW) and (e_ - b).sum() == deg[long_rows].sum()
+
+
+def test_graph_build_rejects_bad_index():
+  with pytest.raises(G.GnpdeError):
+    G.CSRGraph(torch.tensor([[0, 5], [1, 2]]), 3)
+
+
+def test_graph_empty_and_cache():
+  g = G.CSRGraph(torch.zeros(2, 0, dtype=torch.long), 4)
+  assert g.e == 0 and g.rowptr.tolist() == [0, 0, 0, 0, 0]
+  ei = random_graph(50, 3, seed=2)
+  a = G.graph_of(ei, 50)
+  assert G.graph_of(ei, 50) is a
+  ei[0, 0] = (ei[0, 0] + 1) % 50  # in-place edit bumps the version -> rebuilt
+  assert G.graph_of(ei, 50) is not a
+
+
+@pytest.mark.parametrize('parts', [2, 4, 8])
+def test_partition_balanced(parts):
+  ei, n = G.synthetic.make_graph('arxiv', seed=1, scale=0.05)
+  g = G.CSRGraph(ei, n)
+  part = G.partition_rows(g, parts)
+  assert part.min() == 0 and part.max() == parts - 1
+  work = (g.rowptr[1:] - g.rowptr[:-1]).long() + 1
+  load = torch.zeros(parts, dtype=torch.long).index_add_(0, part.long(), work)
+  assert load.max().item() <= 1.1 * load.float().mean().item()
+  # the partition must beat a random assignment on edge cut
+  cut = (part[ei[0]] != part[ei[1]]).float().mean().item()
+  rnd = torch.randint(0, parts, (n,), generator=torch.Generator().manual_seed(0))
+  assert cut < (rnd[ei[0]] != rnd[ei[1]]).float().mean().item()
+
+
+def test_normalisation_helpers_match_golden():
+  fx = Fixture('norms')
+  ei, w = fx.t('edge_index'), fx.t('edge_weight')
+  for fill in (0.0, 0.3, 1.0, 3.2):
+    for nd in (0, 1):
+      e2, w2 = G.get_rw_adj(ei, edge_weight=w, norm_dim=nd, fill_value=fill, num_nodes=50, dtype=torch.float32)
+      assert torch.equal(e2, fx.t('rw_ei_f%g_n%d' % (fill, nd)))
+      assert_parity(w2, fx.t('rw_w_f%g_n%d' % (fill, nd)), 2e-6, 'rw')
+    e2, w2 = G.gcn_norm_fill_val(ei, edge_weight=w, fill_value=fill, num_nodes=50, dtype=torch.float32)
+    assert torch.equal(e2, fx.t('gcn_ei_f%g' % fill))
+    assert_parity(w2, fx.t('gcn_w_f%g' % fill), 2e-6, 'gcn')
+  e2, w2 = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=50, dtype=torch.float32)
+  assert torch.equal(e2, fx.t('rw_ei_unweighted'))
+  assert_parity(w2, fx.t('rw_w_unweighted'), 2e-6, 'rw unweighted')
+
+
+@pytest.mark.parametrize('name', fixtures('block_'))
+def test_host_integrator_loops(name):
+  """The host euler / rk4 / dopri5 loops (used for foreign callables and the adaptive method)
+  reproduce the reference's block output when f is the CPU oracle."""
+  fx = Fixture(name)
+  opt = fx.opt
+  f = _block_rhs(fx)
+  calls = [0]
+
+  def counted(t, y):
+    calls[0] += 1
+    return f(t, y)
+
+  z = G.odeint(counted, fx.t('x'), torch.tensor([0, opt['time']], dtype=torch.float32), method=opt['method'],
+               options=dict(step_size=opt['step_size'], max_iters=opt['max_iters']),
+               atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
+  assert_parity(z, fx.t('z'), 5e-6, name)
+  assert calls[0] == int(fx.arr['nfe'])
+
+
+def test_time_grid():
+  t = torch.tensor([0, 18.294754260552843])
+  g = G.time_grid(t, 1.0)
+  assert torch.equal(g, R.time_grid(18.294754260552843, 1.0))
+  assert len(G.time_grid(torch.tensor([0., 2.2]), 0.5)) == 6
+
+
+@pytest.mark.parametrize('name', fixtures('block_') + fixtures('func_'))
+def test_state_dict_names_match_reference(name):
+  """Parameter names / shapes interchange with the reference's state_dicts."""
+  fx = Fixture(name)
+  x = fx.t('x')
+  data = Data(x, fx.t('edge_index'))
+  fcls = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}[fx.opt['function']]
+  if name.startswith('block_'):
+    bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}[fx.opt['block']]
+    mod = bcls(fcls, [], fx.opt, data, torch.device('cpu'), t=torch.tensor([0, fx.opt['time']]))
+  else:
+    mod = fcls(x.shape[1], x.shape[1], fx.opt, data, torch.device('cpu'))
+  ours = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+  theirs = {k: tuple(v.shape) for k, v in fx.params.items()}
+  assert ours == theirs
+  mod.load_state_dict(fx.params, strict=True)
+
+
+def test_registry():
+  assert G.set_function({'function': 'transformer'}) is G.ODEFuncTransformerAtt
+  assert G.set_function({'function': 'GAT'}) is G.ODEFuncAtt
+  assert G.set_function({'function': 'laplacian'}) is G.LaplacianODEFunc
+  assert G.set_block({'block': 'constant'}) is G.ConstantODEblock
+  assert G.set_block({'block': 'attention'}) is G.AttODEblock
+  with pytest.raises(G.FunctionNotDefined):
+    G.set_function({'function': 'nope'})
+  with pytest.raises(G.BlockNotDefined):
+    G.set_block({'block': 'nope'})
+
+
+def test_heads_must_divide_attention_dim():
+  """reference test_gnn.py: heads not dividing attention_dim raises AssertionError."""
+  fx = Fixture('func_transformer_sd_softmax_n0')
+  opt = dict(fx.opt, heads=3, attention_dim=16)
+  with pytest.raises(AssertionError):
+    G.ODEFuncTransformerAtt(24, 24, opt, Data(fx.t('x'), fx.t('edge_index')), torch.device('cpu'))
+
+
+def test_cpu_tensors_fail_loudly():
+  """There is no CPU fallback: the product path refuses host tensors instead of computing on them."""
+  fx = Fixture('func_laplacian_constant')
+  x = fx.t('x')
+  func = G.LaplacianODEFunc(x.shape[1], x.shape[1], fx.opt, Data(x, fx.t('edge_index')), torch.device('cpu'))
+  func.edge_index, func.edge_weight, func.x0 = fx.t('func_edge_index'), fx.t('edge_weight'), fx.t('x0')
+  with torch.no_grad(), pytest.raises(G.GnpdeError):
+    func(0.0, x)
+  assert not os.path.exists(os.path.join(ROOT, 'graph-neural-pde_amd', 'fallback.py'))
+
+
+def test_product_does_not_import_oracle():
+  pkg = os.path.join(ROOT, 'graph-neural-pde_amd')
+  for fn in os.listdir(pkg):
+    if fn.endswith('.py'):
+      src = open(os.path.join(pkg, fn)).read()
+      assert 'oracle' not in src.replace('oracle/', ''), '%s mentions the oracle' % fn

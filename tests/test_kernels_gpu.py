@@ -1,0 +1,161 @@
+"""Parity of every C-ABI kernel with the CPU oracle (oracle/restate.py) on seeded inputs."""
+import math
+
+import pytest
+import torch
+
+import gnpde_amd as G
+from gnpde_amd import ops, _lib
+from oracle import restate as R
+from helpers import assert_parity, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(e, seed):
+  g = torch.Generator().manual_seed(seed)
+  return torch.rand(e, generator=g) * 0.3 + 0.01
+
+
+@pytest.mark.parametrize('d', [1, 7, 24, 80, 128, 162, 256, 300, 520])
+@pytest.mark.parametrize('source', [False, True])
+def test_spmm_rhs_widths(dev, d, source):
+  n = 500
+  ei = random_graph(n, 6, seed=d, isolated=5, dup=40)
+  w = _weights(ei.size(1), d + 1)
+  g = torch.Generator().manual_seed(d + 2)
+  x = torch.randn(n, d, generator=g)
+  x0 = torch.randn(n, d, generator=g) if source else None
+  alpha, beta = torch.tensor(0.3), torch.tensor(-0.7)
+  ref = R.rhs_laplacian(x, ei, w, alpha, beta, x0, no_alpha_sigmoid=False, add_source=source)
+  graph = G.CSRGraph(ei.to(dev), n)
+  w_csr = ops.edge_to_csr_mean(graph, w.to(dev))
+  out = ops.spmm_rhs(graph, w_csr, x.to(dev), alpha.to(dev), beta.to(dev), None if x0 is None else x0.to(dev), True)
+  assert_parity(out, ref, what='spmm_rhs d=%d' % d)
+  plain = ops.spmm(graph, w_csr, x.to(dev))
+  assert_parity(plain, R.spmm(ei, w, n, x), what='spmm d=%d' % d)
+
+
+@pytest.mark.parametrize('d', [32, 128, 162])
+def test_spmm_rhs_hub_rows(dev, d):
+  """Rows longer than GNPDE_LONG_ROW go through the chunk + reduce path."""
+  n = 3000
+  ei = random_graph(n, 4, seed=7, hubs=3, hub_deg=2500)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.n_long_rows >= 3 and graph.n_long_chunks >= 3 * 5
+  w = _weights(ei.size(1), 3)
+  g = torch.Generator().manual_seed(5)
+  x, x0 = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  alpha, beta = torch.tensor(-0.2), torch.tensor(0.4)
+  ref = R.rhs_laplacian(x, ei, w, alpha, beta, x0, no_alpha_sigmoid=True, add_source=True)
+  out = ops.spmm_rhs(graph, ops.edge_to_csr_mean(graph, w.to(dev)), x.to(dev), alpha.to(dev), beta.to(dev), x0.to(dev), False)
+  assert_parity(out, ref, what='hub rows d=%d' % d)
+
+
+def test_spmm_unaligned_view(dev):
+  """A leading dimension that breaks 16-byte alignment falls back to narrower loads."""
+  n, d = 300, 30
+  ei = random_graph(n, 5, seed=11)
+  w = _weights(ei.size(1), 1)
+  big = torch.randn(n, d + 1, generator=torch.Generator().manual_seed(2))
+  x = big[:, :d]
+  ref = R.spmm(ei, w, n, x.contiguous())
+  graph = G.CSRGraph(ei.to(dev), n)
+  xd = big.to(dev)[:, :d]
+  out = torch.empty(n, d + 1, device=dev)[:, :d]
+  L = _lib.lib()
+  _lib.check(L.gnpde_spmm(graph.ref(), _lib.ptr(ops.edge_to_csr_mean(graph, w.to(dev))), _lib.ptr(xd), d, d + 1,
+                          _lib.ptr(out), None, 0, _lib.stream_of(xd)))
+  # both operands share ld = d+1
+  assert_parity(out, ref, what='unaligned ld')
+
+
+@pytest.mark.parametrize('n,d,m', [(1, 8, 16), (37, 24, 32), (1000, 80, 256), (513, 128, 32), (300, 162, 64),
+                                   (129, 30, 20), (64, 5, 3), (2050, 128, 272)])
+def test_linear(dev, n, d, m):
+  g = torch.Generator().manual_seed(n + d + m)
+  x = torch.randn(n, d, generator=g)
+  W = torch.randn(m, d, generator=g) / math.sqrt(d)
+  b = torch.randn(m, generator=g)
+  ref = torch.nn.functional.linear(x.double(), W.double(), b.double()).float()
+  out = ops.linear(x.to(dev), W.to(dev), b.to(dev))
+  assert_parity(out, ref, what='linear')
+  out2 = ops.linear(x.to(dev), W.to(dev), None)
+  assert_parity(out2, torch.nn.functional.linear(x.double(), W.double()).float(), what='linear no bias')
+
+
+ATT_CASES = [
+  ('scaled_dot', 4, 16, 0, False), ('scaled_dot', 4, 16, 1, False), ('scaled_dot', 8, 128, 1, True),
+  ('scaled_dot', 8, 128, 0, True), ('scaled_dot', 3, 21, 0, False), ('scaled_dot', 1, 24, 1, False),
+  ('cosine_sim', 4, 16, 0, False), ('cosine_sim', 2, 10, 1, False), ('pearson', 4, 32, 1, False),
+  ('pearson', 4, 16, 0, True), ('exp_kernel', 4, 16, 0, False), ('exp_kernel', 2, 12, 1, False),
+]
+
+
+@pytest.mark.parametrize('att_type,h,A,norm_idx,sqp', ATT_CASES)
+@pytest.mark.parametrize('reweight', [False, True])
+def test_edge_attention(dev, att_type, h, A, norm_idx, sqp, reweight):
+  n, d = 400, 20
+  ei = random_graph(n, 5, seed=h + A, hubs=1, hub_deg=700, isolated=3, dup=25)
+  g = torch.Generator().manual_seed(A)
+  x = torch.randn(n, d, generator=g)
+  Wq, Wk = torch.randn(A, d, generator=g) / math.sqrt(d), torch.randn(A, d, generator=g) / math.sqrt(d)
+  bq, bk = torch.randn(A, generator=g) * 0.1, torch.randn(A, generator=g) * 0.1
+  ew = torch.rand(ei.size(1), generator=g) + 0.5 if reweight else None
+  ov, ls = torch.tensor([1.2]), torch.tensor([0.8])
+  att_ref, prods_ref = R.transformer_attention(x, ei, Wq, bq, Wk, bk, h, attention_type=att_type, norm_idx=norm_idx,
+                                               square_plus=sqp, edge_weights=ew, reweight=reweight, output_var=ov,
+                                               lengthscale=ls)
+  graph = G.CSRGraph(ei.to(dev), n)
+  qk = ops.linear(x.to(dev), torch.cat([Wq, Wk]).to(dev), torch.cat([bq, bk]).to(dev))
+  ew_csr = ops.edge_to_csr_mean(graph, ew.to(dev)) if reweight else None
+  st = ops.attention_struct(_lib.ATT_TYPES[att_type], h, A, norm_idx, sqp, q=qk, k=qk[:, A:], ldqk=2 * A,
+                            output_var=ov.to(dev), lengthscale=ls.to(dev), edge_w_csr=ew_csr)
+  w, att, prods = ops.edge_attention(graph, st, True, True, True, like=qk)
+  assert_parity(prods, prods_ref, what='prods')
+  assert_parity(att, att_ref, what='attention')
+  w_ref = att_ref.mean(dim=1)
+  assert_parity(w[:graph.e], w_ref[graph.perm_long.cpu()], what='head-mean weights (CSR order)')
+
+
+@pytest.mark.parametrize('h,A,norm_idx,slope', [(4, 16, 0, 0.2), (2, 16, 1, 0.05), (3, 9, 0, 0.2)])
+def test_gat_attention(dev, h, A, norm_idx, slope):
+  n, d = 350, 24
+  ei = random_graph(n, 6, seed=A + h, hubs=1, hub_deg=600)
+  g = torch.Generator().manual_seed(9)
+  x = torch.randn(n, d, generator=g)
+  W = torch.randn(d, A, generator=g) / math.sqrt(d)
+  a = torch.randn(2 * (A // h), 1, 1, generator=g)
+  att_ref, wx_ref = R.gat_attention(x, ei, W, a, h, slope, norm_idx)
+  graph = G.CSRGraph(ei.to(dev), n)
+  wx = ops.linear(x.to(dev), W.t().contiguous().to(dev))
+  assert_parity(wx, wx_ref, what='wx')
+  st = ops.attention_struct(_lib.ATT_GAT, h, A, norm_idx, False, q=wx, k=wx, ldqk=A, leaky_slope=slope,
+                            gat_a=a.reshape(-1).to(dev))
+  _, att, _ = ops.edge_attention(graph, st, False, True, False, like=wx)
+  assert_parity(att, att_ref, what='GAT attention')
+
+
+def test_attention_rows_sum_to_one(dev):
+  """Reference test_transformer_attention.py::test_function property at a larger size."""
+  n, A, h = 5000, 16, 4
+  ei = random_graph(n, 8, seed=3, hubs=2, hub_deg=1500)
+  qk = torch.randn(n, 2 * A, device=dev)
+  graph = G.CSRGraph(ei.to(dev), n)
+  for norm_idx in (0, 1):
+    st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, norm_idx, False, q=qk, k=qk[:, A:], ldqk=2 * A)
+    _, att, _ = ops.edge_attention(graph, st, False, True, False, like=qk)
+    sums = torch.zeros(n, h, device=dev).index_add_(0, ei[norm_idx].to(dev), att)
+    assert torch.all(att > 0) and torch.all(att <= 1 + 1e-6)
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-4)
+
+
+def test_symmetric_attention_known_answer(dev):
+  """Reference test_symmetric_attention: constant-1e-5 weights, x = 1 on the complete 3-graph -> exactly 0.5."""
+  from helpers import Data
+  opt = dict(heads=2, attention_dim=32, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False,
+             reweight_attention=False, beltrami=False, leaky_relu_slope=0.2)
+  layer = G.SpGraphTransAttentionLayer(2, 2, opt, dev).to(dev)
+  edge = torch.tensor([[0, 0, 1, 1, 2, 2], [1, 2, 0, 2, 0, 1]], device=dev)
+  att, _ = layer(torch.ones(3, 2, device=dev), edge)
+  assert torch.all(torch.eq(att, 0.5 * torch.ones(6, 2, device=dev)))

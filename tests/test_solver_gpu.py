@@ -1,0 +1,152 @@
+"""Native fixed-step solver at the sizes BASELINE.json names: parity with the CPU oracle where the oracle
+finishes in seconds, size-independent properties at full size."""
+import pytest
+import torch
+
+import gnpde_amd as G
+from oracle import restate as R
+from helpers import Data, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False,
+            reweight_attention=False, beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9,
+            add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=128, augment=False, adjoint=False,
+            tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
+            function='transformer', time=3.0)
+
+
+def _block(opt, ei, n, x, dev, seed=0):
+  fcls = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc, 'GAT': G.ODEFuncAtt}[opt['function']]
+  bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}[opt['block']]
+  block = bcls(fcls, [], opt, Data(x, ei), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(seed)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if p.dim() >= 2 and 'multihead_att_layer' in name:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+    for f in (block.odefunc, block.reg_odefunc.odefunc):
+      f.alpha_train.fill_(0.2)
+      f.beta_train.fill_(0.1)
+  block.eval()
+  return block
+
+
+def _oracle_rhs(block, x0):
+  f = block.odefunc
+  cpu = lambda t: t.detach().cpu()
+  lay = f.multihead_att_layer
+  edge = cpu(f.edge_index)
+  o = block.opt
+  return lambda t, y: R.rhs_transformer(y, edge, cpu(lay.Q.weight), cpu(lay.Q.bias), cpu(lay.K.weight), cpu(lay.K.bias),
+                                        lay.h, cpu(f.alpha_train), cpu(f.beta_train), x0, o['no_alpha_sigmoid'],
+                                        o['add_source'], attention_type=o['attention_type'],
+                                        norm_idx=o['attention_norm_idx'], square_plus=o['square_plus'])
+
+
+def test_cora_config_c2_as_run(dev):
+  """BASELINE configs[1] as run_GNN.py runs it: Cora best_params (squareplus, attention_norm_idx=1,
+  A=128, 8 heads, d=80), rk4, T=18.2948 -> 19 steps with a short last step, 76 evaluations."""
+  ei, n = G.synthetic.make_graph('cora')
+  x = torch.randn(n, 80, generator=torch.Generator().manual_seed(1)) * 0.5
+  opt = dict(BASE, heads=8, attention_dim=128, hidden_dim=80, square_plus=True, attention_norm_idx=1,
+             time=18.294754260552843)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  block.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = block(x.to(dev))
+  assert block.odefunc.nfe == 76
+  ref = R.odeint_fixed(_oracle_rhs(block, x), x, opt['time'], 1.0, 'rk4')
+  assert_parity(z, ref, what='C2 Cora squareplus/norm_idx=1 rk4 T=18.29')
+
+
+def test_cora_config_c1_laplacian_euler(dev):
+  """BASELINE configs[0]: Cora GRAND-l, euler step 1, T=4."""
+  ei, n = G.synthetic.make_graph('cora')
+  x = torch.randn(n, 80, generator=torch.Generator().manual_seed(2))
+  opt = dict(BASE, function='laplacian', method='euler', hidden_dim=80, time=4.0)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  block.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = block(x.to(dev))
+  f = block.odefunc
+  cpu = lambda t: t.detach().cpu()
+  rhs = lambda t, y: R.rhs_laplacian(y, cpu(f.edge_index), cpu(f.edge_weight), cpu(f.alpha_train), cpu(f.beta_train), x,
+                                     False, True)
+  assert_parity(z, R.odeint_fixed(rhs, x, 4.0, 1.0, 'euler'), what='C1')
+  assert f.nfe == 4
+
+
+def test_arxiv_full_size_one_eval_and_short_solve(dev):
+  """BASELINE configs[2] at FULL size: one evaluation of f and a 2-step rk4 solve against the oracle
+  (the oracle needs ~1 s per evaluation here), on the hub-heavy synthetic graph."""
+  ei, n = G.synthetic.make_graph('arxiv')
+  x = torch.randn(n, 128, generator=torch.Generator().manual_seed(3))
+  opt = dict(BASE, time=2.0)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  f = block.odefunc
+  assert f._graph(x.to(dev)).n_long_rows > 0, 'the synthetic arxiv graph should contain hub rows'
+  block.set_x0(x.to(dev))
+  rhs = _oracle_rhs(block, x)
+  with torch.no_grad():
+    got = f(0.0, x.to(dev))
+    assert_parity(got, rhs(0.0, x), what='C3 one evaluation')
+    z = block(x.to(dev))
+  assert_parity(z, R.odeint_fixed(rhs, x, 2.0, 1.0, 'rk4'), what='C3 2-step rk4 solve')
+
+
+def test_full_size_properties(dev):
+  """Size-independent checks at full ogbn-arxiv size: constants are a fixed point of row-stochastic
+  attention diffusion (f(c 1) = 0 without source), linearity of the Laplacian RHS in x, bitwise
+  reproducibility, graph replay == eager launch."""
+  ei, n = G.synthetic.make_graph('arxiv')
+  eid = ei.to(dev)
+  x = torch.randn(n, 128, device=dev)
+  opt = dict(BASE, add_source=False, time=3.0)
+  block = _block(opt, eid, n, x, dev)
+  f = block.odefunc
+  with torch.no_grad():
+    const = torch.full((n, 128), 0.7, device=dev)
+    out = f(0.0, const)
+    assert out.abs().max().item() < 5e-6, 'constants must be (numerically) stationary, got %g' % out.abs().max().item()
+    a, b = f(0.0, x), f(0.0, x)
+    assert torch.equal(a, b), 'evaluation is not deterministic'
+    z_graph = block(x)
+    import functools
+    block.test_integrator = functools.partial(G.odeint, use_graph=False)
+    z_eager = block(x)
+    assert torch.equal(z_graph, z_eager), 'hipGraph replay differs from eager launches'
+  lopt = dict(BASE, function='laplacian', add_source=False)
+  lb = _block(lopt, eid, n, x, dev)
+  lf = lb.odefunc
+  with torch.no_grad():
+    y = torch.randn_like(x)
+    lhs = lf(0.0, 2.0 * x + y)
+    rhs = 2.0 * lf(0.0, x) + lf(0.0, y)
+    assert_parity(lhs, rhs, tol=2e-5, what='linearity')
+    # column-stochastic rw weights: the sum over nodes of A x equals the sum of x (mass conservation)
+    ax = lf.sparse_multiply(x)
+    assert torch.allclose(ax.double().sum(0), x.double().sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('function,block', [('GAT', 'constant'), ('laplacian', 'attention')])
+def test_other_functions_medium(dev, function, block):
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.1)
+  x = torch.randn(n, 64, generator=torch.Generator().manual_seed(5))
+  opt = dict(BASE, function=function, block=block, hidden_dim=64, time=2.5, attention_dim=32, heads=2)
+  blk = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  blk.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = blk(x.to(dev))
+  f = blk.odefunc
+  cpu = lambda t: t.detach().cpu()
+  if function == 'GAT':
+    lay = f.multihead_att_layer
+    rhs = lambda t, y: R.rhs_gat(y, cpu(f.edge_index), cpu(lay.W), cpu(lay.a), 2, cpu(f.alpha_train), cpu(f.beta_train), x,
+                                 False, True, 0.2, 0)
+  else:
+    lay = blk.multihead_att_layer
+    att, _ = R.transformer_attention(x, cpu(f.edge_index), cpu(lay.Q.weight), cpu(lay.Q.bias), cpu(lay.K.weight),
+                                     cpu(lay.K.bias), 2, edge_weights=cpu(f.edge_weight), reweight=False)
+    rhs = lambda t, y: R.rhs_laplacian(y, cpu(f.edge_index), att, cpu(f.alpha_train), cpu(f.beta_train), x, False, True)
+  assert_parity(z, R.odeint_fixed(rhs, x, 2.5, 1.0, 'rk4'), what='%s/%s' % (function, block))
