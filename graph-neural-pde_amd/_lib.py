@@ -30,7 +30,9 @@ class GraphStruct(ctypes.Structure):
               ('cscptr', c_vp), ('cscpos', c_vp),
               ('n_long_rows', ctypes.c_int32), ('n_long_chunks', ctypes.c_int32),
               ('long_rows', c_vp), ('long_chunk_ptr', c_vp), ('long_chunk_row', c_vp),
-              ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp)]
+              ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp),
+              ('n_long_cols', ctypes.c_int32), ('n_bin16', ctypes.c_int32), ('n_bin64', ctypes.c_int32),
+              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('reserved_', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp)]
 
 
 class EpilogueStruct(ctypes.Structure):
@@ -59,8 +61,9 @@ class RhsStruct(ctypes.Structure):
 PROTOTYPES = {
   'gnpde_abi_version': (ctypes.c_int, []),
   'gnpde_last_error': (ctypes.c_char_p, []),
-  'gnpde_graph_count_long': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, c_int_p, c_int_p]),
-  'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 11),
+  'gnpde_tune': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_graph_count_long': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, c_int_p, c_int_p, c_int_p]),
+  'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 14),
   'gnpde_partition_rows': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_uint64, c_vp]),
   'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),

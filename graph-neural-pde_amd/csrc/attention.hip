@@ -10,9 +10,15 @@
 // statistics are wave reductions over the CSR (norm_idx=0) or CSC (norm_idx=1) segment -- no atomics
 // except one order-independent max per block for squareplus' global maximum.
 //
-// Pass 1  scores[p,h]   (CSR order)            edge-parallel, balanced regardless of degree skew
-// Pass 2  seg stats     m[seg,h], den[seg,h]   one wavefront per segment
-// Pass 3  normalise     w[p] = mean_h att      edge-parallel; optional scatter to edge order
+// General path (any attention_norm_idx, squareplus, [E,h] outputs):
+//   Pass 1  scores[p,h]   (CSR order)            edge-parallel, balanced regardless of degree skew
+//   Pass 2  seg stats     m[seg,h], den[seg,h]   one wavefront per segment, one block per long segment
+//   Pass 3  normalise     w[p] = mean_h att      edge-parallel; optional scatter to edge order
+// Fused path (the solver's hot case: softmax over the ROW, only the head-mean weights wanted):
+//   one launch; a 16-lane group (rows with <= 16 entries, 4 rows per wavefront) or a whole wavefront
+//   (<= GNPDE_LONG_ROW entries) owns a row, lanes own edges, the h scores of up to 8 passes stay in
+//   registers, max / sum are DPP-style xor reductions inside the group, w is written once.  Long
+//   rows run the general passes restricted to their chunks.
 #include <cmath>
 #include "common.h"
 
@@ -42,6 +48,13 @@ struct AttArgs {
   float* w_mean;      // [e] or null
   float* att_edge;    // [E,h] or null
   float* prods_edge;  // [E,h] or null
+  // when non-null the edge-parallel passes work on these CSR ranges only (one block per chunk)
+  const int* __restrict__ chunk_begin;
+  const int* __restrict__ chunk_end;
+  // long segments handled by seg_stats_long_kernel (segment ids); others by the wave-per-segment kernel
+  const int* __restrict__ long_segs;
+  const int* __restrict__ rowptr;
+  const int* __restrict__ bin_rows;
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -81,63 +94,77 @@ __global__ __launch_bounds__(kBlock) void gat_terms_kernel(const float* __restri
   terms[static_cast<size_t>(i) * 2 * h + h + head] = t;
 }
 
-// ---- pass 1: one lane per (CSR position, head)
+// score of one (edge, head): q-slice of the row node against k-slice of the column node
+template <int TYPE, bool VEC4>
+__device__ __forceinline__ float edge_score(const AttArgs& a, int p, int r, int c, int head) {
+  float s;
+  if constexpr (TYPE == GNPDE_ATT_GAT) {
+    const float v = a.gat_terms[static_cast<size_t>(r) * 2 * a.h + head] +
+                    a.gat_terms[static_cast<size_t>(c) * 2 * a.h + a.h + head];
+    s = v > 0.f ? v : v * a.leaky_slope;
+  } else {
+    const float* qp = a.q + static_cast<size_t>(r) * a.ldqk + head * a.dk;
+    const float* kp = a.k + static_cast<size_t>(c) * a.ldqk + head * a.dk;
+    float mq = 0.f, mk = 0.f;
+    if constexpr (TYPE == GNPDE_ATT_PEARSON) {
+      for (int j = 0; j < a.dk; ++j) { mq += qp[j]; mk += kp[j]; }
+      mq = mq / static_cast<float>(a.dk);
+      mk = mk / static_cast<float>(a.dk);
+    }
+    float dot = 0.f, nq = 0.f, nk = 0.f;
+    auto term = [&](float qv, float kv) {
+      if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
+        dot = fmaf(qv, kv, dot);
+      } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
+        const float df = qv - kv;
+        dot = fmaf(df, df, dot);
+      } else {
+        qv -= mq; kv -= mk;
+        dot = fmaf(qv, kv, dot);
+        nq = fmaf(qv, qv, nq);
+        nk = fmaf(kv, kv, nk);
+      }
+    };
+    if constexpr (VEC4) {
+      for (int j = 0; j < a.dk; j += 4) {
+        const float4 qv = *reinterpret_cast<const float4*>(qp + j);
+        const float4 kv = *reinterpret_cast<const float4*>(kp + j);
+        term(qv.x, kv.x); term(qv.y, kv.y); term(qv.z, kv.z); term(qv.w, kv.w);
+      }
+    } else {
+      for (int j = 0; j < a.dk; ++j) term(qp[j], kp[j]);
+    }
+    if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
+      s = dot / a.inv_sqrt_dk_den;
+    } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
+      const float ov = *a.output_var, ls = *a.lengthscale;
+      s = (ov * ov) * expf(-(dot / (2.0f * (ls * ls))));
+    } else {  // cosine / pearson: x1.x2 / sqrt(max(|x1|^2 |x2|^2, eps^2)), eps = 1e-5
+      s = dot / sqrtf(fmaxf(nq * nk, 1e-10f));
+    }
+  }
+  if (a.edge_w != nullptr) s = s * a.edge_w[p];
+  return s;
+}
+
+// ---- pass 1: one lane per (CSR position, head); over all edges (grid-stride) or one block per chunk
 template <int TYPE, bool VEC4>
 __global__ __launch_bounds__(kBlock) void scores_kernel(const AttArgs a) {
-  const long long total = static_cast<long long>(a.e) * a.h;
-  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  long long first, total, stride;
+  if (a.chunk_begin != nullptr) {
+    first = static_cast<long long>(a.chunk_begin[blockIdx.x]) * a.h + threadIdx.x;
+    total = static_cast<long long>(a.chunk_end[blockIdx.x]) * a.h;
+    stride = blockDim.x;
+  } else {
+    first = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    total = static_cast<long long>(a.e) * a.h;
+    stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  }
   float lmax = -INFINITY;
-  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+  for (long long idx = first; idx < total; idx += stride) {
     const int p = static_cast<int>(idx / a.h);
     const int head = static_cast<int>(idx - static_cast<long long>(p) * a.h);
-    const int r = a.rowidx[p], c = a.colidx[p];
-    float s;
-    if constexpr (TYPE == GNPDE_ATT_GAT) {
-      const float v = a.gat_terms[static_cast<size_t>(r) * 2 * a.h + head] +
-                      a.gat_terms[static_cast<size_t>(c) * 2 * a.h + a.h + head];
-      s = v > 0.f ? v : v * a.leaky_slope;
-    } else {
-      const float* qp = a.q + static_cast<size_t>(r) * a.ldqk + head * a.dk;
-      const float* kp = a.k + static_cast<size_t>(c) * a.ldqk + head * a.dk;
-      float mq = 0.f, mk = 0.f;
-      if constexpr (TYPE == GNPDE_ATT_PEARSON) {
-        for (int j = 0; j < a.dk; ++j) { mq += qp[j]; mk += kp[j]; }
-        mq = mq / static_cast<float>(a.dk);
-        mk = mk / static_cast<float>(a.dk);
-      }
-      float dot = 0.f, nq = 0.f, nk = 0.f;
-      auto term = [&](float qv, float kv) {
-        if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
-          dot = fmaf(qv, kv, dot);
-        } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
-          const float df = qv - kv;
-          dot = fmaf(df, df, dot);
-        } else {
-          qv -= mq; kv -= mk;
-          dot = fmaf(qv, kv, dot);
-          nq = fmaf(qv, qv, nq);
-          nk = fmaf(kv, kv, nk);
-        }
-      };
-      if constexpr (VEC4) {
-        for (int j = 0; j < a.dk; j += 4) {
-          const float4 qv = *reinterpret_cast<const float4*>(qp + j);
-          const float4 kv = *reinterpret_cast<const float4*>(kp + j);
-          term(qv.x, kv.x); term(qv.y, kv.y); term(qv.z, kv.z); term(qv.w, kv.w);
-        }
-      } else {
-        for (int j = 0; j < a.dk; ++j) term(qp[j], kp[j]);
-      }
-      if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
-        s = dot / a.inv_sqrt_dk_den;
-      } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
-        const float ov = *a.output_var, ls = *a.lengthscale;
-        s = (ov * ov) * expf(-(dot / (2.0f * (ls * ls))));
-      } else {  // cosine / pearson: x1.x2 / sqrt(max(|x1|^2 |x2|^2, eps^2)), eps = 1e-5
-        s = dot / sqrtf(fmaxf(nq * nk, 1e-10f));
-      }
-    }
-    if (a.edge_w != nullptr) s = s * a.edge_w[p];
+    const float s = edge_score<TYPE, VEC4>(a, p, a.rowidx[p], a.colidx[p], head);
     a.scores[idx] = s;
     lmax = fmaxf(lmax, s);
   }
@@ -159,23 +186,25 @@ __device__ __forceinline__ float squareplus_num(float s, float gmax) {
   return (z + sqrtf(z * z + 4.0f)) / 2.0f;
 }
 
-// ---- pass 2: one wavefront per segment, heads in an outer loop
+// ---- pass 2: one wavefront per segment (heads in an outer loop); segments longer than GNPDE_LONG_ROW
+// are left to seg_stats_long_kernel so that a hub does not serialise on one wave
+__device__ __forceinline__ float stat_term(const AttArgs& a, int t, int head, float gmax, float m) {
+  const int p = a.segpos ? a.segpos[t] : t;
+  const float s = a.scores[static_cast<size_t>(p) * a.h + head];
+  if (a.square_plus) return squareplus_num(s, gmax);
+  return expf(s - m);
+}
+
 __global__ __launch_bounds__(kBlock) void seg_stats_kernel(const AttArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
   if (seg >= a.n) return;
   const int b = a.segptr[seg], e = a.segptr[seg + 1];
+  if (e - b > GNPDE_LONG_ROW && a.long_segs != nullptr) return;
   const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
   for (int head = 0; head < a.h; ++head) {
-    float m = 0.f, den;
-    if (a.square_plus) {
-      float sum = 0.f;
-      for (int t = b + lane; t < e; t += kWave) {
-        const int p = a.segpos ? a.segpos[t] : t;
-        sum += squareplus_num(a.scores[static_cast<size_t>(p) * a.h + head], gmax);
-      }
-      den = wave_sum(sum) + 1e-16f;
-    } else {
+    float m = 0.f;
+    if (!a.square_plus) {
       float mx = -INFINITY;
       for (int t = b + lane; t < e; t += kWave) {
         const int p = a.segpos ? a.segpos[t] : t;
@@ -183,13 +212,10 @@ __global__ __launch_bounds__(kBlock) void seg_stats_kernel(const AttArgs a) {
       }
       mx = wave_max(mx);
       m = (e > b) ? mx : 0.f;
-      float sum = 0.f;
-      for (int t = b + lane; t < e; t += kWave) {
-        const int p = a.segpos ? a.segpos[t] : t;
-        sum += expf(a.scores[static_cast<size_t>(p) * a.h + head] - m);
-      }
-      den = wave_sum(sum) + 1e-16f;
     }
+    float sum = 0.f;
+    for (int t = b + lane; t < e; t += kWave) sum += stat_term(a, t, head, gmax, m);
+    const float den = wave_sum(sum) + 1e-16f;
     if (lane == 0) {
       a.seg_m[static_cast<size_t>(seg) * a.h + head] = m;
       a.seg_den[static_cast<size_t>(seg) * a.h + head] = den;
@@ -197,11 +223,80 @@ __global__ __launch_bounds__(kBlock) void seg_stats_kernel(const AttArgs a) {
   }
 }
 
+// Long segments: blockIdx.x = long segment, blockIdx.y = 512-entry chunk of it.  Every chunk leaves an
+// online-softmax partial (m_c, l_c) per head (squareplus: just the partial sum); seg_stats_long_combine
+// folds them:  m = max_c m_c,  den = sum_c l_c exp(m_c - m) + 1e-16.
+__global__ __launch_bounds__(kBlock) void seg_stats_long_partial_kernel(const AttArgs a, float* __restrict__ part, int max_chunks) {
+  __shared__ float red[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int seg = a.long_segs[blockIdx.x];
+  const int b = a.segptr[seg] + static_cast<int>(blockIdx.y) * GNPDE_LONG_ROW;
+  const int e = min(a.segptr[seg + 1], b + GNPDE_LONG_ROW);
+  if (b >= a.segptr[seg + 1]) return;
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  float* out = part + (static_cast<size_t>(blockIdx.x) * max_chunks + blockIdx.y) * 2 * a.h;
+  for (int head = 0; head < a.h; ++head) {
+    float m = 0.f;
+    if (!a.square_plus) {
+      float mx = -INFINITY;
+      for (int t = b + threadIdx.x; t < e; t += kBlock) {
+        const int p = a.segpos ? a.segpos[t] : t;
+        mx = fmaxf(mx, a.scores[static_cast<size_t>(p) * a.h + head]);
+      }
+      mx = wave_max(mx);
+      if (lane == 0) red[wave] = mx;
+      __syncthreads();
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      __syncthreads();
+    }
+    float sum = 0.f;
+    for (int t = b + threadIdx.x; t < e; t += kBlock) sum += stat_term(a, t, head, gmax, m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      out[head] = m;
+      out[a.h + head] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kWave) void seg_stats_long_combine_kernel(const AttArgs a, const float* __restrict__ part,
+                                                                      int max_chunks) {
+  const int seg = a.long_segs[blockIdx.x];
+  const int len = a.segptr[seg + 1] - a.segptr[seg];
+  const int nch = (len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+  const float* base = part + static_cast<size_t>(blockIdx.x) * max_chunks * 2 * a.h;
+  for (int head = threadIdx.x; head < a.h; head += blockDim.x) {
+    float m = -INFINITY;
+    if (a.square_plus) m = 0.f;
+    else
+      for (int c = 0; c < nch; ++c) m = fmaxf(m, base[static_cast<size_t>(c) * 2 * a.h + head]);
+    float l = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const float lc = base[static_cast<size_t>(c) * 2 * a.h + a.h + head];
+      l += a.square_plus ? lc : lc * expf(base[static_cast<size_t>(c) * 2 * a.h + head] - m);
+    }
+    a.seg_m[static_cast<size_t>(seg) * a.h + head] = m;
+    a.seg_den[static_cast<size_t>(seg) * a.h + head] = l + 1e-16f;
+  }
+}
+
 // ---- pass 3: one lane per CSR position, heads serial (same order as attention.mean(dim=1))
 __global__ __launch_bounds__(kBlock) void normalise_kernel(const AttArgs a) {
-  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  long long first, last, stride;
+  if (a.chunk_begin != nullptr) {
+    first = static_cast<long long>(a.chunk_begin[blockIdx.x]) + threadIdx.x;
+    last = a.chunk_end[blockIdx.x];
+    stride = blockDim.x;
+  } else {
+    first = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    last = a.e;
+    stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  }
   const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
-  for (long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.e; p += stride) {
+  for (long long p = first; p < last; p += stride) {
     const int seg = a.norm_idx == 0 ? a.rowidx[p] : a.colidx[p];
     const long long dst = (a.att_edge || a.prods_edge) ? static_cast<long long>(a.perm[p]) * a.h : 0;
     float acc = 0.f;
@@ -216,6 +311,64 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(const AttArgs a) {
       if (a.prods_edge) a.prods_edge[dst + head] = s;
     }
     if (a.w_mean) a.w_mean[p] = acc / static_cast<float>(a.h);
+  }
+}
+
+// ---- fused path: softmax over the row, head-mean weights only.
+// GL lanes own one row; inside a group lane = (edge slot, head) with the head fastest, so the H lanes
+// of an edge read one contiguous A-float row of k (one 16-byte load each when d_k = 4) and a pass covers
+// GE = GL / H edges.  Scores of up to P passes stay in registers (one float per pass per lane).
+template <int TYPE, int H, int GL, int P, bool VEC4>
+__global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, int first_row, int n_rows) {
+  constexpr int RPW = kWave / GL;  // rows per wavefront
+  constexpr int GE = GL / H;       // edges per pass
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gi = lane % GL;
+  const int slot = gi / H, head = gi % H;
+  const long long ridx = (static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL;
+  const bool live = ridx < n_rows;
+  int row = live ? a.bin_rows[first_row + ridx] : 0;
+  if constexpr (GL == kWave) row = __builtin_amdgcn_readfirstlane(row);
+  const int e0 = live ? a.rowptr[row] : 0;
+  const int e1 = live ? a.rowptr[row + 1] : 0;
+  int npass = P;  // passes that hold any edge (wave-uniform when a wavefront owns one row)
+  if constexpr (GL == kWave) npass = (e1 - e0 + GE - 1) / GE;
+
+  float s[P];
+  float m = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    s[p] = -INFINITY;
+    if (p < npass) {
+      const int e = e0 + p * GE + slot;
+      if (e < e1) {
+        s[p] = edge_score<TYPE, VEC4>(a, e, row, a.colidx[e], head);
+        m = fmaxf(m, s[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = H; off < GL; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  float l = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (p < npass) {
+      s[p] = expf(s[p] - m);  // empty slots: exp(-inf) = 0
+      l += s[p];
+    }
+  }
+#pragma unroll
+  for (int off = H; off < GL; off <<= 1) l += __shfl_xor(l, off, kWave);
+  const float den = l + 1e-16f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (p < npass) {
+      float v = s[p] / den;
+#pragma unroll
+      for (int off = 1; off < H; off <<= 1) v += __shfl_xor(v, off, kWave);
+      const int e = e0 + p * GE + slot;
+      if (head == 0 && e < e1) a.w_mean[e] = v / static_cast<float>(H);
+    }
   }
 }
 
@@ -242,10 +395,17 @@ inline unsigned stream_grid(long long work_items) {
   return static_cast<unsigned>(blocks);
 }
 
+inline size_t long_slots_of(const gnpde_graph_t* g) {
+  const size_t rc = static_cast<size_t>(g->n_long_rows) * ((g->max_row_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW);
+  const size_t cc = static_cast<size_t>(g->n_long_cols) * ((g->max_col_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW);
+  return rc > cc ? rc : cc;
+}
+
 struct AttLayout {
-  size_t scores, seg_m, seg_den, gmax, gat, total;
+  size_t scores, seg_m, seg_den, gmax, gat, part, total;
 };
-AttLayout att_layout(int n, int e, int h, bool gat) {
+// `long_slots` = (number of long segments) x (max chunks of one segment), an upper bound is fine
+AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots) {
   AttLayout L{};
   size_t off = 0;
   L.scores = off; off += align_up(static_cast<size_t>(e) * h * 4, 256);
@@ -253,6 +413,7 @@ AttLayout att_layout(int n, int e, int h, bool gat) {
   L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.gmax = off; off += 256;
   L.gat = off; if (gat) off += align_up(static_cast<size_t>(n) * 2 * h * 4, 256);
+  L.part = off; off += align_up(long_slots * 2 * h * 4, 256);
   L.total = off;
   return L;
 }
@@ -261,6 +422,62 @@ template <int TYPE>
 void launch_scores(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s) {
   if (vec4) hipLaunchKernelGGL((scores_kernel<TYPE, true>), dim3(grid), dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((scores_kernel<TYPE, false>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s) {
+  switch (a.type) {
+    case GNPDE_ATT_SCALED_DOT: launch_scores<GNPDE_ATT_SCALED_DOT>(a, vec4, grid, s); break;
+    case GNPDE_ATT_COSINE: launch_scores<GNPDE_ATT_COSINE>(a, vec4, grid, s); break;
+    case GNPDE_ATT_PEARSON: launch_scores<GNPDE_ATT_PEARSON>(a, vec4, grid, s); break;
+    case GNPDE_ATT_EXP_KERNEL: launch_scores<GNPDE_ATT_EXP_KERNEL>(a, vec4, grid, s); break;
+    default: launch_scores<GNPDE_ATT_GAT>(a, false, grid, s); break;
+  }
+}
+
+template <int TYPE, int H, bool VEC4>
+void launch_rows_th(const AttArgs& a, int n16, int n64, hipStream_t s) {
+  // rows with <= 16 entries: 16*H lanes cover them in one pass when H <= 4, else a whole wave in H/4 passes
+  constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;
+  constexpr int P16 = (16 * H + GL16 - 1) / GL16;
+  constexpr int RPW16 = kWave / GL16;
+  constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);
+  if (n16 > 0) {
+    const unsigned grid = static_cast<unsigned>((n16 + RPW16 * kWavesPerBlock - 1) / (RPW16 * kWavesPerBlock));
+    hipLaunchKernelGGL((row_attention_kernel<TYPE, H, GL16, P16, VEC4>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16);
+  }
+  if (n64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((row_attention_kernel<TYPE, H, kWave, P64, VEC4>), dim3(grid), dim3(kBlock), 0, s, a, n16, n64);
+  }
+}
+
+template <int TYPE, bool VEC4>
+bool launch_rows_t(const AttArgs& a, int n16, int n64, hipStream_t s) {
+  switch (a.h) {
+    case 1: launch_rows_th<TYPE, 1, VEC4>(a, n16, n64, s); return true;
+    case 2: launch_rows_th<TYPE, 2, VEC4>(a, n16, n64, s); return true;
+    case 4: launch_rows_th<TYPE, 4, VEC4>(a, n16, n64, s); return true;
+    case 8: launch_rows_th<TYPE, 8, VEC4>(a, n16, n64, s); return true;
+    default: return false;
+  }
+}
+
+// fused row kernels exist for these (type, heads, alignment) combinations
+bool fused_supported(const AttArgs& a, bool vec4) {
+  if (!(a.h == 1 || a.h == 2 || a.h == 4 || a.h == 8)) return false;
+  if (a.type == GNPDE_ATT_GAT) return true;
+  return vec4 && (a.type == GNPDE_ATT_SCALED_DOT || a.type == GNPDE_ATT_COSINE || a.type == GNPDE_ATT_PEARSON ||
+                  a.type == GNPDE_ATT_EXP_KERNEL);
+}
+
+void launch_rows_any(const AttArgs& a, int n16, int n64, hipStream_t s) {
+  switch (a.type) {
+    case GNPDE_ATT_SCALED_DOT: launch_rows_t<GNPDE_ATT_SCALED_DOT, true>(a, n16, n64, s); break;
+    case GNPDE_ATT_COSINE: launch_rows_t<GNPDE_ATT_COSINE, true>(a, n16, n64, s); break;
+    case GNPDE_ATT_PEARSON: launch_rows_t<GNPDE_ATT_PEARSON, true>(a, n16, n64, s); break;
+    case GNPDE_ATT_EXP_KERNEL: launch_rows_t<GNPDE_ATT_EXP_KERNEL, true>(a, n16, n64, s); break;
+    default: launch_rows_t<GNPDE_ATT_GAT, false>(a, n16, n64, s); break;
+  }
 }
 
 }  // namespace
@@ -281,7 +498,11 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   GNPDE_CHECK_ARG(g->rowidx && g->perm, GNPDE_EINVAL, "edge_attention: graph lacks rowidx/perm");
   if (g->e == 0 || g->n == 0) return 0;
   const bool gat = at->type == GNPDE_ATT_GAT;
-  const AttLayout L = att_layout(g->n, g->e, at->heads, gat);
+  const int n_long = at->norm_idx == 0 ? g->n_long_rows : g->n_long_cols;
+  const int* long_list = at->norm_idx == 0 ? g->long_rows : g->long_cols;
+  const int max_len = at->norm_idx == 0 ? g->max_row_len : g->max_col_len;
+  const int max_chunks = (max_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+  const AttLayout L = att_layout(g->n, g->e, at->heads, gat, long_slots_of(g));
   GNPDE_CHECK_ARG(ws && ws_bytes >= L.total, GNPDE_EWS, "edge_attention: workspace %zu < %zu bytes", ws_bytes, L.total);
   GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0, GNPDE_EINVAL, "edge_attention: workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
@@ -292,6 +513,7 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   a.inv_sqrt_dk_den = static_cast<float>(std::sqrt(static_cast<double>(a.dk)));
   a.leaky_slope = at->leaky_slope;
   a.rowidx = g->rowidx; a.colidx = g->colidx; a.perm = g->perm;
+  a.rowptr = g->rowptr; a.bin_rows = g->bin_rows;
   a.segptr = at->norm_idx == 0 ? g->rowptr : g->cscptr;
   a.segpos = at->norm_idx == 0 ? nullptr : g->cscpos;
   a.q = at->q; a.k = at->k; a.ldqk = at->ldqk;
@@ -302,6 +524,7 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   a.gmax = reinterpret_cast<unsigned*>(base + L.gmax);
   a.gat_terms = reinterpret_cast<float*>(base + L.gat);
   a.w_mean = w_mean_csr; a.att_edge = att_edge; a.prods_edge = prods_edge;
+  float* part = reinterpret_cast<float*>(base + L.part);
 
   if (a.square_plus) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
   if (gat) {
@@ -312,29 +535,54 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   }
   const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(a.k) % 16 == 0);
-  const unsigned sgrid = stream_grid(static_cast<long long>(a.e) * a.h);
-  switch (a.type) {
-    case GNPDE_ATT_SCALED_DOT: launch_scores<GNPDE_ATT_SCALED_DOT>(a, vec4, sgrid, stream); break;
-    case GNPDE_ATT_COSINE: launch_scores<GNPDE_ATT_COSINE>(a, vec4, sgrid, stream); break;
-    case GNPDE_ATT_PEARSON: launch_scores<GNPDE_ATT_PEARSON>(a, vec4, sgrid, stream); break;
-    case GNPDE_ATT_EXP_KERNEL: launch_scores<GNPDE_ATT_EXP_KERNEL>(a, vec4, sgrid, stream); break;
-    default: launch_scores<GNPDE_ATT_GAT>(a, false, sgrid, stream); break;
+
+  const bool fused = a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
+                     g->bin_rows != nullptr && fused_supported(a, vec4);
+  if (fused) {
+    launch_rows_any(a, g->n_bin16, g->n_bin64, stream);
+    GNPDE_LAUNCH_CHECK();
+    if (g->n_long_rows > 0) {  // hubs: the general passes restricted to the long rows' chunks
+      AttArgs c = a;
+      c.chunk_begin = g->long_chunk_begin;
+      c.chunk_end = g->long_chunk_end;
+      c.long_segs = g->long_rows;
+      launch_scores_any(c, vec4, static_cast<unsigned>(g->n_long_chunks), stream);
+      GNPDE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_stats_long_partial_kernel, dim3(n_long, max_chunks), dim3(kBlock), 0, stream, c, part, max_chunks);
+      GNPDE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_stats_long_combine_kernel, dim3(n_long), dim3(kWave), 0, stream, c, part, max_chunks);
+      GNPDE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 0, stream, c);
+      GNPDE_LAUNCH_CHECK();
+    }
+    return 0;
   }
+
+  launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
   GNPDE_LAUNCH_CHECK();
+  a.long_segs = (n_long > 0 && long_list != nullptr) ? long_list : nullptr;
   hipLaunchKernelGGL(seg_stats_kernel, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, stream, a);
   GNPDE_LAUNCH_CHECK();
+  if (a.long_segs != nullptr) {
+    hipLaunchKernelGGL(seg_stats_long_partial_kernel, dim3(n_long, max_chunks), dim3(kBlock), 0, stream, a, part, max_chunks);
+    GNPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_stats_long_combine_kernel, dim3(n_long), dim3(kWave), 0, stream, a, part, max_chunks);
+    GNPDE_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(normalise_kernel, dim3(stream_grid(a.e)), dim3(kBlock), 0, stream, a);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
 
-size_t attention_workspace_bytes(int n, int e, int h, bool gat) { return att_layout(n, e, h, gat).total; }
+size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
+  return att_layout(g->n, g->e, h, gat, long_slots_of(g)).total;
+}
 
 }  // namespace gnpde
 
 extern "C" size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a) {
   if (!g || !a || a->heads < 1) return 0;
-  return gnpde::attention_workspace_bytes(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT);
+  return gnpde::attention_workspace_bytes(g, a->heads, a->type == GNPDE_ATT_GAT);
 }
 
 extern "C" int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a, float* w_mean_csr, float* att_edge,

@@ -59,6 +59,10 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
   return (b % kXcds) * per + (b / kXcds);
 }
 
+// kernel-variant knobs for A/B measurements (gnpde_tune); 0 = the default variant
+enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_COUNT = 8 };
+extern int g_tune[GNPDE_TUNE_COUNT];
+
 // internal launchers used by the solver (defined in the kernel translation units)
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,

@@ -15,28 +15,36 @@
 
 using namespace gnpde;
 
-extern "C" int gnpde_graph_count_long(const int64_t* row, int64_t n_edges, int32_t n_nodes,
-                                      int32_t* n_long_rows, int32_t* n_long_chunks) {
+extern "C" int gnpde_graph_count_long(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
+                                      int32_t* n_long_rows, int32_t* n_long_chunks, int32_t* n_long_cols) {
   GNPDE_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (int64_t(1) << 31), GNPDE_EINVAL,
                   "graph_count_long: bad sizes n=%d e=%lld", n_nodes, (long long)n_edges);
-  GNPDE_CHECK_ARG((row || n_edges == 0) && n_long_rows && n_long_chunks, GNPDE_EINVAL,
+  GNPDE_CHECK_ARG((row || n_edges == 0) && n_long_rows && n_long_chunks && n_long_cols, GNPDE_EINVAL,
                   "graph_count_long: null pointer");
-  std::vector<int32_t> deg(static_cast<size_t>(n_nodes), 0);
+  std::vector<int32_t> deg(static_cast<size_t>(n_nodes), 0), cdeg(col ? static_cast<size_t>(n_nodes) : 0, 0);
   for (int64_t e = 0; e < n_edges; ++e) {
     const int64_t r = row[e];
     GNPDE_CHECK_ARG(r >= 0 && r < n_nodes, GNPDE_EINVAL, "graph_count_long: row index %lld out of range",
                     (long long)r);
     ++deg[r];
+    if (col) {
+      const int64_t c = col[e];
+      GNPDE_CHECK_ARG(c >= 0 && c < n_nodes, GNPDE_EINVAL, "graph_count_long: column index %lld out of range",
+                      (long long)c);
+      ++cdeg[c];
+    }
   }
-  int32_t lr = 0, lc = 0;
+  int32_t lr = 0, lc = 0, lcol = 0;
   for (int32_t i = 0; i < n_nodes; ++i) {
     if (deg[i] > GNPDE_LONG_ROW) {
       ++lr;
       lc += (deg[i] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
     }
+    if (col && cdeg[i] > GNPDE_LONG_ROW) ++lcol;
   }
   *n_long_rows = lr;
   *n_long_chunks = lc;
+  *n_long_cols = lcol;
   return 0;
 }
 
@@ -44,7 +52,8 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
                                  int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
                                  int32_t* cscptr, int32_t* cscpos, int32_t* long_rows,
                                  int32_t* long_chunk_ptr, int32_t* long_chunk_row,
-                                 int32_t* long_chunk_begin, int32_t* long_chunk_end) {
+                                 int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
+                                 int32_t* bin_rows, int32_t* bin_counts) {
   GNPDE_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (int64_t(1) << 31), GNPDE_EINVAL,
                   "graph_build: bad sizes n=%d e=%lld", n_nodes, (long long)n_edges);
   GNPDE_CHECK_ARG(rowptr && (n_edges == 0 || (row && col && colidx && perm && rowidx)), GNPDE_EINVAL,
@@ -94,6 +103,27 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
     }
   }
   if (long_chunk_ptr) long_chunk_ptr[lr] = lc;
+  if (cscptr && long_cols) {
+    int32_t k = 0;
+    for (int32_t i = 0; i < n_nodes; ++i)
+      if (cscptr[i + 1] - cscptr[i] > GNPDE_LONG_ROW) long_cols[k++] = i;
+  }
+  if (bin_rows && bin_counts) {
+    int32_t n16 = 0, n64 = 0;
+    for (int32_t i = 0; i < n_nodes; ++i) {
+      const int32_t dg = rowptr[i + 1] - rowptr[i];
+      if (dg >= 1 && dg <= 16) ++n16;
+      else if (dg > 16 && dg <= GNPDE_LONG_ROW) ++n64;
+    }
+    int32_t p16 = 0, p64 = n16;
+    for (int32_t i = 0; i < n_nodes; ++i) {
+      const int32_t dg = rowptr[i + 1] - rowptr[i];
+      if (dg >= 1 && dg <= 16) bin_rows[p16++] = i;
+      else if (dg > 16 && dg <= GNPDE_LONG_ROW) bin_rows[p64++] = i;
+    }
+    bin_counts[0] = n16;
+    bin_counts[1] = n64;
+  }
   return 0;
 }
 

@@ -16,7 +16,7 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
                       int ldo, hipStream_t s);
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream);
-size_t attention_workspace_bytes(int n, int e, int h, bool gat);
+size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 
 namespace {
 
@@ -36,7 +36,7 @@ RhsLayout rhs_layout(const gnpde_rhs_t& r) {
     L.proj = off;  off += align_up(static_cast<size_t>(g.n) * r.proj_m * 4, 256);
     L.wmean = off; off += align_up(static_cast<size_t>(g.e) * 4, 256);
     L.att = off;
-    L.att_bytes = attention_workspace_bytes(g.n, g.e, r.att.heads, r.kind == GNPDE_RHS_GAT);
+    L.att_bytes = attention_workspace_bytes(&g, r.att.heads, r.kind == GNPDE_RHS_GAT);
     off += align_up(L.att_bytes, 256);
   }
   L.total = off;

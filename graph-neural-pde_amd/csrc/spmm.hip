@@ -29,6 +29,37 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)
   }
 }
 
+// streaming (touched once per launch) variants: nontemporal hint keeps the gathered rows in L2
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else if constexpr (VEC == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
+    v[0] = t[0]; v[1] = t[1];
+  } else {
+    v[0] = __builtin_nontemporal_load(p);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+  } else if constexpr (VEC == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 t = {v[0], v[1]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f2*>(p));
+  } else {
+    __builtin_nontemporal_store(v[0], p);
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
   if constexpr (VEC == 4) {
@@ -62,16 +93,19 @@ __device__ __forceinline__ float alpha_of(const gnpde_epilogue_t& ep) {
 }
 
 // k = alpha (ax - u_i) + beta x0_i, then the stage algebra in torchdiffeq's operation order.
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off,
                                          const float (&ax)[VEC], const float (&ui)[VEC]) {
+  // per-row streaming operands (y, k1..k3, x0 in; k, y out) are touched once per launch
+  auto ld = [](const float* p, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(p, v); else load_vec<VEC>(p, v); };
+  auto st = [](float* p, const float (&v)[VEC]) { if constexpr (NT) store_vec_nt<VEC>(p, v); else store_vec<VEC>(p, v); };
   constexpr float kThird = 1.0f / 3.0f;
   float k[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) k[v] = alpha * (ax[v] - ui[v]);
   if (ep.x0 != nullptr) {
     float s[VEC];
-    load_vec<VEC>(ep.x0 + off, s);
+    ld(ep.x0 + off, s);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
   }
@@ -79,56 +113,55 @@ __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha
   float y[VEC], a[VEC], b[VEC], c[VEC], o[VEC];
   switch (ep.stage) {
     case GNPDE_STAGE_RHS:
-      store_vec<VEC>(ep.out_k + off, k);
+      st(ep.out_k + off, k);
       break;
     case GNPDE_STAGE_EULER:
-      load_vec<VEC>(ep.y + off, y);
+      ld(ep.y + off, y);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * k[v];
-      store_vec<VEC>(ep.out_y + off, o);
+      st(ep.out_y + off, o);
       break;
     case GNPDE_STAGE_RK1:
-      load_vec<VEC>(ep.y + off, y);
-      store_vec<VEC>(ep.out_k + off, k);
+      ld(ep.y + off, y);
+      st(ep.out_k + off, k);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + (dt * k[v]) * kThird;
-      store_vec<VEC>(ep.out_y + off, o);
+      st(ep.out_y + off, o);
       break;
     case GNPDE_STAGE_RK2:
-      load_vec<VEC>(ep.y + off, y);
-      load_vec<VEC>(ep.k1 + off, a);
-      store_vec<VEC>(ep.out_k + off, k);
+      ld(ep.y + off, y);
+      ld(ep.k1 + off, a);
+      st(ep.out_k + off, k);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * (k[v] - a[v] * kThird);
-      store_vec<VEC>(ep.out_y + off, o);
+      st(ep.out_y + off, o);
       break;
     case GNPDE_STAGE_RK3:
-      load_vec<VEC>(ep.y + off, y);
-      load_vec<VEC>(ep.k1 + off, a);
-      load_vec<VEC>(ep.k2 + off, b);
-      store_vec<VEC>(ep.out_k + off, k);
+      ld(ep.y + off, y);
+      ld(ep.k1 + off, a);
+      ld(ep.k2 + off, b);
+      st(ep.out_k + off, k);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * ((a[v] - b[v]) + k[v]);
-      store_vec<VEC>(ep.out_y + off, o);
+      st(ep.out_y + off, o);
       break;
     case GNPDE_STAGE_RK4:
-      load_vec<VEC>(ep.y + off, y);
-      load_vec<VEC>(ep.k1 + off, a);
-      load_vec<VEC>(ep.k2 + off, b);
-      load_vec<VEC>(ep.k3 + off, c);
+      ld(ep.y + off, y);
+      ld(ep.k1 + off, a);
+      ld(ep.k2 + off, b);
+      ld(ep.k3 + off, c);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + (((a[v] + 3.0f * (b[v] + c[v])) + k[v]) * dt) * 0.125f;
-      store_vec<VEC>(ep.out_y + off, o);
+      st(ep.out_y + off, o);
       break;
     default:
       break;
   }
 }
 
-template <int VEC, int L, int K>
+template <int VEC, int L, int K, int U, bool NTI, bool NT>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
   constexpr int G = kWave / L;
-  constexpr int U = (K >= 4) ? 1 : (K >= 2 ? 2 : 4);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -157,26 +190,25 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
 
-  const int last = e1 - 1;
   for (int j = e0; j < e1; j += G * U) {
     float vals[U][K][VEC];
     float ww[U];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
       const int e = j + t * G + sub;
-      const int ec = e < e1 ? e : last;   // clamp: always a valid (cached) neighbour, weight 0
-      const int c = a.colidx[ec];
-      const float wv = a.w[ec];
-      ww[t] = e < e1 ? wv : 0.0f;
-      const float* src = a.u + static_cast<size_t>(c) * a.ld;
+      ww[t] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int col = (k * L + cl) * VEC;
-        if (col < a.d) {
-          load_vec<VEC>(src + col, vals[t][k]);
-        } else {
+      for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) vals[t][k][v] = 0.0f;
+        for (int v = 0; v < VEC; ++v) vals[t][k][v] = 0.0f;
+      if (e < e1) {  // masked lanes issue no memory request
+        const int c = NTI ? __builtin_nontemporal_load(a.colidx + e) : a.colidx[e];
+        ww[t] = NTI ? __builtin_nontemporal_load(a.w + e) : a.w[e];
+        const float* src = a.u + static_cast<size_t>(c) * a.ld;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int col = (k * L + cl) * VEC;
+          if (col < a.d) load_vec<VEC>(src + col, vals[t][k]);
         }
       }
     }
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
       const size_t off = static_cast<size_t>(row) * a.ld + col;
       float ui[VEC];
       load_vec<VEC>(a.u + off, ui);
-      epilogue<VEC>(a.ep, alpha, beta, off, acc[k], ui);
+      epilogue<VEC, NT>(a.ep, alpha, beta, off, acc[k], ui);
     }
   }
 }
@@ -246,28 +278,53 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(const SpmmArgs
     } else {
       const float ax[1] = {s};
       const float ui[1] = {a.u[off]};
-      epilogue<1>(a.ep, alpha, beta, off, ax, ui);
+      epilogue<1, false>(a.ep, alpha, beta, off, ax, ui);
     }
   }
 }
 
-template <int VEC, int L, int K>
+template <int VEC, int L, int K, int U, bool NTI, bool NT = NTI>
 void launch_rows(const SpmmArgs& a, hipStream_t s) {
   const long long items = static_cast<long long>(a.n) + a.n_long_chunks;
   const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K>), dim3(grid), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K, U, NTI, NT>), dim3(grid), dim3(kBlock), 0, s, a);
 }
 
 template <int VEC>
 int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
   const int slots = (a.d + VEC - 1) / VEC;
-  if (slots <= 8) launch_rows<VEC, 8, 1>(a, s);
-  else if (slots <= 16) launch_rows<VEC, 16, 1>(a, s);
-  else if (slots <= 32) launch_rows<VEC, 32, 1>(a, s);
-  else if (slots <= 64) launch_rows<VEC, 64, 1>(a, s);
-  else if (slots <= 128) launch_rows<VEC, 64, 2>(a, s);
-  else if (slots <= 192) launch_rows<VEC, 64, 3>(a, s);
-  else if (slots <= 256) launch_rows<VEC, 64, 4>(a, s);
+  if (slots <= 8) launch_rows<VEC, 8, 1, 4, false, true>(a, s);
+  else if (slots <= 16) launch_rows<VEC, 16, 1, 4, false, true>(a, s);
+  else if (slots <= 32) {
+    if constexpr (VEC == 4) {  // the headline shape (d = 128): tunable for A/B runs
+      const int v = g_tune[GNPDE_TUNE_SPMM_VARIANT];
+      switch (v) {
+        case 1: launch_rows<4, 32, 1, 8, false>(a, s); break;
+        case 2: launch_rows<4, 16, 2, 2, false>(a, s); break;
+        case 3: launch_rows<4, 32, 1, 4, true>(a, s); break;
+        case 4: launch_rows<4, 32, 1, 8, true>(a, s); break;
+        case 5: launch_rows<4, 16, 2, 4, false>(a, s); break;
+        case 6: launch_rows<4, 32, 1, 2, false>(a, s); break;
+        case 7: launch_rows<4, 16, 2, 4, true>(a, s); break;
+        case 8: launch_rows<4, 16, 2, 8, true>(a, s); break;
+        case 9: launch_rows<4, 8, 4, 2, true>(a, s); break;
+        case 10: launch_rows<4, 8, 4, 4, true>(a, s); break;
+        case 11: launch_rows<4, 16, 2, 4, true, false>(a, s); break;
+        case 12: launch_rows<4, 16, 2, 4, false, true>(a, s); break;
+        case 13: launch_rows<4, 16, 2, 2, true>(a, s); break;
+        case 14: launch_rows<4, 32, 1, 4, false, true>(a, s); break;
+        case 15: launch_rows<4, 32, 1, 4, true, false>(a, s); break;
+        case 16: launch_rows<4, 32, 1, 4, false>(a, s); break;
+        default: launch_rows<4, 16, 2, 4, false, true>(a, s); break;  // measured best on MI355X (tools/spmm_ab.py)
+      }
+    } else {
+      launch_rows<VEC, 16, 2, 4, false, true>(a, s);
+    }
+  }
+  else if (slots <= 64) launch_rows<VEC, 32, 2, 4, false, true>(a, s);
+  else if (slots <= 128) launch_rows<VEC, 64, 2, 2, false, true>(a, s);
+  else if (slots <= 192) launch_rows<VEC, 64, 3, 1, false, true>(a, s);
+  else if (slots <= 256) launch_rows<VEC, 64, 4, 1, false, true>(a, s);
   else {
     set_error("spmm: feature width d=%d too large for VEC=%d (max %d)", a.d, VEC, 256 * VEC);
     return GNPDE_ESHAPE;

@@ -26,9 +26,10 @@ class CSRGraph(object):
     ei = edge_index.detach().to('cpu', torch.int64).contiguous()
     row = ei[0].contiguous().numpy()
     col = ei[1].contiguous().numpy()
-    nlr, nlc = ctypes.c_int32(0), ctypes.c_int32(0)
-    _lib.check(L.gnpde_graph_count_long(row.ctypes.data, self.e, self.n, ctypes.byref(nlr), ctypes.byref(nlc)))
-    self.n_long_rows, self.n_long_chunks = nlr.value, nlc.value
+    nlr, nlc, nlcol = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(L.gnpde_graph_count_long(row.ctypes.data, col.ctypes.data, self.e, self.n, ctypes.byref(nlr),
+                                        ctypes.byref(nlc), ctypes.byref(nlcol)))
+    self.n_long_rows, self.n_long_chunks, self.n_long_cols = nlr.value, nlc.value, nlcol.value
     host = {
       'rowptr': np.zeros(self.n + 1, np.int32), 'colidx': np.zeros(max(self.e, 1), np.int32),
       'perm': np.zeros(max(self.e, 1), np.int32), 'rowidx': np.zeros(max(self.e, 1), np.int32),
@@ -38,16 +39,25 @@ class CSRGraph(object):
       'long_chunk_row': np.zeros(max(self.n_long_chunks, 1), np.int32),
       'long_chunk_begin': np.zeros(max(self.n_long_chunks, 1), np.int32),
       'long_chunk_end': np.zeros(max(self.n_long_chunks, 1), np.int32),
+      'long_cols': np.zeros(max(self.n_long_cols, 1), np.int32),
+      'bin_rows': np.zeros(max(self.n, 1), np.int32),
     }
+    bin_counts = np.zeros(2, np.int32)
     order = ['rowptr', 'colidx', 'perm', 'rowidx', 'cscptr', 'cscpos', 'long_rows', 'long_chunk_ptr',
-             'long_chunk_row', 'long_chunk_begin', 'long_chunk_end']
+             'long_chunk_row', 'long_chunk_begin', 'long_chunk_end', 'long_cols', 'bin_rows']
     _lib.check(L.gnpde_graph_build(row.ctypes.data, col.ctypes.data, self.e, self.n,
-                                   *[host[k].ctypes.data for k in order]))
+                                   *([host[k].ctypes.data for k in order] + [bin_counts.ctypes.data])))
+    self.n_bin16, self.n_bin64 = int(bin_counts[0]), int(bin_counts[1])
     self.t = {k: torch.from_numpy(v).to(device) for k, v in host.items()}
     self.perm_long = self.t['perm'][:self.e].long()
     s = _lib.GraphStruct()
     s.n, s.e = self.n, self.e
     s.n_long_rows, s.n_long_chunks = self.n_long_rows, self.n_long_chunks
+    s.n_long_cols, s.n_bin16, s.n_bin64 = self.n_long_cols, self.n_bin16, self.n_bin64
+    rp, cp = host['rowptr'], host['cscptr']
+    self.max_row_len = int((rp[1:] - rp[:-1]).max()) if self.n > 0 else 0
+    self.max_col_len = int((cp[1:] - cp[:-1]).max()) if self.n > 0 else 0
+    s.max_row_len, s.max_col_len = self.max_row_len, self.max_col_len
     for k in order:
       setattr(s, k, self.t[k].data_ptr())
     self.struct = s

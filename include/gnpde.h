@@ -42,6 +42,8 @@ extern "C" {
 
 int         gnpde_abi_version(void);
 const char* gnpde_last_error(void);
+/* Select a kernel variant for A/B measurements (key 0: aggregation kernel variant); 0 = default. */
+int         gnpde_tune(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph preparation (host, C++).  Replaces the implicit COO handling of torch_sparse.spmm /
@@ -50,22 +52,27 @@ const char* gnpde_last_error(void);
  * -> CSR with a stable permutation, a CSC view, and the long-row chunk list.
  * ---------------------------------------------------------------------------------------------- */
 
-/* Number of long rows / long-row chunks the edge list produces (sizes of the arrays below). */
-int gnpde_graph_count_long(const int64_t* row, int64_t n_edges, int32_t n_nodes,
-                           int32_t* n_long_rows, int32_t* n_long_chunks);
+/* Number of long rows / long-row chunks / long columns the edge list produces (sizes of the arrays
+ * below).  `col` may be NULL (then *n_long_cols = 0). */
+int gnpde_graph_count_long(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
+                           int32_t* n_long_rows, int32_t* n_long_chunks, int32_t* n_long_cols);
 
 /* All arrays are HOST memory, caller allocated:
  *   rowptr[n+1], colidx[E], perm[E] (CSR position -> index into the caller's edge list; stable, so
  *   duplicates keep their relative order), rowidx[E] (row of each CSR position),
  *   cscptr[n+1], cscpos[E] (for every column, the CSR positions of its entries, ascending)  -- may
  *   both be NULL;  long_rows[n_long_rows], long_chunk_ptr[n_long_rows+1],
- *   long_chunk_row/begin/end[n_long_chunks].
+ *   long_chunk_row/begin/end[n_long_chunks], long_cols[n_long_cols] (NULL without the CSC view);
+ *   bin_rows[n]: row ids grouped by degree class -- first the rows with 1..16 entries, then those
+ *   with 17..GNPDE_LONG_ROW (empty and long rows are not listed); bin_counts[2] = sizes of the two
+ *   classes.  Within a class rows keep ascending order.
  * Returns GNPDE_EINVAL if an index is outside [0, n_nodes). */
 int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
                       int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
                       int32_t* cscptr, int32_t* cscpos,
                       int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* long_chunk_row,
-                      int32_t* long_chunk_begin, int32_t* long_chunk_end);
+                      int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
+                      int32_t* bin_rows, int32_t* bin_counts);
 
 /* Balanced k-way row partition for the multi-GPU path (no METIS offline): BFS-grown parts balanced
  * on nnz, refined by label propagation.  part[n] receives values in [0, n_parts).  Host only. */
@@ -89,6 +96,14 @@ typedef struct gnpde_graph {
   const int32_t* long_chunk_row;     /* [n_long_chunks]                                      */
   const int32_t* long_chunk_begin;   /* [n_long_chunks]                                      */
   const int32_t* long_chunk_end;     /* [n_long_chunks]                                      */
+  int32_t n_long_cols;               /* columns with more than GNPDE_LONG_ROW entries        */
+  int32_t n_bin16;                   /* rows with 1..16 entries                              */
+  int32_t n_bin64;                   /* rows with 17..GNPDE_LONG_ROW entries                 */
+  int32_t max_row_len;               /* longest row                                          */
+  int32_t max_col_len;               /* longest column (0 without the CSC view)              */
+  int32_t reserved_;
+  const int32_t* long_cols;          /* [n_long_cols] or NULL                                */
+  const int32_t* bin_rows;           /* [n_bin16 + n_bin64]                                  */
 } gnpde_graph_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -99,7 +114,7 @@ typedef struct gnpde_graph {
  * and then, per `stage` (torchdiffeq 0.2.1 fixed-grid solvers, called from
  * src/block_constant.py:57-62; rk4 == 3/8-rule rk4_alt_step_func, cf. src/early_stop_solver.py:150-155):
  *   GNPDE_STAGE_RHS    out_k = k
- *   GNPDE_STAGE_EULER  out_y = y + dt * k                                   (in place on y allowed)
+ *   GNPDE_STAGE_EULER  out_y = y + dt * k                       (u == y here, so out_y must differ)
  *   GNPDE_STAGE_RK1    out_k = k1 ; out_y = y + dt*k1*(1/3)
  *   GNPDE_STAGE_RK2    out_k = k2 ; out_y = y + dt*(k2 - k1*(1/3))
  *   GNPDE_STAGE_RK3    out_k = k3 ; out_y = y + dt*(k1 - k2 + k3)

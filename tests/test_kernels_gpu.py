@@ -118,6 +118,40 @@ def test_edge_attention(dev, att_type, h, A, norm_idx, sqp, reweight):
   assert_parity(w[:graph.e], w_ref[graph.perm_long.cpu()], what='head-mean weights (CSR order)')
 
 
+FUSED_CASES = [('scaled_dot', 4, 16), ('scaled_dot', 8, 128), ('scaled_dot', 1, 24), ('scaled_dot', 2, 8),
+               ('cosine_sim', 4, 16), ('pearson', 2, 32), ('exp_kernel', 4, 16), ('scaled_dot', 3, 12), ('scaled_dot', 4, 8)]
+
+
+@pytest.mark.parametrize('att_type,h,A', FUSED_CASES)
+@pytest.mark.parametrize('reweight', [False, True])
+def test_row_attention_fused_path(dev, att_type, h, A, reweight):
+  """Only the head-mean weights requested + softmax over rows -> the fused row kernels (16-lane groups,
+  whole-wave rows, hub chunks); (3,12) and (4,8) fall back to the general passes (d_k % 4 != 0 / h = 3)."""
+  n, d = 3000, 20
+  ei = random_graph(n, 9, seed=h * 7 + A, hubs=2, hub_deg=1300, isolated=3, dup=25)
+  extra = random_graph(40, 300, seed=1, loops=False)  # 40 rows with ~300 entries: multi-pass whole-wave rows
+  ei = torch.cat([ei, extra], dim=1)
+  g = torch.Generator().manual_seed(A)
+  x = torch.randn(n, d, generator=g)
+  Wq, Wk = torch.randn(A, d, generator=g) / math.sqrt(d), torch.randn(A, d, generator=g) / math.sqrt(d)
+  bq, bk = torch.randn(A, generator=g) * 0.1, torch.randn(A, generator=g) * 0.1
+  ew = torch.rand(ei.size(1), generator=g) + 0.5 if reweight else None
+  ov, ls = torch.tensor([1.2]), torch.tensor([0.8])
+  att_ref, _ = R.transformer_attention(x, ei, Wq, bq, Wk, bk, h, attention_type=att_type, norm_idx=0, square_plus=False,
+                                       edge_weights=ew, reweight=reweight, output_var=ov, lengthscale=ls)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.n_bin16 > 0 and graph.n_bin64 > 40 and graph.n_long_rows >= 2
+  qk = ops.linear(x.to(dev), torch.cat([Wq, Wk]).to(dev), torch.cat([bq, bk]).to(dev))
+  ew_csr = ops.edge_to_csr_mean(graph, ew.to(dev)) if reweight else None
+  st = ops.attention_struct(_lib.ATT_TYPES[att_type], h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A,
+                            output_var=ov.to(dev), lengthscale=ls.to(dev), edge_w_csr=ew_csr)
+  w, _, _ = ops.edge_attention(graph, st, True, False, False, like=qk)
+  assert_parity(w[:graph.e], att_ref.mean(dim=1)[graph.perm_long.cpu()], what='fused head-mean weights')
+  # the general path must give the same numbers up to rounding
+  w2, _, _ = ops.edge_attention(graph, st, True, True, False, like=qk)
+  assert_parity(w2[:graph.e], w[:graph.e], tol=1e-5, what="fused vs general path")
+
+
 @pytest.mark.parametrize('h,A,norm_idx,slope', [(4, 16, 0, 0.2), (2, 16, 1, 0.05), (3, 9, 0, 0.2)])
 def test_gat_attention(dev, h, A, norm_idx, slope):
   n, d = 350, 24
@@ -134,6 +168,9 @@ def test_gat_attention(dev, h, A, norm_idx, slope):
                             gat_a=a.reshape(-1).to(dev))
   _, att, _ = ops.edge_attention(graph, st, False, True, False, like=wx)
   assert_parity(att, att_ref, what='GAT attention')
+  if norm_idx == 0:
+    w, _, _ = ops.edge_attention(graph, st, True, False, False, like=wx)   # fused row kernel for h in {1,2,4,8}
+    assert_parity(w[:graph.e], att_ref.mean(dim=1)[graph.perm_long.cpu()], what='GAT fused head-mean weights')
 
 
 def test_attention_rows_sum_to_one(dev):
