@@ -79,15 +79,15 @@ def make_block(G, opt, ei, n, x, dev, T, seed):
   return block
 
 
-def spmm_kernel_time(G, block, x, reps=10):
-  """Average duration of one launch of the aggregation kernel over the 4 rk4 stage epilogues, HIP events on
-  the launch stream (torch's current stream, which is the stream the C ABI is handed)."""
+def dominant_kernel_time(G, block, x, reps=10):
+  """Average duration of one launch of the dominant kernel over the 4 rk4 stage epilogues the solver runs,
+  HIP events on the launch stream (torch's current stream, which is the stream the C ABI is handed).
+  GRAND-nl: the one-pass attention + aggregation kernel; GRAND-l: the CSR aggregation kernel."""
+  import ctypes
   from gnpde_amd import ops, _lib
   f = block.odefunc
   graph = f._graph(x)
-  d = x.shape[1]
   dev = x.device
-  w = torch.rand(max(graph.e, 1), device=dev) / 16
   bufs = [torch.randn_like(x) for _ in range(7)]
   y, k1, k2, k3, ua, ub, x0 = bufs
   alpha = ops._scalar_dev(f.alpha_train, x)
@@ -96,12 +96,29 @@ def spmm_kernel_time(G, block, x, reps=10):
             dict(stage=_lib.STAGE_RK2, y=y, k1=k1, out_k=k2, out_y=ub, u=ua),
             dict(stage=_lib.STAGE_RK3, y=y, k1=k1, k2=k2, out_k=k3, out_y=ua, u=ub),
             dict(stage=_lib.STAGE_RK4, y=y, k1=k1, k2=k2, k3=k3, out_y=y, u=ua)]
+  fused = False
+  if hasattr(f, 'multihead_att_layer') and os.environ.get('GNPDE_ONE_PASS', '0') == '1':
+    desc = f._descriptor(x)
+    fused = _lib.lib().gnpde_attn_rhs_fused_supported(ctypes.byref(desc.struct.att), x.shape[1], x.stride(0)) == 1
+  if fused:
+    wqk, bqk = f.multihead_att_layer.qk_weights()
+    att = desc.struct.att
+    name = 'attn_rhs_fused_kernel (one-pass projection + edge softmax + aggregation + rk4 stage)'
+
+    def launch(u, kw):
+      ops.attn_rhs_fused(graph, att, wqk, bqk, u, alpha, beta, x0, True, dt=1.0, **kw)
+  else:
+    w = torch.rand(max(graph.e, 1), device=dev) / 16
+    name = 'spmm_rows_kernel (CSR aggregation + fused epilogue / rk4 stage)'
+
+    def launch(u, kw):
+      ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
 
   def once():
     for st in stages:
       kw = dict(st)
       u = kw.pop('u')
-      ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
+      launch(u, kw)
   once()
   torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,7 +127,7 @@ def spmm_kernel_time(G, block, x, reps=10):
     once()
   e1.record()
   torch.cuda.synchronize()
-  return e0.elapsed_time(e1) * 1e-3 / (reps * 4), graph
+  return e0.elapsed_time(e1) * 1e-3 / (reps * 4), graph, name, fused
 
 
 def cpu_baseline(block, x_cpu, evals):
@@ -145,6 +162,8 @@ def main():
     if world == 1 and args.gpus > 1:
       raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
   import gnpde_amd as G
+  if os.environ.get('GNPDE_ONE_PASS', '0') == '1':
+    G.ops.tune(G._lib.TUNE_ONE_PASS, 1)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
   dev = torch.device('cuda', local_rank)
@@ -190,18 +209,19 @@ def main():
   A, h = opt['attention_dim'], opt['heads']
 
   # roofline of the dominant kernel (B_spmm = E (4 + 4 + 4d) + N (4 + 8d) + 4dN with add_source)
-  t_spmm, graph = spmm_kernel_time(G, main_block, x)
-  bytes_spmm = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n
+  t_spmm, graph, kname, fused = dominant_kernel_time(G, main_block, x)
+  bytes_l = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n                      # SURVEY.md 8d, B_l + source
+  bytes_nl = E * (4 + 4 * A + 4 * d) + n * (4 + 12 * A + 12 * d) + 4 * d * n   # SURVEY.md 8d, B_nl + source
+  bytes_spmm = bytes_nl if fused else bytes_l
   achieved = bytes_spmm / t_spmm / 1e9
   traffic = None
-  tpath = os.path.join(ROOT, 'profiles', 'spmm_hbm_traffic.json')
+  tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   if os.path.exists(tpath):
     try:
-      traffic = json.load(open(tpath)).get('%s_d%d' % (args.graph, d))
+      traffic = json.load(open(tpath)).get('%s_d%d_%s' % (args.graph, d, 'fused' if fused else 'spmm'))
     except Exception:
       traffic = None
-  bytes_eval_nl = E * (4 + 4 * A + 4 * d) + n * (4 + 12 * A + 12 * d) + 4 * d * n
-  bytes_eval = bytes_eval_nl if args.function == 'transformer' else bytes_spmm
+  bytes_eval = bytes_nl if args.function == 'transformer' else bytes_l
   out = {
     'metric': 'ODE steps/sec (full-graph diffusion), ogbn-arxiv d=128 rk4',
     'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
@@ -215,10 +235,11 @@ def main():
                'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
                'long_rows': graph.n_long_rows, 'algorithmic_bytes_per_rhs_eval': bytes_eval,
                'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
-    'roofline': {'kernel': 'spmm_rows_kernel (CSR aggregation + fused epilogue / rk4 stage)', 'bound': 'hbm',
+    'roofline': {'kernel': kname, 'bound': 'hbm',
                  'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                  'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                 'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2)},
+                 'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2),
+                 'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d)},
   }
   if not args.no_cpu_baseline:
     t_eval, ref = cpu_baseline(main_block, x_cpu, args.cpu_evals)

@@ -19,6 +19,7 @@ STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4 = range(2)
+TUNE_SPMM_VARIANT, TUNE_FUSED_BLOCKS_PER_CU, TUNE_ONE_PASS, TUNE_FORK = range(4)
 
 ATT_TYPES = {'scaled_dot': ATT_SCALED_DOT, 'cosine_sim': ATT_COSINE, 'pearson': ATT_PEARSON,
              'exp_kernel': ATT_EXP_KERNEL}
@@ -32,7 +33,7 @@ class GraphStruct(ctypes.Structure):
               ('long_rows', c_vp), ('long_chunk_ptr', c_vp), ('long_chunk_row', c_vp),
               ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp),
               ('n_long_cols', ctypes.c_int32), ('n_bin16', ctypes.c_int32), ('n_bin64', ctypes.c_int32),
-              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('reserved_', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp)]
+              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('reserved_', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp)]
 
 
 class EpilogueStruct(ctypes.Structure):
@@ -63,7 +64,7 @@ PROTOTYPES = {
   'gnpde_last_error': (ctypes.c_char_p, []),
   'gnpde_tune': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
   'gnpde_graph_count_long': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32, c_int_p, c_int_p, c_int_p]),
-  'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 14),
+  'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 15),
   'gnpde_partition_rows': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_uint64, c_vp]),
   'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),
@@ -76,6 +77,11 @@ PROTOTYPES = {
   'gnpde_attention_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),
   'gnpde_edge_attention': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct),
                                           c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_attn_rhs_fused_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_attn_rhs_fused_supported': (ctypes.c_int, [ctypes.POINTER(AttentionStruct), ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_attn_rhs_fused': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp, c_vp, c_vp,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(EpilogueStruct), c_vp,
+                                          ctypes.c_size_t, c_vp]),
   'gnpde_edge_to_csr_mean': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_solver_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
   'gnpde_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.c_int32,

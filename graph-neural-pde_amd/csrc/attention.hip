@@ -314,6 +314,78 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(const AttArgs a) {
   }
 }
 
+// ---- hub rows of the fused path (softmax over the row, head-mean weights only), two launches:
+// (a) one block per 512-entry chunk: scores -> scratch, chunk maximum and sum of exponentials per head
+// (b) one block per chunk: fold the row's chunk partials (<= max_chunks of them) and write the weights
+template <int TYPE, bool VEC4>
+__global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArgs a, float* __restrict__ part) {
+  __shared__ float red[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int b = a.chunk_begin[blockIdx.x], e = a.chunk_end[blockIdx.x];
+  const int row = a.rowidx[b];
+  float* out = part + static_cast<size_t>(blockIdx.x) * 2 * a.h;
+  for (int head = 0; head < a.h; ++head) {
+    float sv[GNPDE_LONG_ROW / kBlock];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < GNPDE_LONG_ROW / kBlock; ++i) {
+      const int p = b + i * kBlock + threadIdx.x;
+      sv[i] = -INFINITY;
+      if (p < e) {
+        sv[i] = edge_score<TYPE, VEC4>(a, p, row, a.colidx[p], head);
+        a.scores[static_cast<size_t>(p) * a.h + head] = sv[i];
+        mx = fmaxf(mx, sv[i]);
+      }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNPDE_LONG_ROW / kBlock; ++i) sum += expf(sv[i] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      out[head] = m;
+      out[a.h + head] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hub_normalise_kernel(const AttArgs a, const float* __restrict__ part,
+                                                              const int* __restrict__ long_chunk_row_first) {
+  // long_chunk_row_first[c] = index of the first chunk of the row chunk c belongs to
+  extern __shared__ float st[];  // [2h]: row maximum and denominator per head
+  const int c = blockIdx.x;
+  const int b = a.chunk_begin[c], e = a.chunk_end[c];
+  const int row = a.rowidx[b];
+  const int c0 = long_chunk_row_first[c];
+  const int nch = (a.rowptr[row + 1] - a.rowptr[row] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+  if (threadIdx.x < a.h) {
+    const int head = threadIdx.x;
+    float m = -INFINITY;
+    for (int i = 0; i < nch; ++i) m = fmaxf(m, part[static_cast<size_t>(c0 + i) * 2 * a.h + head]);
+    float l = 0.f;
+    for (int i = 0; i < nch; ++i) {
+      const float* q = part + static_cast<size_t>(c0 + i) * 2 * a.h;
+      l += q[a.h + head] * expf(q[head] - m);
+    }
+    st[head] = m;
+    st[a.h + head] = l + 1e-16f;
+  }
+  __syncthreads();
+  for (int p = b + threadIdx.x; p < e; p += kBlock) {
+    float acc = 0.f;
+    for (int head = 0; head < a.h; ++head)
+      acc += expf(a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) / st[a.h + head];
+    a.w_mean[p] = acc / static_cast<float>(a.h);
+  }
+}
+
 // ---- fused path: softmax over the row, head-mean weights only.
 // GL lanes own one row; inside a group lane = (edge slot, head) with the head fastest, so the H lanes
 // of an edge read one contiguous A-float row of k (one 16-byte load each when d_k = 4) and a pass covers
@@ -327,10 +399,14 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
   const int slot = gi / H, head = gi % H;
   const long long ridx = (static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL;
   const bool live = ridx < n_rows;
-  int row = live ? a.bin_rows[first_row + ridx] : 0;
-  if constexpr (GL == kWave) row = __builtin_amdgcn_readfirstlane(row);
-  const int e0 = live ? a.rowptr[row] : 0;
-  const int e1 = live ? a.rowptr[row + 1] : 0;
+  int4 info = make_int4(0, 0, 0, 0);  // {row, first CSR position, length, -}
+  if (live) info = reinterpret_cast<const int4*>(a.bin_rows)[first_row + ridx];
+  int row = info.x, e0 = info.y, e1 = info.y + info.z;
+  if constexpr (GL == kWave) {
+    row = __builtin_amdgcn_readfirstlane(row);
+    e0 = __builtin_amdgcn_readfirstlane(e0);
+    e1 = __builtin_amdgcn_readfirstlane(e1);
+  }
   int npass = P;  // passes that hold any edge (wave-uniform when a wavefront owns one row)
   if constexpr (GL == kWave) npass = (e1 - e0 + GE - 1) / GE;
 
@@ -398,7 +474,9 @@ inline unsigned stream_grid(long long work_items) {
 inline size_t long_slots_of(const gnpde_graph_t* g) {
   const size_t rc = static_cast<size_t>(g->n_long_rows) * ((g->max_row_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW);
   const size_t cc = static_cast<size_t>(g->n_long_cols) * ((g->max_col_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW);
-  return rc > cc ? rc : cc;
+  const size_t lc = static_cast<size_t>(g->n_long_chunks);
+  const size_t m = rc > cc ? rc : cc;
+  return m > lc ? m : lc;
 }
 
 struct AttLayout {
@@ -462,6 +540,22 @@ bool launch_rows_t(const AttArgs& a, int n16, int n64, hipStream_t s) {
   }
 }
 
+template <int TYPE>
+void launch_hub_a(const AttArgs& c, bool vec4, float* part, int n_chunks, hipStream_t s) {
+  if (vec4) hipLaunchKernelGGL((hub_scores_partial_kernel<TYPE, true>), dim3(n_chunks), dim3(kBlock), 0, s, c, part);
+  else hipLaunchKernelGGL((hub_scores_partial_kernel<TYPE, false>), dim3(n_chunks), dim3(kBlock), 0, s, c, part);
+}
+
+void launch_hub_a_any(const AttArgs& c, bool vec4, float* part, int n_chunks, hipStream_t s) {
+  switch (c.type) {
+    case GNPDE_ATT_SCALED_DOT: launch_hub_a<GNPDE_ATT_SCALED_DOT>(c, vec4, part, n_chunks, s); break;
+    case GNPDE_ATT_COSINE: launch_hub_a<GNPDE_ATT_COSINE>(c, vec4, part, n_chunks, s); break;
+    case GNPDE_ATT_PEARSON: launch_hub_a<GNPDE_ATT_PEARSON>(c, vec4, part, n_chunks, s); break;
+    case GNPDE_ATT_EXP_KERNEL: launch_hub_a<GNPDE_ATT_EXP_KERNEL>(c, vec4, part, n_chunks, s); break;
+    default: launch_hub_a<GNPDE_ATT_GAT>(c, false, part, n_chunks, s); break;
+  }
+}
+
 // fused row kernels exist for these (type, heads, alignment) combinations
 bool fused_supported(const AttArgs& a, bool vec4) {
   if (!(a.h == 1 || a.h == 2 || a.h == 4 || a.h == 8)) return false;
@@ -483,7 +577,7 @@ void launch_rows_any(const AttArgs& a, int n16, int n64, hipStream_t s) {
 }  // namespace
 
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
-                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream) {
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork) {
   GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
   GNPDE_CHECK_ARG(w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
   GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
@@ -539,22 +633,22 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   const bool fused = a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
                      g->bin_rows != nullptr && fused_supported(a, vec4);
   if (fused) {
-    launch_rows_any(a, g->n_bin16, g->n_bin64, stream);
-    GNPDE_LAUNCH_CHECK();
-    if (g->n_long_rows > 0) {  // hubs: the general passes restricted to the long rows' chunks
+    hipStream_t br = stream;
+    if (g->n_long_rows > 0) {  // hubs: the general passes restricted to the long rows' chunks, as a parallel branch
+      br = fork_begin(fork, stream);
       AttArgs c = a;
       c.chunk_begin = g->long_chunk_begin;
       c.chunk_end = g->long_chunk_end;
       c.long_segs = g->long_rows;
-      launch_scores_any(c, vec4, static_cast<unsigned>(g->n_long_chunks), stream);
+      launch_hub_a_any(c, vec4, part, g->n_long_chunks, br);
       GNPDE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(seg_stats_long_partial_kernel, dim3(n_long, max_chunks), dim3(kBlock), 0, stream, c, part, max_chunks);
-      GNPDE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(seg_stats_long_combine_kernel, dim3(n_long), dim3(kWave), 0, stream, c, part, max_chunks);
-      GNPDE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 0, stream, c);
+      hipLaunchKernelGGL(hub_normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 2 * a.h * sizeof(float), br, c, part,
+                         g->long_chunk_first);
       GNPDE_LAUNCH_CHECK();
     }
+    launch_rows_any(a, g->n_bin16, g->n_bin64, stream);
+    GNPDE_LAUNCH_CHECK();
+    if (g->n_long_rows > 0) fork_end(fork, stream, br);
     return 0;
   }
 
@@ -588,7 +682,7 @@ extern "C" size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const 
 extern "C" int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a, float* w_mean_csr, float* att_edge,
                                     float* prods_edge, void* workspace, size_t workspace_bytes, void* stream) {
   return gnpde::launch_edge_attention(g, a, w_mean_csr, att_edge, prods_edge, workspace, workspace_bytes,
-                                      static_cast<hipStream_t>(stream));
+                                      static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" int gnpde_edge_to_csr_mean(const gnpde_graph_t* g, const float* src_edge, int32_t h, float* w_csr, void* stream) {

@@ -60,12 +60,35 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
 }
 
 // kernel-variant knobs for A/B measurements (gnpde_tune); 0 = the default variant
-enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_COUNT = 8 };
+enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_FUSED_BLOCKS_PER_CU = 1, GNPDE_TUNE_ONE_PASS = 2, GNPDE_TUNE_FORK = 3, GNPDE_TUNE_COUNT = 8 };
 extern int g_tune[GNPDE_TUNE_COUNT];
+
+// Optional second stream for the hub-row work of a launch sequence.  The long-row passes touch rows
+// disjoint from the main kernels', so they run as a parallel branch: fork_begin makes `aux` wait for
+// everything queued on `s`, fork_end makes `s` wait for the branch.  Inside stream capture this becomes
+// a fork/join in the hipGraph; with aux == nullptr everything stays on one stream.
+struct Fork {
+  hipStream_t aux = nullptr;
+  hipEvent_t e_fork = nullptr;
+  hipEvent_t e_join = nullptr;
+};
+
+inline hipStream_t fork_begin(const Fork* f, hipStream_t s) {
+  if (f == nullptr || f->aux == nullptr) return s;
+  if (hipEventRecord(f->e_fork, s) != hipSuccess) return s;
+  if (hipStreamWaitEvent(f->aux, f->e_fork, 0) != hipSuccess) return s;
+  return f->aux;
+}
+
+inline void fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
+  if (branch == s) return;
+  (void)hipEventRecord(f->e_join, branch);
+  (void)hipStreamWaitEvent(s, f->e_join, 0);
+}
 
 // internal launchers used by the solver (defined in the kernel translation units)
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
-                    hipStream_t stream);
+                    hipStream_t stream, const Fork* fork = nullptr);
 
 }  // namespace gnpde

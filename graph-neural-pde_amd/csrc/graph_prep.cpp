@@ -53,7 +53,7 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
                                  int32_t* cscptr, int32_t* cscpos, int32_t* long_rows,
                                  int32_t* long_chunk_ptr, int32_t* long_chunk_row,
                                  int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
-                                 int32_t* bin_rows, int32_t* bin_counts) {
+                                 int32_t* bin_rows, int32_t* bin_counts, int32_t* long_chunk_first) {
   GNPDE_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (int64_t(1) << 31), GNPDE_EINVAL,
                   "graph_build: bad sizes n=%d e=%lld", n_nodes, (long long)n_edges);
   GNPDE_CHECK_ARG(rowptr && (n_edges == 0 || (row && col && colidx && perm && rowidx)), GNPDE_EINVAL,
@@ -95,6 +95,7 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
       long_chunk_ptr[lr] = lc;
       for (int32_t s = b; s < e; s += GNPDE_LONG_ROW) {
         long_chunk_row[lc] = i;
+        if (long_chunk_first) long_chunk_first[lc] = long_chunk_ptr[lr];
         long_chunk_begin[lc] = s;
         long_chunk_end[lc] = std::min(e, s + GNPDE_LONG_ROW);
         ++lc;
@@ -116,10 +117,16 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
       else if (dg > 16 && dg <= GNPDE_LONG_ROW) ++n64;
     }
     int32_t p16 = 0, p64 = n16;
+    auto put = [&](int32_t slot, int32_t i, int32_t dg) {
+      bin_rows[4 * slot + 0] = i;
+      bin_rows[4 * slot + 1] = rowptr[i];
+      bin_rows[4 * slot + 2] = dg;
+      bin_rows[4 * slot + 3] = 0;
+    };
     for (int32_t i = 0; i < n_nodes; ++i) {
       const int32_t dg = rowptr[i + 1] - rowptr[i];
-      if (dg >= 1 && dg <= 16) bin_rows[p16++] = i;
-      else if (dg > 16 && dg <= GNPDE_LONG_ROW) bin_rows[p64++] = i;
+      if (dg >= 1 && dg <= 16) put(p16++, i, dg);
+      else if (dg > 16 && dg <= GNPDE_LONG_ROW) put(p64++, i, dg);
     }
     bin_counts[0] = n16;
     bin_counts[1] = n64;

@@ -59,21 +59,31 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kb = 0; kb < d; kb += 16) {
-    const int k = kb + 4 * kq;
-    const f32x4 av = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
-    f32x4 bv[MT];
+  // KU 16-wide K blocks per iteration: all operand loads of an iteration are issued before the first
+  // MFMA so that several HBM round trips overlap (a wave has only d/16 dependent-free blocks to hide
+  // ~2 us of latency behind)
+  constexpr int KU = MT <= 2 ? 4 : 2;
+  for (int kb = 0; kb < d; kb += 16 * KU) {
+    f32x4 av[KU];
+    f32x4 bv[KU][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int col = col_base + t * 16 + r;
-      const bool ok = col < m;
-      bv[t] = load4_guard<ALIGNED>(W + static_cast<size_t>(ok ? col : 0) * ldw, k, d, ok);
+    for (int u = 0; u < KU; ++u) {
+      const int k = kb + 16 * u + 4 * kq;
+      av[u] = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int col = col_base + t * 16 + r;
+        const bool ok = col < m;
+        bv[u][t] = load4_guard<ALIGNED>(W + static_cast<size_t>(ok ? col : 0) * ldw, k, d, ok);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < KU; ++u)
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t][i], acc[t], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][t][i], acc[t], 0, 0, 0);
   }
 
   // C/D layout of the 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg

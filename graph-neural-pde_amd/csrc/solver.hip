@@ -15,14 +15,19 @@ namespace gnpde {
 int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                       int ldo, hipStream_t s);
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
-                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream);
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
+size_t fused_attn_workspace_bytes(const gnpde_graph_t* g, int d, int heads);
+bool fused_attn_supported(const gnpde_attention_t& at, int d, int ld, const void* u, const gnpde_epilogue_t* epi);
+int launch_attn_rhs_fused(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* proj_w, const float* proj_b,
+                          const float* u, int d, int ld, const gnpde_epilogue_t* epi, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
 
 namespace {
 
 struct RhsLayout {
-  size_t proj, wmean, att, spmm, total;
-  size_t att_bytes, spmm_bytes;
+  size_t proj, wmean, att, spmm, fused, total;
+  size_t att_bytes, spmm_bytes, fused_bytes;
 };
 
 RhsLayout rhs_layout(const gnpde_rhs_t& r) {
@@ -38,6 +43,11 @@ RhsLayout rhs_layout(const gnpde_rhs_t& r) {
     L.att = off;
     L.att_bytes = attention_workspace_bytes(&g, r.att.heads, r.kind == GNPDE_RHS_GAT);
     off += align_up(L.att_bytes, 256);
+    if (r.kind == GNPDE_RHS_TRANSFORMER) {
+      L.fused = off;
+      L.fused_bytes = fused_attn_workspace_bytes(&g, r.d, r.att.heads);
+      off += align_up(L.fused_bytes, 256);
+    }
   }
   L.total = off;
   return L;
@@ -61,9 +71,14 @@ int check_rhs(const gnpde_rhs_t* r) {
 
 // Enqueue f(u) with the given epilogue.  `ws` follows rhs_layout.
 int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, char* ws, const RhsLayout& L,
-                hipStream_t s) {
+                hipStream_t s, const Fork* fork = nullptr) {
   const gnpde_graph_t* g = r.graph;
   const float* w = r.w_csr;
+  if (r.kind == GNPDE_RHS_TRANSFORMER && fused_attn_supported(r.att, r.d, r.ld, u, &epi) &&
+      reinterpret_cast<uintptr_t>(r.proj_w) % 16 == 0) {
+    // scaled-dot attention, softmax over rows: projection + attention + aggregation + epilogue in one pass
+    return launch_attn_rhs_fused(g, &r.att, r.proj_w, r.proj_b, u, r.d, r.ld, &epi, ws + L.fused, L.fused_bytes, s);
+  }
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
     float* proj = reinterpret_cast<float*>(ws + L.proj);
     float* wmean = reinterpret_cast<float*>(ws + L.wmean);
@@ -73,11 +88,11 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     at.ldqk = r.proj_m;
     at.q = proj;
     at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
-    rc = launch_edge_attention(g, &at, wmean, nullptr, nullptr, ws + L.att, L.att_bytes, s);
+    rc = launch_edge_attention(g, &at, wmean, nullptr, nullptr, ws + L.att, L.att_bytes, s, fork);
     if (rc) return rc;
     w = wmean;
   }
-  return launch_spmm_rhs(g, w, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s);
+  return launch_spmm_rhs(g, w, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s, fork);
 }
 
 gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r) {
@@ -104,6 +119,7 @@ struct gnpde_solver {
   RhsLayout L;
   size_t off_k1, off_k2, off_k3, off_ua, off_ub, off_rhs;
   hipStream_t cap_stream = nullptr;
+  Fork fork;                 // second stream + events for the hub-row branch
   hipGraph_t graph_obj = nullptr;
   hipGraphExec_t exec = nullptr;
   float* captured_y = nullptr;
@@ -131,8 +147,21 @@ size_t solver_layout(const gnpde_rhs_t& r, int method, gnpde_solver* s) {
   return off;
 }
 
+int ensure_fork(gnpde_solver* s) {
+  if (s->fork.aux != nullptr) return 0;
+  GNPDE_HIP(hipStreamCreateWithFlags(&s->fork.aux, hipStreamNonBlocking));
+  GNPDE_HIP(hipEventCreateWithFlags(&s->fork.e_fork, hipEventDisableTiming));
+  GNPDE_HIP(hipEventCreateWithFlags(&s->fork.e_join, hipEventDisableTiming));
+  return 0;
+}
+
 int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
   const gnpde_rhs_t& r = s->rhs;
+  const Fork* fk = (s->rhs.graph->n_long_rows > 0 && g_tune[GNPDE_TUNE_FORK] == 1) ? &s->fork : nullptr;  // opt-in: cross-stream joins cost more than they hide
+  if (fk != nullptr) {
+    const int frc = ensure_fork(s);
+    if (frc) return frc;
+  }
   char* rws = s->ws + s->off_rhs;
   float* ua = reinterpret_cast<float*>(s->ws + s->off_ua);
   if (s->method == GNPDE_METHOD_EULER) {
@@ -141,7 +170,7 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
     for (float dt : s->dts) {
       gnpde_epilogue_t e = base_epilogue(r);
       e.stage = GNPDE_STAGE_EULER; e.dt = dt; e.y = cur; e.out_y = nxt;
-      int rc = enqueue_rhs(r, cur, e, rws, s->L, st);
+      int rc = enqueue_rhs(r, cur, e, rws, s->L, st, fk);
       if (rc) return rc;
       float* t = cur; cur = nxt; nxt = t;
     }
@@ -157,16 +186,16 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
     gnpde_epilogue_t e = base_epilogue(r);
     e.dt = dt; e.y = y;
     e.stage = GNPDE_STAGE_RK1; e.out_k = k1; e.out_y = ua;
-    int rc = enqueue_rhs(r, y, e, rws, s->L, st);
+    int rc = enqueue_rhs(r, y, e, rws, s->L, st, fk);
     if (rc) return rc;
     e.stage = GNPDE_STAGE_RK2; e.k1 = k1; e.out_k = k2; e.out_y = ub;
-    rc = enqueue_rhs(r, ua, e, rws, s->L, st);
+    rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
     if (rc) return rc;
     e.stage = GNPDE_STAGE_RK3; e.k2 = k2; e.out_k = k3; e.out_y = ua;
-    rc = enqueue_rhs(r, ub, e, rws, s->L, st);
+    rc = enqueue_rhs(r, ub, e, rws, s->L, st, fk);
     if (rc) return rc;
     e.stage = GNPDE_STAGE_RK4; e.k3 = k3; e.out_k = nullptr; e.out_y = y;
-    rc = enqueue_rhs(r, ua, e, rws, s->L, st);
+    rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
     if (rc) return rc;
   }
   return 0;
@@ -266,6 +295,9 @@ extern "C" int gnpde_solver_destroy(gnpde_solver_t* s) {
   if (!s) return 0;
   drop_graph(s);
   if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+  if (s->fork.aux) (void)hipStreamDestroy(s->fork.aux);
+  if (s->fork.e_fork) (void)hipEventDestroy(s->fork.e_fork);
+  if (s->fork.e_join) (void)hipEventDestroy(s->fork.e_join);
   delete s;
   return 0;
 }

@@ -12,66 +12,13 @@
 // atomics).  Rows longer than GNPDE_LONG_ROW are processed as independent chunks into a partial
 // buffer and summed by a second small kernel, so a 13k-degree hub does not serialise on one wave.
 #include "common.h"
+#include "epilogue.h"
 
 namespace gnpde {
 namespace {
 
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if constexpr (VEC == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    v[0] = t.x; v[1] = t.y;
-  } else {
-    v[0] = *p;
-  }
-}
-
-// streaming (touched once per launch) variants: nontemporal hint keeps the gathered rows in L2
-template <int VEC>
-__device__ __forceinline__ void load_vec_nt(const float* __restrict__ p, float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
-    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-  } else if constexpr (VEC == 2) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
-    v[0] = t[0]; v[1] = t[1];
-  } else {
-    v[0] = __builtin_nontemporal_load(p);
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 t = {v[0], v[1], v[2], v[3]};
-    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
-  } else if constexpr (VEC == 2) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 t = {v[0], v[1]};
-    __builtin_nontemporal_store(t, reinterpret_cast<f2*>(p));
-  } else {
-    __builtin_nontemporal_store(v[0], p);
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  } else if constexpr (VEC == 2) {
-    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-  } else {
-    *p = v[0];
-  }
-}
-
 struct SpmmArgs {
+  int item_base, item_end;   // work items [item_base, item_end): < n are rows, >= n are long-row chunks
   int n, n_long_chunks;
   const int* __restrict__ rowptr;
   const int* __restrict__ colidx;
@@ -87,85 +34,14 @@ struct SpmmArgs {
   gnpde_epilogue_t ep;
 };
 
-__device__ __forceinline__ float alpha_of(const gnpde_epilogue_t& ep) {
-  const float a = *ep.alpha;
-  return ep.alpha_sigmoid ? 1.0f / (1.0f + expf(-a)) : a;
-}
-
-// k = alpha (ax - u_i) + beta x0_i, then the stage algebra in torchdiffeq's operation order.
-template <int VEC, bool NT>
-__device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off,
-                                         const float (&ax)[VEC], const float (&ui)[VEC]) {
-  // per-row streaming operands (y, k1..k3, x0 in; k, y out) are touched once per launch
-  auto ld = [](const float* p, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(p, v); else load_vec<VEC>(p, v); };
-  auto st = [](float* p, const float (&v)[VEC]) { if constexpr (NT) store_vec_nt<VEC>(p, v); else store_vec<VEC>(p, v); };
-  constexpr float kThird = 1.0f / 3.0f;
-  float k[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) k[v] = alpha * (ax[v] - ui[v]);
-  if (ep.x0 != nullptr) {
-    float s[VEC];
-    ld(ep.x0 + off, s);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
-  }
-  const float dt = ep.dt;
-  float y[VEC], a[VEC], b[VEC], c[VEC], o[VEC];
-  switch (ep.stage) {
-    case GNPDE_STAGE_RHS:
-      st(ep.out_k + off, k);
-      break;
-    case GNPDE_STAGE_EULER:
-      ld(ep.y + off, y);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * k[v];
-      st(ep.out_y + off, o);
-      break;
-    case GNPDE_STAGE_RK1:
-      ld(ep.y + off, y);
-      st(ep.out_k + off, k);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = y[v] + (dt * k[v]) * kThird;
-      st(ep.out_y + off, o);
-      break;
-    case GNPDE_STAGE_RK2:
-      ld(ep.y + off, y);
-      ld(ep.k1 + off, a);
-      st(ep.out_k + off, k);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * (k[v] - a[v] * kThird);
-      st(ep.out_y + off, o);
-      break;
-    case GNPDE_STAGE_RK3:
-      ld(ep.y + off, y);
-      ld(ep.k1 + off, a);
-      ld(ep.k2 + off, b);
-      st(ep.out_k + off, k);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = y[v] + dt * ((a[v] - b[v]) + k[v]);
-      st(ep.out_y + off, o);
-      break;
-    case GNPDE_STAGE_RK4:
-      ld(ep.y + off, y);
-      ld(ep.k1 + off, a);
-      ld(ep.k2 + off, b);
-      ld(ep.k3 + off, c);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = y[v] + (((a[v] + 3.0f * (b[v] + c[v])) + k[v]) * dt) * 0.125f;
-      st(ep.out_y + off, o);
-      break;
-    default:
-      break;
-  }
-}
-
 template <int VEC, int L, int K, int U, bool NTI, bool NT>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
   constexpr int G = kWave / L;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blk) * kWavesPerBlock + wave);
+  const int item = __builtin_amdgcn_readfirstlane(a.item_base + static_cast<int>(blk) * kWavesPerBlock + wave);
+  if (item >= a.item_end) return;
   const int sub = lane / L;   // neighbour slot
   const int cl = lane % L;    // column lane
 
@@ -285,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(const SpmmArgs
 
 template <int VEC, int L, int K, int U, bool NTI, bool NT = NTI>
 void launch_rows(const SpmmArgs& a, hipStream_t s) {
-  const long long items = static_cast<long long>(a.n) + a.n_long_chunks;
+  const long long items = static_cast<long long>(a.item_end) - a.item_base;
   const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
   hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K, U, NTI, NT>), dim3(grid), dim3(kBlock), 0, s, a);
 }
@@ -337,7 +213,8 @@ inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpr
 }  // namespace
 
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
-                    const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+                    const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes, hipStream_t stream,
+                    const Fork* fork) {
   GNPDE_CHECK_ARG(g && u && (w_csr || g->e == 0), GNPDE_EINVAL, "spmm: null pointer");
   GNPDE_CHECK_ARG(d >= 1 && ld >= d, GNPDE_EINVAL, "spmm: bad d=%d ld=%d", d, ld);
   GNPDE_CHECK_ARG((epi != nullptr) != (plain_out != nullptr), GNPDE_EINVAL, "spmm: need exactly one of epilogue / plain output");
@@ -387,16 +264,33 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   } else {
     GNPDE_CHECK_ARG(plain_out != u, GNPDE_EINVAL, "spmm: output aliases the gathered operand");
   }
-  int rc;
-  if (a16) rc = dispatch_rows<4>(a, stream);
-  else if (a8) rc = dispatch_rows<2>(a, stream);
-  else rc = dispatch_rows<1>(a, stream);
+  auto run = [&](const SpmmArgs& arg, hipStream_t st) -> int {
+    if (arg.item_end <= arg.item_base) return 0;
+    if (a16) return dispatch_rows<4>(arg, st);
+    if (a8) return dispatch_rows<2>(arg, st);
+    return dispatch_rows<1>(arg, st);
+  };
+  const bool forked = fork != nullptr && fork->aux != nullptr && g->n_long_rows > 0;
+  // rows and long-row chunks in one launch; with a fork the chunks + their reduction run as a parallel branch
+  a.item_base = 0;
+  a.item_end = forked ? g->n : g->n + g->n_long_chunks;
+  int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();
   if (g->n_long_rows > 0) {
-    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, stream, a, g->long_rows,
+    hipStream_t br = forked ? fork_begin(fork, stream) : stream;
+    if (forked) {
+      SpmmArgs c = a;
+      c.item_base = g->n;
+      c.item_end = g->n + g->n_long_chunks;
+      rc = run(c, br);
+      if (rc != 0) return rc;
+      GNPDE_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
                        g->long_chunk_ptr);
     GNPDE_LAUNCH_CHECK();
+    if (forked) fork_end(fork, stream, br);
   }
   return 0;
 }

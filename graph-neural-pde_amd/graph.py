@@ -40,13 +40,15 @@ class CSRGraph(object):
       'long_chunk_begin': np.zeros(max(self.n_long_chunks, 1), np.int32),
       'long_chunk_end': np.zeros(max(self.n_long_chunks, 1), np.int32),
       'long_cols': np.zeros(max(self.n_long_cols, 1), np.int32),
-      'bin_rows': np.zeros(max(self.n, 1), np.int32),
+      'bin_rows': np.zeros(4 * max(self.n, 1), np.int32),
+      'long_chunk_first': np.zeros(max(self.n_long_chunks, 1), np.int32),
     }
     bin_counts = np.zeros(2, np.int32)
     order = ['rowptr', 'colidx', 'perm', 'rowidx', 'cscptr', 'cscpos', 'long_rows', 'long_chunk_ptr',
              'long_chunk_row', 'long_chunk_begin', 'long_chunk_end', 'long_cols', 'bin_rows']
     _lib.check(L.gnpde_graph_build(row.ctypes.data, col.ctypes.data, self.e, self.n,
-                                   *([host[k].ctypes.data for k in order] + [bin_counts.ctypes.data])))
+                                   *([host[k].ctypes.data for k in order] + [bin_counts.ctypes.data,
+                                                                              host['long_chunk_first'].ctypes.data])))
     self.n_bin16, self.n_bin64 = int(bin_counts[0]), int(bin_counts[1])
     self.t = {k: torch.from_numpy(v).to(device) for k, v in host.items()}
     self.perm_long = self.t['perm'][:self.e].long()
@@ -58,7 +60,7 @@ class CSRGraph(object):
     self.max_row_len = int((rp[1:] - rp[:-1]).max()) if self.n > 0 else 0
     self.max_col_len = int((cp[1:] - cp[:-1]).max()) if self.n > 0 else 0
     s.max_row_len, s.max_col_len = self.max_row_len, self.max_col_len
-    for k in order:
+    for k in order + ['long_chunk_first']:
       setattr(s, k, self.t[k].data_ptr())
     self.struct = s
     self._ws = {}

@@ -120,6 +120,31 @@ def edge_attention(graph, att, want_w_mean=True, want_att=False, want_prods=Fals
   return w, a_out, p_out
 
 
+def attn_rhs_fused(graph, att, proj_w, proj_b, u, alpha, beta=None, x0=None, alpha_sigmoid=True, out=None, **stage_kw):
+  """One-pass GRAND-nl evaluation (gnpde_attn_rhs_fused); same epilogue / stage arguments as spmm_rhs."""
+  require_hip(u, proj_w, proj_b, x0)
+  u = f32c(u, 'u')
+  n, d = u.shape
+  alpha_d = _scalar_dev(alpha, u)
+  beta_d = _scalar_dev(beta, u) if x0 is not None else None
+  x0c = f32c(x0, 'x0') if x0 is not None else None
+  if 'stage' not in stage_kw:
+    if out is None:
+      out = torch.empty_like(u)
+    stage_kw = dict(stage=_lib.STAGE_RHS, out_k=out)
+  epi = make_epilogue(alpha_d, beta_d, x0c, alpha_sigmoid, **stage_kw)
+  L = _lib.lib()
+  ws = graph.workspace('fused%d_%d' % (d, att.heads), L.gnpde_attn_rhs_fused_workspace_bytes(graph.ref(), d, att.heads))
+  check(L.gnpde_attn_rhs_fused(graph.ref(), ctypes.byref(att), ptr(proj_w), ptr(proj_b), ptr(u), d, u.stride(0),
+                               ctypes.byref(epi), ptr(ws), ws.numel(), stream_of(u)))
+  return out
+
+
+def tune(key, value):
+  """Kernel-variant knob for A/B measurements (gnpde_tune)."""
+  check(_lib.lib().gnpde_tune(int(key), int(value)))
+
+
 class RhsDescriptor(object):
   """Python owner of a gnpde_rhs_t: keeps every tensor the descriptor points to alive."""
 

@@ -62,17 +62,19 @@ int gnpde_graph_count_long(const int64_t* row, const int64_t* col, int64_t n_edg
  *   duplicates keep their relative order), rowidx[E] (row of each CSR position),
  *   cscptr[n+1], cscpos[E] (for every column, the CSR positions of its entries, ascending)  -- may
  *   both be NULL;  long_rows[n_long_rows], long_chunk_ptr[n_long_rows+1],
- *   long_chunk_row/begin/end[n_long_chunks], long_cols[n_long_cols] (NULL without the CSC view);
- *   bin_rows[n]: row ids grouped by degree class -- first the rows with 1..16 entries, then those
- *   with 17..GNPDE_LONG_ROW (empty and long rows are not listed); bin_counts[2] = sizes of the two
- *   classes.  Within a class rows keep ascending order.
+ *   long_chunk_row/begin/end/first[n_long_chunks] (first = index of the first chunk of the same row),
+ *   long_cols[n_long_cols] (NULL without the CSC view);
+ *   bin_rows[4n]: one int32x4 record {row, first CSR position, length, 0} per listed row, grouped by
+ *   degree class -- first the rows with 1..16 entries, then those with 17..GNPDE_LONG_ROW (empty and
+ *   long rows are not listed); bin_counts[2] = sizes of the two classes.  Within a class rows keep
+ *   ascending order.  (One 16-byte load replaces the rowptr indirection in the row-attention kernels.)
  * Returns GNPDE_EINVAL if an index is outside [0, n_nodes). */
 int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
                       int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
                       int32_t* cscptr, int32_t* cscpos,
                       int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* long_chunk_row,
                       int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
-                      int32_t* bin_rows, int32_t* bin_counts);
+                      int32_t* bin_rows, int32_t* bin_counts, int32_t* long_chunk_first);
 
 /* Balanced k-way row partition for the multi-GPU path (no METIS offline): BFS-grown parts balanced
  * on nnz, refined by label propagation.  part[n] receives values in [0, n_parts).  Host only. */
@@ -103,7 +105,8 @@ typedef struct gnpde_graph {
   int32_t max_col_len;               /* longest column (0 without the CSC view)              */
   int32_t reserved_;
   const int32_t* long_cols;          /* [n_long_cols] or NULL                                */
-  const int32_t* bin_rows;           /* [n_bin16 + n_bin64]                                  */
+  const int32_t* bin_rows;           /* [(n_bin16 + n_bin64) * 4] records {row, begin, len, 0} */
+  const int32_t* long_chunk_first;   /* [n_long_chunks] index of the first chunk of the same row */
 } gnpde_graph_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -207,6 +210,23 @@ size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_atten
 int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a,
                          float* w_mean_csr, float* att_edge, float* prods_edge,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRAND-nl evaluation in ONE pass (the solver's hot case): scaled-dot attention, softmax over the row
+ * (attention_norm_idx 0, no squareplus), head-mean aggregation, epilogue and solver stage.
+ * Replaces the whole of ODEFuncTransformerAtt.forward (src/function_transformer_attention.py:38-53,
+ * incl. the Q/K Linear layers :174-175) with a single gather of every neighbour row: the score is
+ * evaluated as ((W_k,h^T q_i,h) . x_j + q_i,h . b_k,h) / sqrt(d_k), so neither the [N,2A] projection nor
+ * [E,h] scores nor [E] weights are materialised.  proj_w = [Q.weight; K.weight] ([2A, d], 16-byte
+ * aligned), proj_b = [Q.bias; K.bias] or NULL.  att->q / att->k are ignored; att->edge_w_csr is honoured.
+ * gnpde_attn_rhs_fused_supported tells whether the configuration is covered (else use gnpde_linear +
+ * gnpde_edge_attention + gnpde_spmm_rhs, which compute the same function).
+ * ---------------------------------------------------------------------------------------------- */
+size_t gnpde_attn_rhs_fused_workspace_bytes(const gnpde_graph_t* g, int32_t d, int32_t heads);
+int gnpde_attn_rhs_fused_supported(const gnpde_attention_t* att, int32_t d, int32_t ld);
+int gnpde_attn_rhs_fused(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* proj_w,
+                         const float* proj_b, const float* u, int32_t d, int32_t ld,
+                         const gnpde_epilogue_t* epi, void* workspace, size_t workspace_bytes, void* stream);
 
 /* w_csr[p] = mean_h src[perm[p], :]   (src [E,h] in the caller's edge order; h = 1: plain gather).
  * Used when a block hands attention_weights / edge_weight in edge order

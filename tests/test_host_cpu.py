@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_structs_match_header_layout():
   # pointer-sized fields and int32s only: sizes are what the C compiler produces on x86-64
-  assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 2 * 8
+  assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 3 * 8
   assert ctypes.sizeof(_lib.EpilogueStruct) == 3 * 8 + 4 + 4 + 4 + 4 + 6 * 8
   assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8
 
@@ -63,8 +63,9 @@ def test_graph_build_matches_numpy(seed):
   b, e_ = g.t['long_chunk_begin'][:g.n_long_chunks].numpy(), g.t['long_chunk_end'][:g.n_long_chunks].numpy()
   assert np.all(e_ - b <= _lib.LONG_ROW) and (e_ - b).sum() == deg[long_rows].sum()
   # degree classes
-  bins = g.t['bin_rows'].numpy()
-  b16, b64 = bins[:g.n_bin16], bins[g.n_bin16:g.n_bin16 + g.n_bin64]
+  rec = g.t['bin_rows'].numpy().reshape(-1, 4)[:g.n_bin16 + g.n_bin64]
+  assert np.array_equal(rec[:, 1], g.rowptr.numpy()[rec[:, 0]]) and np.array_equal(rec[:, 2], deg[rec[:, 0]])
+  b16, b64 = rec[:g.n_bin16, 0], rec[g.n_bin16:, 0]
   assert np.array_equal(b16, np.nonzero((deg >= 1) & (deg <= 16))[0])
   assert np.array_equal(b64, np.nonzero((deg > 16) & (deg <= _lib.LONG_ROW))[0])
   cdeg = np.bincount(col, minlength=n)

@@ -150,3 +150,40 @@ def test_other_functions_medium(dev, function, block):
                                      cpu(lay.K.bias), 2, edge_weights=cpu(f.edge_weight), reweight=False)
     rhs = lambda t, y: R.rhs_laplacian(y, cpu(f.edge_index), att, cpu(f.alpha_train), cpu(f.beta_train), x, False, True)
   assert_parity(z, R.odeint_fixed(rhs, x, 2.5, 1.0, 'rk4'), what='%s/%s' % (function, block))
+
+
+@pytest.mark.parametrize('heads,att_dim,d', [(4, 16, 128), (8, 128, 80), (1, 8, 36), (2, 32, 256), (4, 64, 128), (8, 64, 256),
+                                             (4, 16, 320)])
+@pytest.mark.parametrize('source', [True, False])
+def test_one_pass_kernel_vs_multi_kernel_and_oracle(dev, heads, att_dim, d, source):
+  """The one-pass GRAND-nl kernel (score = (W_k^T q) . x_j + q . b_k) against the projection + attention +
+  aggregation kernels and against the oracle, incl. hub rows, reweighting off, several widths."""
+  from gnpde_amd import ops, _lib
+  from helpers import random_graph
+  n = 2500
+  ei = random_graph(n, 7, seed=heads + d, hubs=2, hub_deg=1400, isolated=0, dup=30)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(d))
+  opt = dict(BASE, heads=heads, attention_dim=att_dim, hidden_dim=d, add_source=source, self_loop_weight=0)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev, seed=heads)
+  with torch.no_grad():
+    for p in (block.odefunc.multihead_att_layer.Q.bias, block.odefunc.multihead_att_layer.K.bias):
+      p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(3)).to(dev) * 0.3)
+  f = block.odefunc
+  f.x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(9)).to(dev)
+  ref = _oracle_rhs(block, f.x0.cpu())(0.0, x)
+  with torch.no_grad():
+    desc = f._descriptor(x.to(dev))
+    assert _lib.lib().gnpde_attn_rhs_fused_supported(ctypes_ref(desc.struct.att), d, d) == 1
+    multi = f(0.0, x.to(dev))
+    ops.tune(_lib.TUNE_ONE_PASS, 1)
+    try:
+      got = f(0.0, x.to(dev))
+    finally:
+      ops.tune(_lib.TUNE_ONE_PASS, 0)
+  assert_parity(multi, ref, what='multi-kernel path')
+  assert_parity(got, ref, what='one-pass kernel')
+
+
+def ctypes_ref(struct):
+  import ctypes
+  return ctypes.byref(struct)
