@@ -1,0 +1,289 @@
+"""Row-partitioned multi-GPU solve with a halo exchange per right-hand-side evaluation
+(SURVEY.md section 8e).  One process per GPU, `torch.distributed` ("nccl" == RCCL over xGMI).
+
+The reference is single-device (only `nn.DataParallel` wrappers in its HPO scripts,
+ray_tune.py:65-66, which are wrong for a full-graph model).  Here the nodes are split into P parts by
+the native k-way partitioner; rank p owns the rows V_p of the operator and of the state.  Its local
+graph numbers owned columns first and halo columns after them, grouped by owning peer in ascending
+global order, so ONE `all_to_all_single` (a grouped send/recv per peer: every xGMI link busy, no ring)
+drops each peer's boundary rows straight into the halo region [n_own, n_own + n_halo) of the stage
+buffer -- no unpack kernel.  The exchange runs once per evaluation (4x per rk4 step: each stage
+evaluates f at a different state).  Keys of halo rows are recomputed locally (k = W_k x is cheaper than
+a second exchange); softmax over rows needs no further collective.
+
+The arithmetic is delegated to a backend object.  The product backend (`NativeBackend`) calls the HIP
+library and refuses to run without a GPU; tests on CPU (gloo, world size 2) inject a checker backend
+built on the oracle to validate partitioning, index maps and the exchange.
+"""
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .graph import CSRGraph, partition_rows
+from .odeint import time_grid
+
+
+# --------------------------------------------------------------------------------------------------
+# partition plan (host, deterministic: every rank computes the same plan from the same inputs)
+# --------------------------------------------------------------------------------------------------
+class PartitionPlan(object):
+  def __init__(self, edge_index, n, world, part=None, refine_iters=8):
+    ei = edge_index.detach().cpu().long()
+    self.n, self.world = int(n), int(world)
+    if part is None:
+      g = CSRGraph(ei, n, device='cpu')
+      part = partition_rows(g, world, refine_iters=refine_iters)
+    self.part = part.long()
+    key = self.part * self.n + torch.arange(self.n)
+    self.order = torch.argsort(key)                      # new position -> old node id
+    self.newid = torch.empty(self.n, dtype=torch.long)
+    self.newid[self.order] = torch.arange(self.n)        # old node id -> new position
+    self.counts = torch.bincount(self.part, minlength=world)
+    self.offsets = torch.zeros(world + 1, dtype=torch.long)
+    self.offsets[1:] = torch.cumsum(self.counts, 0)
+    self.edge_index = ei
+
+  def edge_cut(self):
+    r, c = self.edge_index
+    return float((self.part[r] != self.part[c]).float().mean())
+
+  def shard(self, rank):
+    return LocalShard(self, rank)
+
+
+class LocalShard(object):
+  """Everything rank `rank` needs: local edge list (rows local, columns local incl. halo), ids of its
+  edges in the global edge list, send list and the per-peer row counts of the exchange."""
+
+  def __init__(self, plan, rank):
+    n, P = plan.n, plan.world
+    row, col = plan.edge_index
+    prow, pcol = plan.part[row], plan.part[col]
+    off = plan.offsets
+    mine = prow == rank
+    self.rank, self.world = rank, P
+    self.n_own = int(plan.counts[rank])
+    self.edge_ids = torch.nonzero(mine).flatten()
+    r_new = plan.newid[row[mine]]
+    c_new = plan.newid[col[mine]]
+    c_own = pcol[mine] == rank
+    self.halo_new = torch.unique(c_new[~c_own])          # sorted => grouped by owner, ascending inside
+    self.n_halo = int(self.halo_new.numel())
+    owner = torch.bucketize(self.halo_new, off[1:], right=True)
+    self.recv_counts = torch.bincount(owner, minlength=P).tolist()
+    c_local = torch.where(c_own, c_new - off[rank], self.n_own + torch.searchsorted(self.halo_new, c_new))
+    self.edge_index = torch.stack([r_new - off[rank], c_local])
+    # rows of mine that peers reference: unique (peer, column) pairs over the peers' rows, same order
+    need = (pcol == rank) & (prow != rank)
+    key = torch.unique(prow[need] * n + plan.newid[col[need]])
+    self.send_idx = (key % n) - off[rank]
+    self.send_counts = torch.bincount(key // n, minlength=P).tolist()
+    self.own_old_ids = plan.order[off[rank]:off[rank + 1]]
+
+  @property
+  def n_local(self):
+    return self.n_own + self.n_halo
+
+
+# --------------------------------------------------------------------------------------------------
+# product backend: HIP kernels through the C ABI
+# --------------------------------------------------------------------------------------------------
+class NativeBackend(object):
+  """f(u) with fused solver stage on the local shard.  kind = 'laplacian' (params: edge_weight over
+  the LOCAL edges) or 'transformer' (params: Wq, bq, Wk, bk, heads; scaled-dot, softmax over rows)."""
+
+  def __init__(self, shard, d, device, kind, params, alpha, beta, alpha_sigmoid=True):
+    from . import ops
+    if torch.device(device).type != 'cuda':
+      raise _lib.GnpdeError('the sharded solve runs only on HIP devices; there is no CPU fallback')
+    self.ops, self.dev, self.kind, self.d = ops, torch.device(device), kind, d
+    self.shard = shard
+    self.graph = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
+    self.graph.struct.n = shard.n_own            # rows to process; columns may address halo rows
+    self.graph.n = shard.n_own
+    self.alpha = alpha.detach().to(self.dev, torch.float32).reshape(-1)
+    self.beta = beta.detach().to(self.dev, torch.float32).reshape(-1)
+    self.alpha_sigmoid = alpha_sigmoid
+    self.send_idx = shard.send_idx.to(torch.int32).to(self.dev)
+    if kind == 'laplacian':
+      self.w_csr = ops.edge_to_csr_mean(self.graph, params['edge_weight'].to(self.dev, torch.float32))
+    elif kind == 'transformer':
+      self.wqk = torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32).contiguous()
+      self.bqk = torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32).contiguous()
+      self.heads = int(params['heads'])
+      self.A = self.wqk.shape[0] // 2
+      self.qk = torch.empty(shard.n_local, 2 * self.A, dtype=torch.float32, device=self.dev)
+    else:
+      raise ValueError(kind)
+
+  def empty(self, rows):
+    return torch.empty(rows, self.d, dtype=torch.float32, device=self.dev)
+
+  def pack(self, u, out):
+    """out[i] = u[send_idx[i]] (boundary rows into the send buffer)."""
+    if out.shape[0] == 0:
+      return out
+    _lib.check(_lib.lib().gnpde_gather_rows(_lib.ptr(u), u.stride(0), _lib.ptr(self.send_idx), out.shape[0], self.d,
+                                            _lib.ptr(out), out.stride(0), _lib.stream_of(u)))
+    return out
+
+  def rhs_stage(self, u, x0, **stage_kw):
+    ops = self.ops
+    if self.kind == 'transformer':
+      ops.linear(u, self.wqk, self.bqk, out=self.qk)
+      st = ops.attention_struct(_lib.ATT_SCALED_DOT, self.heads, self.A, 0, False, q=self.qk, k=self.qk[:, self.A:],
+                                ldqk=2 * self.A)
+      w, _, _ = ops.edge_attention(self.graph, st, True, False, False, like=u)
+    else:
+      w = self.w_csr
+    return ops.spmm_rhs(self.graph, w, u, self.alpha, self.beta, x0, self.alpha_sigmoid, **stage_kw)
+
+  def sync(self):
+    torch.cuda.synchronize(self.dev)
+
+
+# --------------------------------------------------------------------------------------------------
+# sharded fixed-step solver
+# --------------------------------------------------------------------------------------------------
+class ShardedSolver(object):
+  def __init__(self, shard, backend, group=None):
+    self.shard, self.be, self.group = shard, backend, group
+    s = shard
+    self.y = backend.empty(s.n_local)
+    self.ua = backend.empty(s.n_local)
+    self.ub = backend.empty(s.n_local)
+    self.k = [backend.empty(s.n_own) for _ in range(3)]
+    self.send = backend.empty(int(sum(s.send_counts)))
+    self.n_exchanges = 0
+
+  def exchange(self, u):
+    """Refresh the halo rows of `u` (rows [n_own, n_local)) from their owners."""
+    s = self.shard
+    if s.world == 1:
+      return
+    self.be.pack(u, self.send)
+    recv = u[s.n_own:]
+    dist.all_to_all_single(recv, self.send, s.recv_counts, s.send_counts, group=self.group)
+    self.n_exchanges += 1
+
+  def integrate(self, y_own, x0_own, T, step_size=1.0, method='rk4'):
+    """Integrate the owned rows from t = 0 to T; returns the owned rows of y(T) (a view of an
+    internal buffer).  `x0_own` may be None (no source term)."""
+    s, be = self.shard, self.be
+    grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
+    dts = (grid[1:] - grid[:-1]).tolist()
+    y, ua, ub = self.y, self.ua, self.ub
+    k1, k2, k3 = self.k
+    n = s.n_own
+    y[:n].copy_(y_own)
+    for dt in dts:
+      if method == 'euler':
+        self.exchange(y)
+        be.rhs_stage(y, x0_own, stage=_lib.STAGE_EULER, dt=dt, y=y, out_y=ua)
+        y, ua = ua, y
+      elif method == 'rk4':
+        self.exchange(y)
+        be.rhs_stage(y, x0_own, stage=_lib.STAGE_RK1, dt=dt, y=y, out_k=k1, out_y=ua)
+        self.exchange(ua)
+        be.rhs_stage(ua, x0_own, stage=_lib.STAGE_RK2, dt=dt, y=y, k1=k1, out_k=k2, out_y=ub)
+        self.exchange(ub)
+        be.rhs_stage(ub, x0_own, stage=_lib.STAGE_RK3, dt=dt, y=y, k1=k1, k2=k2, out_k=k3, out_y=ua)
+        self.exchange(ua)
+        be.rhs_stage(ua, x0_own, stage=_lib.STAGE_RK4, dt=dt, y=y, k1=k1, k2=k2, k3=k3, out_y=y)
+      else:
+        raise ValueError(method)
+    self.y, self.ua = y, ua
+    return y[:n]
+
+
+def scatter_rows(x_global, shard):
+  """Owned rows of a replicated global tensor, in the shard's local order."""
+  return x_global[shard.own_old_ids.to(x_global.device)]
+
+
+def gather_rows_all(y_own, plan, shard, group=None):
+  """All-gather the owned rows and undo the partition permutation (tests / small graphs)."""
+  P = plan.world
+  m = int(plan.counts.max())
+  pad = torch.zeros(m, y_own.shape[1], dtype=y_own.dtype, device=y_own.device)
+  pad[:y_own.shape[0]] = y_own
+  parts = [torch.empty_like(pad) for _ in range(P)]
+  dist.all_gather(parts, pad, group=group)
+  out = torch.empty(plan.n, y_own.shape[1], dtype=y_own.dtype, device=y_own.device)
+  for p in range(P):
+    ids = plan.order[plan.offsets[p]:plan.offsets[p + 1]].to(y_own.device)
+    out[ids] = parts[p][:ids.numel()]
+  return out
+
+
+# --------------------------------------------------------------------------------------------------
+# bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
+# --------------------------------------------------------------------------------------------------
+def bench_main(args, rank, world, dev):
+  import gnpde_amd as G
+  dist.init_process_group('nccl', device_id=dev)
+  cfg = G.synthetic.CONFIGS[args.graph]
+  ei, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
+  d = cfg['d']
+  A, h = args.att_dim or cfg['att_dim'], args.heads or cfg['heads']
+  ei_loops, _ = G.add_remaining_self_loops(ei, None, 1.0, n)      # as ODEFuncTransformerAtt.__init__ does
+  t0 = time.perf_counter()
+  plan = PartitionPlan(ei_loops, n, world)
+  shard = plan.shard(rank)
+  t_plan = time.perf_counter() - t0
+  g = torch.Generator().manual_seed(args.seed)
+  x = torch.randn(n, d, generator=g)
+  g2 = torch.Generator().manual_seed(args.seed + 1)
+  params = dict(Wq=torch.randn(A, d, generator=g2) / d ** 0.5, Wk=torch.randn(A, d, generator=g2) / d ** 0.5,
+                bq=torch.zeros(A), bk=torch.zeros(A), heads=h)
+  kind = args.function
+  if kind == 'laplacian':
+    _, w = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
+    params = dict(edge_weight=w[shard.edge_ids])
+  be = NativeBackend(shard, d, dev, kind, params, torch.tensor(0.0), torch.tensor(0.1), True)
+  solver = ShardedSolver(shard, be)
+  x_own = scatter_rows(x, shard).to(dev)
+  K, W = args.steps, args.warmup
+  with torch.no_grad():
+    if W > 0:
+      solver.integrate(x_own, x_own, float(W), 1.0, 'rk4')
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    y = solver.integrate(x_own, x_own, float(K), 1.0, 'rk4')
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+  el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  dist.all_reduce(el, op=dist.ReduceOp.MAX)
+  finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=dev)
+  dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+  halo = torch.tensor([float(shard.n_halo), float(shard.n_own), float(shard.edge_index.shape[1])], device=dev)
+  halo_max = halo.clone()
+  dist.all_reduce(halo_max, op=dist.ReduceOp.MAX)
+  if rank == 0:
+    elapsed = float(el.item())
+    E = int(ei_loops.shape[1])
+    out = {
+      'metric': 'ODE steps/sec (full-graph diffusion), ogbn-arxiv d=128 rk4',
+      'value': round(K / elapsed, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+      'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+      'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'synthetic ogbn-arxiv-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
+                             'partitioned over %d GPUs, RCCL halo exchange per evaluation (eager launches)'
+                             % ('nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
+                 'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
+                 'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
+                 'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
+                 'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
+                 'finite': bool(finite.item() == 1.0)},
+      'roofline': None, 'cpu_baseline': None,
+    }
+    print(json.dumps(out))
+  dist.destroy_process_group()

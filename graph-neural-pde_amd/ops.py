@@ -60,13 +60,13 @@ def spmm_rhs(graph, w_csr, u, alpha, beta=None, x0=None, alpha_sigmoid=True, out
   require_hip(u, w_csr, x0)
   u = f32c(u, 'u')
   n, d = u.shape
-  if n != graph.n:
+  if n < graph.n:  # (a sharded state carries halo rows after the graph's own rows)
     raise _lib.GnpdeError('state has %d rows but the graph has %d nodes' % (n, graph.n))
   alpha_d = _scalar_dev(alpha, u)
   beta_d = _scalar_dev(beta, u) if x0 is not None else None
   x0c = f32c(x0, 'x0') if x0 is not None else None
-  if x0c is not None and x0c.shape != u.shape:
-    raise _lib.GnpdeError('x0 shape %s != state shape %s' % (tuple(x0c.shape), tuple(u.shape)))
+  if x0c is not None and (x0c.shape[1] != d or x0c.shape[0] < graph.n):
+    raise _lib.GnpdeError('x0 shape %s does not cover the %d x %d state' % (tuple(x0c.shape), graph.n, d))
   if 'stage' not in stage_kw:
     if out is None:
       out = torch.empty_like(u)

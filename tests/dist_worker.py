@@ -1,0 +1,109 @@
+"""Worker for tests/test_distributed_cpu.py (launched by torch.distributed.run, gloo, CPU).
+
+Runs the product's partition plan / shard index maps / halo exchange / sharded rk4 driver
+(graph-neural-pde_amd/distributed.py) with a CHECKER backend built on the CPU oracle in place of the HIP
+backend, and compares the gathered result with the unpartitioned oracle solve."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import gnpde_amd as G  # noqa: E402
+from gnpde_amd import distributed as D, _lib  # noqa: E402
+from oracle import restate as R  # noqa: E402
+from helpers import random_graph  # noqa: E402
+
+
+class OracleBackend(object):
+  """Same interface as distributed.NativeBackend; arithmetic from oracle/restate.py (test only)."""
+
+  def __init__(self, shard, d, kind, params, alpha, beta):
+    self.shard, self.d, self.kind, self.p, self.alpha, self.beta = shard, d, kind, params, alpha, beta
+
+  def empty(self, rows):
+    return torch.zeros(rows, self.d)
+
+  def pack(self, u, out):
+    out.copy_(u[self.shard.send_idx])
+    return out
+
+  def rhs_stage(self, u, x0, stage, dt=0.0, y=None, k1=None, k2=None, k3=None, out_k=None, out_y=None):
+    s, p = self.shard, self.p
+    n = s.n_own
+    ei = s.edge_index
+    if self.kind == 'transformer':
+      att, _ = R.transformer_attention(u, ei, p['Wq'], p['bq'], p['Wk'], p['bk'], p['heads'])
+      w = att.mean(dim=1)
+    else:
+      w = p['edge_weight']
+    ax = R.spmm(ei, w, n, u)
+    k = torch.sigmoid(self.alpha) * (ax - u[:n])
+    if x0 is not None:
+      k = k + self.beta * x0
+    third = 1 / 3
+    if stage == _lib.STAGE_EULER:
+      out_y[:n] = y[:n] + dt * k
+    elif stage == _lib.STAGE_RK1:
+      out_k.copy_(k); out_y[:n] = y[:n] + dt * k * third
+    elif stage == _lib.STAGE_RK2:
+      out_k.copy_(k); out_y[:n] = y[:n] + dt * (k - k1 * third)
+    elif stage == _lib.STAGE_RK3:
+      out_k.copy_(k); out_y[:n] = y[:n] + dt * (k1 - k2 + k)
+    elif stage == _lib.STAGE_RK4:
+      out_y[:n] = y[:n] + (k1 + 3 * (k2 + k3) + k) * dt * 0.125
+
+
+def main():
+  dist.init_process_group('gloo')
+  rank, world = dist.get_rank(), dist.get_world_size()
+  n, d, A, h = 600, 12, 8, 2
+  ei = random_graph(n, 5, seed=4, hubs=1, hub_deg=200, isolated=4)
+  g = torch.Generator().manual_seed(1)
+  x = torch.randn(n, d, generator=g)
+  params = dict(Wq=torch.randn(A, d, generator=g) / d ** 0.5, Wk=torch.randn(A, d, generator=g) / d ** 0.5,
+                bq=torch.randn(A, generator=g) * 0.1, bk=torch.randn(A, generator=g) * 0.1, heads=h)
+  alpha, beta = torch.tensor(0.3), torch.tensor(0.2)
+  plan = D.PartitionPlan(ei, n, world)
+  shard = plan.shard(rank)
+  # index-map invariants
+  assert shard.n_own == int((plan.part == rank).sum())
+  assert sum(shard.recv_counts) == shard.n_halo and shard.recv_counts[rank] == 0 and shard.send_counts[rank] == 0
+  cnt = torch.tensor(shard.send_counts, dtype=torch.long)
+  allc = [torch.zeros(world, dtype=torch.long) for _ in range(world)]
+  dist.all_gather(allc, cnt)
+  for q in range(world):
+    assert int(allc[q][rank]) == shard.recv_counts[q], 'send/recv counts of the exchange do not match'
+  ok = True
+  for kind, T, method in (('transformer', 2.3, 'rk4'), ('laplacian', 3.0, 'euler'), ('laplacian', 2.0, 'rk4')):
+    if kind == 'laplacian':
+      _, wfull = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
+      p = dict(edge_weight=wfull[shard.edge_ids])
+      rhs = lambda t, y: R.rhs_laplacian(y, ei, wfull, alpha, beta, x, False, True)
+    else:
+      p = params
+      rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,
+                                           x, False, True)
+    be = OracleBackend(shard, d, kind, p, alpha, beta)
+    solver = D.ShardedSolver(shard, be)
+    x_own = D.scatter_rows(x, shard)
+    y_own = solver.integrate(x_own, x_own, T, 1.0, method)
+    y = D.gather_rows_all(y_own.clone(), plan, shard)
+    ref = R.odeint_fixed(rhs, x, T, 1.0, method)
+    e_inf, e_2 = R.parity_error(y, ref)
+    steps = len(G.time_grid(torch.tensor([0.0, T]), 1.0)) - 1
+    assert solver.n_exchanges == steps * (4 if method == 'rk4' else 1)
+    if not (e_inf < 1e-5 and e_2 < 1e-5):
+      ok = False
+      print('rank %d %s %s: mismatch %g %g' % (rank, kind, method, e_inf, e_2))
+  if rank == 0 and ok:
+    print('DIST_OK world=%d cut=%.3f halo=%d' % (world, plan.edge_cut(), shard.n_halo))
+  dist.destroy_process_group()
+  sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,48 @@
+"""Container-only: the reference's own GNN.py / model_configurations.py pick up the MI355X classes when
+graph-neural-pde_amd/dropin precedes the reference's src/ on sys.path, and the resulting model's state_dict
+interchanges with the fixture recorded from the pure reference model.  Skipped where /root/reference is
+absent (the GPU box)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_env  # noqa: E402
+
+SCRIPT = r'''
+import sys, os, json
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import ref_env
+import gnpde_amd
+sys.path.insert(0, os.path.join(ROOT, 'graph-neural-pde_amd', 'dropin'))
+ref_env.activate()                      # stand-ins + reference src appended AFTER the drop-in directory
+import torch
+from helpers import Fixture
+from GNN import GNN                     # the reference's model, unmodified
+from utils import DummyDataset          # the reference's utils
+from torch_geometric.data import Data
+for name in ('gnn_constant_transformer_rk4', 'gnn_attention_laplacian_euler'):
+  fx = Fixture(name)
+  data = Data(x=fx.t('x'), edge_index=fx.t('edge_index'), edge_attr=None)
+  model = GNN(dict(fx.opt), DummyDataset(data, int(fx.arr['num_classes'])), torch.device('cpu'))
+  f = model.odeblock.odefunc
+  assert type(f).__module__.startswith('gnpde_amd'), type(f).__module__
+  assert type(model.odeblock).__module__.startswith('gnpde_amd')
+  ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+  theirs = {k: tuple(v.shape) for k, v in fx.params.items()}
+  assert ours == theirs, set(ours) ^ set(theirs)
+  model.load_state_dict(fx.params, strict=True)
+  print(model)                          # the reference's print(model) raises for --function transformer
+print('DROPIN_OK')
+'''
+
+
+@pytest.mark.skipif(not ref_env.available(), reason='reference tree not present')
+def test_reference_gnn_builds_on_native_classes():
+  res = subprocess.run([sys.executable, '-c', SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0 and 'DROPIN_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -187,3 +187,39 @@ def test_one_pass_kernel_vs_multi_kernel_and_oracle(dev, heads, att_dim, d, sour
 def ctypes_ref(struct):
   import ctypes
   return ctypes.byref(struct)
+
+
+@pytest.mark.parametrize('kind', ['transformer', 'laplacian'])
+def test_sharded_native_backend_one_evaluation(dev, kind):
+  """Multi-GPU path on ONE GPU: every shard's HIP backend (rectangular local graph, halo columns, pack
+  kernel) evaluates f on [owned | halo] rows taken from the global state; owned rows must match the
+  unpartitioned oracle.  (The exchange itself is covered by the gloo tests.)"""
+  from gnpde_amd import distributed as D, _lib
+  from helpers import random_graph
+  n, d, A, h, P = 4000, 64, 16, 4, 4
+  ei = random_graph(n, 6, seed=12, hubs=2, hub_deg=900)
+  g = torch.Generator().manual_seed(2)
+  x = torch.randn(n, d, generator=g)
+  x0 = torch.randn(n, d, generator=g)
+  params = dict(Wq=torch.randn(A, d, generator=g) / d ** 0.5, Wk=torch.randn(A, d, generator=g) / d ** 0.5,
+                bq=torch.randn(A, generator=g) * 0.1, bk=torch.randn(A, generator=g) * 0.1, heads=h)
+  alpha, beta = torch.tensor(0.3), torch.tensor(0.2)
+  if kind == 'laplacian':
+    _, wfull = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
+    ref = R.rhs_laplacian(x, ei, wfull, alpha, beta, x0, False, True)
+  else:
+    ref = R.rhs_transformer(x, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta, x0, False, True)
+  plan = D.PartitionPlan(ei, n, P)
+  assert plan.edge_cut() < 0.95
+  for r in range(P):
+    sh = plan.shard(r)
+    p = dict(edge_weight=wfull[sh.edge_ids]) if kind == 'laplacian' else params
+    be = D.NativeBackend(sh, d, dev, kind, p, alpha, beta, True)
+    old_ids = torch.cat([sh.own_old_ids, plan.order[sh.halo_new]])
+    u = x[old_ids].to(dev)
+    out = torch.empty(sh.n_own, d, device=dev)
+    be.rhs_stage(u, x0[sh.own_old_ids].to(dev), stage=_lib.STAGE_RHS, out_k=out)
+    assert_parity(out, ref[sh.own_old_ids], what='shard %d %s' % (r, kind))
+    send = be.empty(int(sum(sh.send_counts)))
+    be.pack(u, send)
+    assert torch.equal(send.cpu(), x[sh.own_old_ids][sh.send_idx])
