@@ -42,7 +42,7 @@ def parse():
   ap.add_argument('--function', default='transformer', choices=['transformer', 'laplacian'])
   ap.add_argument('--no-graph', action='store_true', help='launch the solver eagerly instead of via hipGraph')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-evals', type=int, default=8)
+  ap.add_argument('--cpu-evals', type=int, default=6)
   ap.add_argument('--seed', type=int, default=0)
   return ap.parse_args()
 
@@ -92,10 +92,11 @@ def dominant_kernel_time(G, block, x, reps=10):
   y, k1, k2, k3, ua, ub, x0 = bufs
   alpha = ops._scalar_dev(f.alpha_train, x)
   beta = ops._scalar_dev(f.beta_train, x)
-  stages = [dict(stage=_lib.STAGE_RK1, y=y, out_k=k1, out_y=ua, u=y),
-            dict(stage=_lib.STAGE_RK2, y=y, k1=k1, out_k=k2, out_y=ub, u=ua),
-            dict(stage=_lib.STAGE_RK3, y=y, k1=k1, k2=k2, out_k=k3, out_y=ua, u=ub),
-            dict(stage=_lib.STAGE_RK4, y=y, k1=k1, k2=k2, k3=k3, out_y=y, u=ua)]
+  # the four stage variants the solver actually runs (compact rk4: stage states from stage inputs)
+  stages = [dict(stage=_lib.STAGE_RK1C, out_y=ua, u=y),
+            dict(stage=_lib.STAGE_RK2C, y=y, out_y=ub, u=ua),
+            dict(stage=_lib.STAGE_RK3C, k1=ua, out_y=k1, u=ub),
+            dict(stage=_lib.STAGE_RK4C, y=y, k1=ub, out_y=y, u=k1)]
   fused = False
   if hasattr(f, 'multihead_att_layer') and os.environ.get('GNPDE_ONE_PASS', '0') == '1':
     desc = f._descriptor(x)
@@ -143,9 +144,22 @@ def cpu_baseline(block, x_cpu, evals):
   else:
     w = cpu(f.edge_weight)
     rhs = lambda y: R.rhs_laplacian(y, edge, w, cpu(f.alpha_train), cpu(f.beta_train), x_cpu, False, True)
-  torch.set_num_threads(os.cpu_count())
+  # torch's CPU scatter/gather ops do not scale to every core of a large host: try a few thread counts
+  # (one evaluation each) and time the sample at the best one, so the baseline is not handicapped
+  ncpu = os.cpu_count() or 1
+  cands = sorted({c for c in (ncpu, 64, 32, 16, 8) if c <= ncpu}, reverse=True)
+  best_t, best_c = None, ncpu
   with torch.no_grad():
+    torch.set_num_threads(cands[0])
     out = rhs(x_cpu)  # warm-up, also the parity reference
+    for c in cands:
+      torch.set_num_threads(c)
+      t0 = time.perf_counter()
+      rhs(x_cpu)
+      t = time.perf_counter() - t0
+      if best_t is None or t < best_t:
+        best_t, best_c = t, c
+    torch.set_num_threads(best_c)
     t0 = time.perf_counter()
     for _ in range(evals):
       rhs(x_cpu)
@@ -250,7 +264,7 @@ def main():
     e_inf, e_2 = R.parity_error(got, ref)
     out['cpu_baseline'] = {'value': round(1.0 / (4 * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
                            'kind': 'port',
-                           'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload with the '
+                           'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the best of a few torch thread counts, with the '
                                      'reference op sequence (oracle/restate.py, torch CPU); steps/s = 1 / (4 t_eval)'
                                      % (args.cpu_evals, args.cpu_evals / 4.0),
                            'ms_per_rhs_eval': round(t_eval * 1e3, 2)}

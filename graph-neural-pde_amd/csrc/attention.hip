@@ -448,6 +448,126 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
   }
 }
 
+// ---- scaled-dot specialisation of the fused row kernel with batched gathers.
+// The generic kernel above issues, per pass, colidx -> k -> use, i.e. two dependent memory round trips
+// that the scheduler cannot overlap across passes (or rows).  Here all index loads of a batch (RI rows x
+// PB passes) are issued first, then all k gathers, then the arithmetic -- 2 round trips per BATCH.
+// Out-of-range slots read a clamped (valid, cached) position and are masked to -inf afterwards, so the
+// batch is branch-free.  d_k = 4 * DK4.
+template <int H, int DK4, int GL, int RI, int PB, int NB>
+__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows) {
+  constexpr int RPW = kWave / GL;
+  constexpr int GE = GL / H;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gi = lane % GL;
+  const int slot = gi / H, head = gi % H;
+  const long long rbase = ((static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL) * RI;
+
+  int row[RI], e0[RI], e1[RI];
+  bool live[RI];
+#pragma unroll
+  for (int r = 0; r < RI; ++r) {
+    live[r] = rbase + r < n_rows;
+    int4 info = make_int4(0, 0, 1, 0);  // dead slot: reads position 0, writes nothing
+    if (live[r]) info = reinterpret_cast<const int4*>(a.bin_rows)[first_row + rbase + r];
+    row[r] = info.x; e0[r] = info.y; e1[r] = info.y + info.z;
+    if constexpr (GL == kWave) {
+      row[r] = __builtin_amdgcn_readfirstlane(row[r]);
+      e0[r] = __builtin_amdgcn_readfirstlane(e0[r]);
+      e1[r] = __builtin_amdgcn_readfirstlane(e1[r]);
+    }
+  }
+  float4 qv[RI][DK4];
+#pragma unroll
+  for (int r = 0; r < RI; ++r)
+#pragma unroll
+    for (int j = 0; j < DK4; ++j)
+      qv[r][j] = *reinterpret_cast<const float4*>(a.q + static_cast<size_t>(row[r]) * a.ldqk + head * a.dk + 4 * j);
+
+  float s[RI][NB * PB];
+  float m[RI];
+#pragma unroll
+  for (int r = 0; r < RI; ++r) m[r] = -INFINITY;
+  int nbatch = NB;
+  if constexpr (GL == kWave && RI == 1) nbatch = (e1[0] - e0[0] + PB * GE - 1) / (PB * GE);  // wave-uniform
+
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (nb < nbatch) {
+      int c[RI][PB];
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int e = e0[r] + (nb * PB + i) * GE + slot;
+          c[r][i] = a.colidx[e < e1[r] ? e : e1[r] - 1];
+        }
+      float4 kv[RI][PB][DK4];
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+          for (int j = 0; j < DK4; ++j)
+            kv[r][i][j] = *reinterpret_cast<const float4*>(a.k + static_cast<size_t>(c[r][i]) * a.ldqk + head * a.dk + 4 * j);
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          float dot = 0.f;
+#pragma unroll
+          for (int j = 0; j < DK4; ++j) {
+            dot = fmaf(qv[r][j].x, kv[r][i][j].x, dot);
+            dot = fmaf(qv[r][j].y, kv[r][i][j].y, dot);
+            dot = fmaf(qv[r][j].z, kv[r][i][j].z, dot);
+            dot = fmaf(qv[r][j].w, kv[r][i][j].w, dot);
+          }
+          const int e = e0[r] + (nb * PB + i) * GE + slot;
+          float sv = dot / a.inv_sqrt_dk_den;
+          if (a.edge_w != nullptr) sv = sv * a.edge_w[e < e1[r] ? e : e1[r] - 1];
+          sv = e < e1[r] ? sv : -INFINITY;
+          s[r][nb * PB + i] = sv;
+          m[r] = fmaxf(m[r], sv);
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) s[r][nb * PB + i] = -INFINITY;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RI; ++r) {
+#pragma unroll
+    for (int off = H; off < GL; off <<= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, kWave));
+    float l = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (nb < nbatch) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          s[r][nb * PB + i] = expf(s[r][nb * PB + i] - m[r]);
+          l += s[r][nb * PB + i];
+        }
+      }
+#pragma unroll
+    for (int off = H; off < GL; off <<= 1) l += __shfl_xor(l, off, kWave);
+    const float den = l + 1e-16f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (nb < nbatch) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          float v = s[r][nb * PB + i] / den;
+#pragma unroll
+          for (int off = 1; off < H; off <<= 1) v += __shfl_xor(v, off, kWave);
+          const int e = e0[r] + (nb * PB + i) * GE + slot;
+          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = v / static_cast<float>(H);
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void edge_to_csr_mean_kernel(const int* __restrict__ perm, const float* __restrict__ src,
                                                                  int h, int e, float* __restrict__ w) {
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -512,8 +632,34 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
   }
 }
 
+template <int H, int DK4>
+void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s) {
+  constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
+  constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
+  constexpr int RPW16 = kWave / GL16;
+  constexpr int RI16 = (DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1);  // rows interleaved per group
+  constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);         // passes to cover GNPDE_LONG_ROW entries
+  constexpr int PB64 = (DK4 == 1) ? 4 : 2;
+  if (n16 > 0) {
+    const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
+    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16);
+  }
+  if (n64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16, n64);
+  }
+}
+
 template <int TYPE, int H, bool VEC4>
 void launch_rows_th(const AttArgs& a, int n16, int n64, hipStream_t s) {
+  if constexpr (TYPE == GNPDE_ATT_SCALED_DOT && VEC4) {
+    if (g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] == 0) {
+      if (a.dk == 4) return launch_rows_sd<H, 1>(a, n16, n64, s);
+      if (a.dk == 8) return launch_rows_sd<H, 2>(a, n16, n64, s);
+      if (a.dk == 16) return launch_rows_sd<H, 4>(a, n16, n64, s);
+    }
+  }
   // rows with <= 16 entries: 16*H lanes cover them in one pass when H <= 4, else a whole wave in H/4 passes
   constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;

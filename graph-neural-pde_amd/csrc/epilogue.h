@@ -127,6 +127,30 @@ __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha
       for (int v = 0; v < VEC; ++v) o[v] = y[v] + (((a[v] + 3.0f * (b[v] + c[v])) + k[v]) * dt) * 0.125f;
       st(ep.out_y + off, o);
       break;
+    case GNPDE_STAGE_RK1C:  // u == y
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = ui[v] + (dt * k[v]) * kThird;
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK2C:
+      ld(ep.y + off, y);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (2.0f * y[v] - ui[v]) + dt * k[v];
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK3C:
+      ld(ep.k1 + off, a);  // u2
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (2.0f * a[v] - ui[v]) + dt * k[v];
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK4C:
+      ld(ep.y + off, y);
+      ld(ep.k1 + off, a);  // u3
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (((6.0f * a[v] + 3.0f * ui[v]) - y[v]) + dt * k[v]) * 0.125f;
+      st(ep.out_y + off, o);
+      break;
     default:
       break;
   }

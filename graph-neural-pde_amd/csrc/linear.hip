@@ -39,15 +39,17 @@ __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ base, int
 }
 
 // MT = number of 16-column output tiles kept in registers by one wave.
-template <int MT, bool ALIGNED>
+// FULL: every row of the tile exists, every column tile is complete and d % 16 == 0 -> no guards, so the
+// operand loads of a K batch are straight-line code the scheduler can issue back to back.
+template <int MT, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int n, int d, int ldx,
                                                         const float* __restrict__ W, int m, int ldw,
                                                         const float* __restrict__ b, float* __restrict__ out,
-                                                        int ldo, int col_base) {
+                                                        int ldo, int col_base, int row_base) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
-  const int row0 = static_cast<int>(tile * 16);
+  const int row0 = row_base + static_cast<int>(tile * 16);
   if (row0 >= n) return;
   const int r = lane & 15;       // row within the tile (A operand) / column within a 16-col tile (B)
   const int kq = lane >> 4;      // which 4-wide K quarter of the 16-wide K block
@@ -69,12 +71,28 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int k = kb + 16 * u + 4 * kq;
-      av[u] = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
+      if constexpr (FULL) {
+        if (kb + 16 * u < d) {  // d % 16 == 0: a K block is complete or absent -- a scalar (wave-uniform) test
+          const float4 ta = *reinterpret_cast<const float4*>(xrow + k);
+          av[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int col = col_base + t * 16 + r;
-        const bool ok = col < m;
-        bv[u][t] = load4_guard<ALIGNED>(W + static_cast<size_t>(ok ? col : 0) * ldw, k, d, ok);
+          for (int t = 0; t < MT; ++t) {
+            const float4 tb = *reinterpret_cast<const float4*>(W + static_cast<size_t>(col_base + t * 16 + r) * ldw + k);
+            bv[u][t] = f32x4{tb.x, tb.y, tb.z, tb.w};
+          }
+        } else {
+          av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < MT; ++t) bv[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+        av[u] = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int col = col_base + t * 16 + r;
+          const bool ok = col < m;
+          bv[u][t] = load4_guard<ALIGNED>(W + static_cast<size_t>(ok ? col : 0) * ldw, k, d, ok);
+        }
       }
     }
 #pragma unroll
@@ -90,35 +108,55 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int col = col_base + t * 16 + r;
-    if (col >= m) continue;
+    if constexpr (!FULL) {
+      if (col >= m) continue;
+    }
     const float bias = b != nullptr ? b[col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int orow = row0 + 4 * kq + i;
-      if (orow < n) out[static_cast<size_t>(orow) * ldo + col] = acc[t][i] + bias;
+      if (FULL || orow < n) out[static_cast<size_t>(orow) * ldo + col] = acc[t][i] + bias;
     }
+  }
+}
+
+template <int MT, bool ALIGNED>
+void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                 int ldo, int col, hipStream_t s) {
+  // complete 16-row tiles with complete column tiles and d % 16 == 0 take the unguarded kernel
+  const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
+  const int full_rows = full_cols ? (n / 16) * 16 : 0;
+  if (full_rows > 0) {
+    const long long tiles = full_rows / 16;
+    const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, true>), dim3(grid), dim3(kBlock), 0, s, x, full_rows, d, ldx, W, m, ldw, b,
+                       out, ldo, col, 0);
+  }
+  if (full_rows < n) {
+    const long long tiles = (static_cast<long long>(n) - full_rows + 15) / 16;
+    const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, false>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out,
+                       ldo, col, full_rows);
   }
 }
 
 template <bool ALIGNED>
 void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                    int ldo, hipStream_t s) {
-  const long long tiles = (static_cast<long long>(n) + 15) / 16;
-  const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   int col = 0;
   while (col < m) {
     const int rem = (m - col + 15) / 16;
     if (rem >= 8) {
-      hipLaunchKernelGGL((linear_kernel<8, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      launch_tile<8, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
       col += 128;
     } else if (rem >= 4) {
-      hipLaunchKernelGGL((linear_kernel<4, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      launch_tile<4, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
       col += 64;
     } else if (rem >= 2) {
-      hipLaunchKernelGGL((linear_kernel<2, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      launch_tile<2, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
       col += 32;
     } else {
-      hipLaunchKernelGGL((linear_kernel<1, ALIGNED>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, col);
+      launch_tile<1, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
       col += 16;
     }
   }

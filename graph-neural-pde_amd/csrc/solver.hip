@@ -182,6 +182,27 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
   float* k1 = reinterpret_cast<float*>(s->ws + s->off_k1);
   float* k2 = reinterpret_cast<float*>(s->ws + s->off_k2);
   float* k3 = reinterpret_cast<float*>(s->ws + s->off_k3);
+  if (g_tune[GNPDE_TUNE_RK4_CLASSIC] == 0) {
+    // compact stages: y, u2 (ua), u3 (ub), u4 (the k1 slot); k1..k3 are never materialised
+    float* uc = k1;
+    for (float dt : s->dts) {
+      gnpde_epilogue_t e = base_epilogue(r);
+      e.dt = dt;
+      e.stage = GNPDE_STAGE_RK1C; e.out_y = ua;
+      int rc = enqueue_rhs(r, y, e, rws, s->L, st, fk);
+      if (rc) return rc;
+      e.stage = GNPDE_STAGE_RK2C; e.y = y; e.out_y = ub;
+      rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
+      if (rc) return rc;
+      e.stage = GNPDE_STAGE_RK3C; e.k1 = ua; e.out_y = uc;
+      rc = enqueue_rhs(r, ub, e, rws, s->L, st, fk);
+      if (rc) return rc;
+      e.stage = GNPDE_STAGE_RK4C; e.k1 = ub; e.out_y = y;
+      rc = enqueue_rhs(r, uc, e, rws, s->L, st, fk);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   for (float dt : s->dts) {
     gnpde_epilogue_t e = base_epilogue(r);
     e.dt = dt; e.y = y;

@@ -247,13 +247,18 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     const gnpde_epilogue_t& e = a.ep;
     GNPDE_CHECK_ARG(e.alpha != nullptr, GNPDE_EINVAL, "spmm: alpha pointer is null");
     GNPDE_CHECK_ARG(e.x0 == nullptr || e.beta != nullptr, GNPDE_EINVAL, "spmm: x0 given without beta");
-    GNPDE_CHECK_ARG(e.stage >= GNPDE_STAGE_RHS && e.stage <= GNPDE_STAGE_RK4, GNPDE_EINVAL, "spmm: bad stage %d", e.stage);
+    GNPDE_CHECK_ARG(e.stage >= GNPDE_STAGE_RHS && e.stage <= GNPDE_STAGE_RK4C, GNPDE_EINVAL, "spmm: bad stage %d", e.stage);
     const int st = e.stage;
-    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RK4 || st == GNPDE_STAGE_EULER || e.out_k != nullptr, GNPDE_EINVAL, "spmm: out_k is null");
-    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RHS || (e.out_y != nullptr && e.y != nullptr), GNPDE_EINVAL, "spmm: y/out_y is null");
-    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK2 || e.k1 != nullptr, GNPDE_EINVAL, "spmm: k1 is null");
-    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK3 || e.k2 != nullptr, GNPDE_EINVAL, "spmm: k2 is null");
-    GNPDE_CHECK_ARG(st < GNPDE_STAGE_RK4 || e.k3 != nullptr, GNPDE_EINVAL, "spmm: k3 is null");
+    const bool needs_k = st == GNPDE_STAGE_RHS || (st >= GNPDE_STAGE_RK1 && st <= GNPDE_STAGE_RK3);
+    const bool needs_y = st == GNPDE_STAGE_EULER || (st >= GNPDE_STAGE_RK1 && st <= GNPDE_STAGE_RK4) ||
+                         st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C;
+    const bool needs_k1 = (st >= GNPDE_STAGE_RK2 && st <= GNPDE_STAGE_RK4) || st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C;
+    GNPDE_CHECK_ARG(!needs_k || e.out_k != nullptr, GNPDE_EINVAL, "spmm: out_k is null");
+    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RHS || e.out_y != nullptr, GNPDE_EINVAL, "spmm: out_y is null");
+    GNPDE_CHECK_ARG(!needs_y || e.y != nullptr, GNPDE_EINVAL, "spmm: y is null");
+    GNPDE_CHECK_ARG(!needs_k1 || e.k1 != nullptr, GNPDE_EINVAL, "spmm: k1 is null");
+    GNPDE_CHECK_ARG(!(st == GNPDE_STAGE_RK3 || st == GNPDE_STAGE_RK4) || e.k2 != nullptr, GNPDE_EINVAL, "spmm: k2 is null");
+    GNPDE_CHECK_ARG(st != GNPDE_STAGE_RK4 || e.k3 != nullptr, GNPDE_EINVAL, "spmm: k3 is null");
     // every row gathers from u while other rows run their epilogue: outputs must not alias u
     GNPDE_CHECK_ARG(e.out_k != u && e.out_y != u, GNPDE_EINVAL, "spmm: output aliases the gathered operand");
     const void* ptrs[] = {e.x0, e.y, e.k1, e.k2, e.k3, e.out_k, e.out_y};

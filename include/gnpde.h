@@ -122,11 +122,18 @@ typedef struct gnpde_graph {
  *   GNPDE_STAGE_RK2    out_k = k2 ; out_y = y + dt*(k2 - k1*(1/3))
  *   GNPDE_STAGE_RK3    out_k = k3 ; out_y = y + dt*(k1 - k2 + k3)
  *   GNPDE_STAGE_RK4               ; out_y = y + (k1 + 3*(k2+k3) + k4)*dt*0.125   (in place on y)
+ *   Compact rk4 (same step, stage states expressed through the previous stage INPUTS so that k1..k3 are
+ *   never stored or re-read: 16 instead of 24 state-sized streams per step; u2 = y + dt k1/3 etc.):
+ *   GNPDE_STAGE_RK1C   out_y = u + dt*k1*(1/3)                          (u == y)
+ *   GNPDE_STAGE_RK2C   out_y = (2*y - u) + dt*k2                        (u == u2;  == y + dt*(k2 - k1/3))
+ *   GNPDE_STAGE_RK3C   out_y = (2*a - u) + dt*k3      a = u2  (field k1)  (u == u3;  == y + dt*(k1 - k2 + k3))
+ *   GNPDE_STAGE_RK4C   out_y = ((6*a + 3*u - y) + dt*k4)*0.125   a = u3  (u == u4; in place on y)
  * `u` is the stage input the operator is applied to, `y` the state at the start of the step.
  * ---------------------------------------------------------------------------------------------- */
 enum {
   GNPDE_STAGE_RHS = 0, GNPDE_STAGE_EULER = 1,
-  GNPDE_STAGE_RK1 = 2, GNPDE_STAGE_RK2 = 3, GNPDE_STAGE_RK3 = 4, GNPDE_STAGE_RK4 = 5
+  GNPDE_STAGE_RK1 = 2, GNPDE_STAGE_RK2 = 3, GNPDE_STAGE_RK3 = 4, GNPDE_STAGE_RK4 = 5,
+  GNPDE_STAGE_RK1C = 6, GNPDE_STAGE_RK2C = 7, GNPDE_STAGE_RK3C = 8, GNPDE_STAGE_RK4C = 9
 };
 
 typedef struct gnpde_epilogue {
