@@ -182,7 +182,7 @@ def main():
     raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
   dev = torch.device('cuda', local_rank)
   torch.cuda.set_device(dev)
-  if world > 1:
+  if world > 1 or os.environ.get('GNPDE_FORCE_SHARDED', '0') == '1':   # (the env switch exercises the sharded driver on one GPU)
     from gnpde_amd import distributed as D
     return D.bench_main(args, rank, world, dev)
 

@@ -1,9 +1,215 @@
-"""Differentiable evaluation of the right-hand side.  Not built yet:
-the forward (inference) path is native; asking for gradients fails loudly rather than silently
-falling back to a PyTorch composite."""
+"""Differentiable evaluation of the right-hand side, so that the
+reference's training loop (`loss.backward()` through the solver steps, run_GNN.py:92) works on these
+classes.  The FORWARD value is always the native kernels' (identical to inference).
+
+* GRAND-l (`LaplacianODEFunc`): the backward is native too.  With f = a (A x - x) + b x0,
+    dL/dx   = a (A^T g - g)          one launch of the same aggregation kernel on the transposed CSR
+    dL/dw_e = a g_row . x_col        gnpde_sddmm (only when the edge weights carry gradients: attention block)
+    dL/da, dL/db                     two dot products over [N,d]
+* GRAND-nl / GAT (attention recomputed inside f): the backward currently RECOMPUTES f from PyTorch
+  device ops and differentiates that composite (index_select / index_add, exactly the reference's op
+  sequence).  It is an interim implementation -- the native VJP (SDDMM + segment-softmax backward + two
+  gather-reduce passes) is the next row of SURVEY.md section 8f -- and it announces itself once.
+"""
+import logging
+import math
+
+import torch
+
+from . import _lib, ops
+
+_log = logging.getLogger('gnpde_amd')
+_warned = set()
+
+
+def _alpha(func):
+  return func.alpha_train if func.opt['no_alpha_sigmoid'] else torch.sigmoid(func.alpha_train)
+
+
+# --------------------------------------------------------------------------------------------------
+# GRAND-l: native forward and backward
+# --------------------------------------------------------------------------------------------------
+class _LaplacianRhs(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, edge_values, alpha_train, beta_train, x0, func):
+    graph = func._graph(x)
+    w_csr = func._weights_csr(graph)
+    with torch.no_grad():
+      f = ops.rhs_eval(func._descriptor(x), x)
+    ctx.func, ctx.graph = func, graph
+    ctx.save_for_backward(x, w_csr.clone(), edge_values, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0))
+    ctx.has_source = x0 is not None
+    return f
+
+  @staticmethod
+  def backward(ctx, g):
+    x, w_csr, edge_values, alpha_train, beta_train, x0 = ctx.saved_tensors
+    func, graph = ctx.func, ctx.graph
+    sig = not func.opt['no_alpha_sigmoid']
+    g = _lib.f32c(g)
+    gt = graph.transposed()
+    need = ctx.needs_input_grad
+    dx = dw = dalpha = dbeta = None
+    with torch.no_grad():
+      if need[0]:
+        # edge e sits at CSR position p of `graph` and at position p' of the transposed graph: go through edge order
+        w_edge = torch.empty_like(w_csr[:graph.e])
+        w_edge[graph.perm_long] = w_csr[:graph.e]
+        w_t = ops.edge_to_csr_mean(gt, w_edge)
+        dx = ops.spmm_rhs(gt, w_t, g, alpha_train, None, None, sig)       # a (A^T g - g)
+      if need[1]:
+        dw_csr = ops.sddmm(graph, g, x, scale=alpha_train, scale_sigmoid=sig)
+        dw_e = torch.empty(graph.e, dtype=torch.float32, device=g.device)
+        dw_e[graph.perm_long] = dw_csr[:graph.e]
+        if edge_values.dim() == 2:                                         # [E,h] attention: mean over heads
+          dw = (dw_e / edge_values.shape[1]).unsqueeze(1).expand_as(edge_values).contiguous()
+        else:
+          dw = dw_e
+      if need[2]:
+        ax = ops.spmm(graph, w_csr, x)
+        s = (g * (ax - x)).sum()
+        if sig:
+          sa = torch.sigmoid(alpha_train)
+          s = s * sa * (1 - sa)
+        dalpha = s.reshape(alpha_train.shape)
+      if need[3] and ctx.has_source:
+        dbeta = (g * x0).sum().reshape(beta_train.shape)
+    return dx, dw, dalpha, dbeta, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# attention functions: native forward, composite (PyTorch device ops) backward
+# --------------------------------------------------------------------------------------------------
+def _segment_softmax(src, index, n):
+  mx = torch.full((n,) + tuple(src.shape[1:]), float('-inf'), dtype=src.dtype, device=src.device)
+  mx = mx.scatter_reduce(0, index.view(-1, 1).expand_as(src), src.detach(), 'amax', include_self=True)
+  out = (src - mx[index]).exp()
+  den = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
+  return out / (den[index] + 1e-16)
+
+
+def _squareplus(src, index, n):
+  out = src - src.max()
+  out = (out + torch.sqrt(out ** 2 + 4)) / 2
+  den = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
+  return out / (den[index] + 1e-16)
+
+
+def _aggregate(edge, w, x):
+  out = torch.zeros_like(x)
+  return out.index_add_(0, edge[0], x.index_select(0, edge[1]) * w.unsqueeze(-1))
+
+
+def composite_transformer(func, x):
+  """f(x) of ODEFuncTransformerAtt from differentiable device ops (reference op order)."""
+  lay, opt = func.multihead_att_layer, func.opt
+  edge, n, h, dk = func.edge_index, x.shape[0], lay.h, lay.d_k
+  q = lay.Q(x).view(-1, h, dk).transpose(1, 2)
+  k = lay.K(x).view(-1, h, dk).transpose(1, 2)
+  src, dst = q[edge[0]], k[edge[1]]
+  t = opt['attention_type']
+  if t == 'scaled_dot':
+    prods = torch.sum(src * dst, dim=1) / math.sqrt(dk)
+  elif t == 'exp_kernel':
+    prods = lay.output_var ** 2 * torch.exp(-(torch.sum((src - dst) ** 2, dim=1) / (2 * lay.lengthscale ** 2)))
+  else:
+    if t == 'pearson':
+      src = src - src.mean(dim=1, keepdim=True)
+      dst = dst - dst.mean(dim=1, keepdim=True)
+    prods = torch.nn.functional.cosine_similarity(src, dst, dim=1, eps=1e-5)
+  if opt['reweight_attention'] and lay.edge_weights is not None:
+    prods = prods * lay.edge_weights.unsqueeze(1)
+  idx = edge[opt['attention_norm_idx']]
+  att = _squareplus(prods, idx, n) if opt['square_plus'] else _segment_softmax(prods, idx, n)
+  f = _alpha(func) * (_aggregate(edge, att.mean(dim=1), x) - x)
+  if opt['add_source']:
+    f = f + func.beta_train * func.x0
+  return f
+
+
+def composite_gat(func, x):
+  """f(x) of ODEFuncAtt (mix_features False) from differentiable device ops."""
+  lay, opt = func.multihead_att_layer, func.opt
+  edge, n, h, dk = func.edge_index, x.shape[0], lay.h, lay.d_k
+  hx = torch.mm(x, lay.W).view(-1, h, dk).transpose(1, 2)
+  edge_h = torch.cat((hx[edge[0]], hx[edge[1]]), dim=1).transpose(0, 1)
+  e = torch.nn.functional.leaky_relu(torch.sum(lay.a * edge_h, dim=0), lay.alpha)
+  att = _segment_softmax(e, edge[opt['attention_norm_idx']], n)
+  f = _alpha(func) * (_aggregate(edge, att.mean(dim=1), x) - x)
+  if opt['add_source']:
+    f = f + func.beta_train * func.x0
+  return f
+
+
+class _CompositeBackwardRhs(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, func, composite, x, *params):
+    with torch.no_grad():
+      f = ops.rhs_eval(func._descriptor(x), x)
+    ctx.func, ctx.composite, ctx.params = func, composite, params
+    ctx.save_for_backward(x)
+    return f
+
+  @staticmethod
+  def backward(ctx, g):
+    (x,) = ctx.saved_tensors
+    with torch.enable_grad():
+      xr = x.detach().requires_grad_(True)
+      f = ctx.composite(ctx.func, xr)
+      grads = torch.autograd.grad(f, [xr] + list(ctx.params), g, allow_unused=True)
+    return (None, None) + tuple(grads)
+
+
+def layer_attention_with_grad(layer, x, edge):
+  """(attention [E,h], prods [E,h]) of SpGraphTransAttentionLayer with autograd history (composite); used
+  when a block differentiates through the attention it computes once per forward pass."""
+  _announce('SpGraphTransAttentionLayer')
+  opt = layer.opt
+  n, h, dk = x.shape[0], layer.h, layer.d_k
+  q = layer.Q(x).view(-1, h, dk).transpose(1, 2)
+  k = layer.K(x).view(-1, h, dk).transpose(1, 2)
+  src, dst = q[edge[0]], k[edge[1]]
+  t = opt['attention_type']
+  if t == 'scaled_dot':
+    prods = torch.sum(src * dst, dim=1) / math.sqrt(dk)
+  elif t == 'exp_kernel':
+    prods = layer.output_var ** 2 * torch.exp(-(torch.sum((src - dst) ** 2, dim=1) / (2 * layer.lengthscale ** 2)))
+  else:
+    if t == 'pearson':
+      src = src - src.mean(dim=1, keepdim=True)
+      dst = dst - dst.mean(dim=1, keepdim=True)
+    prods = torch.nn.functional.cosine_similarity(src, dst, dim=1, eps=1e-5)
+  if opt['reweight_attention'] and layer.edge_weights is not None:
+    prods = prods * layer.edge_weights.unsqueeze(1)
+  idx = edge[opt['attention_norm_idx']]
+  att = _squareplus(prods, idx, n) if opt['square_plus'] else _segment_softmax(prods, idx, n)
+  return att, prods
+
+
+def _announce(name):
+  if name not in _warned:
+    _warned.add(name)
+    _log.warning('%s: gradients requested -- forward is native, backward uses the interim PyTorch composite '
+                 '(native VJP: SURVEY.md section 8f row 1)', name)
 
 
 def rhs_with_grad(func, x):
-  raise NotImplementedError(
-    '%s.forward was asked for gradients: the native VJP of the fused right-hand side is the next row of '
-    'SURVEY.md section 8f; run under torch.no_grad() / model.eval() for the forward solve' % func.__class__.__name__)
+  """Called by ODEFunc.forward when autograd is recording."""
+  _lib.require_hip(x)
+  x = _lib.f32c(x)
+  kind = func.__class__.__name__
+  if kind == 'LaplacianODEFunc':
+    return _LaplacianRhs.apply(x, func._edge_values(), func.alpha_train, func.beta_train, func._source(x), func)
+  if kind == 'ODEFuncTransformerAtt':
+    composite = composite_transformer
+  elif kind == 'ODEFuncAtt':
+    if func.opt['mix_features']:
+      raise NotImplementedError('training with mix_features is not supported yet')
+    composite = composite_gat
+  else:
+    raise NotImplementedError('no backward for %s' % kind)
+  _announce(kind)
+  params = [p for p in func.parameters() if p.requires_grad]
+  return _CompositeBackwardRhs.apply(func, composite, x, *params)

@@ -208,6 +208,79 @@ int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SDDMM: out[p] = scale * a[row_p] . b[col_p] for every stored entry -- the gradient of the aggregation
+// w.r.t. the edge weights (d w_e = alpha' g_row . x_col), needed when attention_weights carry gradients.
+// One wavefront per row (a_row slice kept in registers), L lanes per neighbour, xor-butterfly dot.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int L, int K>
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                      const float* __restrict__ a, const float* __restrict__ b, int n, int d,
+                                                      int lda, int ldb, const float* __restrict__ scale_ptr, int scale_sigmoid,
+                                                      float* __restrict__ out) {
+  constexpr int G = kWave / L;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+  if (row >= n) return;
+  const int sub = lane / L, cl = lane % L;
+  float scale = 1.0f;
+  if (scale_ptr != nullptr) {
+    scale = *scale_ptr;
+    if (scale_sigmoid) scale = 1.0f / (1.0f + expf(-scale));
+  }
+  float av[K][VEC];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int col = (k * L + cl) * VEC;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) av[k][v] = 0.0f;
+    if (col < d) load_vec<VEC>(a + static_cast<size_t>(row) * lda + col, av[k]);
+  }
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int j = e0; j < e1; j += G) {
+    const int e = j + sub;
+    float p = 0.0f;
+    if (e < e1) {
+      const float* src = b + static_cast<size_t>(colidx[e]) * ldb;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int col = (k * L + cl) * VEC;
+        if (col < d) {
+          float bv[VEC];
+          load_vec<VEC>(src + col, bv);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) p = fmaf(av[k][v], bv[v], p);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) p += __shfl_xor(p, off, kWave);
+    if (cl == 0 && e < e1) out[e] = scale * p;
+  }
+}
+
+template <int VEC>
+int dispatch_sddmm(const gnpde_graph_t* g, const float* a, const float* b, int d, int lda, int ldb, const float* scale,
+                   int scale_sigmoid, float* out, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+  const int slots = (d + VEC - 1) / VEC;
+#define GNPDE_SDDMM(LL, KK) \
+  hipLaunchKernelGGL((sddmm_kernel<VEC, LL, KK>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx, a, b, g->n, d, lda, \
+                     ldb, scale, scale_sigmoid, out)
+  if (slots <= 16) GNPDE_SDDMM(16, 1);
+  else if (slots <= 32) GNPDE_SDDMM(16, 2);
+  else if (slots <= 64) GNPDE_SDDMM(32, 2);
+  else if (slots <= 128) GNPDE_SDDMM(64, 2);
+  else if (slots <= 256) GNPDE_SDDMM(64, 4);
+  else {
+    set_error("sddmm: feature width d=%d too large for VEC=%d", d, VEC);
+    return GNPDE_ESHAPE;
+  }
+#undef GNPDE_SDDMM
+  return 0;
+}
+
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -319,4 +392,19 @@ extern "C" int gnpde_spmm(const gnpde_graph_t* g, const float* w_csr, const floa
   GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "spmm: out is null");
   return gnpde::launch_spmm_rhs(g, w_csr, u, d, ld, nullptr, out, workspace, workspace_bytes,
                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnpde_sddmm(const gnpde_graph_t* g, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t d,
+                           const float* scale, int32_t scale_sigmoid, float* out_csr, void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(g && a && b && out_csr && d >= 1 && lda >= d && ldb >= d, GNPDE_EINVAL, "sddmm: bad arguments");
+  if (g->n == 0 || g->e == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (d % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned(a, 16) && aligned(b, 16)) rc = dispatch_sddmm<4>(g, a, b, d, lda, ldb, scale, scale_sigmoid, out_csr, s);
+  else if (d % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && aligned(a, 8) && aligned(b, 8)) rc = dispatch_sddmm<2>(g, a, b, d, lda, ldb, scale, scale_sigmoid, out_csr, s);
+  else rc = dispatch_sddmm<1>(g, a, b, d, lda, ldb, scale, scale_sigmoid, out_csr, s);
+  if (rc) return rc;
+  GNPDE_LAUNCH_CHECK();
+  return 0;
 }

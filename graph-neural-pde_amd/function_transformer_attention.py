@@ -92,8 +92,12 @@ class SpGraphTransAttentionLayer(nn.Module):
   def forward(self, x, edge):
     """(attention [E,h], (v, prods [E,h])) in the order of `edge` (reference :128-214)."""
     _lib.require_hip(x, edge)
-    if torch.is_grad_enabled() and x.requires_grad:
-      raise NotImplementedError('differentiating through the attention layer itself is SURVEY.md 8f row 1 (next)')
+    if torch.is_grad_enabled() and (x.requires_grad or self.Q.weight.requires_grad or self.K.weight.requires_grad):
+      # training: the block differentiates through this attention (interim composite, see autograd.py)
+      from .autograd import layer_attention_with_grad
+      att, prods = layer_attention_with_grad(self, x, edge)
+      v = self.V(x).view(-1, self.h, self.d_k).transpose(1, 2)
+      return att, (v, prods)
     with torch.no_grad():
       xc = _lib.f32c(x)
       graph = graph_of(edge, xc.shape[0], xc.device)

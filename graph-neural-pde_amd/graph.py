@@ -64,6 +64,8 @@ class CSRGraph(object):
       setattr(s, k, self.t[k].data_ptr())
     self.struct = s
     self._ws = {}
+    self._edge_index_cpu = ei
+    self._transposed = None
 
   @property
   def rowptr(self):
@@ -79,6 +81,13 @@ class CSRGraph(object):
 
   def ref(self):
     return ctypes.byref(self.struct)
+
+  def transposed(self):
+    """CSR of the transposed operator over the SAME edge list (edge e <-> same id), used by the backward
+    pass: A^T g is an aggregation over the flipped edges."""
+    if self._transposed is None:
+      self._transposed = CSRGraph(self._edge_index_cpu.flip(0), self.n, self.device)
+    return self._transposed
 
   def workspace(self, tag, nbytes):
     """Persistent scratch keyed by use (stable addresses keep captured hipGraphs valid)."""

@@ -92,6 +92,18 @@ def spmm(graph, w_csr, u, out=None):
   return out
 
 
+def sddmm(graph, a, b, scale=None, scale_sigmoid=False, out=None):
+  """out_csr[p] = s * a[row_p] . b[col_p] over the graph's entries (CSR order)."""
+  require_hip(a, b)
+  a, b = f32c(a, 'a'), f32c(b, 'b')
+  if out is None:
+    out = torch.empty(max(graph.e, 1), dtype=torch.float32, device=a.device)
+  sc = _scalar_dev(scale, a) if scale is not None else None
+  check(_lib.lib().gnpde_sddmm(graph.ref(), ptr(a), a.stride(0), ptr(b), b.stride(0), a.shape[1], ptr(sc),
+                               int(bool(scale_sigmoid)), ptr(out), stream_of(a)))
+  return out
+
+
 def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=None, ldqk=0, leaky_slope=0.2,
                      gat_a=None, output_var=None, lengthscale=None, edge_w_csr=None):
   a = _lib.AttentionStruct()

@@ -166,6 +166,13 @@ int gnpde_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, i
 int gnpde_spmm(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,
                float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sampled dense-dense product on the graph pattern: out_csr[p] = s * a[row_p] . b[col_p], with
+ * s = 1 (scale NULL), *scale, or sigmoid(*scale).  This is the gradient of gnpde_spmm_rhs w.r.t. the
+ * per-edge weights (d w_e = alpha' g_row . u_col) that autograd needs when the reference's blocks hand
+ * attention_weights with gradients (training, src/block_transformer_attention.py:38-39). */
+int gnpde_sddmm(const gnpde_graph_t* g, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t d,
+                const float* scale, int32_t scale_sigmoid, float* out_csr, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense feature mixing on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
  *   out[n, m] = x[n, d] * W[m, d]^T + b[m]          (b may be NULL)

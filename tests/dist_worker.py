@@ -47,14 +47,16 @@ class OracleBackend(object):
     third = 1 / 3
     if stage == _lib.STAGE_EULER:
       out_y[:n] = y[:n] + dt * k
-    elif stage == _lib.STAGE_RK1:
-      out_k.copy_(k); out_y[:n] = y[:n] + dt * k * third
-    elif stage == _lib.STAGE_RK2:
-      out_k.copy_(k); out_y[:n] = y[:n] + dt * (k - k1 * third)
-    elif stage == _lib.STAGE_RK3:
-      out_k.copy_(k); out_y[:n] = y[:n] + dt * (k1 - k2 + k)
-    elif stage == _lib.STAGE_RK4:
-      out_y[:n] = y[:n] + (k1 + 3 * (k2 + k3) + k) * dt * 0.125
+    elif stage == _lib.STAGE_RK1C:
+      out_y[:n] = u[:n] + dt * k * third
+    elif stage == _lib.STAGE_RK2C:
+      out_y[:n] = (2 * y[:n] - u[:n]) + dt * k
+    elif stage == _lib.STAGE_RK3C:
+      out_y[:n] = (2 * k1[:n] - u[:n]) + dt * k
+    elif stage == _lib.STAGE_RK4C:
+      out_y[:n] = ((6 * k1[:n] + 3 * u[:n] - y[:n]) + dt * k) * 0.125
+    else:
+      raise ValueError(stage)
 
 
 def main():

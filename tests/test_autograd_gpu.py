@@ -1,0 +1,144 @@
+"""Gradients of the right-hand side and of a whole differentiated solve against CPU autograd through the
+oracle (same op sequence as the reference)."""
+import pytest
+import torch
+
+import gnpde_amd as G
+from oracle import restate as R
+from helpers import Data, assert_parity, random_graph
+
+pytestmark = pytest.mark.gpu
+
+OPT = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False,
+           reweight_attention=False, beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9,
+           add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=20, augment=False, adjoint=False,
+           tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
+           function='transformer', time=2.0)
+GTOL = 2e-4  # gradients accumulate more rounding than values (long reductions in different orders)
+
+
+def _rand_params(mod, seed, dev):
+  g = torch.Generator().manual_seed(seed)
+  with torch.no_grad():
+    for p in mod.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      else:
+        p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(dev))
+
+
+def _cpu(t):
+  return t.detach().cpu().clone().requires_grad_(True)
+
+
+@pytest.mark.parametrize('block_kind', ['constant', 'attention'])
+def test_laplacian_native_backward(dev, block_kind):
+  n, d = 700, 20
+  ei = random_graph(n, 5, seed=3, hubs=1, hub_deg=600)
+  g = torch.Generator().manual_seed(1)
+  x, x0, go = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  opt = dict(OPT, function='laplacian', block=block_kind)
+  func = G.LaplacianODEFunc(d, d, opt, Data(x, ei), dev).to(dev)
+  _rand_params(func, 2, dev)
+  w_edge = torch.rand(ei.shape[1], 4 if block_kind == 'attention' else 1, generator=g) + 0.1
+  if block_kind != 'attention':
+    w_edge = w_edge[:, 0].contiguous()
+  func.edge_index = ei.to(dev)
+  wd = w_edge.to(dev).requires_grad_(True)
+  func.edge_weight, func.attention_weights, func.x0 = wd, wd, x0.to(dev)
+  xd = x.to(dev).requires_grad_(True)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  # oracle on CPU
+  xc, wc, ac, bc = _cpu(x), _cpu(w_edge), _cpu(func.alpha_train), _cpu(func.beta_train)
+  fr = R.rhs_laplacian(xc, ei, wc, ac, bc, x0, False, True)
+  assert_parity(f, fr, what='value')
+  fr.backward(go)
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  assert_parity(wd.grad, wc.grad, tol=GTOL, what='d edge weights')
+  assert_parity(func.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
+  assert_parity(func.beta_train.grad.reshape(-1), bc.grad.reshape(-1), tol=GTOL, what='dbeta')
+
+
+@pytest.mark.parametrize('function', ['transformer', 'GAT'])
+def test_training_step_through_the_solver(dev, function):
+  """loss.backward() through a 2-step rk4 solve of a block in training mode (what run_GNN.py's train() does)."""
+  n, d = 400, 20
+  ei = random_graph(n, 5, seed=5)
+  g = torch.Generator().manual_seed(4)
+  x = torch.randn(n, d, generator=g)
+  opt = dict(OPT, function=function)
+  fcls = G.ODEFuncTransformerAtt if function == 'transformer' else G.ODEFuncAtt
+  block = G.ConstantODEblock(fcls, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  _rand_params(block, 6, dev)
+  block.train()
+  xd = x.to(dev).requires_grad_(True)
+  block.set_x0(xd)
+  z = block(xd)
+  loss = (z ** 2).sum()
+  loss.backward()
+  f = block.odefunc
+  lay = f.multihead_att_layer
+  edge = f.edge_index.cpu()
+  xc = _cpu(x)
+  ac, bc = _cpu(f.alpha_train), _cpu(f.beta_train)
+  if function == 'transformer':
+    ps = [_cpu(p) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+    rhs = lambda t, y: R.rhs_transformer(y, edge, ps[0], ps[1], ps[2], ps[3], 4, ac, bc, x, False, True)
+    ours = [lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias]
+  else:
+    ps = [_cpu(lay.W), _cpu(lay.a)]
+    rhs = lambda t, y: R.rhs_gat(y, edge, ps[0], ps[1], 4, ac, bc, x, False, True, 0.2, 0)
+    ours = [lay.W, lay.a]
+  zr = R.odeint_fixed(rhs, xc, opt['time'], 1.0, 'rk4')
+  assert_parity(z, zr, what='z')
+  (zr ** 2).sum().backward()
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  scale = max(float(b.grad.abs().max()) for b in ps)
+  for a, b in zip(ours, ps):
+    # (the gradient w.r.t. K.bias is identically zero -- a row softmax ignores q_i.b_k -- so compare absolutely)
+    assert float((a.grad.cpu() - b.grad).abs().max()) <= GTOL * scale, 'dparam'
+  assert_parity(f.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
+
+
+def test_attention_block_training(dev):
+  """AttODEblock in training mode: attention computed once (with history), Laplacian function native backward,
+  edge-weight gradients through gnpde_sddmm into the attention layer's parameters."""
+  n, d = 300, 20
+  ei = random_graph(n, 5, seed=8)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(7))
+  opt = dict(OPT, function='laplacian', block='attention', method='euler', time=3.0)
+  block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, 3.0])).to(dev)
+  _rand_params(block, 9, dev)
+  block.train()
+  xd = x.to(dev).requires_grad_(True)
+  block.set_x0(xd)
+  z = block(xd)
+  (z ** 2).sum().backward()
+  lay, f = block.multihead_att_layer, block.odefunc
+  xc = _cpu(x)
+  ps = [_cpu(p) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+  ac, bc = _cpu(f.alpha_train), _cpu(f.beta_train)
+  e_n, w_n = R.get_rw_adj(ei, None, 1, 1, n)
+  att, _ = R.transformer_attention(xc, e_n, ps[0], ps[1], ps[2], ps[3], 4)
+  rhs = lambda t, y: R.rhs_laplacian(y, e_n, att, ac, bc, x, False, True)
+  zr = R.odeint_fixed(rhs, xc, 3.0, 1.0, 'euler')
+  assert_parity(z, zr, what='z')
+  (zr ** 2).sum().backward()
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  scale = max(float(b.grad.abs().max()) for b in ps)
+  for a, b in zip((lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias), ps):
+    assert float((a.grad.cpu() - b.grad).abs().max()) <= GTOL * scale, 'd attention params'
+
+
+
+def test_sddmm(dev):
+  from gnpde_amd import ops
+  n, d = 900, 36
+  ei = random_graph(n, 6, seed=2, hubs=1, hub_deg=700)
+  g = torch.Generator().manual_seed(3)
+  a, b = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  graph = G.CSRGraph(ei.to(dev), n)
+  out = ops.sddmm(graph, a.to(dev), b.to(dev))
+  ref = (a[ei[0]] * b[ei[1]]).sum(dim=1)
+  assert_parity(out[:graph.e], ref[graph.perm_long.cpu()], what='sddmm')
