@@ -318,12 +318,12 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(const AttArgs a) {
 // (a) one block per 512-entry chunk: scores -> scratch, chunk maximum and sum of exponentials per head
 // (b) one block per chunk: fold the row's chunk partials (<= max_chunks of them) and write the weights
 template <int TYPE, bool VEC4>
-__global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArgs a, float* __restrict__ part) {
+__device__ __forceinline__ void hub_scores_partial_body(const AttArgs& a, float* __restrict__ part, int chunk) {
   __shared__ float red[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int b = a.chunk_begin[blockIdx.x], e = a.chunk_end[blockIdx.x];
+  const int b = a.chunk_begin[chunk], e = a.chunk_end[chunk];
   const int row = a.rowidx[b];
-  float* out = part + static_cast<size_t>(blockIdx.x) * 2 * a.h;
+  float* out = part + static_cast<size_t>(chunk) * 2 * a.h;
   for (int head = 0; head < a.h; ++head) {
     float sv[GNPDE_LONG_ROW / kBlock];
     float mx = -INFINITY;
@@ -356,11 +356,15 @@ __global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArg
   }
 }
 
-__global__ __launch_bounds__(kBlock) void hub_normalise_kernel(const AttArgs a, const float* __restrict__ part,
-                                                              const int* __restrict__ long_chunk_row_first) {
+template <int TYPE, bool VEC4>
+__global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArgs a, float* __restrict__ part) {
+  hub_scores_partial_body<TYPE, VEC4>(a, part, blockIdx.x);
+}
+
+__device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float* __restrict__ part,
+                                                   const int* __restrict__ long_chunk_row_first, int c) {
   // long_chunk_row_first[c] = index of the first chunk of the row chunk c belongs to
-  extern __shared__ float st[];  // [2h]: row maximum and denominator per head
-  const int c = blockIdx.x;
+  __shared__ float st[2 * 64];  // [2h]: row maximum and denominator per head
   const int b = a.chunk_begin[c], e = a.chunk_end[c];
   const int row = a.rowidx[b];
   const int c0 = long_chunk_row_first[c];
@@ -384,6 +388,11 @@ __global__ __launch_bounds__(kBlock) void hub_normalise_kernel(const AttArgs a, 
       acc += expf(a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) / st[a.h + head];
     a.w_mean[p] = acc / static_cast<float>(a.h);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void hub_normalise_kernel(const AttArgs a, const float* __restrict__ part,
+                                                              const int* __restrict__ long_chunk_row_first) {
+  hub_normalise_body(a, part, long_chunk_row_first, blockIdx.x);
 }
 
 // ---- fused path: softmax over the row, head-mean weights only.
@@ -454,14 +463,24 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
 // PB passes) are issued first, then all k gathers, then the arithmetic -- 2 round trips per BATCH.
 // Out-of-range slots read a clamped (valid, cached) position and are masked to -inf afterwards, so the
 // batch is branch-free.  d_k = 4 * DK4.
+// The first `n_hub` blocks of the launch do the hub-row work instead (phase 0: chunk scores + partial
+// statistics, phase 1: fold partials + normalise), so the long rows ride along with the row kernels rather
+// than costing two extra serialised launches.
 template <int H, int DK4, int GL, int RI, int PB, int NB>
-__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows) {
+__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
+                                                                 int hub_phase, float* __restrict__ part,
+                                                                 const int* __restrict__ chunk_first) {
+  if (static_cast<int>(blockIdx.x) < n_hub) {
+    if (hub_phase == 0) hub_scores_partial_body<GNPDE_ATT_SCALED_DOT, true>(a, part, blockIdx.x);
+    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
+    return;
+  }
   constexpr int RPW = kWave / GL;
   constexpr int GE = GL / H;
   const int lane = threadIdx.x & (kWave - 1);
   const int gi = lane % GL;
   const int slot = gi / H, head = gi % H;
-  const long long rbase = ((static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL) * RI;
+  const long long rbase = ((static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL) * RI;
 
   int row[RI], e0[RI], e1[RI];
   bool live[RI];
@@ -633,22 +652,42 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
 }
 
 template <int H, int DK4>
-void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s) {
+void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
+                    const int* chunk_first = nullptr) {
   constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
   constexpr int RPW16 = kWave / GL16;
   constexpr int RI16 = (DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1);  // rows interleaved per group
   constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);         // passes to cover GNPDE_LONG_ROW entries
   constexpr int PB64 = (DK4 == 1) ? 4 : 2;
-  if (n16 > 0) {
+  // launch 1: hub phase 0 + rows with <= 16 entries; launch 2: hub phase 1 + rows with 17..512 entries
+  if (n16 > 0 || n_hub > 0) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
-    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16);
+    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block) + n_hub;
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
+                       0, part, chunk_first);
   }
-  if (n64 > 0) {
-    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16, n64);
+  if (n64 > 0 || n_hub > 0) {
+    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub;
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16,
+                       n64, n_hub, 1, part, chunk_first);
   }
+}
+
+// scaled-dot rows + hub chunks in two launches; false if this (heads, d_k) has no specialised kernel
+bool launch_sd_with_hubs(const AttArgs& c, int n16, int n64, int n_hub, float* part, const int* chunk_first, hipStream_t s) {
+  if (g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] != 0) return false;
+#define GNPDE_SD(HH)                                                                              \
+  case HH:                                                                                        \
+    if (c.dk == 4) { launch_rows_sd<HH, 1>(c, n16, n64, s, n_hub, part, chunk_first); return true; }  \
+    if (c.dk == 8) { launch_rows_sd<HH, 2>(c, n16, n64, s, n_hub, part, chunk_first); return true; }  \
+    if (c.dk == 16) { launch_rows_sd<HH, 4>(c, n16, n64, s, n_hub, part, chunk_first); return true; } \
+    return false;
+  switch (c.h) {
+    GNPDE_SD(1) GNPDE_SD(2) GNPDE_SD(4) GNPDE_SD(8)
+    default: return false;
+  }
+#undef GNPDE_SD
 }
 
 template <int TYPE, int H, bool VEC4>
@@ -779,17 +818,23 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   const bool fused = a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
                      g->bin_rows != nullptr && fused_supported(a, vec4);
   if (fused) {
+    AttArgs c = a;
+    c.chunk_begin = g->long_chunk_begin;
+    c.chunk_end = g->long_chunk_end;
+    c.long_segs = g->long_rows;
+    if (a.type == GNPDE_ATT_SCALED_DOT && vec4 && (fork == nullptr || fork->aux == nullptr) &&
+        (g->n_long_rows == 0 || g->long_chunk_first != nullptr) &&
+        launch_sd_with_hubs(c, g->n_bin16, g->n_bin64, g->n_long_rows > 0 ? g->n_long_chunks : 0, part, g->long_chunk_first,
+                            stream)) {
+      GNPDE_LAUNCH_CHECK();
+      return 0;
+    }
     hipStream_t br = stream;
-    if (g->n_long_rows > 0) {  // hubs: the general passes restricted to the long rows' chunks, as a parallel branch
+    if (g->n_long_rows > 0) {  // hubs: chunk passes, as a parallel branch when a fork stream is given
       br = fork_begin(fork, stream);
-      AttArgs c = a;
-      c.chunk_begin = g->long_chunk_begin;
-      c.chunk_end = g->long_chunk_end;
-      c.long_segs = g->long_rows;
       launch_hub_a_any(c, vec4, part, g->n_long_chunks, br);
       GNPDE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(hub_normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 2 * a.h * sizeof(float), br, c, part,
-                         g->long_chunk_first);
+      hipLaunchKernelGGL(hub_normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 0, br, c, part, g->long_chunk_first);
       GNPDE_LAUNCH_CHECK();
     }
     launch_rows_any(a, g->n_bin16, g->n_bin64, stream);

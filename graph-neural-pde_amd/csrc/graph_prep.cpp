@@ -135,9 +135,14 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// k-way row partition.  Phase 1 grows parts by BFS until each holds ~1/k of the work (work of a row
-// = its nnz + 1, i.e. balance on EDGES, which is what the SpMM time follows).  Phase 2 is a
-// balance-constrained label propagation that moves a row to the part most of its neighbours live in.
+// k-way row partition (METIS is not available offline).  Work of a row = its nnz + 1, i.e. balance on
+// EDGES, which is what the aggregation time follows.
+//   A. size-constrained label propagation: every node joins the cluster most of its neighbours are in,
+//      clusters capped at a quarter of a part  -> communities (hubs do not glue everything together
+//      because a full cluster stops accepting members);
+//   B. clusters, heaviest first, are packed into the part they are most connected to that still has room;
+//   C. balance-constrained label propagation on single nodes across parts.
+// Deterministic for a given seed.
 // ------------------------------------------------------------------------------------------------
 extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes,
                                     int32_t n_parts, int32_t refine_iters, uint64_t seed, int32_t* part) {
@@ -149,69 +154,136 @@ extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx
     return 0;
   }
   auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + 1; };
-  int64_t total = 0;
-  for (int32_t v = 0; v < n; ++v) total += work(v);
-  std::fill(part, part + n, -1);
-  std::vector<int64_t> load(P, 0);
-  int32_t next_unassigned = 0;
-  int64_t assigned_work = 0;
-  uint64_t rng = seed * 6364136223846793005ULL + 1442695040888963407ULL;
-  (void)rng;
-  for (int32_t p = 0; p < P; ++p) {
-    const int64_t target = (total - assigned_work) / (P - p);
-    std::queue<int32_t> q;
-    while (load[p] < target || p == P - 1) {
-      if (q.empty()) {
-        while (next_unassigned < n && part[next_unassigned] != -1) ++next_unassigned;
-        if (next_unassigned >= n) break;
-        part[next_unassigned] = p;
-        load[p] += work(next_unassigned);
-        q.push(next_unassigned);
-        continue;
-      }
-      const int32_t v = q.front();
-      q.pop();
-      for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
-        const int32_t u = colidx[e];
-        if (part[u] == -1 && (load[p] < target || p == P - 1)) {
-          part[u] = p;
-          load[p] += work(u);
-          q.push(u);
-        }
-      }
-    }
-    assigned_work += load[p];
-  }
+  int64_t total = 0, maxw = 0;
   for (int32_t v = 0; v < n; ++v) {
-    if (part[v] < 0) {  // cannot happen (last part sweeps the rest) but keep the output total
-      part[v] = P - 1;
-      load[P - 1] += work(v);
-    }
+    total += work(v);
+    maxw = std::max(maxw, work(v));
   }
   const double avg = double(total) / P;
-  const int64_t hi = static_cast<int64_t>(avg * 1.03) + 1, lo = static_cast<int64_t>(avg * 0.97);
-  std::vector<int32_t> cnt(P, 0), touched;
-  touched.reserve(64);
-  for (int32_t it = 0; it < refine_iters; ++it) {
+  const int64_t hi = static_cast<int64_t>(avg * 1.03) + maxw / 8 + 1, lo = static_cast<int64_t>(avg * 0.97) - maxw / 8;
+
+  // visiting order: a fixed pseudo-random permutation (stride coprime with n)
+  std::vector<int32_t> order(n);
+  {
+    uint64_t stride = (seed * 2654435761ULL + 40503ULL) % std::max<int64_t>(n, 1);
+    if (stride == 0) stride = 1;
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, static_cast<uint64_t>(n)) != 1) ++stride;
+    uint64_t cur = seed % n;
+    for (int32_t i = 0; i < n; ++i) {
+      order[i] = static_cast<int32_t>(cur);
+      cur = (cur + stride) % n;
+    }
+  }
+
+  // ---- A. clusters
+  std::vector<int32_t> label(n);
+  std::vector<int64_t> cw(n);
+  for (int32_t v = 0; v < n; ++v) {
+    label[v] = v;
+    cw[v] = work(v);
+  }
+  const int64_t cap = std::max<int64_t>(static_cast<int64_t>(avg / 4), maxw);
+  std::vector<int32_t> cnt(n, 0), touched;
+  touched.reserve(256);
+  const int cluster_iters = std::max(4, refine_iters);
+  for (int it = 0; it < cluster_iters; ++it) {
     int64_t moved = 0;
-    for (int32_t v = 0; v < n; ++v) {
-      const int32_t from = part[v];
+    for (int32_t oi = 0; oi < n; ++oi) {
+      const int32_t v = order[oi];
+      const int32_t own = label[v];
       touched.clear();
       for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
         const int32_t u = colidx[e];
         if (u == v) continue;
-        if (cnt[part[u]]++ == 0) touched.push_back(part[u]);
+        const int32_t lu = label[u];
+        if (cnt[lu]++ == 0) touched.push_back(lu);
       }
-      int32_t best = from, best_cnt = cnt[from];
-      for (int32_t p : touched) {
-        if (cnt[p] > best_cnt || (cnt[p] == best_cnt && p != from && load[p] < load[best])) {
-          if (p != from) {
-            best = p;
-            best_cnt = cnt[p];
-          }
+      const int64_t w = work(v);
+      int32_t best = own;
+      int32_t best_cnt = cnt[own];
+      for (int32_t lb : touched) {
+        if (lb == own) continue;
+        if (cnt[lb] > best_cnt && cw[lb] + w <= cap) {
+          best = lb;
+          best_cnt = cnt[lb];
         }
       }
-      for (int32_t p : touched) cnt[p] = 0;
+      for (int32_t lb : touched) cnt[lb] = 0;
+      if (best != own) {
+        cw[own] -= w;
+        cw[best] += w;
+        label[v] = best;
+        ++moved;
+      }
+    }
+    if (moved == 0) break;
+  }
+  // compact cluster ids, member lists
+  std::vector<int32_t> cid(n, -1);
+  int32_t nc = 0;
+  for (int32_t v = 0; v < n; ++v)
+    if (cid[label[v]] < 0) cid[label[v]] = nc++;
+  std::vector<int64_t> cweight(nc, 0);
+  std::vector<int32_t> cptr(nc + 1, 0), members(n);
+  for (int32_t v = 0; v < n; ++v) {
+    label[v] = cid[label[v]];
+    cweight[label[v]] += work(v);
+    ++cptr[label[v] + 1];
+  }
+  for (int32_t c = 0; c < nc; ++c) cptr[c + 1] += cptr[c];
+  {
+    std::vector<int32_t> cur(cptr.begin(), cptr.end() - 1);
+    for (int32_t v = 0; v < n; ++v) members[cur[label[v]]++] = v;
+  }
+  // ---- B. pack clusters into parts
+  std::vector<int32_t> corder(nc);
+  std::iota(corder.begin(), corder.end(), 0);
+  std::stable_sort(corder.begin(), corder.end(), [&](int32_t a, int32_t b) { return cweight[a] > cweight[b]; });
+  std::vector<int32_t> cpart(nc, -1);
+  std::vector<int64_t> load(P, 0), conn(P, 0);
+  for (int32_t c : corder) {
+    std::fill(conn.begin(), conn.end(), 0);
+    for (int32_t i = cptr[c]; i < cptr[c + 1]; ++i) {
+      const int32_t v = members[i];
+      for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+        const int32_t pc = cpart[label[colidx[e]]];
+        if (pc >= 0) ++conn[pc];
+      }
+    }
+    int32_t best = -1;
+    for (int32_t p = 0; p < P; ++p) {
+      if (load[p] + cweight[c] > hi) continue;
+      if (best < 0 || conn[p] > conn[best] || (conn[p] == conn[best] && load[p] < load[best])) best = p;
+    }
+    if (best < 0) best = static_cast<int32_t>(std::min_element(load.begin(), load.end()) - load.begin());
+    cpart[c] = best;
+    load[best] += cweight[c];
+  }
+  for (int32_t v = 0; v < n; ++v) part[v] = cpart[label[v]];
+
+  // ---- C. node-level refinement under the balance constraint
+  std::vector<int32_t> pcnt(P, 0), ptouched;
+  ptouched.reserve(P);
+  for (int32_t it = 0; it < refine_iters; ++it) {
+    int64_t moved = 0;
+    for (int32_t oi = 0; oi < n; ++oi) {
+      const int32_t v = order[oi];
+      const int32_t from = part[v];
+      ptouched.clear();
+      for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+        const int32_t u = colidx[e];
+        if (u == v) continue;
+        if (pcnt[part[u]]++ == 0) ptouched.push_back(part[u]);
+      }
+      int32_t best = from, best_cnt = pcnt[from];
+      for (int32_t p : ptouched) {
+        if (p != from && pcnt[p] > best_cnt) {
+          best = p;
+          best_cnt = pcnt[p];
+        }
+      }
+      for (int32_t p : ptouched) pcnt[p] = 0;
       if (best != from) {
         const int64_t w = work(v);
         if (load[best] + w <= hi && load[from] - w >= lo) {

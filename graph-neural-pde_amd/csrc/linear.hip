@@ -39,8 +39,9 @@ __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ base, int
 }
 
 // MT = number of 16-column output tiles kept in registers by one wave.
-// FULL: every row of the tile exists, every column tile is complete and d % 16 == 0 -> no guards, so the
-// operand loads of a K batch are straight-line code the scheduler can issue back to back.
+// FULL: every column tile is complete and d % 16 == 0 -> no guards on the operand loads (rows past the end
+// are clamped to the last row and only their stores are masked), so the loads of a K batch are
+// straight-line code the scheduler can issue back to back, and one launch covers the ragged last tile.
 template <int MT, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int n, int d, int ldx,
                                                         const float* __restrict__ W, int m, int ldw,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
   const int kq = lane >> 4;      // which 4-wide K quarter of the 16-wide K block
   const int arow = row0 + r;
   const bool arow_ok = arow < n;
-  const float* xrow = x + static_cast<size_t>(arow_ok ? arow : 0) * ldx;
+  const float* xrow = x + static_cast<size_t>(arow_ok ? arow : (FULL ? n - 1 : 0)) * ldx;
 
   f32x4 acc[MT];
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int orow = row0 + 4 * kq + i;
-      if (FULL || orow < n) out[static_cast<size_t>(orow) * ldo + col] = acc[t][i] + bias;
+      if (orow < n) out[static_cast<size_t>(orow) * ldo + col] = acc[t][i] + bias;
     }
   }
 }
@@ -125,19 +126,14 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
                  int ldo, int col, hipStream_t s) {
   // complete 16-row tiles with complete column tiles and d % 16 == 0 take the unguarded kernel
   const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
-  const int full_rows = full_cols ? (n / 16) * 16 : 0;
-  if (full_rows > 0) {
-    const long long tiles = full_rows / 16;
-    const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, true>), dim3(grid), dim3(kBlock), 0, s, x, full_rows, d, ldx, W, m, ldw, b,
-                       out, ldo, col, 0);
-  }
-  if (full_rows < n) {
-    const long long tiles = (static_cast<long long>(n) - full_rows + 15) / 16;
-    const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const long long tiles = (static_cast<long long>(n) + 15) / 16;
+  const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (full_cols)
+    hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, true>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo,
+                       col, 0);
+  else
     hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, false>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out,
-                       ldo, col, full_rows);
-  }
+                       ldo, col, 0);
 }
 
 template <bool ALIGNED>
