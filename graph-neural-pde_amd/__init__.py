@@ -15,11 +15,13 @@ from .function_transformer_attention import ODEFuncTransformerAtt, SpGraphTransA
 from .function_GAT_attention import ODEFuncAtt, SpGraphAttentionLayer
 from .block_constant import ConstantODEblock
 from .block_transformer_attention import AttODEblock
+from .block_mixed import MixedODEblock
+from .block_transformer_hard_attention import HardAttODEblock
 from .model_configurations import set_block, set_function, BlockNotDefined, FunctionNotDefined
 from . import synthetic
 
 __all__ = ['GnpdeError', 'build', 'lib', 'CSRGraph', 'graph_of', 'partition_rows', 'ops', 'MaxNFEException',
            'get_rw_adj', 'gcn_norm_fill_val', 'add_remaining_self_loops', 'odeint', 'odeint_adjoint', 'time_grid',
            'ODEFunc', 'ODEblock', 'LaplacianODEFunc', 'ODEFuncTransformerAtt', 'SpGraphTransAttentionLayer',
-           'ODEFuncAtt', 'SpGraphAttentionLayer', 'ConstantODEblock', 'AttODEblock', 'set_block', 'set_function',
+           'ODEFuncAtt', 'SpGraphAttentionLayer', 'ConstantODEblock', 'AttODEblock', 'MixedODEblock', 'HardAttODEblock', 'set_block', 'set_function',
            'synthetic']

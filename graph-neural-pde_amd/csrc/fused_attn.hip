@@ -42,16 +42,37 @@ struct FusedArgs {
   const float* __restrict__ proj_w;  // [2A, d]: rows 0..A-1 = W_q, A..2A-1 = W_k
   const float* __restrict__ proj_b;  // [2A]
   int A, dk;
-  float sqrt_dk;
+  float inv_sqrt_dk;
   const float* __restrict__ edge_w;  // CSR order or null (reweight_attention)
   float* partial;                    // [n_long_chunks][H][ldp + 4]
   int ldp;
   gnpde_epilogue_t ep;
 };
 
-// launch bound: 3 wavefronts per SIMD for H <= 4 (caps the allocation at 168 VGPRs; 169 would drop to 2)
-template <int H, int VEC, int L, int K, int U>
-__global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kernel(const FusedArgs a) {
+// ---- cross-lane helpers.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round trip per call); inside
+// a 16-lane row the same butterflies are single VALU instructions with DPP modifiers.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum / max over the L lanes of a group (L = 16, 32 or 64); every lane of the group ends with the result
+template <int L>
+__device__ __forceinline__ float group_sum(float x) {
+  x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);  // row_half_mirror
+  x += dpp_mov<0x140>(x);  // row_mirror
+  if constexpr (L >= 32) x += __shfl_xor(x, 16, kWave);
+  if constexpr (L >= 64) x += __shfl_xor(x, 32, kWave);
+  return x;
+}
+// exp for arguments <= 0 on the transcendental unit: 2^(x log2 e); the product's rounding costs a relative
+// error of |x| 6e-8, negligible where the weight is not (e^x < 1e-7 beyond |x| = 16)
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+// WPS = wavefronts per SIMD the register allocator must leave room for (launch bound)
+template <int H, int VEC, int L, int K, int U, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void attn_rhs_fused_kernel(const FusedArgs a) {
   constexpr int G = kWave / L;
   extern __shared__ __align__(16) float smem[];
   float* sWq = smem;                                   // [A][d]
@@ -132,8 +153,7 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
             for (int v = 0; v < VEC; ++v) qm = fmaf(wq[v], xi[k][v], qm);
           }
         }
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) qm += __shfl_xor(qm, off, kWave);
+        qm = group_sum<L>(qm);
         qm += sB[mrow];
         cst[h] = fmaf(qm, sB[a.A + mrow], cst[h]);
 #pragma unroll
@@ -189,17 +209,15 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
           sc[t][h] = p;
         }
 #pragma unroll
-      for (int off = 1; off < L; off <<= 1)
+      for (int t = 0; t < U; ++t)
 #pragma unroll
-        for (int t = 0; t < U; ++t)
-#pragma unroll
-          for (int h = 0; h < H; ++h) sc[t][h] += __shfl_xor(sc[t][h], off, kWave);
+        for (int h = 0; h < H; ++h) sc[t][h] = group_sum<L>(sc[t][h]);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float bm = -INFINITY;
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-          float s = (sc[t][h] + cst[h]) / a.sqrt_dk;
+          float s = (sc[t][h] + cst[h]) * a.inv_sqrt_dk;
           if (a.edge_w != nullptr) s = s * ew[t];
           sc[t][h] = ok[t] ? s : -INFINITY;
           bm = fmaxf(bm, sc[t][h]);
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
 #pragma unroll
         for (int off = L; off < kWave; off <<= 1) bm = fmaxf(bm, __shfl_xor(bm, off, kWave));
         const float mn = fmaxf(m[h], bm);
-        const float scale = expf(m[h] - mn);  // first batch: exp(-inf) = 0
+        const float scale = fast_exp(m[h] - mn);  // first batch: exp(-inf) = 0
         m[h] = mn;
         l[h] *= scale;
 #pragma unroll
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
           for (int v = 0; v < VEC; ++v) acc[h][k][v] *= scale;
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-          const float p = expf(sc[t][h] - mn);  // masked slots: exp(-inf) = 0
+          const float p = fast_exp(sc[t][h] - mn);  // masked slots: exp(-inf) = 0
           l[h] += p;
 #pragma unroll
           for (int k = 0; k < K; ++k)
@@ -252,6 +270,9 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
       }
       continue;
     }
+    float rl[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) rl[h] = (1.0f / static_cast<float>(H)) / (l[h] + 1e-16f);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (!colok[k]) continue;
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(kBlock, (H <= 4 ? 3 : 2)) void attn_rhs_fused_kerne
       for (int v = 0; v < VEC; ++v) {
         float s = 0.0f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) s += acc[h][k][v] / (l[h] + 1e-16f);
-        ax[v] = s / static_cast<float>(H);
+        for (int h = 0; h < H; ++h) s = fmaf(acc[h][k][v], rl[h], s);
+        ax[v] = s;
       }
       epilogue<VEC, true>(a.ep, alpha, beta, roff + cols[k], ax, xi[k]);
     }
@@ -311,10 +332,10 @@ __global__ __launch_bounds__(kBlock) void attn_long_reduce_kernel(const FusedArg
 
 int g_num_cus = 0;
 
-template <int H, int L, int K, int U>
+template <int H, int L, int K, int U, int WPS>
 int launch_fused(const FusedArgs& a, const gnpde_graph_t* g, hipStream_t s) {
   const size_t lds = (2 * static_cast<size_t>(a.A) * a.d + 2 * a.A) * sizeof(float);
-  auto kern = attn_rhs_fused_kernel<H, 4, L, K, U>;
+  auto kern = attn_rhs_fused_kernel<H, 4, L, K, U, WPS>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     GNPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -354,9 +375,21 @@ int launch_fused(const FusedArgs& a, const gnpde_graph_t* g, hipStream_t s) {
 template <int H>
 int dispatch_fused(const FusedArgs& a, const gnpde_graph_t* g, hipStream_t s) {
   const int slots = a.d / 4;
-  if (slots <= 32) return launch_fused<H, 16, 2, (H <= 4 ? 4 : 2)>(a, g, s);
-  if (slots <= 64) return launch_fused<H, 32, 2, (H <= 4 ? 4 : 2)>(a, g, s);
-  if (slots <= 128) return launch_fused<H, 64, 2, 2>(a, g, s);
+  if (slots <= 32) {
+    if constexpr (H <= 4) {
+      switch (g_tune[GNPDE_TUNE_ONE_PASS_VARIANT]) {
+        case 1: return launch_fused<H, 16, 2, 4, 2>(a, g, s);
+        case 2: return launch_fused<H, 16, 2, 2, 3>(a, g, s);
+        case 3: return launch_fused<H, 16, 2, 2, 4>(a, g, s);
+        case 4: return launch_fused<H, 16, 2, 1, 4>(a, g, s);
+        default: return launch_fused<H, 16, 2, 4, 3>(a, g, s);
+      }
+    } else {
+      return launch_fused<H, 16, 2, 2, 2>(a, g, s);
+    }
+  }
+  if (slots <= 64) return launch_fused<H, 32, 2, 2, 2>(a, g, s);
+  if (slots <= 128) return launch_fused<H, 64, 2, 2, 2>(a, g, s);
   return GNPDE_ESHAPE;
 }
 
@@ -412,7 +445,7 @@ int launch_attn_rhs_fused(const gnpde_graph_t* g, const gnpde_attention_t* at, c
   a.proj_b = proj_b;
   a.A = at->att_dim;
   a.dk = at->att_dim / at->heads;
-  a.sqrt_dk = static_cast<float>(std::sqrt(static_cast<double>(a.dk)));
+  a.inv_sqrt_dk = static_cast<float>(1.0 / std::sqrt(static_cast<double>(a.dk)));
   a.edge_w = at->edge_w_csr;
   a.ldp = static_cast<int>(align_up(static_cast<size_t>(d), 4));
   a.partial = static_cast<float*>(ws);

@@ -5,6 +5,8 @@ from .function_GAT_attention import ODEFuncAtt
 from .function_laplacian_diffusion import LaplacianODEFunc
 from .block_transformer_attention import AttODEblock
 from .block_constant import ConstantODEblock
+from .block_mixed import MixedODEblock
+from .block_transformer_hard_attention import HardAttODEblock
 
 
 class BlockNotDefined(Exception):
@@ -15,7 +17,8 @@ class FunctionNotDefined(Exception):
   pass
 
 
-_BLOCKS = {'attention': AttODEblock, 'constant': ConstantODEblock}
+_BLOCKS = {'attention': AttODEblock, 'constant': ConstantODEblock, 'mixed': MixedODEblock,
+           'hard_attention': HardAttODEblock}
 _FUNCTIONS = {'laplacian': LaplacianODEFunc, 'GAT': ODEFuncAtt, 'transformer': ODEFuncTransformerAtt}
 
 
@@ -23,7 +26,7 @@ def set_block(opt):
   name = opt['block']
   if name in _BLOCKS:
     return _BLOCKS[name]
-  if name in ('mixed', 'hard_attention', 'rewire_attention'):
+  if name in ('rewire_attention',):
     raise BlockNotDefined('block %r is a "next" row of SURVEY.md section 8f, not built yet' % name)
   raise BlockNotDefined
 

@@ -31,6 +31,8 @@ from function_GAT_attention import ODEFuncAtt  # noqa: E402
 from function_laplacian_diffusion import LaplacianODEFunc  # noqa: E402
 from block_constant import ConstantODEblock  # noqa: E402
 from block_transformer_attention import AttODEblock  # noqa: E402
+from block_mixed import MixedODEblock  # noqa: E402
+from block_transformer_hard_attention import HardAttODEblock  # noqa: E402
 from GNN import GNN  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
@@ -203,11 +205,17 @@ def gen_blocks():
                                        tol_scale=800.0),
     'constant_transformer_dopri5': dict(block='constant', function='transformer', method='dopri5', time=2.0,
                                         tol_scale=100.0),
+    'mixed_laplacian_rk4': dict(block='mixed', function='laplacian', method='rk4', time=2.3),
+    'hard_laplacian_euler': dict(block='hard_attention', function='laplacian', method='euler', time=3.0,
+                                 att_samp_pct=0.6, use_flux=False),
+    'hard_transformer_rk4': dict(block='hard_attention', function='transformer', method='rk4', time=2.0,
+                                 att_samp_pct=0.8, use_flux=False),
   }
   for i, (name, over) in enumerate(cases.items()):
     opt = {**BASE, **over}
     fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt, 'GAT': ODEFuncAtt}[opt['function']]
-    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
+    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock, 'mixed': MixedODEblock,
+            'hard_attention': HardAttODEblock}[opt['block']]
     t = torch.tensor([0, opt['time']])
     block = bcls(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=t)
     randomise(block, 400 + i)
@@ -215,7 +223,19 @@ def gen_blocks():
     block.set_x0(x)
     with torch.no_grad():
       z = block(x)
-    save('block_' + name, opt, {'edge_index': ei, 'x': x, 'z': z, 'nfe': np.int64(block.odefunc.nfe)}, block)
+    extra = {}
+    if opt['block'] == 'hard_attention':   # also the training-mode forward: quantile edge sampling + renormalisation
+      nfe_eval = block.odefunc.nfe
+      block.train()
+      block.set_x0(x)
+      import io, contextlib
+      with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        z_train = block(x)
+      extra = {'z_train': z_train, 'train_edge_index': block.odefunc.edge_index,
+               'train_attention': block.odefunc.attention_weights}
+      block.eval()
+      block.odefunc.nfe = nfe_eval
+    save('block_' + name, opt, dict({'edge_index': ei, 'x': x, 'z': z, 'nfe': np.int64(block.odefunc.nfe)}, **extra), block)
 
 
 def gen_gnn():

@@ -8,7 +8,8 @@ from helpers import Fixture, fixtures, Data, assert_parity
 pytestmark = pytest.mark.gpu
 
 FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}
-BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
+BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock, 'mixed': G.MixedODEblock,
+          'hard_attention': G.HardAttODEblock}
 
 
 @pytest.mark.parametrize('name', fixtures('func_transformer_') + fixtures('func_gat_'))
@@ -122,3 +123,21 @@ def test_max_nfe(dev):
       f(0.0, x)
     with pytest.raises(G.MaxNFEException):
       f(0.0, x)
+
+
+@pytest.mark.parametrize('name', fixtures('block_hard_'))
+def test_hard_attention_training_mode_sampling(dev, name):
+  """Training-mode forward of the hard-attention block (no gradients needed for the check): the quantile edge
+  selection must pick exactly the reference's edges, the renormalised weights and the state must match."""
+  fx = Fixture(name)
+  x = fx.t('x', dev)
+  block = G.HardAttODEblock(FUNCS[fx.opt['function']], [], fx.opt, Data(x, fx.t('edge_index', dev)), dev,
+                            t=torch.tensor([0, fx.opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  block.train()
+  block.set_x0(x)
+  with torch.no_grad():
+    z = block(x)
+  assert torch.equal(block.odefunc.edge_index.cpu(), fx.t('train_edge_index')), 'a different edge subset was sampled'
+  assert_parity(block.odefunc.attention_weights, fx.t('train_attention'), what='renormalised attention')
+  assert_parity(z, fx.t('z_train'), what='z (training mode)')

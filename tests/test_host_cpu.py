@@ -153,7 +153,8 @@ def test_state_dict_names_match_reference(name):
   data = Data(x, fx.t('edge_index'))
   fcls = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}[fx.opt['function']]
   if name.startswith('block_'):
-    bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}[fx.opt['block']]
+    bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock, 'mixed': G.MixedODEblock,
+            'hard_attention': G.HardAttODEblock}[fx.opt['block']]
     mod = bcls(fcls, [], fx.opt, data, torch.device('cpu'), t=torch.tensor([0, fx.opt['time']]))
   else:
     mod = fcls(x.shape[1], x.shape[1], fx.opt, data, torch.device('cpu'))
@@ -169,6 +170,8 @@ def test_registry():
   assert G.set_function({'function': 'laplacian'}) is G.LaplacianODEFunc
   assert G.set_block({'block': 'constant'}) is G.ConstantODEblock
   assert G.set_block({'block': 'attention'}) is G.AttODEblock
+  assert G.set_block({'block': 'mixed'}) is G.MixedODEblock
+  assert G.set_block({'block': 'hard_attention'}) is G.HardAttODEblock
   with pytest.raises(G.FunctionNotDefined):
     G.set_function({'function': 'nope'})
   with pytest.raises(G.BlockNotDefined):

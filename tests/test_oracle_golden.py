@@ -112,15 +112,25 @@ def _block_rhs(fx):
     e_n, w_n = R.gcn_norm_fill_val(ei, None, opt['self_loop_weight'], n)
   if opt['function'] == 'laplacian':
     w = w_n
-    if opt['block'] == 'attention':
+    if opt['block'] in ('attention', 'mixed', 'hard_attention'):
+      # block-level attention layer, evaluated once at x(0); the mixed block's layer carries no edge weights
+      ew = None if opt['block'] == 'mixed' else w_n
       att, _ = R.transformer_attention(x, e_n, p['multihead_att_layer.Q.weight'], p['multihead_att_layer.Q.bias'],
                                        p['multihead_att_layer.K.weight'], p['multihead_att_layer.K.bias'], opt['heads'],
-                                       edge_weights=w_n, reweight=opt['reweight_attention'], **_att_kwargs(opt))
+                                       edge_weights=ew, reweight=opt['reweight_attention'], **_att_kwargs(opt))
       w = att
+      if opt['block'] == 'mixed':        # block_mixed.py:41-45
+        gam = torch.sigmoid(p['gamma'])
+        w = att.mean(dim=1) * (1 - gam) + w_n * gam
+      elif opt['block'] == 'hard_attention':   # eval mode: all edges, head-mean attention (:67-69)
+        w = att.mean(dim=1)
     return lambda t, y: R.rhs_laplacian(y, e_n, w, p[pre + 'alpha_train'], p[pre + 'beta_train'], x0,
                                         opt['no_alpha_sigmoid'], opt['add_source'])
-  # transformer / GAT functions use their own self-loop-augmented edge list, not the block's
+  # transformer / GAT functions use their own self-loop-augmented edge list, not the block's -- except under the
+  # hard-attention block, which overwrites the function's edge_index with its own (:68)
   edge, _ = R.add_remaining_self_loops(ei, None, opt['self_loop_weight'], int(ei.max()) + 1)
+  if opt['block'] == 'hard_attention':
+    edge = e_n
   if opt['function'] == 'transformer':
     return _transformer_rhs(fx, p, pre, edge, x0)
   return lambda t, y: R.rhs_gat(y, edge, p[pre + 'multihead_att_layer.W'], p[pre + 'multihead_att_layer.a'], opt['heads'],
