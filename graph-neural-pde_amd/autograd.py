@@ -6,10 +6,13 @@ classes.  The FORWARD value is always the native kernels' (identical to inferenc
     dL/dx   = a (A^T g - g)          one launch of the same aggregation kernel on the transposed CSR
     dL/dw_e = a g_row . x_col        gnpde_sddmm (only when the edge weights carry gradients: attention block)
     dL/da, dL/db                     two dot products over [N,d]
-* GRAND-nl / GAT (attention recomputed inside f): the backward currently RECOMPUTES f from PyTorch
-  device ops and differentiates that composite (index_select / index_add, exactly the reference's op
-  sequence).  It is an interim implementation -- the native VJP (SDDMM + segment-softmax backward + two
-  gather-reduce passes) is the next row of SURVEY.md section 8f -- and it announces itself once.
+* GRAND-nl with scaled-dot attention and a softmax over the row (the default configuration): native VJP --
+  recompute q||k and the attention (native), then  A^T g  (aggregation on the transposed CSR), dw = SDDMM,
+  ds = gnpde_softmax_rows_bwd, dq / dk = gnpde_head_spmm over rows / columns, dx += [dq dk] [Wq; Wk] on
+  the MFMA projection kernel; the [A,N]x[N,d] weight-gradient GEMMs go to the vendor BLAS through torch.
+* every other attention variant (squareplus, attention_norm_idx = 1, cosine / pearson / exp_kernel, GAT): the
+  backward RECOMPUTES f from PyTorch device ops and differentiates that composite (index_select / index_add,
+  the reference's op sequence).  Interim; it announces itself once.
 """
 import logging
 import math
@@ -79,7 +82,77 @@ class _LaplacianRhs(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
-# attention functions: native forward, composite (PyTorch device ops) backward
+# GRAND-nl, scaled-dot attention, softmax over the row: native forward and backward
+# --------------------------------------------------------------------------------------------------
+def _native_transformer_vjp_ok(func):
+  lay, opt = func.multihead_att_layer, func.opt
+  a4 = lay.attention_dim // 4
+  return (opt['attention_type'] == 'scaled_dot' and not opt['square_plus'] and opt['attention_norm_idx'] == 0 and
+          not opt['mix_features'] and lay.d_k % 4 == 0 and lay.attention_dim % 4 == 0 and a4 <= 64 and (a4 & (a4 - 1)) == 0)
+
+
+class _TransformerRhs(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, wq, bq, wk, bk, alpha_train, beta_train, x0, func):
+    with torch.no_grad():
+      f = ops.rhs_eval(func._descriptor(x), x)
+    ctx.func = func
+    ctx.has_source = x0 is not None
+    ctx.save_for_backward(x, x0 if x0 is not None else x.new_zeros(0), alpha_train, beta_train)
+    return f
+
+  @staticmethod
+  def backward(ctx, g):
+    x, x0, alpha_train, beta_train = ctx.saved_tensors
+    func = ctx.func
+    lay = func.multihead_att_layer
+    sig = not func.opt['no_alpha_sigmoid']
+    A, h, dk = lay.attention_dim, lay.h, lay.d_k
+    g = _lib.f32c(g)
+    need = ctx.needs_input_grad
+    with torch.no_grad():
+      graph = func._graph(x)
+      wqk, bqk = lay.qk_weights()
+      qk = ops.linear(x, wqk, bqk)
+      st, keep = lay.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
+      w_csr, att_edge, _ = ops.edge_attention(graph, st, True, True, False, like=x)
+      # d/dx through the aggregation and the -x term: a (A^T g - g)
+      gt = graph.transposed()
+      w_edge = torch.empty(graph.e, dtype=torch.float32, device=g.device)
+      w_edge[graph.perm_long] = w_csr[:graph.e]
+      dx = ops.spmm_rhs(gt, ops.edge_to_csr_mean(gt, w_edge), g, alpha_train, None, None, sig)
+      # through the attention weights
+      dw = ops.sddmm(graph, g, x, scale=alpha_train, scale_sigmoid=sig)
+      ds = ops.softmax_rows_bwd(graph, att_edge, dw, edge_w_csr=lay._reweight_csr(graph))
+      inv = 1.0 / math.sqrt(dk)
+      dq = ops.head_spmm(graph, ds, qk[:, A:], h, dk, inv, by_column=False)
+      dkk = ops.head_spmm(graph, ds, qk[:, :A], h, dk, inv, by_column=True)
+      dqk = torch.cat([dq, dkk], dim=1)
+      dx = dx + ops.linear(dqk, wqk.t().contiguous())          # [N,2A] x [2A,d] on the MFMA kernel
+      dwq = dbq = dwk = dbk = dalpha = dbeta = None
+      if need[1]:
+        dwq = dq.t().mm(x)                                      # [A,N] x [N,d]: plain library GEMM
+      if need[2]:
+        dbq = dq.sum(dim=0)
+      if need[3]:
+        dwk = dkk.t().mm(x)
+      if need[4]:
+        dbk = dkk.sum(dim=0)
+      if need[5]:
+        ax = ops.spmm(graph, w_csr, x)
+        s = (g * (ax - x)).sum()
+        if sig:
+          sa = torch.sigmoid(alpha_train)
+          s = s * sa * (1 - sa)
+        dalpha = s.reshape(alpha_train.shape)
+      if need[6] and ctx.has_source:
+        dbeta = (g * x0).sum().reshape(beta_train.shape)
+    return (dx if need[0] else None), dwq, dbq, dwk, dbk, dalpha, dbeta, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# other attention variants: native forward, composite (PyTorch device ops) backward
 # --------------------------------------------------------------------------------------------------
 def _segment_softmax(src, index, n):
   mx = torch.full((n,) + tuple(src.shape[1:]), float('-inf'), dtype=src.dtype, device=src.device)
@@ -203,6 +276,10 @@ def rhs_with_grad(func, x):
   if kind == 'LaplacianODEFunc':
     return _LaplacianRhs.apply(x, func._edge_values(), func.alpha_train, func.beta_train, func._source(x), func)
   if kind == 'ODEFuncTransformerAtt':
+    if _native_transformer_vjp_ok(func) and not func.opt.get('gnpde_composite_backward', False):
+      lay = func.multihead_att_layer
+      return _TransformerRhs.apply(x, lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias, func.alpha_train,
+                                   func.beta_train, func._source(x), func)
     composite = composite_transformer
   elif kind == 'ODEFuncAtt':
     if func.opt['mix_features']:

@@ -132,6 +132,31 @@ class ODEblock(nn.Module):
   def set_time(self, time):
     self.t = torch.tensor([0, time]).to(self.device)
 
+  def _second_function(self, odefunc, opt, data, device):
+    """The reference's blocks build a SECOND function object and leave the first inside reg_odefunc
+    (state_dicts therefore hold both); same here."""
+    width = self.aug_dim * opt['hidden_dim']
+    self.odefunc = odefunc(width, width, opt, data, device)
+
+  def _share_graph(self, edge_index, edge_weight, device):
+    """Hand the block's normalised adjacency to both function objects."""
+    self.odefunc.edge_index = edge_index.to(device)
+    self.odefunc.edge_weight = edge_weight.to(device)
+    inner = self.reg_odefunc.odefunc
+    inner.edge_index, inner.edge_weight = self.odefunc.edge_index, self.odefunc.edge_weight
+
+  def _rw_graph(self, data, opt, device):
+    from .utils import get_rw_adj
+    ei, ew = get_rw_adj(data.edge_index, edge_weight=data.edge_attr, norm_dim=1, fill_value=opt['self_loop_weight'],
+                        num_nodes=data.num_nodes, dtype=data.x.dtype)
+    self._share_graph(ei, ew, device)
+    return self.odefunc.edge_index, self.odefunc.edge_weight
+
+  def _use_default_integrators(self, opt):
+    self.train_integrator = odeint_adjoint if opt['adjoint'] else odeint
+    self.test_integrator = odeint
+    self.set_tol()
+
   def _integrate(self, x, options):
     """Common tail of the block forwards (reference src/block_constant.py:35-70)."""
     t = self.t.type_as(x)

@@ -7,8 +7,6 @@ import torch
 
 from .base_classes import ODEblock
 from .function_transformer_attention import SpGraphTransAttentionLayer
-from .odeint import odeint, odeint_adjoint
-from .utils import get_rw_adj
 
 
 class HardAttODEblock(ODEblock):
@@ -16,18 +14,10 @@ class HardAttODEblock(ODEblock):
     super(HardAttODEblock, self).__init__(odefunc, regularization_fns, opt, data, device, t)
     assert opt['att_samp_pct'] > 0 and opt['att_samp_pct'] <= 1, "attention sampling threshold must be in (0,1]"
     self.opt = opt
-    self.odefunc = odefunc(self.aug_dim * opt['hidden_dim'], self.aug_dim * opt['hidden_dim'], opt, data, device)
+    self._second_function(odefunc, opt, data, device)
     self.num_nodes = data.num_nodes
-    edge_index, edge_weight = get_rw_adj(data.edge_index, edge_weight=data.edge_attr, norm_dim=1,
-                                         fill_value=opt['self_loop_weight'], num_nodes=data.num_nodes,
-                                         dtype=data.x.dtype)
-    self.data_edge_index = edge_index.to(device)
-    self.odefunc.edge_index = edge_index.to(device)  # replaced by the sampled edges while training
-    self.odefunc.edge_weight = edge_weight.to(device)
-    self.reg_odefunc.odefunc.edge_index, self.reg_odefunc.odefunc.edge_weight = self.odefunc.edge_index, self.odefunc.edge_weight
-    self.train_integrator = odeint_adjoint if opt['adjoint'] else odeint
-    self.test_integrator = odeint
-    self.set_tol()
+    self.data_edge_index, _ = self._rw_graph(data, opt, device)   # odefunc.edge_index is swapped while training
+    self._use_default_integrators(opt)
     if opt['function'] not in {'GAT', 'transformer'}:
       self.multihead_att_layer = SpGraphTransAttentionLayer(opt['hidden_dim'], opt['hidden_dim'], opt, device,
                                                             edge_weights=self.odefunc.edge_weight).to(device)

@@ -1,0 +1,119 @@
+// Backward (VJP) pieces of the GRAND-nl right-hand side for scaled-dot attention with a softmax over the
+// row -- what autograd needs to differentiate ODEFuncTransformerAtt.forward (reference
+// src/function_transformer_attention.py:38-53) without materialising [E,d_k,h] temporaries:
+//   w_e = (1/H) sum_h a_eh,  a_eh = softmax_row(s_eh),  s_eh = q_row,h . k_col,h / sqrt(d_k)
+//   given dL/dw_e (from gnpde_sddmm):
+//     ds_eh = (a_eh / H) (dw_e - sum_{e' in row} a_e'h dw_e')            gnpde_softmax_rows_bwd
+//     dq_i,h = (1/sqrt d_k) sum_{e in row i} ds_eh k_col(e),h            gnpde_head_spmm (rows)
+//     dk_j,h = (1/sqrt d_k) sum_{e in col j} ds_eh q_row(e),h            gnpde_head_spmm (columns, CSC view)
+// All reductions are segment-local (no atomics, deterministic).
+#include "common.h"
+
+namespace gnpde {
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// one wavefront per row; heads in an outer loop; att is in the CALLER's edge order (indexed through perm)
+__global__ __launch_bounds__(kBlock) void softmax_rows_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ perm,
+                                                                 const float* __restrict__ att_edge, const float* __restrict__ dw,
+                                                                 const float* __restrict__ edge_w, int n, int h,
+                                                                 float* __restrict__ ds) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+  if (row >= n) return;
+  const int b = rowptr[row], e = rowptr[row + 1];
+  const float inv_h = 1.0f / static_cast<float>(h);
+  for (int head = 0; head < h; ++head) {
+    float c = 0.f;
+    for (int p = b + lane; p < e; p += kWave) c = fmaf(att_edge[static_cast<size_t>(perm[p]) * h + head], dw[p], c);
+    c = wsum(c);
+    for (int p = b + lane; p < e; p += kWave) {
+      float v = att_edge[static_cast<size_t>(perm[p]) * h + head] * inv_h * (dw[p] - c);
+      if (edge_w != nullptr) v *= edge_w[p];
+      ds[static_cast<size_t>(p) * h + head] = v;
+    }
+  }
+}
+
+// out[seg, :] = scale * sum_{p in seg} ds[pos(p), head(col)] * feat[other(p), :]   (A = h * dk columns, dk % 4 == 0)
+// lane = (edge slot, float4 column); A4 = A / 4 lanes per edge, a power of two <= 64
+template <int A4>
+__global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict__ segptr, const int* __restrict__ segpos,
+                                                          const int* __restrict__ other_of_pos, const float* __restrict__ ds,
+                                                          int h, int dk, const float* __restrict__ feat, int ldf, float scale,
+                                                          int n, float* __restrict__ out, int ldo) {
+  constexpr int ES = kWave / A4;  // edges per iteration
+  const int lane = threadIdx.x & (kWave - 1);
+  const int seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+  if (seg >= n) return;
+  const int es = lane / A4, a4 = lane % A4;
+  const int head = (a4 * 4) / dk;
+  const int b = segptr[seg], e = segptr[seg + 1];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = b + es; t < e; t += ES) {
+    const int p = segpos != nullptr ? segpos[t] : t;
+    const int o = other_of_pos[p];
+    const float w = ds[static_cast<size_t>(p) * h + head];
+    const float4 f = *reinterpret_cast<const float4*>(feat + static_cast<size_t>(o) * ldf + a4 * 4);
+    acc[0] = fmaf(w, f.x, acc[0]); acc[1] = fmaf(w, f.y, acc[1]);
+    acc[2] = fmaf(w, f.z, acc[2]); acc[3] = fmaf(w, f.w, acc[3]);
+  }
+#pragma unroll
+  for (int off = A4; off < kWave; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+  if (es == 0)
+    *reinterpret_cast<float4*>(out + static_cast<size_t>(seg) * ldo + a4 * 4) =
+        make_float4(scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]);
+}
+
+}  // namespace
+}  // namespace gnpde
+
+extern "C" int gnpde_softmax_rows_bwd(const gnpde_graph_t* g, const float* att_edge, int32_t heads, const float* dw_csr,
+                                      const float* edge_w_csr, float* ds_csr, void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(g && g->perm && att_edge && dw_csr && ds_csr && heads >= 1, GNPDE_EINVAL, "softmax_rows_bwd: bad arguments");
+  if (g->n == 0 || g->e == 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), g->rowptr, g->perm, att_edge, dw_csr, edge_w_csr, g->n, heads, ds_csr);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const float* ds_csr, int32_t heads, int32_t dk,
+                               const float* feat, int32_t ldf, float scale, float* out, int32_t ldo, void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(g && ds_csr && feat && out && heads >= 1 && dk >= 4 && dk % 4 == 0, GNPDE_EINVAL, "head_spmm: bad arguments");
+  const int A = heads * dk, a4 = A / 4;
+  GNPDE_CHECK_ARG(a4 <= 64 && (a4 & (a4 - 1)) == 0, GNPDE_ESHAPE, "head_spmm: attention_dim/4 = %d must be a power of two <= 64", a4);
+  GNPDE_CHECK_ARG(ldf >= A && ldo >= A && ldf % 4 == 0 && ldo % 4 == 0 && reinterpret_cast<uintptr_t>(feat) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(out) % 16 == 0, GNPDE_EINVAL, "head_spmm: operands must be 16-byte aligned");
+  GNPDE_CHECK_ARG(!by_column || (g->cscptr && g->cscpos && g->rowidx), GNPDE_EINVAL, "head_spmm: column mode needs the CSC view");
+  if (g->n == 0) return 0;
+  const int* segptr = by_column ? g->cscptr : g->rowptr;
+  const int* segpos = by_column ? g->cscpos : nullptr;
+  const int* other = by_column ? g->rowidx : g->colidx;
+  const unsigned grid = static_cast<unsigned>((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define GNPDE_HS(N4) \
+  hipLaunchKernelGGL((head_spmm_kernel<N4>), dim3(grid), dim3(kBlock), 0, s, segptr, segpos, other, ds_csr, heads, dk, feat, ldf, \
+                     scale, g->n, out, ldo)
+  switch (a4) {
+    case 1: GNPDE_HS(1); break;
+    case 2: GNPDE_HS(2); break;
+    case 4: GNPDE_HS(4); break;
+    case 8: GNPDE_HS(8); break;
+    case 16: GNPDE_HS(16); break;
+    case 32: GNPDE_HS(32); break;
+    default: GNPDE_HS(64); break;
+  }
+#undef GNPDE_HS
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}

@@ -104,6 +104,28 @@ def sddmm(graph, a, b, scale=None, scale_sigmoid=False, out=None):
   return out
 
 
+def softmax_rows_bwd(graph, att_edge, dw_csr, edge_w_csr=None):
+  """ds [E,h] (CSR order) of the row softmax + head mean, see gnpde_softmax_rows_bwd."""
+  require_hip(att_edge, dw_csr)
+  att_edge = f32c(att_edge, 'attention')
+  h = att_edge.shape[1]
+  ds = torch.empty(max(graph.e, 1), h, dtype=torch.float32, device=att_edge.device)
+  check(_lib.lib().gnpde_softmax_rows_bwd(graph.ref(), ptr(att_edge), h, ptr(dw_csr), ptr(edge_w_csr), ptr(ds),
+                                          stream_of(att_edge)))
+  return ds
+
+
+def head_spmm(graph, ds_csr, feat, heads, dk, scale, by_column):
+  """Head-wise weighted segment sum (gnpde_head_spmm): [N, heads*dk]."""
+  require_hip(ds_csr, feat)
+  if feat.stride(1) != 1:
+    feat = feat.contiguous()
+  out = torch.empty(graph.n, heads * dk, dtype=torch.float32, device=feat.device)
+  check(_lib.lib().gnpde_head_spmm(graph.ref(), int(bool(by_column)), ptr(ds_csr), heads, dk, ptr(feat), feat.stride(0),
+                                   float(scale), ptr(out), out.stride(0), stream_of(feat)))
+  return out
+
+
 def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=None, ldqk=0, leaky_slope=0.2,
                      gat_a=None, output_var=None, lengthscale=None, edge_w_csr=None):
   a = _lib.AttentionStruct()

@@ -173,6 +173,19 @@ int gnpde_spmm(const gnpde_graph_t* g, const float* w_csr, const float* u, int32
 int gnpde_sddmm(const gnpde_graph_t* g, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t d,
                 const float* scale, int32_t scale_sigmoid, float* out_csr, void* stream);
 
+/* Backward of the row softmax + head mean of gnpde_edge_attention (scaled-dot, attention_norm_idx 0):
+ *   ds[p,h] = (a[p,h] / H) (dw[p] - sum_{p' in row} a[p',h] dw[p'])   [* edge_w[p] if given]
+ * att_edge is the [E,h] attention in the caller's edge order, dw_csr / ds_csr are in CSR order. */
+int gnpde_softmax_rows_bwd(const gnpde_graph_t* g, const float* att_edge, int32_t heads, const float* dw_csr,
+                           const float* edge_w_csr, float* ds_csr, void* stream);
+
+/* Head-wise weighted segment sum over the graph pattern (d q / d k of the attention scores):
+ *   out[i, c] = scale * sum_{p in row i} ds[p, head(c)] * feat[col_p, c]           (by_column = 0)
+ *   out[j, c] = scale * sum_{p in column j} ds[p, head(c)] * feat[row_p, c]        (by_column = 1, CSC view)
+ * c < heads*dk, head(c) = c / dk; dk % 4 == 0 and heads*dk/4 a power of two <= 64. */
+int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const float* ds_csr, int32_t heads, int32_t dk,
+                    const float* feat, int32_t ldf, float scale, float* out, int32_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense feature mixing on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
  *   out[n, m] = x[n, d] * W[m, d]^T + b[m]          (b may be NULL)

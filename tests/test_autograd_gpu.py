@@ -60,14 +60,15 @@ def test_laplacian_native_backward(dev, block_kind):
   assert_parity(func.beta_train.grad.reshape(-1), bc.grad.reshape(-1), tol=GTOL, what='dbeta')
 
 
-@pytest.mark.parametrize('function', ['transformer', 'GAT'])
-def test_training_step_through_the_solver(dev, function):
-  """loss.backward() through a 2-step rk4 solve of a block in training mode (what run_GNN.py's train() does)."""
+@pytest.mark.parametrize('function,composite', [('transformer', False), ('transformer', True), ('GAT', True)])
+def test_training_step_through_the_solver(dev, function, composite):
+  """loss.backward() through a 2-step rk4 solve of a block in training mode (what run_GNN.py's train() does);
+  GRAND-nl both through the native VJP and through the composite backward."""
   n, d = 400, 20
-  ei = random_graph(n, 5, seed=5)
+  ei = random_graph(n, 5, seed=5, hubs=1, hub_deg=150)
   g = torch.Generator().manual_seed(4)
   x = torch.randn(n, d, generator=g)
-  opt = dict(OPT, function=function)
+  opt = dict(OPT, function=function, gnpde_composite_backward=composite)
   fcls = G.ODEFuncTransformerAtt if function == 'transformer' else G.ODEFuncAtt
   block = G.ConstantODEblock(fcls, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, opt['time']])).to(dev)
   _rand_params(block, 6, dev)
@@ -142,3 +143,35 @@ def test_sddmm(dev):
   out = ops.sddmm(graph, a.to(dev), b.to(dev))
   ref = (a[ei[0]] * b[ei[1]]).sum(dim=1)
   assert_parity(out[:graph.e], ref[graph.perm_long.cpu()], what='sddmm')
+
+
+@pytest.mark.parametrize('heads,att_dim,reweight', [(4, 16, False), (8, 128, False), (1, 8, True), (2, 32, True)])
+def test_transformer_native_vjp_one_evaluation(dev, heads, att_dim, reweight):
+  """Native VJP of one GRAND-nl evaluation (hub rows, biases, optional reweighting) against CPU autograd
+  through the oracle."""
+  n, d = 900, 24
+  ei = random_graph(n, 6, seed=heads, hubs=1, hub_deg=700, dup=10)
+  g = torch.Generator().manual_seed(att_dim)
+  x, x0, go = (torch.randn(n, d, generator=g) for _ in range(3))
+  opt = dict(OPT, heads=heads, attention_dim=att_dim, hidden_dim=d, reweight_attention=reweight, self_loop_weight=0)
+  ew = torch.rand(ei.shape[1], generator=g) + 0.5
+  data = Data(x.to(dev), ei.to(dev), edge_attr=ew.to(dev) if reweight else None)
+  func = G.ODEFuncTransformerAtt(d, d, opt, data, dev).to(dev)
+  _rand_params(func, 3, dev)
+  func.x0 = x0.to(dev)
+  xd = x.to(dev).requires_grad_(True)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  lay = func.multihead_att_layer
+  ps = [_cpu(p) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+  ac, bc, xc = _cpu(func.alpha_train), _cpu(func.beta_train), _cpu(x)
+  fr = R.rhs_transformer(xc, ei, ps[0], ps[1], ps[2], ps[3], heads, ac, bc, x0, False, True,
+                         edge_weights=ew if reweight else None, reweight=reweight)
+  assert_parity(f, fr, what='value')
+  fr.backward(go)
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  scale = max(float(b.grad.abs().max()) for b in ps)
+  for a, b in zip((lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias), ps):
+    assert float((a.grad.cpu() - b.grad).abs().max()) <= GTOL * scale, 'dparam'
+  assert_parity(func.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
+  assert_parity(func.beta_train.grad.reshape(-1), bc.grad.reshape(-1), tol=GTOL, what='dbeta')
