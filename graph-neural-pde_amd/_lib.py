@@ -17,6 +17,7 @@ LONG_ROW = 512
 
 STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 STAGE_RK1C, STAGE_RK2C, STAGE_RK3C, STAGE_RK4C = range(6, 10)
+STAGE_LINCOMB = 10
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4 = range(2)
@@ -40,7 +41,8 @@ class GraphStruct(ctypes.Structure):
 class EpilogueStruct(ctypes.Structure):
   _fields_ = [('alpha', c_vp), ('beta', c_vp), ('x0', c_vp),
               ('alpha_sigmoid', ctypes.c_int32), ('stage', ctypes.c_int32), ('dt', ctypes.c_float),
-              ('y', c_vp), ('k1', c_vp), ('k2', c_vp), ('k3', c_vp), ('out_k', c_vp), ('out_y', c_vp)]
+              ('y', c_vp), ('k1', c_vp), ('k2', c_vp), ('k3', c_vp), ('out_k', c_vp), ('out_y', c_vp),
+              ('n_prev', ctypes.c_int32), ('pad_', ctypes.c_int32), ('prev', c_vp * 7), ('coef', ctypes.c_float * 8)]
 
 
 class AttentionStruct(ctypes.Structure):
@@ -94,6 +96,9 @@ PROTOTYPES = {
                                          c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
   'gnpde_solver_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_rhs_eval': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_rhs_stage': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, ctypes.POINTER(EpilogueStruct), c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_rk_error_ratio': (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_int32, ctypes.c_float,
+                                          ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp]),
   'gnpde_rhs_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct)]),
   'gnpde_solver_num_rhs_evals': (ctypes.c_int, [c_vp]),
   'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),

@@ -151,6 +151,23 @@ __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha
       for (int v = 0; v < VEC; ++v) o[v] = (((6.0f * a[v] + 3.0f * ui[v]) - y[v]) + dt * k[v]) * 0.125f;
       st(ep.out_y + off, o);
       break;
+    case GNPDE_STAGE_LINCOMB: {
+      if (ep.out_k != nullptr) st(ep.out_k + off, k);
+      if (ep.out_y != nullptr) {
+        ld(ep.y + off, y);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = 0.0f;
+        for (int j = 0; j < ep.n_prev; ++j) {
+          ld(ep.prev[j] + off, a);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) o[v] = fmaf(a[v], ep.coef[j], o[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = y[v] + fmaf(k[v], ep.coef[ep.n_prev], o[v]);
+        st(ep.out_y + off, o);
+      }
+      break;
+    }
     default:
       break;
   }

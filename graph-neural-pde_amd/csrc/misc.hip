@@ -18,8 +18,79 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
   for (int c = lane; c < d; c += kWave) o[c] = s[c];
 }
 
+struct ErrArgs {
+  const float* y0;
+  const float* y1;
+  const float* k[GNPDE_MAX_PREV];
+  float coef[GNPDE_MAX_PREV];
+  int n_k;
+  float atol, rtol;
+  long long n;
+  int d, ld;
+};
+
+// block partial sums of (err / tol)^2 in a fixed order -> ws[blockIdx]
+__global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(const ErrArgs a, float* __restrict__ ws) {
+  __shared__ float red[kWavesPerBlock];
+  const long long total = a.n * a.d;
+  float acc = 0.f;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long r = i / a.d;
+    const size_t off = static_cast<size_t>(r) * a.ld + static_cast<size_t>(i - r * a.d);
+    float err = 0.f;
+    for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j], err);
+    const float tol = a.atol + a.rtol * fmaxf(fabsf(a.y0[off]), fabsf(a.y1[off]));
+    const float q = err / tol;
+    acc = fmaf(q, q, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void rk_error_final_kernel(const float* __restrict__ ws, int nblocks, double count,
+                                                               float* __restrict__ ratio) {
+  __shared__ double red[kBlock];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += static_cast<double>(ws[i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ratio = static_cast<float>(sqrt(red[0] / count));
+}
+
 }  // namespace
 }  // namespace gnpde
+
+extern "C" int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k,
+                                    float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
+                                    void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(y0 && y1 && k && coef && ratio && workspace && n_k >= 1 && n_k <= GNPDE_MAX_PREV && n >= 1 && d >= 1 && ld >= d,
+                  GNPDE_EINVAL, "rk_error_ratio: bad arguments");
+  ErrArgs a{};
+  a.y0 = y0; a.y1 = y1; a.n_k = n_k; a.atol = atol; a.rtol = rtol; a.n = n; a.d = d; a.ld = ld;
+  for (int j = 0; j < n_k; ++j) {
+    GNPDE_CHECK_ARG(k[j] != nullptr, GNPDE_EINVAL, "rk_error_ratio: k[%d] is null", j);
+    a.k[j] = k[j];
+    a.coef[j] = coef[j];
+  }
+  long long blocks = (n * d + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rk_error_partial_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
+  GNPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rk_error_final_kernel, dim3(1), dim3(kBlock), 0, s, workspace, static_cast<int>(blocks),
+                     static_cast<double>(n) * d, ratio);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int32_t count, int32_t d,
                                  float* dst, int32_t ld_dst, void* stream) {

@@ -249,6 +249,22 @@ extern "C" int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out
   return enqueue_rhs(*rhs, u, e, static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int gnpde_rhs_stage(const gnpde_rhs_t* rhs, const float* u, const gnpde_epilogue_t* epi, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  int rc = check_rhs(rhs);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(u && epi, GNPDE_EINVAL, "rhs_stage: null argument");
+  const RhsLayout L = rhs_layout(*rhs);
+  GNPDE_CHECK_ARG(L.total == 0 || (workspace && workspace_bytes >= L.total), GNPDE_EWS, "rhs_stage: workspace %zu < %zu bytes",
+                  workspace_bytes, L.total);
+  gnpde_epilogue_t e = *epi;
+  e.alpha = rhs->alpha;
+  e.beta = rhs->beta;
+  e.x0 = rhs->x0;
+  e.alpha_sigmoid = rhs->alpha_sigmoid;
+  return enqueue_rhs(*rhs, u, e, static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t gnpde_solver_workspace_bytes(const gnpde_rhs_t* rhs, int32_t method) {
   if (check_rhs(rhs)) return 0;
   if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4) return 0;

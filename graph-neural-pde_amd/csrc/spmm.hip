@@ -353,14 +353,24 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     const gnpde_epilogue_t& e = a.ep;
     GNPDE_CHECK_ARG(e.alpha != nullptr, GNPDE_EINVAL, "spmm: alpha pointer is null");
     GNPDE_CHECK_ARG(e.x0 == nullptr || e.beta != nullptr, GNPDE_EINVAL, "spmm: x0 given without beta");
-    GNPDE_CHECK_ARG(e.stage >= GNPDE_STAGE_RHS && e.stage <= GNPDE_STAGE_RK4C, GNPDE_EINVAL, "spmm: bad stage %d", e.stage);
+    GNPDE_CHECK_ARG(e.stage >= GNPDE_STAGE_RHS && e.stage <= GNPDE_STAGE_LINCOMB, GNPDE_EINVAL, "spmm: bad stage %d", e.stage);
     const int st = e.stage;
+    if (st == GNPDE_STAGE_LINCOMB) {
+      GNPDE_CHECK_ARG(e.n_prev >= 0 && e.n_prev <= GNPDE_MAX_PREV, GNPDE_EINVAL, "spmm: bad n_prev %d", e.n_prev);
+      GNPDE_CHECK_ARG(e.out_k != nullptr || e.out_y != nullptr, GNPDE_EINVAL, "spmm: LINCOMB without output");
+      GNPDE_CHECK_ARG(e.out_y == nullptr || e.y != nullptr, GNPDE_EINVAL, "spmm: LINCOMB needs y");
+      for (int j = 0; j < e.n_prev; ++j) {
+        GNPDE_CHECK_ARG(e.prev[j] != nullptr, GNPDE_EINVAL, "spmm: LINCOMB prev[%d] is null", j);
+        a16 = a16 && aligned(e.prev[j], 16);
+        a8 = a8 && aligned(e.prev[j], 8);
+      }
+    }
     const bool needs_k = st == GNPDE_STAGE_RHS || (st >= GNPDE_STAGE_RK1 && st <= GNPDE_STAGE_RK3);
     const bool needs_y = st == GNPDE_STAGE_EULER || (st >= GNPDE_STAGE_RK1 && st <= GNPDE_STAGE_RK4) ||
                          st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C;
     const bool needs_k1 = (st >= GNPDE_STAGE_RK2 && st <= GNPDE_STAGE_RK4) || st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C;
     GNPDE_CHECK_ARG(!needs_k || e.out_k != nullptr, GNPDE_EINVAL, "spmm: out_k is null");
-    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RHS || e.out_y != nullptr, GNPDE_EINVAL, "spmm: out_y is null");
+    GNPDE_CHECK_ARG(st == GNPDE_STAGE_RHS || st == GNPDE_STAGE_LINCOMB || e.out_y != nullptr, GNPDE_EINVAL, "spmm: out_y is null");
     GNPDE_CHECK_ARG(!needs_y || e.y != nullptr, GNPDE_EINVAL, "spmm: y is null");
     GNPDE_CHECK_ARG(!needs_k1 || e.k1 != nullptr, GNPDE_EINVAL, "spmm: k1 is null");
     GNPDE_CHECK_ARG(!(st == GNPDE_STAGE_RK3 || st == GNPDE_STAGE_RK4) || e.k2 != nullptr, GNPDE_EINVAL, "spmm: k2 is null");

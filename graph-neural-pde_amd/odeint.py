@@ -205,6 +205,89 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
   return out
 
 
+def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2):
+  """dopri5 with torchdiffeq 0.2.1's controller on the host (one scalar read per trial step) and everything
+  state-sized on the device: each stage is ONE right-hand-side launch whose epilogue also forms the next stage
+  input  y + sum_j (beta_ij dt) k_j  (GNPDE_STAGE_LINCOMB), the error ratio is a device reduction.  Same
+  accept / reject rule, step-size update (float64), FSAL and quartic end-point interpolation as the host loop
+  `_solve_dopri5` (which stays the path for foreign callables)."""
+  import numpy as np
+  from . import ops
+  dev = y0.device
+  f32 = np.float32
+  T0, T1 = float(t[0]), float(t[-1])
+  y = y0.detach().clone().contiguous()
+  y1 = torch.empty_like(y)
+  u = [torch.empty_like(y) for _ in range(2)]
+  K = [torch.empty_like(y) for _ in range(7)]
+  ratio_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+  err_ws = torch.empty(4096, dtype=torch.float32, device=dev)
+  desc = func._descriptor(y)
+  L = _lib.lib()
+  ws = desc.graph.workspace('rhs%d_%d' % (desc.struct.kind, desc.struct.d), L.gnpde_rhs_workspace_bytes(desc.ref()))
+
+  def feval(src, out_k=None, out_y=None, ybase=None, prev=(), coef=()):
+    func._check_nfe()
+    ops.rhs_stage(desc, src, _lib.STAGE_LINCOMB, ws=ws, y=ybase, out_k=out_k, out_y=out_y, prev=prev, coef=coef)
+
+  rtol64, atol64 = float(rtol), float(atol)
+  feval(y, out_k=K[0])
+  # initial step (order 4 estimate), a handful of reductions once per solve
+  scale = atol64 + torch.abs(y) * rtol64
+  d0, d1 = float(_rms(y / scale)), float(_rms(K[0] / scale))
+  h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else float(f32(0.01) * f32(d0) / f32(d1))
+  torch.add(y, K[0], alpha=h0, out=u[0])
+  feval(u[0], out_k=K[1])
+  d2 = float(_rms((K[1] - K[0]) / scale)) / h0
+  h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else float(f32(f32(0.01) / f32(max(d1, d2))) ** f32(1.0 / 5.0))
+  dt = float(min(100 * h0, h1))
+  t_cur = T0
+  out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
+  out[0].copy_(y0)
+  n_steps = 0
+  while T1 > t_cur:
+    assert t_cur + dt > t_cur, 'underflow in dt {}'.format(dt)
+    dty = f32(dt)
+    w = [[f32(b) * dty for b in row] for row in _DP_B]
+    torch.add(y, K[0], alpha=float(w[0][0]), out=u[0])              # first stage input (k0 is FSAL)
+    for i in range(1, 6):                                            # k_i = f(u_i);  u_{i+1} in the same launch
+      dst = y1 if i == 5 else u[i % 2]
+      feval(u[(i - 1) % 2], out_k=K[i], out_y=dst, ybase=y, prev=K[:i], coef=w[i])
+    feval(y1, out_k=K[6])                                            # f(y1): next step's k0 if accepted
+    ops.rk_error_ratio(y, y1, K, [f32(e) * dty for e in _DP_E], atol64, rtol64, ratio_dev, err_ws)
+    ratio = float(ratio_dev.item())                                  # the one host sync of the step
+    if ratio <= 1:
+      t_next = t_cur + dt
+      if t_next >= T1:   # end point inside this step: quartic interpolation (torchdiffeq _interp_fit / _interp_evaluate)
+        y_mid = y.clone()
+        for kj, c in zip(K, _DP_MID):
+          if c != 0.0:
+            y_mid.add_(kj, alpha=float(f32(c) * dty))
+        h = float(dty)
+        fa, fb = K[0], K[6]
+        ca = 2 * h * (fb - fa) - 8 * (y1 + y) + 16 * y_mid
+        cb = h * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * y_mid
+        cc = h * (fb - 4 * fa) - 11 * y - 5 * y1 + 16 * y_mid
+        cd = h * fa
+        xf = float(f32((T1 - t_cur) / (t_next - t_cur)))
+        total = y + xf * cd
+        xp = xf
+        for coefv in (cc, cb, ca):
+          xp = xp * xf
+          total = total + xp * coefv
+        out[1].copy_(total)
+      y, y1 = y1, y
+      K[0], K[6] = K[6], K[0]
+      t_cur = t_next
+    if ratio == 0:
+      dt = dt * ifactor
+    else:
+      lo = 1.0 if ratio < 1 else dfactor
+      dt = dt * min(ifactor, max(safety / ratio ** (1.0 / 5.0), lo))
+    n_steps += 1
+  return out
+
+
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_graph=True, **adjoint_kwargs):
   """Drop-in for torchdiffeq.odeint on this path.  Unknown options (e.g. `max_iters`, which the
   reference passes and torchdiffeq ignores with a warning) are ignored."""
@@ -218,6 +301,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
       return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
     return _solve_fixed_host(func, y0, t, method, step_size)
   if method == 'dopri5':
+    if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
+      return _solve_dopri5_native(func, y0, t, rtol, atol)
     return _solve_dopri5(func, y0, t, rtol, atol)
   raise ValueError('unsupported method %r (euler, rk4, dopri5)' % (method,))
 

@@ -45,8 +45,13 @@ def edge_to_csr_mean(graph, src_edge, out=None):
 
 
 def make_epilogue(alpha, beta, x0, alpha_sigmoid, stage=_lib.STAGE_RHS, dt=0.0, y=None, k1=None, k2=None, k3=None,
-                  out_k=None, out_y=None):
+                  out_k=None, out_y=None, prev=(), coef=()):
   e = _lib.EpilogueStruct()
+  e.n_prev = len(prev)
+  for j, t in enumerate(prev):
+    e.prev[j] = t.data_ptr()
+  for j, c in enumerate(coef):
+    e.coef[j] = float(c)
   e.alpha, e.beta = alpha.data_ptr(), (beta.data_ptr() if beta is not None else None)
   e.x0 = x0.data_ptr() if x0 is not None else None
   e.alpha_sigmoid, e.stage, e.dt = int(alpha_sigmoid), int(stage), float(dt)
@@ -215,6 +220,37 @@ def rhs_eval(desc, u, out=None):
   L = _lib.lib()
   ws = desc.graph.workspace('rhs%d_%d' % (desc.struct.kind, desc.struct.d), L.gnpde_rhs_workspace_bytes(desc.ref()))
   check(L.gnpde_rhs_eval(desc.ref(), ptr(u), ptr(out), ptr(ws), ws.numel(), stream_of(u)))
+  return out
+
+
+def rhs_stage(desc, u, stage, ws=None, **kw):
+  """f(u) of a descriptor with an explicit stage epilogue (gnpde_rhs_stage); alpha / beta / x0 come from
+  the descriptor."""
+  e = _lib.EpilogueStruct()
+  e.stage = int(stage)
+  e.dt = float(kw.get('dt', 0.0))
+  for name in ('y', 'k1', 'k2', 'k3', 'out_k', 'out_y'):
+    t = kw.get(name)
+    setattr(e, name, t.data_ptr() if t is not None else None)
+  prev, coef = kw.get('prev', ()), kw.get('coef', ())
+  e.n_prev = len(prev)
+  for j, t in enumerate(prev):
+    e.prev[j] = t.data_ptr()
+  for j, c in enumerate(coef):
+    e.coef[j] = float(c)
+  L = _lib.lib()
+  if ws is None:
+    ws = desc.graph.workspace('rhs%d_%d' % (desc.struct.kind, desc.struct.d), L.gnpde_rhs_workspace_bytes(desc.ref()))
+  check(L.gnpde_rhs_stage(desc.ref(), ptr(u), ctypes.byref(e), ptr(ws), ws.numel(), stream_of(u)))
+
+
+def rk_error_ratio(y0, y1, ks, coefs, atol, rtol, out, ws):
+  """Device-side error ratio of an embedded RK step (gnpde_rk_error_ratio); `out` is a 1-element tensor."""
+  n, d = y0.shape
+  karr = (ctypes.c_void_p * len(ks))(*[k.data_ptr() for k in ks])
+  carr = (ctypes.c_float * len(ks))(*[float(c) for c in coefs])
+  check(_lib.lib().gnpde_rk_error_ratio(ptr(y0), ptr(y1), karr, carr, len(ks), float(atol), float(rtol), n, d,
+                                        y0.stride(0), ptr(out), ptr(ws), stream_of(y0)))
   return out
 
 

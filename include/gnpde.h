@@ -128,13 +128,20 @@ typedef struct gnpde_graph {
  *   GNPDE_STAGE_RK2C   out_y = (2*y - u) + dt*k2                        (u == u2;  == y + dt*(k2 - k1/3))
  *   GNPDE_STAGE_RK3C   out_y = (2*a - u) + dt*k3      a = u2  (field k1)  (u == u3;  == y + dt*(k1 - k2 + k3))
  *   GNPDE_STAGE_RK4C   out_y = ((6*a + 3*u - y) + dt*k4)*0.125   a = u3  (u == u4; in place on y)
+ *   General explicit Runge-Kutta stage (adaptive solvers: dopri5 of torchdiffeq, reference default method):
+ *   GNPDE_STAGE_LINCOMB  out_k = k (if non-NULL) ;
+ *                        out_y = y + sum_{j < n_prev} coef[j] * prev[j] + coef[n_prev] * k   (if non-NULL)
+ *                        with coef[j] = fl32(beta_j) * fl32(dt) prepared by the caller (torchdiffeq's
+ *                        k.matmul(beta * dt) rounding).
  * `u` is the stage input the operator is applied to, `y` the state at the start of the step.
  * ---------------------------------------------------------------------------------------------- */
 enum {
   GNPDE_STAGE_RHS = 0, GNPDE_STAGE_EULER = 1,
   GNPDE_STAGE_RK1 = 2, GNPDE_STAGE_RK2 = 3, GNPDE_STAGE_RK3 = 4, GNPDE_STAGE_RK4 = 5,
-  GNPDE_STAGE_RK1C = 6, GNPDE_STAGE_RK2C = 7, GNPDE_STAGE_RK3C = 8, GNPDE_STAGE_RK4C = 9
+  GNPDE_STAGE_RK1C = 6, GNPDE_STAGE_RK2C = 7, GNPDE_STAGE_RK3C = 8, GNPDE_STAGE_RK4C = 9,
+  GNPDE_STAGE_LINCOMB = 10
 };
+#define GNPDE_MAX_PREV 7
 
 typedef struct gnpde_epilogue {
   const float* alpha;      /* device scalar (alpha_train)                                   */
@@ -149,6 +156,10 @@ typedef struct gnpde_epilogue {
   const float* k3;         /* [n, ld] (RK4)                                                 */
   float* out_k;            /* [n, ld] (RHS, RK1..RK3)                                       */
   float* out_y;            /* [n, ld] (all but RHS)                                         */
+  int32_t n_prev;          /* LINCOMB: number of earlier stage derivatives                  */
+  int32_t pad_;
+  const float* prev[GNPDE_MAX_PREV];   /* LINCOMB: [n, ld] each                             */
+  float coef[GNPDE_MAX_PREV + 1];      /* LINCOMB: weights of prev[0..n_prev-1], then of k  */
 } gnpde_epilogue_t;
 
 /* Bytes of scratch gnpde_spmm_rhs needs for the long-row partial sums (0 if no long rows). */
@@ -301,6 +312,18 @@ int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* strea
 int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);
 size_t gnpde_rhs_workspace_bytes(const gnpde_rhs_t* rhs);
+
+/* f(u) of a descriptor with an arbitrary epilogue / stage (building block of host-controlled adaptive
+ * solvers); the epilogue's alpha / beta / x0 / alpha_sigmoid fields are taken from the descriptor. */
+int gnpde_rhs_stage(const gnpde_rhs_t* rhs, const float* u, const gnpde_epilogue_t* epi, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Error ratio of an embedded Runge-Kutta step, on device (torchdiffeq _compute_error_ratio with the rms norm):
+ *   err = sum_j coef[j] * k[j],  tol = atol + rtol * max(|y0|, |y1|),  *ratio = sqrt(mean((err / tol)^2)).
+ * Deterministic two-level reduction; workspace: 4096 floats. */
+int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k,
+                         float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
+                         void* stream);
 
 int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s);
 int gnpde_solver_destroy(gnpde_solver_t* s);

@@ -247,3 +247,26 @@ def test_long_horizon_rk4_compact_and_classic(dev):
   assert_parity(z_classic, ref, what='classic stages, T=60')
   assert_parity(z_compact, ref, what='compact stages, T=60')
   assert_parity(z_compact, z_classic, what='compact vs classic')
+
+
+@pytest.mark.parametrize('function', ['transformer', 'laplacian'])
+def test_native_dopri5_matches_host_controller(dev, function):
+  """dopri5 with every stage as one launch (GNPDE_STAGE_LINCOMB epilogues, device error ratio) takes the same
+  accepted / rejected steps as the host loop that mirrors torchdiffeq, and lands on the same state."""
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.05)
+  x = torch.randn(n, 64, generator=torch.Generator().manual_seed(21))
+  opt = dict(BASE, function=function, hidden_dim=64, method='dopri5', time=6.0, tol_scale=50.0)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  f = block.odefunc
+  f.x0 = x.to(dev)
+  t = torch.tensor([0.0, 6.0], device=dev)
+  kw = dict(method='dopri5', atol=50.0 * 1e-7, rtol=50.0 * 1e-9)
+  with torch.no_grad():
+    f.nfe = 0
+    z_native = G.odeint(f, x.to(dev), t, options={}, **kw)[1]
+    nfe_native = f.nfe
+    f.nfe = 0
+    z_host = G.odeint(f, x.to(dev), t, options={'host_controller': True}, **kw)[1]
+    nfe_host = f.nfe
+  assert nfe_native == nfe_host and nfe_native >= 14
+  assert_parity(z_native, z_host, tol=2e-5, what='native vs host-controlled dopri5')
