@@ -54,7 +54,7 @@ class AttentionStruct(ctypes.Structure):
 
 class RhsStruct(ctypes.Structure):
   _fields_ = [('kind', ctypes.c_int32), ('graph', ctypes.POINTER(GraphStruct)),
-              ('d', ctypes.c_int32), ('ld', ctypes.c_int32),
+              ('d', ctypes.c_int32), ('ld', ctypes.c_int32), ('n_state_rows', ctypes.c_int32), ('pad_', ctypes.c_int32),
               ('alpha', c_vp), ('beta', c_vp), ('x0', c_vp), ('alpha_sigmoid', ctypes.c_int32),
               ('w_csr', c_vp),
               ('proj_w', c_vp), ('proj_b', c_vp), ('proj_m', ctypes.c_int32),

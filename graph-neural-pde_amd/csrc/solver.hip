@@ -38,7 +38,8 @@ RhsLayout rhs_layout(const gnpde_rhs_t& r) {
   L.spmm_bytes = gnpde_spmm_workspace_bytes(&g, r.d);
   off += align_up(L.spmm_bytes, 256);
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
-    L.proj = off;  off += align_up(static_cast<size_t>(g.n) * r.proj_m * 4, 256);
+    const size_t prow = r.n_state_rows > g.n ? r.n_state_rows : g.n;
+    L.proj = off;  off += align_up(prow * r.proj_m * 4, 256);
     L.wmean = off; off += align_up(static_cast<size_t>(g.e) * 4, 256);
     L.att = off;
     L.att_bytes = attention_workspace_bytes(&g, r.att.heads, r.kind == GNPDE_RHS_GAT);
@@ -82,7 +83,8 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
     float* proj = reinterpret_cast<float*>(ws + L.proj);
     float* wmean = reinterpret_cast<float*>(ws + L.wmean);
-    int rc = launch_linear_any(u, g->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.proj_b, proj, r.proj_m, s);
+    const int prow = r.n_state_rows > g->n ? r.n_state_rows : g->n;   // keys of halo rows are recomputed locally
+    int rc = launch_linear_any(u, prow, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.proj_b, proj, r.proj_m, s);
     if (rc) return rc;
     gnpde_attention_t at = r.att;
     at.ldqk = r.proj_m;

@@ -109,16 +109,37 @@ class NativeBackend(object):
     self.beta = beta.detach().to(self.dev, torch.float32).reshape(-1)
     self.alpha_sigmoid = alpha_sigmoid
     self.send_idx = shard.send_idx.to(torch.int32).to(self.dev)
+    self.x0 = torch.zeros(shard.n_own, d, dtype=torch.float32, device=self.dev)   # persistent source term
+    self.has_source = False
     if kind == 'laplacian':
       self.w_csr = ops.edge_to_csr_mean(self.graph, params['edge_weight'].to(self.dev, torch.float32))
+      self._kw = dict(kind=_lib.RHS_LAPLACIAN, w_csr=self.w_csr)
     elif kind == 'transformer':
       self.wqk = torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32).contiguous()
       self.bqk = torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32).contiguous()
       self.heads = int(params['heads'])
       self.A = self.wqk.shape[0] // 2
-      self.qk = torch.empty(shard.n_local, 2 * self.A, dtype=torch.float32, device=self.dev)
+      att = ops.attention_struct(_lib.ATT_SCALED_DOT, self.heads, self.A, 0, False)
+      self._kw = dict(kind=_lib.RHS_TRANSFORMER, proj_w=self.wqk, proj_b=self.bqk, att=att)
     else:
       raise ValueError(kind)
+    self._desc = {}
+    self._ws = None
+    self._src_ptr = None
+
+  def _descriptor(self, with_source):
+    """gnpde_rhs_t over the local shard: aggregation on the n_own rows, projection over all n_local rows."""
+    d = self._desc.get(with_source)
+    if d is None:
+      kw = dict(self._kw)
+      kind = kw.pop('kind')
+      d = self.ops.RhsDescriptor(kind, self.graph, self.d, self.d, self.alpha, self.beta if with_source else None,
+                                 self.x0 if with_source else None, self.alpha_sigmoid, n_state_rows=self.shard.n_local, **kw)
+      self._desc[with_source] = d
+      need = _lib.lib().gnpde_rhs_workspace_bytes(d.ref())
+      if self._ws is None or self._ws.numel() < need:
+        self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.dev)
+    return d
 
   def empty(self, rows):
     return torch.empty(rows, self.d, dtype=torch.float32, device=self.dev)
@@ -131,16 +152,14 @@ class NativeBackend(object):
                                             _lib.ptr(out), out.stride(0), _lib.stream_of(u)))
     return out
 
-  def rhs_stage(self, u, x0, **stage_kw):
-    ops = self.ops
-    if self.kind == 'transformer':
-      ops.linear(u, self.wqk, self.bqk, out=self.qk)
-      st = ops.attention_struct(_lib.ATT_SCALED_DOT, self.heads, self.A, 0, False, q=self.qk, k=self.qk[:, self.A:],
-                                ldqk=2 * self.A)
-      w, _, _ = ops.edge_attention(self.graph, st, True, False, False, like=u)
-    else:
-      w = self.w_csr
-    return ops.spmm_rhs(self.graph, w, u, self.alpha, self.beta, x0, self.alpha_sigmoid, **stage_kw)
+  def rhs_stage(self, u, x0, stage, **stage_kw):
+    """One evaluation with a fused solver stage: ONE call into the library (projection over own + halo rows,
+    attention and aggregation over the own rows), so the host side stays cheap next to the per-GPU work."""
+    if x0 is not None and x0.data_ptr() != self._src_ptr:   # new source tensor: refresh the persistent copy once
+      self.x0.copy_(x0)
+      self._src_ptr = x0.data_ptr()
+    desc = self._descriptor(x0 is not None)
+    self.ops.rhs_stage(desc, u, stage, ws=self._ws, **stage_kw)
 
   def sync(self):
     torch.cuda.synchronize(self.dev)

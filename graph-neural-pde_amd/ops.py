@@ -188,13 +188,14 @@ class RhsDescriptor(object):
   """Python owner of a gnpde_rhs_t: keeps every tensor the descriptor points to alive."""
 
   def __init__(self, kind, graph, d, ld, alpha, beta, x0, alpha_sigmoid, w_csr=None, proj_w=None, proj_b=None,
-               att=None):
+               att=None, n_state_rows=0):
     self.graph = graph
     self.keep = [alpha, beta, x0, w_csr, proj_w, proj_b]
     r = _lib.RhsStruct()
     r.kind = int(kind)
     r.graph = ctypes.pointer(graph.struct)
     r.d, r.ld = int(d), int(ld)
+    r.n_state_rows = int(n_state_rows)
     r.alpha = alpha.data_ptr()
     r.beta = beta.data_ptr() if beta is not None else None
     r.x0 = x0.data_ptr() if x0 is not None else None

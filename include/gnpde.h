@@ -283,6 +283,9 @@ typedef struct gnpde_rhs {
   int32_t kind;               /* GNPDE_RHS_*                                                   */
   const gnpde_graph_t* graph;
   int32_t d, ld;              /* state width and leading dimension                             */
+  int32_t n_state_rows;       /* rows of the state incl. halo rows of a row-partitioned graph (0: graph->n);
+                                 the projection covers all of them, the aggregation only graph->n rows */
+  int32_t pad_;
   /* epilogue scalars */
   const float* alpha; const float* beta; const float* x0; int32_t alpha_sigmoid;
   /* LAPLACIAN: fixed weights, CSR order */

@@ -270,3 +270,43 @@ def test_native_dopri5_matches_host_controller(dev, function):
     nfe_host = f.nfe
   assert nfe_native == nfe_host and nfe_native >= 14
   assert_parity(z_native, z_host, tol=2e-5, what='native vs host-controlled dopri5')
+
+
+def test_blend_arxiv_config_c4(dev):
+  """BASELINE configs[3] shape: ogbn-arxiv best_params -- hard_attention block (eval mode: all edges, head-mean
+  attention computed once), Laplacian function, dopri5 with tol_scale 11353, T = 3.676, d = 162 = 64 + 98
+  (features + positional encoding), attention_dim 32 / 2 heads -- at 1/10 of the node count, against the
+  host dopri5 loop driven by the CPU oracle."""
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.1)
+  d = 162
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(31)) * 0.5
+  opt = dict(BASE, function='laplacian', block='hard_attention', hidden_dim=d, heads=2, attention_dim=32, method='dopri5',
+             time=3.6760155951687636, tol_scale=11353.558848254957, add_source=False, att_samp_pct=0.81, use_flux=False)
+  block = G.HardAttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev,
+                            t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(3)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if p.dim() >= 2 and 'multihead_att_layer' in name:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+    block.odefunc.alpha_train.fill_(0.4)
+  block.eval()
+  block.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = block(x.to(dev))
+  nfe = block.odefunc.nfe
+  cpu = lambda t: t.detach().cpu()
+  lay, f = block.multihead_att_layer, block.odefunc
+  e_n, w_n = R.get_rw_adj(ei, None, 1, 1, n)
+  att, _ = R.transformer_attention(x, e_n, cpu(lay.Q.weight), cpu(lay.Q.bias), cpu(lay.K.weight), cpu(lay.K.bias), 2,
+                                   edge_weights=w_n, reweight=False)
+  calls = [0]
+
+  def rhs(t, y):
+    calls[0] += 1
+    return R.rhs_laplacian(y, e_n, att.mean(dim=1), cpu(f.alpha_train), cpu(f.beta_train), None, False, False)
+
+  ref = G.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
+                 atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
+  assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
+  assert_parity(z, ref, tol=1e-4, what='C4 (solver tolerance 1.1e-3)')
