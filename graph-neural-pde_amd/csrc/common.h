@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
 }
 
 // kernel-variant knobs for A/B measurements (gnpde_tune); 0 = the default variant
-enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_FUSED_BLOCKS_PER_CU = 1, GNPDE_TUNE_ONE_PASS = 2, GNPDE_TUNE_FORK = 3, GNPDE_TUNE_ATT_GENERIC_ROWS = 4, GNPDE_TUNE_RK4_CLASSIC = 5, GNPDE_TUNE_SPMM_INKERNEL_REDUCE = 6, GNPDE_TUNE_ONE_PASS_VARIANT = 7, GNPDE_TUNE_COUNT = 8 };
+enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_FUSED_BLOCKS_PER_CU = 1, GNPDE_TUNE_ONE_PASS = 2, GNPDE_TUNE_FORK = 3, GNPDE_TUNE_ATT_GENERIC_ROWS = 4, GNPDE_TUNE_RK4_CLASSIC = 5, GNPDE_TUNE_SPMM_INKERNEL_REDUCE = 6, GNPDE_TUNE_ONE_PASS_VARIANT = 7, GNPDE_TUNE_LINEAR_STREAMING = 8, GNPDE_TUNE_COUNT = 16 };
 extern int g_tune[GNPDE_TUNE_COUNT];
 
 // Optional second stream for the hub-row work of a launch sequence.  The long-row passes touch rows

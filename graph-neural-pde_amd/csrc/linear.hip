@@ -121,12 +121,105 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
   }
 }
 
+// Persistent variant for the projection shapes of the hot path (d = 16*KB <= 128 wide, m = 16*MT <= 32 columns):
+// the whole B operand (all of W) stays in registers for the life of the wavefront, wavefronts stride over the
+// 16-row tiles, and the A operand of the NEXT tile is in flight while the MFMAs of the current one issue, so
+// the kernel streams x at memory speed instead of paying one HBM round trip per tile.
+template <int MT, int KB>
+__global__ __launch_bounds__(kBlock) void linear_persistent_kernel(const float* __restrict__ x, int n, int ldx,
+                                                                   const float* __restrict__ W, int ldw,
+                                                                   const float* __restrict__ b, float* __restrict__ out,
+                                                                   int ldo, int col_base) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = lane & 15, kq = lane >> 4;
+  const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
+  const long long stride = static_cast<long long>(gridDim.x) * kWavesPerBlock;
+  long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
+
+  f32x4 bv[KB][MT];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const float4 tb = *reinterpret_cast<const float4*>(W + static_cast<size_t>(col_base + t * 16 + r) * ldw + 16 * u + 4 * kq);
+      bv[u][t] = f32x4{tb.x, tb.y, tb.z, tb.w};
+    }
+  float bias[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) bias[t] = b != nullptr ? b[col_base + t * 16 + r] : 0.0f;
+
+  auto load_tile = [&](long long tl, f32x4 (&av)[KB]) {
+    long long row = tl * 16 + r;
+    if (row >= n) row = n - 1;  // ragged last tile: clamp reads, mask writes
+    const float* xr = x + static_cast<size_t>(row) * ldx + 4 * kq;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const float4 ta = *reinterpret_cast<const float4*>(xr + 16 * u);
+      av[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+    }
+  };
+
+  f32x4 cur[KB], nxt[KB];
+  load_tile(tile, cur);
+  while (true) {
+    const long long next = tile + stride;
+    const bool more = next < n_tiles;
+    if (more) load_tile(next, nxt);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][i], bv[u][t][i], acc[t], 0, 0, 0);
+    const long long row0 = tile * 16;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long orow = row0 + 4 * kq + i;
+        if (orow < n) out[static_cast<size_t>(orow) * ldo + col_base + t * 16 + r] = acc[t][i] + bias[t];
+      }
+    if (!more) break;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) cur[u] = nxt[u];
+    tile = next;
+  }
+}
+
 template <int MT, bool ALIGNED>
 void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                  int ldo, int col, hipStream_t s) {
   // complete 16-row tiles with complete column tiles and d % 16 == 0 take the unguarded kernel
   const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
   const long long tiles = (static_cast<long long>(n) + 15) / 16;
+  if constexpr (MT <= 2) {
+    if (full_cols && d <= 128 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] == 0) {
+      // persistent grid: enough wavefronts to fill the chip (8 per SIMD at these register counts would be
+      // ideal; W fragments + double-buffered A cost ~150 VGPRs -> 3 per SIMD), each striding over tiles
+      long long blocks = 256LL * 3;
+      const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+      if (blocks > need) blocks = need;
+      const unsigned pg = static_cast<unsigned>(blocks);
+#define GNPDE_LP(KBV) \
+  hipLaunchKernelGGL((linear_persistent_kernel<MT, KBV>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col)
+      switch (d / 16) {
+        case 1: GNPDE_LP(1); return;
+        case 2: GNPDE_LP(2); return;
+        case 3: GNPDE_LP(3); return;
+        case 4: GNPDE_LP(4); return;
+        case 5: GNPDE_LP(5); return;
+        case 6: GNPDE_LP(6); return;
+        case 7: GNPDE_LP(7); return;
+        case 8: GNPDE_LP(8); return;
+        default: break;
+      }
+#undef GNPDE_LP
+    }
+  }
   const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (full_cols)
     hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, true>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo,

@@ -142,6 +142,9 @@ def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=
   for name, t in (('gat_a', gat_a), ('output_var', output_var), ('lengthscale', lengthscale),
                   ('edge_w_csr', edge_w_csr)):
     setattr(a, name, t.data_ptr() if t is not None else None)
+  # the struct only holds raw addresses: keep the tensors alive as long as the struct (a temporary passed by
+  # the caller would otherwise be freed, and its memory reused, before the kernels read it)
+  a._keepalive = (q, k, gat_a, output_var, lengthscale, edge_w_csr)
   return a
 
 
