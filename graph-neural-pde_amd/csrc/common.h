@@ -60,7 +60,18 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
 }
 
 // kernel-variant knobs for A/B measurements (gnpde_tune); 0 = the default variant
-enum { GNPDE_TUNE_SPMM_VARIANT = 0, GNPDE_TUNE_FUSED_BLOCKS_PER_CU = 1, GNPDE_TUNE_ONE_PASS = 2, GNPDE_TUNE_FORK = 3, GNPDE_TUNE_ATT_GENERIC_ROWS = 4, GNPDE_TUNE_RK4_CLASSIC = 5, GNPDE_TUNE_SPMM_INKERNEL_REDUCE = 6, GNPDE_TUNE_ONE_PASS_VARIANT = 7, GNPDE_TUNE_LINEAR_STREAMING = 8, GNPDE_TUNE_COUNT = 16 };
+enum {
+  GNPDE_TUNE_SPMM_VARIANT = 0,         // aggregation kernel <L,K,U,nontemporal> variant (tools/spmm_ab.py)
+  GNPDE_TUNE_FUSED_BLOCKS_PER_CU = 1,  // persistent grid of the one-pass kernel
+  GNPDE_TUNE_ONE_PASS = 2,             // 1: GRAND-nl evaluations use the one-pass kernel
+  GNPDE_TUNE_FORK = 3,                 // 1: hub-row work on a second stream (fork / join)
+  GNPDE_TUNE_ATT_GENERIC_ROWS = 4,     // 1: generic row-attention kernel instead of the scaled-dot specialisation
+  GNPDE_TUNE_RK4_CLASSIC = 5,          // 1: torchdiffeq-order rk4 stages (k1..k3 stored) instead of the compact form
+  GNPDE_TUNE_RESERVED6 = 6,
+  GNPDE_TUNE_ONE_PASS_VARIANT = 7,     // register / unroll variants of the one-pass kernel (tools/onepass_ab.py)
+  GNPDE_TUNE_LINEAR_STREAMING = 8,     // 1: one-tile-per-wave projection kernel instead of the persistent one
+  GNPDE_TUNE_COUNT = 16
+};
 extern int g_tune[GNPDE_TUNE_COUNT];
 
 // Optional second stream for the hub-row work of a launch sequence.  The long-row passes touch rows

@@ -31,9 +31,6 @@ struct SpmmArgs {
   float* plain_out;      // != nullptr: write ax only (no epilogue)
   float* partial;        // [n_long_chunks, ldp]
   int ldp;
-  unsigned* arrivals;    // [n_long_chunks] zeroed before the launch; entry [first chunk of a row] counts its finished chunks
-  const int* __restrict__ lc_first;   // first chunk index of the row a chunk belongs to
-  const int* __restrict__ rowptr_full;
   gnpde_epilogue_t ep;
 };
 
@@ -115,36 +112,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
       const int col = (k * L + cl) * VEC;
       if (col < a.d) store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc[k]);
     }
-    if (a.arrivals == nullptr) return;  // a separate reduction kernel follows
-    // Last-arriver reduction: publish the partial (agent-scope release), count this chunk in; the wave that
-    // completes the row folds all of its chunks in chunk order (deterministic) and runs the epilogue.
-    const int first = a.lc_first[chunk];
-    const int nch = (a.rowptr_full[row + 1] - a.rowptr_full[row] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned prev = 0;
-    if (lane == 0) prev = atomicAdd(a.arrivals + first, 1u);
-    prev = __builtin_amdgcn_readfirstlane(prev);
-    if (prev != static_cast<unsigned>(nch - 1)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (lane == 0) a.arrivals[first] = 0u;  // leave the counter clean for the next launch
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
-    for (int c = first; c < first + nch; ++c) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int col = (k * L + cl) * VEC;
-        if (col < a.d) {
-          float pv[VEC];
-          load_vec<VEC>(a.partial + static_cast<size_t>(c) * a.ldp + col, pv);
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[k][v] += pv[v];
-        }
-      }
-    }
-    // fall through to the row epilogue below with the folded sums
+    return;  // spmm_long_reduce_kernel folds the chunks of a row in chunk order
   }
   if (a.plain_out != nullptr) {
 #pragma unroll
@@ -340,8 +308,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   a.ldp = static_cast<int>(align_up(static_cast<size_t>(d), 4));
   a.partial = static_cast<float*>(ws);
   if (g->n_long_chunks > 0) {
-    const size_t need = align_up(static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float), 256) +
-                        static_cast<size_t>(g->n_long_chunks) * sizeof(unsigned);
+    const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
     GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need, GNPDE_EWS, "spmm: workspace %zu < %zu bytes", ws_bytes, need);
     GNPDE_CHECK_ARG(g->long_rows && g->long_chunk_ptr && g->long_chunk_row && g->long_chunk_begin && g->long_chunk_end,
                     GNPDE_EINVAL, "spmm: long-row arrays missing");
@@ -392,22 +359,15 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     return dispatch_rows<1>(arg, st);
   };
   const bool forked = fork != nullptr && fork->aux != nullptr && g->n_long_rows > 0;
-  const bool in_kernel_reduce = !forked && g->n_long_rows > 0 && g->long_chunk_first != nullptr &&
-                                g_tune[GNPDE_TUNE_SPMM_INKERNEL_REDUCE] == 1;  // opt-in: measured 1.7x SLOWER (each release fence writes back the XCD's dirty L2 lines)
-  if (in_kernel_reduce) {
-    a.arrivals = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align_up(static_cast<size_t>(g->n_long_chunks) * a.ldp * 4, 256));
-    a.lc_first = g->long_chunk_first;
-    a.rowptr_full = g->rowptr;
-    GNPDE_HIP(hipMemsetAsync(a.arrivals, 0, static_cast<size_t>(g->n_long_chunks) * sizeof(unsigned), stream));
-  }
-  // rows and long-row chunks in one launch; the wave that finishes a long row's last chunk folds the row
-  // (or, with a fork / the tuning knob, the chunks + a separate reduction kernel)
+  // rows and long-row chunks in one launch, then the per-row reduction of the chunk partials (a last-arriver
+  // reduction inside the kernel was measured 1.7x slower: every agent-scope release fence writes back the
+  // XCD's dirty L2 lines); with a fork the chunks + reduction run as a parallel branch
   a.item_base = 0;
   a.item_end = forked ? g->n : g->n + g->n_long_chunks;
   int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();
-  if (g->n_long_rows > 0 && !in_kernel_reduce) {
+  if (g->n_long_rows > 0) {
     hipStream_t br = forked ? fork_begin(fork, stream) : stream;
     if (forked) {
       SpmmArgs c = a;
@@ -429,9 +389,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
 
 extern "C" size_t gnpde_spmm_workspace_bytes(const gnpde_graph_t* g, int32_t d) {
   if (!g || d < 1) return 0;
-  if (g->n_long_chunks == 0) return 0;
-  return gnpde::align_up(static_cast<size_t>(g->n_long_chunks) * gnpde::align_up(static_cast<size_t>(d), 4) * sizeof(float), 256) +
-         static_cast<size_t>(g->n_long_chunks) * sizeof(unsigned);
+  return static_cast<size_t>(g->n_long_chunks) * gnpde::align_up(static_cast<size_t>(d), 4) * sizeof(float);
 }
 
 extern "C" int gnpde_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int32_t d, int32_t ld,

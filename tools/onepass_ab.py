@@ -13,7 +13,7 @@ wqk = (torch.randn(2 * A, d, device=dev) / d ** 0.5).contiguous(); bqk = torch.z
 att = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False)
 alpha, beta = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
 for v in [0, 1, 2, 3, 4]:
-  ops.tune(7, v)
+  ops.tune(_lib.TUNE_ONE_PASS_VARIANT, v)
   for bpc in ([0] if v else [0, 2, 4]):
     ops.tune(_lib.TUNE_FUSED_BLOCKS_PER_CU, bpc)
     for _ in range(2): ops.attn_rhs_fused(graph, att, wqk, bqk, x, alpha, beta, x0, True, out=out)
