@@ -18,7 +18,7 @@ namespace gnpde {
 namespace {
 
 struct SpmmArgs {
-  int item_base, item_end;   // work items [item_base, item_end): < n are rows, >= n are long-row chunks
+  int item_base, item_end;   // work items [item_base, item_end): < n_long_chunks are long-row chunks, then the rows
   int n, n_long_chunks;
   const int* __restrict__ rowptr;
   const int* __restrict__ colidx;
@@ -45,16 +45,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
   const int sub = lane / L;   // neighbour slot
   const int cl = lane % L;    // column lane
 
+  // Work items: first the long-row chunks (512 edges each = the longest-running waves, so they start at time 0
+  // and overlap with everything else instead of forming the kernel's tail), then the rows.
   int row, e0, e1;
   int chunk = -1;
-  if (item < a.n) {
-    row = item;
+  if (item >= a.n_long_chunks) {
+    row = item - a.n_long_chunks;
+    if (row >= a.n) return;
     e0 = a.rowptr[row];
     e1 = a.rowptr[row + 1];
-    if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed below as chunks
+    if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed as chunks
   } else {
-    chunk = item - a.n;
-    if (chunk >= a.n_long_chunks) return;
+    chunk = item;
     row = a.lc_row[chunk];
     e0 = a.lc_begin[chunk];
     e1 = a.lc_end[chunk];
@@ -362,8 +364,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   // rows and long-row chunks in one launch, then the per-row reduction of the chunk partials (a last-arriver
   // reduction inside the kernel was measured 1.7x slower: every agent-scope release fence writes back the
   // XCD's dirty L2 lines); with a fork the chunks + reduction run as a parallel branch
-  a.item_base = 0;
-  a.item_end = forked ? g->n : g->n + g->n_long_chunks;
+  a.item_base = forked ? g->n_long_chunks : 0;
+  a.item_end = g->n_long_chunks + g->n;
   int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();
@@ -371,8 +373,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     hipStream_t br = forked ? fork_begin(fork, stream) : stream;
     if (forked) {
       SpmmArgs c = a;
-      c.item_base = g->n;
-      c.item_end = g->n + g->n_long_chunks;
+      c.item_base = 0;
+      c.item_end = g->n_long_chunks;
       rc = run(c, br);
       if (rc != 0) return rc;
       GNPDE_LAUNCH_CHECK();

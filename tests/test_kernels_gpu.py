@@ -196,3 +196,43 @@ def test_symmetric_attention_known_answer(dev):
   edge = torch.tensor([[0, 0, 1, 1, 2, 2], [1, 2, 0, 2, 0, 1]], device=dev)
   att, _ = layer(torch.ones(3, 2, device=dev), edge)
   assert torch.all(torch.eq(att, 0.5 * torch.ones(6, 2, device=dev)))
+
+
+def test_degenerate_graphs(dev):
+  """Empty edge list, a single self-loop, one hub row among isolated nodes, one-column state."""
+  alpha, beta = torch.tensor(0.5), torch.tensor(0.25)
+  # (1) no edges at all: A x = 0 -> f = a (0 - x) + b x0
+  n, d = 37, 9
+  x, x0 = torch.randn(n, d), torch.randn(n, d)
+  graph = G.CSRGraph(torch.zeros(2, 0, dtype=torch.long, device=dev), n)
+  w = torch.zeros(1, device=dev)
+  out = ops.spmm_rhs(graph, w, x.to(dev), alpha.to(dev), beta.to(dev), x0.to(dev), True)
+  assert_parity(out, torch.sigmoid(alpha) * (0 - x) + beta * x0, what='empty graph')
+  # (2) a single node with a self loop of weight 1: f = b x0
+  graph = G.CSRGraph(torch.zeros(2, 1, dtype=torch.long, device=dev), 1)
+  out = ops.spmm_rhs(graph, torch.ones(1, device=dev), x[:1].contiguous().to(dev), alpha.to(dev), beta.to(dev),
+                     x0[:1].contiguous().to(dev), True)
+  assert_parity(out, beta * x0[:1], what='single self-loop')
+  # (3) one hub row (long-row path) whose neighbours are otherwise isolated, d = 1
+  n = 3000
+  nb = torch.arange(1, n)
+  ei = torch.stack([torch.zeros(n - 1, dtype=torch.long), nb])
+  x1, x01 = torch.randn(n, 1), torch.randn(n, 1)
+  w1 = torch.rand(n - 1) / n
+  ref = R.rhs_laplacian(x1, ei, w1, alpha, beta, x01, False, True)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.n_long_rows == 1 and graph.n_bin16 == 0
+  out = ops.spmm_rhs(graph, ops.edge_to_csr_mean(graph, w1.to(dev)), x1.to(dev), alpha.to(dev), beta.to(dev), x01.to(dev), True)
+  assert_parity(out, ref, what='single hub, d=1')
+  # (4) attention on that hub graph: softmax over one 2999-entry row, every other row empty
+  A, h = 8, 2
+  g = torch.Generator().manual_seed(0)
+  xx = torch.randn(n, 12, generator=g)
+  Wq, Wk = torch.randn(A, 12, generator=g) * 0.3, torch.randn(A, 12, generator=g) * 0.3
+  att_ref, _ = R.transformer_attention(xx, ei, Wq, torch.zeros(A), Wk, torch.zeros(A), h)
+  qk = ops.linear(xx.to(dev), torch.cat([Wq, Wk]).to(dev), None)
+  st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A)
+  wm, att, _ = ops.edge_attention(graph, st, True, True, False, like=qk)
+  assert_parity(att, att_ref, what='hub-only attention')
+  wf, _, _ = ops.edge_attention(graph, st, True, False, False, like=qk)   # fused row path: hub phases only
+  assert_parity(wf[:graph.e], att_ref.mean(dim=1)[graph.perm_long.cpu()], what='hub-only fused attention')
