@@ -175,3 +175,36 @@ def test_transformer_native_vjp_one_evaluation(dev, heads, att_dim, reweight):
     assert float((a.grad.cpu() - b.grad).abs().max()) <= GTOL * scale, 'dparam'
   assert_parity(func.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
   assert_parity(func.beta_train.grad.reshape(-1), bc.grad.reshape(-1), tol=GTOL, what='dbeta')
+
+
+def test_cora_best_params_training_step(dev):
+  """The reference's Cora configuration in TRAINING mode: attention block (squareplus, attention_norm_idx 1,
+  8 heads) computed once with autograd history, Laplacian function with native backward, dopri5 through the
+  differentiable host controller -- loss gradients w.r.t. the input and the attention parameters against CPU
+  autograd through the oracle driven by the same controller."""
+  n, d = 500, 24
+  ei = random_graph(n, 5, seed=13)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(14)) * 0.5
+  opt = dict(OPT, function='laplacian', block='attention', method='dopri5', time=4.0, tol_scale=800.0, heads=8,
+             attention_dim=32, hidden_dim=d, square_plus=True, attention_norm_idx=1)
+  block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, 4.0])).to(dev)
+  _rand_params(block, 15, dev)
+  block.train()
+  xd = x.to(dev).requires_grad_(True)
+  block.set_x0(xd)
+  z = block(xd)
+  (z ** 2).sum().backward()
+  lay, f = block.multihead_att_layer, block.odefunc
+  xc = _cpu(x)
+  ps = [_cpu(p) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+  ac, bc = _cpu(f.alpha_train), _cpu(f.beta_train)
+  e_n, w_n = R.get_rw_adj(ei, None, 1, 1, n)
+  att, _ = R.transformer_attention(xc, e_n, ps[0], ps[1], ps[2], ps[3], 8, norm_idx=1, square_plus=True)
+  rhs = lambda t, y: R.rhs_laplacian(y, e_n, att, ac, bc, x, False, True)
+  zr = G.odeint(rhs, xc, torch.tensor([0, 4.0]), method='dopri5', options={}, atol=800.0 * 1e-7, rtol=800.0 * 1e-9)[1]
+  assert_parity(z, zr, tol=1e-4, what='z')
+  (zr ** 2).sum().backward()
+  assert_parity(xd.grad, xc.grad, tol=2e-3, what='dx')
+  scale = max(float(b.grad.abs().max()) for b in ps)
+  for a, b in zip((lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias), ps):
+    assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-3 * scale, 'd attention params'
