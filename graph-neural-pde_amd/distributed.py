@@ -249,6 +249,8 @@ def bench_main(args, rank, world, dev):
   d = cfg['d']
   A, h = args.att_dim or cfg['att_dim'], args.heads or cfg['heads']
   ei_loops, _ = G.add_remaining_self_loops(ei, None, 1.0, n)      # as ODEFuncTransformerAtt.__init__ does
+  if args.function == 'laplacian':                                  # the block's rw-normalised edge list (same loops)
+    ei_loops, w_loops = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
   t0 = time.perf_counter()
   plan = PartitionPlan(ei_loops, n, world)
   shard = plan.shard(rank)
@@ -260,8 +262,7 @@ def bench_main(args, rank, world, dev):
                 bq=torch.zeros(A), bk=torch.zeros(A), heads=h)
   kind = args.function
   if kind == 'laplacian':
-    _, w = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
-    params = dict(edge_weight=w[shard.edge_ids])
+    params = dict(edge_weight=w_loops[shard.edge_ids])
   be = NativeBackend(shard, d, dev, kind, params, torch.tensor(0.0), torch.tensor(0.1), True)
   solver = ShardedSolver(shard, be)
   x_own = scatter_rows(x, shard).to(dev)
@@ -278,6 +279,32 @@ def bench_main(args, rank, world, dev):
     dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+  # self-check outside the timed region: one sharded evaluation f(x) (incl. the halo exchange) against the
+  # same evaluation on the unpartitioned graph, computed natively on this rank's GPU
+  with torch.no_grad():
+    from . import ops
+    chk = ShardedSolver(shard, be)
+    chk.y[:shard.n_own].copy_(x_own)
+    chk.exchange(chk.y)
+    f_own = be.empty(shard.n_own)
+    be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
+    full = CSRGraph(ei_loops.to(dev), n) if kind == 'transformer' else None
+    xg = x.to(dev)
+    alpha_d, beta_d = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
+    if kind == 'transformer':
+      wqk = torch.cat([params['Wq'], params['Wk']]).to(dev).contiguous()
+      qk = ops.linear(xg, wqk, torch.zeros(2 * A, device=dev))
+      st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A)
+      w_full, _, _ = ops.edge_attention(full, st, True, False, False, like=xg)
+      f_full = ops.spmm_rhs(full, w_full, xg, alpha_d, beta_d, xg, True)
+    else:
+      e_rw, w_rw = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
+      full = CSRGraph(e_rw.to(dev), n)
+      f_full = ops.spmm_rhs(full, ops.edge_to_csr_mean(full, w_rw.to(dev)), xg, alpha_d, beta_d, xg, True)
+    ref_own = f_full[shard.own_old_ids.to(dev)]
+    err = ((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30)).reshape(1).float()
+    dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    del chk, full, f_full, xg
   el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
   dist.all_reduce(el, op=dist.ReduceOp.MAX)
   finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=dev)
@@ -300,7 +327,8 @@ def bench_main(args, rank, world, dev):
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
                  'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
-                 'finite': bool(finite.item() == 1.0)},
+                 'finite': bool(finite.item() == 1.0),
+                 'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
       'roofline': None, 'cpu_baseline': None,
     }
     print(json.dumps(out))
