@@ -36,7 +36,7 @@ class GraphStruct(ctypes.Structure):
               ('long_rows', c_vp), ('long_chunk_ptr', c_vp), ('long_chunk_row', c_vp),
               ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp),
               ('n_long_cols', ctypes.c_int32), ('n_bin16', ctypes.c_int32), ('n_bin64', ctypes.c_int32),
-              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('reserved_', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp)]
+              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('row_begin', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp)]
 
 
 class EpilogueStruct(ctypes.Structure):
@@ -55,7 +55,8 @@ class AttentionStruct(ctypes.Structure):
 
 class RhsStruct(ctypes.Structure):
   _fields_ = [('kind', ctypes.c_int32), ('graph', ctypes.POINTER(GraphStruct)),
-              ('d', ctypes.c_int32), ('ld', ctypes.c_int32), ('n_state_rows', ctypes.c_int32), ('pad_', ctypes.c_int32),
+              ('d', ctypes.c_int32), ('ld', ctypes.c_int32), ('n_state_rows', ctypes.c_int32), ('proj_row_begin', ctypes.c_int32), ('proj_row_end', ctypes.c_int32),
+              ('pad_', ctypes.c_int32),
               ('alpha', c_vp), ('beta', c_vp), ('x0', c_vp), ('alpha_sigmoid', ctypes.c_int32),
               ('w_csr', c_vp),
               ('proj_w', c_vp), ('proj_b', c_vp), ('proj_m', ctypes.c_int32),

@@ -817,6 +817,7 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
 
   const bool fused = a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
                      g->bin_rows != nullptr && fused_supported(a, vec4);
+  GNPDE_CHECK_ARG(g->row_begin == 0 || fused, GNPDE_EINVAL, "edge_attention: a row sub-range needs the fused row path");
   if (fused) {
     AttArgs c = a;
     c.chunk_begin = g->long_chunk_begin;

@@ -30,16 +30,21 @@ struct RhsLayout {
   size_t att_bytes, spmm_bytes, fused_bytes;
 };
 
+// The projection comes FIRST so that two descriptors over the same state rows (interior / boundary pass of a
+// partitioned graph) that are handed the same workspace see the SAME q||k buffer; the regions behind it are
+// scratch that each pass overwrites (the passes are ordered on one stream).
 RhsLayout rhs_layout(const gnpde_rhs_t& r) {
   RhsLayout L{};
   const gnpde_graph_t& g = *r.graph;
   size_t off = 0;
+  if (r.kind != GNPDE_RHS_LAPLACIAN) {
+    const size_t prow = r.n_state_rows > g.n ? r.n_state_rows : g.n;
+    L.proj = off;  off += align_up(prow * r.proj_m * 4, 256);
+  }
   L.spmm = off;
   L.spmm_bytes = gnpde_spmm_workspace_bytes(&g, r.d);
   off += align_up(L.spmm_bytes, 256);
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
-    const size_t prow = r.n_state_rows > g.n ? r.n_state_rows : g.n;
-    L.proj = off;  off += align_up(prow * r.proj_m * 4, 256);
     L.wmean = off; off += align_up(static_cast<size_t>(g.e) * 4, 256);
     L.att = off;
     L.att_bytes = attention_workspace_bytes(&g, r.att.heads, r.kind == GNPDE_RHS_GAT);
@@ -83,8 +88,14 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
     float* proj = reinterpret_cast<float*>(ws + L.proj);
     float* wmean = reinterpret_cast<float*>(ws + L.wmean);
-    const int prow = r.n_state_rows > g->n ? r.n_state_rows : g->n;   // keys of halo rows are recomputed locally
-    int rc = launch_linear_any(u, prow, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.proj_b, proj, r.proj_m, s);
+    int p0 = 0, p1 = r.n_state_rows > g->n ? r.n_state_rows : g->n;   // keys of halo rows are recomputed locally
+    if (r.proj_row_end > 0) {  // this pass projects only a slice of the state rows
+      p0 = r.proj_row_begin;
+      p1 = r.proj_row_end;
+    }
+    int rc = p1 > p0 ? launch_linear_any(u + static_cast<size_t>(p0) * r.ld, p1 - p0, r.d, r.ld, r.proj_w, r.proj_m, r.d,
+                                         r.proj_b, proj + static_cast<size_t>(p0) * r.proj_m, r.proj_m, s)
+                     : 0;
     if (rc) return rc;
     gnpde_attention_t at = r.att;
     at.ldqk = r.proj_m;

@@ -366,6 +366,18 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   // XCD's dirty L2 lines); with a fork the chunks + reduction run as a parallel branch
   a.item_base = forked ? g->n_long_chunks : 0;
   a.item_end = g->n_long_chunks + g->n;
+  if (g->row_begin > 0) {  // boundary pass of a partitioned graph: rows [row_begin, n) only (chunks belong to them)
+    GNPDE_CHECK_ARG(!forked && g->row_begin <= g->n, GNPDE_EINVAL, "spmm: bad row_begin %d", g->row_begin);
+    if (g->n_long_chunks > 0) {
+      SpmmArgs c = a;
+      c.item_base = 0;
+      c.item_end = g->n_long_chunks;
+      const int rc0 = run(c, stream);
+      if (rc0 != 0) return rc0;
+      GNPDE_LAUNCH_CHECK();
+    }
+    a.item_base = g->n_long_chunks + g->row_begin;
+  }
   int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();

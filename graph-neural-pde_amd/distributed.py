@@ -68,21 +68,30 @@ class LocalShard(object):
     self.rank, self.world = rank, P
     self.n_own = int(plan.counts[rank])
     self.edge_ids = torch.nonzero(mine).flatten()
-    r_new = plan.newid[row[mine]]
+    r_part = plan.newid[row[mine]] - off[rank]             # row position inside the part (ascending old id)
     c_new = plan.newid[col[mine]]
     c_own = pcol[mine] == rank
+    # interior rows (every neighbour owned) first, boundary rows after them: the interior pass of an evaluation
+    # can then run while the halo exchange is in flight
+    touches_halo = torch.zeros(self.n_own, dtype=torch.bool)
+    touches_halo[r_part[~c_own]] = True
+    order_local = torch.argsort(touches_halo.long() * self.n_own + torch.arange(self.n_own))
+    self.n_interior = int((~touches_halo).sum())
+    pos_local = torch.empty(self.n_own, dtype=torch.long)
+    pos_local[order_local] = torch.arange(self.n_own)     # position inside the part -> local row id
     self.halo_new = torch.unique(c_new[~c_own])          # sorted => grouped by owner, ascending inside
     self.n_halo = int(self.halo_new.numel())
     owner = torch.bucketize(self.halo_new, off[1:], right=True)
     self.recv_counts = torch.bincount(owner, minlength=P).tolist()
-    c_local = torch.where(c_own, c_new - off[rank], self.n_own + torch.searchsorted(self.halo_new, c_new))
-    self.edge_index = torch.stack([r_new - off[rank], c_local])
+    c_local = torch.where(c_own, pos_local[(c_new - off[rank]).clamp(0, max(self.n_own - 1, 0))],
+                          self.n_own + torch.searchsorted(self.halo_new, c_new))
+    self.edge_index = torch.stack([pos_local[r_part], c_local])
     # rows of mine that peers reference: unique (peer, column) pairs over the peers' rows, same order
     need = (pcol == rank) & (prow != rank)
     key = torch.unique(prow[need] * n + plan.newid[col[need]])
-    self.send_idx = (key % n) - off[rank]
+    self.send_idx = pos_local[(key % n) - off[rank]]
     self.send_counts = torch.bincount(key // n, minlength=P).tolist()
-    self.own_old_ids = plan.order[off[rank]:off[rank + 1]]
+    self.own_old_ids = plan.order[off[rank]:off[rank + 1]][order_local]
 
   @property
   def n_local(self):
@@ -105,6 +114,17 @@ class NativeBackend(object):
     self.graph = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
     self.graph.struct.n = shard.n_own            # rows to process; columns may address halo rows
     self.graph.n = shard.n_own
+    # interior / boundary views for the overlapped evaluation: the same local numbering, each holding only its
+    # rows' edges; the boundary view aggregates rows [n_interior, n_own)
+    inter = shard.edge_index[0] < shard.n_interior
+    self.eid_int = torch.nonzero(inter).flatten()
+    self.eid_bnd = torch.nonzero(~inter).flatten()
+    self.g_int = CSRGraph(shard.edge_index[:, inter], shard.n_local, device=self.dev)
+    self.g_int.struct.n = self.g_int.n = shard.n_interior
+    self.g_bnd = CSRGraph(shard.edge_index[:, ~inter], shard.n_local, device=self.dev)
+    self.g_bnd.struct.n = self.g_bnd.n = shard.n_own
+    self.g_bnd.struct.row_begin = shard.n_interior
+    self.supports_split = True
     self.alpha = alpha.detach().to(self.dev, torch.float32).reshape(-1)
     self.beta = beta.detach().to(self.dev, torch.float32).reshape(-1)
     self.alpha_sigmoid = alpha_sigmoid
@@ -112,8 +132,11 @@ class NativeBackend(object):
     self.x0 = torch.zeros(shard.n_own, d, dtype=torch.float32, device=self.dev)   # persistent source term
     self.has_source = False
     if kind == 'laplacian':
-      self.w_csr = ops.edge_to_csr_mean(self.graph, params['edge_weight'].to(self.dev, torch.float32))
-      self._kw = dict(kind=_lib.RHS_LAPLACIAN, w_csr=self.w_csr)
+      ew = params['edge_weight'].to(self.dev, torch.float32)
+      self.w_csr = ops.edge_to_csr_mean(self.graph, ew)
+      self.w_int = ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)])
+      self.w_bnd = ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)])
+      self._kw = dict(kind=_lib.RHS_LAPLACIAN)
     elif kind == 'transformer':
       self.wqk = torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32).contiguous()
       self.bqk = torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32).contiguous()
@@ -127,18 +150,30 @@ class NativeBackend(object):
     self._ws = None
     self._src_ptr = None
 
-  def _descriptor(self, with_source):
-    """gnpde_rhs_t over the local shard: aggregation on the n_own rows, projection over all n_local rows."""
-    d = self._desc.get(with_source)
+  def _descriptor(self, with_source, part=None):
+    """gnpde_rhs_t over the local shard: aggregation on the n_own rows (or the interior / boundary rows),
+    projection over all n_local rows (or the own / halo rows).  All variants share one workspace, whose first
+    region is the q||k projection (csrc/solver.hip rhs_layout)."""
+    d = self._desc.get((with_source, part))
     if d is None:
       kw = dict(self._kw)
       kind = kw.pop('kind')
-      d = self.ops.RhsDescriptor(kind, self.graph, self.d, self.d, self.alpha, self.beta if with_source else None,
-                                 self.x0 if with_source else None, self.alpha_sigmoid, n_state_rows=self.shard.n_local, **kw)
-      self._desc[with_source] = d
+      sh = self.shard
+      graph = {None: self.graph, 'interior': self.g_int, 'boundary': self.g_bnd}[part]
+      if kind == _lib.RHS_LAPLACIAN:
+        kw['w_csr'] = {None: self.w_csr, 'interior': self.w_int, 'boundary': self.w_bnd}[part]
+      else:
+        # interior pass: keys / queries of the own rows; boundary pass: keys of the halo rows that just arrived
+        # (an empty slice when there is no halo)
+        kw['proj_rows'] = {None: None, 'interior': (0, sh.n_own), 'boundary': (sh.n_own, sh.n_local)}[part]
+      d = self.ops.RhsDescriptor(kind, graph, self.d, self.d, self.alpha, self.beta if with_source else None,
+                                 self.x0 if with_source else None, self.alpha_sigmoid, n_state_rows=sh.n_local, **kw)
+      self._desc[(with_source, part)] = d
       need = _lib.lib().gnpde_rhs_workspace_bytes(d.ref())
       if self._ws is None or self._ws.numel() < need:
+        old_ws = self._ws
         self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.dev)
+        del old_ws
     return d
 
   def empty(self, rows):
@@ -152,13 +187,14 @@ class NativeBackend(object):
                                             _lib.ptr(out), out.stride(0), _lib.stream_of(u)))
     return out
 
-  def rhs_stage(self, u, x0, stage, **stage_kw):
+  def rhs_stage(self, u, x0, stage, part=None, **stage_kw):
     """One evaluation with a fused solver stage: ONE call into the library (projection over own + halo rows,
-    attention and aggregation over the own rows), so the host side stays cheap next to the per-GPU work."""
+    attention and aggregation over the own rows), so the host side stays cheap next to the per-GPU work.
+    part='interior' / 'boundary' runs the half of the evaluation that does not / does need the halo rows."""
     if x0 is not None and x0.data_ptr() != self._src_ptr:   # new source tensor: refresh the persistent copy once
       self.x0.copy_(x0)
       self._src_ptr = x0.data_ptr()
-    desc = self._descriptor(x0 is not None)
+    desc = self._descriptor(x0 is not None, part)
     self.ops.rhs_stage(desc, u, stage, ws=self._ws, **stage_kw)
 
   def sync(self):
@@ -178,16 +214,30 @@ class ShardedSolver(object):
     self.uc = backend.empty(s.n_local)
     self.send = backend.empty(int(sum(s.send_counts)))
     self.n_exchanges = 0
+    self.overlap = os.environ.get('GNPDE_NO_OVERLAP', '0') != '1'   # interior rows overlap the halo exchange
 
-  def exchange(self, u):
+  def exchange(self, u, async_op=False):
     """Refresh the halo rows of `u` (rows [n_own, n_local)) from their owners."""
     s = self.shard
     if s.world == 1 and os.environ.get('GNPDE_FORCE_SHARDED', '0') != '1':
-      return
+      return None
     self.be.pack(u, self.send)
     recv = u[s.n_own:]
-    dist.all_to_all_single(recv, self.send, s.recv_counts, s.send_counts, group=self.group)
     self.n_exchanges += 1
+    return dist.all_to_all_single(recv, self.send, s.recv_counts, s.send_counts, group=self.group, async_op=async_op)
+
+  def evaluate(self, u, x0, stage, **kw):
+    """Exchange + f(u) with the fused stage.  When the backend can split the rows, the interior rows (no halo
+    neighbour) are evaluated while the all-to-all is in flight and the boundary rows after it has landed."""
+    if getattr(self.be, 'supports_split', False) and self.overlap:
+      work = self.exchange(u, async_op=True)
+      self.be.rhs_stage(u, x0, stage, part='interior', **kw)
+      if work is not None:
+        work.wait()
+      self.be.rhs_stage(u, x0, stage, part='boundary', **kw)
+    else:
+      self.exchange(u)
+      self.be.rhs_stage(u, x0, stage, **kw)
 
   def integrate(self, y_own, x0_own, T, step_size=1.0, method='rk4'):
     """Integrate the owned rows from t = 0 to T; returns the owned rows of y(T) (a view of an
@@ -200,18 +250,13 @@ class ShardedSolver(object):
     y[:n].copy_(y_own)
     for dt in dts:
       if method == 'euler':
-        self.exchange(y)
-        be.rhs_stage(y, x0_own, stage=_lib.STAGE_EULER, dt=dt, y=y, out_y=ua)
+        self.evaluate(y, x0_own, _lib.STAGE_EULER, dt=dt, y=y, out_y=ua)
         y, ua = ua, y
       elif method == 'rk4':   # compact stage algebra (gnpde.h): stage states from stage inputs, no k arrays
-        self.exchange(y)
-        be.rhs_stage(y, x0_own, stage=_lib.STAGE_RK1C, dt=dt, out_y=ua)
-        self.exchange(ua)
-        be.rhs_stage(ua, x0_own, stage=_lib.STAGE_RK2C, dt=dt, y=y, out_y=ub)
-        self.exchange(ub)
-        be.rhs_stage(ub, x0_own, stage=_lib.STAGE_RK3C, dt=dt, k1=ua, out_y=uc)
-        self.exchange(uc)
-        be.rhs_stage(uc, x0_own, stage=_lib.STAGE_RK4C, dt=dt, y=y, k1=ub, out_y=y)
+        self.evaluate(y, x0_own, _lib.STAGE_RK1C, dt=dt, out_y=ua)
+        self.evaluate(ua, x0_own, _lib.STAGE_RK2C, dt=dt, y=y, out_y=ub)
+        self.evaluate(ub, x0_own, _lib.STAGE_RK3C, dt=dt, k1=ua, out_y=uc)
+        self.evaluate(uc, x0_own, _lib.STAGE_RK4C, dt=dt, y=y, k1=ub, out_y=y)
       else:
         raise ValueError(method)
     self.y, self.ua = y, ua
@@ -224,17 +269,23 @@ def scatter_rows(x_global, shard):
 
 
 def gather_rows_all(y_own, plan, shard, group=None):
-  """All-gather the owned rows and undo the partition permutation (tests / small graphs)."""
+  """All-gather the owned rows and undo the partition permutation (tests / small graphs).  Every rank orders
+  its own rows interior-first, so the original ids travel with the rows."""
   P = plan.world
   m = int(plan.counts.max())
-  pad = torch.zeros(m, y_own.shape[1], dtype=y_own.dtype, device=y_own.device)
+  dev = y_own.device
+  pad = torch.zeros(m, y_own.shape[1], dtype=y_own.dtype, device=dev)
   pad[:y_own.shape[0]] = y_own
+  ids = torch.full((m,), -1, dtype=torch.long, device=dev)
+  ids[:shard.n_own] = shard.own_old_ids.to(dev)
   parts = [torch.empty_like(pad) for _ in range(P)]
+  id_parts = [torch.empty_like(ids) for _ in range(P)]
   dist.all_gather(parts, pad, group=group)
-  out = torch.empty(plan.n, y_own.shape[1], dtype=y_own.dtype, device=y_own.device)
+  dist.all_gather(id_parts, ids, group=group)
+  out = torch.empty(plan.n, y_own.shape[1], dtype=y_own.dtype, device=dev)
   for p in range(P):
-    ids = plan.order[plan.offsets[p]:plan.offsets[p + 1]].to(y_own.device)
-    out[ids] = parts[p][:ids.numel()]
+    ok = id_parts[p] >= 0
+    out[id_parts[p][ok]] = parts[p][ok]
   return out
 
 

@@ -40,6 +40,8 @@ def edge_to_csr_mean(graph, src_edge, out=None):
     raise _lib.GnpdeError('edge weights have %d rows but the graph has %d edges' % (src.shape[0], graph.e))
   if out is None:
     out = torch.empty(max(graph.e, 1), dtype=torch.float32, device=src.device)
+  if graph.e == 0:
+    return out.zero_()
   check(_lib.lib().gnpde_edge_to_csr_mean(graph.ref(), ptr(src), h, ptr(out), stream_of(src)))
   return out
 
@@ -191,7 +193,7 @@ class RhsDescriptor(object):
   """Python owner of a gnpde_rhs_t: keeps every tensor the descriptor points to alive."""
 
   def __init__(self, kind, graph, d, ld, alpha, beta, x0, alpha_sigmoid, w_csr=None, proj_w=None, proj_b=None,
-               att=None, n_state_rows=0):
+               att=None, n_state_rows=0, proj_rows=None):
     self.graph = graph
     self.keep = [alpha, beta, x0, w_csr, proj_w, proj_b]
     r = _lib.RhsStruct()
@@ -199,6 +201,8 @@ class RhsDescriptor(object):
     r.graph = ctypes.pointer(graph.struct)
     r.d, r.ld = int(d), int(ld)
     r.n_state_rows = int(n_state_rows)
+    if proj_rows is not None:
+      r.proj_row_begin, r.proj_row_end = int(proj_rows[0]), int(proj_rows[1])
     r.alpha = alpha.data_ptr()
     r.beta = beta.data_ptr() if beta is not None else None
     r.x0 = x0.data_ptr() if x0 is not None else None

@@ -103,7 +103,8 @@ typedef struct gnpde_graph {
   int32_t n_bin64;                   /* rows with 17..GNPDE_LONG_ROW entries                 */
   int32_t max_row_len;               /* longest row                                          */
   int32_t max_col_len;               /* longest column (0 without the CSC view)              */
-  int32_t reserved_;
+  int32_t row_begin;                 /* aggregation covers rows [row_begin, n) (0 normally; the boundary
+                                        pass of a row-partitioned graph starts after the interior rows) */
   const int32_t* long_cols;          /* [n_long_cols] or NULL                                */
   const int32_t* bin_rows;           /* [(n_bin16 + n_bin64) * 4] records {row, begin, len, 0} */
   const int32_t* long_chunk_first;   /* [n_long_chunks] index of the first chunk of the same row */
@@ -285,6 +286,9 @@ typedef struct gnpde_rhs {
   int32_t d, ld;              /* state width and leading dimension                             */
   int32_t n_state_rows;       /* rows of the state incl. halo rows of a row-partitioned graph (0: graph->n);
                                  the projection covers all of them, the aggregation only graph->n rows */
+  int32_t proj_row_begin;     /* with proj_row_end > 0: project only rows [proj_row_begin, proj_row_end)
+                                 (interior / boundary passes overlapping the halo exchange) */
+  int32_t proj_row_end;
   int32_t pad_;
   /* epilogue scalars */
   const float* alpha; const float* beta; const float* x0; int32_t alpha_sigmoid;

@@ -21,6 +21,8 @@ from helpers import random_graph  # noqa: E402
 class OracleBackend(object):
   """Same interface as distributed.NativeBackend; arithmetic from oracle/restate.py (test only)."""
 
+  supports_split = True
+
   def __init__(self, shard, d, kind, params, alpha, beta):
     self.shard, self.d, self.kind, self.p, self.alpha, self.beta = shard, d, kind, params, alpha, beta
 
@@ -31,10 +33,22 @@ class OracleBackend(object):
     out.copy_(u[self.shard.send_idx])
     return out
 
-  def rhs_stage(self, u, x0, stage, dt=0.0, y=None, k1=None, k2=None, k3=None, out_k=None, out_y=None):
+  def rhs_stage(self, u, x0, stage, part=None, dt=0.0, y=None, k1=None, k2=None, k3=None, out_k=None, out_y=None):
+    """part = 'interior' evaluates only the rows without halo neighbours (the halo region of `u` may be stale
+    then, so it is poisoned here to prove those rows do not read it), 'boundary' the others."""
     s, p = self.shard, self.p
     n = s.n_own
     ei = s.edge_index
+    lo, hi = {None: (0, n), 'interior': (0, s.n_interior), 'boundary': (s.n_interior, n)}[part]
+    if part == 'interior':
+      keep = ei[0] < s.n_interior
+      assert bool((ei[1][keep] < n).all()), 'an interior row references a halo column'
+      u = u.clone()
+      u[n:] = float('nan')
+      ei = ei[:, keep]
+      if self.kind != 'transformer':
+        p = dict(p, edge_weight=p['edge_weight'][keep])
+    rows = slice(lo, hi)
     if self.kind == 'transformer':
       att, _ = R.transformer_attention(u, ei, p['Wq'], p['bq'], p['Wk'], p['bk'], p['heads'])
       w = att.mean(dim=1)
@@ -45,16 +59,17 @@ class OracleBackend(object):
     if x0 is not None:
       k = k + self.beta * x0
     third = 1 / 3
+    k, un = k[rows], u[:n][rows]
     if stage == _lib.STAGE_EULER:
-      out_y[:n] = y[:n] + dt * k
+      out_y[rows] = y[rows] + dt * k
     elif stage == _lib.STAGE_RK1C:
-      out_y[:n] = u[:n] + dt * k * third
+      out_y[rows] = un + dt * k * third
     elif stage == _lib.STAGE_RK2C:
-      out_y[:n] = (2 * y[:n] - u[:n]) + dt * k
+      out_y[rows] = (2 * y[rows] - un) + dt * k
     elif stage == _lib.STAGE_RK3C:
-      out_y[:n] = (2 * k1[:n] - u[:n]) + dt * k
+      out_y[rows] = (2 * k1[rows] - un) + dt * k
     elif stage == _lib.STAGE_RK4C:
-      out_y[:n] = ((6 * k1[:n] + 3 * u[:n] - y[:n]) + dt * k) * 0.125
+      out_y[rows] = ((6 * k1[rows] + 3 * un - y[rows]) + dt * k) * 0.125
     else:
       raise ValueError(stage)
 

@@ -45,9 +45,13 @@ def test_plan_is_a_permutation_and_local_graphs_cover_all_edges():
     glob_cols = ei[1][sh.edge_ids]
     loc = sh.edge_index[1]
     own = loc < sh.n_own
-    assert torch.equal(plan.order[plan.offsets[r] + loc[own]], glob_cols[own])
+    assert torch.equal(sh.own_old_ids[loc[own]], glob_cols[own])
     assert torch.equal(plan.order[sh.halo_new[loc[~own] - sh.n_own]], glob_cols[~own])
-    assert torch.equal(plan.order[plan.offsets[r] + sh.edge_index[0]], ei[0][sh.edge_ids])
+    assert torch.equal(sh.own_old_ids[sh.edge_index[0]], ei[0][sh.edge_ids])
+    # interior rows come first and never reference a halo column
+    rows_with_halo = torch.unique(sh.edge_index[0][~own])
+    assert rows_with_halo.numel() == sh.n_own - sh.n_interior
+    assert rows_with_halo.numel() == 0 or int(rows_with_halo.min()) >= sh.n_interior
   assert torch.all(seen == 1)
 
 

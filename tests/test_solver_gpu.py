@@ -220,6 +220,15 @@ def test_sharded_native_backend_one_evaluation(dev, kind):
     out = torch.empty(sh.n_own, d, device=dev)
     be.rhs_stage(u, x0[sh.own_old_ids].to(dev), stage=_lib.STAGE_RHS, out_k=out)
     assert_parity(out, ref[sh.own_old_ids], what='shard %d %s' % (r, kind))
+    # the overlapped form: interior rows with a POISONED halo region, then boundary rows with the halo in place
+    assert 0 < sh.n_interior < sh.n_own
+    out2 = torch.full((sh.n_own, d), float('nan'), device=dev)
+    u_stale = u.clone()
+    u_stale[sh.n_own:] = float('nan')
+    be.rhs_stage(u_stale, x0[sh.own_old_ids].to(dev), stage=_lib.STAGE_RHS, part='interior', out_k=out2)
+    assert torch.isfinite(out2[:sh.n_interior]).all() and torch.isnan(out2[sh.n_interior:]).all()
+    be.rhs_stage(u, x0[sh.own_old_ids].to(dev), stage=_lib.STAGE_RHS, part='boundary', out_k=out2)
+    assert torch.equal(out2, out), 'interior + boundary passes differ from the single pass'
     send = be.empty(int(sum(sh.send_counts)))
     be.pack(u, send)
     assert torch.equal(send.cpu(), x[sh.own_old_ids][sh.send_idx])
