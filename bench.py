@@ -44,12 +44,15 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-evals', type=int, default=6)
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
+  ap.add_argument('--square-plus', action='store_true', help='squareplus normalisation (Cora best_params)')
   return ap.parse_args()
 
 
 def build_opt(cfg, args):
   return dict(heads=args.heads or cfg['heads'], attention_dim=args.att_dim or cfg['att_dim'],
-              attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+              attention_type='scaled_dot', attention_norm_idx=args.norm_idx, square_plus=args.square_plus,
+              reweight_attention=False,
               beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True,
               no_alpha_sigmoid=False, mix_features=False, hidden_dim=cfg['d'], augment=False, adjoint=False,
               tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
@@ -247,6 +250,7 @@ def main():
                              'add_source', K),
                'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
+               'attention_norm_idx': args.norm_idx, 'square_plus': args.square_plus,
                'long_rows': graph.n_long_rows, 'algorithmic_bytes_per_rhs_eval': bytes_eval,
                'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
     'roofline': {'kernel': kname, 'bound': 'hbm',

@@ -223,6 +223,44 @@ __global__ __launch_bounds__(kBlock) void seg_stats_kernel(const AttArgs a) {
   }
 }
 
+// Head-parallel variant for h in {1,2,4,8}: lane = (entry slot, head) with the head fastest, so the h scores of
+// an entry are one contiguous 4h-byte read (instead of h strided passes over the segment) and both sweeps
+// cover all heads at once.  Reductions over the entry slots are xor butterflies with stride H.
+template <int H>
+__global__ __launch_bounds__(kBlock) void seg_stats_heads_kernel(const AttArgs a) {
+  constexpr int ES = kWave / H;  // entries per wave pass
+  const int lane = threadIdx.x & (kWave - 1);
+  const int seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
+  if (seg >= a.n) return;
+  const int b = a.segptr[seg], e = a.segptr[seg + 1];
+  if (e - b > GNPDE_LONG_ROW && a.long_segs != nullptr) return;
+  const int es = lane / H, head = lane % H;
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  float m = 0.f;
+  if (!a.square_plus) {
+    float mx = -INFINITY;
+    for (int t = b + es; t < e; t += ES) {
+      const int p = a.segpos ? a.segpos[t] : t;
+      mx = fmaxf(mx, a.scores[static_cast<size_t>(p) * H + head]);
+    }
+#pragma unroll
+    for (int off = H; off < kWave; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    m = (e > b) ? mx : 0.f;
+  }
+  float sum = 0.f;
+  for (int t = b + es; t < e; t += ES) {
+    const int p = a.segpos ? a.segpos[t] : t;
+    const float sv = a.scores[static_cast<size_t>(p) * H + head];
+    sum += a.square_plus ? squareplus_num(sv, gmax) : expf(sv - m);
+  }
+#pragma unroll
+  for (int off = H; off < kWave; off <<= 1) sum += __shfl_xor(sum, off, kWave);
+  if (es == 0) {
+    a.seg_m[static_cast<size_t>(seg) * H + head] = m;
+    a.seg_den[static_cast<size_t>(seg) * H + head] = sum + 1e-16f;
+  }
+}
+
 // Long segments: blockIdx.x = long segment, blockIdx.y = 512-entry chunk of it.  Every chunk leaves an
 // online-softmax partial (m_c, l_c) per head (squareplus: just the partial sum); seg_stats_long_combine
 // folds them:  m = max_c m_c,  den = sum_c l_c exp(m_c - m) + 1e-16.
@@ -847,7 +885,16 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
   GNPDE_LAUNCH_CHECK();
   a.long_segs = (n_long > 0 && long_list != nullptr) ? long_list : nullptr;
-  hipLaunchKernelGGL(seg_stats_kernel, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, stream, a);
+  {
+    const dim3 sgrid((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (a.h) {
+      case 1: hipLaunchKernelGGL(seg_stats_heads_kernel<1>, sgrid, dim3(kBlock), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL(seg_stats_heads_kernel<2>, sgrid, dim3(kBlock), 0, stream, a); break;
+      case 4: hipLaunchKernelGGL(seg_stats_heads_kernel<4>, sgrid, dim3(kBlock), 0, stream, a); break;
+      case 8: hipLaunchKernelGGL(seg_stats_heads_kernel<8>, sgrid, dim3(kBlock), 0, stream, a); break;
+      default: hipLaunchKernelGGL(seg_stats_kernel, sgrid, dim3(kBlock), 0, stream, a); break;
+    }
+  }
   GNPDE_LAUNCH_CHECK();
   if (a.long_segs != nullptr) {
     hipLaunchKernelGGL(seg_stats_long_partial_kernel, dim3(n_long, max_chunks), dim3(kBlock), 0, stream, a, part, max_chunks);
