@@ -63,6 +63,13 @@ class RhsStruct(ctypes.Structure):
               ('att', AttentionStruct)]
 
 
+class DecoderStruct(ctypes.Structure):
+  _fields_ = [('weight', c_vp), ('bias', c_vp), ('labels', c_vp), ('split', c_vp),
+              ('n_classes', ctypes.c_int32), ('d_dec', ctypes.c_int32)]
+
+
+EARLY_STATE_INTS = 8
+
 # name -> (restype, argtypes); every symbol include/gnpde.h declares
 PROTOTYPES = {
   'gnpde_abi_version': (ctypes.c_int, []),
@@ -102,6 +109,10 @@ PROTOTYPES = {
   'gnpde_rk_error_ratio': (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_int32, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp]),
   'gnpde_rhs_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct)]),
+  'gnpde_early_stop_reset': (ctypes.c_int, [c_vp, c_vp]),
+  'gnpde_early_stop_eval': (ctypes.c_int, [ctypes.POINTER(DecoderStruct), c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_solver_set_early_stop': (ctypes.c_int, [c_vp, ctypes.POINTER(DecoderStruct), c_vp, c_vp, ctypes.c_int32]),
   'gnpde_solver_num_rhs_evals': (ctypes.c_int, [c_vp]),
   'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_gather_rows': (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,

@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I${ROOT}/include -I. -Wall -Wno-unused-function"
 mkdir -p build
 objs=""
-for f in error.cpp graph_prep.cpp spmm.hip linear.hip attention.hip fused_attn.hip backward.hip solver.hip misc.hip; do
+for f in error.cpp graph_prep.cpp spmm.hip linear.hip attention.hip fused_attn.hip backward.hip solver.hip misc.hip early_stop.hip; do
   o="build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ epilogue.h -nt "$o" ] || [ "${ROOT}/include/gnpde.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &

@@ -102,4 +102,9 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
                     hipStream_t stream, const Fork* fork = nullptr);
 
+// early_stop.hip
+int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,
+                            int trace_capacity, hipStream_t st);
+int check_decoder(const gnpde_decoder_t* dec, int d_state);
+
 }  // namespace gnpde

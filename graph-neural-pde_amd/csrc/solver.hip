@@ -137,6 +137,11 @@ struct gnpde_solver {
   hipGraphExec_t exec = nullptr;
   float* captured_y = nullptr;
   int n_evals = 0;
+  bool early = false;        // early-stopping evaluator after every step
+  gnpde_decoder_t dec{};
+  int* early_state = nullptr;
+  int* early_trace = nullptr;
+  int early_trace_capacity = 0;
 };
 
 namespace {
@@ -177,6 +182,14 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
   }
   char* rws = s->ws + s->off_rhs;
   float* ua = reinterpret_cast<float*>(s->ws + s->off_ua);
+  int step = 0;
+  auto evaluate = [&](const float* state) -> int {
+    ++step;
+    if (!s->early) return 0;
+    return enqueue_early_stop_eval(s->dec, state, r.ld, r.graph->n, step, s->early_state,
+                                   s->early_trace, s->early_trace_capacity, st);
+  };
+  if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, GNPDE_EARLY_STATE_INTS * sizeof(int32_t), st));
   if (s->method == GNPDE_METHOD_EULER) {
     float* cur = y;
     float* nxt = ua;
@@ -186,6 +199,8 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
       int rc = enqueue_rhs(r, cur, e, rws, s->L, st, fk);
       if (rc) return rc;
       float* t = cur; cur = nxt; nxt = t;
+      rc = evaluate(cur);
+      if (rc) return rc;
     }
     if (cur != y)
       GNPDE_HIP(hipMemcpyAsync(y, cur, static_cast<size_t>(r.graph->n) * r.ld * 4, hipMemcpyDeviceToDevice, st));
@@ -213,6 +228,8 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
       e.stage = GNPDE_STAGE_RK4C; e.k1 = ub; e.out_y = y;
       rc = enqueue_rhs(r, uc, e, rws, s->L, st, fk);
       if (rc) return rc;
+      rc = evaluate(y);
+      if (rc) return rc;
     }
     return 0;
   }
@@ -230,6 +247,8 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
     if (rc) return rc;
     e.stage = GNPDE_STAGE_RK4; e.k3 = k3; e.out_k = nullptr; e.out_y = y;
     rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
+    if (rc) return rc;
+    rc = evaluate(y);
     if (rc) return rc;
   }
   return 0;
@@ -336,6 +355,26 @@ extern "C" int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, 
     s->captured_y = y;
   }
   GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int gnpde_solver_set_early_stop(gnpde_solver_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
+                                           int32_t trace_capacity) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "solver_set_early_stop: solver is null");
+  drop_graph(s);
+  if (dec == nullptr) {
+    s->early = false;
+    return 0;
+  }
+  int rc = check_decoder(dec, s->rhs.d);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(state != nullptr, GNPDE_EINVAL, "solver_set_early_stop: state is null");
+  GNPDE_CHECK_ARG(trace != nullptr || trace_capacity == 0, GNPDE_EINVAL, "solver_set_early_stop: trace capacity without a trace");
+  s->dec = *dec;
+  s->early_state = state;
+  s->early_trace = trace;
+  s->early_trace_capacity = trace_capacity;
+  s->early = true;
   return 0;
 }
 

@@ -1,0 +1,176 @@
+"""Test-time integrators with early stopping (reference src/early_stop_solver.py).
+
+Surface kept: `EarlyStopInt(T, opt, device)` is installed as `odeblock.test_integrator` by the reference's
+GNNEarly (src/GNN_early.py:28-36), which writes `data`, `m2_weight`, `m2_bias` on it before every forward and
+reads `solver.best_train / best_val / best_test / best_time` after it (src/run_GNN.py:266-271).  The call
+integrates to `earlystopxT * T`, evaluates the decoder on the state after EVERY step and remembers the step
+with the best validation accuracy.
+
+What is different underneath: the reference leaves the solver after each step for relu -> linear -> argmax ->
+three masked accuracies with `.item()` (early_stop_solver.py:178-218).  Here the evaluation is two kernels
+appended to the step inside the solver's hipGraph (csrc/early_stop.hip) and the four numbers are read back
+once, after the solve.  dopri5 keeps its host step-size controller (one scalar read per trial step) and runs the
+same device evaluator after each accepted step; a rejected trial leaves the state -- hence the accuracies and,
+with the strict comparison, the best -- unchanged, but still counts towards `max_test_steps`.
+"""
+import torch
+
+from . import _lib
+from .odeint import time_grid, _native_ok, _solve_native, _solve_fixed_host, _solve_dopri5, _solve_dopri5_native
+from . import ops
+
+
+class _EarlyStopSolver(object):
+  """Common part of the two solvers: the result fields the callers read."""
+
+  def __init__(self, func, y0, opt):
+    self.func = func
+    self.y0 = y0
+    self.opt = opt
+    self.dataset = opt['dataset']
+    self.data = None
+    self.m2_weight = None
+    self.m2_bias = None
+    self.best_train = 0
+    self.best_val = 0
+    self.best_test = 0
+    self.best_time = 0
+    self.trace = None
+    self.evaluator = None
+
+  def set_accs(self, train, val, test, time):
+    self.best_train = train
+    self.best_val = val
+    self.best_test = test
+    self.best_time = time.item() if torch.is_tensor(time) else float(time)
+
+  def set_data(self, data):
+    if self.data is None:
+      self.data = data
+
+  def set_m2(self, m2):
+    self.m2_weight = m2.weight.data.detach().clone()
+    self.m2_bias = None if m2.bias is None else m2.bias.data.detach().clone()
+
+  def _collect(self, times):
+    """One device->host read: best accuracies and the time of the step they were measured at."""
+    res = self.evaluator.read()
+    if res['best_hits'][1] > 0:           # strict improvement over the initial best_val = 0
+      self.set_accs(res['best'][0], res['best'][1], res['best'][2], times[res['step']])
+    if res['trace'] is not None:
+      self.trace = [dict(r, time=float(times[r['step']])) for r in res['trace']]
+
+
+class EarlyStopRK4(_EarlyStopSolver):
+  """Fixed-grid 3/8-rule rk4 with the evaluator after every step (reference early_stop_solver.py:131-225)."""
+  order = 4
+
+  def __init__(self, func, y0, opt, eps=0, step_size=None, rtol=None, atol=None, **unused):
+    super(EarlyStopRK4, self).__init__(func, y0, opt)
+    if step_size is None:
+      raise ValueError('fixed-grid methods need options["step_size"]')
+    if eps != 0:
+      raise NotImplementedError('EarlyStopRK4: eps != 0 is not supported (the reference never sets it)')
+    self.step_size = step_size
+
+  def integrate(self, t):
+    grid = time_grid(t.detach().to('cpu'), self.step_size)
+    if _native_ok(self.func, self.y0, t):
+      sol = _solve_native(self.func, self.y0, t, 'rk4', self.step_size, evaluator=self.evaluator)
+    else:
+      self.evaluator.reset()
+      sol = _solve_fixed_host(self.func, self.y0, t, 'rk4', self.step_size,
+                                      on_step=lambda y, i: self.evaluator.evaluate(y.contiguous(), i))
+    self._collect(grid)
+    return grid[-1], sol
+
+
+class EarlyStopDopri5(_EarlyStopSolver):
+  """Adaptive Dormand-Prince with the evaluator after every step (reference early_stop_solver.py:30-128)."""
+  order = 5
+
+  def __init__(self, func, y0, rtol, atol, opt, **unused):
+    super(EarlyStopDopri5, self).__init__(func, y0, opt)
+    self.rtol, self.atol = rtol, atol
+    self.max_test_steps = opt['max_test_steps']
+
+  def integrate(self, t):
+    times = [float(t[0])]
+
+    def on_accept(y, t1):
+      times.append(t1)
+      self.evaluator.evaluate(y if y.is_contiguous() else y.contiguous(), len(times) - 1)
+
+    self.evaluator.reset()
+    if _native_ok(self.func, self.y0, t) and t.dtype == torch.float32:
+      sol = _solve_dopri5_native(self.func, self.y0, t, self.rtol, self.atol, on_accept=on_accept,
+                                         stop_after=self.max_test_steps)
+    else:
+      sol = _solve_dopri5(self.func, self.y0, t, self.rtol, self.atol, on_accept=on_accept,
+                                  stop_after=self.max_test_steps)
+    self._collect(times)
+    return t[-1], sol
+
+
+SOLVERS = {
+  'dopri5': EarlyStopDopri5,
+  'rk4': EarlyStopRK4,
+}
+
+
+class EarlyStopInt(torch.nn.Module):
+  """Callable with torchdiffeq.odeint's signature; ignores the `t` it is given and integrates over
+  [0, earlystopxT * T] (reference early_stop_solver.py:234-245, :288-308)."""
+
+  def __init__(self, t, opt, device=None):
+    super(EarlyStopInt, self).__init__()
+    self.device = device
+    self.solver = None
+    self.data = None
+    self.max_test_steps = opt['max_test_steps']
+    self.m2_weight = None
+    self.m2_bias = None
+    self.opt = opt
+    self.keep_trace = False    # True: solver.trace lists the accuracies of every step (costs nothing on the device)
+    self.t = torch.tensor([0, opt['earlystopxT'] * t], dtype=torch.float).to(self.device)
+    self._evaluator = None
+    self._evaluator_key = None
+
+  def _get_evaluator(self, y0):
+    data = self.data
+    if data is None or self.m2_weight is None:
+      raise _lib.GnpdeError('EarlyStopInt: `data` and `m2_weight` must be assigned before the call '
+                            '(GNNEarly.set_solver_data / set_solver_m2)')
+    w = self.m2_weight
+    key = (id(data), tuple(w.shape), self.m2_bias is None, str(y0.device), bool(self.keep_trace))
+    if self._evaluator is None or self._evaluator_key != key:
+      cap = 0
+      if self.keep_trace:
+        cap = max(int(self.max_test_steps), 1) + 4096
+      self._evaluator = ops.EarlyStopEvaluator(w.to(y0.device), self.m2_bias, data.y, data.train_mask, data.val_mask,
+                                               data.test_mask, max_trace=cap)
+      self._evaluator_key = key
+    else:   # same shapes: refresh the decoder in place, so a captured solver graph stays valid
+      self._evaluator.weight.copy_(w)
+      if self.m2_bias is not None:
+        self._evaluator.bias.copy_(self.m2_bias)
+    return self._evaluator
+
+  def __call__(self, func, y0, t, method=None, rtol=1e-7, atol=1e-9, adjoint_method='dopri5', adjoint_atol=1e-9,
+               adjoint_rtol=1e-7, options=None):
+    method = self.opt['method']
+    assert method in ['rk4', 'dopri5'], "Only dopri5 and rk4 implemented with early stopping"
+    options = dict(options or {})
+    options.pop('max_iters', None)      # passed by ConstantODEblock, ignored by torchdiffeq with a warning
+    times = self.t.to(y0.device)
+    if method == 'rk4':
+      self.solver = EarlyStopRK4(func, y0, opt=self.opt, rtol=rtol, atol=atol, **options)
+    else:
+      self.solver = EarlyStopDopri5(func, y0, rtol=rtol, atol=atol, opt=self.opt, **options)
+    if self.solver.data is None:
+      self.solver.data = self.data
+    self.solver.m2_weight = self.m2_weight
+    self.solver.m2_bias = self.m2_bias
+    self.solver.evaluator = self._get_evaluator(y0)
+    _, solution = self.solver.integrate(times)
+    return solution

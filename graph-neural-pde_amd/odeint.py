@@ -32,7 +32,7 @@ def _native_ok(func, y0, t):
           and len(t) == 2 and not func._needs_grad(y0))
 
 
-def _solve_native(func, y0, t, method, step_size, use_graph=True):
+def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None):
   from . import ops
   grid = time_grid(t.detach().to('cpu'), step_size)
   dts = (grid[1:] - grid[:-1]).tolist()
@@ -65,6 +65,8 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True):
       ent['solver'].close()
     ent['solver'] = ops.FixedStepSolver(desc, method, dts, y0.device)
     ent['sig'] = sig
+  if getattr(ent['solver'], 'evaluator', None) is not evaluator:
+    ent['solver'].set_early_stop(evaluator)     # per-step early-stopping evaluation inside the same hipGraph
   ent['solver'].run(ent['y'], use_graph=use_graph)
   func.nfe += n_evals
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
@@ -84,7 +86,7 @@ def _rk4_38_step(func, t0, dt, t1, y0):
   return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
 
 
-def _solve_fixed_host(func, y0, t, method, step_size):
+def _solve_fixed_host(func, y0, t, method, step_size, on_step=None):
   grid = time_grid(t, step_size)
   out = torch.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
   out[0] = y0
@@ -104,6 +106,8 @@ def _solve_fixed_host(func, y0, t, method, step_size):
         out[j] = y + ((t[j] - ta) / (tb - ta)) * (y_next - y)
       j += 1
     y = y_next
+    if on_step is not None:
+      on_step(y, i + 1)
   return out
 
 
@@ -137,7 +141,8 @@ def _combine(y0, ks, coeffs, dt):
   return acc if y0 is None else y0 + acc
 
 
-def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9, ifactor=10.0, dfactor=0.2):
+def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9, ifactor=10.0, dfactor=0.2,
+                  on_accept=None, stop_after=None):
   """Adaptive Dormand-Prince with torchdiffeq 0.2.1's controller: time and step size in float64,
   state in y0's dtype, rms error norm, FSAL, quartic-interpolated output."""
   dev = y0.device
@@ -162,7 +167,7 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
   interp = None
   for i in range(1, len(t)):
     n_steps = 0
-    while tt[i] > t_cur:
+    while tt[i] > t_cur and (stop_after is None or n_steps < stop_after):
       assert n_steps < max_num_steps, 'max_num_steps exceeded'
       assert t_cur + dt > t_cur, 'underflow in dt {}'.format(float(dt))
       dty = dt.to(y.dtype)
@@ -181,6 +186,8 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
         interp = (y, y1, y_mid, ks[0], ks[-1], dty, t_cur, t_cur + dt)
         t_prev, t_cur = t_cur, t_cur + dt
         y, f = y1, f1
+        if on_accept is not None:
+          on_accept(y, float(t_cur))
       # step-size controller
       if ratio == 0:
         dt = dt * ifactor
@@ -190,6 +197,9 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
         factor = torch.clamp(safety / r ** (1.0 / 5.0), min=lo, max=ifactor)
         dt = dt * factor
       n_steps += 1
+    if stop_after is not None and n_steps >= stop_after:   # EarlyStopDopri5.advance: the state where it stopped
+      out[i] = y
+      continue
     ya, yb, ym, fa, fb, h, ta, tb = interp
     xfrac = ((tt[i] - ta) / (tb - ta)).to(y0.dtype)
     ca = 2 * h * (fb - fa) - 8 * (yb + ya) + 16 * ym
@@ -205,7 +215,8 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
   return out
 
 
-def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2):
+def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2, on_accept=None,
+                         stop_after=None):
   """dopri5 with torchdiffeq 0.2.1's controller on the host (one scalar read per trial step) and everything
   state-sized on the device: each stage is ONE right-hand-side launch whose epilogue also forms the next stage
   input  y + sum_j (beta_ij dt) k_j  (GNPDE_STAGE_LINCOMB), the error ratio is a device reduction.  Same
@@ -245,7 +256,7 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
   out[0].copy_(y0)
   n_steps = 0
-  while T1 > t_cur:
+  while T1 > t_cur and (stop_after is None or n_steps < stop_after):
     assert t_cur + dt > t_cur, 'underflow in dt {}'.format(dt)
     dty = f32(dt)
     w = [[f32(b) * dty for b in row] for row in _DP_B]
@@ -279,12 +290,16 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
       y, y1 = y1, y
       K[0], K[6] = K[6], K[0]
       t_cur = t_next
+      if on_accept is not None:
+        on_accept(y, t_cur)
     if ratio == 0:
       dt = dt * ifactor
     else:
       lo = 1.0 if ratio < 1 else dfactor
       dt = dt * min(ifactor, max(safety / ratio ** (1.0 / 5.0), lo))
     n_steps += 1
+  if stop_after is not None and n_steps >= stop_after:   # EarlyStopDopri5.advance: the state where it stopped
+    out[1].copy_(y)
   return out
 
 

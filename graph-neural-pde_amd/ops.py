@@ -262,6 +262,60 @@ def rk_error_ratio(y0, y1, ks, coefs, atol, rtol, out, ws):
   return out
 
 
+class EarlyStopEvaluator(object):
+  """Device-side early-stopping evaluator (gnpde_decoder_t + its int32 state / trace).
+
+  weight [C, d_dec], bias [C] or None: the decoder m2; labels [N] integer; masks: three bool [N] tensors
+  (train, val, test).  After evaluations, `read()` returns python numbers (ONE device->host copy)."""
+
+  def __init__(self, weight, bias, labels, train_mask, val_mask, test_mask, max_trace=0):
+    require_hip(weight)
+    dev = weight.device
+    self.weight = weight.detach().to(torch.float32).contiguous()
+    self.bias = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    lab = labels.detach().to(dev).reshape(-1)
+    self.labels = lab.to(torch.int32).contiguous()
+    masks = [m.detach().to(dev).reshape(-1).to(torch.bool) for m in (train_mask, val_mask, test_mask)]
+    n = self.labels.numel()
+    for m in masks:
+      if m.numel() != n:
+        raise _lib.GnpdeError('early stop: mask of %d entries for %d labels' % (m.numel(), n))
+    self.split = (masks[0].to(torch.uint8) | (masks[1].to(torch.uint8) << 1) | (masks[2].to(torch.uint8) << 2)).contiguous()
+    self.sizes = [int(v) for v in torch.stack([m.sum() for m in masks]).tolist()]
+    self.n = n
+    self.state = torch.zeros(_lib.EARLY_STATE_INTS, dtype=torch.int32, device=dev)
+    self.trace = torch.zeros((max(int(max_trace), 1), 4), dtype=torch.int32, device=dev)
+    self.trace_capacity = int(max_trace)
+    self.struct = _lib.DecoderStruct(weight=ptr(self.weight), bias=ptr(self.bias), labels=ptr(self.labels),
+                                     split=ptr(self.split), n_classes=int(self.weight.shape[0]),
+                                     d_dec=int(self.weight.shape[1]))
+
+  def ref(self):
+    return ctypes.byref(self.struct)
+
+  def reset(self):
+    check(_lib.lib().gnpde_early_stop_reset(ptr(self.state), stream_of(self.state)))
+
+  def evaluate(self, y, step):
+    """Count the hits of state y [N, d] and fold them into the best-so-far (no host synchronisation)."""
+    require_hip(y)
+    if y.dtype != torch.float32 or y.dim() != 2 or y.stride(1) != 1 or y.shape[0] != self.n:
+      raise _lib.GnpdeError('early stop: state must be float32 [%d, d] with unit column stride' % self.n)
+    check(_lib.lib().gnpde_early_stop_eval(self.ref(), ptr(y), int(y.shape[1]), int(y.stride(0)), int(y.shape[0]), int(step),
+                                           ptr(self.state), ptr(self.trace) if self.trace_capacity else None,
+                                           self.trace_capacity, stream_of(y)))
+
+  def read(self):
+    """{'best': (train, val, test) accuracies, 'step': tag of the best step, 'evals': count, 'trace': [[...]]}"""
+    st = self.state.tolist()
+    acc = lambda hits: [h / s if s else float('nan') for h, s in zip(hits, self.sizes)]  # noqa: E731
+    out = {'best': acc(st[3:6]), 'best_hits': st[3:6], 'step': st[6], 'evals': st[7], 'trace': None}
+    if self.trace_capacity:
+      rows = self.trace[:min(st[7], self.trace_capacity)].tolist()
+      out['trace'] = [{'acc': acc(r[:3]), 'hits': r[:3], 'step': r[3]} for r in rows]
+    return out
+
+
 class FixedStepSolver(object):
   """gnpde_solver_t: euler / rk4 over a fixed grid, the whole loop captured in one hipGraph."""
 
@@ -278,6 +332,17 @@ class FixedStepSolver(object):
                                 self.ws.numel()))
     self.handle = handle
     self.n_rhs_evals = L.gnpde_solver_num_rhs_evals(handle)
+
+  def set_early_stop(self, evaluator):
+    """Evaluate `evaluator` (EarlyStopEvaluator or None) after every step, inside the same hipGraph."""
+    L = _lib.lib()
+    if evaluator is None:
+      check(L.gnpde_solver_set_early_stop(self.handle, None, None, None, 0))
+    else:
+      check(L.gnpde_solver_set_early_stop(self.handle, evaluator.ref(), ptr(evaluator.state),
+                                          ptr(evaluator.trace) if evaluator.trace_capacity else None,
+                                          evaluator.trace_capacity))
+    self.evaluator = evaluator
 
   def run(self, y, use_graph=True):
     """Integrate y in place."""

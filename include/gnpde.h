@@ -332,6 +332,39 @@ int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k
                          float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Early-stopping evaluator  [replaces EarlyStopRK4.evaluate / EarlyStopDopri5.evaluate + test / test_OGB + the
+ * best-validation bookkeeping, reference src/early_stop_solver.py:100-128, :156-157, :178-218]
+ *
+ * After a solver step: logits = relu(y[:, 0:d_dec]) W^T + b, prediction = first arg-max over the classes,
+ * hits counted per split; the step with the strictly largest validation count so far is remembered.  No host
+ * synchronisation: the counters live in a device `state` of GNPDE_EARLY_STATE_INTS int32:
+ *   [0..2] running train / val / test hits of the evaluation in flight (zero between evaluations)
+ *   [3..5] train / val / test hits of the best step     [6] its `step` tag     [7] evaluations done
+ * Accuracies are hits / split size (the host knows the sizes).  `trace` (nullable, [trace_capacity][4] int32)
+ * receives {train, val, test, step} of every evaluation, in order.
+ * ---------------------------------------------------------------------------------------------- */
+#define GNPDE_EARLY_STATE_INTS 8
+
+typedef struct {
+  const float* weight;    /* device [n_classes, d_dec] row-major: nn.Linear weight of the decoder m2              */
+  const float* bias;      /* device [n_classes] or NULL                                                            */
+  const int32_t* labels;  /* device [n]                                                                            */
+  const uint8_t* split;   /* device [n]: bit 0 train_mask, bit 1 val_mask, bit 2 test_mask                         */
+  int32_t n_classes;      /* <= 64                                                                                 */
+  int32_t d_dec;          /* decoder input width; < d when the state is augmented (early_stop_solver.py:180-181)   */
+} gnpde_decoder_t;
+
+int gnpde_early_stop_reset(int32_t* state, void* stream);
+int gnpde_early_stop_eval(const gnpde_decoder_t* dec, const float* y, int32_t d, int32_t ld, int32_t n, int32_t step,
+                          int32_t* state, int32_t* trace, int32_t trace_capacity, void* stream);
+
+/* Attach the evaluator to a fixed-step solver: every gnpde_solver_run then resets `state`, and evaluates the
+ * state after each step (step tag = 1-based index into the time grid), all inside the same hipGraph.  Call
+ * before the first run or between runs (drops a captured graph); dec == NULL detaches. */
+int gnpde_solver_set_early_stop(gnpde_solver_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
+                                int32_t trace_capacity);
+
 int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s);
 int gnpde_solver_destroy(gnpde_solver_t* s);
 

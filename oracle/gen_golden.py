@@ -257,6 +257,67 @@ def gen_gnn():
                               'nfe': np.int64(model.getNFE())}, model)
 
 
+def gen_early():
+  """Test-time integrators with early stopping (reference src/early_stop_solver.py), installed on a block the way
+  GNNEarly does (src/GNN_early.py:28-36): best (train, val, test, time) and the accuracies after every step."""
+  import early_stop_solver as es
+  n, d, classes = 150, 24, 5
+  ei = make_graph(n, 6, 41)
+  g = torch.Generator().manual_seed(42)
+  x = torch.randn(n, d, generator=g)
+  y = torch.randint(0, classes, (n,), generator=g)
+  role = torch.randperm(n, generator=g)
+  train_mask, val_mask, test_mask = role < 40, (role >= 40) & (role < 95), role >= 95
+  cases = {
+    'rk4_transformer': dict(block='constant', function='transformer', method='rk4', time=2.3),
+    'rk4_laplacian_arxiv': dict(block='attention', function='laplacian', method='rk4', time=1.5, step_size=0.5,
+                                dataset='ogbn-arxiv'),
+    'dopri5_laplacian': dict(block='attention', function='laplacian', method='dopri5', time=2.0, tol_scale=800.0),
+    'dopri5_transformer_cut': dict(block='constant', function='transformer', method='dopri5', time=1.5,
+                                   tol_scale=50.0, max_test_steps=6),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, 'earlystopxT': 3, 'max_test_steps': 100, **over}
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt}[opt['function']]
+    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
+    arxiv = opt['dataset'] == 'ogbn-arxiv'
+    data = Data(x=x, edge_index=ei, y=y.view(-1, 1) if arxiv else y, train_mask=train_mask, val_mask=val_mask,
+                test_mask=test_mask)
+    block = bcls(fcls, [], opt, data, torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+    randomise(block, 600 + i)
+    gi = torch.Generator().manual_seed(650 + i)
+    m2_w = torch.randn(classes, d, generator=gi) * 0.8
+    m2_b = torch.randn(classes, generator=gi) * 0.1
+    integ = es.EarlyStopInt(opt['time'], opt, torch.device('cpu'))
+    integ.data, integ.m2_weight, integ.m2_bias = data, m2_w, m2_b
+    block.test_integrator = integ
+    log = []
+    cls = es.SOLVERS[opt['method']]
+    orig = cls.evaluate
+
+    def recorder(self, *a, _orig=orig, _log=log, _m=opt['method']):
+      r = _orig(self, *a)
+      t1 = float(self.rk_state.t1) if _m == 'dopri5' else float(a[2])
+      _log.append([t1] + [float(v) for v in r])
+      return r
+
+    cls.evaluate = recorder
+    try:
+      block.eval()
+      block.set_x0(x)
+      with torch.no_grad():
+        z = block(x)
+    finally:
+      cls.evaluate = orig
+    sol = integ.solver
+    best = np.array([sol.best_train, sol.best_val, sol.best_test, sol.best_time], dtype=np.float64)
+    save('early_' + name, opt, {'edge_index': ei, 'x': x, 'z': z, 'labels': y, 'train_mask': train_mask,
+                                'val_mask': val_mask, 'test_mask': test_mask, 'm2_weight': m2_w, 'm2_bias': m2_b,
+                                'best': best, 'steps': np.array(log, dtype=np.float64),
+                                'nfe': np.int64(block.odefunc.nfe)}, block)
+    print('    best (train, val, test, time) =', best.round(4).tolist(), ' evaluations:', len(log))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   torch.manual_seed(0)
@@ -264,3 +325,4 @@ if __name__ == '__main__':
   gen_funcs()
   gen_blocks()
   gen_gnn()
+  gen_early()

@@ -242,6 +242,43 @@ def odeint_fixed(func, y0, T, step_size=1.0, method='rk4'):
 
 
 # ------------------------------------------------------------------------------------------------
+# early-stopping evaluation of the test-time integrator (early_stop_solver.py:131-225)
+# ------------------------------------------------------------------------------------------------
+def early_stop_accuracies(z, m2_weight, m2_bias, labels, masks):
+  """EarlyStopRK4.evaluate + test (:178-218, :162-168): relu -> linear -> arg-max -> accuracy per mask.
+  (The ogbn-arxiv branch inserts a log_softmax, which leaves the arg-max unchanged, and scores with
+  ogb's Evaluator, the same ratio.)  The state is cut to the decoder's width when augmented (:180-181)."""
+  if m2_weight.shape[1] != z.shape[1]:
+    z = z[:, :m2_weight.shape[1]]
+  logits = torch.nn.functional.linear(torch.relu(z), m2_weight, m2_bias)
+  pred = logits.max(1)[1]
+  labels = labels.reshape(-1)
+  return [float(pred[m].eq(labels[m]).sum().item()) / float(m.sum().item()) for m in masks]
+
+
+def odeint_rk4_early_stop(func, y0, T, step_size, m2_weight, m2_bias, labels, masks):
+  """EarlyStopRK4.integrate (:163-186) over [0, T]: returns (y(T), best = [train, val, test, time] of the step
+  with the strictly best validation accuracy (initial best_val = 0), list of [t1, train, val, test] per step)."""
+  grid = time_grid(T, step_size, y0.dtype)
+  y = y0
+  third = 1 / 3
+  best = [0.0, 0.0, 0.0, 0.0]
+  steps = []
+  for t0, t1 in zip(grid[:-1], grid[1:]):
+    dt = t1 - t0
+    k1 = func(t0, y)
+    k2 = func(t0 + dt * third, y + dt * k1 * third)
+    k3 = func(t0 + dt * 2 * third, y + dt * (k2 - k1 * third))
+    k4 = func(t1, y + dt * (k1 - k2 + k3))
+    y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+    acc = early_stop_accuracies(y, m2_weight, m2_bias, labels, masks)
+    if acc[1] > best[1]:
+      best = acc + [float(t1)]
+    steps.append([float(t1)] + acc)
+  return y, best, steps
+
+
+# ------------------------------------------------------------------------------------------------
 # parity metric (SURVEY.md section 8c)
 # ------------------------------------------------------------------------------------------------
 def parity_error(a, b):

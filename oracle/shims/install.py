@@ -236,6 +236,32 @@ class Data(object):
         self.__dict__[k] = v.to(device)
     return self
 
+  def __call__(self, *keys):
+    """PyG Data.__call__: iterate (key, value) over the named attributes that are set
+    (used by the reference's EarlyStopRK4.test, early_stop_solver.py:162-168)."""
+    for k in keys:
+      v = getattr(self, k, None)
+      if v is not None:
+        yield k, v
+
+
+class Evaluator(object):
+  """ogb.nodeproppred.Evaluator for the accuracy datasets: eval({'y_true','y_pred'}) -> {'acc': mean over the
+  rows of (y_true == y_pred)}, both [n, 1] (ogb 1.3 evaluate.py, _eval_acc)."""
+
+  def __init__(self, name=None):
+    self.name = name
+
+  def eval(self, input_dict):
+    y_true, y_pred = input_dict['y_true'], input_dict['y_pred']
+    y_true = y_true.detach().cpu().numpy() if torch.is_tensor(y_true) else y_true
+    y_pred = y_pred.detach().cpu().numpy() if torch.is_tensor(y_pred) else y_pred
+    accs = []
+    for i in range(y_true.shape[1]):
+      ok = y_true[:, i] == y_pred[:, i]
+      accs.append(float(ok.sum()) / len(ok))
+    return {'acc': sum(accs) / len(accs)}
+
 
 # ----------------------------------------------------------------------------------------------
 # torchdiffeq 0.2.1 (REAL: odeint with euler / rk4 / dopri5; fixed-grid pieces used by the
@@ -245,14 +271,14 @@ _one_third = 1 / 3
 _two_thirds = 2 / 3
 
 
-def rk4_alt_step_func(func, t0, dt, t1, y0, f0=None, perturb=False):
-  """3/8-rule step, the `rk4` of torchdiffeq 0.2.1 (rk_common.py)."""
-  k1 = f0
+def rk4_alt_step_func(func, t, dt, y, k1=None, perturb=False):
+  """3/8-rule step, the `rk4` of torchdiffeq 0.2.1 (rk_common.py; 0.2.1 signature -- the reference's
+  early_stop_solver.py:150-155 picks the argument list from torchdiffeq.__version__)."""
   if k1 is None:
-    k1 = func(t0, y0)
-  k2 = func(t0 + dt * _one_third, y0 + dt * k1 * _one_third)
-  k3 = func(t0 + dt * _two_thirds, y0 + dt * (k2 - k1 * _one_third))
-  k4 = func(t1, y0 + dt * (k1 - k2 + k3))
+    k1 = func(t, y)
+  k2 = func(t + dt * _one_third, y + dt * k1 * _one_third)
+  k3 = func(t + dt * _two_thirds, y + dt * (k2 - k1 * _one_third))
+  k4 = func(t + dt, y + dt * (k1 - k2 + k3))
   return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
 
 
@@ -319,7 +345,7 @@ class RK4(FixedGridODESolver):
   order = 4
 
   def _step_func(self, func, t0, dt, t1, y0):
-    return rk4_alt_step_func(func, t0, dt, t1, y0)
+    return rk4_alt_step_func(func, t0, dt, y0)
 
 
 class _Tableau(object):
@@ -583,7 +609,7 @@ def install():
        rk4_alt_step_func=rk4_alt_step_func, _runge_kutta_step=_runge_kutta_step)
 
   _mod('ogb', inert=True)
-  _mod('ogb.nodeproppred', inert=True)
+  _mod('ogb.nodeproppred', inert=True, Evaluator=Evaluator)
   _mod('pykeops', inert=True)
   _mod('pykeops.torch', inert=True)
   _mod('numba', inert=True, jit=lambda *a, **k: (lambda f: f))

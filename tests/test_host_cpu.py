@@ -33,6 +33,7 @@ def test_structs_match_header_layout():
   assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 3 * 8
   assert ctypes.sizeof(_lib.EpilogueStruct) == 3 * 8 + 4 + 4 + 4 + 4 + 6 * 8 + 8 + 7 * 8 + 8 * 4
   assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8
+  assert ctypes.sizeof(_lib.DecoderStruct) == 4 * 8 + 2 * 4
 
 
 @pytest.mark.parametrize('seed', [0, 1])
@@ -195,6 +196,31 @@ def test_cpu_tensors_fail_loudly():
   with torch.no_grad(), pytest.raises(G.GnpdeError):
     func(0.0, x)
   assert not os.path.exists(os.path.join(ROOT, 'graph-neural-pde_amd', 'fallback.py'))
+
+
+def test_early_stop_integrator_surface():
+  """EarlyStopInt keeps the reference's constructor, time span and the fields GNNEarly writes / run_GNN reads
+  (reference early_stop_solver.py:234-245, GNN_early.py:28-40, run_GNN.py:266-271); no CPU evaluation path."""
+  fx = Fixture('early_rk4_transformer')
+  integ = G.EarlyStopInt(fx.opt['time'], fx.opt, torch.device('cpu'))
+  assert integ.solver is None and integ.data is None and integ.m2_weight is None and integ.m2_bias is None
+  assert integ.max_test_steps == fx.opt['max_test_steps']
+  assert integ.t.dtype == torch.float32 and integ.t.tolist() == pytest.approx([0.0, 3 * fx.opt['time']])
+  x = fx.t('x')
+  with pytest.raises(G.GnpdeError):           # data / decoder never assigned
+    integ(lambda t, y: y, x, integ.t, method='rk4', options={'step_size': 1.0})
+  data = Data(x, fx.t('edge_index'))
+  data.y = fx.t('labels')
+  for k in ('train_mask', 'val_mask', 'test_mask'):
+    setattr(data, k, fx.t(k).bool())
+  integ.data, integ.m2_weight, integ.m2_bias = data, fx.t('m2_weight'), fx.t('m2_bias')
+  with pytest.raises(G.GnpdeError):           # host tensors: refused, not computed on the CPU
+    integ(lambda t, y: y, x, integ.t, method='rk4', options={'step_size': 1.0})
+  bad = G.EarlyStopInt(1.0, dict(fx.opt, method='euler'), torch.device('cpu'))
+  with pytest.raises(AssertionError):
+    bad(lambda t, y: y, x, bad.t, method='euler', options={'step_size': 1.0})
+  sys_path = os.path.join(ROOT, 'graph-neural-pde_amd', 'dropin')
+  assert os.path.exists(os.path.join(sys_path, 'early_stop_solver.py'))
 
 
 def test_product_does_not_import_oracle():

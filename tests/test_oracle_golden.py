@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/restate.py) against the golden vectors recorded from the reference's
 own code, and against the known-answer facts of the reference's unit tests."""
+import numpy as np
 import pytest
 import torch
 
@@ -143,6 +144,18 @@ def test_block_fixed_step(name):
   fx = Fixture(name)
   z = R.odeint_fixed(_block_rhs(fx), fx.t('x'), fx.opt['time'], fx.opt['step_size'], fx.opt['method'])
   assert_parity(z, fx.t('z'), TIGHT, name)
+
+
+@pytest.mark.parametrize('name', [n for n in fixtures('early_') if 'rk4' in n])
+def test_early_stop_rk4(name):
+  """Oracle restatement of EarlyStopRK4 against the reference's own run (best step and every step's accuracies)."""
+  fx = Fixture(name)
+  masks = [fx.t(k).bool() for k in ('train_mask', 'val_mask', 'test_mask')]
+  z, best, steps = R.odeint_rk4_early_stop(_block_rhs(fx), fx.t('x'), fx.opt['earlystopxT'] * fx.opt['time'],
+                                           fx.opt['step_size'], fx.t('m2_weight'), fx.t('m2_bias'), fx.t('labels'), masks)
+  assert_parity(z, fx.t('z'), TIGHT, name)
+  assert np.allclose(np.array(steps), fx.arr['steps'], rtol=0, atol=1e-6)
+  assert np.allclose(np.array(best), fx.arr['best'], rtol=0, atol=1e-6)
 
 
 def test_time_grid_short_last_step():
