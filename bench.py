@@ -46,6 +46,9 @@ def parse():
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
   ap.add_argument('--square-plus', action='store_true', help='squareplus normalisation (Cora best_params)')
+  ap.add_argument('--early-stop', action='store_true',
+                  help='run the test-time early-stopping evaluator (40-class decoder, arg-max, split accuracies) after '
+                       'every step inside the hipGraph, as the reference does at evaluation time (not the headline metric)')
   return ap.parse_args()
 
 
@@ -201,6 +204,21 @@ def main():
 
   main_block = make_block(G, opt, ei, n, x, dev, float(K), args.seed)
   main_block.set_x0(x)
+  early = None
+  if args.early_stop:
+    gen = torch.Generator().manual_seed(args.seed + 1)
+    role = torch.rand(n, generator=gen)
+
+    class _Split(object):
+      pass
+    split = _Split()
+    split.y = torch.randint(0, 40, (n,), generator=gen).to(dev)
+    split.train_mask, split.val_mask, split.test_mask = (role < 0.54).to(dev), ((role >= 0.54) & (role < 0.71)).to(dev), (role >= 0.71).to(dev)
+    early = G.EarlyStopInt(float(K), dict(opt, earlystopxT=1, max_test_steps=10 ** 6, dataset='ogbn-arxiv'), dev)
+    early.data = split
+    early.m2_weight = (torch.randn(40, d, generator=gen) / d ** 0.5).to(dev)
+    early.m2_bias = torch.zeros(40, device=dev)
+    main_block.test_integrator = early
   with torch.no_grad():
     if W > 0:
       warm_block = make_block(G, opt, ei, n, x, dev, float(W), args.seed)
@@ -251,6 +269,7 @@ def main():
                'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
                'attention_norm_idx': args.norm_idx, 'square_plus': args.square_plus,
+               'early_stop_evaluator': bool(args.early_stop),
                'long_rows': graph.n_long_rows, 'algorithmic_bytes_per_rhs_eval': bytes_eval,
                'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
     'roofline': {'kernel': kname, 'bound': 'hbm',
@@ -259,6 +278,10 @@ def main():
                  'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2),
                  'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d)},
   }
+  if early is not None:
+    sol = early.solver
+    out['early_stop'] = {'best_val': sol.best_val, 'best_test': sol.best_test, 'best_time': sol.best_time,
+                         'classes': 40, 'evaluations': K}
   if not args.no_cpu_baseline:
     t_eval, ref = cpu_baseline(main_block, x_cpu, args.cpu_evals)
     with torch.no_grad():

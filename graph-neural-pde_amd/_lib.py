@@ -68,7 +68,7 @@ class DecoderStruct(ctypes.Structure):
               ('n_classes', ctypes.c_int32), ('d_dec', ctypes.c_int32)]
 
 
-EARLY_STATE_INTS = 8
+EARLY_STATE_INTS = 8 + 3 * 2048
 
 # name -> (restype, argtypes); every symbol include/gnpde.h declares
 PROTOTYPES = {

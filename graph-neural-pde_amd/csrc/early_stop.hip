@@ -8,10 +8,11 @@
 //   decode_count_kernel   logits = relu(y[:, :d_dec]) W^T + b on the fp32 matrix cores (16 nodes x 16 classes per
 //                         v_mfma_f32_16x16x4_f32 tile, same operand scheme as linear.hip), arg-max over the
 //                         classes (first maximum wins, like torch.max), compared with the label and counted per
-//                         split with integer atomics (order independent, so deterministic);
-//   early_stop_update     one thread: strict "val > best_val" (early_stop_solver.py:156-157 / :79-80) on the
-//                         integer counts -- the denominators are equal, so this is the reference's float
-//                         comparison without the division -- then clears the running counters.
+//                         split; one partial count per block, no atomics (several thousand same-address atomics
+//                         serialise in one L2 channel: 180 us at the ogbn-arxiv shape, measured);
+//   early_stop_update     one block: sums the partial counts, then strict "val > best_val"
+//                         (early_stop_solver.py:156-157 / :79-80) on the integer counts -- the denominators are
+//                         equal, so this is the reference's float comparison without the division.
 //
 // The ogbn-arxiv branch of the reference applies log_softmax before the arg-max (:192-193); it does not change
 // the arg-max and the loss computed next to it is discarded (:196-198), so neither is evaluated here.
@@ -21,6 +22,8 @@ namespace gnpde {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kStateHead = 8;                                     // result fields; per-block partial counts follow
+constexpr int kMaxParts = (GNPDE_EARLY_STATE_INTS - kStateHead) / 3;
 
 struct DecArgs {
   const float* __restrict__ y;
@@ -37,75 +40,107 @@ struct DecArgs {
 template <int CT>
 __global__ __launch_bounds__(kBlock) void decode_count_kernel(const DecArgs a) {
   extern __shared__ float w_lds[];   // [16 * CT][dpad], zero padded in both directions
-  for (int idx = threadIdx.x; idx < 16 * CT * a.dpad; idx += kBlock) {
-    const int row = idx / a.dpad, k = idx - row * a.dpad;
-    w_lds[idx] = (row < a.c && k < a.d) ? a.weight[static_cast<size_t>(row) * a.d + k] : 0.f;
-  }
+  for (int row = threadIdx.x >> 6; row < 16 * CT; row += kWavesPerBlock)
+    for (int k = threadIdx.x & (kWave - 1); k < a.dpad; k += kWave)
+      w_lds[row * a.dpad + k] = (row < a.c && k < a.d) ? a.weight[static_cast<size_t>(row) * a.d + k] : 0.f;
   __syncthreads();
 
+  constexpr int KB = 8;              // 16-column blocks per batch: their loads are issued together (128 columns)
   const int lane = threadIdx.x & (kWave - 1);
   const int j = lane & 15, kq = lane >> 4;
   const int n_tiles = (a.n + 15) / 16;
+  const int n_batch = (a.d16 + 16 * KB - 1) / (16 * KB);
+  const int stride = gridDim.x * kWavesPerBlock;
   int hit_train = 0, hit_val = 0, hit_test = 0;
 
-  for (int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
-    const int node = tile * 16 + j;                  // A operand row of this lane
+  // batch `bt` of tile `tile`: this lane's 8 float4 of the A operand (row tile * 16 + j)
+  auto load_batch = [&](float4 (&av)[KB], int tile, int bt) {
+    const int node = tile * 16 + j;
     const bool live = node < a.n;
     const float* yrow = a.y + static_cast<size_t>(live ? node : 0) * a.ld;
-    f32x4 acc[CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < a.d16; kb += 16) {
-      const int k = kb + 4 * kq;
-      float av[4];
-      if (a.vec && k + 3 < a.d) {
-        const float4 v = *reinterpret_cast<const float4*>(yrow + k);
-        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = (k + i < a.d) ? yrow[k + i] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = live ? fmaxf(av[i], 0.f) : 0.f;     // F.relu
-      float4 bv[CT];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) bv[t] = *reinterpret_cast<const float4*>(w_lds + (t * 16 + j) * a.dpad + k);
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[t].w, acc[t], 0, 0, 0);
-      }
-    }
-    // C/D layout: class = t * 16 + j, node = tile * 16 + 4 * kq + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float best = -INFINITY;
-      int arg = 0x7fffffff;
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        const int cls = t * 16 + j;
-        if (cls < a.c) {
-          const float v = acc[t][r] + (a.bias ? a.bias[cls] : 0.f);
-          if (v > best || arg == 0x7fffffff) { best = v; arg = cls; }
+    for (int u = 0; u < KB; ++u) {
+      const int k = (bt * KB + u) * 16 + 4 * kq;
+      av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && k < a.d) {
+        if (a.vec && k + 3 < a.d) {
+          av[u] = *reinterpret_cast<const float4*>(yrow + k);
+        } else {
+          av[u].x = yrow[k];
+          if (k + 1 < a.d) av[u].y = yrow[k + 1];
+          if (k + 2 < a.d) av[u].z = yrow[k + 2];
+          if (k + 3 < a.d) av[u].w = yrow[k + 3];
         }
       }
+    }
+  };
+
+  int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  int bt = 0;
+  float4 cur[KB], nxt[KB];
+  if (tile < n_tiles) load_batch(cur, tile, 0);
+  f32x4 acc[CT];
+  while (tile < n_tiles) {
+    // software pipeline: the next batch (same tile, or the wave's next tile) is in flight during the MFMAs
+    int ntile = tile, nbt = bt + 1;
+    if (nbt == n_batch) { nbt = 0; ntile = tile + stride; }
+    if (ntile < n_tiles) load_batch(nxt, ntile, nbt);
+    if (bt == 0) {
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        const float ov = __shfl_xor(best, off, kWave);
-        const int oa = __shfl_xor(arg, off, kWave);
-        if (oa != 0x7fffffff && (arg == 0x7fffffff || ov > best || (ov == best && oa < arg))) { best = ov; arg = oa; }
-      }
-      const int vnode = tile * 16 + 4 * kq + r;
-      if (j == r && vnode < a.n) {
-        const int ok = (arg == a.labels[vnode]) ? 1 : 0;
-        const unsigned sp = a.split[vnode];
-        hit_train += ok & static_cast<int>(sp & 1u);
-        hit_val += ok & static_cast<int>((sp >> 1) & 1u);
-        hit_test += ok & static_cast<int>((sp >> 2) & 1u);
+      for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int kb = (bt * KB + u) * 16;
+      if (kb < a.d16) {                                                  // wave-uniform
+        const int k = kb + 4 * kq;
+        const float x[4] = {fmaxf(cur[u].x, 0.f), fmaxf(cur[u].y, 0.f), fmaxf(cur[u].z, 0.f), fmaxf(cur[u].w, 0.f)};  // F.relu
+        float bv[CT][4];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w_lds + (t * 16 + j) * a.dpad + k);
+          bv[t][0] = w4.x; bv[t][1] = w4.y; bv[t][2] = w4.z; bv[t][3] = w4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i], bv[t][i], acc[t], 0, 0, 0);
       }
     }
+    if (bt == n_batch - 1) {
+      // C/D layout: class = t * 16 + j, node = tile * 16 + 4 * kq + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          const int cls = t * 16 + j;
+          if (cls < a.c) {
+            const float v = acc[t][r] + (a.bias ? a.bias[cls] : 0.f);
+            if (v > best || arg == 0x7fffffff) { best = v; arg = cls; }
+          }
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          const float ov = __shfl_xor(best, off, kWave);
+          const int oa = __shfl_xor(arg, off, kWave);
+          if (oa != 0x7fffffff && (arg == 0x7fffffff || ov > best || (ov == best && oa < arg))) { best = ov; arg = oa; }
+        }
+        const int vnode = tile * 16 + 4 * kq + r;
+        if (j == r && vnode < a.n) {
+          const int ok = (arg == a.labels[vnode]) ? 1 : 0;
+          const unsigned sp = a.split[vnode];
+          hit_train += ok & static_cast<int>(sp & 1u);
+          hit_val += ok & static_cast<int>((sp >> 1) & 1u);
+          hit_test += ok & static_cast<int>((sp >> 2) & 1u);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) cur[u] = nxt[u];
+    tile = ntile;
+    bt = nbt;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -113,16 +148,37 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const DecArgs a) {
     hit_val += __shfl_xor(hit_val, off, kWave);
     hit_test += __shfl_xor(hit_test, off, kWave);
   }
+  __shared__ int red[kWavesPerBlock][3];
   if (lane == 0) {
-    if (hit_train) atomicAdd(a.state + 0, hit_train);
-    if (hit_val) atomicAdd(a.state + 1, hit_val);
-    if (hit_test) atomicAdd(a.state + 2, hit_test);
+    red[threadIdx.x >> 6][0] = hit_train; red[threadIdx.x >> 6][1] = hit_val; red[threadIdx.x >> 6][2] = hit_test;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int* part = a.state + kStateHead + 3 * blockIdx.x;
+    part[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
-__global__ void early_stop_update_kernel(int* __restrict__ state, int step, int* __restrict__ trace, int trace_capacity) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int tr = state[0], va = state[1], te = state[2];
+__global__ __launch_bounds__(kBlock) void early_stop_update_kernel(int* __restrict__ state, int n_parts, int step,
+                                                                   int* __restrict__ trace, int trace_capacity) {
+  __shared__ int red[kBlock][3];
+  int s0 = 0, s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < n_parts; i += kBlock) {
+    const int* part = state + kStateHead + 3 * i;
+    s0 += part[0]; s1 += part[1]; s2 += part[2];
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
+  __syncthreads();
+  for (int off = kBlock / 2; off >= 1; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) {
+      red[threadIdx.x][0] += red[threadIdx.x + off][0];
+      red[threadIdx.x][1] += red[threadIdx.x + off][1];
+      red[threadIdx.x][2] += red[threadIdx.x + off][2];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const int tr = red[0][0], va = red[0][1], te = red[0][2];
   const int slot = state[7];
   if (trace != nullptr && slot < trace_capacity) {
     trace[4 * slot + 0] = tr; trace[4 * slot + 1] = va; trace[4 * slot + 2] = te; trace[4 * slot + 3] = step;
@@ -130,21 +186,26 @@ __global__ void early_stop_update_kernel(int* __restrict__ state, int step, int*
   if (va > state[4]) {
     state[3] = tr; state[4] = va; state[5] = te; state[6] = step;
   }
-  state[0] = 0; state[1] = 0; state[2] = 0;
+  state[0] = tr; state[1] = va; state[2] = te;    // counts of the latest evaluation
   state[7] = slot + 1;
 }
 
 template <int CT>
-int launch_decode(const DecArgs& a, hipStream_t st) {
+int launch_decode(const DecArgs& a, hipStream_t st, int* n_parts) {
   const size_t lds = static_cast<size_t>(16) * CT * a.dpad * sizeof(float);
   GNPDE_CHECK_ARG(lds <= 160 * 1024, GNPDE_ESHAPE, "early_stop_eval: decoder %d x %d does not fit the LDS", a.c, a.d);
   if (lds > 48 * 1024) {
     GNPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_count_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds)));
   }
+  // persistent waves with an equal number of tiles each (the decoder is staged into the LDS once per block)
   const int n_tiles = (a.n + 15) / 16;
-  int grid = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (grid > 1024) grid = 1024;     // persistent beyond that: the decoder is staged into the LDS once per block
+  const int max_waves = 256 * 3 * kWavesPerBlock;
+  const int per_wave = (n_tiles + max_waves - 1) / max_waves;
+  const int waves = (n_tiles + per_wave - 1) / per_wave;
+  int grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > kMaxParts) grid = kMaxParts;
+  *n_parts = grid;
   hipLaunchKernelGGL((decode_count_kernel<CT>), dim3(grid), dim3(kBlock), lds, st, a);
   GNPDE_LAUNCH_CHECK();
   return 0;
@@ -154,6 +215,7 @@ int launch_decode(const DecArgs& a, hipStream_t st) {
 
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,
                             int trace_capacity, hipStream_t st) {
+  int n_parts = 0;
   if (n > 0) {
     DecArgs a;
     a.y = y; a.weight = dec.weight; a.bias = dec.bias; a.labels = dec.labels; a.split = dec.split; a.state = state;
@@ -164,17 +226,17 @@ int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, 
     int rc;
     const int ct = (dec.n_classes + 15) / 16;
     switch (ct) {
-      case 1: rc = launch_decode<1>(a, st); break;
-      case 2: rc = launch_decode<2>(a, st); break;
-      case 3: rc = launch_decode<3>(a, st); break;
-      case 4: rc = launch_decode<4>(a, st); break;
+      case 1: rc = launch_decode<1>(a, st, &n_parts); break;
+      case 2: rc = launch_decode<2>(a, st, &n_parts); break;
+      case 3: rc = launch_decode<3>(a, st, &n_parts); break;
+      case 4: rc = launch_decode<4>(a, st, &n_parts); break;
       default:
         set_error("early_stop_eval: %d classes (at most 64 supported)", dec.n_classes);
         return GNPDE_ESHAPE;
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(early_stop_update_kernel, dim3(1), dim3(1), 0, st, state, step, trace, trace_capacity);
+  hipLaunchKernelGGL(early_stop_update_kernel, dim3(1), dim3(kBlock), 0, st, state, n_parts, step, trace, trace_capacity);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -194,7 +256,7 @@ using namespace gnpde;
 
 extern "C" int gnpde_early_stop_reset(int32_t* state, void* stream) {
   GNPDE_CHECK_ARG(state != nullptr, GNPDE_EINVAL, "early_stop_reset: state is null");
-  GNPDE_HIP(hipMemsetAsync(state, 0, GNPDE_EARLY_STATE_INTS * sizeof(int32_t), static_cast<hipStream_t>(stream)));
+  GNPDE_HIP(hipMemsetAsync(state, 0, kStateHead * sizeof(int32_t), static_cast<hipStream_t>(stream)));
   return 0;
 }
 

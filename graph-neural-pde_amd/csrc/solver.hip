@@ -189,7 +189,7 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
     return enqueue_early_stop_eval(s->dec, state, r.ld, r.graph->n, step, s->early_state,
                                    s->early_trace, s->early_trace_capacity, st);
   };
-  if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, GNPDE_EARLY_STATE_INTS * sizeof(int32_t), st));
+  if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, 8 * sizeof(int32_t), st));
   if (s->method == GNPDE_METHOD_EULER) {
     float* cur = y;
     float* nxt = ua;

@@ -307,7 +307,7 @@ class EarlyStopEvaluator(object):
 
   def read(self):
     """{'best': (train, val, test) accuracies, 'step': tag of the best step, 'evals': count, 'trace': [[...]]}"""
-    st = self.state.tolist()
+    st = self.state[:8].tolist()
     acc = lambda hits: [h / s if s else float('nan') for h, s in zip(hits, self.sizes)]  # noqa: E731
     out = {'best': acc(st[3:6]), 'best_hits': st[3:6], 'step': st[6], 'evals': st[7], 'trace': None}
     if self.trace_capacity:

@@ -339,12 +339,13 @@ int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k
  * After a solver step: logits = relu(y[:, 0:d_dec]) W^T + b, prediction = first arg-max over the classes,
  * hits counted per split; the step with the strictly largest validation count so far is remembered.  No host
  * synchronisation: the counters live in a device `state` of GNPDE_EARLY_STATE_INTS int32:
- *   [0..2] running train / val / test hits of the evaluation in flight (zero between evaluations)
+ *   [0..2] train / val / test hits of the latest evaluation
  *   [3..5] train / val / test hits of the best step     [6] its `step` tag     [7] evaluations done
+ *   [8..]  scratch: per-block partial counts (summed in a fixed order, no atomics)
  * Accuracies are hits / split size (the host knows the sizes).  `trace` (nullable, [trace_capacity][4] int32)
  * receives {train, val, test, step} of every evaluation, in order.
  * ---------------------------------------------------------------------------------------------- */
-#define GNPDE_EARLY_STATE_INTS 8
+#define GNPDE_EARLY_STATE_INTS (8 + 3 * 2048)
 
 typedef struct {
   const float* weight;    /* device [n_classes, d_dec] row-major: nn.Linear weight of the decoder m2              */
