@@ -125,8 +125,28 @@ _DP_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -26
            187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
 
 
+_DP_SOL = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0)
+
+# embedded pairs of torchdiffeq 0.2.1 (dopri5.py, adaptive_heun.py): stage nodes, stage weights, solution and error
+# weights, mid-point weights of the quartic interpolant, order; `fsal`: the last stage input is the solution
+_TABLEAUS = {
+  'dopri5': dict(alpha=_DP_A, beta=_DP_B, c_sol=_DP_SOL, c_err=_DP_E, c_mid=_DP_MID, order=5, fsal=True),
+  'adaptive_heun': dict(alpha=(1.0,), beta=((1.0,),), c_sol=(0.5, 0.5), c_err=(0.5, -0.5), c_mid=(0.5, 0.0), order=2,
+                        fsal=False),
+}
+
+
 def _rms(v):
   return v.pow(2).mean().sqrt()
+
+
+def _mixed_norm(shapes):
+  """torchdiffeq's default norm of a tuple state (misc.py _mixed_linf_rms_norm): the largest component rms."""
+  sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+
+  def norm(v):
+    return max(_rms(part) for part in torch.split(v, sizes))
+  return norm
 
 
 def _combine(y0, ks, coeffs, dt):
@@ -142,9 +162,14 @@ def _combine(y0, ks, coeffs, dt):
 
 
 def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9, ifactor=10.0, dfactor=0.2,
-                  on_accept=None, stop_after=None):
-  """Adaptive Dormand-Prince with torchdiffeq 0.2.1's controller: time and step size in float64,
-  state in y0's dtype, rms error norm, FSAL, quartic-interpolated output."""
+                  on_accept=None, stop_after=None, tableau='dopri5', norm=None):
+  """Adaptive embedded Runge-Kutta (Dormand-Prince 5(4) by default, `adaptive_heun` 2(1)) with torchdiffeq 0.2.1's
+  controller: time and step size in float64, state in y0's dtype, rms error norm (or `norm`), the last stage
+  derivative reused as the next step's first (rk_common.py: f1 = k[..., -1], also for the non-FSAL Heun pair),
+  quartic-interpolated output."""
+  tb = _TABLEAUS[tableau]
+  order = tb['order']
+  nrm = norm if norm is not None else _rms
   dev = y0.device
   f64 = dict(dtype=torch.float64, device=dev)
   rtol_t, atol_t = torch.as_tensor(rtol, **f64), torch.as_tensor(atol, **f64)
@@ -154,14 +179,14 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
   f0 = func(tt[0], y0)
   # initial step (Hairer, Norsett & Wanner), order p = 4
   scale = atol_t + torch.abs(y0) * rtol_t
-  d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+  d0, d1 = nrm(y0 / scale), nrm(f0 / scale)
   h0 = torch.tensor(1e-6, dtype=y0.dtype, device=dev) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
   f1 = func(tt[0].to(y0.dtype) + h0, y0 + h0 * f0)
-  d2 = _rms((f1 - f0) / scale) / h0
+  d2 = nrm((f1 - f0) / scale) / h0
   if d1 <= 1e-15 and d2 <= 1e-15:
     h1 = torch.max(torch.tensor(1e-6, dtype=y0.dtype, device=dev), h0 * 1e-3)
   else:
-    h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    h1 = (0.01 / max(d1, d2)) ** (1.0 / order)
   dt = torch.min(100 * h0, h1).to(torch.float64)
   y, f, t_prev, t_cur = y0, f0, tt[0], tt[0]
   interp = None
@@ -173,16 +198,17 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
       dty = dt.to(y.dtype)
       ks = [f]
       yi = None
-      for a_i, b_i in zip(_DP_A, _DP_B):
+      for a_i, b_i in zip(tb['alpha'], tb['beta']):
         yi = _combine(y, ks, b_i, dty)
         ks.append(func(t_cur + dt if a_i == 1.0 else t_cur + a_i * dt, yi))
-      y1, f1 = yi, ks[-1]
-      err = _combine(None, ks, _DP_E, dty)
+      y1 = yi if tb['fsal'] else _combine(y, ks, tb['c_sol'], dty)
+      f1 = ks[-1]
+      err = _combine(None, ks, tb['c_err'], dty)
       tol = atol_t + rtol_t * torch.max(y.abs(), y1.abs())
-      ratio = _rms(err / tol)
+      ratio = nrm(err / tol)
       accept = bool(ratio <= 1)
       if accept:
-        y_mid = _combine(y, ks, _DP_MID, dty)
+        y_mid = _combine(y, ks, tb['c_mid'], dty)
         interp = (y, y1, y_mid, ks[0], ks[-1], dty, t_cur, t_cur + dt)
         t_prev, t_cur = t_cur, t_cur + dt
         y, f = y1, f1
@@ -194,7 +220,7 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
       else:
         lo = 1.0 if ratio < 1 else dfactor
         r = ratio.to(torch.float64)
-        factor = torch.clamp(safety / r ** (1.0 / 5.0), min=lo, max=ifactor)
+        factor = torch.clamp(safety / r ** (1.0 / order), min=lo, max=ifactor)
         dt = dt * factor
       n_steps += 1
     if stop_after is not None and n_steps >= stop_after:   # EarlyStopDopri5.advance: the state where it stopped
@@ -318,11 +344,94 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
   if method == 'dopri5':
     if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
       return _solve_dopri5_native(func, y0, t, rtol, atol)
-    return _solve_dopri5(func, y0, t, rtol, atol)
-  raise ValueError('unsupported method %r (euler, rk4, dopri5)' % (method,))
+    return _solve_dopri5(func, y0, t, rtol, atol, norm=options.get('norm'))
+  if method == 'adaptive_heun':
+    return _solve_dopri5(func, y0, t, rtol, atol, tableau='adaptive_heun', norm=options.get('norm'))
+  raise ValueError('unsupported method %r (euler, rk4, dopri5, adaptive_heun)' % (method,))
 
 
-def odeint_adjoint(func, y0, t, **kw):
-  """Forward values of the adjoint integrator equal those of `odeint`; the adjoint backward pass is
-  SURVEY.md section 8f row 1 (next)."""
-  return odeint(func, y0, t, **kw)
+# --------------------------------------------------------------------------------------------------
+# adjoint sensitivity (torchdiffeq 0.2.1 adjoint.py, as selected by opt['adjoint'], reference
+# src/base_classes.py:44-47, src/block_constant.py:45-55)
+# --------------------------------------------------------------------------------------------------
+def _flatten(parts):
+  return torch.cat([p.reshape(-1) for p in parts])
+
+
+def _unflatten(v, shapes):
+  out, pos = [], 0
+  for sh in shapes:
+    cnt = int(torch.Size(sh).numel())
+    out.append(v[pos:pos + cnt].view(sh))
+    pos += cnt
+  return out
+
+
+class _AdjointSolve(torch.autograd.Function):
+  """Forward: the plain solve WITHOUT a tape -- on this package's functions that is the native hipGraph solver, so
+  the training forward runs at inference speed and stores two states, not the trajectory.  Backward: the augmented
+  system (vjp_t, y, a, g_theta) with  dy/dt = f,  da/dt = -a^T df/dy,  dg/dt = -a^T df/dtheta  is integrated from
+  t[i] back to t[i-1] with the ADJOINT method / step size / tolerances; like torchdiffeq, the time reversal is the
+  substitution s = -t (so a fixed grid puts its short step next to t[i-1]), the tuple is integrated as one flat
+  vector (mixed linf-rms norm for adaptive methods), y is reset to the stored forward value and the incoming
+  gradient is added at every output time.  f and its vector-Jacobian products run through the native kernels."""
+
+  @staticmethod
+  def forward(ctx, func, y0, t, fwd, adj, *params):
+    ctx.func, ctx.adj = func, adj
+    ans = odeint(func, y0.detach(), t, **fwd)
+    ctx.save_for_backward(t, ans, *params)
+    return ans
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    func, adj = ctx.func, ctx.adj
+    t, ans, *params = ctx.saved_tensors
+    params = tuple(params)
+    with torch.no_grad():
+      state = [torch.zeros((), dtype=ans.dtype, device=ans.device), ans[-1], grad_out[-1].contiguous()]
+      state.extend(torch.zeros_like(p) for p in params)
+      shapes = [s_.shape for s_ in state]
+
+      def reversed_flat_dynamics(s, flat):
+        """-(vjp_t, f, vjp_y, vjp_params) at time t = -s, vjp = grad(f, ., -a)  (adjoint.py augmented_dynamics
+        under misc.py _ReverseFunc and _TupleFunc)."""
+        parts = _unflatten(flat, shapes)
+        with torch.enable_grad():
+          y = parts[1].detach().requires_grad_(True)
+          f_eval = func(-s, y)
+          grads = torch.autograd.grad(f_eval, (y,) + params, -parts[2], allow_unused=True)
+        outs = [torch.zeros_like(parts[0]), f_eval.detach()]
+        outs.append(torch.zeros_like(y) if grads[0] is None else grads[0])
+        for p, g in zip(params, grads[1:]):
+          outs.append(torch.zeros_like(p) if g is None else g)
+        return -_flatten(outs)
+
+      options = dict(adj['options'])
+      if adj['method'] in ('dopri5', 'adaptive_heun') and 'norm' not in options:
+        options['norm'] = _mixed_norm(shapes)
+      for i in range(len(t) - 1, 0, -1):
+        span = -t[i - 1:i + 1].flip(0)
+        flat = odeint(reversed_flat_dynamics, _flatten(state), span, rtol=adj['rtol'], atol=adj['atol'],
+                      method=adj['method'], options=options)[1]
+        state = [p.clone() for p in _unflatten(flat, shapes)]
+        state[1] = ans[i - 1]
+        state[2] = state[2] + grad_out[i - 1]
+    return (None, state[2], None, None, None) + tuple(state[3:])
+
+
+def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None, adjoint_atol=None,
+                   adjoint_method=None, adjoint_options=None, adjoint_params=None, use_graph=True):
+  """Drop-in for torchdiffeq.odeint_adjoint: same values as `odeint`; gradients with respect to y0 and the
+  function's parameters come from solving the adjoint ODE backwards (see _AdjointSolve), not from a tape."""
+  options = dict(options or {})
+  fwd = dict(rtol=rtol, atol=atol, method=method, options=options, use_graph=use_graph)
+  if adjoint_params is None:
+    adjoint_params = tuple(func.parameters()) if isinstance(func, torch.nn.Module) else ()
+  params = tuple(p for p in adjoint_params if p.requires_grad)
+  if not torch.is_grad_enabled() or not (y0.requires_grad or params):
+    return odeint(func, y0, t, **fwd)
+  adj = dict(rtol=rtol if adjoint_rtol is None else adjoint_rtol, atol=atol if adjoint_atol is None else adjoint_atol,
+             method=(method or 'dopri5') if adjoint_method is None else adjoint_method,
+             options={k: v for k, v in options.items() if k != 'norm'} if adjoint_options is None else dict(adjoint_options))
+  return _AdjointSolve.apply(func, y0, t, fwd, adj, *params)

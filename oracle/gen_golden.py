@@ -318,6 +318,46 @@ def gen_early():
     print('    best (train, val, test, time) =', best.round(4).tolist(), ' evaluations:', len(log))
 
 
+def gen_adjoint():
+  """Training-mode block forward + backward with opt['adjoint'] (torchdiffeq.odeint_adjoint, restated in
+  oracle/shims): output, gradient of <z, c> with respect to the input and to every parameter that receives one."""
+  n, d = 120, 24
+  ei = make_graph(n, 6, 51)
+  g = torch.Generator().manual_seed(52)
+  x = torch.randn(n, d, generator=g)
+  c = torch.randn(n, d, generator=g)
+  cases = {
+    'constant_transformer_rk4_rk4': dict(block='constant', function='transformer', method='rk4', time=2.3,
+                                         adjoint_method='rk4', adjoint_step_size=1.0),
+    'attention_laplacian_dopri5_rk4': dict(block='attention', function='laplacian', method='dopri5', time=2.0, tol_scale=800.0,
+                                           adjoint_method='rk4', adjoint_step_size=0.5),
+    'constant_laplacian_euler_heun': dict(block='constant', function='laplacian', method='euler', time=2.0, step_size=0.5,
+                                          adjoint_method='adaptive_heun', tol_scale_adjoint=3000.0),
+    'constant_gat_dopri5_dopri5': dict(block='constant', function='GAT', method='dopri5', time=1.5, tol_scale=20.0,
+                                       adjoint_method='dopri5', tol_scale_adjoint=20.0),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, 'adjoint': True, 'adjoint_step_size': 1.0, 'tol_scale_adjoint': 1.0, **over}
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt, 'GAT': ODEFuncAtt}[opt['function']]
+    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
+    block = bcls(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+    randomise(block, 700 + i)
+    block.train()
+    xin = x.clone().requires_grad_(True)
+    block.set_x0(xin)
+    z = block(xin)
+    nfe_fwd = block.odefunc.nfe
+    (z * c).sum().backward()
+    rec = {'edge_index': ei, 'x': x, 'c': c, 'z': z, 'grad_x': xin.grad, 'nfe_forward': np.int64(nfe_fwd),
+           'nfe': np.int64(block.odefunc.nfe)}
+    for k, p in block.named_parameters():
+      if p.grad is not None:
+        rec['grad/' + k] = p.grad
+    save('adjoint_' + name, opt, rec, block)
+    print('    nfe forward %d, total %d; grads: %s' % (nfe_fwd, block.odefunc.nfe,
+                                                       ', '.join(k[5:] for k in rec if k.startswith('grad/'))))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
   torch.manual_seed(0)
@@ -326,3 +366,4 @@ if __name__ == '__main__':
   gen_blocks()
   gen_gnn()
   gen_early()
+  gen_adjoint()

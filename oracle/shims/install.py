@@ -541,39 +541,183 @@ class Dopri5Solver(RKAdaptiveStepsizeODESolver):
   mid = DPS_C_MID
 
 
-SOLVERS = {'euler': Euler, 'rk4': RK4, 'dopri5': Dopri5Solver}
+class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
+  """adaptive_heun.py: Heun-Euler 2(1) pair (the reference's default `adjoint_method`, run_GNN.py:334)."""
+  order = 2
+  tableau = _Tableau(alpha=torch.tensor([1.], dtype=torch.float64), beta=[torch.tensor([1.], dtype=torch.float64)],
+                     c_sol=torch.tensor([0.5, 0.5], dtype=torch.float64),
+                     c_error=torch.tensor([0.5, -0.5], dtype=torch.float64))
+  mid = torch.tensor([0.5, 0.], dtype=torch.float64)
+
+
+SOLVERS = {'euler': Euler, 'rk4': RK4, 'dopri5': Dopri5Solver, 'adaptive_heun': AdaptiveHeunSolver}
+
+
+class _TupleFunc(torch.nn.Module):
+  """misc.py _TupleFunc: a function of a tuple state seen as a function of the flattened concatenation."""
+
+  def __init__(self, base_func, shapes):
+    super(_TupleFunc, self).__init__()
+    self.base_func, self.shapes = base_func, shapes
+
+  def forward(self, t, y):
+    f = self.base_func(t, _flat_to_shape(y, (), self.shapes))
+    return torch.cat([f_.reshape(-1) for f_ in f])
+
+
+class _ReverseFunc(torch.nn.Module):
+  """misc.py _ReverseFunc: integration towards smaller t is integration of -f(-s, y) towards larger s = -t."""
+
+  def __init__(self, base_func):
+    super(_ReverseFunc, self).__init__()
+    self.base_func = base_func
+
+  def forward(self, t, y):
+    return -self.base_func(-t, y)
+
+
+class _PerturbFunc(torch.nn.Module):
+  """misc.py _PerturbFunc, the part that matters here: the time handed to the user function has the state's
+  dtype (adaptive solvers keep time in float64)."""
+
+  def __init__(self, base_func):
+    super(_PerturbFunc, self).__init__()
+    self.base_func = base_func
+
+  def forward(self, t, y):
+    return self.base_func(t.to(y.dtype), y)
+
+
+def _mixed_linf_rms_norm(shapes):
+  """misc.py: the default norm of a tuple state -- the largest of the components' rms norms."""
+  def _norm(tensor):
+    total = 0
+    out = []
+    for shape in shapes:
+      next_total = total + int(torch.Size(shape).numel())
+      out.append(_rms_norm(tensor[total:next_total]))
+      total = next_total
+    assert total == tensor.numel()
+    return max(out)
+  return _norm
 
 
 def _check_inputs(func, y0, t, rtol, atol, method, options, event_fn, solvers):
+  """misc.py _check_inputs, the parts the path uses: tuple states are flattened, decreasing times are negated,
+  a default norm is put into the options."""
   shapes = None
-  if options is None:
-    options = {}
-  else:
-    options = dict(options)
+  if not torch.is_tensor(y0):
+    assert isinstance(y0, tuple), 'y0 must be either a torch.Tensor or a tuple'
+    shapes = [y0_.shape for y0_ in y0]
+    y0 = torch.cat([y0_.reshape(-1) for y0_ in y0])
+    func = _TupleFunc(func, shapes)
+  options = {} if options is None else dict(options)
   if method is None:
     method = 'dopri5'
-  return shapes, func, y0, t, rtol, atol, method, options, event_fn, False
+  if 'norm' not in options:
+    options['norm'] = _rms_norm if shapes is None else _mixed_linf_rms_norm(shapes)
+  t_is_reversed = bool(len(t) > 1 and (t[1:] < t[:-1]).all())
+  if t_is_reversed:
+    t = -t
+    func = _ReverseFunc(func)
+  func = _PerturbFunc(func)
+  return shapes, func, y0, t, rtol, atol, method, options, event_fn, t_is_reversed
 
 
 def _flat_to_shape(tensor, length, shapes):
-  return tensor
+  if shapes is None:
+    return tensor
+  out = []
+  total = 0
+  for shape in shapes:
+    next_total = total + int(torch.Size(shape).numel())
+    out.append(tensor[..., total:next_total].view((*length, *shape)))
+    total = next_total
+  return tuple(out)
 
 
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None):
   shapes, func, y0, t, rtol, atol, method, options, event_fn, _ = _check_inputs(
     func, y0, t, rtol, atol, method, options, event_fn, SOLVERS)
   solver = SOLVERS[method](func=func, y0=y0, rtol=rtol, atol=atol, **options)
-  return solver.integrate(t)
+  solution = solver.integrate(t)
+  if shapes is not None:
+    solution = _flat_to_shape(solution, (len(t),), shapes)
+  return solution
+
+
+class OdeintAdjointMethod(torch.autograd.Function):
+  """adjoint.py (torchdiffeq 0.2.1): forward solve without a tape; backward integrates the augmented system
+  (vjp_t, y, adj_y, adj_params) from t[i] back to t[i-1] with the ADJOINT method / options, resetting y to the
+  stored forward value and adding the incoming gradient at every output time."""
+
+  @staticmethod
+  def forward(ctx, func, y0, t, rtol, atol, method, options, adjoint_rtol, adjoint_atol, adjoint_method,
+              adjoint_options, *adjoint_params):
+    ctx.func = func
+    ctx.adjoint_rtol, ctx.adjoint_atol = adjoint_rtol, adjoint_atol
+    ctx.adjoint_method, ctx.adjoint_options = adjoint_method, adjoint_options
+    with torch.no_grad():
+      y = odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
+    ctx.save_for_backward(t, y, *adjoint_params)
+    return y
+
+  @staticmethod
+  def backward(ctx, grad_y):
+    with torch.no_grad():
+      func = ctx.func
+      t, y, *adjoint_params = ctx.saved_tensors
+      adjoint_params = tuple(adjoint_params)
+      aug_state = [torch.zeros((), dtype=y.dtype, device=y.device), y[-1], grad_y[-1]]
+      aug_state.extend([torch.zeros_like(param) for param in adjoint_params])
+
+      def augmented_dynamics(t, y_aug):
+        y = y_aug[1]
+        adj_y = y_aug[2]
+        with torch.enable_grad():
+          t_ = t.detach()
+          y = y.detach().requires_grad_(True)
+          func_eval = func(t_, y)
+          vjp_y, *vjp_params = torch.autograd.grad(func_eval, (y,) + adjoint_params, -adj_y, allow_unused=True,
+                                                   retain_graph=True)
+        vjp_t = torch.zeros_like(t_)
+        vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
+        vjp_params = [torch.zeros_like(param) if vjp_param is None else vjp_param
+                      for param, vjp_param in zip(adjoint_params, vjp_params)]
+        return (vjp_t, func_eval, vjp_y, *vjp_params)
+
+      for i in range(len(t) - 1, 0, -1):
+        aug_state = odeint(augmented_dynamics, tuple(aug_state), t[i - 1:i + 1].flip(0), rtol=ctx.adjoint_rtol,
+                           atol=ctx.adjoint_atol, method=ctx.adjoint_method, options=ctx.adjoint_options)
+        aug_state = [a[1] for a in aug_state]
+        aug_state[1] = y[i - 1]
+        aug_state[2] += grad_y[i - 1]
+      adj_y = aug_state[2]
+      adj_params = aug_state[3:]
+    return (None, adj_y, None, None, None, None, None, None, None, None, None, *adj_params)
 
 
 def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, event_fn=None,
                    adjoint_rtol=None, adjoint_atol=None, adjoint_method=None, adjoint_options=None,
                    adjoint_params=None):
-  # forward values are identical to odeint; the adjoint backward is not on the measured path
-  return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
+  """adjoint.py odeint_adjoint: defaults of the adjoint_* arguments, parameters found on the module."""
+  if adjoint_rtol is None:
+    adjoint_rtol = rtol
+  if adjoint_atol is None:
+    adjoint_atol = atol
+  if adjoint_method is None:
+    adjoint_method = method
+  if adjoint_options is None:
+    adjoint_options = {k: v for k, v in options.items() if k != 'norm'} if options is not None else {}
+  else:
+    adjoint_options = dict(adjoint_options)
+  if adjoint_params is None:
+    adjoint_params = tuple(func.parameters())
+  adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
+  return OdeintAdjointMethod.apply(func, y0, t, rtol, atol, method, options, adjoint_rtol, adjoint_atol, adjoint_method,
+                                   adjoint_options, *adjoint_params)
 
 
-# ----------------------------------------------------------------------------------------------
 def install():
   """Register every stand-in in sys.modules (idempotent)."""
   if 'torch_scatter' in sys.modules and getattr(sys.modules['torch_scatter'], '_gnpde_shim', False):

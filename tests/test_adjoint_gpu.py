@@ -1,0 +1,73 @@
+"""Training with opt['adjoint']: the MI355X blocks (native hipGraph forward, adjoint ODE solved backwards through the
+native f and VJP kernels) against the gradients of the reference's blocks (tests/golden/adjoint_*.npz)."""
+import pytest
+import torch
+
+import gnpde_amd as G
+from helpers import Fixture, fixtures, Data, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}
+BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
+
+
+@pytest.mark.parametrize('name', fixtures('adjoint_'))
+def test_block_adjoint_training(dev, name):
+  fx = Fixture(name)
+  opt = fx.opt
+  x = fx.t('x', dev)
+  block = BLOCKS[opt['block']](FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev)), dev,
+                               t=torch.tensor([0, opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  block.train()
+  assert block.train_integrator is G.odeint_adjoint
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  tol, gtol = 1e-5, 2e-4      # gradients: long reductions in a different order (as in test_autograd_gpu.py)
+  if opt['method'] == 'dopri5':
+    tol, gtol = max(1e-5, 20 * opt['tol_scale'] * 1e-7), 5e-4
+  if opt['adjoint_method'] in ('dopri5', 'adaptive_heun'):
+    gtol = 1e-3               # adaptive adjoint: agreement to the solver tolerance (see test_adjoint_cpu.py)
+  assert_parity(z, fx.t('z'), tol, name + ' z')
+  assert z.requires_grad
+  nfe_fwd = block.odefunc.nfe
+  assert nfe_fwd == int(fx.arr['nfe_forward'])
+  (z * fx.t('c', dev)).sum().backward()
+  assert_parity(xin.grad, fx.t('grad_x'), gtol, name + ' grad_x')
+  checked = 0
+  for k, p in block.named_parameters():
+    key = 'grad/' + k
+    if key not in fx.arr:
+      assert p.grad is None or float(p.grad.abs().max()) == 0.0, '%s received a gradient the reference does not produce' % k
+      continue
+    ref = fx.t(key)
+    assert p.grad is not None, k
+    if float(ref.abs().max()) < 1e-6:
+      assert float(p.grad.abs().max()) < 1e-4, k
+    else:
+      assert_parity(p.grad, ref, gtol, name + ' ' + k)
+      checked += 1
+  assert checked >= 2
+  if opt['adjoint_method'] in ('euler', 'rk4'):
+    assert block.odefunc.nfe == int(fx.arr['nfe']), 'nfe %d vs reference %d' % (block.odefunc.nfe, int(fx.arr['nfe']))
+
+
+def test_adjoint_forward_uses_the_graph_solver_and_no_tape(dev):
+  """The forward of an adjoint solve is the captured hipGraph solver: the result carries no per-step autograd graph
+  and a second call replays bit-identically."""
+  fx = Fixture('adjoint_constant_transformer_rk4_rk4')
+  x = fx.t('x', dev)
+  block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], fx.opt, Data(x, fx.t('edge_index', dev)), dev,
+                             t=torch.tensor([0, fx.opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  block.train()
+  block.set_x0(x)
+  z1 = block(x.clone().requires_grad_(True))
+  assert '_solver_state' in block.odefunc.__dict__ and block.odefunc.__dict__['_solver_state'], 'native solver was not used'
+  block.eval()
+  block.set_x0(x)
+  with torch.no_grad():
+    z2 = block(x)
+  assert torch.equal(z1.detach(), z2)
