@@ -177,24 +177,8 @@ def _aggregate(edge, w, x):
 def composite_transformer(func, x):
   """f(x) of ODEFuncTransformerAtt from differentiable device ops (reference op order)."""
   lay, opt = func.multihead_att_layer, func.opt
-  edge, n, h, dk = func.edge_index, x.shape[0], lay.h, lay.d_k
-  q = lay.Q(x).view(-1, h, dk).transpose(1, 2)
-  k = lay.K(x).view(-1, h, dk).transpose(1, 2)
-  src, dst = q[edge[0]], k[edge[1]]
-  t = opt['attention_type']
-  if t == 'scaled_dot':
-    prods = torch.sum(src * dst, dim=1) / math.sqrt(dk)
-  elif t == 'exp_kernel':
-    prods = lay.output_var ** 2 * torch.exp(-(torch.sum((src - dst) ** 2, dim=1) / (2 * lay.lengthscale ** 2)))
-  else:
-    if t == 'pearson':
-      src = src - src.mean(dim=1, keepdim=True)
-      dst = dst - dst.mean(dim=1, keepdim=True)
-    prods = torch.nn.functional.cosine_similarity(src, dst, dim=1, eps=1e-5)
-  if opt['reweight_attention'] and lay.edge_weights is not None:
-    prods = prods * lay.edge_weights.unsqueeze(1)
-  idx = edge[opt['attention_norm_idx']]
-  att = _squareplus(prods, idx, n) if opt['square_plus'] else _segment_softmax(prods, idx, n)
+  edge = func.edge_index
+  att, _ = _layer_attention(lay, x, edge)
   f = _alpha(func) * (_aggregate(edge, att.mean(dim=1), x) - x)
   if opt['add_source']:
     f = f + func.beta_train * func.x0
@@ -239,13 +223,30 @@ def layer_attention_with_grad(layer, x, edge):
   """(attention [E,h], prods [E,h]) of SpGraphTransAttentionLayer with autograd history (composite); used
   when a block differentiates through the attention it computes once per forward pass."""
   _announce('SpGraphTransAttentionLayer')
+  return _layer_attention(layer, x, edge)
+
+
+def _layer_attention(layer, x, edge):
   opt = layer.opt
   n, h, dk = x.shape[0], layer.h, layer.d_k
-  q = layer.Q(x).view(-1, h, dk).transpose(1, 2)
-  k = layer.K(x).view(-1, h, dk).transpose(1, 2)
-  src, dst = q[edge[0]], k[edge[1]]
   t = opt['attention_type']
-  if t == 'scaled_dot':
+  if getattr(layer, 'split_kernel', False):       # BLEND: feature kernel times positional kernel (reference :133-171)
+    f0, lab = opt['feat_hidden_dim'], opt['feat_hidden_dim'] + opt['pos_enc_hidden_dim']
+    p = x[:, f0:lab]
+    xf = torch.cat((x[:, :f0], x[:, lab:]), dim=1)
+    heads = lambda lin, inp: lin(inp).view(-1, h, dk).transpose(1, 2)  # noqa: E731
+    dx = heads(layer.Qx, xf)[edge[0]] - heads(layer.Kx, xf)[edge[1]]
+    dp = heads(layer.Qp, p)[edge[0]] - heads(layer.Kp, p)[edge[1]]
+    prods = layer.output_var_x ** 2 * torch.exp(-torch.sum(dx ** 2, dim=1) / (2 * layer.lengthscale_x ** 2)) \
+        * layer.output_var_p ** 2 * torch.exp(-torch.sum(dp ** 2, dim=1) / (2 * layer.lengthscale_p ** 2))
+    src = dst = None
+  else:
+    q = layer.Q(x).view(-1, h, dk).transpose(1, 2)
+    k = layer.K(x).view(-1, h, dk).transpose(1, 2)
+    src, dst = q[edge[0]], k[edge[1]]
+  if src is None:
+    pass
+  elif t == 'scaled_dot':
     prods = torch.sum(src * dst, dim=1) / math.sqrt(dk)
   elif t == 'exp_kernel':
     prods = layer.output_var ** 2 * torch.exp(-(torch.sum((src - dst) ** 2, dim=1) / (2 * layer.lengthscale ** 2)))

@@ -32,24 +32,48 @@ class SpGraphTransAttentionLayer(nn.Module):
     self.d_k = self.attention_dim // self.h
     if opt['attention_type'] not in _lib.ATT_TYPES:
       raise ValueError('unknown attention_type %r' % (opt['attention_type'],))
-    if opt['beltrami'] and opt['attention_type'] == "exp_kernel":
-      raise NotImplementedError('the split feature / positional exp_kernel (beltrami) is SURVEY.md 8f row 4 (next)')
-    if opt['attention_type'] == "exp_kernel":
-      self.output_var = nn.Parameter(torch.ones(1))
-      self.lengthscale = nn.Parameter(torch.ones(1))
-    self.Q = nn.Linear(in_features, self.attention_dim)
-    self.V = nn.Linear(in_features, self.attention_dim)
-    self.K = nn.Linear(in_features, self.attention_dim)
+    # BLEND: separate feature / positional kernels, multiplied (reference :83-101, :133-171)
+    self.split_kernel = bool(opt['beltrami'] and opt['attention_type'] == "exp_kernel")
+    if self.split_kernel:
+      self.output_var_x = nn.Parameter(torch.ones(1))
+      self.lengthscale_x = nn.Parameter(torch.ones(1))
+      self.output_var_p = nn.Parameter(torch.ones(1))
+      self.lengthscale_p = nn.Parameter(torch.ones(1))
+      fdim, pdim = opt['hidden_dim'] - opt['pos_enc_hidden_dim'], opt['pos_enc_hidden_dim']
+      self.Qx, self.Vx, self.Kx = (nn.Linear(fdim, self.attention_dim) for _ in range(3))
+      self.Qp, self.Vp, self.Kp = (nn.Linear(pdim, self.attention_dim) for _ in range(3))
+      linears = (self.Qx, self.Vx, self.Kx, self.Qp, self.Vp, self.Kp)
+    else:
+      if opt['attention_type'] == "exp_kernel":
+        self.output_var = nn.Parameter(torch.ones(1))
+        self.lengthscale = nn.Parameter(torch.ones(1))
+      self.Q = nn.Linear(in_features, self.attention_dim)
+      self.V = nn.Linear(in_features, self.attention_dim)
+      self.K = nn.Linear(in_features, self.attention_dim)
+      linears = (self.Q, self.V, self.K)
     self.activation = nn.Sigmoid()
     self.Wout = nn.Linear(self.d_k, in_features)
-    for m in (self.Q, self.V, self.K, self.Wout):
+    for m in linears + (self.Wout,):
       nn.init.constant_(m.weight, 1e-5)  # reference init (:122-126)
     self._bufs = {}
+
+  @property
+  def kernel_att_dim(self):
+    """Width of q (and of k) as the device kernels see it: the split kernel runs as ONE exp_kernel over the
+    concatenation [q_x / l_x ; q_p / l_p] per head (see qk_weights)."""
+    return 2 * self.attention_dim if self.split_kernel else self.attention_dim
+
+  def _grad_sources(self):
+    if self.split_kernel:
+      return (self.Qx.weight, self.Kx.weight, self.Qp.weight, self.Kp.weight)
+    return (self.Q.weight, self.K.weight)
 
   # ---- native descriptor pieces ---------------------------------------------------------------
   def qk_weights(self):
     """[Q.weight; K.weight] ([2A, d]) and [Q.bias; K.bias], refreshed in place when a parameter's
     version changes so that captured solver graphs keep pointing at live data."""
+    if self.split_kernel:
+      return self._split_qk_weights()
     srcs = (self.Q.weight, self.K.weight, self.Q.bias, self.K.bias)
     sig = tuple((id(p), p._version, str(p.device)) for p in srcs)
     ent = self._bufs.get('qk')
@@ -63,6 +87,44 @@ class SpGraphTransAttentionLayer(nn.Module):
         ent[1][self.attention_dim:].copy_(self.K.weight)
         ent[2][:self.attention_dim].copy_(self.Q.bias)
         ent[2][self.attention_dim:].copy_(self.K.bias)
+      ent[0] = sig
+    return ent[1], ent[2]
+
+  def _split_qk_weights(self):
+    """Split feature / positional kernel as one projection + one exp_kernel.  The reference's score is
+        ov_x^2 exp(-|q_x - k_x|^2 / 2 l_x^2) * ov_p^2 exp(-|q_p - k_p|^2 / 2 l_p^2)
+      = (ov_x ov_p)^2 exp(-|[q_x / l_x ; q_p / l_p] - [k_x / l_x ; k_p / l_p]|^2 / 2),
+    so the projection matrix gets, per head, the d_k rows of Qx (scaled by 1 / l_x, acting on the feature and label
+    columns of the state) followed by the d_k rows of Qp (scaled by 1 / l_p, acting on the positional columns), the
+    same for K, and the kernel runs with output_var = ov_x ov_p, lengthscale = 1 and heads of width 2 d_k."""
+    opt = self.opt
+    srcs = (self.Qx.weight, self.Qx.bias, self.Kx.weight, self.Kx.bias, self.Qp.weight, self.Qp.bias, self.Kp.weight,
+            self.Kp.bias, self.lengthscale_x, self.lengthscale_p, self.output_var_x, self.output_var_p)
+    sig = tuple((id(p), p._version, str(p.device)) for p in srcs)
+    dev = self.Qx.weight.device
+    A, h, dk = self.attention_dim, self.h, self.d_k
+    ent = self._bufs.get('qk')
+    if ent is None or ent[1].device != dev:
+      ent = [None, torch.zeros(4 * A, self.in_features, dtype=torch.float32, device=dev),
+             torch.zeros(4 * A, dtype=torch.float32, device=dev),
+             torch.ones(1, dtype=torch.float32, device=dev), torch.ones(1, dtype=torch.float32, device=dev)]
+      self._bufs['qk'] = ent
+    if ent[0] != sig:
+      f0, p0 = opt['feat_hidden_dim'], opt['pos_enc_hidden_dim']
+      lab = f0 + p0                                   # label columns (use_labels) follow the positional block
+      with torch.no_grad():
+        for half, (lx, lp) in enumerate(((self.Qx, self.Qp), (self.Kx, self.Kp))):
+          w = ent[1][half * 2 * A:(half + 1) * 2 * A].view(h, 2 * dk, self.in_features)
+          b = ent[2][half * 2 * A:(half + 1) * 2 * A].view(h, 2 * dk)
+          wx = (lx.weight / self.lengthscale_x).view(h, dk, -1)
+          wp = (lp.weight / self.lengthscale_p).view(h, dk, -1)
+          w.zero_()
+          w[:, :dk, :f0] = wx[:, :, :f0]
+          w[:, :dk, lab:] = wx[:, :, f0:]
+          w[:, dk:, f0:lab] = wp
+          b[:, :dk] = (lx.bias / self.lengthscale_x).view(h, dk)
+          b[:, dk:] = (lp.bias / self.lengthscale_p).view(h, dk)
+        ent[3].copy_(self.output_var_x * self.output_var_p)
       ent[0] = sig
     return ent[1], ent[2]
 
@@ -80,10 +142,14 @@ class SpGraphTransAttentionLayer(nn.Module):
   def attention_struct(self, graph, q=None, k=None, ldqk=0):
     dev = graph.device
     kw = {}
-    if self.opt['attention_type'] == 'exp_kernel':
+    if self.split_kernel:
+      self.qk_weights()                       # refreshes the derived output_var
+      ent = self._bufs['qk']
+      kw = dict(output_var=ent[3], lengthscale=ent[4])
+    elif self.opt['attention_type'] == 'exp_kernel':
       kw = dict(output_var=ops._scalar_dev(self.output_var, graph.rowptr),
                 lengthscale=ops._scalar_dev(self.lengthscale, graph.rowptr))
-    st = ops.attention_struct(_lib.ATT_TYPES[self.opt['attention_type']], self.h, self.attention_dim,
+    st = ops.attention_struct(_lib.ATT_TYPES[self.opt['attention_type']], self.h, self.kernel_att_dim,
                               self.opt['attention_norm_idx'], self.opt['square_plus'], q=q, k=k, ldqk=ldqk,
                               edge_w_csr=self._reweight_csr(graph), **kw)
     keep = [q, k] + list(kw.values())
@@ -92,20 +158,22 @@ class SpGraphTransAttentionLayer(nn.Module):
   def forward(self, x, edge):
     """(attention [E,h], (v, prods [E,h])) in the order of `edge` (reference :128-214)."""
     _lib.require_hip(x, edge)
-    if torch.is_grad_enabled() and (x.requires_grad or self.Q.weight.requires_grad or self.K.weight.requires_grad):
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._grad_sources())):
       # training: the block differentiates through this attention (interim composite, see autograd.py)
       from .autograd import layer_attention_with_grad
       att, prods = layer_attention_with_grad(self, x, edge)
-      v = self.V(x).view(-1, self.h, self.d_k).transpose(1, 2)
+      v = None if self.split_kernel else self.V(x).view(-1, self.h, self.d_k).transpose(1, 2)
       return att, (v, prods)
     with torch.no_grad():
       xc = _lib.f32c(x)
       graph = graph_of(edge, xc.shape[0], xc.device)
       wqk, bqk = self.qk_weights()
       qk = ops.linear(xc, wqk, bqk)
-      A = self.attention_dim
+      A = self.kernel_att_dim
       st, keep = self.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
       _, att, prods = ops.edge_attention(graph, st, want_w_mean=False, want_att=True, want_prods=True, like=xc)
+      if self.split_kernel:
+        return att, (None, prods)             # the reference returns v = None on this branch (:171)
       # V is dead on this path (mix_features crashes in the reference, SURVEY.md a6) but part of the
       # return value: [N, d_k, h] like the reference's transposed view
       v = ops.linear(xc, _lib.f32c(self.V.weight.detach()), _lib.f32c(self.V.bias.detach()))

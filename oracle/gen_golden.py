@@ -257,6 +257,45 @@ def gen_gnn():
                               'nfe': np.int64(model.getNFE())}, model)
 
 
+def gen_beltrami():
+  """BLEND attention: separate exp kernels on the feature and positional channels, multiplied
+  (function_transformer_attention.py:83-101, :133-171); with and without label columns after the positional block."""
+  n = 160
+  ei = make_graph(n, 8, 61, with_loops=True)
+  g = torch.Generator().manual_seed(62)
+  for i, (name, feat, pos, lab, over) in enumerate([
+      ('beltrami_expkernel', 16, 8, 0, {}),
+      ('beltrami_expkernel_labels_n1', 16, 8, 3, {'attention_norm_idx': 1, 'heads': 2, 'attention_dim': 8}),
+      ('beltrami_expkernel_sqp', 12, 12, 0, {'square_plus': True})]):
+    d = feat + pos + lab
+    x = torch.randn(n, d, generator=g)
+    x0 = torch.randn(n, d, generator=g)
+    opt = {**BASE, 'attention_type': 'exp_kernel', 'beltrami': True, 'feat_hidden_dim': feat, 'pos_enc_hidden_dim': pos,
+           'hidden_dim': d, **over}
+    func = ODEFuncTransformerAtt(d, d, opt, data_of(ei, x), torch.device('cpu'))
+    randomise(func, 800 + i)
+    func.x0 = x0
+    with torch.no_grad():
+      att, (v, prods) = func.multihead_att_layer(x, func.edge_index)
+      f = func(0.0, x)
+    assert v is None
+    save('func_transformer_' + name, opt, {'edge_index': ei, 'x': x, 'x0': x0, 'func_edge_index': func.edge_index,
+                                           'attention': att, 'prods': prods, 'f': f}, func)
+  # a whole block: attention computed once with the split kernel, GRAND-l diffusion (the BLEND configuration C4)
+  d, feat, pos = 24, 16, 8
+  x = torch.randn(n, d, generator=g)
+  opt = {**BASE, 'attention_type': 'exp_kernel', 'beltrami': True, 'feat_hidden_dim': feat, 'pos_enc_hidden_dim': pos,
+         'hidden_dim': d, 'block': 'attention', 'function': 'laplacian', 'method': 'rk4', 'time': 2.5}
+  block = AttODEblock(LaplacianODEFunc, [], opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+  randomise(block, 850)
+  block.eval()
+  block.set_x0(x)
+  with torch.no_grad():
+    z = block(x)
+  save('block_attention_laplacian_beltrami_rk4', opt, {'edge_index': ei, 'x': x, 'z': z,
+                                                       'nfe': np.int64(block.odefunc.nfe)}, block)
+
+
 def gen_early():
   """Test-time integrators with early stopping (reference src/early_stop_solver.py), installed on a block the way
   GNNEarly does (src/GNN_early.py:28-36): best (train, val, test, time) and the accuracies after every step."""
@@ -365,5 +404,6 @@ if __name__ == '__main__':
   gen_funcs()
   gen_blocks()
   gen_gnn()
+  gen_beltrami()
   gen_early()
   gen_adjoint()

@@ -150,6 +150,34 @@ def transformer_attention(x, edge, Wq, bq, Wk, bk, heads, attention_type='scaled
   return attention, prods
 
 
+def transformer_attention_split(x, edge, P, heads, feat_dim, pos_dim, norm_idx=0, square_plus=False, edge_weights=None,
+                                reweight=False):
+  """SpGraphTransAttentionLayer.forward, beltrami + exp_kernel branch (function_transformer_attention.py:133-171):
+  one exp kernel on the feature (+ label) columns, one on the positional columns, multiplied.  P maps the layer's
+  parameter names (Qx.weight, ..., lengthscale_p) to tensors.  Returns (attention [E,h], prods [E,h])."""
+  n = x.shape[0]
+  label_index = feat_dim + pos_dim
+  p = x[:, feat_dim:label_index]
+  xf = torch.cat((x[:, :feat_dim], x[:, label_index:]), dim=1)
+  d_k = P['Qx.weight'].shape[0] // heads
+
+  def split_heads(w, b, inp):
+    return torch.nn.functional.linear(inp, w, b).view(-1, heads, d_k).transpose(1, 2)
+  src_x = split_heads(P['Qx.weight'], P['Qx.bias'], xf)[edge[0, :], :, :]
+  dst_x = split_heads(P['Kx.weight'], P['Kx.bias'], xf)[edge[1, :], :, :]
+  src_p = split_heads(P['Qp.weight'], P['Qp.bias'], p)[edge[0, :], :, :]
+  dst_p = split_heads(P['Kp.weight'], P['Kp.bias'], p)[edge[1, :], :, :]
+  prods = P['output_var_x'] ** 2 * torch.exp(-torch.sum((src_x - dst_x) ** 2, dim=1) / (2 * P['lengthscale_x'] ** 2)) \
+      * P['output_var_p'] ** 2 * torch.exp(-torch.sum((src_p - dst_p) ** 2, dim=1) / (2 * P['lengthscale_p'] ** 2))
+  if reweight and edge_weights is not None:
+    prods = prods * edge_weights.unsqueeze(dim=1)
+  if square_plus:
+    attention = squareplus(prods, edge[norm_idx], n)
+  else:
+    attention = segment_softmax(prods, edge[norm_idx], n)
+  return attention, prods
+
+
 def gat_attention(x, edge, W, a, heads, leaky_slope=0.2, norm_idx=0):
   """SpGraphAttentionLayer.forward (function_GAT_attention.py:105-115).
   Returns (attention [E,h], wx [N,A])."""
@@ -190,6 +218,12 @@ def rhs_transformer(x, edge, Wq, bq, Wk, bk, heads, alpha_train, beta_train, x0=
   """ODEFuncTransformerAtt.forward with mix_features=False (function_transformer_attention.py:38-53,
   :33-35)."""
   attention, _ = transformer_attention(x, edge, Wq, bq, Wk, bk, heads, **att_kw)
+  ax = spmm(edge, attention.mean(dim=1), x.shape[0], x)
+  return _epilogue(ax, x, alpha_train, beta_train, x0, no_alpha_sigmoid, add_source)
+
+
+def rhs_from_attention(x, edge, attention, alpha_train, beta_train, x0=None, no_alpha_sigmoid=False, add_source=False):
+  """ODEFuncTransformerAtt.forward after the attention layer (function_transformer_attention.py:33-35, :46-53)."""
   ax = spmm(edge, attention.mean(dim=1), x.shape[0], x)
   return _epilogue(ax, x, alpha_train, beta_train, x0, no_alpha_sigmoid, add_source)
 

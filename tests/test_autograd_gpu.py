@@ -208,3 +208,35 @@ def test_cora_best_params_training_step(dev):
   scale = max(float(b.grad.abs().max()) for b in ps)
   for a, b in zip((lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias), ps):
     assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-3 * scale, 'd attention params'
+
+
+def test_split_kernel_gradients(dev):
+  """BLEND split feature / positional exp kernel: native forward (one combined projection + exp_kernel), composite
+  backward, against CPU autograd through the oracle's restatement of the reference branch."""
+  from helpers import Fixture
+  fx = Fixture('func_transformer_beltrami_expkernel_labels_n1')
+  opt = fx.opt
+  x = fx.t('x')
+  func = G.ODEFuncTransformerAtt(x.shape[1], x.shape[1], opt, Data(x.to(dev), fx.t('edge_index', dev)), dev).to(dev)
+  func.load_state_dict(fx.params, strict=True)
+  func.x0 = fx.t('x0', dev)
+  g = torch.Generator().manual_seed(4)
+  go = torch.randn(x.shape, generator=g)
+  xd = x.to(dev).requires_grad_(True)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  # oracle
+  P = {k: v.clone().requires_grad_(True) for k, v in fx.params.items()}
+  lay = {k[len('multihead_att_layer.'):]: v for k, v in P.items() if k.startswith('multihead_att_layer.')}
+  xc = x.clone().requires_grad_(True)
+  edge = fx.t('func_edge_index')
+  att, _ = R.transformer_attention_split(xc, edge, lay, opt['heads'], opt['feat_hidden_dim'], opt['pos_enc_hidden_dim'],
+                                         opt['attention_norm_idx'], opt['square_plus'])
+  fr = R.rhs_from_attention(xc, edge, att, P['alpha_train'], P['beta_train'], fx.t('x0'), opt['no_alpha_sigmoid'], opt['add_source'])
+  assert_parity(f, fr, what='value')
+  fr.backward(go)
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  named = dict(func.named_parameters())
+  for k in ('multihead_att_layer.Qx.weight', 'multihead_att_layer.Kp.weight', 'multihead_att_layer.Kx.bias',
+            'multihead_att_layer.lengthscale_x', 'multihead_att_layer.output_var_p', 'alpha_train'):
+    assert_parity(named[k].grad.reshape(-1), P[k].grad.reshape(-1), tol=GTOL, what=k)

@@ -19,8 +19,23 @@ def _qk(p, prefix=''):
           p[prefix + 'multihead_att_layer.K.weight'], p[prefix + 'multihead_att_layer.K.bias'])
 
 
+def _is_split(opt):
+  return bool(opt['beltrami'] and opt['attention_type'] == 'exp_kernel')
+
+
+def _split_attention(opt, p, prefix, x, edge, edge_weights=None):
+  lay = prefix + 'multihead_att_layer.'
+  P = {k[len(lay):]: v for k, v in p.items() if k.startswith(lay)}
+  return R.transformer_attention_split(x, edge, P, opt['heads'], opt['feat_hidden_dim'], opt['pos_enc_hidden_dim'],
+                                       opt['attention_norm_idx'], opt['square_plus'], edge_weights,
+                                       opt['reweight_attention'])
+
+
 def _transformer_rhs(fx, p, prefix, edge, x0):
   opt = fx.opt
+  if _is_split(opt):
+    return lambda t, x: R.rhs_from_attention(x, edge, _split_attention(opt, p, prefix, x, edge)[0], p[prefix + 'alpha_train'],
+                                             p[prefix + 'beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'])
   kw = _att_kwargs(opt)
   if opt['attention_type'] == 'exp_kernel':
     kw.update(output_var=p[prefix + 'multihead_att_layer.output_var'], lengthscale=p[prefix + 'multihead_att_layer.lengthscale'])
@@ -38,10 +53,13 @@ def test_transformer_function(name):
   if opt['self_loop_weight'] > 0:
     edge, _ = R.add_remaining_self_loops(edge, None, opt['self_loop_weight'], int(edge.max()) + 1)
   assert torch.equal(edge, fx.t('func_edge_index'))
-  kw = _att_kwargs(opt)
-  if opt['attention_type'] == 'exp_kernel':
-    kw.update(output_var=p['multihead_att_layer.output_var'], lengthscale=p['multihead_att_layer.lengthscale'])
-  att, prods = R.transformer_attention(x, edge, *_qk(p), opt['heads'], **kw)
+  if _is_split(opt):
+    att, prods = _split_attention(opt, p, '', x, edge)
+  else:
+    kw = _att_kwargs(opt)
+    if opt['attention_type'] == 'exp_kernel':
+      kw.update(output_var=p['multihead_att_layer.output_var'], lengthscale=p['multihead_att_layer.lengthscale'])
+    att, prods = R.transformer_attention(x, edge, *_qk(p), opt['heads'], **kw)
   assert_parity(prods, fx.t('prods'), TIGHT, 'prods')
   assert_parity(att, fx.t('attention'), TIGHT, 'attention')
   f = _transformer_rhs(fx, p, '', edge, x0)(0.0, x)
@@ -116,9 +134,12 @@ def _block_rhs(fx):
     if opt['block'] in ('attention', 'mixed', 'hard_attention'):
       # block-level attention layer, evaluated once at x(0); the mixed block's layer carries no edge weights
       ew = None if opt['block'] == 'mixed' else w_n
-      att, _ = R.transformer_attention(x, e_n, p['multihead_att_layer.Q.weight'], p['multihead_att_layer.Q.bias'],
-                                       p['multihead_att_layer.K.weight'], p['multihead_att_layer.K.bias'], opt['heads'],
-                                       edge_weights=ew, reweight=opt['reweight_attention'], **_att_kwargs(opt))
+      if _is_split(opt):
+        att, _ = _split_attention(opt, p, '', x, e_n, ew)
+      else:
+        att, _ = R.transformer_attention(x, e_n, p['multihead_att_layer.Q.weight'], p['multihead_att_layer.Q.bias'],
+                                         p['multihead_att_layer.K.weight'], p['multihead_att_layer.K.bias'], opt['heads'],
+                                         edge_weights=ew, reweight=opt['reweight_attention'], **_att_kwargs(opt))
       w = att
       if opt['block'] == 'mixed':        # block_mixed.py:41-45
         gam = torch.sigmoid(p['gamma'])
