@@ -17,6 +17,7 @@ from .block_constant import ConstantODEblock
 from .block_transformer_attention import AttODEblock
 from .block_mixed import MixedODEblock
 from .block_transformer_hard_attention import HardAttODEblock
+from .block_transformer_rewiring import RewireAttODEblock
 from .early_stop_solver import EarlyStopInt, EarlyStopRK4, EarlyStopDopri5
 from .model_configurations import set_block, set_function, BlockNotDefined, FunctionNotDefined
 from . import synthetic
@@ -24,5 +25,5 @@ from . import synthetic
 __all__ = ['GnpdeError', 'build', 'lib', 'CSRGraph', 'graph_of', 'partition_rows', 'ops', 'MaxNFEException',
            'get_rw_adj', 'gcn_norm_fill_val', 'add_remaining_self_loops', 'odeint', 'odeint_adjoint', 'time_grid',
            'ODEFunc', 'ODEblock', 'LaplacianODEFunc', 'ODEFuncTransformerAtt', 'SpGraphTransAttentionLayer',
-           'ODEFuncAtt', 'SpGraphAttentionLayer', 'ConstantODEblock', 'AttODEblock', 'MixedODEblock', 'HardAttODEblock', 'EarlyStopInt', 'EarlyStopRK4', 'EarlyStopDopri5', 'set_block', 'set_function',
+           'ODEFuncAtt', 'SpGraphAttentionLayer', 'ConstantODEblock', 'AttODEblock', 'MixedODEblock', 'HardAttODEblock', 'RewireAttODEblock', 'EarlyStopInt', 'EarlyStopRK4', 'EarlyStopDopri5', 'set_block', 'set_function',
            'synthetic']

@@ -1,0 +1,133 @@
+"""Block that rewires the graph with its own attention while training -- adds edges (random pairs, or the two-hop
+neighbourhood of the current transition matrix), drops the weakest ones, renormalises -- and always integrates over
+head-mean attention recomputed on the current edge set (reference src/block_transformer_rewiring.py:10-260,
+`--block rewire_attention`).
+
+The rewiring is once-per-forward host-side bookkeeping on device tensors (sort / unique / index_add); the attention
+and every evaluation of f inside the solver stay on the native kernels.  The function's CSR is rebuilt lazily because
+`edge_index` is a new tensor after each rewiring."""
+import numpy as np
+import torch
+
+from .base_classes import ODEblock
+from .function_transformer_attention import SpGraphTransAttentionLayer
+
+
+def _coalesce(index, value, n):
+  """Sum duplicates, entries ordered by (row, col) -- torch_sparse.coalesce(op='add')."""
+  key = index[0] * n + index[1]
+  uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+  out = torch.zeros(uniq.numel(), dtype=value.dtype, device=value.device).index_add_(0, inverse, value)
+  return torch.stack([torch.div(uniq, n, rounding_mode='floor'), uniq % n]), out
+
+
+def _spspmm(index_a, value_a, index_b, value_b, n):
+  """C = A B for COO operands, coalesced (torch_sparse.spspmm(..., coalesced=True)): every entry (i, k) of A is
+  paired with row k of B through B's row pointer."""
+  order = torch.argsort(index_b[0] * n + index_b[1])
+  b_row, b_col, b_val = index_b[0][order], index_b[1][order], value_b[order]
+  rowptr = torch.zeros(n + 1, dtype=torch.long, device=b_row.device)
+  rowptr[1:] = torch.cumsum(torch.bincount(b_row, minlength=n), 0)
+  counts = rowptr[index_a[1] + 1] - rowptr[index_a[1]]
+  src = torch.repeat_interleave(torch.arange(index_a.shape[1], device=counts.device), counts)
+  first = torch.cumsum(counts, 0) - counts
+  pos = torch.arange(src.numel(), device=counts.device) - first[src] + rowptr[index_a[1]][src]
+  return _coalesce(torch.stack([index_a[0][src], b_col[pos]]), value_a[src] * b_val[pos], n)
+
+
+class RewireAttODEblock(ODEblock):
+  def __init__(self, odefunc, regularization_fns, opt, data, device, t=torch.tensor([0, 1]), gamma=0.5):
+    super(RewireAttODEblock, self).__init__(odefunc, regularization_fns, opt, data, device, t)
+    assert opt['att_samp_pct'] > 0 and opt['att_samp_pct'] <= 1, "attention sampling threshold must be in (0,1]"
+    self.opt = opt
+    self._second_function(odefunc, opt, data, device)
+    self.num_nodes = data.num_nodes
+    self.data_edge_index, _ = self._rw_graph(data, opt, device)   # changed by the rewiring
+    self._use_default_integrators(opt)
+    if opt['function'] not in {'GAT', 'transformer'}:
+      self.multihead_att_layer = SpGraphTransAttentionLayer(opt['hidden_dim'], opt['hidden_dim'], opt, device,
+                                                            edge_weights=self.odefunc.edge_weight).to(device)
+
+  def get_attention_weights(self, x):
+    if self.opt['function'] not in {'GAT', 'transformer'}:
+      attention, values = self.multihead_att_layer(x, self.data_edge_index)
+    else:
+      attention, values = self.odefunc.multihead_att_layer(x, self.data_edge_index)
+    return attention
+
+  def renormalise_attention(self, attention):
+    index = self.odefunc.edge_index[self.opt['attention_norm_idx']]
+    sums = torch.zeros(self.num_nodes, dtype=attention.dtype, device=attention.device).index_add_(0, index, attention)
+    return attention / (sums[index] + 1e-16)
+
+  def add_random_edges(self):
+    """M uniformly random (ordered) node pairs, duplicates of existing edges dropped (reference :52-66; same numpy
+    generator call, so a seeded run draws the same pairs)."""
+    M = int(self.num_nodes * (1 / (1 - (self.opt['rw_addD'])) - 1))
+    with torch.no_grad():
+      new_edges = torch.tensor(np.random.choice(self.num_nodes, size=(2, M), replace=True, p=None))
+      cat = torch.cat([self.data_edge_index, new_edges.to(self.data_edge_index)], dim=1)
+      self.data_edge_index = torch.unique(cat, sorted=False, return_inverse=False, return_counts=False, dim=1)
+      self.odefunc.edge_index = self.data_edge_index
+
+  def add_khop_edges(self, k=2, rm_self_loops=True):
+    """(A + A^2 without its diagonal) / 2 on the current transition matrix (reference :68-86)."""
+    n = self.num_nodes
+    for _ in range(k - 1):
+      ei, ew = self.odefunc.edge_index, self.odefunc.edge_weight
+      new_edges, new_weights = _spspmm(ei, ew, ei, ew, n)
+      keep = new_edges[0] != new_edges[1]
+      new_edges, new_weights = new_edges[:, keep], new_weights[keep]
+      both_index = torch.cat([ei, new_edges], dim=1)
+      both_value = torch.cat([ew, new_weights], dim=0) / 2
+      ei, ew = _coalesce(both_index, both_value, n)
+      self.data_edge_index = ei
+      self.odefunc.edge_index = self.data_edge_index
+      self.odefunc.attention_weights = ew
+
+  def densify_edges(self):
+    kind = self.opt['new_edges']
+    if kind == 'random':
+      self.add_random_edges()
+    elif kind == 'random_walk':
+      raise NotImplementedError("new_edges='random_walk' is not implemented in the reference either "
+                                '(its add_rw_edges is commented out)')
+    elif kind == 'k_hop_lap':
+      pass
+    elif kind == 'k_hop_att':
+      self.add_khop_edges(k=2)
+
+  def threshold_edges(self, x, threshold):
+    if self.opt['new_edges'] == 'k_hop_att' and self.opt['sparsify'] == 'S_hat':   # sparsify on (A + A^2) / 2
+      mean_att = self.odefunc.attention_weights
+    else:                                                                           # on recomputed attention
+      mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)
+    if self.opt['use_flux']:
+      delta = torch.linalg.norm(x[self.data_edge_index[0, :], :] - x[self.data_edge_index[1, :], :], dim=1)
+      mean_att = mean_att * delta
+    mask = mean_att > threshold
+    self.odefunc.edge_index = self.data_edge_index[:, mask]
+    sampled_attention_weights = self.renormalise_attention(mean_att[mask])
+    print('retaining {} of {} edges'.format(self.odefunc.edge_index.shape[1], self.data_edge_index.shape[1]))
+    self.data_edge_index = self.data_edge_index[:, mask]
+    self.odefunc.edge_weight = sampled_attention_weights
+    self.odefunc.attention_weights = sampled_attention_weights
+
+  def forward(self, x):
+    if self.training:
+      with torch.no_grad():
+        attention_weights = self.get_attention_weights(x)
+        self.odefunc.attention_weights = attention_weights.mean(dim=1, keepdim=False)
+        pre_count = self.odefunc.edge_index.shape[1]
+        self.densify_edges()
+        post_count = self.odefunc.edge_index.shape[1]
+        pc_change = post_count / pre_count - 1
+        threshold = torch.quantile(self.odefunc.edge_weight, 1 / (pc_change - self.opt['rw_addD']))
+        self.threshold_edges(x, threshold)
+    self.odefunc.edge_index = self.data_edge_index
+    mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)
+    self.odefunc.edge_weight = mean_att
+    self.odefunc.attention_weights = mean_att
+    self.reg_odefunc.odefunc.edge_index, self.reg_odefunc.odefunc.edge_weight = self.odefunc.edge_index, self.odefunc.edge_weight
+    self.reg_odefunc.odefunc.attention_weights = self.odefunc.attention_weights
+    return self._integrate(x, {'step_size': self.opt['step_size']})

@@ -1,5 +1,5 @@
 """String -> class registry with the reference's names (src/model_configurations.py:17-44).
-Blocks outside SURVEY.md section 8's current rows raise BlockNotDefined with a pointer to it."""
+All five blocks and three functions of the reference are registered."""
 from .function_transformer_attention import ODEFuncTransformerAtt
 from .function_GAT_attention import ODEFuncAtt
 from .function_laplacian_diffusion import LaplacianODEFunc
@@ -7,6 +7,7 @@ from .block_transformer_attention import AttODEblock
 from .block_constant import ConstantODEblock
 from .block_mixed import MixedODEblock
 from .block_transformer_hard_attention import HardAttODEblock
+from .block_transformer_rewiring import RewireAttODEblock
 
 
 class BlockNotDefined(Exception):
@@ -18,7 +19,7 @@ class FunctionNotDefined(Exception):
 
 
 _BLOCKS = {'attention': AttODEblock, 'constant': ConstantODEblock, 'mixed': MixedODEblock,
-           'hard_attention': HardAttODEblock}
+           'hard_attention': HardAttODEblock, 'rewire_attention': RewireAttODEblock}
 _FUNCTIONS = {'laplacian': LaplacianODEFunc, 'GAT': ODEFuncAtt, 'transformer': ODEFuncTransformerAtt}
 
 
@@ -26,8 +27,6 @@ def set_block(opt):
   name = opt['block']
   if name in _BLOCKS:
     return _BLOCKS[name]
-  if name in ('rewire_attention',):
-    raise BlockNotDefined('block %r is a "next" row of SURVEY.md section 8f, not built yet' % name)
   raise BlockNotDefined
 
 

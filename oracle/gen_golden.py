@@ -33,6 +33,7 @@ from block_constant import ConstantODEblock  # noqa: E402
 from block_transformer_attention import AttODEblock  # noqa: E402
 from block_mixed import MixedODEblock  # noqa: E402
 from block_transformer_hard_attention import HardAttODEblock  # noqa: E402
+from block_transformer_rewiring import RewireAttODEblock  # noqa: E402
 from GNN import GNN  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
@@ -296,6 +297,54 @@ def gen_beltrami():
                                                        'nfe': np.int64(block.odefunc.nfe)}, block)
 
 
+def gen_rewire():
+  """RewireAttODEblock (src/block_transformer_rewiring.py): the eval forward, and training forwards whose rewiring
+  (two-hop densification or random pairs, quantile threshold, renormalisation) is recorded edge by edge."""
+  import io, contextlib
+  n, d = 90, 24
+  ei = make_graph(n, 4, 71)
+  g = torch.Generator().manual_seed(72)
+  x = torch.randn(n, d, generator=g)
+  base = dict(block='rewire_attention', function='laplacian', method='rk4', time=2.0, att_samp_pct=1.0, use_flux=False,
+              rw_addD=0.02, new_edges='k_hop_att', sparsify='S_hat')
+  cases = {
+    'khop_shat': {},
+    'khop_recalc_flux': dict(sparsify='recalc_att', use_flux=True),
+    'random': dict(new_edges='random', rw_addD=0.93),
+    'khop_transformer': dict(function='transformer', method='euler'),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, **base, **over}
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt}[opt['function']]
+    block = RewireAttODEblock(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+    randomise(block, 900 + i)
+    block.eval()
+    block.set_x0(x)
+    with torch.no_grad():
+      z_eval = block(x)
+    nfe_eval = block.odefunc.nfe
+    rec = {'edge_index': ei, 'x': x, 'z': z_eval, 'nfe': np.int64(nfe_eval)}
+    block.train()
+    np.random.seed(1234 + i)
+    rounds = 0
+    for rnd in (1, 2):                      # the rewiring accumulates from one training forward to the next
+      block.set_x0(x)
+      try:
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+          z_train = block(x)
+      except RuntimeError as err:           # quantile level 1 / (pc_change - rw_addD) outside [0, 1]: the reference stops
+        assert 'quantile' in str(err)
+        break
+      rounds = rnd
+      rec['z_train%d' % rnd] = z_train
+      rec['train_edge_index%d' % rnd] = block.odefunc.edge_index
+      rec['train_weights%d' % rnd] = block.odefunc.edge_weight
+    rec['rounds'] = np.int64(rounds)
+    save('rewire_' + name, opt, rec, block)
+    print('    edges: %d -> %s (%d training forwards before the quantile level leaves [0, 1])' % (
+      ei.shape[1] + n, ' -> '.join(str(rec['train_edge_index%d' % r].shape[1]) for r in range(1, rounds + 1)), rounds))
+
+
 def gen_early():
   """Test-time integrators with early stopping (reference src/early_stop_solver.py), installed on a block the way
   GNNEarly does (src/GNN_early.py:28-36): best (train, val, test, time) and the accuracies after every step."""
@@ -405,5 +454,6 @@ if __name__ == '__main__':
   gen_blocks()
   gen_gnn()
   gen_beltrami()
+  gen_rewire()
   gen_early()
   gen_adjoint()

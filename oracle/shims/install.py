@@ -159,6 +159,15 @@ def coalesce(index, value, m, n, op='add'):
   return new_index, value
 
 
+def spspmm(indexA, valueA, indexB, valueB, m, k, n, coalesced=False):
+  """torch_sparse.spspmm 0.6.9: sparse-sparse matrix product of COO operands; returns (index, value) of the
+  coalesced product (row-major order)."""
+  A = torch.sparse_coo_tensor(indexA, valueA, (m, k)).coalesce()
+  B = torch.sparse_coo_tensor(indexB, valueB, (k, n)).coalesce()
+  C = torch.sparse.mm(A, B).coalesce()
+  return C.indices(), C.values()
+
+
 def to_undirected(edge_index, num_nodes=None):
   N = maybe_num_nodes(edge_index, num_nodes)
   row, col = edge_index
@@ -723,7 +732,7 @@ def install():
   if 'torch_scatter' in sys.modules and getattr(sys.modules['torch_scatter'], '_gnpde_shim', False):
     return
   _mod('torch_scatter', inert=True, _gnpde_shim=True, scatter_add=scatter_add, scatter=scatter)
-  _mod('torch_sparse', inert=True, spmm=spmm, coalesce=coalesce)
+  _mod('torch_sparse', inert=True, spmm=spmm, coalesce=coalesce, spspmm=spspmm)
 
   _mod('torch_geometric', inert=True)
   _mod('torch_geometric.nn', inert=True)

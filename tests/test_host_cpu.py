@@ -233,3 +233,24 @@ def test_product_does_not_import_oracle():
         src = open(os.path.join(dirpath, fn)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), '%s imports the oracle' % fn
         assert 'restate' not in src and 'ref_env' not in src, '%s references oracle modules' % fn
+
+
+def test_rewiring_sparse_helpers_match_dense():
+  """Host helpers of the rewiring block: COO product through the row pointer and duplicate-summing coalesce,
+  against dense matrices (what torch_sparse.spspmm / coalesce compute for the reference)."""
+  from gnpde_amd.block_transformer_rewiring import _spspmm, _coalesce
+  g = torch.Generator().manual_seed(0)
+  n = 23
+  ia = torch.randint(0, n, (2, 90), generator=g)
+  va = torch.rand(90, generator=g)
+  ib = torch.randint(0, n, (2, 70), generator=g)
+  vb = torch.rand(70, generator=g)
+  dense = lambda i, v: torch.zeros(n, n).index_put_((i[0], i[1]), v, accumulate=True)  # noqa: E731
+  ic, vc = _spspmm(ia, va, ib, vb, n)
+  assert torch.allclose(dense(ic, vc), dense(ia, va) @ dense(ib, vb), atol=1e-6)
+  key = ic[0] * n + ic[1]
+  assert torch.all(key[1:] > key[:-1]), 'product is not coalesced in row-major order'
+  i2, v2 = _coalesce(torch.cat([ia, ia[:, :10]], 1), torch.cat([va, va[:10]]), n)
+  assert torch.allclose(dense(i2, v2), dense(ia, va) + dense(ia[:, :10], va[:10]), atol=1e-6)
+  empty_i, empty_v = _spspmm(ia[:, :0], va[:0], ib, vb, n)
+  assert empty_i.shape == (2, 0) and empty_v.numel() == 0

@@ -131,7 +131,7 @@ def _block_rhs(fx):
     e_n, w_n = R.gcn_norm_fill_val(ei, None, opt['self_loop_weight'], n)
   if opt['function'] == 'laplacian':
     w = w_n
-    if opt['block'] in ('attention', 'mixed', 'hard_attention'):
+    if opt['block'] in ('attention', 'mixed', 'hard_attention', 'rewire_attention'):
       # block-level attention layer, evaluated once at x(0); the mixed block's layer carries no edge weights
       ew = None if opt['block'] == 'mixed' else w_n
       if _is_split(opt):
@@ -144,14 +144,14 @@ def _block_rhs(fx):
       if opt['block'] == 'mixed':        # block_mixed.py:41-45
         gam = torch.sigmoid(p['gamma'])
         w = att.mean(dim=1) * (1 - gam) + w_n * gam
-      elif opt['block'] == 'hard_attention':   # eval mode: all edges, head-mean attention (:67-69)
-        w = att.mean(dim=1)
+      elif opt['block'] in ('hard_attention', 'rewire_attention'):   # eval mode: all edges, head-mean attention
+        w = att.mean(dim=1)                    # (block_transformer_hard_attention.py:67-69, block_transformer_rewiring.py:203-207)
     return lambda t, y: R.rhs_laplacian(y, e_n, w, p[pre + 'alpha_train'], p[pre + 'beta_train'], x0,
                                         opt['no_alpha_sigmoid'], opt['add_source'])
   # transformer / GAT functions use their own self-loop-augmented edge list, not the block's -- except under the
   # hard-attention block, which overwrites the function's edge_index with its own (:68)
   edge, _ = R.add_remaining_self_loops(ei, None, opt['self_loop_weight'], int(ei.max()) + 1)
-  if opt['block'] == 'hard_attention':
+  if opt['block'] in ('hard_attention', 'rewire_attention'):
     edge = e_n
   if opt['function'] == 'transformer':
     return _transformer_rhs(fx, p, pre, edge, x0)
@@ -160,7 +160,7 @@ def _block_rhs(fx):
                                 opt['add_source'], opt['leaky_relu_slope'], opt['attention_norm_idx'])
 
 
-@pytest.mark.parametrize('name', [n for n in fixtures('block_') if 'dopri5' not in n])
+@pytest.mark.parametrize('name', [n for n in fixtures('block_') if 'dopri5' not in n] + fixtures('rewire_'))
 def test_block_fixed_step(name):
   fx = Fixture(name)
   z = R.odeint_fixed(_block_rhs(fx), fx.t('x'), fx.opt['time'], fx.opt['step_size'], fx.opt['method'])
