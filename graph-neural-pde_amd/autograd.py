@@ -29,6 +29,18 @@ def _alpha(func):
   return func.alpha_train if func.opt['no_alpha_sigmoid'] else torch.sigmoid(func.alpha_train)
 
 
+def _dalpha(g, f, x, alpha_train, beta_train, gx0, sig, aggregate):
+  """d/d alpha_train of  f = a (A x - x) + b x0.  With a = sigmoid(alpha_train) > 0 the bracket is (f - b x0) / a, so
+  sum g . (A x - x) costs two dot products on tensors that already exist (da/dalpha_train = a (1 - a) cancels the
+  division); with a raw alpha (which may be 0) the aggregation is recomputed."""
+  if sig:
+    s = (g * f).sum()
+    if gx0 is not None:
+      s = s - beta_train.reshape(()) * gx0
+    return s * (1 - torch.sigmoid(alpha_train.reshape(())))
+  return (g * (aggregate() - x)).sum()
+
+
 # --------------------------------------------------------------------------------------------------
 # GRAND-l: native forward and backward
 # --------------------------------------------------------------------------------------------------
@@ -41,13 +53,13 @@ class _LaplacianRhs(torch.autograd.Function):
     with torch.no_grad():
       f = ops.rhs_eval(func._descriptor(x), x)
     ctx.func, ctx.graph = func, graph
-    ctx.save_for_backward(x, w_csr.clone(), edge_values, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0))
+    ctx.save_for_backward(x, w_csr.clone(), edge_values, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0), f)
     ctx.has_source = x0 is not None
     return f
 
   @staticmethod
   def backward(ctx, g):
-    x, w_csr, edge_values, alpha_train, beta_train, x0 = ctx.saved_tensors
+    x, w_csr, edge_values, alpha_train, beta_train, x0, f = ctx.saved_tensors
     func, graph = ctx.func, ctx.graph
     sig = not func.opt['no_alpha_sigmoid']
     g = _lib.f32c(g)
@@ -69,15 +81,11 @@ class _LaplacianRhs(torch.autograd.Function):
           dw = (dw_e / edge_values.shape[1]).unsqueeze(1).expand_as(edge_values).contiguous()
         else:
           dw = dw_e
+      gx0 = (g * x0).sum() if ctx.has_source and (need[2] or need[3]) else None
       if need[2]:
-        ax = ops.spmm(graph, w_csr, x)
-        s = (g * (ax - x)).sum()
-        if sig:
-          sa = torch.sigmoid(alpha_train)
-          s = s * sa * (1 - sa)
-        dalpha = s.reshape(alpha_train.shape)
+        dalpha = _dalpha(g, f, x, alpha_train, beta_train, gx0, sig, lambda: ops.spmm(graph, w_csr, x)).reshape(alpha_train.shape)
       if need[3] and ctx.has_source:
-        dbeta = (g * x0).sum().reshape(beta_train.shape)
+        dbeta = gx0.reshape(beta_train.shape)
     return dx, dw, dalpha, dbeta, None, None
 
 
@@ -99,12 +107,12 @@ class _TransformerRhs(torch.autograd.Function):
       f = ops.rhs_eval(func._descriptor(x), x)
     ctx.func = func
     ctx.has_source = x0 is not None
-    ctx.save_for_backward(x, x0 if x0 is not None else x.new_zeros(0), alpha_train, beta_train)
+    ctx.save_for_backward(x, x0 if x0 is not None else x.new_zeros(0), alpha_train, beta_train, f)
     return f
 
   @staticmethod
   def backward(ctx, g):
-    x, x0, alpha_train, beta_train = ctx.saved_tensors
+    x, x0, alpha_train, beta_train, f = ctx.saved_tensors
     func = ctx.func
     lay = func.multihead_att_layer
     sig = not func.opt['no_alpha_sigmoid']
@@ -122,32 +130,30 @@ class _TransformerRhs(torch.autograd.Function):
       w_edge = torch.empty(graph.e, dtype=torch.float32, device=g.device)
       w_edge[graph.perm_long] = w_csr[:graph.e]
       dx = ops.spmm_rhs(gt, ops.edge_to_csr_mean(gt, w_edge), g, alpha_train, None, None, sig)
-      # through the attention weights
-      dw = ops.sddmm(graph, g, x, scale=alpha_train, scale_sigmoid=sig)
-      ds = ops.softmax_rows_bwd(graph, att_edge, dw, edge_w_csr=lay._reweight_csr(graph))
+      # through the attention weights: r_e = g_row . x_col (unscaled), alpha applied inside the softmax backward
+      r = ops.sddmm(graph, g, x)
+      ds = ops.softmax_rows_bwd(graph, att_edge, r, edge_w_csr=lay._reweight_csr(graph), scale=alpha_train, scale_sigmoid=sig)
       inv = 1.0 / math.sqrt(dk)
-      dq = ops.head_spmm(graph, ds, qk[:, A:], h, dk, inv, by_column=False)
-      dkk = ops.head_spmm(graph, ds, qk[:, :A], h, dk, inv, by_column=True)
-      dqk = torch.cat([dq, dkk], dim=1)
+      dqk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=x.device)
+      ops.head_spmm(graph, ds, qk[:, A:], h, dk, inv, by_column=False, out=dqk[:, :A])
+      ops.head_spmm(graph, ds, qk[:, :A], h, dk, inv, by_column=True, out=dqk[:, A:])
       dx = dx + ops.linear(dqk, wqk.t().contiguous())          # [N,2A] x [2A,d] on the MFMA kernel
       dwq = dbq = dwk = dbk = dalpha = dbeta = None
-      if need[1]:
-        dwq = dq.t().mm(x)                                      # [A,N] x [N,d]: plain library GEMM
-      if need[2]:
-        dbq = dq.sum(dim=0)
-      if need[3]:
-        dwk = dkk.t().mm(x)
-      if need[4]:
-        dbk = dkk.sum(dim=0)
+      if need[1] or need[3]:
+        dw_all = ops.tall_skinny_gram(dqk, x)                   # [2A,N] x [N,d], both weight gradients at once
+        dwq, dwk = (dw_all[:A] if need[1] else None), (dw_all[A:] if need[3] else None)
+      if need[2] or need[4]:
+        db_all = dqk.sum(dim=0)
+        dbq, dbk = (db_all[:A] if need[2] else None), (db_all[A:] if need[4] else None)
+      gx0 = (g * x0).sum() if ctx.has_source and (need[5] or need[6]) else None
       if need[5]:
-        ax = ops.spmm(graph, w_csr, x)
-        s = (g * (ax - x)).sum()
+        # raw alpha: sum_i g_i . (A x)_i = sum_e w_e (g_row . x_col), no second aggregation pass
         if sig:
-          sa = torch.sigmoid(alpha_train)
-          s = s * sa * (1 - sa)
-        dalpha = s.reshape(alpha_train.shape)
+          dalpha = _dalpha(g, f, x, alpha_train, beta_train, gx0, True, None).reshape(alpha_train.shape)
+        else:
+          dalpha = (torch.dot(w_csr[:graph.e], r[:graph.e]) - (g * x).sum()).reshape(alpha_train.shape)
       if need[6] and ctx.has_source:
-        dbeta = (g * x0).sum().reshape(beta_train.shape)
+        dbeta = gx0.reshape(beta_train.shape)
     return (dx if need[0] else None), dwq, dbq, dwk, dbk, dalpha, dbeta, None, None
 
 

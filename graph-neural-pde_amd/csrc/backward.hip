@@ -3,7 +3,7 @@
 // src/function_transformer_attention.py:38-53) without materialising [E,d_k,h] temporaries:
 //   w_e = (1/H) sum_h a_eh,  a_eh = softmax_row(s_eh),  s_eh = q_row,h . k_col,h / sqrt(d_k)
 //   given dL/dw_e (from gnpde_sddmm):
-//     ds_eh = (a_eh / H) (dw_e - sum_{e' in row} a_e'h dw_e')            gnpde_softmax_rows_bwd
+//     ds_eh = scale (a_eh / H) (dw_e - sum_{e' in row} a_e'h dw_e')      gnpde_softmax_rows_bwd
 //     dq_i,h = (1/sqrt d_k) sum_{e in row i} ds_eh k_col(e),h            gnpde_head_spmm (rows)
 //     dk_j,h = (1/sqrt d_k) sum_{e in col j} ds_eh q_row(e),h            gnpde_head_spmm (columns, CSC view)
 // All reductions are segment-local (no atomics, deterministic).
@@ -18,24 +18,80 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
-// one wavefront per row; heads in an outer loop; att is in the CALLER's edge order (indexed through perm)
+// Segments (rows, or columns through the CSC view) longer than GNPDE_LONG_ROW are "hub" segments: in the kernels
+// below the first n_long blocks of the grid take one hub each with all four wavefronts (partial sums through the
+// LDS, fixed order), the remaining blocks take one ordinary segment per wavefront and skip the hubs.  Without
+// this a power-law graph's 13 K-entry rows serialise in single wavefronts and set the kernel time.
+__device__ __forceinline__ float block_sum(float v, float* red) {   // all 256 threads participate
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ds[p, :] = scale * a[p, :] / H * (dw[p] - sum_{p' in row} a[p', head] dw[p'])   [* edge_w[p]]
+// att is in the CALLER's edge order (indexed through perm).  HT = compile-time head count (0: run-time loop).
+template <int HT>
 __global__ __launch_bounds__(kBlock) void softmax_rows_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ perm,
                                                                  const float* __restrict__ att_edge, const float* __restrict__ dw,
-                                                                 const float* __restrict__ edge_w, int n, int h,
-                                                                 float* __restrict__ ds) {
+                                                                 const float* __restrict__ edge_w, const float* __restrict__ scale_ptr,
+                                                                 int scale_sigmoid, int n, int h, const int* __restrict__ long_rows,
+                                                                 int n_long, float* __restrict__ ds) {
+  __shared__ float red[kWavesPerBlock];
+  constexpr int HC = HT > 0 ? HT : 1;
   const int lane = threadIdx.x & (kWave - 1);
-  const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
-  if (row >= n) return;
+  const bool hub = static_cast<int>(blockIdx.x) < n_long;
+  int row;
+  if (hub) {
+    row = long_rows[blockIdx.x];
+  } else {
+    row = (static_cast<int>(blockIdx.x) - n_long) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= n) return;
+  }
   const int b = rowptr[row], e = rowptr[row + 1];
-  const float inv_h = 1.0f / static_cast<float>(h);
-  for (int head = 0; head < h; ++head) {
-    float c = 0.f;
-    for (int p = b + lane; p < e; p += kWave) c = fmaf(att_edge[static_cast<size_t>(perm[p]) * h + head], dw[p], c);
-    c = wsum(c);
-    for (int p = b + lane; p < e; p += kWave) {
-      float v = att_edge[static_cast<size_t>(perm[p]) * h + head] * inv_h * (dw[p] - c);
-      if (edge_w != nullptr) v *= edge_w[p];
-      ds[static_cast<size_t>(p) * h + head] = v;
+  if (!hub && e - b > GNPDE_LONG_ROW) return;
+  float scale = 1.0f / static_cast<float>(h);
+  if (scale_ptr != nullptr) {
+    float sc = *scale_ptr;
+    if (scale_sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+    scale *= sc;
+  }
+  const int first = hub ? static_cast<int>(threadIdx.x) : lane;
+  const int step = hub ? kBlock : kWave;
+  if constexpr (HT > 0) {
+    float c[HC];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) c[i] = 0.f;
+    for (int p = b + first; p < e; p += step) {
+      const float* ar = att_edge + static_cast<size_t>(perm[p]) * HC;
+      const float d = dw[p];
+#pragma unroll
+      for (int i = 0; i < HC; ++i) c[i] = fmaf(ar[i], d, c[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < HC; ++i) c[i] = hub ? block_sum(c[i], red) : wsum(c[i]);
+    for (int p = b + first; p < e; p += step) {
+      const float* ar = att_edge + static_cast<size_t>(perm[p]) * HC;
+      const float d = dw[p];
+      const float ew = edge_w != nullptr ? edge_w[p] : 1.0f;
+#pragma unroll
+      for (int i = 0; i < HC; ++i) {
+        float v = ar[i] * scale * (d - c[i]);
+        if (edge_w != nullptr) v *= ew;
+        ds[static_cast<size_t>(p) * HC + i] = v;
+      }
+    }
+  } else {
+    for (int head = 0; head < h; ++head) {
+      float c = 0.f;
+      for (int p = b + first; p < e; p += step) c = fmaf(att_edge[static_cast<size_t>(perm[p]) * h + head], dw[p], c);
+      c = hub ? block_sum(c, red) : wsum(c);
+      for (int p = b + first; p < e; p += step) {
+        float v = att_edge[static_cast<size_t>(perm[p]) * h + head] * scale * (dw[p] - c);
+        if (edge_w != nullptr) v *= edge_w[p];
+        ds[static_cast<size_t>(p) * h + head] = v;
+      }
     }
   }
 }
@@ -46,16 +102,28 @@ template <int A4>
 __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict__ segptr, const int* __restrict__ segpos,
                                                           const int* __restrict__ other_of_pos, const float* __restrict__ ds,
                                                           int h, int dk, const float* __restrict__ feat, int ldf, float scale,
-                                                          int n, float* __restrict__ out, int ldo) {
-  constexpr int ES = kWave / A4;  // edges per iteration
+                                                          int n, const int* __restrict__ long_segs, int n_long,
+                                                          float* __restrict__ out, int ldo) {
+  __shared__ float part[kWavesPerBlock][A4][4];
+  constexpr int ES = kWave / A4;  // edges per wavefront iteration
   const int lane = threadIdx.x & (kWave - 1);
-  const int seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
-  if (seg >= n) return;
+  const int wave = threadIdx.x >> 6;
+  const bool hub = static_cast<int>(blockIdx.x) < n_long;
+  int seg;
+  if (hub) {
+    seg = long_segs[blockIdx.x];
+  } else {
+    seg = (static_cast<int>(blockIdx.x) - n_long) * kWavesPerBlock + wave;
+    if (seg >= n) return;
+  }
   const int es = lane / A4, a4 = lane % A4;
   const int head = (a4 * 4) / dk;
   const int b = segptr[seg], e = segptr[seg + 1];
+  if (!hub && e - b > GNPDE_LONG_ROW) return;
+  const int first = hub ? wave * ES + es : es;
+  const int step = hub ? ES * kWavesPerBlock : ES;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int t = b + es; t < e; t += ES) {
+  for (int t = b + first; t < e; t += step) {
     const int p = segpos != nullptr ? segpos[t] : t;
     const int o = other_of_pos[p];
     const float w = ds[static_cast<size_t>(p) * h + head];
@@ -67,6 +135,16 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
   for (int off = A4; off < kWave; off <<= 1)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+  if (hub) {
+    if (es == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][a4][i] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (part[0][a4][i] + part[1][a4][i]) + (part[2][a4][i] + part[3][a4][i]);
+  }
   if (es == 0)
     *reinterpret_cast<float4*>(out + static_cast<size_t>(seg) * ldo + a4 * 4) =
         make_float4(scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]);
@@ -76,12 +154,26 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
 }  // namespace gnpde
 
 extern "C" int gnpde_softmax_rows_bwd(const gnpde_graph_t* g, const float* att_edge, int32_t heads, const float* dw_csr,
-                                      const float* edge_w_csr, float* ds_csr, void* stream) {
+                                      const float* edge_w_csr, const float* scale, int32_t scale_sigmoid, float* ds_csr,
+                                      void* stream) {
   using namespace gnpde;
   GNPDE_CHECK_ARG(g && g->perm && att_edge && dw_csr && ds_csr && heads >= 1, GNPDE_EINVAL, "softmax_rows_bwd: bad arguments");
+  GNPDE_CHECK_ARG(g->n_long_rows == 0 || g->long_rows, GNPDE_EINVAL, "softmax_rows_bwd: graph has long rows but no list of them");
   if (g->n == 0 || g->e == 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), g->rowptr, g->perm, att_edge, dw_csr, edge_w_csr, g->n, heads, ds_csr);
+  const int nl = g->n_long_rows;
+  const dim3 grid(static_cast<unsigned>(nl + (g->n + kWavesPerBlock - 1) / kWavesPerBlock));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define GNPDE_SB(HH) \
+  hipLaunchKernelGGL((softmax_rows_bwd_kernel<HH>), grid, dim3(kBlock), 0, s, g->rowptr, g->perm, att_edge, dw_csr, edge_w_csr, \
+                     scale, scale_sigmoid, g->n, heads, g->long_rows, nl, ds_csr)
+  switch (heads) {
+    case 1: GNPDE_SB(1); break;
+    case 2: GNPDE_SB(2); break;
+    case 4: GNPDE_SB(4); break;
+    case 8: GNPDE_SB(8); break;
+    default: GNPDE_SB(0); break;
+  }
+#undef GNPDE_SB
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -99,11 +191,14 @@ extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const 
   const int* segptr = by_column ? g->cscptr : g->rowptr;
   const int* segpos = by_column ? g->cscpos : nullptr;
   const int* other = by_column ? g->rowidx : g->colidx;
-  const unsigned grid = static_cast<unsigned>((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+  const int* long_segs = by_column ? g->long_cols : g->long_rows;
+  const int nl = by_column ? g->n_long_cols : g->n_long_rows;
+  GNPDE_CHECK_ARG(nl == 0 || long_segs, GNPDE_EINVAL, "head_spmm: graph has long segments but no list of them");
+  const unsigned grid = static_cast<unsigned>(nl + (g->n + kWavesPerBlock - 1) / kWavesPerBlock);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define GNPDE_HS(N4) \
   hipLaunchKernelGGL((head_spmm_kernel<N4>), dim3(grid), dim3(kBlock), 0, s, segptr, segpos, other, ds_csr, heads, dk, feat, ldf, \
-                     scale, g->n, out, ldo)
+                     scale, g->n, long_segs, nl, out, ldo)
   switch (a4) {
     case 1: GNPDE_HS(1); break;
     case 2: GNPDE_HS(2); break;

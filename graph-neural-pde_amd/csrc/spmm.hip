@@ -214,22 +214,48 @@ int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // SDDMM: out[p] = scale * a[row_p] . b[col_p] for every stored entry -- the gradient of the aggregation
 // w.r.t. the edge weights (d w_e = alpha' g_row . x_col), needed when attention_weights carry gradients.
-// One wavefront per row (a_row slice kept in registers), L lanes per neighbour, xor-butterfly dot.
+// Same work items as the aggregation (512-entry chunks of the hub rows first, then one wavefront per row, XCD-aware
+// block order), a_row slice kept in registers, L lanes per neighbour, U independent gathers in flight,
+// xor-butterfly dot.  Entries are independent, so the hub chunks need no second pass.
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int L, int K>
-__global__ __launch_bounds__(kBlock) void sddmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
-                                                      const float* __restrict__ a, const float* __restrict__ b, int n, int d,
-                                                      int lda, int ldb, const float* __restrict__ scale_ptr, int scale_sigmoid,
-                                                      float* __restrict__ out) {
+struct SddmmArgs {
+  int n, n_long_chunks;
+  const int* __restrict__ rowptr;
+  const int* __restrict__ colidx;
+  const int* __restrict__ lc_row;
+  const int* __restrict__ lc_begin;
+  const int* __restrict__ lc_end;
+  const float* __restrict__ a;
+  const float* __restrict__ b;
+  int d, lda, ldb;
+  const float* __restrict__ scale_ptr;
+  int scale_sigmoid;
+  float* __restrict__ out;
+};
+
+template <int VEC, int L, int K, int U>
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(const SddmmArgs s) {
   constexpr int G = kWave / L;
   const int lane = threadIdx.x & (kWave - 1);
-  const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6));
-  if (row >= n) return;
+  const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blk) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  int row, e0, e1;
+  if (item >= s.n_long_chunks) {
+    row = item - s.n_long_chunks;
+    if (row >= s.n) return;
+    e0 = s.rowptr[row];
+    e1 = s.rowptr[row + 1];
+    if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed as chunks
+  } else {
+    row = s.lc_row[item];
+    e0 = s.lc_begin[item];
+    e1 = s.lc_end[item];
+  }
   const int sub = lane / L, cl = lane % L;
   float scale = 1.0f;
-  if (scale_ptr != nullptr) {
-    scale = *scale_ptr;
-    if (scale_sigmoid) scale = 1.0f / (1.0f + expf(-scale));
+  if (s.scale_ptr != nullptr) {
+    scale = *s.scale_ptr;
+    if (s.scale_sigmoid) scale = 1.0f / (1.0f + expf(-scale));
   }
   float av[K][VEC];
 #pragma unroll
@@ -237,44 +263,58 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int* __restrict__ r
     const int col = (k * L + cl) * VEC;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) av[k][v] = 0.0f;
-    if (col < d) load_vec<VEC>(a + static_cast<size_t>(row) * lda + col, av[k]);
+    if (col < s.d) load_vec<VEC>(s.a + static_cast<size_t>(row) * s.lda + col, av[k]);
   }
-  const int e0 = rowptr[row], e1 = rowptr[row + 1];
-  for (int j = e0; j < e1; j += G) {
-    const int e = j + sub;
-    float p = 0.0f;
-    if (e < e1) {
-      const float* src = b + static_cast<size_t>(colidx[e]) * ldb;
+  for (int j = e0; j < e1; j += G * U) {
+    float bv[U][K][VEC];
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int col = (k * L + cl) * VEC;
-        if (col < d) {
-          float bv[VEC];
-          load_vec<VEC>(src + col, bv);
+    for (int t = 0; t < U; ++t) {
+      const int e = j + t * G + sub;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) p = fmaf(av[k][v], bv[v], p);
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) bv[t][k][v] = 0.0f;
+      if (e < e1) {
+        const float* src = s.b + static_cast<size_t>(s.colidx[e]) * s.ldb;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int col = (k * L + cl) * VEC;
+          if (col < s.d) load_vec<VEC>(src + col, bv[t][k]);
         }
       }
     }
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) p += __shfl_xor(p, off, kWave);
-    if (cl == 0 && e < e1) out[e] = scale * p;
+    for (int t = 0; t < U; ++t) {
+      float p = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) p = fmaf(av[k][v], bv[t][k][v], p);
+#pragma unroll
+      for (int off = 1; off < L; off <<= 1) p += __shfl_xor(p, off, kWave);
+      const int e = j + t * G + sub;
+      if (cl == 0 && e < e1) s.out[e] = scale * p;
+    }
   }
 }
 
 template <int VEC>
 int dispatch_sddmm(const gnpde_graph_t* g, const float* a, const float* b, int d, int lda, int ldb, const float* scale,
-                   int scale_sigmoid, float* out, hipStream_t s) {
-  const unsigned grid = static_cast<unsigned>((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+                   int scale_sigmoid, float* out, hipStream_t st) {
+  SddmmArgs s;
+  s.n = g->n; s.n_long_chunks = g->n_long_chunks;
+  s.rowptr = g->rowptr; s.colidx = g->colidx;
+  s.lc_row = g->long_chunk_row; s.lc_begin = g->long_chunk_begin; s.lc_end = g->long_chunk_end;
+  s.a = a; s.b = b; s.d = d; s.lda = lda; s.ldb = ldb; s.scale_ptr = scale; s.scale_sigmoid = scale_sigmoid; s.out = out;
+  const long long items = static_cast<long long>(g->n) + g->n_long_chunks;
+  const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
   const int slots = (d + VEC - 1) / VEC;
-#define GNPDE_SDDMM(LL, KK) \
-  hipLaunchKernelGGL((sddmm_kernel<VEC, LL, KK>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx, a, b, g->n, d, lda, \
-                     ldb, scale, scale_sigmoid, out)
-  if (slots <= 16) GNPDE_SDDMM(16, 1);
-  else if (slots <= 32) GNPDE_SDDMM(16, 2);
-  else if (slots <= 64) GNPDE_SDDMM(32, 2);
-  else if (slots <= 128) GNPDE_SDDMM(64, 2);
-  else if (slots <= 256) GNPDE_SDDMM(64, 4);
+#define GNPDE_SDDMM(LL, KK, UU) hipLaunchKernelGGL((sddmm_kernel<VEC, LL, KK, UU>), dim3(grid), dim3(kBlock), 0, st, s)
+  if (slots <= 16) GNPDE_SDDMM(16, 1, 4);
+  else if (slots <= 32) GNPDE_SDDMM(16, 2, 4);
+  else if (slots <= 64) GNPDE_SDDMM(32, 2, 2);
+  else if (slots <= 128) GNPDE_SDDMM(64, 2, 2);
+  else if (slots <= 256) GNPDE_SDDMM(64, 4, 1);
   else {
     set_error("sddmm: feature width d=%d too large for VEC=%d", d, VEC);
     return GNPDE_ESHAPE;

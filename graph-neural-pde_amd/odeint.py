@@ -398,7 +398,9 @@ class _AdjointSolve(torch.autograd.Function):
         under misc.py _ReverseFunc and _TupleFunc)."""
         parts = _unflatten(flat, shapes)
         with torch.enable_grad():
-          y = parts[1].detach().requires_grad_(True)
+          # fresh allocations, not views into the flat vector: a view starts one float after the vjp_t slot, which
+          # would push every kernel onto its unaligned (scalar-load) variant
+          y = parts[1].detach().clone().requires_grad_(True)
           f_eval = func(-s, y)
           grads = torch.autograd.grad(f_eval, (y,) + params, -parts[2], allow_unused=True)
         outs = [torch.zeros_like(parts[0]), f_eval.detach()]

@@ -111,23 +111,43 @@ def sddmm(graph, a, b, scale=None, scale_sigmoid=False, out=None):
   return out
 
 
-def softmax_rows_bwd(graph, att_edge, dw_csr, edge_w_csr=None):
+def softmax_rows_bwd(graph, att_edge, dw_csr, edge_w_csr=None, scale=None, scale_sigmoid=False):
   """ds [E,h] (CSR order) of the row softmax + head mean, see gnpde_softmax_rows_bwd."""
   require_hip(att_edge, dw_csr)
   att_edge = f32c(att_edge, 'attention')
   h = att_edge.shape[1]
   ds = torch.empty(max(graph.e, 1), h, dtype=torch.float32, device=att_edge.device)
-  check(_lib.lib().gnpde_softmax_rows_bwd(graph.ref(), ptr(att_edge), h, ptr(dw_csr), ptr(edge_w_csr), ptr(ds),
-                                          stream_of(att_edge)))
+  sc = _scalar_dev(scale, att_edge) if scale is not None else None
+  check(_lib.lib().gnpde_softmax_rows_bwd(graph.ref(), ptr(att_edge), h, ptr(dw_csr), ptr(edge_w_csr), ptr(sc),
+                                          int(bool(scale_sigmoid)), ptr(ds), stream_of(att_edge)))
   return ds
 
 
-def head_spmm(graph, ds_csr, feat, heads, dk, scale, by_column):
-  """Head-wise weighted segment sum (gnpde_head_spmm): [N, heads*dk]."""
+def tall_skinny_gram(a, b, slabs=512):
+  """a^T b for a [N, m], b [N, d] with N >> m, d  (weight gradients [A, N] x [N, d]).  The vendor GEMM gives such a
+  product one workgroup per 16 x 32 output tile -- a handful of CUs streaming all of N (0.3 ms at the ogbn-arxiv
+  shape, measured); as a batched product over row slabs it fills the chip, and the slab sum is a fixed-order
+  reduction."""
+  n = a.shape[0]
+  rows = n // slabs
+  if rows < 64:
+    return a.t().mm(b)
+  main = rows * slabs
+  out = torch.bmm(a[:main].view(slabs, rows, a.shape[1]).transpose(1, 2), b[:main].view(slabs, rows, b.shape[1])).sum(dim=0)
+  if main < n:
+    out = out + a[main:].t().mm(b[main:])
+  return out
+
+
+def head_spmm(graph, ds_csr, feat, heads, dk, scale, by_column, out=None):
+  """Head-wise weighted segment sum (gnpde_head_spmm): [N, heads*dk] (optionally into a column slice `out`)."""
   require_hip(ds_csr, feat)
   if feat.stride(1) != 1:
     feat = feat.contiguous()
-  out = torch.empty(graph.n, heads * dk, dtype=torch.float32, device=feat.device)
+  if out is None:
+    out = torch.empty(graph.n, heads * dk, dtype=torch.float32, device=feat.device)
+  elif out.stride(1) != 1 or out.shape != (graph.n, heads * dk):
+    raise _lib.GnpdeError('head_spmm: out must be [n, heads*dk] with unit column stride')
   check(_lib.lib().gnpde_head_spmm(graph.ref(), int(bool(by_column)), ptr(ds_csr), heads, dk, ptr(feat), feat.stride(0),
                                    float(scale), ptr(out), out.stride(0), stream_of(feat)))
   return out

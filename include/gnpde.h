@@ -186,10 +186,13 @@ int gnpde_sddmm(const gnpde_graph_t* g, const float* a, int32_t lda, const float
                 const float* scale, int32_t scale_sigmoid, float* out_csr, void* stream);
 
 /* Backward of the row softmax + head mean of gnpde_edge_attention (scaled-dot, attention_norm_idx 0):
- *   ds[p,h] = (a[p,h] / H) (dw[p] - sum_{p' in row} a[p',h] dw[p'])   [* edge_w[p] if given]
- * att_edge is the [E,h] attention in the caller's edge order, dw_csr / ds_csr are in CSR order. */
+ *   ds[p,h] = s (a[p,h] / H) (dw[p] - sum_{p' in row} a[p',h] dw[p'])   [* edge_w[p] if given]
+ * with s = 1 (scale NULL), *scale, or sigmoid(*scale) (device scalar: the alpha of the epilogue, so that dw can be
+ * the UNSCALED g_row . x_col, which also yields d alpha).  att_edge is the [E,h] attention in the caller's edge
+ * order, dw_csr / ds_csr are in CSR order.  Rows longer than GNPDE_LONG_ROW are taken by whole blocks. */
 int gnpde_softmax_rows_bwd(const gnpde_graph_t* g, const float* att_edge, int32_t heads, const float* dw_csr,
-                           const float* edge_w_csr, float* ds_csr, void* stream);
+                           const float* edge_w_csr, const float* scale, int32_t scale_sigmoid, float* ds_csr,
+                           void* stream);
 
 /* Head-wise weighted segment sum over the graph pattern (d q / d k of the attention scores):
  *   out[i, c] = scale * sum_{p in row i} ds[p, head(c)] * feat[col_p, c]           (by_column = 0)

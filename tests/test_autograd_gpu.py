@@ -240,3 +240,52 @@ def test_split_kernel_gradients(dev):
   for k in ('multihead_att_layer.Qx.weight', 'multihead_att_layer.Kp.weight', 'multihead_att_layer.Kx.bias',
             'multihead_att_layer.lengthscale_x', 'multihead_att_layer.output_var_p', 'alpha_train'):
     assert_parity(named[k].grad.reshape(-1), P[k].grad.reshape(-1), tol=GTOL, what=k)
+
+
+@pytest.mark.parametrize('d', [128, 36, 162, 27])
+def test_sddmm_hub_chunks_and_widths(dev, d):
+  """Chunked hub rows (two hubs of 1300 entries = 3 chunks each), vector widths 4 / 2 / 1, scaled by sigmoid(alpha)."""
+  from gnpde_amd import ops
+  n = 2500
+  ei = random_graph(n, 5, seed=d, hubs=2, hub_deg=1300)
+  g = torch.Generator().manual_seed(d)
+  a, b = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.n_long_chunks >= 6
+  alpha = torch.tensor([0.3], device=dev)
+  out = ops.sddmm(graph, a.to(dev), b.to(dev), scale=alpha, scale_sigmoid=True)
+  ref = torch.sigmoid(torch.tensor(0.3)) * (a[ei[0]] * b[ei[1]]).sum(dim=1)
+  assert_parity(out[:graph.e], ref[graph.perm_long.cpu()], what='sddmm d=%d' % d)
+
+
+def test_tall_skinny_gram(dev):
+  from gnpde_amd import ops
+  g = torch.Generator().manual_seed(0)
+  for n in (40017, 1000):
+    a, b = torch.randn(n, 32, generator=g).to(dev), torch.randn(n, 128, generator=g).to(dev)
+    ref = (a.double().t() @ b.double()).float()
+    assert_parity(ops.tall_skinny_gram(a, b), ref, tol=2e-5, what='gram n=%d' % n)
+
+
+def test_transformer_native_vjp_raw_alpha(dev):
+  """no_alpha_sigmoid: d alpha from sum_e w_e (g_row . x_col) instead of the saved forward value."""
+  n, d = 900, 24
+  ei = random_graph(n, 6, seed=5, hubs=1, hub_deg=700)
+  g = torch.Generator().manual_seed(6)
+  x, x0, go = (torch.randn(n, d, generator=g) for _ in range(3))
+  opt = dict(OPT, hidden_dim=d, no_alpha_sigmoid=True, self_loop_weight=0)
+  func = G.ODEFuncTransformerAtt(d, d, opt, Data(x.to(dev), ei.to(dev)), dev).to(dev)
+  _rand_params(func, 7, dev)
+  func.x0 = x0.to(dev)
+  xd = x.to(dev).requires_grad_(True)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  lay = func.multihead_att_layer
+  ps = [_cpu(p) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+  ac, bc, xc = _cpu(func.alpha_train), _cpu(func.beta_train), _cpu(x)
+  fr = R.rhs_transformer(xc, ei, ps[0], ps[1], ps[2], ps[3], 4, ac, bc, x0, True, True)
+  assert_parity(f, fr, what='value')
+  fr.backward(go)
+  assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
+  assert_parity(func.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
+  assert_parity(lay.Q.weight.grad, ps[0].grad, tol=GTOL, what='dWq')
