@@ -53,7 +53,15 @@ class _LaplacianRhs(torch.autograd.Function):
     with torch.no_grad():
       f = ops.rhs_eval(func._descriptor(x), x)
     ctx.func, ctx.graph = func, graph
-    ctx.save_for_backward(x, w_csr.clone(), edge_values, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0), f)
+    # the weights of a solve are constant: one snapshot (and one transposed copy, see backward) serves every evaluation
+    snap = func._cache.get('w_snapshot')
+    sig = (id(graph), func._cache['w_csr']['sig'])     # identity + version of the edge values the buffer was built from
+    if snap is None or snap[0] != sig:
+      snap = (sig, w_csr.clone(), {})
+      func._cache['w_snapshot'] = snap
+    ctx.w_extra = snap[2]
+    w_csr = snap[1]
+    ctx.save_for_backward(x, w_csr, edge_values, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0), f)
     ctx.has_source = x0 is not None
     return f
 
@@ -69,9 +77,12 @@ class _LaplacianRhs(torch.autograd.Function):
     with torch.no_grad():
       if need[0]:
         # edge e sits at CSR position p of `graph` and at position p' of the transposed graph: go through edge order
-        w_edge = torch.empty_like(w_csr[:graph.e])
-        w_edge[graph.perm_long] = w_csr[:graph.e]
-        w_t = ops.edge_to_csr_mean(gt, w_edge)
+        w_t = ctx.w_extra.get('w_t')
+        if w_t is None:
+          w_edge = torch.empty_like(w_csr[:graph.e])
+          w_edge[graph.perm_long] = w_csr[:graph.e]
+          w_t = ops.edge_to_csr_mean(gt, w_edge)
+          ctx.w_extra['w_t'] = w_t
         dx = ops.spmm_rhs(gt, w_t, g, alpha_train, None, None, sig)       # a (A^T g - g)
       if need[1]:
         dw_csr = ops.sddmm(graph, g, x, scale=alpha_train, scale_sigmoid=sig)

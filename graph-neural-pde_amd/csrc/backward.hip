@@ -123,13 +123,27 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
   const int first = hub ? wave * ES + es : es;
   const int step = hub ? ES * kWavesPerBlock : ES;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int t = b + first; t < e; t += step) {
-    const int p = segpos != nullptr ? segpos[t] : t;
-    const int o = other_of_pos[p];
-    const float w = ds[static_cast<size_t>(p) * h + head];
-    const float4 f = *reinterpret_cast<const float4*>(feat + static_cast<size_t>(o) * ldf + a4 * 4);
-    acc[0] = fmaf(w, f.x, acc[0]); acc[1] = fmaf(w, f.y, acc[1]);
-    acc[2] = fmaf(w, f.z, acc[2]); acc[3] = fmaf(w, f.w, acc[3]);
+  constexpr int U = 4;     // independent (position -> other end -> feature row) load chains in flight
+  for (int t0 = b + first; t0 < e; t0 += U * step) {
+    float w[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * step;
+      w[u] = 0.f;
+      f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < e) {
+        const int p = segpos != nullptr ? segpos[t] : t;
+        const int o = other_of_pos[p];
+        w[u] = ds[static_cast<size_t>(p) * h + head];
+        f[u] = *reinterpret_cast<const float4*>(feat + static_cast<size_t>(o) * ldf + a4 * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] = fmaf(w[u], f[u].x, acc[0]); acc[1] = fmaf(w[u], f[u].y, acc[1]);
+      acc[2] = fmaf(w[u], f[u].z, acc[2]); acc[3] = fmaf(w[u], f[u].w, acc[3]);
+    }
   }
 #pragma unroll
   for (int off = A4; off < kWave; off <<= 1)

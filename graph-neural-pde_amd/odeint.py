@@ -367,6 +367,53 @@ def _unflatten(v, shapes):
   return out
 
 
+def _adjoint_fixed_grid(func, params, y, a, gparams, span, method, step_size):
+  """euler / rk4 (3/8 rule) on the augmented system over the reversed-time grid s = -t (torchdiffeq's grid: the
+  short step lands next to the earlier time), written on the separate components (y, a, g_theta) with fused
+  axpy updates instead of one flat vector: per stage one evaluation F = f(u_y) and one vector-Jacobian product
+  (V_y, V_theta) = u_a^T df/d(y, theta); in s the derivatives are  y' = -F,  a' = +V_y,  g' = +V_theta.
+  Same stage formulas as rk_common.rk4_alt_step_func; agrees with the flat-vector path to rounding (the products
+  dt * k / 3 are formed as k * (dt / 3))."""
+  grid = time_grid(span, step_size)
+  dts = (grid[1:] - grid[:-1]).tolist()
+  y, a = y.clone(), a.clone()
+  gparams = [g.clone() for g in gparams]
+
+  def stage(uy, ua, s_now):
+    with torch.enable_grad():
+      yy = uy.detach().requires_grad_(True)
+      F = func(-s_now, yy)
+      grads = torch.autograd.grad(F, (yy,) + tuple(params), ua, allow_unused=True)
+    V = grads[0] if grads[0] is not None else torch.zeros_like(uy)
+    return F.detach(), V, grads[1:]
+
+  def acc_params(vps, coef):
+    for g, v in zip(gparams, vps):
+      if v is not None:
+        g.add_(v, alpha=coef)
+
+  for step, dt in enumerate(dts):
+    s0, s1 = grid[step], grid[step + 1]
+    if method == 'euler':
+      F1, V1, P1 = stage(y, a, s0)
+      y.add_(F1, alpha=-dt)
+      a.add_(V1, alpha=dt)
+      acc_params(P1, dt)
+      continue
+    third, eighth = dt / 3.0, dt * 0.125
+    F1, V1, P1 = stage(y, a, s0)
+    F2, V2, P2 = stage(torch.add(y, F1, alpha=-third), torch.add(a, V1, alpha=third), s0 + third)
+    F3, V3, P3 = stage(torch.add(y, F2, alpha=-dt).add_(F1, alpha=third), torch.add(a, V2, alpha=dt).add_(V1, alpha=-third),
+                       s0 + 2 * third)
+    F4, V4, P4 = stage(torch.add(y, F1, alpha=-dt).add_(F2, alpha=dt).add_(F3, alpha=-dt),
+                       torch.add(a, V1, alpha=dt).add_(V2, alpha=-dt).add_(V3, alpha=dt), s1)
+    y.add_(F1, alpha=-eighth).add_(F2, alpha=-3 * eighth).add_(F3, alpha=-3 * eighth).add_(F4, alpha=-eighth)
+    a.add_(V1, alpha=eighth).add_(V2, alpha=3 * eighth).add_(V3, alpha=3 * eighth).add_(V4, alpha=eighth)
+    for P, c in ((P1, eighth), (P2, 3 * eighth), (P3, 3 * eighth), (P4, eighth)):
+      acc_params(P, c)
+  return a, gparams
+
+
 class _AdjointSolve(torch.autograd.Function):
   """Forward: the plain solve WITHOUT a tape -- on this package's functions that is the native hipGraph solver, so
   the training forward runs at inference speed and stores two states, not the trajectory.  Backward: the augmented
@@ -412,11 +459,19 @@ class _AdjointSolve(torch.autograd.Function):
       options = dict(adj['options'])
       if adj['method'] in ('dopri5', 'adaptive_heun') and 'norm' not in options:
         options['norm'] = _mixed_norm(shapes)
+      fixed = adj['method'] in ('euler', 'rk4')
+      if fixed and options.get('step_size') is None:
+        raise ValueError('fixed-grid adjoint methods need adjoint_options["step_size"]')
       for i in range(len(t) - 1, 0, -1):
         span = -t[i - 1:i + 1].flip(0)
-        flat = odeint(reversed_flat_dynamics, _flatten(state), span, rtol=adj['rtol'], atol=adj['atol'],
-                      method=adj['method'], options=options)[1]
-        state = [p.clone() for p in _unflatten(flat, shapes)]
+        if fixed:
+          state[2], gp = _adjoint_fixed_grid(func, params, state[1], state[2], state[3:], span, adj['method'],
+                                             options['step_size'])
+          state = state[:3] + list(gp)
+        else:
+          flat = odeint(reversed_flat_dynamics, _flatten(state), span, rtol=adj['rtol'], atol=adj['atol'],
+                        method=adj['method'], options=options)[1]
+          state = [p.clone() for p in _unflatten(flat, shapes)]
         state[1] = ans[i - 1]
         state[2] = state[2] + grad_out[i - 1]
     return (None, state[2], None, None, None) + tuple(state[3:])
