@@ -38,6 +38,20 @@ for name in ('gnn_constant_transformer_rk4', 'gnn_attention_laplacian_euler'):
   assert ours == theirs, set(ours) ^ set(theirs)
   model.load_state_dict(fx.params, strict=True)
   print(model)                          # the reference's print(model) raises for --function transformer
+# the reference's early-stopping model (GNN_early.py) picks up the device evaluator, its registry the rewiring block
+from GNN_early import GNNEarly
+fx = Fixture('gnn_constant_transformer_rk4')
+data = Data(x=fx.t('x'), edge_index=fx.t('edge_index'), edge_attr=None)
+opt = dict(fx.opt, earlystopxT=3, max_test_steps=100)
+early = GNNEarly(opt, DummyDataset(data, int(fx.arr['num_classes'])), torch.device('cpu'))
+integ = early.odeblock.test_integrator
+assert type(integ).__module__.startswith('gnpde_amd'), type(integ).__module__
+assert integ.data is data and abs(float(integ.t[1]) - 3 * opt['time']) < 1e-6
+early.load_state_dict(fx.params, strict=True)
+early.set_solver_m2()
+assert integ.m2_weight.shape == early.m2.weight.shape
+from model_configurations import set_block
+assert set_block(dict(opt, block='rewire_attention')).__module__.startswith('gnpde_amd')
 print('DROPIN_OK')
 '''
 
