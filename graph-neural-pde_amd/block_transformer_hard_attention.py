@@ -1,8 +1,11 @@
-"""Block that keeps only the strongest att_samp_pct of the edges while training and integrates a
-function over the sampled, renormalised attention (reference src/block_transformer_hard_attention.py:7-103;
-`block` of the ogbn-arxiv / Computers / Photo best_params).  The edge selection (quantile, mask, segment
-sum) is host-side bookkeeping done once per forward with device tensor ops; attention and f stay native.
-The function's graph is rebuilt lazily whenever `edge_index` is swapped."""
+"""Hard attention: while training, only the strongest `att_samp_pct` share of the edges (ranked by head-mean
+attention, optionally times the feature distance across the edge) carries the diffusion, with the kept attention
+renormalised per node; in evaluation mode every edge is used (reference
+src/block_transformer_hard_attention.py:7-103; `block` of the ogbn-arxiv / Computers / Photo best_params).
+
+The selection (quantile, mask, per-node sum) is once-per-forward bookkeeping on device tensors; the attention itself
+and every evaluation of f run on the native kernels.  Swapping `odefunc.edge_index` makes the function rebuild
+its CSR lazily."""
 import torch
 
 from .base_classes import ODEblock
@@ -14,41 +17,48 @@ class HardAttODEblock(ODEblock):
     super(HardAttODEblock, self).__init__(odefunc, regularization_fns, opt, data, device, t)
     assert opt['att_samp_pct'] > 0 and opt['att_samp_pct'] <= 1, "attention sampling threshold must be in (0,1]"
     self.opt = opt
-    self._second_function(odefunc, opt, data, device)
     self.num_nodes = data.num_nodes
-    self.data_edge_index, _ = self._rw_graph(data, opt, device)   # odefunc.edge_index is swapped while training
+    self._second_function(odefunc, opt, data, device)
+    self.data_edge_index, _ = self._rw_graph(data, opt, device)   # the full edge set; odefunc.edge_index is a subset of it while training
     self._use_default_integrators(opt)
-    if opt['function'] not in {'GAT', 'transformer'}:
+    self._own_layer = opt['function'] not in {'GAT', 'transformer'}
+    if self._own_layer:
       self.multihead_att_layer = SpGraphTransAttentionLayer(opt['hidden_dim'], opt['hidden_dim'], opt, device,
                                                             edge_weights=self.odefunc.edge_weight).to(device)
 
   def get_attention_weights(self, x):
-    if self.opt['function'] not in {'GAT', 'transformer'}:
-      attention, values = self.multihead_att_layer(x, self.data_edge_index)
-    else:
-      attention, values = self.odefunc.multihead_att_layer(x, self.data_edge_index)
-    return attention
+    layer = self.multihead_att_layer if self._own_layer else self.odefunc.multihead_att_layer
+    return layer(x, self.data_edge_index)[0]
 
   def renormalise_attention(self, attention):
-    index = self.odefunc.edge_index[self.opt['attention_norm_idx']]
-    sums = torch.zeros(self.num_nodes, dtype=attention.dtype, device=attention.device).index_add_(0, index, attention)
-    return attention / (sums[index] + 1e-16)
+    """attention / (its sum over the edges that share the normalisation endpoint + 1e-16)."""
+    endpoint = self.odefunc.edge_index[self.opt['attention_norm_idx']]
+    total = attention.new_zeros(self.num_nodes).index_add_(0, endpoint, attention)
+    return attention / (total[endpoint] + 1e-16)
+
+  def _edge_scores(self, x, attention):
+    score = attention.mean(dim=1)
+    if self.opt['use_flux']:
+      src, dst = self.data_edge_index
+      score = score * torch.linalg.norm(x[src] - x[dst], dim=1)
+    return score
+
+  def _sample_edges(self, x, attention):
+    """Keep the edges whose score exceeds the (1 - att_samp_pct) quantile (reference :48-66)."""
+    score = self._edge_scores(x, attention)
+    keep = score > torch.quantile(score, 1 - self.opt['att_samp_pct'])
+    self.odefunc.edge_index = self.data_edge_index[:, keep]
+    self.odefunc.attention_weights = self.renormalise_attention(score[keep])
 
   def forward(self, x):
-    attention_weights = self.get_attention_weights(x)
+    attention = self.get_attention_weights(x)
     if self.training:
       with torch.no_grad():
-        mean_att = attention_weights.mean(dim=1, keepdim=False)
-        if self.opt['use_flux']:
-          delta = torch.linalg.norm(x[self.data_edge_index[0, :], :] - x[self.data_edge_index[1, :], :], dim=1)
-          mean_att = mean_att * delta
-        threshold = torch.quantile(mean_att, 1 - self.opt['att_samp_pct'])
-        mask = mean_att > threshold
-        self.odefunc.edge_index = self.data_edge_index[:, mask]
-        self.odefunc.attention_weights = self.renormalise_attention(mean_att[mask])
+        self._sample_edges(x, attention)
     else:
       self.odefunc.edge_index = self.data_edge_index
-      self.odefunc.attention_weights = attention_weights.mean(dim=1, keepdim=False)
-    self.reg_odefunc.odefunc.edge_index, self.reg_odefunc.odefunc.edge_weight = self.odefunc.edge_index, self.odefunc.edge_weight
-    self.reg_odefunc.odefunc.attention_weights = self.odefunc.attention_weights
+      self.odefunc.attention_weights = attention.mean(dim=1)
+    twin = self.reg_odefunc.odefunc
+    twin.edge_index, twin.edge_weight, twin.attention_weights = (self.odefunc.edge_index, self.odefunc.edge_weight,
+                                                                 self.odefunc.attention_weights)
     return self._integrate(x, {'step_size': self.opt['step_size']})
