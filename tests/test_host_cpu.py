@@ -254,3 +254,34 @@ def test_rewiring_sparse_helpers_match_dense():
   assert torch.allclose(dense(i2, v2), dense(ia, va) + dense(ia[:, :10], va[:10]), atol=1e-6)
   empty_i, empty_v = _spspmm(ia[:, :0], va[:0], ib, vb, n)
   assert empty_i.shape == (2, 0) and empty_v.numel() == 0
+
+
+def test_header_is_valid_c_and_links(tmp_path):
+  """include/gnpde.h is a C header (not C++): a C99 translation unit that takes the address of every declared entry
+  point compiles with -Wall -Werror and links against libgnpde_hip.so (no device needed to link)."""
+  import shutil
+  import subprocess
+  if shutil.which('gcc') is None:
+    pytest.skip('no gcc')
+  header = open(os.path.join(ROOT, 'include', 'gnpde.h')).read()
+  names = sorted(set(re.findall(r'\b(gnpde_[a-z_0-9]+)\s*\(', header)))
+  src = tmp_path / 'abi.c'
+  src.write_text('#include "gnpde.h"\n#include <stdio.h>\n'
+                 'typedef void (*fn_t)(void);\nint main(void) {\n  fn_t table[] = {\n' +
+                 ''.join('    (fn_t)%s,\n' % n for n in names) +
+                 '  };\n  gnpde_graph_t g; gnpde_epilogue_t e; gnpde_rhs_t r; gnpde_decoder_t d;\n'
+                 '  printf("%zu %zu %zu %zu %zu\\n", sizeof table / sizeof table[0], sizeof g, sizeof e, sizeof r, sizeof d);\n'
+                 '  return 0;\n}\n')
+  libdir = os.path.dirname(_lib.LIB_PATH)
+  exe = tmp_path / 'abi'
+  cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe),
+         '-L', libdir, '-lgnpde_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-L', '/opt/rocm/lib',
+         '-Wl,--allow-shlib-undefined']
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-3000:]
+  out = subprocess.run([str(exe)], capture_output=True, text=True)
+  if out.returncode == 0:      # runs wherever the HIP runtime library can be loaded (it only prints sizes)
+    n, sg, se, sr, sd = (int(v) for v in out.stdout.split())
+    assert n == len(names)
+    assert (sg, se, sd) == (ctypes.sizeof(_lib.GraphStruct), ctypes.sizeof(_lib.EpilogueStruct), ctypes.sizeof(_lib.DecoderStruct))
+    assert sr == ctypes.sizeof(_lib.RhsStruct)
