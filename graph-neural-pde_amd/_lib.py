@@ -87,6 +87,8 @@ PROTOTYPES = {
   'gnpde_sddmm': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32,
                                  c_vp, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_softmax_rows_bwd': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32, c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_attention_rows_bwd': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp, c_vp,
+                                              ctypes.c_int32, c_vp, c_vp]),
   'gnpde_head_spmm': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,
                                      ctypes.c_int32, ctypes.c_float, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_linear': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32,

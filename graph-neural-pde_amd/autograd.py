@@ -135,7 +135,7 @@ class _TransformerRhs(torch.autograd.Function):
       wqk, bqk = lay.qk_weights()
       qk = ops.linear(x, wqk, bqk)
       st, keep = lay.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
-      w_csr, att_edge, _ = ops.edge_attention(graph, st, True, True, False, like=x)
+      w_csr, _, _ = ops.edge_attention(graph, st, True, False, False, like=x)   # fused row kernels: head-mean weights only
       # d/dx through the aggregation and the -x term: a (A^T g - g)
       gt = graph.transposed()
       w_edge = torch.empty(graph.e, dtype=torch.float32, device=g.device)
@@ -143,7 +143,10 @@ class _TransformerRhs(torch.autograd.Function):
       dx = ops.spmm_rhs(gt, ops.edge_to_csr_mean(gt, w_edge), g, alpha_train, None, None, sig)
       # through the attention weights: r_e = g_row . x_col (unscaled), alpha applied inside the softmax backward
       r = ops.sddmm(graph, g, x)
-      ds = ops.softmax_rows_bwd(graph, att_edge, r, edge_w_csr=lay._reweight_csr(graph), scale=alpha_train, scale_sigmoid=sig)
+      ds = ops.attention_rows_bwd(graph, st, r, h, scale=alpha_train, scale_sigmoid=sig)   # scores + softmax + its backward
+      if ds is None:     # head shapes without a one-pass kernel: per-head attention in edge order, then its backward
+        _, att_edge, _ = ops.edge_attention(graph, st, False, True, False, like=x)
+        ds = ops.softmax_rows_bwd(graph, att_edge, r, edge_w_csr=lay._reweight_csr(graph), scale=alpha_train, scale_sigmoid=sig)
       inv = 1.0 / math.sqrt(dk)
       dqk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=x.device)
       ops.head_spmm(graph, ds, qk[:, A:], h, dk, inv, by_column=False, out=dqk[:, :A])

@@ -164,6 +164,214 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
         make_float4(scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row attention backward in one pass: recomputes the scaled-dot scores and their row softmax from q, k and writes
+//   ds[p, h] = scale (a[p,h] / H) (r[p] - sum_{p' in row} a[p',h] r[p'])   [* edge_w[p]]
+// i.e. scores + segment statistics + normalise + softmax backward of the general path (four launches and an [E,h]
+// attention array in edge order) as ONE launch that never materialises the attention.  lane = one entry of the
+// row at a time (its k row is A = H * DK floats, gathered as float4s), scores of up to 8 entries per lane kept in
+// registers for rows <= 512; hub rows are taken by whole blocks in three passes (max, sum and c, write).
+// ------------------------------------------------------------------------------------------------
+template <int H, int DK>
+__device__ __forceinline__ void row_scores(const float* __restrict__ qrow, const float* __restrict__ krow, float inv, float ew,
+                                           float (&sc)[H]) {
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) {
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      const float4 qv = *reinterpret_cast<const float4*>(qrow + hh * DK + c);
+      const float4 kv = *reinterpret_cast<const float4*>(krow + hh * DK + c);
+      dot = fmaf(qv.x, kv.x, dot); dot = fmaf(qv.y, kv.y, dot); dot = fmaf(qv.z, kv.z, dot); dot = fmaf(qv.w, kv.w, dot);
+    }
+    sc[hh] = dot * inv * ew;
+  }
+}
+
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wmax(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// group reductions over GL consecutive lanes (GL = 16 or 64)
+template <int GL>
+__device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+  for (int off = GL / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+template <int GL>
+__device__ __forceinline__ float gmax(float v) {
+#pragma unroll
+  for (int off = GL / 2; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+// Ordinary rows come from the degree-binned records {row, begin, len, 0} (graph_prep): rows with <= 16 entries
+// take GL = 16 lanes (four rows per wavefront, one entry per lane), rows with 17..512 entries a whole wavefront
+// (GL = 64, up to PER = 8 entries per lane, scores kept in registers).  With HUBS the first n_long blocks of the
+// grid take one hub row each.
+template <int H, int DK, int GL, int PER, bool HUBS>
+__global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                                   const int* __restrict__ bin_rows, int first_rec, int n_rec,
+                                                                   const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+                                                                   const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                   const float* __restrict__ scale_ptr, int scale_sigmoid,
+                                                                   const int* __restrict__ long_rows, int n_long,
+                                                                   float* __restrict__ ds) {
+  __shared__ float red[kWavesPerBlock];
+  constexpr int RPW = kWave / GL;               // rows per wavefront
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool hub = HUBS && static_cast<int>(blockIdx.x) < n_long;
+  float scale = 1.0f / static_cast<float>(H);
+  if (scale_ptr != nullptr) {
+    float sc = *scale_ptr;
+    if (scale_sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+    scale *= sc;
+  }
+  const float inv = 1.0f / sqrtf(static_cast<float>(DK));
+
+  if (!hub) {
+    const int gl = lane % GL;
+    const long long rec = (static_cast<long long>(blockIdx.x) - (HUBS ? n_long : 0)) * (kWavesPerBlock * RPW) +
+                          (threadIdx.x >> 6) * RPW + lane / GL;
+    const bool live_row = rec < n_rec;
+    int4 info = make_int4(0, 0, 0, 0);
+    if (live_row) info = reinterpret_cast<const int4*>(bin_rows)[first_rec + rec];
+    const int b = info.y, e = info.y + info.z;
+    const float* qrow = q + static_cast<size_t>(info.x) * ldqk;
+    float s[PER][H];
+    float rr[PER], ew[PER];
+    float mx[H];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) mx[hh] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = b + gl + i * GL;
+      rr[i] = 0.f; ew[i] = 1.f;
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) s[i][hh] = -INFINITY;
+      if (p < e) {
+        ew[i] = edge_w != nullptr ? edge_w[p] : 1.f;
+        rr[i] = r[p];
+        row_scores<H, DK>(qrow, k + static_cast<size_t>(colidx[p]) * ldqk, inv, ew[i], s[i]);
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) mx[hh] = fmaxf(mx[hh], s[i][hh]);
+      }
+    }
+    float den[H], c[H];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      mx[hh] = gmax<GL>(mx[hh]);
+      den[hh] = 0.f; c[hh] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const bool live = b + gl + i * GL < e;
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        const float ex = live ? expf(s[i][hh] - mx[hh]) : 0.f;
+        s[i][hh] = ex;
+        den[hh] += ex;
+        c[hh] = fmaf(ex, rr[i], c[hh]);
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      den[hh] = gsum<GL>(den[hh]) + 1e-16f;
+      c[hh] = gsum<GL>(c[hh]) / den[hh];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = b + gl + i * GL;
+      if (p < e) {
+        float out[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) out[hh] = (s[i][hh] / den[hh]) * scale * (rr[i] - c[hh]) * ew[i];
+        if constexpr (H == 4) {
+          *reinterpret_cast<float4*>(ds + static_cast<size_t>(p) * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+          for (int hh = 0; hh < H; ++hh) ds[static_cast<size_t>(p) * H + hh] = out[hh];
+        }
+      }
+    }
+    return;
+  }
+
+  // hub row: every pass recomputes the scores (three gathers of the k rows, hub entries only)
+  const int row = long_rows[blockIdx.x];
+  const int b = rowptr[row], e = rowptr[row + 1];
+  const float* qrow = q + static_cast<size_t>(row) * ldqk;
+  float mx[H], den[H], c[H];
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) { mx[hh] = -INFINITY; den[hh] = 0.f; c[hh] = 0.f; }
+  for (int p = b + static_cast<int>(threadIdx.x); p < e; p += kBlock) {
+    float sc[H];
+    row_scores<H, DK>(qrow, k + static_cast<size_t>(colidx[p]) * ldqk, inv, edge_w != nullptr ? edge_w[p] : 1.f, sc);
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) mx[hh] = fmaxf(mx[hh], sc[hh]);
+  }
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) mx[hh] = block_max(mx[hh], red);
+  for (int p = b + static_cast<int>(threadIdx.x); p < e; p += kBlock) {
+    float sc[H];
+    row_scores<H, DK>(qrow, k + static_cast<size_t>(colidx[p]) * ldqk, inv, edge_w != nullptr ? edge_w[p] : 1.f, sc);
+    const float rp = r[p];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      const float ex = expf(sc[hh] - mx[hh]);
+      den[hh] += ex;
+      c[hh] = fmaf(ex, rp, c[hh]);
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) {
+    den[hh] = block_sum(den[hh], red) + 1e-16f;
+    c[hh] = block_sum(c[hh], red) / den[hh];
+  }
+  for (int p = b + static_cast<int>(threadIdx.x); p < e; p += kBlock) {
+    float sc[H];
+    const float ewp = edge_w != nullptr ? edge_w[p] : 1.f;
+    row_scores<H, DK>(qrow, k + static_cast<size_t>(colidx[p]) * ldqk, inv, ewp, sc);
+    const float rp = r[p];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+      ds[static_cast<size_t>(p) * H + hh] = (expf(sc[hh] - mx[hh]) / den[hh]) * scale * (rp - c[hh]) * ewp;
+  }
+}
+
+template <int H, int DK>
+int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                              int scale_sigmoid, float* ds_csr, hipStream_t s) {
+  const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
+  if (n16 > 0) {
+    constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
+    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
+                       g->bin_rows, 0, n16, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
+                       ds_csr);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n64 > 0 || nl > 0) {
+    const unsigned grid = static_cast<unsigned>(nl + (n64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, true>), dim3(grid), dim3(kBlock), 0, s,
+                       g->rowptr, g->colidx, g->bin_rows, n16, n64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
+                       scale_sigmoid, g->long_rows, nl, ds_csr);
+    GNPDE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 }  // namespace
 }  // namespace gnpde
 
@@ -225,4 +433,27 @@ extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const 
 #undef GNPDE_HS
   GNPDE_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                        int32_t scale_sigmoid, float* ds_csr, void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(g && att && r_csr && ds_csr && att->q && att->k, GNPDE_EINVAL, "attention_rows_bwd: null argument");
+  GNPDE_CHECK_ARG(att->type == GNPDE_ATT_SCALED_DOT && att->norm_idx == 0 && !att->square_plus, GNPDE_ESHAPE,
+                  "attention_rows_bwd: only scaled-dot attention with a softmax over the row");
+  GNPDE_CHECK_ARG(att->heads >= 1 && att->att_dim % att->heads == 0, GNPDE_EINVAL, "attention_rows_bwd: bad head count");
+  GNPDE_CHECK_ARG(att->ldqk % 4 == 0 && reinterpret_cast<uintptr_t>(att->q) % 16 == 0 && reinterpret_cast<uintptr_t>(att->k) % 16 == 0,
+                  GNPDE_EINVAL, "attention_rows_bwd: q / k must be 16-byte aligned with ld %% 4 == 0");
+  GNPDE_CHECK_ARG(g->n_long_rows == 0 || g->long_rows, GNPDE_EINVAL, "attention_rows_bwd: graph has long rows but no list of them");
+  if (g->n == 0 || g->e == 0) return 0;
+  GNPDE_CHECK_ARG(g->bin_rows != nullptr, GNPDE_EINVAL, "attention_rows_bwd: graph has no degree-binned row records");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int h = att->heads, dk = att->att_dim / att->heads;
+#define GNPDE_AB(HH, DD) \
+  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, s);
+  GNPDE_AB(1, 4) GNPDE_AB(1, 8) GNPDE_AB(1, 16) GNPDE_AB(2, 4) GNPDE_AB(2, 8) GNPDE_AB(2, 16) GNPDE_AB(4, 4) GNPDE_AB(4, 8)
+  GNPDE_AB(4, 16) GNPDE_AB(8, 4) GNPDE_AB(8, 8) GNPDE_AB(8, 16)
+#undef GNPDE_AB
+  set_error("attention_rows_bwd: no kernel for heads=%d, d_k=%d (heads in {1,2,4,8}, d_k in {4,8,16})", h, dk);
+  return GNPDE_ESHAPE;
 }

@@ -123,6 +123,19 @@ def softmax_rows_bwd(graph, att_edge, dw_csr, edge_w_csr=None, scale=None, scale
   return ds
 
 
+def attention_rows_bwd(graph, att, r_csr, heads, scale=None, scale_sigmoid=False):
+  """ds [E,h] (CSR order) from q, k in one pass (gnpde_attention_rows_bwd); None when the shape has no kernel."""
+  require_hip(r_csr)
+  dk = att.att_dim // att.heads
+  if att.heads not in (1, 2, 4, 8) or dk not in (4, 8, 16):
+    return None
+  ds = torch.empty(max(graph.e, 1), heads, dtype=torch.float32, device=r_csr.device)
+  sc = _scalar_dev(scale, r_csr) if scale is not None else None
+  check(_lib.lib().gnpde_attention_rows_bwd(graph.ref(), ctypes.byref(att), ptr(r_csr), ptr(sc), int(bool(scale_sigmoid)),
+                                            ptr(ds), stream_of(r_csr)))
+  return ds
+
+
 def tall_skinny_gram(a, b, slabs=512):
   """a^T b for a [N, m], b [N, d] with N >> m, d  (weight gradients [A, N] x [N, d]).  The vendor GEMM gives such a
   product one workgroup per 16 x 32 output tile -- a handful of CUs streaming all of N (0.3 ms at the ogbn-arxiv

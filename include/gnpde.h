@@ -253,6 +253,14 @@ int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a,
                          float* w_mean_csr, float* att_edge, float* prods_edge,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same ds as gnpde_softmax_rows_bwd, but computed from q and k in ONE pass (scores, row softmax and its
+ * backward; no [E,h] attention array): att->type must be GNPDE_ATT_SCALED_DOT with norm_idx 0 and no squareplus,
+ * heads in {1,2,4,8}, d_k in {4,8,16} (GNPDE_ESHAPE otherwise: use gnpde_edge_attention + gnpde_softmax_rows_bwd).
+ * r_csr[p] = g_row . x_col (gnpde_sddmm without scale); att->edge_w_csr is honoured. */
+int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                             int32_t scale_sigmoid, float* ds_csr, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------------
  * GRAND-nl evaluation in ONE pass (the solver's hot case): scaled-dot attention, softmax over the row
  * (attention_norm_idx 0, no squareplus), head-mean aggregation, epilogue and solver stage.

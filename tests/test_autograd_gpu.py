@@ -289,3 +289,27 @@ def test_transformer_native_vjp_raw_alpha(dev):
   assert_parity(xd.grad, xc.grad, tol=GTOL, what='dx')
   assert_parity(func.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
   assert_parity(lay.Q.weight.grad, ps[0].grad, tol=GTOL, what='dWq')
+
+
+@pytest.mark.parametrize('heads,dk,reweight', [(4, 4, False), (8, 16, False), (1, 8, True), (2, 4, True), (4, 16, False)])
+def test_attention_rows_bwd_matches_two_step_path(dev, heads, dk, reweight):
+  """One-pass scores + softmax + backward against per-head attention followed by gnpde_softmax_rows_bwd, on a graph
+  with hub rows (block-wide three-pass branch), empty rows and duplicate edges."""
+  from gnpde_amd import ops, _lib
+  n, A = 1500, heads * dk
+  ei = random_graph(n, 7, seed=heads + dk, hubs=2, hub_deg=900, isolated=5, dup=20)
+  g = torch.Generator().manual_seed(dk)
+  qk = (torch.randn(n, 2 * A, generator=g) * 0.7).to(dev)
+  r = torch.randn(ei.shape[1], generator=g).to(dev)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.n_long_rows >= 2
+  ew = (torch.rand(ei.shape[1], generator=g) + 0.5).to(dev) if reweight else None
+  ew_csr = ops.edge_to_csr_mean(graph, ew) if reweight else None
+  st = ops.attention_struct(_lib.ATT_SCALED_DOT, heads, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A, edge_w_csr=ew_csr)
+  alpha = torch.tensor([0.4], device=dev)
+  r_csr = ops.edge_to_csr_mean(graph, r)
+  fused = ops.attention_rows_bwd(graph, st, r_csr, heads, scale=alpha, scale_sigmoid=True)
+  assert fused is not None
+  _, att_edge, _ = ops.edge_attention(graph, st, False, True, False, like=qk)
+  ref = ops.softmax_rows_bwd(graph, att_edge, r_csr, edge_w_csr=ew_csr, scale=alpha, scale_sigmoid=True)
+  assert_parity(fused[:graph.e], ref[:graph.e], tol=2e-5, what='ds')
