@@ -97,29 +97,39 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_bwd_kernel(const int* __r
 }
 
 // out[seg, :] = scale * sum_{p in seg} ds[pos(p), head(col)] * feat[other(p), :]   (A = h * dk columns, dk % 4 == 0)
-// lane = (edge slot, float4 column); A4 = A / 4 lanes per edge, a power of two <= 64
-template <int A4>
+// lane = (edge slot, float4 column); A4 = A / 4 lanes per edge, a power of two <= 64.  GL lanes work on one segment:
+// GL = 16 (four segments per wavefront) for the segments with len_lo < length <= len_hi = 64 -- most rows of a
+// power-law graph --, GL = 64 for the longer ones; each launch skips the segments outside its length class, and the
+// GL = 64 launch also takes the hub segments (HUBS) with whole blocks.
+template <int A4, int GL, bool HUBS>
 __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict__ segptr, const int* __restrict__ segpos,
                                                           const int* __restrict__ other_of_pos, const float* __restrict__ ds,
                                                           int h, int dk, const float* __restrict__ feat, int ldf, float scale,
-                                                          int n, const int* __restrict__ long_segs, int n_long,
-                                                          float* __restrict__ out, int ldo) {
+                                                          int n, int len_lo, int len_hi, const int* __restrict__ long_segs,
+                                                          int n_long, float* __restrict__ out, int ldo) {
   __shared__ float part[kWavesPerBlock][A4][4];
-  constexpr int ES = kWave / A4;  // edges per wavefront iteration
+  constexpr int ES = GL / A4;        // edges per group iteration
+  constexpr int SPW = kWave / GL;    // segments per wavefront
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const bool hub = static_cast<int>(blockIdx.x) < n_long;
-  int seg;
+  const bool hub = HUBS && static_cast<int>(blockIdx.x) < n_long;
+  const int gl = lane % GL;
+  const int es = gl / A4, a4 = gl % A4;
+  const int head = (a4 * 4) / dk;
+  int seg, b = 0, e = 0;
   if (hub) {
     seg = long_segs[blockIdx.x];
+    b = segptr[seg]; e = segptr[seg + 1];
   } else {
-    seg = (static_cast<int>(blockIdx.x) - n_long) * kWavesPerBlock + wave;
-    if (seg >= n) return;
+    seg = ((static_cast<int>(blockIdx.x) - (HUBS ? n_long : 0)) * kWavesPerBlock + wave) * SPW + lane / GL;
+    if (seg < n) {
+      b = segptr[seg]; e = segptr[seg + 1];
+      if (e - b <= len_lo || e - b > len_hi) e = b;      // not this launch's length class: nothing to do
+    } else {
+      seg = -1;
+    }
   }
-  const int es = lane / A4, a4 = lane % A4;
-  const int head = (a4 * 4) / dk;
-  const int b = segptr[seg], e = segptr[seg + 1];
-  if (!hub && e - b > GNPDE_LONG_ROW) return;
+  const bool mine = e > b || (seg >= 0 && !hub && len_lo == 0 && e == b && segptr[seg + 1] == segptr[seg]);  // empty segments: zero row, written by the first class
   const int first = hub ? wave * ES + es : es;
   const int step = hub ? ES * kWavesPerBlock : ES;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
     }
   }
 #pragma unroll
-  for (int off = A4; off < kWave; off <<= 1)
+  for (int off = A4; off < GL; off <<= 1)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
   if (hub) {
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void head_spmm_kernel(const int* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (part[0][a4][i] + part[1][a4][i]) + (part[2][a4][i] + part[3][a4][i]);
   }
-  if (es == 0)
+  if (es == 0 && (mine || hub))
     *reinterpret_cast<float4*>(out + static_cast<size_t>(seg) * ldo + a4 * 4) =
         make_float4(scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]);
 }
@@ -416,11 +426,14 @@ extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const 
   const int* long_segs = by_column ? g->long_cols : g->long_rows;
   const int nl = by_column ? g->n_long_cols : g->n_long_rows;
   GNPDE_CHECK_ARG(nl == 0 || long_segs, GNPDE_EINVAL, "head_spmm: graph has long segments but no list of them");
-  const unsigned grid = static_cast<unsigned>(nl + (g->n + kWavesPerBlock - 1) / kWavesPerBlock);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // one launch: a wavefront per segment, hub segments by whole blocks.  (A split into a 16-lane class for segments of
+  // <= 64 entries plus a wavefront class for the rest was measured slower: 60 + 110 us against 136 us at the
+  // ogbn-arxiv shape -- both launches walk all segment pointers; the template keeps the option.)
+  const unsigned grid64 = static_cast<unsigned>(nl + (g->n + kWavesPerBlock - 1) / kWavesPerBlock);
+#define GNPDE_HS_ARGS(LO, HI, NL) segptr, segpos, other, ds_csr, heads, dk, feat, ldf, scale, g->n, LO, HI, long_segs, NL, out, ldo
 #define GNPDE_HS(N4) \
-  hipLaunchKernelGGL((head_spmm_kernel<N4>), dim3(grid), dim3(kBlock), 0, s, segptr, segpos, other, ds_csr, heads, dk, feat, ldf, \
-                     scale, g->n, long_segs, nl, out, ldo)
+  hipLaunchKernelGGL((head_spmm_kernel<N4, 64, true>), dim3(grid64), dim3(kBlock), 0, s, GNPDE_HS_ARGS(0, GNPDE_LONG_ROW, nl));
   switch (a4) {
     case 1: GNPDE_HS(1); break;
     case 2: GNPDE_HS(2); break;
@@ -430,6 +443,7 @@ extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const 
     case 32: GNPDE_HS(32); break;
     default: GNPDE_HS(64); break;
   }
+#undef GNPDE_HS_ARGS
 #undef GNPDE_HS
   GNPDE_LAUNCH_CHECK();
   return 0;

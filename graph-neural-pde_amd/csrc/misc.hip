@@ -18,6 +18,43 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
   for (int c = lane; c < d; c += kWave) o[c] = s[c];
 }
 
+struct LinArgs {
+  const float* base;
+  const float* v[GNPDE_MAX_PREV];
+  float c[GNPDE_MAX_PREV];
+  int n_v;
+  long long n;
+  float* out;
+};
+
+// out = base + sum_j c_j v_j over a flat array (stage algebra of host-driven Runge-Kutta loops in ONE pass)
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void lincomb_kernel(const LinArgs a) {
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  if constexpr (VEC4) {
+    const long long n4 = a.n / 4;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 r = reinterpret_cast<const float4*>(a.base)[i];
+      for (int j = 0; j < a.n_v; ++j) {
+        const float4 t = reinterpret_cast<const float4*>(a.v[j])[i];
+        r.x = fmaf(a.c[j], t.x, r.x); r.y = fmaf(a.c[j], t.y, r.y); r.z = fmaf(a.c[j], t.z, r.z); r.w = fmaf(a.c[j], t.w, r.w);
+      }
+      reinterpret_cast<float4*>(a.out)[i] = r;
+    }
+    for (long long i = n4 * 4 + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+      float r = a.base[i];
+      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j], a.v[j][i], r);
+      a.out[i] = r;
+    }
+  } else {
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+      float r = a.base[i];
+      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j], a.v[j][i], r);
+      a.out[i] = r;
+    }
+  }
+}
+
 struct ErrArgs {
   const float* y0;
   const float* y1;
@@ -99,6 +136,33 @@ extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t
   GNPDE_CHECK_ARG(src && idx && dst, GNPDE_EINVAL, "gather_rows: null pointer");
   hipLaunchKernelGGL(gnpde::gather_rows_kernel, dim3((count + gnpde::kWavesPerBlock - 1) / gnpde::kWavesPerBlock),
                      dim3(gnpde::kBlock), 0, static_cast<hipStream_t>(stream), src, ld_src, idx, count, d, dst, ld_dst);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gnpde_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
+                             void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(base && out && n >= 0 && n_v >= 0 && n_v <= GNPDE_MAX_PREV && (n_v == 0 || (v && coef)), GNPDE_EINVAL,
+                  "lincomb: bad arguments");
+  if (n == 0) return 0;
+  LinArgs a;
+  a.base = base; a.n_v = n_v; a.n = n; a.out = out;
+  bool al = reinterpret_cast<uintptr_t>(base) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  for (int j = 0; j < GNPDE_MAX_PREV; ++j) {
+    a.v[j] = j < n_v ? v[j] : nullptr;
+    a.c[j] = j < n_v ? coef[j] : 0.f;
+    if (j < n_v) {
+      GNPDE_CHECK_ARG(v[j] != nullptr, GNPDE_EINVAL, "lincomb: vector %d is null", j);
+      al = al && reinterpret_cast<uintptr_t>(v[j]) % 16 == 0;
+    }
+  }
+  long long blocks = (n / 4 + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (al) hipLaunchKernelGGL((lincomb_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL((lincomb_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }

@@ -387,6 +387,17 @@ def _adjoint_fixed_grid(func, params, y, a, gparams, span, method, step_size):
     V = grads[0] if grads[0] is not None else torch.zeros_like(uy)
     return F.detach(), V, grads[1:]
 
+  def comb(base, terms, inplace=False):
+    """base + sum_j c_j v_j: one fused pass on the device (gnpde_lincomb), chained axpys elsewhere."""
+    if base.is_cuda and base.dtype == torch.float32 and base.is_contiguous() and all(
+        v.is_contiguous() and v.dtype == torch.float32 for v, _ in terms):
+      from . import ops
+      return ops.lincomb(base, terms, out=base if inplace else None)
+    out = base if inplace else None
+    for v, c in terms:
+      out = torch.add(base, v, alpha=c) if out is None else out.add_(v, alpha=c)
+    return out
+
   def acc_params(vps, coef):
     for g, v in zip(gparams, vps):
       if v is not None:
@@ -396,19 +407,17 @@ def _adjoint_fixed_grid(func, params, y, a, gparams, span, method, step_size):
     s0, s1 = grid[step], grid[step + 1]
     if method == 'euler':
       F1, V1, P1 = stage(y, a, s0)
-      y.add_(F1, alpha=-dt)
-      a.add_(V1, alpha=dt)
+      y = comb(y, [(F1, -dt)], inplace=True)
+      a = comb(a, [(V1, dt)], inplace=True)
       acc_params(P1, dt)
       continue
     third, eighth = dt / 3.0, dt * 0.125
     F1, V1, P1 = stage(y, a, s0)
-    F2, V2, P2 = stage(torch.add(y, F1, alpha=-third), torch.add(a, V1, alpha=third), s0 + third)
-    F3, V3, P3 = stage(torch.add(y, F2, alpha=-dt).add_(F1, alpha=third), torch.add(a, V2, alpha=dt).add_(V1, alpha=-third),
-                       s0 + 2 * third)
-    F4, V4, P4 = stage(torch.add(y, F1, alpha=-dt).add_(F2, alpha=dt).add_(F3, alpha=-dt),
-                       torch.add(a, V1, alpha=dt).add_(V2, alpha=-dt).add_(V3, alpha=dt), s1)
-    y.add_(F1, alpha=-eighth).add_(F2, alpha=-3 * eighth).add_(F3, alpha=-3 * eighth).add_(F4, alpha=-eighth)
-    a.add_(V1, alpha=eighth).add_(V2, alpha=3 * eighth).add_(V3, alpha=3 * eighth).add_(V4, alpha=eighth)
+    F2, V2, P2 = stage(comb(y, [(F1, -third)]), comb(a, [(V1, third)]), s0 + third)
+    F3, V3, P3 = stage(comb(y, [(F2, -dt), (F1, third)]), comb(a, [(V2, dt), (V1, -third)]), s0 + 2 * third)
+    F4, V4, P4 = stage(comb(y, [(F1, -dt), (F2, dt), (F3, -dt)]), comb(a, [(V1, dt), (V2, -dt), (V3, dt)]), s1)
+    y = comb(y, [(F1, -eighth), (F2, -3 * eighth), (F3, -3 * eighth), (F4, -eighth)], inplace=True)
+    a = comb(a, [(V1, eighth), (V2, 3 * eighth), (V3, 3 * eighth), (V4, eighth)], inplace=True)
     for P, c in ((P1, eighth), (P2, 3 * eighth), (P3, 3 * eighth), (P4, eighth)):
       acc_params(P, c)
   return a, gparams

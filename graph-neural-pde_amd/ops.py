@@ -136,6 +136,23 @@ def attention_rows_bwd(graph, att, r_csr, heads, scale=None, scale_sigmoid=False
   return ds
 
 
+def lincomb(base, terms, out=None):
+  """base + sum_j c_j v_j in one pass (gnpde_lincomb); terms = [(v_j, c_j), ...], all tensors contiguous float32 of
+  base's shape.  `out` may be base (in-place update)."""
+  require_hip(base)
+  if out is None:
+    out = torch.empty_like(base)
+  vs = (ctypes.c_void_p * len(terms))(*[t[0].data_ptr() for t in terms])
+  cs = (ctypes.c_float * len(terms))(*[float(t[1]) for t in terms])
+  for v, _ in terms:
+    if v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != base.numel():
+      raise _lib.GnpdeError('lincomb: operands must be contiguous float32 tensors of one size')
+  if base.dtype != torch.float32 or not base.is_contiguous() or not out.is_contiguous():
+    raise _lib.GnpdeError('lincomb: operands must be contiguous float32 tensors of one size')
+  check(_lib.lib().gnpde_lincomb(ptr(base), vs, cs, len(terms), base.numel(), ptr(out), stream_of(base)))
+  return out
+
+
 def tall_skinny_gram(a, b, slabs=512):
   """a^T b for a [N, m], b [N, d] with N >> m, d  (weight gradients [A, N] x [N, d]).  The vendor GEMM gives such a
   product one workgroup per 16 x 32 output tile -- a handful of CUs streaming all of N (0.3 ms at the ogbn-arxiv

@@ -377,6 +377,12 @@ int gnpde_early_stop_eval(const gnpde_decoder_t* dec, const float* y, int32_t d,
 int gnpde_solver_set_early_stop(gnpde_solver_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
                                 int32_t trace_capacity);
 
+/* out[i] = base[i] + sum_j coef[j] * v[j][i]  for i < n, n_v <= GNPDE_MAX_PREV (host arrays of device pointers /
+ * coefficients): the stage algebra of host-driven Runge-Kutta loops (adjoint solve) in one pass.  out may alias
+ * base or any v[j]. */
+int gnpde_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
+                  void* stream);
+
 int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s);
 int gnpde_solver_destroy(gnpde_solver_t* s);
 

@@ -236,3 +236,23 @@ def test_degenerate_graphs(dev):
   assert_parity(att, att_ref, what='hub-only attention')
   wf, _, _ = ops.edge_attention(graph, st, True, False, False, like=qk)   # fused row path: hub phases only
   assert_parity(wf[:graph.e], att_ref.mean(dim=1)[graph.perm_long.cpu()], what='hub-only fused attention')
+
+
+@pytest.mark.parametrize('n', [1, 7, 4096 + 3, 169343 * 8 + 1])
+def test_lincomb(dev, n):
+  """gnpde_lincomb: base + sum_j c_j v_j, aligned and unaligned (offset view) operands, in place."""
+  from gnpde_amd import ops
+  g = torch.Generator().manual_seed(n % 1000)
+  buf = [torch.randn(n + 1, generator=g).to(dev) for _ in range(5)]
+  for off in (0, 1):
+    base = buf[0][off:off + n].contiguous() if off == 0 else buf[0][off:off + n]
+    vs = [b[off:off + n] for b in buf[1:]]
+    cs = [0.5, -1.25, 3.0, 0.125]
+    ref = base.double()
+    for v, c in zip(vs, cs):
+      ref = ref + c * v.double()
+    out = ops.lincomb(base, list(zip(vs, cs)))
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    inplace = base.clone()
+    ops.lincomb(inplace, [(vs[0], 2.0)], out=inplace)
+    assert torch.allclose(inplace, base + 2.0 * vs[0], rtol=1e-6, atol=1e-6)
