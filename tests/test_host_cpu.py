@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol():
   assert G.lib().gnpde_abi_version() == 1
 
 
+def test_every_entry_point_is_documented():
+  """INTEGRATION.md's table names every symbol of the C ABI (what it replaces in the reference)."""
+  header = open(os.path.join(ROOT, 'include', 'gnpde.h')).read()
+  doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+  missing = [n for n in sorted(set(re.findall(r'\b(gnpde_[a-z_0-9]+)\s*\(', header))) if n not in doc]
+  assert not missing, 'undocumented entry points: %s' % missing
+
+
 def test_structs_match_header_layout():
   # pointer-sized fields and int32s only: sizes are what the C compiler produces on x86-64
   assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 3 * 8
