@@ -9,6 +9,74 @@ import torch
 from . import _lib
 
 
+LONG_ROW = 512     # GNPDE_LONG_ROW
+
+
+def build_arrays_on_device(edge_index, n):
+  """The arrays of gnpde_graph_build, computed where the edge list already lives (sort / scan / gather ops), so
+  that blocks which hand over a NEW edge set every training forward (hard attention, rewiring; reference
+  src/block_transformer_hard_attention.py:55-61) pay neither the device->host copy of [2,E] int64 nor the host
+  counting sort.  Element for element the same result as csrc/graph_prep.cpp: both sorts are stable."""
+  dev = edge_index.device
+  e = int(edge_index.shape[1])
+  row, col = edge_index[0].long(), edge_index[1].long()
+  i32 = dict(dtype=torch.int32, device=dev)
+  out = {}
+  if e > 0:
+    lo = torch.minimum(row.min(), col.min())
+    hi = torch.maximum(row.max(), col.max())
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= n:
+      raise _lib.GnpdeError('libgnpde_hip error -1: graph_build: edge index outside [0,%d)' % n)
+  perm = torch.sort(row, stable=True).indices
+  colidx = col[perm]
+  deg = torch.bincount(row, minlength=n) if e > 0 else torch.zeros(n, dtype=torch.long, device=dev)
+  rowptr = torch.zeros(n + 1, dtype=torch.long, device=dev)
+  rowptr[1:] = torch.cumsum(deg, 0)
+  cscpos = torch.sort(colidx, stable=True).indices
+  cdeg = torch.bincount(col, minlength=n) if e > 0 else torch.zeros(n, dtype=torch.long, device=dev)
+  cscptr = torch.zeros(n + 1, dtype=torch.long, device=dev)
+  cscptr[1:] = torch.cumsum(cdeg, 0)
+  long_rows = torch.nonzero(deg > LONG_ROW).flatten()
+  long_cols = torch.nonzero(cdeg > LONG_ROW).flatten()
+  chunks_per = (deg[long_rows] + LONG_ROW - 1) // LONG_ROW
+  chunk_ptr = torch.zeros(long_rows.numel() + 1, dtype=torch.long, device=dev)
+  chunk_ptr[1:] = torch.cumsum(chunks_per, 0)
+  which = torch.repeat_interleave(torch.arange(long_rows.numel(), device=dev), chunks_per)   # long-row slot of each chunk
+  within = torch.arange(which.numel(), device=dev) - chunk_ptr[which]
+  chunk_row = long_rows[which]
+  chunk_begin = rowptr[chunk_row] + within * LONG_ROW
+  chunk_end = torch.minimum(chunk_begin + LONG_ROW, rowptr[chunk_row + 1])
+  rows16 = torch.nonzero((deg >= 1) & (deg <= 16)).flatten()
+  rows64 = torch.nonzero((deg > 16) & (deg <= LONG_ROW)).flatten()
+  listed = torch.cat([rows16, rows64])
+  bins = torch.stack([listed, rowptr[listed], deg[listed], torch.zeros_like(listed)], dim=1).reshape(-1)
+
+  def fit(t, size):
+    buf = torch.zeros(max(int(size), 1), **i32)
+    buf[:t.numel()] = t.to(torch.int32)
+    return buf
+  out['rowptr'] = rowptr.to(torch.int32)
+  out['colidx'] = fit(colidx, e)
+  out['perm'] = fit(perm, e)
+  out['rowidx'] = fit(row[perm], e)
+  out['cscptr'] = cscptr.to(torch.int32)
+  out['cscpos'] = fit(cscpos, e)
+  nlr, nlc = int(long_rows.numel()), int(which.numel())
+  out['long_rows'] = fit(long_rows, nlr)
+  out['long_chunk_ptr'] = chunk_ptr.to(torch.int32)
+  out['long_chunk_row'] = fit(chunk_row, nlc)
+  out['long_chunk_begin'] = fit(chunk_begin, nlc)
+  out['long_chunk_end'] = fit(chunk_end, nlc)
+  out['long_cols'] = fit(long_cols, long_cols.numel())
+  out['bin_rows'] = fit(bins, 4 * max(n, 1))
+  out['long_chunk_first'] = fit(chunk_ptr[which], nlc)
+  counts = dict(n_long_rows=nlr, n_long_chunks=nlc, n_long_cols=int(long_cols.numel()), n_bin16=int(rows16.numel()),
+                n_bin64=int(rows64.numel()), max_row_len=int(deg.max()) if n > 0 and e > 0 else 0,
+                max_col_len=int(cdeg.max()) if n > 0 and e > 0 else 0)
+  return out, counts
+
+
 class CSRGraph(object):
   """Device-resident CSR view of `edge_index` for a square N x N operator.
 
@@ -22,6 +90,11 @@ class CSRGraph(object):
     self.device = device
     self.n = int(num_nodes)
     self.e = int(edge_index.size(1))
+    self._ws = {}
+    self._transposed = None
+    if edge_index.is_cuda and edge_index.device == device:
+      self._init_on_device(edge_index.detach())
+      return
     L = _lib.lib()
     ei = edge_index.detach().to('cpu', torch.int64).contiguous()
     row = ei[0].contiguous().numpy()
@@ -63,9 +136,23 @@ class CSRGraph(object):
     for k in order + ['long_chunk_first']:
       setattr(s, k, self.t[k].data_ptr())
     self.struct = s
-    self._ws = {}
-    self._edge_index_cpu = ei
-    self._transposed = None
+    self._edge_index = ei
+
+  def _init_on_device(self, edge_index):
+    self.t, c = build_arrays_on_device(edge_index, self.n)
+    self.n_long_rows, self.n_long_chunks, self.n_long_cols = c['n_long_rows'], c['n_long_chunks'], c['n_long_cols']
+    self.n_bin16, self.n_bin64 = c['n_bin16'], c['n_bin64']
+    self.max_row_len, self.max_col_len = c['max_row_len'], c['max_col_len']
+    self.perm_long = self.t['perm'][:self.e].long()
+    s = _lib.GraphStruct()
+    s.n, s.e = self.n, self.e
+    s.n_long_rows, s.n_long_chunks = self.n_long_rows, self.n_long_chunks
+    s.n_long_cols, s.n_bin16, s.n_bin64 = self.n_long_cols, self.n_bin16, self.n_bin64
+    s.max_row_len, s.max_col_len = self.max_row_len, self.max_col_len
+    for k, v in self.t.items():
+      setattr(s, k, v.data_ptr())
+    self.struct = s
+    self._edge_index = edge_index
 
   @property
   def rowptr(self):
@@ -86,7 +173,7 @@ class CSRGraph(object):
     """CSR of the transposed operator over the SAME edge list (edge e <-> same id), used by the backward
     pass: A^T g is an aggregation over the flipped edges."""
     if self._transposed is None:
-      self._transposed = CSRGraph(self._edge_index_cpu.flip(0), self.n, self.device)
+      self._transposed = CSRGraph(self._edge_index.flip(0), self.n, self.device)
     return self._transposed
 
   def workspace(self, tag, nbytes):

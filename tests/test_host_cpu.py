@@ -293,3 +293,26 @@ def test_header_is_valid_c_and_links(tmp_path):
     assert n == len(names)
     assert (sg, se, sd) == (ctypes.sizeof(_lib.GraphStruct), ctypes.sizeof(_lib.EpilogueStruct), ctypes.sizeof(_lib.DecoderStruct))
     assert sr == ctypes.sizeof(_lib.RhsStruct)
+
+
+@pytest.mark.parametrize('seed,hubs', [(0, 0), (1, 3), (2, 1)])
+def test_device_graph_build_equals_host_builder(seed, hubs):
+  """graph.build_arrays_on_device (sort / scan ops, run here on CPU tensors) produces element for element the arrays
+  of the C++ builder: CSR, stable permutation, CSC view, hub chunk lists, degree-class records, counts."""
+  from gnpde_amd.graph import build_arrays_on_device
+  n = 700
+  ei = random_graph(n, 6, seed, hubs=hubs, hub_deg=1300, isolated=4, dup=15)
+  host = G.CSRGraph(ei, n, device=torch.device('cpu'))
+  arrays, counts = build_arrays_on_device(ei, n)
+  for k in ('n_long_rows', 'n_long_chunks', 'n_long_cols', 'n_bin16', 'n_bin64', 'max_row_len', 'max_col_len'):
+    assert counts[k] == getattr(host, k), k
+  used = {'rowptr': n + 1, 'colidx': host.e, 'perm': host.e, 'rowidx': host.e, 'cscptr': n + 1, 'cscpos': host.e,
+          'long_rows': host.n_long_rows, 'long_chunk_ptr': host.n_long_rows + 1, 'long_chunk_row': host.n_long_chunks,
+          'long_chunk_begin': host.n_long_chunks, 'long_chunk_end': host.n_long_chunks, 'long_cols': host.n_long_cols,
+          'bin_rows': 4 * (host.n_bin16 + host.n_bin64), 'long_chunk_first': host.n_long_chunks}
+  for k, m in used.items():
+    assert torch.equal(arrays[k][:m].cpu(), host.t[k][:m].cpu()), k
+  empty, c0 = build_arrays_on_device(torch.zeros(2, 0, dtype=torch.long), 5)
+  assert c0['n_bin16'] == 0 and empty['rowptr'].tolist() == [0] * 6
+  with pytest.raises(G.GnpdeError):
+    build_arrays_on_device(torch.tensor([[0], [9]]), 5)
