@@ -167,8 +167,8 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
   controller: time and step size in float64, state in y0's dtype, rms error norm (or `norm`), the last stage
   derivative reused as the next step's first (rk_common.py: f1 = k[..., -1], also for the non-FSAL Heun pair),
   quartic-interpolated output."""
-  tb = _TABLEAUS[tableau]
-  order = tb['order']
+  tab = _TABLEAUS[tableau]
+  order = tab['order']
   nrm = norm if norm is not None else _rms
   dev = y0.device
   f64 = dict(dtype=torch.float64, device=dev)
@@ -198,17 +198,17 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
       dty = dt.to(y.dtype)
       ks = [f]
       yi = None
-      for a_i, b_i in zip(tb['alpha'], tb['beta']):
+      for a_i, b_i in zip(tab['alpha'], tab['beta']):
         yi = _combine(y, ks, b_i, dty)
         ks.append(func(t_cur + dt if a_i == 1.0 else t_cur + a_i * dt, yi))
-      y1 = yi if tb['fsal'] else _combine(y, ks, tb['c_sol'], dty)
+      y1 = yi if tab['fsal'] else _combine(y, ks, tab['c_sol'], dty)
       f1 = ks[-1]
-      err = _combine(None, ks, tb['c_err'], dty)
+      err = _combine(None, ks, tab['c_err'], dty)
       tol = atol_t + rtol_t * torch.max(y.abs(), y1.abs())
       ratio = nrm(err / tol)
       accept = bool(ratio <= 1)
       if accept:
-        y_mid = _combine(y, ks, tb['c_mid'], dty)
+        y_mid = _combine(y, ks, tab['c_mid'], dty)
         interp = (y, y1, y_mid, ks[0], ks[-1], dty, t_cur, t_cur + dt)
         t_prev, t_cur = t_cur, t_cur + dt
         y, f = y1, f1

@@ -107,3 +107,20 @@ def test_adjoint_without_grad_is_plain_solve():
   a = O.odeint_adjoint(f, y0, t, method='rk4', options={'step_size': 1.0})
   b = O.odeint(f, y0, t, method='rk4', options={'step_size': 1.0})
   assert torch.equal(a, b) and not a.requires_grad
+
+
+@pytest.mark.parametrize('method,opts', [('adaptive_heun', {}), ('dopri5', {}), ('rk4', {'step_size': 0.7}), ('euler', {'step_size': 0.3})])
+def test_forward_methods_match_restated_torchdiffeq(method, opts):
+  """odeint on a foreign callable (host loops): values and evaluation counts of every supported method against the
+  restated torchdiffeq, including several output times."""
+  from oracle.shims import install as S
+  y0 = torch.randn(20, 6, generator=torch.Generator().manual_seed(5))
+  t = torch.tensor([0.0, 0.9, 2.0])
+  res = []
+  for impl in (S.odeint, O.odeint):
+    f = _Dense()
+    with torch.no_grad():
+      out = impl(f, y0, t, method=method, options=dict(opts), rtol=1e-5, atol=1e-7)
+    res.append((out, f.nfe))
+  assert res[0][1] == res[1][1], 'evaluation count %d vs %d' % (res[1][1], res[0][1])
+  assert_parity(res[1][0], res[0][0], 2e-6)
