@@ -124,3 +124,42 @@ def test_forward_methods_match_restated_torchdiffeq(method, opts):
     res.append((out, f.nfe))
   assert res[0][1] == res[1][1], 'evaluation count %d vs %d' % (res[1][1], res[0][1])
   assert_parity(res[1][0], res[0][0], 2e-6)
+
+
+@pytest.mark.parametrize('stop_after', [None, 4, 100])
+def test_adaptive_solver_hooks_follow_the_reference_stepping(stop_after):
+  """The hooks the early-stopping dopri5 integrator relies on (`on_accept`, `stop_after`): accepted times / states and
+  the returned state against the reference's own loop (EarlyStopDopri5.advance, early_stop_solver.py:66-86, over
+  the restated RKAdaptiveStepsizeODESolver): a rejected trial counts towards the limit, and when the limit ends
+  the loop the state where it stopped is returned instead of the interpolation at the end time."""
+  from oracle.shims import install as S
+  y0 = torch.randn(20, 6, generator=torch.Generator().manual_seed(8))
+  t = torch.tensor([0.0, 3.0])
+  f_ref = _Dense()
+  with torch.no_grad():
+    solver = S.Dopri5Solver(func=S._PerturbFunc(f_ref), y0=y0, rtol=1e-4, atol=1e-6)
+    solver._before_integrate(t.to(torch.float64))
+    ref_times, ref_states, n_steps = [], [], 0
+    limit = 10 ** 9 if stop_after is None else stop_after
+    while t[1] > solver.rk_state.t1 and n_steps < limit:
+      before = float(solver.rk_state.t1)
+      solver.rk_state = solver._adaptive_step(solver.rk_state)
+      n_steps += 1
+      if float(solver.rk_state.t1) != before:
+        ref_times.append(float(solver.rk_state.t1))
+        ref_states.append(solver.rk_state.y1.clone())
+    end = t[1].to(torch.float64) if n_steps < limit else solver.rk_state.t1
+    ref_out = S._interp_evaluate(solver.rk_state.interp_coeff, solver.rk_state.t0, solver.rk_state.t1, end)
+  f = _Dense()
+  times, states = [], []
+  with torch.no_grad():
+    out = O._solve_dopri5(f, y0, t, 1e-4, 1e-6, on_accept=lambda y, t1: (times.append(t1), states.append(y.clone())),
+                          stop_after=stop_after)
+  # same trial / accept / reject sequence; the step SIZES come from fp32 error estimates summed in a different order
+  # (chained axpys here, a matmul there), so the accepted times agree to ~1e-4 and the states at those times with them
+  assert f.nfe == f_ref.nfe
+  assert len(times) == len(ref_times) and max(abs(a - b) / b for a, b in zip(times, ref_times)) < 1e-3
+  for a, b in zip(states, ref_states):
+    assert_parity(a, b, 1e-3)
+  cut = stop_after is not None and len(times) < 100 and times[-1] < float(t[1])
+  assert_parity(out[1], ref_out, 1e-3 if cut else 2e-5)
