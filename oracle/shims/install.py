@@ -245,6 +245,13 @@ class Data(object):
         self.__dict__[k] = v.to(device)
     return self
 
+  def is_undirected(self):
+    """Every edge has its reverse (PyG Data.is_undirected, for unweighted graphs)."""
+    n = self.num_nodes
+    key = self.edge_index[0] * n + self.edge_index[1]
+    rev = self.edge_index[1] * n + self.edge_index[0]
+    return bool(torch.equal(torch.sort(torch.unique(key)).values, torch.sort(torch.unique(rev)).values))
+
   def __call__(self, *keys):
     """PyG Data.__call__: iterate (key, value) over the named attributes that are set
     (used by the reference's EarlyStopRK4.test, early_stop_solver.py:162-168)."""

@@ -60,3 +60,13 @@ print('DROPIN_OK')
 def test_reference_gnn_builds_on_native_classes():
   res = subprocess.run([sys.executable, '-c', SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
   assert res.returncode == 0 and 'DROPIN_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.skipif(not ref_env.available(), reason='reference tree not present')
+def test_reference_unit_tests_pass_over_the_stand_ins():
+  """The reference's whole test directory (24 tests: attention known answers, normalisations, blocks, GNN, early
+  stopping) passes over oracle/shims -- what pins the stand-ins the golden vectors were generated with."""
+  res = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'run_reference_tests.py')], capture_output=True,
+                       text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+  assert 'ran 24, failures 0, errors 0' in res.stdout
