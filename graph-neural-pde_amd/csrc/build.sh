@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 ROOT="$(cd ../.. && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I${ROOT}/include -I. -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I${ROOT}/include -I. -Wall -Wno-unused-function -Wno-pass-failed"
 mkdir -p build
 objs=""
 pids=""
