@@ -60,9 +60,12 @@ class _LaplacianRhs(torch.autograd.Function):
     ctx.func, ctx.graph = func, graph
     # the weights of a solve are constant: one snapshot (and one transposed copy, see backward) serves every evaluation
     snap = func._cache.get('w_snapshot')
-    sig = (id(graph), func._cache['w_csr']['sig'])     # identity + version of the edge values the buffer was built from
-    if snap is None or snap[0] != sig:
-      snap = (sig, w_csr.clone(), {})
+    # keyed on the graph OBJECT (held by the snapshot, compared with `is`) and the monotonically increasing generation
+    # of the weight buffer's contents -- never on id(): the id of an attention tensor freed by an eval forward is
+    # reused by the next training forward's tensor, which would make a stale snapshot compare equal
+    gen = func._cache['w_csr']['gen']
+    if snap is None or snap[0] is not graph or snap[3] != gen:
+      snap = (graph, w_csr.clone(), {}, gen)
       func._cache['w_snapshot'] = snap
     ctx.w_extra = snap[2]
     w_csr = snap[1]

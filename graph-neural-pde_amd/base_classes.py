@@ -92,6 +92,7 @@ class ODEFunc(nn.Module):
       from .autograd import rhs_with_grad
       return rhs_with_grad(self, x)
     with torch.no_grad():
+      x = _lib.f32c(x)   # descriptor (leading dimension) and kernels must see the same, contiguous, operand
       return ops.rhs_eval(self._descriptor(x), x)
 
   def __repr__(self):

@@ -148,7 +148,7 @@ class NativeBackend(object):
       raise ValueError(kind)
     self._desc = {}
     self._ws = None
-    self._src_ptr = None
+    self._src, self._src_version = None, -1
 
   def _descriptor(self, with_source, part=None):
     """gnpde_rhs_t over the local shard: aggregation on the n_own rows (or the interior / boundary rows),
@@ -191,9 +191,12 @@ class NativeBackend(object):
     """One evaluation with a fused solver stage: ONE call into the library (projection over own + halo rows,
     attention and aggregation over the own rows), so the host side stays cheap next to the per-GPU work.
     part='interior' / 'boundary' runs the half of the evaluation that does not / does need the halo rows."""
-    if x0 is not None and x0.data_ptr() != self._src_ptr:   # new source tensor: refresh the persistent copy once
+    # new or modified source tensor: refresh the persistent copy.  Keyed on the tensor OBJECT (kept alive here, so its
+    # address cannot be handed to another tensor) and its version counter (in-place updates), not on data_ptr():
+    # the caching allocator gives the next forward's x0 the address of the freed previous one.
+    if x0 is not None and (x0 is not self._src or x0._version != self._src_version):
       self.x0.copy_(x0)
-      self._src_ptr = x0.data_ptr()
+      self._src, self._src_version = x0, x0._version
     desc = self._descriptor(x0 is not None, part)
     self.ops.rhs_stage(desc, u, stage, ws=self._ws, **stage_kw)
 

@@ -11,7 +11,8 @@ three masked accuracies with `.item()` (early_stop_solver.py:178-218).  Here the
 appended to the step inside the solver's hipGraph (csrc/early_stop.hip) and the four numbers are read back
 once, after the solve.  dopri5 keeps its host step-size controller (one scalar read per trial step) and runs the
 same device evaluator after each accepted step; a rejected trial leaves the state -- hence the accuracies and,
-with the strict comparison, the best -- unchanged, but still counts towards `max_test_steps`.
+with the strict comparison, the best -- unchanged, but still counts towards `max_test_steps` (trials rejected
+before the first accept evaluate the initial state once, at t0, as the reference does).
 """
 import torch
 
@@ -101,13 +102,24 @@ class EarlyStopDopri5(_EarlyStopSolver):
       times.append(t1)
       self.evaluator.evaluate(y if y.is_contiguous() else y.contiguous(), len(times) - 1)
 
+    seen_initial = []
+
+    def on_reject(y, t_cur):
+      # the reference evaluates rk_state.y1 after EVERY trial step (early_stop_solver.py:82-90); after a rejection
+      # that is the unchanged previous state, which matters exactly once: trials rejected before the first accept
+      # evaluate y0 at t0 (tag 0), so the initial state can become the best.  Later rejections re-evaluate a state
+      # already counted and cannot win the strict `val > best`.
+      if len(times) == 1 and not seen_initial:
+        seen_initial.append(True)
+        self.evaluator.evaluate(y if y.is_contiguous() else y.contiguous(), 0)
+
     self.evaluator.reset()
     if _native_ok(self.func, self.y0, t) and t.dtype == torch.float32:
       sol = _solve_dopri5_native(self.func, self.y0, t, self.rtol, self.atol, on_accept=on_accept,
-                                         stop_after=self.max_test_steps)
+                                         stop_after=self.max_test_steps, on_reject=on_reject)
     else:
       sol = _solve_dopri5(self.func, self.y0, t, self.rtol, self.atol, on_accept=on_accept,
-                                  stop_after=self.max_test_steps)
+                                  stop_after=self.max_test_steps, on_reject=on_reject)
     self._collect(times)
     return t[-1], sol
 

@@ -38,12 +38,15 @@ class LaplacianODEFunc(ODEFunc):
     ent = self._cache.get('w_csr')
     if ent is None or ent['graph'] is not graph:
       ent = {'graph': graph, 'buf': torch.empty(max(graph.e, 1), dtype=torch.float32, device=graph.device),
-             'sig': None, 'src': None}
+             'sig': None, 'src': None, 'gen': 0}
       self._cache['w_csr'] = ent
     sig = (id(src), src._version)
     if ent['sig'] != sig:
       ops.edge_to_csr_mean(graph, src, out=ent['buf'])  # in place: captured graphs keep the pointer
       ent['sig'], ent['src'] = sig, src
+      # generation of the buffer's CONTENTS: ids of freed tensors are reused by Python, this counter is not
+      self._w_generation = getattr(self, '_w_generation', 0) + 1
+      ent['gen'] = self._w_generation
     return ent['buf']
 
   def sparse_multiply(self, x):

@@ -133,9 +133,9 @@ class SpGraphTransAttentionLayer(nn.Module):
       return None
     ew = self.edge_weights
     ent = self._bufs.get('rw')
-    sig = (id(graph), id(ew), ew._version)
-    if ent is None or ent[0] != sig:
-      ent = (sig, ops.edge_to_csr_mean(graph, ew.to(graph.device)), ew)
+    # the entry holds graph and weight tensor themselves (compared with `is`): ids of freed objects get reused
+    if ent is None or ent[0] is not graph or ent[2] is not ew or ent[3] != ew._version:
+      ent = (graph, ops.edge_to_csr_mean(graph, ew.to(graph.device)), ew, ew._version)
       self._bufs['rw'] = ent
     return ent[1]
 

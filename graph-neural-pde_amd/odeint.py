@@ -162,7 +162,7 @@ def _combine(y0, ks, coeffs, dt):
 
 
 def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9, ifactor=10.0, dfactor=0.2,
-                  on_accept=None, stop_after=None, tableau='dopri5', norm=None):
+                  on_accept=None, stop_after=None, tableau='dopri5', norm=None, on_reject=None):
   """Adaptive embedded Runge-Kutta (Dormand-Prince 5(4) by default, `adaptive_heun` 2(1)) with torchdiffeq 0.2.1's
   controller: time and step size in float64, state in y0's dtype, rms error norm (or `norm`), the last stage
   derivative reused as the next step's first (rk_common.py: f1 = k[..., -1], also for the non-FSAL Heun pair),
@@ -214,6 +214,8 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
         y, f = y1, f1
         if on_accept is not None:
           on_accept(y, float(t_cur))
+      elif on_reject is not None:
+        on_reject(y, float(t_cur))
       # step-size controller
       if ratio == 0:
         dt = dt * ifactor
@@ -242,7 +244,7 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
 
 
 def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2, on_accept=None,
-                         stop_after=None):
+                         stop_after=None, on_reject=None):
   """dopri5 with torchdiffeq 0.2.1's controller on the host (one scalar read per trial step) and everything
   state-sized on the device: each stage is ONE right-hand-side launch whose epilogue also forms the next stage
   input  y + sum_j (beta_ij dt) k_j  (GNPDE_STAGE_LINCOMB), the error ratio is a device reduction.  Same
@@ -318,6 +320,8 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
       t_cur = t_next
       if on_accept is not None:
         on_accept(y, t_cur)
+    elif on_reject is not None:
+      on_reject(y, t_cur)
     if ratio == 0:
       dt = dt * ifactor
     else:

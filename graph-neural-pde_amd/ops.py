@@ -325,11 +325,21 @@ class EarlyStopEvaluator(object):
     self.bias = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
     lab = labels.detach().to(dev).reshape(-1)
     self.labels = lab.to(torch.int32).contiguous()
-    masks = [m.detach().to(dev).reshape(-1).to(torch.bool) for m in (train_mask, val_mask, test_mask)]
     n = self.labels.numel()
-    for m in masks:
-      if m.numel() != n:
+    masks = []
+    for m in (train_mask, val_mask, test_mask):
+      m = m.detach().to(dev).reshape(-1)
+      if m.dtype != torch.bool:
+        # node-index splits: the reference's ogbn-arxiv Data carries train_mask = split_idx['train'] etc.
+        # (reference src/data.py:90), which `logits[mask]` / `y[mask]` index the same way as a bool mask
+        idx = m.long()
+        if idx.numel() > 0 and (int(idx.min()) < 0 or int(idx.max()) >= n):
+          raise _lib.GnpdeError('early stop: split index outside [0, %d)' % n)
+        m = torch.zeros(n, dtype=torch.bool, device=dev)
+        m[idx] = True
+      elif m.numel() != n:
         raise _lib.GnpdeError('early stop: mask of %d entries for %d labels' % (m.numel(), n))
+      masks.append(m)
     self.split = (masks[0].to(torch.uint8) | (masks[1].to(torch.uint8) << 1) | (masks[2].to(torch.uint8) << 2)).contiguous()
     self.sizes = [int(v) for v in torch.stack([m.sum() for m in masks]).tolist()]
     self.n = n
