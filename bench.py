@@ -4,9 +4,11 @@
 One "step" = one rk4 (3/8 rule) solver step = 4 evaluations of f(t,x) = alpha (A(x) x - x) + beta x0 on
 the synthetic ogbn-arxiv-shaped graph (169,343 nodes, ~2.48 M edges incl. self-loops, d = 128,
 attention_dim 16 / 4 heads, softmax over rows, add_source) -- BASELINE.json configs[2].  The K timed
-steps are ONE launch of the hipGraph-captured native solver (T = K, step_size = 1), state resident in HBM.
+steps are ONE launch of the hipGraph-captured native solver (T = K, step_size = 1), state resident in HBM;
+the launch is repeated `--replays` times (each bracketed by a device synchronisation) and the MEDIAN is reported.
 
   python bench.py --gpus 1 --steps 100 --warmup 10
+  python bench.py --graph rmat --steps 8 --warmup 1        (BASELINE configs[4] shape on ONE GPU: 2 M nodes, d = 256)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row-partitioned, RCCL halo)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the CSR aggregation
@@ -42,7 +44,10 @@ def parse():
   ap.add_argument('--function', default='transformer', choices=['transformer', 'laplacian'])
   ap.add_argument('--no-graph', action='store_true', help='launch the solver eagerly instead of via hipGraph')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-evals', type=int, default=6)
+  ap.add_argument('--cpu-evals', type=int, default=None,
+                  help='full-size evaluations of f timed on the host (default 6; the rmat shape needs ~100 GB of '
+                       'host temporaries per evaluation and is skipped unless a count is given)')
+  ap.add_argument('--replays', type=int, default=5, help='timed launches of the K-step solve (median reported)')
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
   ap.add_argument('--square-plus', action='store_true', help='squareplus normalisation (Cora best_params)')
@@ -64,6 +69,34 @@ def build_opt(cfg, args):
 
 class _Data(object):
   pass
+
+
+GRAPH_NAMES = {'arxiv': 'ogbn-arxiv', 'cora': 'Cora', 'rmat': 'RMAT-2M'}
+
+
+def metric_name(graph, d, world=1):
+  """BASELINE.json's metric with the graph that was ACTUALLY run."""
+  return 'ODE steps/sec (full-graph diffusion), %s d=%d rk4' % (GRAPH_NAMES.get(graph, graph), d)
+
+
+def workload_name(graph, function, K):
+  shape = {'arxiv': 'synthetic ogbn-arxiv-shaped graph (power-law degrees, 40 communities, shuffled ids)',
+           'cora': 'synthetic Cora-shaped graph (uniform random)',
+           'rmat': 'synthetic R-MAT graph (Graph500 parameters, 2^21 nodes, 40 M generated edges, symmetrised)'}[graph]
+  return '%s, GRAND-%s add_source, rk4 3/8-rule, step_size 1, T=%d, hipGraph-captured solver' % (
+    shape, 'nl scaled_dot softmax attention' if function == 'transformer' else 'l', K)
+
+
+def host_info():
+  model = ''
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        model = line.split(':', 1)[1].strip()
+        break
+  except OSError:
+    pass
+  return {'host_cores': os.cpu_count() or 1, 'cpu_model': model}
 
 
 def make_block(G, opt, ei, n, x, dev, T, seed):
@@ -232,12 +265,15 @@ def main():
       import functools
       main_block.test_integrator = functools.partial(G.odeint, use_graph=False)
     main_block(x)                          # untimed: instantiates the K-step hipGraph
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    z = main_block(x)                      # EXACTLY K steps
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    times = []
+    for _ in range(max(args.replays, 1)):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      z = main_block(x)                    # EXACTLY K steps
+      torch.cuda.synchronize()
+      times.append(time.perf_counter() - t0)
   assert torch.isfinite(z).all()
+  elapsed = sorted(times)[len(times) // 2]  # median replay
   steps_per_s = K / elapsed
   f = main_block.odefunc
   E = int(f.edge_index.shape[1])
@@ -257,15 +293,18 @@ def main():
     except Exception:
       traffic = None
   bytes_eval = bytes_nl if args.function == 'transformer' else bytes_l
+  # compulsory DRAM bytes of one aggregation launch with perfect reuse of gathered rows (SURVEY 8d B_min without the
+  # projection): colidx + w + one read of u + the per-row streams (x0 in, out)
+  dram_floor = E * 8 + n * (4 + 12 * d)
+  state_mb = n * d * 4 / 2 ** 20
   out = {
-    'metric': 'ODE steps/sec (full-graph diffusion), ogbn-arxiv d=128 rk4',
+    'metric': metric_name(args.graph, d),
     'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
     'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
     'dtype': 'f32', 'data': 'synthetic',
-    'config': {'workload': 'synthetic ogbn-arxiv-shaped graph (power-law, shuffled ids), GRAND-%s %s, rk4 3/8-rule, '
-                           'step_size 1, T=%d, hipGraph-captured solver' % (
-                             'nl scaled_dot softmax attention' if args.function == 'transformer' else 'l',
-                             'add_source', K),
+    'timing': {'replays': len(times), 'statistic': 'median', 'ms_per_step_min': round(1e3 * min(times) / K, 4),
+               'ms_per_step_max': round(1e3 * max(times) / K, 4)},
+    'config': {'workload': workload_name(args.graph, args.function, K),
                'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
                'attention_norm_idx': args.norm_idx, 'square_plus': args.square_plus,
@@ -276,25 +315,47 @@ def main():
                  'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                  'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                  'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2),
-                 'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d)},
+                 'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d),
+                 'dram_floor_bytes': dram_floor,
+                 'gathered_table_mib': round(state_mb, 1),
+                 'table_fits_infinity_cache': bool(state_mb < 256),
+                 'note': ('the gathered state (%.0f MiB) fits the 256 MiB Infinity Cache: `achieved` is gather-model bytes '
+                          'served mostly by MALL/L2, not DRAM bandwidth' % state_mb) if state_mb < 256 else
+                         ('the gathered state (%.0f MiB) exceeds the 256 MiB Infinity Cache: gathers are DRAM traffic '
+                          'except for hub columns' % state_mb)},
   }
+  if isinstance(traffic, dict):   # measured PMC record (tools/pmc_traffic.py): bytes + provenance
+    out['roofline']['traffic'] = traffic.get('bytes_per_launch')
+    out['roofline']['traffic_source'] = {k: traffic.get(k) for k in ('kernel', 'commit', 'fetch_bytes', 'write_bytes',
+                                                                       'dram_read_bytes', 'l2_hit_rate', 'method')}
   if early is not None:
     sol = early.solver
     out['early_stop'] = {'best_val': sol.best_val, 'best_test': sol.best_test, 'best_time': sol.best_time,
                          'classes': 40, 'evaluations': K}
-  if not args.no_cpu_baseline:
-    t_eval, ref = cpu_baseline(main_block, x_cpu, args.cpu_evals)
+  cpu_evals = args.cpu_evals
+  if cpu_evals is None:
+    cpu_evals = 6 if args.graph != 'rmat' else 0
+  if not args.no_cpu_baseline and cpu_evals == 0:
+    out['cpu_baseline'] = dict(host_info(), value=None, unit='steps/s', cores=None, kind='port',
+                               sample='skipped: one evaluation of the reference op sequence at this shape materialises '
+                                      '[E,d] temporaries of %.0f GB each (SURVEY 8d: "reference path OOM"); pass '
+                                      '--cpu-evals N to time it on a host that has the memory' % (E * d * 4 / 1e9))
+  elif not args.no_cpu_baseline:
+    t_eval, ref = cpu_baseline(main_block, x_cpu, cpu_evals)
     with torch.no_grad():
       f.x0 = x
       got = f(0.0, x)
     from oracle import restate as R
     e_inf, e_2 = R.parity_error(got, ref)
-    out['cpu_baseline'] = {'value': round(1.0 / (4 * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
-                           'kind': 'port',
-                           'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the best of a few torch thread counts, with the '
-                                     'reference op sequence (oracle/restate.py, torch CPU); steps/s = 1 / (4 t_eval)'
-                                     % (args.cpu_evals, args.cpu_evals / 4.0),
-                           'ms_per_rhs_eval': round(t_eval * 1e3, 2)}
+    out['cpu_baseline'] = dict(host_info(), **{
+      'value': round(1.0 / (4 * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+      'threads_used': torch.get_num_threads(), 'kind': 'port',
+      'kind_note': 'oracle/restate.py = the reference op sequence (index_select -> mul -> scatter_add, PyG softmax) in '
+                   'torch CPU; the reference src/ itself needs /root/reference and third-party wheels that do not exist '
+                   'on the GPU box',
+      'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the best of a few torch thread '
+                'counts (`threads_used` of `host_cores`); steps/s = 1 / (4 t_eval)' % (cpu_evals, cpu_evals / 4.0),
+      'ms_per_rhs_eval': round(t_eval * 1e3, 2)})
     out['parity_vs_oracle_one_eval'] = {'rel_max': e_inf, 'rel_l2': e_2}
     out['speedup_vs_cpu'] = round(steps_per_s / out['cpu_baseline']['value'], 1)
   print(json.dumps(out))

@@ -18,7 +18,8 @@ namespace gnpde {
 namespace {
 
 struct SpmmArgs {
-  int item_base, item_end;   // work items [item_base, item_end): < n_long_chunks are long-row chunks, then the rows
+  // work of one launch: long-row chunks [chunk_begin, chunk_end) and rows [row_begin, row_end)
+  int chunk_begin, chunk_end, row_begin, row_end;
   int n, n_long_chunks;
   const int* __restrict__ rowptr;
   const int* __restrict__ colidx;
@@ -34,33 +35,65 @@ struct SpmmArgs {
   gnpde_epilogue_t ep;
 };
 
-template <int VEC, int L, int K, int U, bool NTI, bool NT>
-__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(const SpmmArgs a) {
+
+// Work item of wave `lw` (index local to the XCD) of a block that runs on XCD x = blockIdx % 8.  Every XCD gets every
+// 8th long-row chunk FIRST (512 entries each = the longest-running waves: they start at time 0 and overlap with
+// everything else instead of forming the kernel's tail) and then a CONTIGUOUS eighth of the rows, so that rows that are
+// neighbours in the (locality-ordered) graph share that XCD's 4 MiB L2.  (Handing the chunks out contiguously put all
+// of them -- 58 % of the entries of the R-MAT graph, 10 % at the ogbn-arxiv shape -- on XCD 0: 42 ms instead of 18.)
+struct Item { int row, e0, e1, chunk; bool valid; };
+
+__device__ __forceinline__ int chunks_of_xcd(const SpmmArgs& a, int x) {
+  return (a.chunk_end - a.chunk_begin + kXcds - 1 - x) / kXcds;
+}
+__device__ __forceinline__ int rows_per_xcd(const SpmmArgs& a) { return (a.row_end - a.row_begin + kXcds - 1) / kXcds; }
+
+__device__ __forceinline__ Item item_of(const SpmmArgs& a, int x, int lw) {
+  Item it;
+  it.valid = false;
+  it.chunk = -1;
+  it.row = it.e0 = it.e1 = 0;
+  const int cx = chunks_of_xcd(a, x);
+  if (lw < cx) {
+    it.chunk = a.chunk_begin + lw * kXcds + x;
+    it.row = __builtin_amdgcn_readfirstlane(a.lc_row[it.chunk]);
+    it.e0 = __builtin_amdgcn_readfirstlane(a.lc_begin[it.chunk]);
+    it.e1 = __builtin_amdgcn_readfirstlane(a.lc_end[it.chunk]);
+    it.valid = true;
+    return it;
+  }
+  const int per = rows_per_xcd(a);
+  const int r = lw - cx;
+  if (r >= per) return it;
+  it.row = a.row_begin + x * per + r;
+  if (it.row >= a.row_end) return it;
+  it.e0 = __builtin_amdgcn_readfirstlane(a.rowptr[it.row]);
+  it.e1 = __builtin_amdgcn_readfirstlane(a.rowptr[it.row + 1]);
+  it.valid = it.e1 - it.e0 <= GNPDE_LONG_ROW;   // longer rows are processed as chunks
+  return it;
+}
+
+// blocks of WPB waves so that every XCD can reach the end of its local list
+inline unsigned balanced_grid(const SpmmArgs& a, int wpb) {
+  const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
+  const long long per_xcd = (cn + kXcds - 1) / kXcds + (rn + kXcds - 1) / kXcds;
+  long long blocks = (per_xcd + wpb - 1) / wpb;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks * kXcds);
+}
+
+template <int VEC, int L, int K, int U, bool NTI, bool NT, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void spmm_rows_kernel(const SpmmArgs a) {
   constexpr int G = kWave / L;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int item = __builtin_amdgcn_readfirstlane(a.item_base + static_cast<int>(blk) * kWavesPerBlock + wave);
-  if (item >= a.item_end) return;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * (BLK / kWave) + wave);
+  const Item it = item_of(a, xcd, lw);
+  if (!it.valid) return;
   const int sub = lane / L;   // neighbour slot
   const int cl = lane % L;    // column lane
-
-  // Work items: first the long-row chunks (512 edges each = the longest-running waves, so they start at time 0
-  // and overlap with everything else instead of forming the kernel's tail), then the rows.
-  int row, e0, e1;
-  int chunk = -1;
-  if (item >= a.n_long_chunks) {
-    row = item - a.n_long_chunks;
-    if (row >= a.n) return;
-    e0 = a.rowptr[row];
-    e1 = a.rowptr[row + 1];
-    if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed as chunks
-  } else {
-    chunk = item;
-    row = a.lc_row[chunk];
-    e0 = a.lc_begin[chunk];
-    e1 = a.lc_end[chunk];
-  }
+  const int row = it.row, e0 = it.e0, e1 = it.e1, chunk = it.chunk;
 
   float acc[K][VEC];
 #pragma unroll
@@ -161,16 +194,260 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(const SpmmArgs
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wide-row variant (state widths whose row fits ONE wave instruction: d <= 64 VEC).  Differences from
+// spmm_rows_kernel, all aimed at the HBM-bound shapes (RMAT, d = 256: 1-KB rows, table >> Infinity Cache):
+//  * the column ids and weights of up to 64 entries are fetched by ONE coalesced load per wave (lane = entry)
+//    and handed to the gather loop by v_readlane (G == 1: the neighbour is wave-uniform, so the row base
+//    address lives in SGPRs and the gather is `global_load_dwordx4 v, v_off, s[base]`) or by ds_bpermute
+//    (G > 1), instead of every lane group re-loading them: the dependent chain per 64 entries is
+//    index load -> U gathers, not (index load -> gather) x 64/(G U);
+//  * the per-row streaming operands of the epilogue (u_i, x0_i, y_i, k1_i) are requested BEFORE the gather
+//    loop, so their latency overlaps the gathers instead of extending the wave's life;
+//  * BLK = 64: one wavefront per workgroup, so a finished wave frees its slot at once (rows of a power-law
+//    graph differ by 100x in length; with 4 waves per workgroup the slots of the short ones idle until the
+//    longest is done);  PERSIST: a resident grid strides over the work items instead of one launch slot per row.
+// Same work items, same summation order inside a row (entries in CSR order, G slots combined by the xor
+// butterfly), same epilogue arithmetic.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, bool NT>
+struct Pre {   // epilogue operands requested ahead of the gather loop
+  float ui[VEC], x0[VEC], y[VEC], k1[VEC];
+};
+
+template <int VEC, bool NT>
+__device__ __forceinline__ bool stage_prefetchable(int stage) {
+  return stage == GNPDE_STAGE_RHS || stage == GNPDE_STAGE_EULER || (stage >= GNPDE_STAGE_RK1C && stage <= GNPDE_STAGE_RK4C);
+}
+
+// k = alpha (ax - u_i) + beta x0_i and the compact / euler / plain stages from operands already in registers
+template <int VEC, bool NT>
+__device__ __forceinline__ void epilogue_pre(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off,
+                                             const float (&ax)[VEC], const Pre<VEC, NT>& p) {
+  auto st = [](float* q, const float (&v)[VEC]) { if constexpr (NT) store_vec_nt<VEC>(q, v); else store_vec<VEC>(q, v); };
+  constexpr float kThird = 1.0f / 3.0f;
+  float k[VEC], o[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) k[v] = alpha * (ax[v] - p.ui[v]);
+  if (ep.x0 != nullptr) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * p.x0[v];
+  }
+  const float dt = ep.dt;
+  switch (ep.stage) {
+    case GNPDE_STAGE_RHS:
+      st(ep.out_k + off, k);
+      break;
+    case GNPDE_STAGE_EULER:
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = p.y[v] + dt * k[v];
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK1C:
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = p.ui[v] + (dt * k[v]) * kThird;
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK2C:
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (2.0f * p.y[v] - p.ui[v]) + dt * k[v];
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK3C:
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (2.0f * p.k1[v] - p.ui[v]) + dt * k[v];
+      st(ep.out_y + off, o);
+      break;
+    case GNPDE_STAGE_RK4C:
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = (((6.0f * p.k1[v] + 3.0f * p.ui[v]) - p.y[v]) + dt * k[v]) * 0.125f;
+      st(ep.out_y + off, o);
+      break;
+    default:
+      break;
+  }
+}
+
+
+// U gathers of one wave (G neighbours each) from the 64 (column id, weight) pairs held one per lane in cv / wv.
+// G == 1: the entry is wave-uniform -> v_readlane, row base address in SGPRs.  TAIL: entries >= cnt are skipped.
+template <int VEC, int L, int U, bool TAIL, bool FULL>
+__device__ __forceinline__ void gather_batch(const SpmmArgs& a, int cv, float wv, int t0, int cnt, int sub, int col,
+                                             bool col_ok_rt, float (&acc)[VEC]) {
+  const bool col_ok = FULL ? true : col_ok_rt;   // FULL: d == L * VEC, no column predicate
+  constexpr int G = kWave / L;
+  float vals[U][VEC];
+  float ww[U];
+#pragma unroll
+  for (int t = 0; t < U; ++t) {
+    int c;
+    bool ok = col_ok;
+    if constexpr (G == 1) {
+      const int idx = t0 + t;
+      c = __builtin_amdgcn_readlane(cv, idx & (kWave - 1));
+      ww[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), idx & (kWave - 1)));   // bit pattern, not a numeric conversion
+      if constexpr (TAIL) ok = ok && idx < cnt;
+    } else {
+      const int idx = t0 + t * G + sub;
+      c = __shfl(cv, idx & (kWave - 1), kWave);
+      ww[t] = __shfl(wv, idx & (kWave - 1), kWave);
+      if constexpr (TAIL) ok = ok && idx < cnt;
+    }
+    if constexpr (TAIL) ww[t] = ok ? ww[t] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
+    const float* rowp = a.u + static_cast<size_t>(c) * a.ld;
+    if (ok) load_vec<VEC>(rowp + col, vals[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < U; ++t)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(ww[t], vals[t][v], acc[v]);
+}
+
+template <int VEC, int L, int U, int BLK, bool PERSIST, bool NT, bool FULL>
+__global__ __launch_bounds__(BLK) void spmm_wide_kernel(const SpmmArgs a) {
+  constexpr int G = kWave / L;
+  constexpr int WPB = BLK / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / L;   // neighbour slot
+  const int cl = lane % L;    // column lane
+  const int col = cl * VEC;
+  const bool col_ok = FULL ? true : col < a.d;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * WPB + static_cast<int>(threadIdx.x >> 6));
+  const int stride = static_cast<int>(gridDim.x / kXcds) * WPB;   // waves per XCD of this launch
+  const int lw_end = chunks_of_xcd(a, xcd) + rows_per_xcd(a);
+  const bool pre_ok = a.plain_out == nullptr && stage_prefetchable<VEC, NT>(a.ep.stage);
+  const float alpha = a.plain_out == nullptr ? alpha_of(a.ep) : 0.0f;
+  const float beta = (a.plain_out == nullptr && a.ep.x0 != nullptr) ? *a.ep.beta : 0.0f;
+
+  for (; lw < lw_end; lw += stride) {
+    const Item it = item_of(a, xcd, lw);
+    if (!it.valid) {
+      if constexpr (PERSIST) continue; else break;
+    }
+    const int row = it.row, e0 = it.e0, e1 = it.e1, chunk = it.chunk;
+    const size_t off = static_cast<size_t>(row) * a.ld + col;
+
+    // epilogue operands: in flight while the neighbours are gathered
+    Pre<VEC, NT> pre;
+    const bool do_pre = pre_ok && chunk < 0 && sub == 0 && col_ok;
+    if (do_pre) {
+      auto ldp = [](const float* q, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(q, v); else load_vec<VEC>(q, v); };
+      load_vec<VEC>(a.u + off, pre.ui);
+      if (a.ep.x0 != nullptr) ldp(a.ep.x0 + off, pre.x0);
+      const int st = a.ep.stage;
+      if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) ldp(a.ep.y + off, pre.y);
+      if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) ldp(a.ep.k1 + off, pre.k1);
+    }
+
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+
+    for (int base = e0; base < e1; base += kWave) {
+      const int me = base + lane;
+      const bool in = me < e1;
+      const int cv = in ? a.colidx[me] : 0;     // ONE coalesced load of 64 column ids ...
+      const float wv = in ? a.w[me] : 0.0f;     // ... and weights per wave
+      const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;   // wave-uniform
+      // full batches of G*U entries without predicates (all U gathers issue back to back), then one predicated tail
+      int t0 = 0;
+      for (; t0 + G * U <= cnt; t0 += G * U) gather_batch<VEC, L, U, false, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+      if (t0 < cnt) gather_batch<VEC, L, U, true, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+    }
+
+    // combine the G neighbour slots (lanes with equal column lane)
+#pragma unroll
+    for (int o = L; o < kWave; o <<= 1)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], o, kWave);
+
+    if (sub != 0 || !col_ok) continue;
+    if (chunk >= 0) {
+      store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);
+      continue;  // spmm_long_reduce_kernel folds the chunks of a row in chunk order
+    }
+    if (a.plain_out != nullptr) {
+      store_vec<VEC>(a.plain_out + off, acc);
+      continue;
+    }
+    if (pre_ok) {
+      epilogue_pre<VEC, NT>(a.ep, alpha, beta, off, acc, pre);
+    } else {
+      float ui[VEC];
+      load_vec<VEC>(a.u + off, ui);
+      epilogue<VEC, NT>(a.ep, alpha, beta, off, acc, ui);
+    }
+    if constexpr (!PERSIST) break;
+  }
+}
+
+// resident grid for the persistent variants: every CU filled with the waves its registers admit
+inline unsigned persistent_grid(int wpb) { return xcd_grid(256LL * 32 / wpb); }
+
+template <int VEC, int L, int U, int BLK, bool PERSIST>
+void launch_wide(const SpmmArgs& a, hipStream_t s) {
+  constexpr int WPB = BLK / kWave;
+  unsigned grid = balanced_grid(a, WPB);
+  if (PERSIST && grid > persistent_grid(WPB)) grid = persistent_grid(WPB);
+  if (a.d == L * VEC) hipLaunchKernelGGL((spmm_wide_kernel<VEC, L, U, BLK, PERSIST, true, true>), dim3(grid), dim3(BLK), 0, s, a);
+  else hipLaunchKernelGGL((spmm_wide_kernel<VEC, L, U, BLK, PERSIST, true, false>), dim3(grid), dim3(BLK), 0, s, a);
+}
+
+// tune codes >= 100 (tools/spmm_ab.py): 100 + 10 * {0: U4, 1: U8, 2: U16} + {0: 256 thr, 1: 64 thr, 2: 256 thr persistent,
+// 3: 64 thr persistent}
+template <int VEC, int L>
+bool dispatch_wide(const SpmmArgs& a, hipStream_t s, int code) {
+  switch (code) {
+    case 100: launch_wide<VEC, L, 4, 256, false>(a, s); return true;
+    case 101: launch_wide<VEC, L, 4, 64, false>(a, s); return true;
+    case 102: launch_wide<VEC, L, 4, 256, true>(a, s); return true;
+    case 103: launch_wide<VEC, L, 4, 64, true>(a, s); return true;
+    case 110: launch_wide<VEC, L, 8, 256, false>(a, s); return true;
+    case 111: launch_wide<VEC, L, 8, 64, false>(a, s); return true;
+    case 112: launch_wide<VEC, L, 8, 256, true>(a, s); return true;
+    case 113: launch_wide<VEC, L, 8, 64, true>(a, s); return true;
+    case 120: launch_wide<VEC, L, 16, 256, false>(a, s); return true;
+    case 121: launch_wide<VEC, L, 16, 64, false>(a, s); return true;
+    case 122: launch_wide<VEC, L, 16, 256, true>(a, s); return true;
+    case 123: launch_wide<VEC, L, 16, 64, true>(a, s); return true;
+    default: return false;
+  }
+}
+
 template <int VEC, int L, int K, int U, bool NTI, bool NT = NTI>
 void launch_rows(const SpmmArgs& a, hipStream_t s) {
-  const long long items = static_cast<long long>(a.item_end) - a.item_base;
-  const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K, U, NTI, NT>), dim3(grid), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K, U, NTI, NT>), dim3(balanced_grid(a, kWavesPerBlock)), dim3(kBlock), 0, s, a);
+}
+
+template <int VEC, int L, int K, int U>
+void launch_rows_b64(const SpmmArgs& a, hipStream_t s) {   // one wavefront per workgroup (A/B: intra-block imbalance)
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, L, K, U, false, true, 64>), dim3(balanced_grid(a, 1)), dim3(64), 0, s, a);
 }
 
 template <int VEC>
 int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
   const int slots = (a.d + VEC - 1) / VEC;
+  int code = g_tune[GNPDE_TUNE_SPMM_VARIANT];
+  // default for 16-byte lanes and rows of 17..64 lanes (d = 68..256): the wide-row kernel, 8 gathers in flight, one
+  // wavefront per workgroup -- measured best at the ogbn-arxiv shape (178 vs 221 us) and within 1 % of the best at the
+  // R-MAT d = 256 shape (16.6 vs 16.8 ms), tools/spmm_ab.py, profiles/r02_ab_*.log
+  if (code == 0 && VEC == 4 && slots > 16 && slots <= 64) code = 111;
+  if (code == 99) code = 0;   // A/B: force the round-1 kernel
+  if (code >= 100) {
+    bool done = false;
+    if (slots <= 16) done = dispatch_wide<VEC, 16>(a, s, code);
+    else if (slots <= 32) done = dispatch_wide<VEC, 32>(a, s, code);
+    else if (slots <= 64) done = dispatch_wide<VEC, 64>(a, s, code);
+    if (done) return 0;
+  }
+  if (code == 50) {
+    if (slots <= 32 && slots > 16) { launch_rows_b64<VEC, 16, 2, 4>(a, s); return 0; }
+    if (slots <= 64 && slots > 32) { launch_rows_b64<VEC, 32, 2, 4>(a, s); return 0; }
+  }
   if (slots <= 8) launch_rows<VEC, 8, 1, 4, false, true>(a, s);
   else if (slots <= 16) launch_rows<VEC, 16, 1, 4, false, true>(a, s);
   else if (slots <= 32) {
@@ -237,16 +514,21 @@ template <int VEC, int L, int K, int U>
 __global__ __launch_bounds__(kBlock) void sddmm_kernel(const SddmmArgs s) {
   constexpr int G = kWave / L;
   const int lane = threadIdx.x & (kWave - 1);
-  const unsigned blk = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blk) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  // same XCD-balanced work list as the aggregation (item_of): every 8th chunk first, then a contiguous eighth of the rows
+  const int x = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  const int cx = (s.n_long_chunks + kXcds - 1 - x) / kXcds;
+  const int per = (s.n + kXcds - 1) / kXcds;
   int row, e0, e1;
-  if (item >= s.n_long_chunks) {
-    row = item - s.n_long_chunks;
+  if (lw >= cx) {
+    if (lw - cx >= per) return;
+    row = x * per + (lw - cx);
     if (row >= s.n) return;
     e0 = s.rowptr[row];
     e1 = s.rowptr[row + 1];
     if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed as chunks
   } else {
+    const int item = lw * kXcds + x;
     row = s.lc_row[item];
     e0 = s.lc_begin[item];
     e1 = s.lc_end[item];
@@ -306,8 +588,8 @@ int dispatch_sddmm(const gnpde_graph_t* g, const float* a, const float* b, int d
   s.rowptr = g->rowptr; s.colidx = g->colidx;
   s.lc_row = g->long_chunk_row; s.lc_begin = g->long_chunk_begin; s.lc_end = g->long_chunk_end;
   s.a = a; s.b = b; s.d = d; s.lda = lda; s.ldb = ldb; s.scale_ptr = scale; s.scale_sigmoid = scale_sigmoid; s.out = out;
-  const long long items = static_cast<long long>(g->n) + g->n_long_chunks;
-  const unsigned grid = xcd_grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
+  const long long per_xcd = (static_cast<long long>(g->n_long_chunks) + kXcds - 1) / kXcds + (static_cast<long long>(g->n) + kXcds - 1) / kXcds;
+  const unsigned grid = static_cast<unsigned>(((per_xcd + kWavesPerBlock - 1) / kWavesPerBlock) * kXcds);
   const int slots = (d + VEC - 1) / VEC;
 #define GNPDE_SDDMM(LL, KK, UU) hipLaunchKernelGGL((sddmm_kernel<VEC, LL, KK, UU>), dim3(grid), dim3(kBlock), 0, st, s)
   if (slots <= 16) GNPDE_SDDMM(16, 1, 4);
@@ -395,7 +677,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     GNPDE_CHECK_ARG(plain_out != u, GNPDE_EINVAL, "spmm: output aliases the gathered operand");
   }
   auto run = [&](const SpmmArgs& arg, hipStream_t st) -> int {
-    if (arg.item_end <= arg.item_base) return 0;
+    if (arg.chunk_end <= arg.chunk_begin && arg.row_end <= arg.row_begin) return 0;
     if (a16) return dispatch_rows<4>(arg, st);
     if (a8) return dispatch_rows<2>(arg, st);
     return dispatch_rows<1>(arg, st);
@@ -403,21 +685,14 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   const bool forked = fork != nullptr && fork->aux != nullptr && g->n_long_rows > 0;
   // rows and long-row chunks in one launch, then the per-row reduction of the chunk partials (a last-arriver
   // reduction inside the kernel was measured 1.7x slower: every agent-scope release fence writes back the
-  // XCD's dirty L2 lines); with a fork the chunks + reduction run as a parallel branch
-  a.item_base = forked ? g->n_long_chunks : 0;
-  a.item_end = g->n_long_chunks + g->n;
-  if (g->row_begin > 0) {  // boundary pass of a partitioned graph: rows [row_begin, n) only (chunks belong to them)
-    GNPDE_CHECK_ARG(!forked && g->row_begin <= g->n, GNPDE_EINVAL, "spmm: bad row_begin %d", g->row_begin);
-    if (g->n_long_chunks > 0) {
-      SpmmArgs c = a;
-      c.item_base = 0;
-      c.item_end = g->n_long_chunks;
-      const int rc0 = run(c, stream);
-      if (rc0 != 0) return rc0;
-      GNPDE_LAUNCH_CHECK();
-    }
-    a.item_base = g->n_long_chunks + g->row_begin;
-  }
+  // XCD's dirty L2 lines); with a fork the chunks + reduction run as a parallel branch.  The boundary pass of a
+  // partitioned graph covers rows [row_begin, n) only (its chunks belong to those rows).
+  GNPDE_CHECK_ARG(g->row_begin >= 0 && g->row_begin <= g->n, GNPDE_EINVAL, "spmm: bad row_begin %d", g->row_begin);
+  GNPDE_CHECK_ARG(!(forked && g->row_begin > 0), GNPDE_EINVAL, "spmm: fork with row_begin");
+  a.chunk_begin = 0;
+  a.chunk_end = forked ? 0 : g->n_long_chunks;
+  a.row_begin = g->row_begin;
+  a.row_end = g->n;
   int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();
@@ -425,8 +700,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     hipStream_t br = forked ? fork_begin(fork, stream) : stream;
     if (forked) {
       SpmmArgs c = a;
-      c.item_base = 0;
-      c.item_end = g->n_long_chunks;
+      c.chunk_end = g->n_long_chunks;
+      c.row_begin = c.row_end = 0;
       rc = run(c, br);
       if (rc != 0) return rc;
       GNPDE_LAUNCH_CHECK();

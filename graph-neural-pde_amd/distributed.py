@@ -369,14 +369,16 @@ def bench_main(args, rank, world, dev):
   if rank == 0:
     elapsed = float(el.item())
     E = int(ei_loops.shape[1])
+    names = {'arxiv': 'ogbn-arxiv', 'cora': 'Cora', 'rmat': 'RMAT-2M'}
     out = {
-      'metric': 'ODE steps/sec (full-graph diffusion), ogbn-arxiv d=128 rk4',
+      'metric': 'ODE steps/sec (full-graph diffusion), %s d=%d rk4' % (names.get(args.graph, args.graph), d),
       'value': round(K / elapsed, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
       'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': 'synthetic ogbn-arxiv-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
+      'config': {'workload': 'synthetic %s-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
                              'partitioned over %d GPUs, RCCL halo exchange per evaluation (eager launches)'
-                             % ('nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
+                             % (names.get(args.graph, args.graph),
+                                'nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
                  'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
