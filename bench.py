@@ -149,7 +149,8 @@ def dominant_kernel_time(G, block, x, reps=10):
       ops.attn_rhs_fused(graph, att, wqk, bqk, u, alpha, beta, x0, True, dt=1.0, **kw)
   else:
     w = torch.rand(max(graph.e, 1), device=dev) / 16
-    name = 'spmm_rows_kernel + spmm_long_reduce_kernel (CSR aggregation + fused epilogue / rk4 stage, incl. the hub-row fold)'
+    name = ('CSR aggregation + fused epilogue / rk4 stage: spmm_wide_kernel (16-byte lanes, d = 68..256; spmm_rows_kernel '
+            'otherwise) + spmm_long_reduce_kernel (hub-row fold)')
 
     def launch(u, kw):
       ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
