@@ -328,7 +328,7 @@ def main():
   if isinstance(traffic, dict):   # measured PMC record (tools/pmc_traffic.py): bytes + provenance
     out['roofline']['traffic'] = traffic.get('bytes_per_launch')
     out['roofline']['traffic_source'] = {k: traffic.get(k) for k in ('kernel', 'commit', 'fetch_bytes', 'write_bytes',
-                                                                       'dram_read_bytes', 'l2_hit_rate', 'method')}
+                                                                       'l2_hit_rate', 'method')}
   if early is not None:
     sol = early.solver
     out['early_stop'] = {'best_val': sol.best_val, 'best_test': sol.best_test, 'best_time': sol.best_time,

@@ -68,6 +68,12 @@ class DecoderStruct(ctypes.Structure):
               ('n_classes', ctypes.c_int32), ('d_dec', ctypes.c_int32)]
 
 
+class HaloStruct(ctypes.Structure):
+  _fields_ = [('world', ctypes.c_int32), ('rank', ctypes.c_int32), ('n_own', ctypes.c_int32), ('n_halo', ctypes.c_int32),
+              ('send_idx', c_vp), ('send_counts', c_int_p), ('recv_counts', c_int_p)]
+
+
+COMM_ID_BYTES = 128
 EARLY_STATE_INTS = 8 + 3 * 2048
 
 # name -> (restype, argtypes); every symbol include/gnpde.h declares
@@ -120,6 +126,18 @@ PROTOTYPES = {
   'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_gather_rows': (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,
                                        ctypes.c_int32, c_vp]),
+  'gnpde_comm_load_library': (ctypes.c_int, [ctypes.c_char_p]),
+  'gnpde_comm_get_unique_id': (ctypes.c_int, [c_vp]),
+  'gnpde_comm_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_comm_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_sharded_solver_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(HaloStruct), ctypes.POINTER(RhsStruct),
+                                                             ctypes.POINTER(RhsStruct), ctypes.c_int32]),
+  'gnpde_sharded_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(HaloStruct),
+                                                 ctypes.POINTER(RhsStruct), ctypes.POINTER(RhsStruct), ctypes.c_int32,
+                                                 c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
+  'gnpde_sharded_solver_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_sharded_solver_num_rhs_evals': (ctypes.c_int, [c_vp]),
+  'gnpde_sharded_solver_destroy': (ctypes.c_int, [c_vp]),
 }
 
 

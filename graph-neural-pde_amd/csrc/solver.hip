@@ -9,6 +9,7 @@
 // 1 (GRAND-l) or 5 (GRAND-nl) launches per stage here and a single graph launch per forward pass.
 #include <vector>
 #include "common.h"
+#include "rhs.h"
 
 namespace gnpde {
 
@@ -23,12 +24,6 @@ int launch_attn_rhs_fused(const gnpde_graph_t* g, const gnpde_attention_t* at, c
                           const float* u, int d, int ld, const gnpde_epilogue_t* epi, void* ws, size_t ws_bytes,
                           hipStream_t stream);
 
-namespace {
-
-struct RhsLayout {
-  size_t proj, wmean, att, spmm, fused, total;
-  size_t att_bytes, spmm_bytes, fused_bytes;
-};
 
 // The projection comes FIRST so that two descriptors over the same state rows (interior / boundary pass of a
 // partitioned graph) that are handed the same workspace see the SAME q||k buffer; the regions behind it are
@@ -77,7 +72,7 @@ int check_rhs(const gnpde_rhs_t* r) {
 
 // Enqueue f(u) with the given epilogue.  `ws` follows rhs_layout.
 int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, char* ws, const RhsLayout& L,
-                hipStream_t s, const Fork* fork = nullptr) {
+                hipStream_t s, const Fork* fork) {
   const gnpde_graph_t* g = r.graph;
   const float* w = r.w_csr;
   if (r.kind == GNPDE_RHS_TRANSFORMER && fused_attn_supported(r.att, r.d, r.ld, u, &epi) &&
@@ -117,7 +112,6 @@ gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r) {
   return e;
 }
 
-}  // namespace
 }  // namespace gnpde
 
 using namespace gnpde;

@@ -266,6 +266,97 @@ class ShardedSolver(object):
     return y[:n]
 
 
+# --------------------------------------------------------------------------------------------------
+# native sharded solver: the whole solve enqueued by the library, RCCL inside the hipGraph
+# --------------------------------------------------------------------------------------------------
+_comm_cache = {}
+
+
+def _rccl_library_path():
+  """The librccl torch.distributed's nccl backend uses: handing the same file to the library makes both share one
+  RCCL instance in the process (the copy bundled with torch has no SONAME, so a bare dlopen('librccl.so.1') would
+  load a second one from /opt/rocm)."""
+  cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+  return cand if os.path.exists(cand) else None
+
+
+def native_comm(rank, world, group=None):
+  """gnpde_comm_t for this process: rank 0 draws the RCCL unique id, torch.distributed ships it (any backend), every
+  rank joins.  World 1 needs no process group (self send / recv)."""
+  key = (rank, world, id(group))
+  if key in _comm_cache:
+    return _comm_cache[key]
+  import ctypes
+  L = _lib.lib()
+  path = _rccl_library_path()
+  _lib.check(L.gnpde_comm_load_library(path.encode() if path else None))
+  buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+  if rank == 0:
+    _lib.check(L.gnpde_comm_get_unique_id(buf))
+  if world > 1:
+    box = [bytes(buf.raw)]
+    dist.broadcast_object_list(box, src=0, group=group)
+    buf = ctypes.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+  handle = ctypes.c_void_p()
+  _lib.check(L.gnpde_comm_create(ctypes.byref(handle), buf, rank, world))
+  _comm_cache[key] = handle
+  return handle
+
+
+class NativeShardedSolver(object):
+  """gnpde_sharded_solver_t over a NativeBackend's shard: same result as ShardedSolver (the Python-driven loop), but the
+  host issues ONE hipGraphLaunch per solve; the exchange is a grouped ncclSend / ncclRecv inside the graph."""
+
+  def __init__(self, shard, backend, T, step_size=1.0, method='rk4', with_source=True, comm=None):
+    import ctypes
+    self.shard, self.be = shard, backend
+    s = shard
+    L = _lib.lib()
+    grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
+    dts = (grid[1:] - grid[:-1]).tolist()
+    self.d_int = backend._descriptor(with_source, 'interior')
+    self.d_bnd = backend._descriptor(with_source, 'boundary')
+    self.send_counts = (ctypes.c_int32 * s.world)(*[int(v) for v in s.send_counts])
+    self.recv_counts = (ctypes.c_int32 * s.world)(*[int(v) for v in s.recv_counts])
+    self.halo = _lib.HaloStruct(world=s.world, rank=s.rank, n_own=s.n_own, n_halo=s.n_halo,
+                                send_idx=_lib.ptr(backend.send_idx) if backend.send_idx.numel() else None,
+                                send_counts=self.send_counts, recv_counts=self.recv_counts)
+    exchanges = sum(s.send_counts) + sum(s.recv_counts) > 0
+    self.comm = comm if comm is not None else (native_comm(s.rank, s.world) if exchanges else None)
+    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
+    need = L.gnpde_sharded_solver_workspace_bytes(ctypes.byref(self.halo), self.d_int.ref(), self.d_bnd.ref(), self.method)
+    if need == 0:
+      raise _lib.GnpdeError('sharded solver: %s' % L.gnpde_last_error().decode(errors='replace'))
+    self.ws = torch.empty(int(need), dtype=torch.uint8, device=backend.dev)
+    arr = (ctypes.c_float * len(dts))(*dts)
+    handle = ctypes.c_void_p()
+    _lib.check(L.gnpde_sharded_solver_create(ctypes.byref(handle), self.comm, ctypes.byref(self.halo), self.d_int.ref(),
+                                             self.d_bnd.ref(), self.method, arr, len(dts), _lib.ptr(self.ws), self.ws.numel()))
+    self.handle = handle
+    self.y = backend.empty(s.n_local)
+    self.n_rhs_evals = L.gnpde_sharded_solver_num_rhs_evals(handle)
+
+  def integrate(self, y_own, x0_own=None, use_graph=True):
+    """Owned rows of y(T) (a view of an internal buffer).  x0_own refreshes the persistent source term in place."""
+    be = self.be
+    if x0_own is not None:
+      be.x0.copy_(x0_own)
+    self.y[:self.shard.n_own].copy_(y_own)
+    _lib.check(_lib.lib().gnpde_sharded_solver_run(self.handle, _lib.ptr(self.y), int(bool(use_graph)), _lib.stream_of(self.y)))
+    return self.y[:self.shard.n_own]
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      _lib.lib().gnpde_sharded_solver_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+
 def scatter_rows(x_global, shard):
   """Owned rows of a replicated global tensor, in the shard's local order."""
   return x_global[shard.own_old_ids.to(x_global.device)]
@@ -318,25 +409,42 @@ def bench_main(args, rank, world, dev):
   if kind == 'laplacian':
     params = dict(edge_weight=w_loops[shard.edge_ids])
   be = NativeBackend(shard, d, dev, kind, params, torch.tensor(0.0), torch.tensor(0.1), True)
-  solver = ShardedSolver(shard, be)
   x_own = scatter_rows(x, shard).to(dev)
   K, W = args.steps, args.warmup
+  python_loop = os.environ.get('GNPDE_SHARDED_PYTHON_LOOP', '0') == '1'   # the round-1 driver, kept for A/B
+  use_graph = not args.no_graph
   with torch.no_grad():
-    if W > 0:
-      solver.integrate(x_own, x_own, float(W), 1.0, 'rk4')
-    torch.cuda.synchronize(dev)
-    dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    y = solver.integrate(x_own, x_own, float(K), 1.0, 'rk4')
-    torch.cuda.synchronize(dev)
-    dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    if python_loop:
+      solver = ShardedSolver(shard, be)
+      run = lambda T: solver.integrate(x_own, x_own, float(T), 1.0, 'rk4')   # noqa: E731
+      if W > 0:
+        run(W)
+    else:
+      if W > 0:
+        warm = NativeShardedSolver(shard, be, float(W), 1.0, 'rk4')
+        warm.integrate(x_own, x_own, use_graph=use_graph)
+        torch.cuda.synchronize(dev)
+        warm.close()
+      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4')
+      solver.integrate(x_own, x_own, use_graph=use_graph)                    # untimed: captures the K-step graph
+      run = lambda T: solver.integrate(x_own, x_own, use_graph=use_graph)   # noqa: E731
+    times = []
+    for _ in range(max(getattr(args, 'replays', 1), 1)):
+      torch.cuda.synchronize(dev)
+      dist.barrier()
+      torch.cuda.synchronize(dev)
+      t0 = time.perf_counter()
+      y = run(K)
+      torch.cuda.synchronize(dev)
+      dist.barrier()
+      torch.cuda.synchronize(dev)
+      times.append(time.perf_counter() - t0)
+    elapsed = sorted(times)[len(times) // 2]
   # self-check outside the timed region: one sharded evaluation f(x) (incl. the halo exchange) against the
   # same evaluation on the unpartitioned graph, computed natively on this rank's GPU
   with torch.no_grad():
     from . import ops
+    y = y.clone()
     chk = ShardedSolver(shard, be)
     chk.y[:shard.n_own].copy_(x_own)
     chk.exchange(chk.y)
@@ -376,14 +484,15 @@ def bench_main(args, rank, world, dev):
       'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': 'synthetic %s-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
-                             'partitioned over %d GPUs, RCCL halo exchange per evaluation (eager launches)'
+                             'partitioned over %d GPUs, RCCL halo exchange per evaluation inside the per-rank hipGraph'
                              % (names.get(args.graph, args.graph),
                                 'nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
                  'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
                  'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
-                 'finite': bool(finite.item() == 1.0),
+                 'finite': bool(finite.item() == 1.0), 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
+                 'replays': len(times),
                  'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
       'roofline': None, 'cpu_baseline': None,
     }

@@ -393,6 +393,55 @@ int gnpde_solver_destroy(gnpde_solver_t* s);
 int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int32_t count, int32_t d,
                       float* dst, int32_t ld_dst, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-partitioned solve over the GPUs of one node: one process per GPU, RCCL point-to-point halo exchange once per
+ * evaluation of f, the whole solve (pack, grouped send/recv on a second stream, interior rows, boundary rows, every
+ * stage of every step) captured per rank in ONE hipGraph.  The reference has no counterpart (single device;
+ * nn.DataParallel replicas in src/ray_tune.py:65-66); this is the multi-GPU form of the solver loop of
+ * src/block_constant.py:57-62 that BASELINE.json's north star asks for.
+ *
+ * RCCL is bound at run time: gnpde_comm_load_library(path) names the librccl to use (NULL / never called: the first
+ * of "librccl.so.1", "librccl.so" that loads; a library already in the process is reused).
+ * Bootstrap: rank 0 calls gnpde_comm_get_unique_id, ships the GNPDE_COMM_ID_BYTES to the other ranks by any means
+ * (the Python host broadcasts them through torch.distributed), every rank calls gnpde_comm_create (collective).
+ * ---------------------------------------------------------------------------------------------- */
+#define GNPDE_COMM_ID_BYTES 128
+typedef struct gnpde_comm gnpde_comm_t;
+int gnpde_comm_load_library(const char* path);
+int gnpde_comm_get_unique_id(void* id_out /* GNPDE_COMM_ID_BYTES */);
+int gnpde_comm_create(gnpde_comm_t** out, const void* id, int32_t rank, int32_t world);
+int gnpde_comm_destroy(gnpde_comm_t* comm);
+
+/* What this rank exchanges per evaluation.  Local row numbering of the state: [interior rows | boundary rows | halo rows
+ * grouped by owning rank, ascending]; rows [0, n_own) are owned.  send_idx (device) lists, grouped by destination rank,
+ * the owned rows each peer needs (send_counts[p] of them for rank p); recv_counts[p] rows arrive from rank p and land,
+ * in rank order, in the halo region [n_own, n_own + n_halo) of the stage buffer -- nothing is unpacked. */
+typedef struct gnpde_halo {
+  int32_t world, rank;
+  int32_t n_own, n_halo;
+  const int32_t* send_idx;      /* device [sum(send_counts)]  */
+  const int32_t* send_counts;   /* host [world]               */
+  const int32_t* recv_counts;   /* host [world]               */
+} gnpde_halo_t;
+
+typedef struct gnpde_sharded_solver gnpde_sharded_solver_t;
+
+/* rhs_interior: descriptor over the graph view holding the rows without halo neighbours (graph->n = their count;
+ * projection rows [0, n_own)); rhs_boundary: the view holding the other owned rows (graph->n = n_own, graph->row_begin =
+ * number of interior rows; projection rows [n_own, n_own + n_halo)).  Both with n_state_rows = n_own + n_halo,
+ * ld == d, the same kind / scalars / x0 ([n_own, d]).  comm may be NULL when nothing is exchanged (world 1). */
+size_t gnpde_sharded_solver_workspace_bytes(const gnpde_halo_t* halo, const gnpde_rhs_t* rhs_interior,
+                                            const gnpde_rhs_t* rhs_boundary, int32_t method);
+int gnpde_sharded_solver_create(gnpde_sharded_solver_t** out, gnpde_comm_t* comm, const gnpde_halo_t* halo,
+                                const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int32_t method,
+                                const float* dts, int32_t n_steps, void* workspace, size_t workspace_bytes);
+/* y: [n_own + n_halo, d] device; the owned rows are integrated in place over the whole grid (halo rows are scratch).
+ * use_graph != 0: captured once per y pointer and replayed (the first call performs one exchange outside capture so
+ * that RCCL can set up its peer connections).  Every rank must call it (the exchange is collective). */
+int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_graph, void* stream);
+int gnpde_sharded_solver_num_rhs_evals(const gnpde_sharded_solver_t* s);
+int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,11 +49,8 @@ def main():
       rec['bytes_per_launch'] = rec['fetch_bytes'] + rec['write_bytes']
     if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m and m['TCC_HIT_sum'] + m['TCC_MISS_sum'] > 0:
       rec['l2_hit_rate'] = round(m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']), 4)
-    if 'TCC_EA0_RDREQ_DRAM_sum' in m and 'TCC_EA0_RDREQ_sum' in m and m['TCC_EA0_RDREQ_sum'] > 0:
-      # share of the L2's fabric read requests that went to DRAM rather than being served on the way (MALL)
-      rec['dram_share_of_fabric_reads'] = round(m['TCC_EA0_RDREQ_DRAM_sum'] / m['TCC_EA0_RDREQ_sum'], 4)
-      if 'fetch_bytes' in rec:
-        rec['dram_read_bytes'] = rec['fetch_bytes'] * rec['dram_share_of_fabric_reads']
+    # (TCC_EA0_RDREQ_DRAM_sum equals TCC_EA0_RDREQ_sum on gfx950 whether or not the Infinity Cache serves the request, so it
+    #  does not separate MALL hits from DRAM reads; the raw values stay in counters_mean_per_launch)
     if 'TCP_UTCL1_TRANSLATION_MISS_sum' in m and m.get('TCP_UTCL1_REQUEST_sum', 0) > 0:
       rec['utcl1_miss_rate'] = round(m['TCP_UTCL1_TRANSLATION_MISS_sum'] / m['TCP_UTCL1_REQUEST_sum'], 5)
     detail[k] = rec
