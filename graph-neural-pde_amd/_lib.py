@@ -74,6 +74,7 @@ class HaloStruct(ctypes.Structure):
 
 
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 128
 EARLY_STATE_INTS = 8 + 3 * 2048
 
 # name -> (restype, argtypes); every symbol include/gnpde.h declares
@@ -130,8 +131,19 @@ PROTOTYPES = {
   'gnpde_comm_get_unique_id': (ctypes.c_int, [c_vp]),
   'gnpde_comm_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.c_int32, ctypes.c_int32]),
   'gnpde_comm_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_p2p_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int32]),
+  'gnpde_p2p_get_handle': (ctypes.c_int, [c_vp, c_vp]),
+  'gnpde_p2p_connect': (ctypes.c_int, [c_vp, c_vp]),
+  'gnpde_p2p_buffer': (c_vp, [c_vp, ctypes.c_int32]),
+  'gnpde_p2p_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_sharded_solver_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(HaloStruct), ctypes.POINTER(RhsStruct),
-                                                             ctypes.POINTER(RhsStruct), ctypes.c_int32]),
+                                                             ctypes.POINTER(RhsStruct), ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_sharded_solver_create_p2p': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(HaloStruct),
+                                                     ctypes.POINTER(RhsStruct), ctypes.POINTER(RhsStruct), ctypes.c_int32,
+                                                     c_float_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                                     ctypes.POINTER(ctypes.c_int64), c_vp, ctypes.c_size_t]),
+  'gnpde_sharded_solver_status': (ctypes.c_int, [c_vp, c_int_p, ctypes.POINTER(ctypes.c_int64)]),
+  'gnpde_sharded_solver_set_spin_limit': (ctypes.c_int, [c_vp, ctypes.c_int64]),
   'gnpde_sharded_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(HaloStruct),
                                                  ctypes.POINTER(RhsStruct), ctypes.POINTER(RhsStruct), ctypes.c_int32,
                                                  c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),

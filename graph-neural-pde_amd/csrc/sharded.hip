@@ -15,13 +15,24 @@
 //   main stream : f on the INTERIOR rows (no halo neighbour) while the exchange is in flight; wait event;
 //                 f on the BOUNDARY rows (projects the halo rows that just arrived, then attends / aggregates).
 // Point-to-point sends use every xGMI link of the rank at once (no ring); nothing is unpacked: the halo region of the
-// stage buffer IS the receive buffer.  RCCL is bound at run time (dlopen / dlsym): the library has no link-time
-// dependency on it, single-GPU users never load it, and a Python host can hand over the very librccl its
-// torch.distributed already loaded.
+// stage buffer IS the receive buffer.
+//
+// Two transports for the exchange:
+//  * P2P (default): the stage buffers of every rank live in IPC-shared device memory (hipIpcGetMemHandle /
+//    hipIpcOpenMemHandle); a push kernel on the side stream stores this rank's boundary rows STRAIGHT INTO the peers'
+//    halo regions over xGMI and then raises an epoch flag in each peer's (fine-grained) flag array; the receiving rank's
+//    main stream runs a one-block wait kernel in front of its boundary pass.  No library call, no host involvement,
+//    nothing but kernel nodes in the graph -- and several ranks can share ONE GPU (processes map each other's memory
+//    the same way), which is how tests/test_sharded_gpu.py runs real 2- and 4-rank partitions on a single-GPU box.
+//  * RCCL (ncclSend / ncclRecv grouped per evaluation): bound at run time (dlopen / dlsym), so the library has no
+//    link-time dependency on it; eager launches only -- capturing the grouped send/recv on a forked stream sends
+//    hip::Stream::EndCapture of the HIP runtime bundled with torch 2.10 (7.0.51831) into unbounded recursion
+//    (profiles/r02_rccl_capture_segfault.txt).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <cstring>
 #include <vector>
+#include "gnpde.h"
 #include "common.h"
 #include "rhs.h"
 
@@ -90,8 +101,101 @@ struct gnpde_comm {
   hipStream_t stream = nullptr;     // the exchange runs beside the interior rows
 };
 
+// IPC-shared exchange memory of one rank.  data: n_buffers stage buffers (coarse-grained: read through L2 by the
+// kernels launched after the wait kernel; a kernel boundary invalidates stale lines).  ctl (fine-grained, never cached):
+// [0, 128) epoch flags written by the peers, [128] pushes done, [129] waits done, [130] push blocks finished, [131] error.
+constexpr int kCtlWords = 256, kCtlPush = 128, kCtlWait = 129, kCtlDone = 130, kCtlErr = 131, kMaxWorld = 128;
+
+struct gnpde_p2p {
+  int rank = 0, world = 1;
+  size_t buffer_bytes = 0;
+  int n_buffers = 0;
+  char* data = nullptr;
+  uint32_t* ctl = nullptr;
+  std::vector<char*> peer_data;
+  std::vector<uint32_t*> peer_ctl;
+  hipStream_t stream = nullptr;
+};
+
+namespace {
+
+struct PushArgs {
+  const float* src;            // local stage buffer
+  int ld, d, n_send, rank, world;
+  const int32_t* send_idx;     // [n_send] local rows, grouped by destination
+  const int32_t* seg;          // [world+1] prefix of the send counts
+  float* const* dst;           // [world] base of the SAME stage buffer on every peer
+  const long long* dst_row0;   // [world] first halo row of this rank's rows on peer p
+  uint32_t* const* peer_ctl;   // [world]
+  uint32_t* ctl;               // local
+};
+
+// One wavefront per row: copy it into the owner-side halo slot on the peer (xGMI stores), then -- last block -- publish
+// the new epoch in every peer's flag array (system-scope release after all row stores of all blocks).
+__global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  if (i < a.n_send) {
+    int p = 0;
+    while (p + 1 < a.world && i >= a.seg[p + 1]) ++p;
+    const float* src = a.src + static_cast<size_t>(a.send_idx[i]) * a.ld;
+    float* dst = a.dst[p] + static_cast<size_t>(a.dst_row0[p] + (i - a.seg[p])) * a.ld;
+    if ((a.d & 3) == 0 && (a.ld & 3) == 0) {
+      for (int c = lane * 4; c < a.d; c += kWave * 4)
+        *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+      for (int c = lane; c < a.d; c += kWave) dst[c] = src[c];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(a.ctl + kCtlDone, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.ctl + kCtlDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned e = __hip_atomic_load(a.ctl + kCtlPush, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      __hip_atomic_store(a.ctl + kCtlPush, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int p = 0; p < a.world; ++p)
+        if (p != a.rank) __hip_atomic_store(a.peer_ctl[p] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// In front of the boundary pass: wait until every peer has published the epoch of THIS evaluation.  Bounded spin: a
+// peer that never arrives sets the error word instead of hanging the GPU (gnpde_sharded_solver_status).
+__global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, int rank, int world, long long max_spins) {
+  __shared__ unsigned expect;
+  if (threadIdx.x == 0) {
+    expect = __hip_atomic_load(ctl + kCtlWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(ctl + kCtlWait, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int p = threadIdx.x;
+  if (p < world && p != rank) {
+    long long n = 0;
+    // (signed distance: epochs wrap after 2^32 evaluations)
+    while (static_cast<int>(__hip_atomic_load(ctl + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++n > max_spins) {
+        __hip_atomic_store(ctl + kCtlErr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __threadfence_system();
+}
+
+}  // namespace
+
 struct gnpde_sharded_solver {
   gnpde_comm* comm;
+  gnpde_p2p* p2p = nullptr;            // != nullptr: P2P transport, stage buffers are p2p buffers 0..3
+  int32_t* d_seg = nullptr;            // [world+1] on device (inside the workspace)
+  long long* d_dst_row0 = nullptr;     // [world]
+  float** d_dst[4] = {nullptr, nullptr, nullptr, nullptr};   // per stage buffer: [world] peer bases
+  uint32_t** d_peer_ctl = nullptr;     // [world]
+  size_t off_tables = 0;
   gnpde_rhs_t rhs_int, rhs_bnd;
   gnpde_graph_t g_int, g_bnd;
   RhsLayout L_int, L_bnd;
@@ -107,34 +211,53 @@ struct gnpde_sharded_solver {
   hipGraph_t graph_obj = nullptr;
   hipGraphExec_t exec = nullptr;
   float* captured_y = nullptr;
-  bool warmed = false;              // connections to the peers exist (first exchange must run outside capture)
+  bool exchanges = false;           // an exchange (and, with P2P, an epoch handshake with every peer) per evaluation
+  long long max_spins = 1LL << 24;  // bound of the wait kernel's poll loop (~1 us per poll): a lost peer cannot hang the GPU
   int n_evals = 0;
 };
 
 namespace {
 
-size_t sharded_layout(const gnpde_rhs_t& ri, const gnpde_rhs_t& rb, int method, int n_local, int n_send,
+// Workspace: [ua | ub | uc | send]  (RCCL transport only; with P2P the stage buffers live in the shared block)
+//            [device tables of the P2P transport] [scratch of one evaluation: max of the two passes]
+size_t sharded_layout(const gnpde_rhs_t& ri, const gnpde_rhs_t& rb, int method, int n_local, int n_send, int world, bool p2p,
                       gnpde_sharded_solver* s) {
   const size_t state = align_up(static_cast<size_t>(n_local) * ri.ld * 4, 256);
   size_t off = 0;
-  const size_t ua = off; off += state;
-  size_t ub = 0, uc = 0;
-  if (method == GNPDE_METHOD_RK4) {
-    ub = off; off += state;
-    uc = off; off += state;
+  size_t ua = 0, ub = 0, uc = 0, send = 0;
+  if (!p2p) {
+    ua = off; off += state;
+    if (method == GNPDE_METHOD_RK4) {
+      ub = off; off += state;
+      uc = off; off += state;
+    }
+    send = off; off += align_up(static_cast<size_t>(n_send > 0 ? n_send : 1) * ri.d * 4, 256);
   }
-  const size_t send = off; off += align_up(static_cast<size_t>(n_send > 0 ? n_send : 1) * ri.d * 4, 256);
+  const size_t tables = off;
+  if (p2p) off += align_up(static_cast<size_t>(world + 1) * 4, 256) + 6 * align_up(static_cast<size_t>(world) * 8, 256);
   const size_t rhs_off = off;
   const size_t ti = rhs_layout(ri).total, tb = rhs_layout(rb).total;
   off += ti > tb ? ti : tb;
   if (s) {
-    s->off_ua = ua; s->off_ub = ub; s->off_uc = uc; s->off_send = send; s->off_rhs = rhs_off;
+    s->off_ua = ua; s->off_ub = ub; s->off_uc = uc; s->off_send = send; s->off_rhs = rhs_off; s->off_tables = tables;
   }
   return off;
 }
 
-// pack + grouped send / recv of the halo rows of `u`; leaves e_recv recorded on the comm stream
-int enqueue_exchange(gnpde_sharded_solver* s, float* u, hipStream_t st) {
+float* stage_buffer(gnpde_sharded_solver* s, int b) {   // 0: y (P2P only), 1: ua, 2: ub, 3: uc
+  if (s->p2p) return reinterpret_cast<float*>(s->p2p->data + static_cast<size_t>(b) * s->p2p->buffer_bytes);
+  const size_t offs[4] = {0, s->off_ua, s->off_ub, s->off_uc};
+  return reinterpret_cast<float*>(s->ws + offs[b]);
+}
+
+int buffer_index(gnpde_sharded_solver* s, const float* u) {
+  for (int b = 0; b < 4; ++b)
+    if (stage_buffer(s, b) == u) return b;
+  return -1;
+}
+
+// RCCL: pack + grouped send / recv of the halo rows of `u`; leaves e_recv recorded on the comm stream
+int enqueue_exchange_rccl(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   gnpde_comm* c = s->comm;
   float* send = reinterpret_cast<float*>(s->ws + s->off_send);
   if (s->n_send > 0) {
@@ -158,19 +281,44 @@ int enqueue_exchange(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   return 0;
 }
 
+// P2P: push kernel on the side stream (rows into the peers' halo regions, then the epoch flags); e_recv = push issued
+int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
+  gnpde_p2p* x = s->p2p;
+  const int b = buffer_index(s, u);
+  GNPDE_CHECK_ARG(b >= 0, GNPDE_ESTATE, "sharded solver: stage input is not a shared stage buffer");
+  GNPDE_HIP(hipEventRecord(s->e_pack, st));
+  GNPDE_HIP(hipStreamWaitEvent(x->stream, s->e_pack, 0));
+  PushArgs a;
+  a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = s->n_send; a.rank = x->rank; a.world = x->world;
+  a.send_idx = s->send_idx; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
+  a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl;
+  const unsigned grid = static_cast<unsigned>(s->n_send > 0 ? (s->n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
+  hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
+  GNPDE_LAUNCH_CHECK();
+  GNPDE_HIP(hipEventRecord(s->e_recv, x->stream));
+  return 0;
+}
+
 // exchange + f(u) with the fused stage: interior rows overlap the exchange, boundary rows follow it
 int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStream_t st) {
   char* rws = s->ws + s->off_rhs;
-  const bool exch = s->n_send > 0 || s->n_halo > 0;
+  const bool exch = s->exchanges;
   if (exch) {
-    const int rc = enqueue_exchange(s, u, st);
+    const int rc = s->p2p ? enqueue_exchange_p2p(s, u, st) : enqueue_exchange_rccl(s, u, st);
     if (rc) return rc;
   }
   if (s->g_int.n > 0) {
     const int rc = enqueue_rhs(s->rhs_int, u, e, rws, s->L_int, st);
     if (rc) return rc;
   }
-  if (exch) GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
+  if (exch) {
+    GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
+    if (s->p2p) {   // the peers' rows have landed once every peer has published this evaluation's epoch
+      hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, s->p2p->ctl, s->p2p->rank, s->p2p->world,
+                         s->max_spins);
+      GNPDE_LAUNCH_CHECK();
+    }
+  }
   if (s->g_bnd.n > s->g_bnd.row_begin) {
     const int rc = enqueue_rhs(s->rhs_bnd, u, e, rws, s->L_bnd, st);
     if (rc) return rc;
@@ -178,8 +326,9 @@ int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStrea
   return 0;
 }
 
+// y_work: the stage buffer that holds the state ([n_own + n_halo, ld]); the caller's y with RCCL, shared buffer 0 with P2P
 int enqueue_sharded_solve(gnpde_sharded_solver* s, float* y, hipStream_t st) {
-  float* ua = reinterpret_cast<float*>(s->ws + s->off_ua);
+  float* ua = stage_buffer(s, 1);
   gnpde_epilogue_t base = base_epilogue(s->rhs_int);
   if (s->method == GNPDE_METHOD_EULER) {
     float* cur = y;
@@ -195,8 +344,8 @@ int enqueue_sharded_solve(gnpde_sharded_solver* s, float* y, hipStream_t st) {
       GNPDE_HIP(hipMemcpyAsync(y, cur, static_cast<size_t>(s->n_own) * s->ld * 4, hipMemcpyDeviceToDevice, st));
     return 0;
   }
-  float* ub = reinterpret_cast<float*>(s->ws + s->off_ub);
-  float* uc = reinterpret_cast<float*>(s->ws + s->off_uc);
+  float* ub = stage_buffer(s, 2);
+  float* uc = stage_buffer(s, 3);
   for (float dt : s->dts) {   // compact rk4 stages (gnpde.h): stage states from the previous stage inputs
     gnpde_epilogue_t e = base;
     e.dt = dt;
@@ -216,14 +365,107 @@ int enqueue_sharded_solve(gnpde_sharded_solver* s, float* y, hipStream_t st) {
   return 0;
 }
 
+// the whole solve of the caller's y: with P2P the state is copied into / out of the shared stage buffer 0
+int enqueue_run(gnpde_sharded_solver* s, float* y, hipStream_t st) {
+  if (!s->p2p) return enqueue_sharded_solve(s, y, st);
+  float* y0 = stage_buffer(s, 0);
+  const size_t bytes = static_cast<size_t>(s->n_own) * s->ld * 4;
+  GNPDE_HIP(hipMemcpyAsync(y0, y, bytes, hipMemcpyDeviceToDevice, st));
+  const int rc = enqueue_sharded_solve(s, y0, st);
+  if (rc) return rc;
+  GNPDE_HIP(hipMemcpyAsync(y, y0, bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 void drop_sharded_graph(gnpde_sharded_solver* s) {
   if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
   if (s->graph_obj) { (void)hipGraphDestroy(s->graph_obj); s->graph_obj = nullptr; }
   s->captured_y = nullptr;
 }
 
+int check_sharded_args(const gnpde_halo_t* h, const gnpde_rhs_t* ri, const gnpde_rhs_t* rb) {
+  GNPDE_CHECK_ARG(h && ri && rb, GNPDE_EINVAL, "sharded solver: null argument");
+  int rc = check_rhs(ri);
+  if (rc) return rc;
+  rc = check_rhs(rb);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(h->world >= 1 && h->world <= kMaxWorld && h->n_own >= 0 && h->n_halo >= 0 && h->send_counts && h->recv_counts,
+                  GNPDE_EINVAL, "sharded solver: bad halo description");
+  GNPDE_CHECK_ARG(ri->d == rb->d && ri->ld == rb->ld && ri->kind == rb->kind, GNPDE_EINVAL,
+                  "sharded solver: interior / boundary descriptors disagree");
+  GNPDE_CHECK_ARG(ri->ld == ri->d, GNPDE_ESHAPE, "sharded solver: the state must be dense (ld == d): halo rows are received in place");
+  GNPDE_CHECK_ARG(ri->graph->n <= h->n_own && rb->graph->n == h->n_own && rb->graph->row_begin == ri->graph->n, GNPDE_EINVAL,
+                  "sharded solver: interior rows [0,%d) / boundary rows [%d,%d) do not tile the %d owned rows", ri->graph->n,
+                  rb->graph->row_begin, rb->graph->n, h->n_own);
+  return 0;
+}
+
+long long sum_counts(const int32_t* c, int world) {
+  long long t = 0;
+  for (int p = 0; p < world; ++p) t += c[p];
+  return t;
+}
+
+// common part of the two constructors
+int create_common(gnpde_sharded_solver** out, gnpde_comm* comm, gnpde_p2p* p2p, const gnpde_halo_t* halo,
+                  const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int method, const float* dts, int n_steps,
+                  void* workspace, size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "sharded_solver_create: out is null");
+  *out = nullptr;
+  int rc = check_sharded_args(halo, rhs_interior, rhs_boundary);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "sharded_solver_create: bad method %d", method);
+  GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "sharded_solver_create: bad time grid");
+  for (int p = 0; p < halo->world; ++p)
+    GNPDE_CHECK_ARG(halo->send_counts[p] >= 0 && halo->recv_counts[p] >= 0, GNPDE_EINVAL, "sharded_solver_create: negative count");
+  const long long n_send = sum_counts(halo->send_counts, halo->world), n_recv = sum_counts(halo->recv_counts, halo->world);
+  GNPDE_CHECK_ARG(n_recv == halo->n_halo, GNPDE_EINVAL, "sharded_solver_create: recv counts sum to %lld, halo has %d rows", n_recv, halo->n_halo);
+  GNPDE_CHECK_ARG(n_send == 0 || halo->send_idx != nullptr, GNPDE_EINVAL, "sharded_solver_create: send_idx is null");
+  gnpde_sharded_solver* s = new gnpde_sharded_solver();
+  s->comm = comm;
+  s->p2p = p2p;
+  // P2P: every rank signals every peer each evaluation (also with nothing to send), so world > 1 always "exchanges"
+  s->exchanges = p2p ? halo->world > 1 : (n_send > 0 || n_recv > 0);
+  s->rhs_int = *rhs_interior;
+  s->rhs_bnd = *rhs_boundary;
+  s->g_int = *rhs_interior->graph;
+  s->g_bnd = *rhs_boundary->graph;
+  s->rhs_int.graph = &s->g_int;
+  s->rhs_bnd.graph = &s->g_bnd;
+  s->L_int = rhs_layout(s->rhs_int);
+  s->L_bnd = rhs_layout(s->rhs_bnd);
+  s->method = method;
+  s->dts.assign(dts, dts + n_steps);
+  s->n_own = halo->n_own;
+  s->n_halo = halo->n_halo;
+  s->n_send = static_cast<int>(n_send);
+  s->d = rhs_interior->d;
+  s->ld = rhs_interior->ld;
+  s->send_counts.assign(halo->send_counts, halo->send_counts + halo->world);
+  s->recv_counts.assign(halo->recv_counts, halo->recv_counts + halo->world);
+  s->send_idx = halo->send_idx;
+  const size_t need = sharded_layout(s->rhs_int, s->rhs_bnd, method, s->n_own + s->n_halo, s->n_send, halo->world, p2p != nullptr, s);
+  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
+    set_error("sharded_solver_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+    delete s;
+    return GNPDE_EWS;
+  }
+  s->ws = static_cast<char*>(workspace);
+  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
+  hipError_t e = hipEventCreateWithFlags(&s->e_pack, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->e_recv, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+    gnpde_sharded_solver_destroy(s);
+    return static_cast<int>(e);
+  }
+  *out = s;
+  return 0;
+}
+
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ RCCL communicator
 extern "C" int gnpde_comm_load_library(const char* path) { return load_rccl(path); }
 
 extern "C" int gnpde_comm_get_unique_id(void* id_out) {
@@ -273,84 +515,146 @@ extern "C" int gnpde_comm_destroy(gnpde_comm_t* c) {
   return 0;
 }
 
-static int check_sharded_args(const gnpde_halo_t* h, const gnpde_rhs_t* ri, const gnpde_rhs_t* rb) {
-  GNPDE_CHECK_ARG(h && ri && rb, GNPDE_EINVAL, "sharded solver: null argument");
-  int rc = check_rhs(ri);
-  if (rc) return rc;
-  rc = check_rhs(rb);
-  if (rc) return rc;
-  GNPDE_CHECK_ARG(h->world >= 1 && h->n_own >= 0 && h->n_halo >= 0 && h->send_counts && h->recv_counts, GNPDE_EINVAL,
-                  "sharded solver: bad halo description");
-  GNPDE_CHECK_ARG(ri->d == rb->d && ri->ld == rb->ld && ri->kind == rb->kind, GNPDE_EINVAL,
-                  "sharded solver: interior / boundary descriptors disagree");
-  GNPDE_CHECK_ARG(ri->ld == ri->d, GNPDE_ESHAPE, "sharded solver: the state must be dense (ld == d): halo rows are received in place");
-  GNPDE_CHECK_ARG(ri->graph->n <= h->n_own && rb->graph->n == h->n_own && rb->graph->row_begin == ri->graph->n, GNPDE_EINVAL,
-                  "sharded solver: interior rows [0,%d) / boundary rows [%d,%d) do not tile the %d owned rows", ri->graph->n,
-                  rb->graph->row_begin, rb->graph->n, h->n_own);
+// ------------------------------------------------------------------------------------------------ P2P shared memory
+extern "C" int gnpde_p2p_create(gnpde_p2p_t** out, int32_t rank, int32_t world, size_t buffer_bytes, int32_t n_buffers) {
+  GNPDE_CHECK_ARG(out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n_buffers >= 1 && n_buffers <= 4 &&
+                  buffer_bytes > 0, GNPDE_EINVAL, "p2p_create: bad arguments");
+  *out = nullptr;
+  static_assert(2 * sizeof(hipIpcMemHandle_t) <= GNPDE_P2P_HANDLE_BYTES, "IPC handles do not fit");
+  gnpde_p2p* x = new gnpde_p2p();
+  x->rank = rank;
+  x->world = world;
+  x->buffer_bytes = align_up(buffer_bytes, 256);
+  x->n_buffers = n_buffers;
+  x->peer_data.assign(world, nullptr);
+  x->peer_ctl.assign(world, nullptr);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&x->data), x->buffer_bytes * n_buffers);
+  // flags other devices / processes write while a kernel of this rank polls them: fine-grained (never cached in L2)
+  if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&x->ctl), kCtlWords * sizeof(uint32_t), hipDeviceMallocFinegrained);
+  if (e == hipSuccess) e = hipMemset(x->data, 0, x->buffer_bytes * n_buffers);
+  if (e == hipSuccess) e = hipMemset(x->ctl, 0, kCtlWords * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    set_error("p2p_create failed: %s", hipGetErrorString(e));
+    gnpde_p2p_destroy(x);
+    return static_cast<int>(e);
+  }
+  x->peer_data[rank] = x->data;
+  x->peer_ctl[rank] = x->ctl;
+  *out = x;
   return 0;
 }
 
+extern "C" int gnpde_p2p_get_handle(gnpde_p2p_t* x, void* handle_out) {
+  GNPDE_CHECK_ARG(x && handle_out, GNPDE_EINVAL, "p2p_get_handle: null argument");
+  hipIpcMemHandle_t h[2];
+  GNPDE_HIP(hipIpcGetMemHandle(&h[0], x->data));
+  GNPDE_HIP(hipIpcGetMemHandle(&h[1], x->ctl));
+  std::memset(handle_out, 0, GNPDE_P2P_HANDLE_BYTES);
+  std::memcpy(handle_out, h, sizeof(h));
+  return 0;
+}
+
+extern "C" int gnpde_p2p_connect(gnpde_p2p_t* x, const void* handles) {
+  GNPDE_CHECK_ARG(x && handles, GNPDE_EINVAL, "p2p_connect: null argument");
+  const char* base = static_cast<const char*>(handles);
+  for (int p = 0; p < x->world; ++p) {
+    if (p == x->rank || x->peer_data[p] != nullptr) continue;
+    hipIpcMemHandle_t h[2];
+    std::memcpy(h, base + static_cast<size_t>(p) * GNPDE_P2P_HANDLE_BYTES, sizeof(h));
+    void* pd = nullptr;
+    void* pc = nullptr;
+    GNPDE_HIP(hipIpcOpenMemHandle(&pd, h[0], hipIpcMemLazyEnablePeerAccess));
+    GNPDE_HIP(hipIpcOpenMemHandle(&pc, h[1], hipIpcMemLazyEnablePeerAccess));
+    x->peer_data[p] = static_cast<char*>(pd);
+    x->peer_ctl[p] = static_cast<uint32_t*>(pc);
+  }
+  return 0;
+}
+
+extern "C" void* gnpde_p2p_buffer(gnpde_p2p_t* x, int32_t b) {
+  if (!x || b < 0 || b >= x->n_buffers) return nullptr;
+  return x->data + static_cast<size_t>(b) * x->buffer_bytes;
+}
+
+extern "C" int gnpde_p2p_destroy(gnpde_p2p_t* x) {
+  if (!x) return 0;
+  for (int p = 0; p < x->world; ++p) {
+    if (p == x->rank) continue;
+    if (x->peer_data[p]) (void)hipIpcCloseMemHandle(x->peer_data[p]);
+    if (x->peer_ctl[p]) (void)hipIpcCloseMemHandle(x->peer_ctl[p]);
+  }
+  if (x->stream) (void)hipStreamDestroy(x->stream);
+  if (x->data) (void)hipFree(x->data);
+  if (x->ctl) (void)hipFree(x->ctl);
+  delete x;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ solver
 extern "C" size_t gnpde_sharded_solver_workspace_bytes(const gnpde_halo_t* halo, const gnpde_rhs_t* rhs_interior,
-                                                       const gnpde_rhs_t* rhs_boundary, int32_t method) {
+                                                       const gnpde_rhs_t* rhs_boundary, int32_t method, int32_t p2p) {
   if (check_sharded_args(halo, rhs_interior, rhs_boundary)) return 0;
   if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4) return 0;
-  long long n_send = 0;
-  for (int p = 0; p < halo->world; ++p) n_send += halo->send_counts[p];
-  return sharded_layout(*rhs_interior, *rhs_boundary, method, halo->n_own + halo->n_halo, static_cast<int>(n_send), nullptr);
+  return sharded_layout(*rhs_interior, *rhs_boundary, method, halo->n_own + halo->n_halo,
+                        static_cast<int>(sum_counts(halo->send_counts, halo->world)), halo->world, p2p != 0, nullptr);
 }
 
 extern "C" int gnpde_sharded_solver_create(gnpde_sharded_solver_t** out, gnpde_comm_t* comm, const gnpde_halo_t* halo,
                                            const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int32_t method,
                                            const float* dts, int32_t n_steps, void* workspace, size_t workspace_bytes) {
-  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "sharded_solver_create: out is null");
-  *out = nullptr;
-  int rc = check_sharded_args(halo, rhs_interior, rhs_boundary);
+  if (halo && halo->send_counts && halo->recv_counts && halo->world >= 1 && halo->world <= kMaxWorld) {
+    const bool exch = sum_counts(halo->send_counts, halo->world) > 0 || sum_counts(halo->recv_counts, halo->world) > 0;
+    GNPDE_CHECK_ARG(!exch || (comm != nullptr && comm->world == halo->world && comm->rank == halo->rank), GNPDE_EINVAL,
+                    "sharded_solver_create: communicator does not match the halo description");
+  }
+  return create_common(out, comm, nullptr, halo, rhs_interior, rhs_boundary, method, dts, n_steps, workspace, workspace_bytes);
+}
+
+extern "C" int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnpde_p2p_t* p2p, const gnpde_halo_t* halo,
+                                               const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int32_t method,
+                                               const float* dts, int32_t n_steps, const int64_t* peer_halo_row0,
+                                               const int64_t* peer_buffer_bytes, void* workspace, size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(p2p && halo && peer_halo_row0 && peer_buffer_bytes, GNPDE_EINVAL, "sharded_solver_create_p2p: null argument");
+  GNPDE_CHECK_ARG(p2p->world == halo->world && p2p->rank == halo->rank, GNPDE_EINVAL, "sharded_solver_create_p2p: rank / world mismatch");
+  const int nbuf = method == GNPDE_METHOD_RK4 ? 4 : 2;
+  GNPDE_CHECK_ARG(p2p->n_buffers >= nbuf, GNPDE_EINVAL, "sharded_solver_create_p2p: %d shared buffers, need %d", p2p->n_buffers, nbuf);
+  const size_t state = static_cast<size_t>(halo->n_own + halo->n_halo) * (rhs_interior ? rhs_interior->ld : 0) * 4;
+  GNPDE_CHECK_ARG(p2p->buffer_bytes >= state, GNPDE_EINVAL, "sharded_solver_create_p2p: shared buffers of %zu bytes, state needs %zu",
+                  p2p->buffer_bytes, state);
+  for (int p = 0; p < p2p->world; ++p)
+    GNPDE_CHECK_ARG(p2p->peer_data[p] && p2p->peer_ctl[p], GNPDE_ESTATE, "sharded_solver_create_p2p: peer %d is not connected", p);
+  gnpde_sharded_solver* s = nullptr;
+  int rc = create_common(&s, nullptr, p2p, halo, rhs_interior, rhs_boundary, method, dts, n_steps, workspace, workspace_bytes);
   if (rc) return rc;
-  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "sharded_solver_create: bad method %d", method);
-  GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "sharded_solver_create: bad time grid");
-  long long n_send = 0, n_recv = 0;
-  for (int p = 0; p < halo->world; ++p) {
-    GNPDE_CHECK_ARG(halo->send_counts[p] >= 0 && halo->recv_counts[p] >= 0, GNPDE_EINVAL, "sharded_solver_create: negative count");
-    n_send += halo->send_counts[p];
-    n_recv += halo->recv_counts[p];
+  // device tables of the push kernel
+  const int W = halo->world;
+  char* t = s->ws + s->off_tables;
+  const size_t seg_bytes = align_up(static_cast<size_t>(W + 1) * 4, 256), tab = align_up(static_cast<size_t>(W) * 8, 256);
+  s->d_seg = reinterpret_cast<int32_t*>(t);
+  s->d_dst_row0 = reinterpret_cast<long long*>(t + seg_bytes);
+  s->d_peer_ctl = reinterpret_cast<uint32_t**>(t + seg_bytes + tab);
+  std::vector<int32_t> seg(W + 1, 0);
+  std::vector<long long> row0(W);
+  std::vector<uint32_t*> pctl(W);
+  for (int p = 0; p < W; ++p) {
+    seg[p + 1] = seg[p] + halo->send_counts[p];
+    row0[p] = peer_halo_row0[p];
+    pctl[p] = p2p->peer_ctl[p];
   }
-  GNPDE_CHECK_ARG(n_recv == halo->n_halo, GNPDE_EINVAL, "sharded_solver_create: recv counts sum to %lld, halo has %d rows", n_recv, halo->n_halo);
-  GNPDE_CHECK_ARG(n_send == 0 || halo->send_idx != nullptr, GNPDE_EINVAL, "sharded_solver_create: send_idx is null");
-  const bool exch = n_send > 0 || n_recv > 0;
-  GNPDE_CHECK_ARG(!exch || (comm != nullptr && comm->world == halo->world && comm->rank == halo->rank), GNPDE_EINVAL,
-                  "sharded_solver_create: communicator does not match the halo description");
-  gnpde_sharded_solver* s = new gnpde_sharded_solver();
-  s->comm = comm;
-  s->rhs_int = *rhs_interior;
-  s->rhs_bnd = *rhs_boundary;
-  s->g_int = *rhs_interior->graph;
-  s->g_bnd = *rhs_boundary->graph;
-  s->rhs_int.graph = &s->g_int;
-  s->rhs_bnd.graph = &s->g_bnd;
-  s->L_int = rhs_layout(s->rhs_int);
-  s->L_bnd = rhs_layout(s->rhs_bnd);
-  s->method = method;
-  s->dts.assign(dts, dts + n_steps);
-  s->n_own = halo->n_own;
-  s->n_halo = halo->n_halo;
-  s->n_send = static_cast<int>(n_send);
-  s->d = rhs_interior->d;
-  s->ld = rhs_interior->ld;
-  s->send_counts.assign(halo->send_counts, halo->send_counts + halo->world);
-  s->recv_counts.assign(halo->recv_counts, halo->recv_counts + halo->world);
-  s->send_idx = halo->send_idx;
-  const size_t need = sharded_layout(s->rhs_int, s->rhs_bnd, method, s->n_own + s->n_halo, s->n_send, s);
-  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
-    set_error("sharded_solver_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
-    delete s;
-    return GNPDE_EWS;
+  hipError_t e = hipMemcpy(s->d_seg, seg.data(), (W + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->d_dst_row0, row0.data(), W * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->d_peer_ctl, pctl.data(), W * 8, hipMemcpyHostToDevice);
+  for (int b = 0; b < 4 && e == hipSuccess; ++b) {
+    s->d_dst[b] = reinterpret_cast<float**>(t + seg_bytes + (2 + b) * tab);
+    std::vector<float*> dst(W);
+    for (int p = 0; p < W; ++p)
+      dst[p] = reinterpret_cast<float*>(p2p->peer_data[p] + static_cast<size_t>(b) * static_cast<size_t>(peer_buffer_bytes[p]));
+    e = hipMemcpy(s->d_dst[b], dst.data(), W * 8, hipMemcpyHostToDevice);
   }
-  s->ws = static_cast<char*>(workspace);
-  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
-  hipError_t e = hipEventCreateWithFlags(&s->e_pack, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->e_recv, hipEventDisableTiming);
   if (e != hipSuccess) {
-    set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+    set_error("sharded_solver_create_p2p: table upload failed: %s", hipGetErrorString(e));
     gnpde_sharded_solver_destroy(s);
     return static_cast<int>(e);
   }
@@ -361,28 +665,15 @@ extern "C" int gnpde_sharded_solver_create(gnpde_sharded_solver_t** out, gnpde_c
 extern "C" int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_graph, void* stream) {
   GNPDE_CHECK_ARG(s && y, GNPDE_EINVAL, "sharded_solver_run: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool exch = s->n_send > 0 || s->n_halo > 0;
-  if (!use_graph) {
-    s->warmed = true;
-    return enqueue_sharded_solve(s, y, st);
-  }
+  if (!use_graph) return enqueue_run(s, y, st);
+  GNPDE_CHECK_ARG(s->p2p != nullptr || !s->exchanges, GNPDE_ESTATE,
+                  "sharded_solver_run: the RCCL transport cannot be captured with this HIP runtime (hip::Stream::EndCapture "
+                  "recurses without bound on the forked send/recv stream); run it eagerly or use the P2P transport");
   if (s->exec == nullptr || s->captured_y != y) {
     drop_sharded_graph(s);
     if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
-    if (exch && !s->warmed) {
-      // RCCL sets up its peer connections (allocations, IPC mappings) on first use: that cannot happen inside stream
-      // capture.  One exchange of the scratch stage buffer outside capture, then wait for it.
-      float* ua = reinterpret_cast<float*>(s->ws + s->off_ua);
-      GNPDE_HIP(hipMemsetAsync(ua, 0, static_cast<size_t>(s->n_own + s->n_halo) * s->ld * 4, s->cap_stream));
-      const int rc = enqueue_exchange(s, ua, s->cap_stream);
-      if (rc) return rc;
-      GNPDE_HIP(hipStreamWaitEvent(s->cap_stream, s->e_recv, 0));
-      GNPDE_HIP(hipStreamSynchronize(s->cap_stream));
-      s->warmed = true;
-    }
-    // relaxed mode: RCCL may call capture-unsafe runtime functions on this thread while it records its kernels
-    GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeRelaxed));
-    const int rc = enqueue_sharded_solve(s, y, s->cap_stream);
+    GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_run(s, y, s->cap_stream);
     hipGraph_t gobj = nullptr;
     const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
     if (rc != 0) {
@@ -398,6 +689,22 @@ extern "C" int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int
     s->captured_y = y;
   }
   GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* timed_out, int64_t* epochs) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "sharded_solver_status: null solver");
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (s->p2p) GNPDE_HIP(hipMemcpy(w, s->p2p->ctl + kCtlPush, sizeof(w), hipMemcpyDeviceToHost));   // synchronises
+  if (timed_out) *timed_out = static_cast<int32_t>(w[kCtlErr - kCtlPush]);
+  if (epochs) *epochs = static_cast<int64_t>(w[0]);
+  return 0;
+}
+
+extern "C" int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins) {
+  GNPDE_CHECK_ARG(s != nullptr && max_spins > 0, GNPDE_EINVAL, "sharded_solver_set_spin_limit: bad argument");
+  drop_sharded_graph(s);
+  s->max_spins = max_spins;
   return 0;
 }
 

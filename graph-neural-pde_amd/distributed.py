@@ -303,13 +303,51 @@ def native_comm(rank, world, group=None):
   return handle
 
 
+class P2PContext(object):
+  """gnpde_p2p_t of this rank: IPC-shared stage buffers + flag array, connected to every peer.  The 128-byte handles and
+  the halo geometry of the peers travel through torch.distributed (any backend: gloo is enough, nothing here needs RCCL)."""
+
+  def __init__(self, shard, d, n_buffers=4, group=None):
+    import ctypes
+    L = _lib.lib()
+    s = shard
+    self.shard, self.d = shard, d
+    self.buffer_bytes = (max(s.n_local, 1) * d * 4 + 255) // 256 * 256
+    handle = ctypes.c_void_p()
+    _lib.check(L.gnpde_p2p_create(ctypes.byref(handle), s.rank, s.world, self.buffer_bytes, n_buffers))
+    self.handle = handle
+    buf = ctypes.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+    _lib.check(L.gnpde_p2p_get_handle(handle, buf))
+    mine = dict(handle=bytes(buf.raw), n_own=s.n_own, recv_counts=[int(v) for v in s.recv_counts],
+                buffer_bytes=self.buffer_bytes)
+    if s.world > 1:
+      metas = [None] * s.world
+      dist.all_gather_object(metas, mine, group=group)
+    else:
+      metas = [mine]
+    blob = b''.join(m['handle'] for m in metas)
+    _lib.check(L.gnpde_p2p_connect(handle, ctypes.create_string_buffer(blob, len(blob))))
+    # where THIS rank's rows start inside peer p's stage buffers: after p's own rows and the rows p receives from lower ranks
+    self.peer_row0 = [m['n_own'] + sum(m['recv_counts'][:s.rank]) for m in metas]
+    self.peer_buffer_bytes = [m['buffer_bytes'] for m in metas]
+    if s.world > 1:
+      dist.barrier(group=group)     # every rank has mapped every peer before anyone pushes
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      _lib.lib().gnpde_p2p_destroy(self.handle)
+      self.handle = None
+
+
 class NativeShardedSolver(object):
   """gnpde_sharded_solver_t over a NativeBackend's shard: same result as ShardedSolver (the Python-driven loop), but the
-  host issues ONE hipGraphLaunch per solve; the exchange is a grouped ncclSend / ncclRecv inside the graph."""
+  host issues ONE hipGraphLaunch per solve.  transport 'p2p' (default): boundary rows are pushed straight into the peers'
+  IPC-mapped halo regions by a kernel inside the graph; 'rccl': grouped ncclSend / ncclRecv, eager launches only."""
 
-  def __init__(self, shard, backend, T, step_size=1.0, method='rk4', with_source=True, comm=None):
+  def __init__(self, shard, backend, T, step_size=1.0, method='rk4', with_source=True, transport='p2p', ctx=None,
+               comm=None, group=None):
     import ctypes
-    self.shard, self.be = shard, backend
+    self.shard, self.be, self.transport = shard, backend, transport
     s = shard
     L = _lib.lib()
     grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
@@ -321,17 +359,33 @@ class NativeShardedSolver(object):
     self.halo = _lib.HaloStruct(world=s.world, rank=s.rank, n_own=s.n_own, n_halo=s.n_halo,
                                 send_idx=_lib.ptr(backend.send_idx) if backend.send_idx.numel() else None,
                                 send_counts=self.send_counts, recv_counts=self.recv_counts)
-    exchanges = sum(s.send_counts) + sum(s.recv_counts) > 0
-    self.comm = comm if comm is not None else (native_comm(s.rank, s.world) if exchanges else None)
     self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
-    need = L.gnpde_sharded_solver_workspace_bytes(ctypes.byref(self.halo), self.d_int.ref(), self.d_bnd.ref(), self.method)
+    p2p = transport == 'p2p'
+    need = L.gnpde_sharded_solver_workspace_bytes(ctypes.byref(self.halo), self.d_int.ref(), self.d_bnd.ref(), self.method, int(p2p))
     if need == 0:
       raise _lib.GnpdeError('sharded solver: %s' % L.gnpde_last_error().decode(errors='replace'))
     self.ws = torch.empty(int(need), dtype=torch.uint8, device=backend.dev)
     arr = (ctypes.c_float * len(dts))(*dts)
     handle = ctypes.c_void_p()
-    _lib.check(L.gnpde_sharded_solver_create(ctypes.byref(handle), self.comm, ctypes.byref(self.halo), self.d_int.ref(),
-                                             self.d_bnd.ref(), self.method, arr, len(dts), _lib.ptr(self.ws), self.ws.numel()))
+    self.ctx = self.comm = None
+    self._own_ctx = False
+    if p2p:
+      if ctx is None:
+        ctx = P2PContext(shard, backend.d, 4, group=group)
+        self._own_ctx = True
+      self.ctx = ctx
+      row0 = (ctypes.c_int64 * s.world)(*ctx.peer_row0)
+      pbytes = (ctypes.c_int64 * s.world)(*ctx.peer_buffer_bytes)
+      _lib.check(L.gnpde_sharded_solver_create_p2p(ctypes.byref(handle), ctx.handle, ctypes.byref(self.halo), self.d_int.ref(),
+                                                   self.d_bnd.ref(), self.method, arr, len(dts), row0, pbytes,
+                                                   _lib.ptr(self.ws), self.ws.numel()))
+    elif transport == 'rccl':
+      exchanges = sum(s.send_counts) + sum(s.recv_counts) > 0
+      self.comm = comm if comm is not None else (native_comm(s.rank, s.world, group) if exchanges else None)
+      _lib.check(L.gnpde_sharded_solver_create(ctypes.byref(handle), self.comm, ctypes.byref(self.halo), self.d_int.ref(),
+                                               self.d_bnd.ref(), self.method, arr, len(dts), _lib.ptr(self.ws), self.ws.numel()))
+    else:
+      raise ValueError(transport)
     self.handle = handle
     self.y = backend.empty(s.n_local)
     self.n_rhs_evals = L.gnpde_sharded_solver_num_rhs_evals(handle)
@@ -345,10 +399,23 @@ class NativeShardedSolver(object):
     _lib.check(_lib.lib().gnpde_sharded_solver_run(self.handle, _lib.ptr(self.y), int(bool(use_graph)), _lib.stream_of(self.y)))
     return self.y[:self.shard.n_own]
 
+  def status(self):
+    """(timed_out, epochs) -- synchronises; timed_out means a peer never published an evaluation's epoch."""
+    import ctypes
+    t, e = ctypes.c_int32(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().gnpde_sharded_solver_status(self.handle, ctypes.byref(t), ctypes.byref(e)))
+    return bool(t.value), int(e.value)
+
+  def set_spin_limit(self, n):
+    _lib.check(_lib.lib().gnpde_sharded_solver_set_spin_limit(self.handle, int(n)))
+
   def close(self):
     if getattr(self, 'handle', None) is not None and self.handle.value:
       _lib.lib().gnpde_sharded_solver_destroy(self.handle)
       self.handle = None
+    if self._own_ctx and self.ctx is not None:
+      self.ctx.close()
+      self.ctx = None
 
   def __del__(self):
     try:
@@ -420,12 +487,14 @@ def bench_main(args, rank, world, dev):
       if W > 0:
         run(W)
     else:
+      ctx = P2PContext(shard, d, 4)
       if W > 0:
-        warm = NativeShardedSolver(shard, be, float(W), 1.0, 'rk4')
+        warm = NativeShardedSolver(shard, be, float(W), 1.0, 'rk4', ctx=ctx)
         warm.integrate(x_own, x_own, use_graph=use_graph)
         torch.cuda.synchronize(dev)
+        dist.barrier()
         warm.close()
-      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4')
+      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', ctx=ctx)
       solver.integrate(x_own, x_own, use_graph=use_graph)                    # untimed: captures the K-step graph
       run = lambda T: solver.integrate(x_own, x_own, use_graph=use_graph)   # noqa: E731
     times = []
@@ -467,6 +536,7 @@ def bench_main(args, rank, world, dev):
     err = ((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30)).reshape(1).float()
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     del chk, full, f_full, xg
+  timed_out = False if python_loop else solver.status()[0]
   el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
   dist.all_reduce(el, op=dist.ReduceOp.MAX)
   finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=dev)
@@ -484,14 +554,15 @@ def bench_main(args, rank, world, dev):
       'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': 'synthetic %s-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
-                             'partitioned over %d GPUs, RCCL halo exchange per evaluation inside the per-rank hipGraph'
+                             'partitioned over %d GPUs, boundary rows pushed into the peers\' halo regions (IPC-mapped, xGMI '
+                             'stores + epoch flags) once per evaluation inside the per-rank hipGraph'
                              % (names.get(args.graph, args.graph),
                                 'nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
                  'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
                  'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
-                 'finite': bool(finite.item() == 1.0), 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
+                 'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
                  'replays': len(times),
                  'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
       'roofline': None, 'cpu_baseline': None,

@@ -424,21 +424,51 @@ typedef struct gnpde_halo {
   const int32_t* recv_counts;   /* host [world]               */
 } gnpde_halo_t;
 
+/* P2P transport (the default of the Python layer): the stage buffers of every rank live in IPC-shared device memory; a
+ * push kernel stores this rank's boundary rows straight into the peers' halo regions over xGMI and raises an epoch flag
+ * in each peer's flag array, a one-block wait kernel in front of the boundary pass polls the flags (bounded spin).  No
+ * library call and no host involvement per evaluation: the per-rank hipGraph holds kernel and memcpy nodes only.
+ * Several ranks may share one device (the processes map each other's memory the same way).
+ *   gnpde_p2p_create      allocates n_buffers (4 for rk4, 2 for euler) stage buffers of buffer_bytes >= (n_own + n_halo) * d * 4
+ *                         and the flag array (fine-grained memory)
+ *   gnpde_p2p_get_handle  -> GNPDE_P2P_HANDLE_BYTES to be all-gathered over the ranks by the host
+ *   gnpde_p2p_connect     handles of ALL ranks, [world][GNPDE_P2P_HANDLE_BYTES]; maps the peers' memory */
+#define GNPDE_P2P_HANDLE_BYTES 128
+typedef struct gnpde_p2p gnpde_p2p_t;
+int   gnpde_p2p_create(gnpde_p2p_t** out, int32_t rank, int32_t world, size_t buffer_bytes, int32_t n_buffers);
+int   gnpde_p2p_get_handle(gnpde_p2p_t* p2p, void* handle_out);
+int   gnpde_p2p_connect(gnpde_p2p_t* p2p, const void* handles);
+void* gnpde_p2p_buffer(gnpde_p2p_t* p2p, int32_t b);      /* device pointer of local stage buffer b */
+int   gnpde_p2p_destroy(gnpde_p2p_t* p2p);
+
 typedef struct gnpde_sharded_solver gnpde_sharded_solver_t;
 
 /* rhs_interior: descriptor over the graph view holding the rows without halo neighbours (graph->n = their count;
  * projection rows [0, n_own)); rhs_boundary: the view holding the other owned rows (graph->n = n_own, graph->row_begin =
  * number of interior rows; projection rows [n_own, n_own + n_halo)).  Both with n_state_rows = n_own + n_halo,
- * ld == d, the same kind / scalars / x0 ([n_own, d]).  comm may be NULL when nothing is exchanged (world 1). */
+ * ld == d, the same kind / scalars / x0 ([n_own, d]).
+ * gnpde_sharded_solver_create: RCCL transport (comm may be NULL when nothing is exchanged, world 1); EAGER launches only:
+ * capturing the grouped send/recv on a forked stream crashes the HIP 7.0 runtime bundled with torch 2.10.
+ * gnpde_sharded_solver_create_p2p: P2P transport; peer_halo_row0[p] = row of peer p's stage buffers where THIS rank's rows
+ * start (= n_own of p + the recv counts of p for ranks below this one), peer_buffer_bytes[p] = p's buffer_bytes (aligned
+ * up to 256). */
 size_t gnpde_sharded_solver_workspace_bytes(const gnpde_halo_t* halo, const gnpde_rhs_t* rhs_interior,
-                                            const gnpde_rhs_t* rhs_boundary, int32_t method);
+                                            const gnpde_rhs_t* rhs_boundary, int32_t method, int32_t p2p);
 int gnpde_sharded_solver_create(gnpde_sharded_solver_t** out, gnpde_comm_t* comm, const gnpde_halo_t* halo,
                                 const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int32_t method,
                                 const float* dts, int32_t n_steps, void* workspace, size_t workspace_bytes);
-/* y: [n_own + n_halo, d] device; the owned rows are integrated in place over the whole grid (halo rows are scratch).
- * use_graph != 0: captured once per y pointer and replayed (the first call performs one exchange outside capture so
- * that RCCL can set up its peer connections).  Every rank must call it (the exchange is collective). */
+int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnpde_p2p_t* p2p, const gnpde_halo_t* halo,
+                                    const gnpde_rhs_t* rhs_interior, const gnpde_rhs_t* rhs_boundary, int32_t method,
+                                    const float* dts, int32_t n_steps, const int64_t* peer_halo_row0,
+                                    const int64_t* peer_buffer_bytes, void* workspace, size_t workspace_bytes);
+/* y: device state whose first n_own rows are integrated in place over the whole grid (RCCL transport: [n_own + n_halo, d],
+ * the halo rows are scratch; P2P: [>= n_own, d], copied into / out of the shared stage buffer).  use_graph != 0: captured
+ * once per y pointer and replayed (P2P transport only).  Every rank must call it (the exchange is collective). */
 int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_graph, void* stream);
+/* Synchronises.  *timed_out != 0: a wait kernel gave up polling a peer's epoch flag (results are invalid);
+ * *epochs = evaluations this rank has published so far. */
+int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* timed_out, int64_t* epochs);
+int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins);
 int gnpde_sharded_solver_num_rhs_evals(const gnpde_sharded_solver_t* s);
 int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s);
 

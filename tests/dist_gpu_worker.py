@@ -1,0 +1,78 @@
+"""Worker for tests/test_sharded_gpu.py::test_ranks_sharing_one_gpu (launched by torch.distributed.run, gloo for the
+host-side bootstrap, EVERY rank on cuda:0).
+
+Each rank builds its shard of a real P-way partition, maps the other ranks' stage buffers through the IPC handles
+(distributed.P2PContext) and runs the native row-partitioned solver with the P2P transport: boundary rows are pushed
+into the peers' halo regions and awaited through epoch flags inside each rank's hipGraph.  Rank 0 gathers the owned rows,
+undoes the partition permutation and compares with the unpartitioned CPU oracle solve."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import gnpde_amd as G  # noqa: E402
+from gnpde_amd import distributed as D  # noqa: E402
+from oracle import restate as R  # noqa: E402
+from helpers import random_graph, parity  # noqa: E402
+
+
+def main():
+  out_path, kind, method, T = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+  dist.init_process_group('gloo')
+  rank, world = dist.get_rank(), dist.get_world_size()
+  dev = torch.device('cuda:0')
+  torch.cuda.set_device(dev)
+  n, d, A, h = 5000, 128, 16, 4
+  ei = random_graph(n, 8, seed=21, hubs=2, hub_deg=1200)
+  g = torch.Generator().manual_seed(22)
+  x = torch.randn(n, d, generator=g)
+  params = dict(Wq=torch.randn(A, d, generator=g) / d ** 0.5, Wk=torch.randn(A, d, generator=g) / d ** 0.5,
+                bq=torch.randn(A, generator=g) * 0.1, bk=torch.randn(A, generator=g) * 0.1, heads=h)
+  alpha, beta = torch.tensor(0.3), torch.tensor(0.2)
+  plan = D.PartitionPlan(ei, n, world)
+  sh = plan.shard(rank)
+  if kind == 'laplacian':
+    _, w = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
+    p = dict(edge_weight=w[sh.edge_ids])
+  else:
+    p = params
+  be = D.NativeBackend(sh, d, dev, kind, p, alpha, beta, True)
+  ctx = D.P2PContext(sh, d, 4)
+  x_own = D.scatter_rows(x, sh).to(dev)
+  res = {}
+  with torch.no_grad():
+    for use_graph in (False, True):
+      solver = D.NativeShardedSolver(sh, be, T, 1.0, method, ctx=ctx)
+      solver.set_spin_limit(1 << 22)
+      z1 = solver.integrate(x_own, x_own, use_graph=use_graph).clone()
+      z2 = solver.integrate(x_own, x_own, use_graph=use_graph).clone()   # second solve: epochs keep counting, graph replays
+      timed_out, epochs = solver.status()
+      assert not timed_out, 'rank %d: a peer never published its epoch' % rank
+      assert torch.equal(z1, z2), 'rank %d: repeated solve differs' % rank
+      res[use_graph] = z1
+      dist.barrier()
+      solver.close()
+    assert torch.equal(res[False], res[True]), 'rank %d: hipGraph replay differs from eager launches' % rank
+  full = D.gather_rows_all(res[True].cpu(), plan, sh)
+  if rank == 0:
+    if kind == 'laplacian':
+      rhs = lambda t, y: R.rhs_laplacian(y, ei, w, alpha, beta, x, False, True)   # noqa: E731
+    else:
+      rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
+                                           x, False, True)
+    ref = R.odeint_fixed(rhs, x, T, 1.0, method)
+    e_inf, e_2 = parity(full, ref)
+    json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
+               'interior_rows': sh.n_interior, 'own_rows': sh.n_own}, open(out_path, 'w'))
+  dist.barrier()
+  ctx.close()
+  dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()
