@@ -281,18 +281,19 @@ int enqueue_exchange_rccl(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   return 0;
 }
 
-// P2P: push kernel on the side stream (rows into the peers' halo regions, then the epoch flags); e_recv = push issued
+// P2P: push kernel on the side stream (rows into the peers' halo regions, then the epoch flags); e_recv = push issued.
+// u == nullptr: publish the epoch only (the end-of-solve rendezvous).
 int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   gnpde_p2p* x = s->p2p;
-  const int b = buffer_index(s, u);
+  const int b = u != nullptr ? buffer_index(s, u) : 0;
   GNPDE_CHECK_ARG(b >= 0, GNPDE_ESTATE, "sharded solver: stage input is not a shared stage buffer");
   GNPDE_HIP(hipEventRecord(s->e_pack, st));
   GNPDE_HIP(hipStreamWaitEvent(x->stream, s->e_pack, 0));
   PushArgs a;
-  a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = s->n_send; a.rank = x->rank; a.world = x->world;
+  a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = u != nullptr ? s->n_send : 0; a.rank = x->rank; a.world = x->world;
   a.send_idx = s->send_idx; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
   a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl;
-  const unsigned grid = static_cast<unsigned>(s->n_send > 0 ? (s->n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
+  const unsigned grid = static_cast<unsigned>(a.n_send > 0 ? (a.n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
   hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
   GNPDE_LAUNCH_CHECK();
   GNPDE_HIP(hipEventRecord(s->e_recv, x->stream));
@@ -371,9 +372,21 @@ int enqueue_run(gnpde_sharded_solver* s, float* y, hipStream_t st) {
   float* y0 = stage_buffer(s, 0);
   const size_t bytes = static_cast<size_t>(s->n_own) * s->ld * 4;
   GNPDE_HIP(hipMemcpyAsync(y0, y, bytes, hipMemcpyDeviceToDevice, st));
-  const int rc = enqueue_sharded_solve(s, y0, st);
+  int rc = enqueue_sharded_solve(s, y0, st);
   if (rc) return rc;
   GNPDE_HIP(hipMemcpyAsync(y, y0, bytes, hipMemcpyDeviceToDevice, st));
+  if (s->exchanges) {
+    // End-of-solve rendezvous (one more epoch, no rows).  Inside a solve a halo region is rewritten at the earliest two
+    // evaluations after it was read, and the per-evaluation handshake keeps every peer within one evaluation of this
+    // rank, so no acknowledgement is needed; but the LAST evaluation of a solve and the FIRST of the next one may use the
+    // same stage buffer (euler with an odd number of steps), and then a fast rank would push into a halo region its peer
+    // is still reading.  After this epoch every peer has finished its last boundary pass.
+    rc = enqueue_exchange_p2p(s, nullptr, st);
+    if (rc) return rc;
+    GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, s->p2p->ctl, s->p2p->rank, s->p2p->world, s->max_spins);
+    GNPDE_LAUNCH_CHECK();
+  }
   return 0;
 }
 
