@@ -220,7 +220,7 @@ def main():
     G.ops.tune(G._lib.TUNE_ONE_PASS, 1)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
-  dev = torch.device('cuda', local_rank)
+  dev = torch.device('cuda', 0 if os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') == '1' else local_rank)
   torch.cuda.set_device(dev)
   if world > 1 or os.environ.get('GNPDE_FORCE_SHARDED', '0') == '1':   # (the env switch exercises the sharded driver on one GPU)
     from gnpde_amd import distributed as D

@@ -6,11 +6,12 @@ classes.  The FORWARD value is always the native kernels' (identical to inferenc
     dL/dx   = a (A^T g - g)          one launch of the same aggregation kernel on the transposed CSR
     dL/dw_e = a g_row . x_col        gnpde_sddmm (only when the edge weights carry gradients: attention block)
     dL/da, dL/db                     two dot products over [N,d]
-* GRAND-nl with scaled-dot attention and a softmax over the row (the default configuration): native VJP --
+* GRAND-nl with scaled-dot attention and ANY normaliser (softmax or squareplus, over rows or -- attention_norm_idx = 1,
+  what run_GNN.py trains Cora / Citeseer / Pubmed / CoauthorCS with -- columns): native VJP --
   recompute q||k and the attention (native), then  A^T g  (aggregation on the transposed CSR), dw = SDDMM,
   ds = gnpde_softmax_rows_bwd, dq / dk = gnpde_head_spmm over rows / columns, dx += [dq dk] [Wq; Wk] on
   the MFMA projection kernel; the [A,N]x[N,d] weight-gradient GEMMs go to the vendor BLAS through torch.
-* every other attention variant (squareplus, attention_norm_idx = 1, cosine / pearson / exp_kernel, GAT): the
+* the remaining score functions (cosine / pearson / exp_kernel incl. the BLEND split kernel, GAT): the
   backward RECOMPUTES f from PyTorch device ops and differentiates that composite (index_select / index_add,
   the reference's op sequence).  Interim; it announces itself once.
 """
@@ -114,8 +115,10 @@ class _LaplacianRhs(torch.autograd.Function):
 def _native_transformer_vjp_ok(func):
   lay, opt = func.multihead_att_layer, func.opt
   a4 = lay.attention_dim // 4
-  return (opt['attention_type'] == 'scaled_dot' and not opt['square_plus'] and opt['attention_norm_idx'] == 0 and
-          not opt['mix_features'] and lay.d_k % 4 == 0 and lay.attention_dim % 4 == 0 and a4 <= 64 and (a4 & (a4 - 1)) == 0)
+  # scaled-dot scores with ANY normaliser (softmax / squareplus over rows / columns); the head-SpMM of d q / d k needs
+  # float4 lanes over a power-of-two attention width
+  return (opt['attention_type'] == 'scaled_dot' and not opt['mix_features'] and not getattr(lay, 'split_kernel', False) and
+          lay.d_k % 4 == 0 and lay.attention_dim % 4 == 0 and a4 <= 64 and (a4 & (a4 - 1)) == 0)
 
 
 class _TransformerRhs(torch.autograd.Function):
@@ -159,10 +162,13 @@ class _TransformerRhs(torch.autograd.Function):
       dx = ops.spmm_rhs(gt, ops.edge_to_csr_mean(gt, w_edge), g, alpha_train, None, None, sig)
       # through the attention weights: r_e = g_row . x_col (unscaled), alpha applied inside the softmax backward
       r = ops.sddmm(graph, g, x)
-      ds = ops.attention_rows_bwd(graph, st, r, h, scale=alpha_train, scale_sigmoid=sig)   # scores + softmax + its backward
-      if ds is None:     # head shapes without a one-pass kernel: per-head attention in edge order, then its backward
-        _, att_edge, _ = ops.edge_attention(graph, st, False, True, False, like=x)
-        ds = ops.softmax_rows_bwd(graph, att_edge, r, edge_w_csr=lay._reweight_csr(graph), scale=alpha_train, scale_sigmoid=sig)
+      if func.opt['attention_norm_idx'] == 0 and not func.opt['square_plus']:
+        ds = ops.attention_rows_bwd(graph, st, r, h, scale=alpha_train, scale_sigmoid=sig)   # scores + softmax + its backward
+        if ds is None:     # head shapes without a one-pass kernel: per-head attention in edge order, then its backward
+          _, att_edge, _ = ops.edge_attention(graph, st, False, True, False, like=x)
+          ds = ops.softmax_rows_bwd(graph, att_edge, r, edge_w_csr=lay._reweight_csr(graph), scale=alpha_train, scale_sigmoid=sig)
+      else:                # squareplus and / or normalisation over the column: the general segment backward
+        ds = ops.edge_attention_bwd(graph, st, r, scale=alpha_train, scale_sigmoid=sig)
       inv = 1.0 / math.sqrt(dk)
       dqk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=x.device)
       ops.head_spmm(graph, ds, qk[:, A:], h, dk, inv, by_column=False, out=dqk[:, :A])

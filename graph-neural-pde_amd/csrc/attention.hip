@@ -799,10 +799,15 @@ void launch_rows_any(const AttArgs& a, int n16, int n64, hipStream_t s) {
 
 }  // namespace
 
-int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
-                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork) {
+size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
+
+// stats_only: run the general passes 1-2 only (scores + segment statistics stay in the workspace) and hand back the
+// kernel arguments -- the backward pass continues from there
+static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
+                               float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork,
+                               bool stats_only, AttArgs* args_out) {
   GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
-  GNPDE_CHECK_ARG(w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
+  GNPDE_CHECK_ARG(stats_only || w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
   GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
                   "edge_attention: heads (%d) must be a factor of the attention dimension (%d)", at->heads, at->att_dim);
   GNPDE_CHECK_ARG(at->type >= GNPDE_ATT_SCALED_DOT && at->type <= GNPDE_ATT_GAT, GNPDE_EINVAL, "edge_attention: bad type %d", at->type);
@@ -853,7 +858,7 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
   const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(a.k) % 16 == 0);
 
-  const bool fused = a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
+  const bool fused = !stats_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
                      g->bin_rows != nullptr && fused_supported(a, vec4);
   GNPDE_CHECK_ARG(g->row_begin == 0 || fused, GNPDE_EINVAL, "edge_attention: a row sub-range needs the fused row path");
   if (fused) {
@@ -902,8 +907,190 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
     hipLaunchKernelGGL(seg_stats_long_combine_kernel, dim3(n_long), dim3(kWave), 0, stream, a, part, max_chunks);
     GNPDE_LAUNCH_CHECK();
   }
+  if (args_out != nullptr) *args_out = a;
+  if (stats_only) return 0;
   hipLaunchKernelGGL(normalise_kernel, dim3(stream_grid(a.e)), dim3(kBlock), 0, stream, a);
   GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork) {
+  return edge_attention_impl(g, at, w_mean_csr, att_edge, prods_edge, ws, ws_bytes, stream, fork, false, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the normalisation + head mean for EVERY normaliser (softmax or squareplus, over rows or columns):
+//   given dw[p] = dL/d(mean_h att[p,h]) / scale  (CSR order; the aggregation's SDDMM r = g_row . x_col)
+//   returns ds[p,h] = dL/d(prods[p,h])  -- the scores BEFORE the optional edge re-weighting.
+// softmax    a = e^{s-m}/den :  ds = c a (dw - t),            t[seg,h] = sum_{seg} a dw,   c = scale / H
+// squareplus a = u/den, u = (z + sqrt(z^2+4))/2, z = s - M :   dz = c (dw - t)/den * u / sqrt(z^2+4),  ds = dz, and the
+//            global maximum M (reference src/utils.py:196, `src.max()`) takes -sum(dz), which autograd hands EVENLY to the
+//            entries equal to M (evenly_distribute_backward): ds -= [s == M] sum(dz) / #{s == M}.
+// Passes: scores + segment statistics (the forward's passes 1-2, recomputed), t by one wavefront per segment (a block per
+// long segment), one edge-parallel pass for ds with block partials of (sum dz, #max) summed in a fixed order, and for
+// squareplus a second edge-parallel pass that applies the maximum's share.  No atomics.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct BwdArgs {
+  const float* __restrict__ dw;      // [e]
+  float* t;                          // [n,h]
+  float* ds;                         // [e,h]
+  float* partial;                    // [grid,2]: sum dz, count of maxima
+  const float* __restrict__ scale_ptr;
+  int scale_sigmoid;
+};
+
+__device__ __forceinline__ float att_value(const AttArgs& a, float s, int seg, int head, float gmax) {
+  const float den = a.seg_den[static_cast<size_t>(seg) * a.h + head];
+  if (a.square_plus) return squareplus_num(s, gmax) / den;
+  return expf(s - a.seg_m[static_cast<size_t>(seg) * a.h + head]) / den;
+}
+
+// t[seg,h] = sum over the segment of att * dw; BLOCK = false: a wavefront per segment (long ones skipped),
+// BLOCK = true: a block per long segment
+template <bool BLOCK>
+__global__ __launch_bounds__(kBlock) void seg_dot_kernel(const AttArgs a, const BwdArgs b) {
+  __shared__ float red[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  int seg;
+  if (BLOCK) {
+    seg = a.long_segs[blockIdx.x];
+  } else {
+    seg = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + wave);
+    if (seg >= a.n) return;
+  }
+  const int s0 = a.segptr[seg], s1 = a.segptr[seg + 1];
+  if (!BLOCK && s1 - s0 > GNPDE_LONG_ROW && a.long_segs != nullptr) return;
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  const int first = BLOCK ? static_cast<int>(threadIdx.x) : lane;
+  const int step = BLOCK ? kBlock : kWave;
+  for (int head = 0; head < a.h; ++head) {
+    float sum = 0.f;
+    for (int t = s0 + first; t < s1; t += step) {
+      const int p = a.segpos ? a.segpos[t] : t;
+      sum += att_value(a, a.scores[static_cast<size_t>(p) * a.h + head], seg, head, gmax) * b.dw[p];
+    }
+    sum = wave_sum(sum);
+    if (BLOCK) {
+      if (lane == 0) red[wave] = sum;
+      __syncthreads();
+      if (threadIdx.x == 0) b.t[static_cast<size_t>(seg) * a.h + head] = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+    } else if (lane == 0) {
+      b.t[static_cast<size_t>(seg) * a.h + head] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void att_bwd_edge_kernel(const AttArgs a, const BwdArgs b) {
+  __shared__ float rs[kWavesPerBlock], rc[kWavesPerBlock];
+  float scale = 1.0f;
+  if (b.scale_ptr != nullptr) {
+    scale = *b.scale_ptr;
+    if (b.scale_sigmoid) scale = 1.0f / (1.0f + expf(-scale));
+  }
+  const float c = scale / static_cast<float>(a.h);
+  const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
+  float lsum = 0.f, lcnt = 0.f;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.e; p += stride) {
+    const int seg = a.norm_idx == 0 ? a.rowidx[p] : a.colidx[p];
+    const float dwp = b.dw[p];
+    const float ew = a.edge_w != nullptr ? a.edge_w[p] : 1.0f;
+    for (int head = 0; head < a.h; ++head) {
+      const float s = a.scores[p * a.h + head];
+      const float v = dwp - b.t[static_cast<size_t>(seg) * a.h + head];
+      float out;
+      if (a.square_plus) {
+        const float z = s - gmax;
+        const float den = a.seg_den[static_cast<size_t>(seg) * a.h + head];
+        const float root = sqrtf(z * z + 4.0f);
+        out = c * v / den * (0.5f * (z + root)) / root;    // du/dz = u / sqrt(z^2 + 4)
+        lsum += out;
+        lcnt += (s == gmax) ? 1.0f : 0.0f;
+      } else {
+        out = c * att_value(a, s, seg, head, gmax) * v;
+      }
+      b.ds[p * a.h + head] = out * ew;
+    }
+  }
+  if (a.square_plus) {   // block partials, folded in block order by att_bwd_max_share_kernel
+    lsum = wave_sum(lsum);
+    lcnt = wave_sum(lcnt);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) { rs[wave] = lsum; rc[wave] = lcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      b.partial[2 * blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+      b.partial[2 * blockIdx.x + 1] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+    }
+  }
+}
+
+// squareplus: ds -= [s == M] sum(dz) / #{s == M}   (every block folds the partials in the same order)
+__global__ __launch_bounds__(kBlock) void att_bwd_max_share_kernel(const AttArgs a, const BwdArgs b, int n_partials) {
+  __shared__ float share;
+  if (threadIdx.x == 0) {
+    float tot = 0.f, cnt = 0.f;
+    for (int i = 0; i < n_partials; ++i) { tot += b.partial[2 * i]; cnt += b.partial[2 * i + 1]; }
+    share = cnt > 0.f ? tot / cnt : 0.f;
+  }
+  __syncthreads();
+  const float gmax = ord2f(*a.gmax);
+  const long long total = static_cast<long long>(a.e) * a.h;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (a.scores[i] == gmax) {
+      const float ew = a.edge_w != nullptr ? a.edge_w[i / a.h] : 1.0f;
+      b.ds[i] -= share * ew;
+    }
+  }
+}
+
+constexpr int kBwdPartials = 2048;
+
+}  // namespace
+
+size_t attention_bwd_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
+  return align_up(attention_workspace_bytes(g, h, gat), 256) + align_up(static_cast<size_t>(g->n) * h * 4, 256) + kBwdPartials * 2 * 4;
+}
+
+int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* dw_csr, const float* scale,
+                              int scale_sigmoid, float* ds_csr, void* ws, size_t ws_bytes, hipStream_t stream) {
+  GNPDE_CHECK_ARG(g && at && dw_csr && ds_csr, GNPDE_EINVAL, "edge_attention_bwd: null argument");
+  if (g->e == 0 || g->n == 0) return 0;
+  const bool gat = at->type == GNPDE_ATT_GAT;
+  const size_t fwd = align_up(attention_workspace_bytes(g, at->heads, gat), 256);
+  const size_t need = attention_bwd_workspace_bytes(g, at->heads, gat);
+  GNPDE_CHECK_ARG(ws && ws_bytes >= need, GNPDE_EWS, "edge_attention_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+  AttArgs a{};
+  int rc = edge_attention_impl(g, at, nullptr, nullptr, nullptr, ws, fwd, stream, nullptr, true, &a);
+  if (rc) return rc;
+  BwdArgs b{};
+  b.dw = dw_csr;
+  b.ds = ds_csr;
+  b.t = reinterpret_cast<float*>(static_cast<char*>(ws) + fwd);
+  b.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + fwd + align_up(static_cast<size_t>(g->n) * at->heads * 4, 256));
+  b.scale_ptr = scale;
+  b.scale_sigmoid = scale_sigmoid;
+  hipLaunchKernelGGL(seg_dot_kernel<false>, dim3((g->n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, stream, a, b);
+  GNPDE_LAUNCH_CHECK();
+  if (a.long_segs != nullptr) {
+    const int n_long = at->norm_idx == 0 ? g->n_long_rows : g->n_long_cols;
+    hipLaunchKernelGGL(seg_dot_kernel<true>, dim3(n_long), dim3(kBlock), 0, stream, a, b);
+    GNPDE_LAUNCH_CHECK();
+  }
+  unsigned grid = stream_grid(a.e);
+  if (grid > kBwdPartials) grid = kBwdPartials;
+  hipLaunchKernelGGL(att_bwd_edge_kernel, dim3(grid), dim3(kBlock), 0, stream, a, b);
+  GNPDE_LAUNCH_CHECK();
+  if (a.square_plus) {
+    hipLaunchKernelGGL(att_bwd_max_share_kernel, dim3(stream_grid(static_cast<long long>(a.e) * a.h)), dim3(kBlock), 0, stream,
+                       a, b, static_cast<int>(grid));
+    GNPDE_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -922,6 +1109,17 @@ extern "C" int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attentio
                                     float* prods_edge, void* workspace, size_t workspace_bytes, void* stream) {
   return gnpde::launch_edge_attention(g, a, w_mean_csr, att_edge, prods_edge, workspace, workspace_bytes,
                                       static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" size_t gnpde_attention_bwd_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a) {
+  if (!g || !a || a->heads < 1) return 0;
+  return gnpde::attention_bwd_workspace_bytes(g, a->heads, a->type == GNPDE_ATT_GAT);
+}
+
+extern "C" int gnpde_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* dw_csr, const float* scale,
+                                        int32_t scale_sigmoid, float* ds_csr, void* workspace, size_t workspace_bytes, void* stream) {
+  return gnpde::launch_edge_attention_bwd(g, a, dw_csr, scale, scale_sigmoid, ds_csr, workspace, workspace_bytes,
+                                          static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnpde_edge_to_csr_mean(const gnpde_graph_t* g, const float* src_edge, int32_t h, float* w_csr, void* stream) {

@@ -455,7 +455,15 @@ def gather_rows_all(y_own, plan, shard, group=None):
 # --------------------------------------------------------------------------------------------------
 def bench_main(args, rank, world, dev):
   import gnpde_amd as G
-  dist.init_process_group('nccl', device_id=dev)
+  # GNPDE_RANKS_SHARE_DEVICE=1 (set by the caller, together with a device every rank can see): all ranks on ONE GPU, gloo for
+  # the host-side collectives -- the P2P transport does not care which device a peer's memory is on.  Functional runs of the
+  # multi-rank bench path on a single-GPU box; the numbers are not a scaling measurement.
+  shared = os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') == '1'
+  if shared:
+    dist.init_process_group('gloo')
+  else:
+    dist.init_process_group('nccl', device_id=dev)
+  red = torch.device('cpu') if shared else dev          # where the small result reductions live
   cfg = G.synthetic.CONFIGS[args.graph]
   ei, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
   d = cfg['d']
@@ -514,11 +522,18 @@ def bench_main(args, rank, world, dev):
   with torch.no_grad():
     from . import ops
     y = y.clone()
-    chk = ShardedSolver(shard, be)
-    chk.y[:shard.n_own].copy_(x_own)
-    chk.exchange(chk.y)
-    f_own = be.empty(shard.n_own)
-    be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
+    if python_loop:
+      chk = ShardedSolver(shard, be)
+      chk.y[:shard.n_own].copy_(x_own)
+      chk.exchange(chk.y)
+      f_own = be.empty(shard.n_own)
+      be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
+    else:     # one euler step of size 1 through the native solver (exchange included): f = y1 - y0
+      chk = NativeShardedSolver(shard, be, 1.0, 1.0, 'euler', ctx=ctx)
+      f_own = chk.integrate(x_own, x_own, use_graph=False).clone() - x_own
+      torch.cuda.synchronize(dev)
+      dist.barrier()
+      chk.close()
     full = CSRGraph(ei_loops.to(dev), n) if kind == 'transformer' else None
     xg = x.to(dev)
     alpha_d, beta_d = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
@@ -533,15 +548,15 @@ def bench_main(args, rank, world, dev):
       full = CSRGraph(e_rw.to(dev), n)
       f_full = ops.spmm_rhs(full, ops.edge_to_csr_mean(full, w_rw.to(dev)), xg, alpha_d, beta_d, xg, True)
     ref_own = f_full[shard.own_old_ids.to(dev)]
-    err = ((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30)).reshape(1).float()
+    err = ((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30)).reshape(1).float().to(red)
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     del chk, full, f_full, xg
   timed_out = False if python_loop else solver.status()[0]
-  el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  el = torch.tensor([elapsed], dtype=torch.float64, device=red)
   dist.all_reduce(el, op=dist.ReduceOp.MAX)
-  finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=dev)
+  finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=red)
   dist.all_reduce(finite, op=dist.ReduceOp.MIN)
-  halo = torch.tensor([float(shard.n_halo), float(shard.n_own), float(shard.edge_index.shape[1])], device=dev)
+  halo = torch.tensor([float(shard.n_halo), float(shard.n_own), float(shard.edge_index.shape[1])], device=red)
   halo_max = halo.clone()
   dist.all_reduce(halo_max, op=dist.ReduceOp.MAX)
   if rank == 0:
@@ -562,7 +577,7 @@ def bench_main(args, rank, world, dev):
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
                  'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
-                 'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
+                 'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared, 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
                  'replays': len(times),
                  'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
       'roofline': None, 'cpu_baseline': None,

@@ -136,6 +136,18 @@ def attention_rows_bwd(graph, att, r_csr, heads, scale=None, scale_sigmoid=False
   return ds
 
 
+def edge_attention_bwd(graph, att, r_csr, scale=None, scale_sigmoid=False):
+  """ds [E,h] (CSR order) for any normaliser (softmax / squareplus over rows / columns), see gnpde_edge_attention_bwd."""
+  require_hip(r_csr)
+  L = _lib.lib()
+  ds = torch.empty(max(graph.e, 1), att.heads, dtype=torch.float32, device=r_csr.device)
+  ws = graph.workspace('att_bwd', L.gnpde_attention_bwd_workspace_bytes(graph.ref(), ctypes.byref(att)))
+  sc = _scalar_dev(scale, r_csr) if scale is not None else None
+  check(L.gnpde_edge_attention_bwd(graph.ref(), ctypes.byref(att), ptr(r_csr), ptr(sc), int(bool(scale_sigmoid)), ptr(ds),
+                                   ptr(ws), ws.numel(), stream_of(r_csr)))
+  return ds
+
+
 def lincomb(base, terms, out=None):
   """base + sum_j c_j v_j in one pass (gnpde_lincomb); terms = [(v_j, c_j), ...], all tensors contiguous float32 of
   base's shape.  `out` may be base (in-place update)."""

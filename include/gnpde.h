@@ -253,6 +253,17 @@ int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a,
                          float* w_mean_csr, float* att_edge, float* prods_edge,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of the normalisation + head mean of gnpde_edge_attention for EVERY normaliser the reference has (softmax or
+ * squareplus, opt['attention_norm_idx'] 0 or 1; reference src/function_transformer_attention.py:210-213, src/utils.py:179-208,
+ * torch_geometric.utils.softmax):  dw_csr[p] = g_row . x_col (gnpde_sddmm without scale, CSR order);
+ *   ds_csr[p,h] = dL / d prods[p,h]   (the raw scores, before att->edge_w_csr is applied), scaled by s / H with
+ * s = 1 (scale NULL), *scale, or sigmoid(*scale).  squareplus: the global maximum's gradient goes evenly to the entries that
+ * attain it, as autograd's `src.max()` does.  The scores and segment statistics are recomputed from att->q / att->k
+ * (any att->type).  Feed ds to gnpde_head_spmm for the scaled-dot score's d q / d k. */
+size_t gnpde_attention_bwd_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a);
+int gnpde_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* dw_csr, const float* scale,
+                             int32_t scale_sigmoid, float* ds_csr, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same ds as gnpde_softmax_rows_bwd, but computed from q and k in ONE pass (scores, row softmax and its
  * backward; no [E,h] attention array): att->type must be GNPDE_ATT_SCALED_DOT with norm_idx 0 and no squareplus,
  * heads in {1,2,4,8}, d_k in {4,8,16} (GNPDE_ESHAPE otherwise: use gnpde_edge_attention + gnpde_softmax_rows_bwd).

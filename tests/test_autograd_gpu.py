@@ -102,6 +102,60 @@ def test_training_step_through_the_solver(dev, function, composite):
   assert_parity(f.alpha_train.grad.reshape(-1), ac.grad.reshape(-1), tol=GTOL, what='dalpha')
 
 
+@pytest.mark.parametrize('square_plus', [False, True])
+@pytest.mark.parametrize('norm_idx', [0, 1])
+def test_native_vjp_every_normaliser_against_float64(dev, square_plus, norm_idx):
+  """Native VJP (no composite) of GRAND-nl for softmax / squareplus over rows / columns -- squareplus + attention_norm_idx = 1
+  is what run_GNN.py trains Cora / Citeseer / Pubmed / CoauthorCS with.  The reference gradient is the oracle evaluated in
+  FLOAT64; the fp32 CPU autograd gradient of the same op sequence is measured against it too, which shows what GTOL has to
+  cover: the GPU result must be as close to the float64 truth as fp32 arithmetic allows (within 3x of the CPU fp32 error
+  or 2e-5 relative), not merely close to another fp32 number."""
+  from gnpde_amd import autograd as AG
+  n, d = 500, 24
+  ei = random_graph(n, 6, seed=15, hubs=1, hub_deg=700)
+  g = torch.Generator().manual_seed(16)
+  x = torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, square_plus=square_plus, attention_norm_idx=norm_idx, time=2.0)
+  block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, 2.0])).to(dev)
+  _rand_params(block, 17, dev)
+  block.train()
+  f = block.odefunc
+  assert AG._native_transformer_vjp_ok(f), 'this configuration must not fall back to the composite backward'
+  AG._warned.discard('ODEFuncTransformerAtt')
+  xd = x.to(dev).requires_grad_(True)
+  block.set_x0(xd)
+  z = block(xd)
+  (z ** 2).sum().backward()
+  assert 'ODEFuncTransformerAtt' not in AG._warned, 'the composite backward announced itself'
+  lay = f.multihead_att_layer
+  edge = f.edge_index.cpu()
+  ours = [lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias, f.alpha_train, f.beta_train]
+
+  def reference(dtype):
+    cast = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(True)   # noqa: E731
+    xc = cast(x)
+    ps = [cast(p) for p in ours]
+    x0 = x.to(dtype)
+    rhs = lambda t, y: R.rhs_transformer(y, edge, ps[0], ps[1], ps[2], ps[3], 4, ps[4], ps[5], x0, False, True,   # noqa: E731
+                                         norm_idx=norm_idx, square_plus=square_plus)
+    zr = R.odeint_fixed(rhs, xc, 2.0, 1.0, 'rk4')
+    (zr ** 2).sum().backward()
+    return zr.detach(), [xc.grad] + [p.grad for p in ps]
+
+  z64, g64 = reference(torch.float64)
+  z32, g32 = reference(torch.float32)
+  assert_parity(z, z64.float(), what='z')
+  got = [xd.grad] + [p.grad for p in ours]
+  names = ['dx', 'dWq', 'dbq', 'dWk', 'dbk', 'dalpha', 'dbeta']
+  scale = max(float(t.abs().max()) for t in g64[1:5])
+  for name, a, b32, b64 in zip(names, got, g32, g64):
+    ref_scale = float(b64.abs().max()) if name in ('dx', 'dalpha', 'dbeta') else scale
+    e_gpu = float((a.detach().cpu().double().reshape(b64.shape) - b64).abs().max()) / ref_scale
+    e_cpu = float((b32.double() - b64).abs().max()) / ref_scale
+    assert e_gpu <= max(3 * e_cpu, 2e-5), '%s: GPU error %.2e vs float64, CPU fp32 error %.2e' % (name, e_gpu, e_cpu)
+    assert e_gpu <= GTOL
+
+
 def test_attention_block_training(dev):
   """AttODEblock in training mode: attention computed once (with history), Laplacian function native backward,
   edge-weight gradients through gnpde_sddmm into the attention layer's parameters."""
