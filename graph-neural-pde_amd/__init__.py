@@ -9,7 +9,7 @@ from .graph import CSRGraph, graph_of, partition_rows
 from . import ops
 from .utils import MaxNFEException, get_rw_adj, gcn_norm_fill_val, add_remaining_self_loops, DummyData, DummyDataset
 from .odeint import odeint, odeint_adjoint, time_grid
-from .base_classes import ODEFunc, ODEblock, RegularizedODEfunc
+from .base_classes import ODEFunc, ODEblock, RegularizedODEfunc, REGULARIZATION_FNS, create_regularization_fns
 from .function_laplacian_diffusion import LaplacianODEFunc
 from .function_transformer_attention import ODEFuncTransformerAtt, SpGraphTransAttentionLayer
 from .function_GAT_attention import ODEFuncAtt, SpGraphAttentionLayer

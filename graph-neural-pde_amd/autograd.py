@@ -241,6 +241,32 @@ def composite_gat(func, x):
   return f
 
 
+def composite_laplacian(func, x):
+  """f(x) of LaplacianODEFunc from differentiable device ops."""
+  w = func._edge_values()
+  if w.dim() == 2:
+    w = w.mean(dim=1)
+  f = _alpha(func) * (_aggregate(func.edge_index, w, x) - x)
+  if func.opt['add_source']:
+    f = f + func.beta_train * func.x0
+  return f
+
+
+def twice_differentiable_rhs(func, x):
+  """f(x) as a composite of PyTorch device ops, for callers that differentiate THROUGH the backward (the regularisers
+  of base_classes.py with create_graph=True).  Same arithmetic as the kernels; announced once."""
+  _lib.require_hip(x)
+  kind = func.__class__.__name__
+  comp = {'LaplacianODEFunc': composite_laplacian, 'ODEFuncTransformerAtt': composite_transformer,
+          'ODEFuncAtt': composite_gat}.get(kind)
+  if comp is None:
+    raise NotImplementedError('no twice-differentiable form of %s' % kind)
+  if kind == 'ODEFuncAtt' and func.opt['mix_features']:
+    raise NotImplementedError('training with mix_features is not supported yet')
+  _announce(kind + ' (second-order regulariser)')
+  return comp(func, x)
+
+
 class _CompositeBackwardRhs(torch.autograd.Function):
 
   @staticmethod

@@ -12,10 +12,74 @@ from .utils import MaxNFEException
 from .odeint import odeint, odeint_adjoint
 
 
+# --------------------------------------------------------------------------------------------------
+# Regularisers of the dynamics (reference src/regularized_ODE_function.py:35-81, registry src/base_classes.py:10-29;
+# "Adapted from cfinlay/ffjord-rnode" there).  Each maps (x, t, dx, func) -> one value per node that the solver integrates
+# next to the state; run_GNN.py adds coeff * mean to the loss (:82-87).  Off in every best_params entry.
+# --------------------------------------------------------------------------------------------------
+def quadratic_cost(x, t, dx, unused_context):
+  """kinetic_energy: 1/2 mean_c dx^2 per node (first order: uses the native backward)."""
+  return 0.5 * dx.reshape(dx.shape[0], -1).pow(2).mean(dim=-1)
+
+
+def directional_derivative(x, t, dx, unused_context):
+  """directional_penalty: 1/2 mean_c (J dx)^2 with the vector-Jacobian product grad(dx, x, dx) of the reference (:58-64)."""
+  ddx = torch.autograd.grad(dx, x, dx, create_graph=True)[0]
+  return 0.5 * ddx.reshape(x.size(0), -1).pow(2).mean(dim=-1)
+
+
+def total_derivative(x, t, dx, unused_context):
+  """total_deriv: needs df/dt; these right-hand sides are autonomous, so -- like the reference (:38-55) -- it raises and
+  points at the mathematically equivalent directional_penalty."""
+  ddx = torch.autograd.grad(dx, x, dx, create_graph=True)[0]
+  try:
+    u = torch.full_like(dx, 1 / x.numel(), requires_grad=True)
+    tmp = torch.autograd.grad((u * dx).sum(), t, create_graph=True)[0]
+    partial_dt = torch.autograd.grad(tmp.sum(), u, create_graph=True)[0]
+  except RuntimeError as e:
+    if 'One of the differentiated Tensors' in str(e):
+      raise RuntimeError('No partial derivative with respect to time. Use mathematically equivalent '
+                         '"directional_derivative" regularizer instead')
+    raise
+  return 0.5 * (ddx + partial_dt).pow(2).reshape(x.size(0), -1).mean(dim=-1)
+
+
+def jacobian_frobenius_regularization_fn(x, t, dx, context):
+  """jacobian_norm2: what the reference computes under that name (:67-81) -- the sum over feature columns i of
+  d(sum_nodes dx[:, i]) / dx[:, i], one backward pass per column."""
+  total = 0.
+  for i in range(x.shape[1]):
+    total = total + torch.autograd.grad(dx[:, i].sum(), x, create_graph=True)[0][:, i]
+  return total
+
+
+REGULARIZATION_FNS = {
+  'kinetic_energy': quadratic_cost,
+  'jacobian_norm2': jacobian_frobenius_regularization_fn,
+  'total_deriv': total_derivative,
+  'directional_penalty': directional_derivative,
+}
+
+
+def create_regularization_fns(args):
+  """(functions, coefficients) of the regularisers switched on in `args` (reference src/base_classes.py:18-29)."""
+  fns, coeffs = [], []
+  for key, fn in REGULARIZATION_FNS.items():
+    if args.get(key) is not None:
+      fns.append(fn)
+      coeffs.append(args[key])
+  return fns, coeffs
+
+
+def _first_order(fn):
+  return getattr(fn, '__name__', '') == 'quadratic_cost'
+
+
 class RegularizedODEfunc(nn.Module):
-  """Holder matching reference src/regularized_ODE_function.py:8-33 (state_dict prefix
-  `reg_odefunc.odefunc.`).  The autograd-based regularisers themselves are training-only and outside
-  this hot path (SURVEY.md section 2, #13): with an empty list this is a pass-through."""
+  """Reference src/regularized_ODE_function.py:8-33 (state_dict prefix `reg_odefunc.odefunc.`): integrates the
+  regularisers' per-node values next to the state.  dx = f(t, x) comes from the native kernels; a regulariser that
+  differentiates dx a second time (create_graph) needs a twice-differentiable f, which the kernel-backed autograd
+  function is not, so for those evaluations f is the composite of PyTorch device ops (same arithmetic, announced once)."""
 
   def __init__(self, odefunc, regularization_fns):
     super(RegularizedODEfunc, self).__init__()
@@ -23,10 +87,26 @@ class RegularizedODEfunc(nn.Module):
     self.regularization_fns = regularization_fns
 
   def forward(self, t, state):
-    if len(self.regularization_fns) > 0:
-      raise NotImplementedError('kinetic / Jacobian regularisers are not part of the MI355X hot path')
-    x = state[0] if isinstance(state, tuple) else state
-    return self.odefunc(t, x)
+    if not isinstance(state, tuple):
+      return self.odefunc(t, state)
+    with torch.enable_grad():
+      x = state[0]
+      if not x.requires_grad:
+        x.requires_grad_(True)
+      if not torch.is_tensor(t):
+        t = torch.tensor(float(t), dtype=x.dtype, device=x.device)
+      if t.is_floating_point() and not t.requires_grad:
+        t = t.detach().requires_grad_(True)
+      if len(state) == 1:
+        return (self.odefunc(t, x),)
+      if all(_first_order(fn) for fn in self.regularization_fns):
+        dx = self.odefunc(t, x)
+      else:
+        from .autograd import twice_differentiable_rhs
+        self.odefunc._check_nfe()
+        dx = twice_differentiable_rhs(self.odefunc, x)
+      reg = tuple(fn(x, t, dx, self.odefunc) for fn in self.regularization_fns)
+      return (dx,) + reg
 
 
 class ODEFunc(nn.Module):
@@ -162,13 +242,16 @@ class ODEblock(nn.Module):
     """Common tail of the block forwards (reference src/block_constant.py:35-70)."""
     t = self.t.type_as(x)
     integrator = self.train_integrator if self.training else self.test_integrator
-    if self.training and self.nreg > 0:
-      raise NotImplementedError('regularised training states are not part of the MI355X hot path')
+    regularised = self.training and self.nreg > 0
     kw = dict(method=self.opt['method'], options=options, atol=self.atol, rtol=self.rtol)
     if self.opt['adjoint'] and self.training:
       kw.update(adjoint_method=self.opt['adjoint_method'],
                 adjoint_options=dict(step_size=self.opt['adjoint_step_size']),
                 adjoint_atol=self.atol_adjoint, adjoint_rtol=self.rtol_adjoint)
+    if regularised:   # reference src/block_constant.py:40-43,64-67: (state, one integral per regulariser)
+      state = (x,) + tuple(torch.zeros(x.size(0)).to(x) for _ in range(self.nreg))
+      state_dt = integrator(self.reg_odefunc, state, t, **kw)
+      return state_dt[0][1], tuple(st[1] for st in state_dt[1:])
     state_dt = integrator(self.odefunc, x, t, **kw)
     return state_dt[1]
 

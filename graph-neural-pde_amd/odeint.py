@@ -333,9 +333,40 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   return out
 
 
+class _TupleFunc(object):
+  """A function of a tuple state seen as a function of the flattened concatenation (torchdiffeq misc.py _TupleFunc):
+  the regularised training state (x, r_1, ..., r_k) of reference src/block_constant.py:40-43."""
+
+  def __init__(self, func, shapes):
+    self.func, self.shapes = func, shapes
+
+  def __call__(self, t, flat):
+    out = self.func(t, tuple(_unflatten(flat, self.shapes)))
+    return _flatten(out)
+
+  def parameters(self):
+    return self.func.parameters() if isinstance(self.func, torch.nn.Module) else iter(())
+
+
+def _solve_tuple(solver, func, y0, t, kw):
+  shapes = [p.shape for p in y0]
+  if kw.get('method') in (None, 'dopri5', 'adaptive_heun'):     # torchdiffeq's default norm of a tuple state
+    kw = dict(kw, options=dict(kw.get('options') or {}))
+    kw['options'].setdefault('norm', _mixed_norm(shapes))
+  flat = solver(_TupleFunc(func, shapes), _flatten(y0), t, **kw)          # [len(t), total]
+  outs, pos = [], 0
+  for sh in shapes:
+    cnt = int(torch.Size(sh).numel())
+    outs.append(flat[:, pos:pos + cnt].reshape((flat.shape[0],) + tuple(sh)))
+    pos += cnt
+  return tuple(outs)
+
+
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_graph=True, **adjoint_kwargs):
   """Drop-in for torchdiffeq.odeint on this path.  Unknown options (e.g. `max_iters`, which the
   reference passes and torchdiffeq ignores with a warning) are ignored."""
+  if isinstance(y0, tuple):
+    return _solve_tuple(odeint, func, y0, t, dict(rtol=rtol, atol=atol, method=method, options=options, use_graph=use_graph))
   options = dict(options or {})
   method = 'dopri5' if method is None else method
   if method in ('euler', 'rk4'):
@@ -494,6 +525,13 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
                    adjoint_method=None, adjoint_options=None, adjoint_params=None, use_graph=True):
   """Drop-in for torchdiffeq.odeint_adjoint: same values as `odeint`; gradients with respect to y0 and the
   function's parameters come from solving the adjoint ODE backwards (see _AdjointSolve), not from a tape."""
+  if isinstance(y0, tuple):
+    if adjoint_params is None:
+      adjoint_params = tuple(func.parameters()) if isinstance(func, torch.nn.Module) else ()
+    return _solve_tuple(odeint_adjoint, func, y0, t,
+                        dict(rtol=rtol, atol=atol, method=method, options=options, adjoint_rtol=adjoint_rtol,
+                             adjoint_atol=adjoint_atol, adjoint_method=adjoint_method, adjoint_options=adjoint_options,
+                             adjoint_params=tuple(adjoint_params), use_graph=use_graph))
   options = dict(options or {})
   fwd = dict(rtol=rtol, atol=atol, method=method, options=options, use_graph=use_graph)
   if adjoint_params is None:

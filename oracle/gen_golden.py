@@ -446,7 +446,54 @@ def gen_adjoint():
                                                        ', '.join(k[5:] for k in rec if k.startswith('grad/'))))
 
 
+def gen_regularised():
+  """Training forward with the reference's regularisers (src/regularized_ODE_function.py, registry src/base_classes.py:10-29):
+  state + one integral per regulariser, and the gradient of  <z, c> + sum_j coeff_j mean(reg_j)  (run_GNN.py:82-87)."""
+  from base_classes import create_regularization_fns
+  n, d = 90, 12
+  ei = make_graph(n, 6, 61)
+  g = torch.Generator().manual_seed(62)
+  x = torch.randn(n, d, generator=g)
+  c = torch.randn(n, d, generator=g)
+  cases = {
+    'transformer_rk4_kinetic': dict(function='transformer', method='rk4', time=2.0, kinetic_energy=0.05),
+    'laplacian_rk4_all': dict(function='laplacian', method='rk4', time=2.0, kinetic_energy=0.05, jacobian_norm2=0.02,
+                              directional_penalty=0.03),
+    'transformer_euler_directional': dict(function='transformer', method='euler', time=1.5, step_size=0.5,
+                                          directional_penalty=0.1, attention_norm_idx=1, square_plus=True),
+    'gat_rk4_kinetic_jacobian': dict(function='GAT', method='rk4', time=1.0, step_size=0.5, kinetic_energy=0.05,
+                                     jacobian_norm2=0.02),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, 'hidden_dim': d, 'attention_dim': 8, 'heads': 2, 'kinetic_energy': None, 'jacobian_norm2': None,
+           'total_deriv': None, 'directional_penalty': None, **over}
+    fns, coeffs = create_regularization_fns(opt)
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt, 'GAT': ODEFuncAtt}[opt['function']]
+    block = ConstantODEblock(fcls, fns, opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+    randomise(block, 800 + i)
+    block.train()
+    xin = x.clone().requires_grad_(True)
+    block.set_x0(xin)
+    z, regs = block(xin)
+    loss = (z * c).sum() + sum(cf * r.mean() for cf, r in zip(coeffs, regs))
+    loss.backward()
+    # (the regularised solve integrates reg_odefunc.odefunc -- the block's FIRST function object, base_classes.py:39-42)
+    rec = {'edge_index': ei, 'x': x, 'c': c, 'z': z, 'grad_x': xin.grad, 'coeffs': np.asarray(coeffs, dtype=np.float64),
+           'nfe': np.int64(block.reg_odefunc.odefunc.nfe)}
+    for j, r in enumerate(regs):
+      rec['reg%d' % j] = r
+    for k, p in block.named_parameters():
+      if p.grad is not None:
+        rec['grad/' + k] = p.grad
+    save('reg_' + name, opt, rec, block)
+    print('    regs %s nfe %d' % ([float(r.mean()) for r in regs], block.reg_odefunc.odefunc.nfe))
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1:          # regenerate selected groups only: python oracle/gen_golden.py regularised
+    for name in sys.argv[1:]:
+      globals()['gen_' + name]()
+    sys.exit(0)
   os.makedirs(OUT, exist_ok=True)
   torch.manual_seed(0)
   gen_norms()
@@ -457,3 +504,4 @@ if __name__ == '__main__':
   gen_rewire()
   gen_early()
   gen_adjoint()
+  gen_regularised()

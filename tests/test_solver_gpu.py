@@ -319,3 +319,55 @@ def test_blend_arxiv_config_c4(dev):
                  atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
   assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
   assert_parity(z, ref, tol=1e-4, what='C4 (solver tolerance 1.1e-3)')
+
+
+def test_blend_arxiv_config_c4_full_size(dev):
+  """BASELINE configs[3] AS NAMED, at full size: 169 343 nodes, BLEND (beltrami: 64 feature + 98 positional channels =
+  d 162, one exp kernel per channel group multiplied -- reference src/function_transformer_attention.py:133-171),
+  `block_transformer_rewiring` (RewireAttODEblock, eval mode: head-mean attention recomputed on the full rw-normalised
+  edge set, reference src/block_transformer_rewiring.py:185-241), Laplacian function, dopri5 with tol_scale 11353,
+  T = 3.676.  Against the host dopri5 loop driven by the CPU oracle (split-kernel attention + reference SpMM sequence):
+  same number of evaluations (= same accept / reject decisions) and the same state within the solver's tolerance."""
+  ei, n = G.synthetic.make_graph('arxiv')
+  assert n == 169343
+  f0, p0 = 64, 98
+  d = f0 + p0
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(41)) * 0.5
+  opt = dict(BASE, function='laplacian', block='rewire_attention', hidden_dim=d, heads=2, attention_dim=32, method='dopri5',
+             time=3.6760155951687636, tol_scale=11353.558848254957, add_source=False, beltrami=True, feat_hidden_dim=f0,
+             pos_enc_hidden_dim=p0, attention_type='exp_kernel', att_samp_pct=0.81, use_flux=False, new_edges='k_hop_att',
+             sparsify='S_hat', rw_addD=0.02, threshold_type='addD_rvR', rw_rmvR=0.02)
+  block = G.RewireAttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev,
+                              t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(5)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if 'multihead_att_layer' in name and p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      elif 'lengthscale' in name or 'output_var' in name:
+        p.copy_((1.0 + 0.3 * torch.rand(p.shape, generator=g)).to(dev))
+    block.odefunc.alpha_train.fill_(0.4)
+  block.eval()
+  block.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = block(x.to(dev))
+  nfe = block.odefunc.nfe
+  cpu = lambda t: t.detach().cpu()   # noqa: E731
+  lay, f = block.multihead_att_layer, block.odefunc
+  assert lay.split_kernel, 'the BLEND layer must use the split feature / positional kernel'
+  e_n, w_n = R.get_rw_adj(ei, None, 1, 1, n)
+  assert torch.equal(cpu(f.edge_index), e_n)
+  P = {k: cpu(v) for k, v in lay.state_dict().items()}
+  att, _ = R.transformer_attention_split(x, e_n, P, 2, f0, p0, edge_weights=w_n, reweight=False)
+  assert_parity(f.edge_weight, att.mean(dim=1), what='C4 head-mean BLEND attention over 2.48 M edges')
+  w_mean = att.mean(dim=1)
+  calls = [0]
+
+  def rhs(t, y):
+    calls[0] += 1
+    return R.rhs_laplacian(y, e_n, w_mean, cpu(f.alpha_train), cpu(f.beta_train), None, False, False)
+
+  ref = G.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
+                 atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
+  assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
+  assert_parity(z, ref, tol=1e-4, what='C4 full size (solver tolerance 1.1e-3)')
