@@ -40,9 +40,10 @@ def test_regularised_training_forward_and_gradients(dev, name):
     ref = fx.t('reg%d' % j)
     assert r.shape == ref.shape
     if float(ref.abs().max()) < 1e-5:       # jacobian_norm2 of a column-stochastic Laplacian: rounding-level values
-      assert float((r.cpu() - ref).abs().max()) < 1e-5
+      assert float((r.detach().cpu() - ref).abs().max()) < 1e-5
     else:
-      assert_parity(r, ref, tol=2e-5, what='%s reg%d' % (name, j))
+      # (integrals of SQUARED first / second derivatives of f evaluated in fp32 by two different op orders)
+      assert_parity(r, ref, tol=1e-4, what='%s reg%d' % (name, j))
   loss = (z * fx.t('c', dev)).sum() + sum(cf * r.mean() for cf, r in zip(coeffs, regs))
   loss.backward()
   assert_parity(xin.grad, fx.t('grad_x'), tol=GTOL, what=name + ' grad_x')

@@ -23,7 +23,10 @@ with torch.no_grad():
       p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
 block.eval(); block.set_x0(x)
 import functools
-for label, integ in (('native stages', G.odeint), ('host loop', functools.partial(G.odeint, options_override=True))):
+modes = (('native stages', G.odeint), ('host loop', functools.partial(G.odeint, options_override=True)))
+if len(sys.argv) > 1 and sys.argv[1] == 'native':
+  modes = modes[:1]
+for label, integ in modes:
   if label == 'host loop':
     def integ(func, y0, t, **kw):
       kw['options'] = dict(kw.get('options') or {}, host_controller=True)
