@@ -56,7 +56,7 @@ class AttentionStruct(ctypes.Structure):
 class RhsStruct(ctypes.Structure):
   _fields_ = [('kind', ctypes.c_int32), ('graph', ctypes.POINTER(GraphStruct)),
               ('d', ctypes.c_int32), ('ld', ctypes.c_int32), ('n_state_rows', ctypes.c_int32), ('proj_row_begin', ctypes.c_int32), ('proj_row_end', ctypes.c_int32),
-              ('pad_', ctypes.c_int32),
+              ('flags', ctypes.c_int32),
               ('alpha', c_vp), ('beta', c_vp), ('x0', c_vp), ('alpha_sigmoid', ctypes.c_int32),
               ('w_csr', c_vp),
               ('proj_w', c_vp), ('proj_b', c_vp), ('proj_m', ctypes.c_int32),
@@ -214,6 +214,34 @@ def f32c(t, name='tensor'):
   if t.dtype != torch.float32:
     raise GnpdeError('%s must be float32 (got %s)' % (name, t.dtype))
   return t if t.is_contiguous() else t.contiguous()
+
+
+RHS_PADDED_ROWS = 1
+
+
+def f32rows(t, name='tensor'):
+  """A float32 matrix whose rows may be padded (unit column stride, row stride >= width) is handed on as it is; anything
+  else is made contiguous."""
+  if t.dtype != torch.float32:
+    raise GnpdeError('%s must be float32 (got %s)' % (name, t.dtype))
+  if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+    return t
+  return t if t.is_contiguous() else t.contiguous()
+
+
+def alloc_state(n, d, device):
+  """[n, d] float32 state buffer; when d is not a multiple of 4 its rows are padded to the next multiple (a view of an
+  [n, ld] allocation), which lets the kernels use 16-byte lanes (GNPDE_RHS_PADDED_ROWS)."""
+  ld = (d + 3) // 4 * 4
+  out = torch.zeros(n, ld, dtype=torch.float32, device=device)[:, :d]
+  if ld != d:
+    out._gnpde_padded = True     # marks THIS tensor object: a column slice of somebody else's matrix never qualifies
+  return out
+
+
+def is_padded(t):
+  """True only for buffers handed out by alloc_state (their columns [d, ld) are ours to overwrite)."""
+  return bool(getattr(t, '_gnpde_padded', False))
 
 
 def stream_of(t):

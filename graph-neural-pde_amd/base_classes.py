@@ -155,6 +155,15 @@ class ODEFunc(nn.Module):
       raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
     return self.x0
 
+  @staticmethod
+  def _match_rows(x0, x):
+    """The source term in the row layout of the state (the kernels use ONE leading dimension for every operand)."""
+    x0 = _lib.f32rows(x0, 'x0')
+    if x0.stride(0) == x.stride(0) or x0.shape != x.shape:
+      return x0
+    out = _lib.alloc_state(x.shape[0], x.shape[1], x.device) if _lib.is_padded(x) else torch.empty_like(x, memory_format=torch.contiguous_format)
+    return out.copy_(x0)
+
   def _memo(self, key, tensors, make):
     """Cache derived device buffers on (identity, version) of their source tensors."""
     sig = tuple((id(t), t._version) if t is not None else None for t in tensors)

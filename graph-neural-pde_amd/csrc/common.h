@@ -100,7 +100,7 @@ inline void fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
 // internal launchers used by the solver (defined in the kernel translation units)
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
-                    hipStream_t stream, const Fork* fork = nullptr);
+                    hipStream_t stream, const Fork* fork = nullptr, bool padded_rows = false);
 
 // early_stop.hip
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,

@@ -100,7 +100,8 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     if (rc) return rc;
     w = wmean;
   }
-  return launch_spmm_rhs(g, w, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s, fork);
+  return launch_spmm_rhs(g, w, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s, fork,
+                         (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0);
 }
 
 gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r) {

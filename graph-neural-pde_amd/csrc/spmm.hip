@@ -611,7 +611,7 @@ inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpr
 
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes, hipStream_t stream,
-                    const Fork* fork) {
+                    const Fork* fork, bool padded_rows) {
   GNPDE_CHECK_ARG(g && u && (w_csr || g->e == 0), GNPDE_EINVAL, "spmm: null pointer");
   GNPDE_CHECK_ARG(d >= 1 && ld >= d, GNPDE_EINVAL, "spmm: bad d=%d ld=%d", d, ld);
   GNPDE_CHECK_ARG((epi != nullptr) != (plain_out != nullptr), GNPDE_EINVAL, "spmm: need exactly one of epilogue / plain output");
@@ -637,7 +637,9 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     GNPDE_CHECK_ARG(g->long_rows && g->long_chunk_ptr && g->long_chunk_row && g->long_chunk_begin && g->long_chunk_end,
                     GNPDE_EINVAL, "spmm: long-row arrays missing");
   }
-  bool a16 = (d % 4 == 0) && (ld % 4 == 0) && aligned(u, 16) && aligned(plain_out, 16) && aligned(ws, 16);
+  // padded_rows: the caller guarantees that columns [d, ld) of every operand are padding (GNPDE_RHS_PADDED_ROWS), so a
+  // width that is not a multiple of 4 still takes 16-byte lanes (the last lane reads / writes up to 3 padding columns)
+  bool a16 = (d % 4 == 0 || padded_rows) && (ld % 4 == 0) && aligned(u, 16) && aligned(plain_out, 16) && aligned(ws, 16);
   bool a8 = (d % 2 == 0) && (ld % 2 == 0) && aligned(u, 8) && aligned(plain_out, 8) && aligned(ws, 8);
   if (epi) {
     a.ep = *epi;

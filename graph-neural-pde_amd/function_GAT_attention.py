@@ -131,8 +131,8 @@ class ODEFuncAtt(ODEFunc):
     beta = ops._scalar_dev(self.beta_train, x) if x0 is not None else None
     st, keep = layer.attention_struct(graph)
     desc = ops.RhsDescriptor(_lib.RHS_GAT, graph, x.shape[1], x.stride(0), alpha, beta,
-                             None if x0 is None else _lib.f32c(x0), not self.opt['no_alpha_sigmoid'],
-                             proj_w=layer.proj_weight(), proj_b=None, att=st)
+                             None if x0 is None else self._match_rows(x0, x), not self.opt['no_alpha_sigmoid'],
+                             proj_w=layer.proj_weight(), proj_b=None, att=st, padded_rows=_lib.is_padded(x))
     desc.keep += keep
     return desc
 

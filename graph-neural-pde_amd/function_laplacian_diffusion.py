@@ -61,8 +61,8 @@ class LaplacianODEFunc(ODEFunc):
     alpha = ops._scalar_dev(self.alpha_train, x)
     beta = ops._scalar_dev(self.beta_train, x) if x0 is not None else None
     return ops.RhsDescriptor(_lib.RHS_LAPLACIAN, graph, x.shape[1], x.stride(0), alpha, beta,
-                             None if x0 is None else _lib.f32c(x0), not self.opt['no_alpha_sigmoid'],
-                             w_csr=self._weights_csr(graph))
+                             None if x0 is None else self._match_rows(x0, x), not self.opt['no_alpha_sigmoid'],
+                             w_csr=self._weights_csr(graph), padded_rows=_lib.is_padded(x))
 
   def _descriptor_signature(self, desc):
     s = desc.struct

@@ -219,8 +219,8 @@ class ODEFuncTransformerAtt(ODEFunc):
     wqk, bqk = layer.qk_weights()
     st, keep = layer.attention_struct(graph)
     desc = ops.RhsDescriptor(_lib.RHS_TRANSFORMER, graph, x.shape[1], x.stride(0), alpha, beta,
-                             None if x0 is None else _lib.f32c(x0), not self.opt['no_alpha_sigmoid'],
-                             proj_w=wqk, proj_b=bqk, att=st)
+                             None if x0 is None else self._match_rows(x0, x), not self.opt['no_alpha_sigmoid'],
+                             proj_w=wqk, proj_b=bqk, att=st, padded_rows=_lib.is_padded(x))
     desc.keep += keep
     return desc
 

@@ -48,8 +48,9 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
   ent = st.get(key)
   y0c = y0.detach()
   if ent is None:
-    ent = {'y': torch.empty_like(y0c, memory_format=torch.contiguous_format),
-           'x0': torch.empty_like(y0c, memory_format=torch.contiguous_format) if func.opt['add_source'] else None,
+    # (rows padded to a multiple of 4 floats when the width is not one: 16-byte lanes for d = 162 etc.)
+    ent = {'y': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device),
+           'x0': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device) if func.opt['add_source'] else None,
            'solver': None, 'sig': None}
     st.clear()  # one live solver per function object: buffers are state-sized
     st[key] = ent
@@ -255,10 +256,11 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   dev = y0.device
   f32 = np.float32
   T0, T1 = float(t[0]), float(t[-1])
-  y = y0.detach().clone().contiguous()
-  y1 = torch.empty_like(y)
-  u = [torch.empty_like(y) for _ in range(2)]
-  K = [torch.empty_like(y) for _ in range(7)]
+  new = lambda: _lib.alloc_state(y0.shape[0], y0.shape[1], dev)   # noqa: E731  (padded rows when d % 4 != 0)
+  y = new().copy_(y0.detach())
+  y1 = new()
+  u = [new() for _ in range(2)]
+  K = [new() for _ in range(7)]
   ratio_dev = torch.zeros(1, dtype=torch.float32, device=dev)
   err_ws = torch.empty(4096, dtype=torch.float32, device=dev)
   desc = func._descriptor(y)

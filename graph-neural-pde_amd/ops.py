@@ -255,7 +255,7 @@ class RhsDescriptor(object):
   """Python owner of a gnpde_rhs_t: keeps every tensor the descriptor points to alive."""
 
   def __init__(self, kind, graph, d, ld, alpha, beta, x0, alpha_sigmoid, w_csr=None, proj_w=None, proj_b=None,
-               att=None, n_state_rows=0, proj_rows=None):
+               att=None, n_state_rows=0, proj_rows=None, padded_rows=False):
     self.graph = graph
     self.keep = [alpha, beta, x0, w_csr, proj_w, proj_b]
     r = _lib.RhsStruct()
@@ -263,6 +263,7 @@ class RhsDescriptor(object):
     r.graph = ctypes.pointer(graph.struct)
     r.d, r.ld = int(d), int(ld)
     r.n_state_rows = int(n_state_rows)
+    r.flags = _lib.RHS_PADDED_ROWS if padded_rows else 0
     if proj_rows is not None:
       r.proj_row_begin, r.proj_row_end = int(proj_rows[0]), int(proj_rows[1])
     r.alpha = alpha.data_ptr()
@@ -284,7 +285,7 @@ class RhsDescriptor(object):
 def rhs_eval(desc, u, out=None):
   """One evaluation f(u) of a descriptor (gnpde_rhs_eval)."""
   require_hip(u)
-  u = f32c(u, 'u')
+  u = _lib.f32rows(u, 'u') if desc.struct.flags & _lib.RHS_PADDED_ROWS else f32c(u, 'u')
   if out is None:
     out = torch.empty_like(u)
   L = _lib.lib()
@@ -419,8 +420,8 @@ class FixedStepSolver(object):
   def run(self, y, use_graph=True):
     """Integrate y in place."""
     require_hip(y)
-    if y.dtype != torch.float32 or not y.is_contiguous():
-      raise _lib.GnpdeError('solver state must be contiguous float32')
+    if y.dtype != torch.float32 or y.dim() != 2 or y.stride(1) != 1 or y.stride(0) != self.desc.struct.ld:
+      raise _lib.GnpdeError('solver state must be float32 [n, d] with unit column stride and the descriptor\'s row stride')
     check(_lib.lib().gnpde_solver_run(self.handle, ptr(y), int(bool(use_graph)), stream_of(y)))
     return y
 

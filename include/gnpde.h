@@ -300,6 +300,10 @@ int gnpde_edge_to_csr_mean(const gnpde_graph_t* g, const float* src_edge, int32_
  * src/block_transformer_attention.py:58-63) with the whole time loop captured in one hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 enum { GNPDE_RHS_LAPLACIAN = 0, GNPDE_RHS_TRANSFORMER = 1, GNPDE_RHS_GAT = 2 };
+/* flags of gnpde_rhs_t.  PADDED_ROWS: ld is a multiple of 4 and the columns [d, ld) of EVERY state-shaped operand (stage
+ * input, x0, y, k*, outputs) are padding that may be read and overwritten -- lets a state width that is not a multiple of
+ * 4 (BLEND ogbn-arxiv: d = 162, reference best_params feat_hidden_dim 64 + pos_enc_hidden_dim 98) use 16-byte lanes. */
+#define GNPDE_RHS_PADDED_ROWS 1
 enum { GNPDE_METHOD_EULER = 0, GNPDE_METHOD_RK4 = 1 };
 
 typedef struct gnpde_rhs {
@@ -311,7 +315,7 @@ typedef struct gnpde_rhs {
   int32_t proj_row_begin;     /* with proj_row_end > 0: project only rows [proj_row_begin, proj_row_end)
                                  (interior / boundary passes overlapping the halo exchange) */
   int32_t proj_row_end;
-  int32_t pad_;
+  int32_t flags;              /* GNPDE_RHS_PADDED_ROWS or 0 */
   /* epilogue scalars */
   const float* alpha; const float* beta; const float* x0; int32_t alpha_sigmoid;
   /* LAPLACIAN: fixed weights, CSR order */

@@ -5,7 +5,7 @@ import torch
 
 import gnpde_amd as G
 from oracle import restate as R
-from helpers import Data, assert_parity
+from helpers import Data, assert_parity, random_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -371,3 +371,34 @@ def test_blend_arxiv_config_c4_full_size(dev):
                  atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
   assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
   assert_parity(z, ref, tol=1e-4, what='C4 full size (solver tolerance 1.1e-3)')
+
+
+@pytest.mark.parametrize('function,d,method', [('laplacian', 161, 'rk4'), ('transformer', 90, 'rk4'), ('laplacian', 162, 'dopri5'),
+                                               ('transformer', 30, 'euler')])
+def test_padded_rows_for_widths_not_multiple_of_four(dev, function, d, method):
+  """State widths that are not a multiple of 4 floats: the solvers keep their state in row-padded buffers
+  (GNPDE_RHS_PADDED_ROWS) so that the kernels use 16-byte lanes; result must match the oracle like any other width."""
+  from gnpde_amd import _lib
+  n = 3000
+  ei = random_graph(n, 7, seed=61, hubs=2, hub_deg=800)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(62))
+  T = 2.5
+  opt = dict(BASE, function=function, hidden_dim=d, method=method, time=T, tol_scale=50.0, attention_dim=16, heads=4)
+  block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+  block.set_x0(x.to(dev))
+  with torch.no_grad():
+    z = block(x.to(dev))
+  f = block.odefunc
+  assert _lib.alloc_state(4, d, dev).stride(0) == (d + 3) // 4 * 4
+  cpu = lambda t: t.detach().cpu()   # noqa: E731
+  if function == 'laplacian':
+    rhs = lambda t, y: R.rhs_laplacian(y, cpu(f.edge_index), cpu(f.edge_weight), cpu(f.alpha_train), cpu(f.beta_train), x,   # noqa: E731
+                                       False, True)
+  else:
+    rhs = _oracle_rhs(block, x)
+  if method == 'dopri5':
+    ref = G.odeint(rhs, x, torch.tensor([0, T], dtype=torch.float32), method='dopri5', options={}, atol=opt['tol_scale'] * 1e-7,
+                   rtol=opt['tol_scale'] * 1e-9)[1]
+    assert_parity(z, ref, tol=2e-5, what='padded dopri5 d=%d' % d)
+  else:
+    assert_parity(z, R.odeint_fixed(rhs, x, T, 1.0, method), what='padded %s %s d=%d' % (function, method, d))
