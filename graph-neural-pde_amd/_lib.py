@@ -120,6 +120,8 @@ PROTOTYPES = {
   'gnpde_rhs_stage': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, ctypes.POINTER(EpilogueStruct), c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_rk_error_ratio': (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_int32, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp]),
+  'gnpde_dopri5_interp': (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_rhs_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct)]),
   'gnpde_early_stop_reset': (ctypes.c_int, [c_vp, c_vp]),
   'gnpde_early_stop_eval': (ctypes.c_int, [ctypes.POINTER(DecoderStruct), c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

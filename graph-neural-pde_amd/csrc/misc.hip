@@ -102,8 +102,66 @@ __global__ __launch_bounds__(kBlock) void rk_error_final_kernel(const float* __r
   if (threadIdx.x == 0) *ratio = static_cast<float>(sqrt(red[0] / count));
 }
 
+struct InterpArgs {
+  const float* y0;
+  const float* y1;
+  const float* k[GNPDE_MAX_PREV];
+  float mid[GNPDE_MAX_PREV];   // fl32(c_mid_j) * fl32(dt)
+  float h, x;
+  long long n;
+  int d, ld;
+  float* out;
+};
+
+// torchdiffeq's quartic end-point interpolation (_interp_fit + _interp_evaluate of the dopri5 solver) in one pass:
+// y_mid = y0 + sum_j mid_j k_j;  a, b, c, d from (y0, y1, y_mid, f0 = k_0, f1 = k_6, h);  out = y0 + x d + x^2 c + x^3 b + x^4 a
+__global__ __launch_bounds__(kBlock) void dopri5_interp_kernel(const InterpArgs a) {
+  const long long total = a.n * a.d;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long r = i / a.d;
+    const size_t off = static_cast<size_t>(r) * a.ld + static_cast<size_t>(i - r * a.d);
+    const float ya = a.y0[off], yb = a.y1[off];
+    float ym = ya;
+#pragma unroll
+    for (int j = 0; j < GNPDE_MAX_PREV; ++j)
+      if (a.mid[j] != 0.0f) ym += a.k[j][off] * a.mid[j];
+    const float fa = a.k[0][off], fb = a.k[6][off], h = a.h, x = a.x;
+    const float ca = 2.0f * h * (fb - fa) - 8.0f * (yb + ya) + 16.0f * ym;
+    const float cb = h * (5.0f * fa - 3.0f * fb) + 18.0f * ya + 14.0f * yb - 32.0f * ym;
+    const float cc = h * (fb - 4.0f * fa) - 11.0f * ya - 5.0f * yb + 16.0f * ym;
+    const float cd = h * fa;
+    float tot = ya + x * cd;
+    float xp = x * x;
+    tot += xp * cc;
+    xp *= x;
+    tot += xp * cb;
+    xp *= x;
+    tot += xp * ca;
+    a.out[off] = tot;
+  }
+}
+
 }  // namespace
 }  // namespace gnpde
+
+extern "C" int gnpde_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h,
+                                   float x, int64_t n, int32_t d, int32_t ld, float* out, void* stream) {
+  using namespace gnpde;
+  GNPDE_CHECK_ARG(y0 && y1 && k && mid_coef && out && n >= 1 && d >= 1 && ld >= d, GNPDE_EINVAL, "dopri5_interp: bad arguments");
+  InterpArgs a{};
+  a.y0 = y0; a.y1 = y1; a.h = h; a.x = x; a.n = n; a.d = d; a.ld = ld; a.out = out;
+  for (int j = 0; j < GNPDE_MAX_PREV; ++j) {
+    GNPDE_CHECK_ARG(k[j] != nullptr, GNPDE_EINVAL, "dopri5_interp: k[%d] is null", j);
+    a.k[j] = k[j];
+    a.mid[j] = mid_coef[j];
+  }
+  long long blocks = (n * d + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dopri5_interp_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k,
                                     float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,

@@ -256,11 +256,16 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   dev = y0.device
   f32 = np.float32
   T0, T1 = float(t[0]), float(t[-1])
-  new = lambda: _lib.alloc_state(y0.shape[0], y0.shape[1], dev)   # noqa: E731  (padded rows when d % 4 != 0)
-  y = new().copy_(y0.detach())
-  y1 = new()
-  u = [new() for _ in range(2)]
-  K = [new() for _ in range(7)]
+  # state-sized buffers (rows padded when d % 4 != 0) are kept on the function object between solves
+  cache = func.__dict__.setdefault('_dopri5_buffers', {})
+  bkey = (tuple(y0.shape), str(dev))
+  if cache.get('key') != bkey:
+    cache.clear()
+    cache['key'] = bkey
+    cache['bufs'] = [_lib.alloc_state(y0.shape[0], y0.shape[1], dev) for _ in range(12)]
+  bufs = cache['bufs']
+  y, y1, u, K, y_out = bufs[0], bufs[1], bufs[2:4], bufs[4:11], bufs[11]
+  y.copy_(y0.detach())
   ratio_dev = torch.zeros(1, dtype=torch.float32, device=dev)
   err_ws = torch.empty(4096, dtype=torch.float32, device=dev)
   desc = func._descriptor(y)
@@ -274,12 +279,16 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   rtol64, atol64 = float(rtol), float(atol)
   feval(y, out_k=K[0])
   # initial step (order 4 estimate), a handful of reductions once per solve
-  scale = atol64 + torch.abs(y) * rtol64
-  d0, d1 = float(_rms(y / scale)), float(_rms(K[0] / scale))
+  def scaled_rms(terms, coefs):
+    """rms(sum_j c_j v_j / (atol + rtol |y|)) in one fused pass (the error-ratio kernel with y0 = y1 = y)."""
+    ops.rk_error_ratio(y, y, terms, coefs, atol64, rtol64, ratio_dev, err_ws)
+    return float(ratio_dev.item())
+
+  d0, d1 = scaled_rms([y], [1.0]), scaled_rms([K[0]], [1.0])
   h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else float(f32(0.01) * f32(d0) / f32(d1))
   torch.add(y, K[0], alpha=h0, out=u[0])
   feval(u[0], out_k=K[1])
-  d2 = float(_rms((K[1] - K[0]) / scale)) / h0
+  d2 = scaled_rms([K[1], K[0]], [1.0, -1.0]) / h0
   h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else float(f32(f32(0.01) / f32(max(d1, d2))) ** f32(1.0 / 5.0))
   dt = float(min(100 * h0, h1))
   t_cur = T0
@@ -300,23 +309,9 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
     if ratio <= 1:
       t_next = t_cur + dt
       if t_next >= T1:   # end point inside this step: quartic interpolation (torchdiffeq _interp_fit / _interp_evaluate)
-        y_mid = y.clone()
-        for kj, c in zip(K, _DP_MID):
-          if c != 0.0:
-            y_mid.add_(kj, alpha=float(f32(c) * dty))
-        h = float(dty)
-        fa, fb = K[0], K[6]
-        ca = 2 * h * (fb - fa) - 8 * (y1 + y) + 16 * y_mid
-        cb = h * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * y_mid
-        cc = h * (fb - 4 * fa) - 11 * y - 5 * y1 + 16 * y_mid
-        cd = h * fa
         xf = float(f32((T1 - t_cur) / (t_next - t_cur)))
-        total = y + xf * cd
-        xp = xf
-        for coefv in (cc, cb, ca):
-          xp = xp * xf
-          total = total + xp * coefv
-        out[1].copy_(total)
+        ops.dopri5_interp(y, y1, K, [f32(c) * dty for c in _DP_MID], float(dty), xf, y_out)
+        out[1].copy_(y_out)
       y, y1 = y1, y
       K[0], K[6] = K[6], K[0]
       t_cur = t_next

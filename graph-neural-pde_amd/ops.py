@@ -325,6 +325,16 @@ def rk_error_ratio(y0, y1, ks, coefs, atol, rtol, out, ws):
   return out
 
 
+def dopri5_interp(y0, y1, ks, mid_coefs, h, x, out):
+  """Quartic end-point interpolation of an accepted dopri5 step in one pass (gnpde_dopri5_interp)."""
+  n, d = y0.shape
+  karr = (ctypes.c_void_p * len(ks))(*[k.data_ptr() for k in ks])
+  carr = (ctypes.c_float * len(ks))(*[float(c) for c in mid_coefs])
+  check(_lib.lib().gnpde_dopri5_interp(ptr(y0), ptr(y1), karr, carr, float(h), float(x), n, d, y0.stride(0), ptr(out),
+                                       stream_of(y0)))
+  return out
+
+
 class EarlyStopEvaluator(object):
   """Device-side early-stopping evaluator (gnpde_decoder_t + its int32 state / trace).
 

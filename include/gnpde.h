@@ -358,6 +358,13 @@ int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k
                          float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
                          void* stream);
 
+/* End-point interpolation of an accepted Dormand-Prince step (torchdiffeq _interp_fit / _interp_evaluate, the quartic
+ * through y0, y1, the mid-point estimate and the two end slopes) in one pass:
+ *   y_mid = y0 + sum_j mid_coef[j] * k[j]   (7 stage derivatives; mid_coef[j] = fl32(c_mid_j) * fl32(dt))
+ *   out   = value of the quartic at fraction x = (t_out - t0) / (t1 - t0) of the step, h = fl32(dt). */
+int gnpde_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h, float x,
+                        int64_t n, int32_t d, int32_t ld, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Early-stopping evaluator  [replaces EarlyStopRK4.evaluate / EarlyStopDopri5.evaluate + test / test_OGB + the
  * best-validation bookkeeping, reference src/early_stop_solver.py:100-128, :156-157, :178-218]
