@@ -132,6 +132,11 @@ PROTOTYPES = {
   'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_gather_rows': (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,
                                        ctypes.c_int32, c_vp]),
+  'gnpde_quantile_workspace_bytes': (ctypes.c_size_t, []),
+  'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_threshold_edges_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),
+  'gnpde_threshold_edges': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp,
+                                           c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_comm_load_library': (ctypes.c_int, [ctypes.c_char_p]),
   'gnpde_comm_get_unique_id': (ctypes.c_int, [c_vp]),
   'gnpde_comm_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.c_int32, ctypes.c_int32]),

@@ -3,8 +3,8 @@ attention, optionally times the feature distance across the edge) carries the di
 renormalised per node; in evaluation mode every edge is used (reference
 src/block_transformer_hard_attention.py:7-103; `block` of the ogbn-arxiv / Computers / Photo best_params).
 
-The selection (quantile, mask, per-node sum) is once-per-forward bookkeeping on device tensors; the attention itself
-and every evaluation of f run on the native kernels.  Swapping `odefunc.edge_index` makes the function rebuild
+The selection (quantile by radix select, stable compaction, per-node renormalisation: csrc/rewire.hip) and the attention
+itself and every evaluation of f run on the native kernels.  Swapping `odefunc.edge_index` makes the function rebuild
 its CSR lazily."""
 import torch
 
@@ -46,6 +46,13 @@ class HardAttODEblock(ODEblock):
   def _sample_edges(self, x, attention):
     """Keep the edges whose score exceeds the (1 - att_samp_pct) quantile (reference :48-66)."""
     score = self._edge_scores(x, attention)
+    if score.is_cuda and score.dtype == torch.float32:
+      # native: radix-select quantile (same float32 rank arithmetic as torch.quantile), stable compaction, renormalisation
+      from . import ops
+      thr = ops.quantile(score, 1 - self.opt['att_samp_pct'])
+      self.odefunc.edge_index, self.odefunc.attention_weights = ops.threshold_edges(
+        self.data_edge_index, score, thr, self.opt['attention_norm_idx'], self.num_nodes)
+      return
     keep = score > torch.quantile(score, 1 - self.opt['att_samp_pct'])
     self.odefunc.edge_index = self.data_edge_index[:, keep]
     self.odefunc.attention_weights = self.renormalise_attention(score[keep])

@@ -105,11 +105,19 @@ class RewireAttODEblock(ODEblock):
     if self.opt['use_flux']:
       delta = torch.linalg.norm(x[self.data_edge_index[0, :], :] - x[self.data_edge_index[1, :], :], dim=1)
       mean_att = mean_att * delta
-    mask = mean_att > threshold
-    self.odefunc.edge_index = self.data_edge_index[:, mask]
-    sampled_attention_weights = self.renormalise_attention(mean_att[mask])
-    print('retaining {} of {} edges'.format(self.odefunc.edge_index.shape[1], self.data_edge_index.shape[1]))
-    self.data_edge_index = self.data_edge_index[:, mask]
+    total = self.data_edge_index.shape[1]
+    if mean_att.is_cuda and mean_att.dtype == torch.float32 and torch.is_tensor(threshold):
+      from . import ops          # native: stable compaction + renormalisation (csrc/rewire.hip)
+      kept, sampled_attention_weights = ops.threshold_edges(self.data_edge_index, mean_att, threshold,
+                                                            self.opt['attention_norm_idx'], self.num_nodes)
+      self.odefunc.edge_index = kept
+    else:
+      mask = mean_att > threshold
+      self.odefunc.edge_index = self.data_edge_index[:, mask]
+      sampled_attention_weights = self.renormalise_attention(mean_att[mask])
+      kept = self.data_edge_index[:, mask]
+    print('retaining {} of {} edges'.format(self.odefunc.edge_index.shape[1], total))
+    self.data_edge_index = kept
     self.odefunc.edge_weight = sampled_attention_weights
     self.odefunc.attention_weights = sampled_attention_weights
 
@@ -122,7 +130,13 @@ class RewireAttODEblock(ODEblock):
         self.densify_edges()
         post_count = self.odefunc.edge_index.shape[1]
         pc_change = post_count / pre_count - 1
-        threshold = torch.quantile(self.odefunc.edge_weight, 1 / (pc_change - self.opt['rw_addD']))
+        q = 1 / (pc_change - self.opt['rw_addD'])
+        ew = self.odefunc.edge_weight
+        if ew.is_cuda and ew.dtype == torch.float32:
+          from . import ops
+          threshold = ops.quantile(ew, q)          # radix select, same float32 rank arithmetic as torch.quantile
+        else:
+          threshold = torch.quantile(ew, q)
         self.threshold_edges(x, threshold)
     self.odefunc.edge_index = self.data_edge_index
     mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)

@@ -148,6 +148,39 @@ def edge_attention_bwd(graph, att, r_csr, scale=None, scale_sigmoid=False):
   return ds
 
 
+def quantile(v, q):
+  """torch.quantile(v, q) (default linear interpolation) of a float32 device vector as a 0-d device tensor, by radix select
+  (gnpde_quantile): no sort, same float32 rank arithmetic as torch, no 16 M element limit."""
+  require_hip(v)
+  v = f32c(v.detach().reshape(-1), 'quantile input')
+  L = _lib.lib()
+  out = torch.empty(1, dtype=torch.float32, device=v.device)
+  ws = torch.empty(int(L.gnpde_quantile_workspace_bytes()), dtype=torch.uint8, device=v.device)
+  check(L.gnpde_quantile(ptr(v), v.numel(), float(q), ptr(out), ptr(ws), ws.numel(), stream_of(v)))
+  return out.reshape(())
+
+
+def threshold_edges(edge_index, score, threshold, norm_idx, n_nodes):
+  """(edge_index[:, score > threshold], renormalised kept scores): stable compaction + per-endpoint renormalisation in one
+  native sequence (gnpde_threshold_edges); one host read for the kept count."""
+  require_hip(edge_index, score, threshold)
+  ei = edge_index.detach()
+  if ei.dtype != torch.int64 or not ei.is_contiguous():
+    ei = ei.to(torch.int64).contiguous()
+  sc = f32c(score.detach().reshape(-1), 'score')
+  thr = threshold.detach().to(torch.float32).reshape(1)
+  E = ei.shape[1]
+  L = _lib.lib()
+  out_ei = torch.empty_like(ei)
+  out_w = torch.empty(max(E, 1), dtype=torch.float32, device=ei.device)
+  cnt = torch.zeros(1, dtype=torch.int64, device=ei.device)
+  ws = torch.empty(int(L.gnpde_threshold_edges_workspace_bytes(E, int(n_nodes))), dtype=torch.uint8, device=ei.device)
+  check(L.gnpde_threshold_edges(ptr(ei), ptr(sc), E, ptr(thr), int(norm_idx), int(n_nodes), ptr(out_ei), ptr(out_w), ptr(cnt),
+                                ptr(ws), ws.numel(), stream_of(sc)))
+  k = int(cnt.item())
+  return out_ei[:, :k].contiguous(), out_w[:k].clone()
+
+
 def lincomb(base, terms, out=None):
   """base + sum_j c_j v_j in one pass (gnpde_lincomb); terms = [(v_j, c_j), ...], all tensors contiguous float32 of
   base's shape.  `out` may be base (in-place update)."""

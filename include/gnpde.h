@@ -416,6 +416,23 @@ int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int3
                       float* dst, int32_t ld_dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Edge-set bookkeeping of the hard-attention / rewiring blocks (once per training forward):
+ *   threshold = torch.quantile(score, q);  mask = score > threshold;  edge_index[:, mask];  kept scores renormalised by their
+ *   sum per endpoint (reference src/block_transformer_hard_attention.py:48-66, src/block_transformer_rewiring.py:40-50,154-183).
+ * gnpde_quantile: *out (device) = the q-quantile of v[0..n) with torch.quantile's default linear interpolation, evaluated in
+ *   float32 exactly as torch does (rank = fl32(q) * fl32(n-1)); a radix select, no sort; n is not limited to 16 M.
+ * gnpde_threshold_edges: stable compaction of the columns of edge_index ([2, n_edges] int64, row-major) whose score exceeds
+ *   *threshold (device scalar) into out_edge_index ([2, n_edges] capacity, same row stride), out_weight[i] = score / (sum of the
+ *   kept scores with the same endpoint edge_index[norm_idx] + 1e-16); *out_count (device int64) = number of kept edges.
+ * ---------------------------------------------------------------------------------------------- */
+size_t gnpde_quantile_workspace_bytes(void);
+int gnpde_quantile(const float* v, int64_t n, double q, float* out, void* workspace, size_t workspace_bytes, void* stream);
+size_t gnpde_threshold_edges_workspace_bytes(int64_t n_edges, int32_t n_nodes);
+int gnpde_threshold_edges(const int64_t* edge_index, const float* score, int64_t n_edges, const float* threshold,
+                          int32_t norm_idx, int32_t n_nodes, int64_t* out_edge_index, float* out_weight, int64_t* out_count,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row-partitioned solve over the GPUs of one node: one process per GPU, RCCL point-to-point halo exchange once per
  * evaluation of f, the whole solve (pack, grouped send/recv on a second stream, interior rows, boundary rows, every
  * stage of every step) captured per rank in ONE hipGraph.  The reference has no counterpart (single device;
