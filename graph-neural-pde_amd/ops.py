@@ -170,6 +170,8 @@ def threshold_edges(edge_index, score, threshold, norm_idx, n_nodes):
   sc = f32c(score.detach().reshape(-1), 'score')
   thr = threshold.detach().to(torch.float32).reshape(1)
   E = ei.shape[1]
+  if E == 0:
+    return ei.clone(), sc.clone()
   L = _lib.lib()
   out_ei = torch.empty_like(ei)
   out_w = torch.empty(max(E, 1), dtype=torch.float32, device=ei.device)
