@@ -106,6 +106,8 @@ PROTOTYPES = {
   'gnpde_attention_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),
   'gnpde_edge_attention_bwd': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp, c_vp,
                                               ctypes.c_int32, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_edge_attention_bwd_heads': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp,
+                                                    ctypes.c_int32, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_attn_rhs_fused_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32, ctypes.c_int32]),
   'gnpde_attn_rhs_fused_supported': (ctypes.c_int, [ctypes.POINTER(AttentionStruct), ctypes.c_int32, ctypes.c_int32]),
   'gnpde_attn_rhs_fused': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp, c_vp, c_vp,

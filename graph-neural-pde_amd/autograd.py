@@ -21,6 +21,7 @@ import math
 import torch
 
 from . import _lib, ops
+from .graph import graph_of
 
 _log = logging.getLogger('gnpde_amd')
 _warned = set()
@@ -193,8 +194,199 @@ class _TransformerRhs(torch.autograd.Function):
     return (dx if need[0] else None), dwq, dbq, dwk, dbk, dalpha, dbeta, None, None
 
 
+
 # --------------------------------------------------------------------------------------------------
-# other attention variants: native forward, composite (PyTorch device ops) backward
+# Native VJP of the attention for EVERY score function (round 2)
+#
+# att[E,h] = normalise_{row|col}( g(qt_i, kt_j) [* edge_w] )  with  g = scale * <qt_i, kt_j>          ("dot")
+#                                                               g = amp * exp(-|qt_i - kt_j|^2 / 2)   ("exp")
+#                                                               g = LeakyReLU(ts_i + td_j)            ("gat")
+# where (qt, kt) are NODE-level transforms of the projections:  scaled_dot: q, k;  cosine: q / |q| per head;  pearson: centred,
+# then normalised;  exp_kernel: q / l;  BLEND split kernel: [q_x / l_x ; q_p / l_p] per head (amp = (ov_x ov_p)^2).
+# The node-level part ([N,A] tensors: Linear layers, normalisations, length scales) is ordinary PyTorch with autograd;
+# everything per EDGE is native, forward (the inference kernels, unchanged values) and backward:
+#   ds = gnpde_edge_attention_bwd_heads(datt)            normaliser backward for any of softmax / squareplus x row / column
+#   dot: d qt = scale * sum_row ds kt_j,  d kt = scale * sum_col ds qt_i                      (gnpde_head_spmm)
+#   exp: with c = ds * score:  d qt_i = sum_row c (kt_j - qt_i),  d kt_j = sum_col c (qt_i - kt_j),  d amp = sum c / amp
+#   gat: with c = ds * LeakyReLU':  d ts_i = sum_row c,  d td_j = sum_col c
+# --------------------------------------------------------------------------------------------------
+def _heads(t, h):
+  return t.view(t.shape[0], h, -1)
+
+
+def transformed_qk(layer, x):
+  """(qt, kt, kind, scale, amp) of SpGraphTransAttentionLayer with autograd history (node-level only)."""
+  opt, h = layer.opt, layer.h
+  t = opt['attention_type']
+  lin = torch.nn.functional.linear
+  if getattr(layer, 'split_kernel', False):
+    f0, lab = opt['feat_hidden_dim'], opt['feat_hidden_dim'] + opt['pos_enc_hidden_dim']
+    p = x[:, f0:lab]
+    xf = torch.cat((x[:, :f0], x[:, lab:]), dim=1)
+    def both(lx, lp):
+      a = _heads(lin(xf, lx.weight, lx.bias) / layer.lengthscale_x, h)
+      b = _heads(lin(p, lp.weight, lp.bias) / layer.lengthscale_p, h)
+      return torch.cat((a, b), dim=2).reshape(x.shape[0], -1)      # per head: d_k feature rows, then d_k positional rows
+    return both(layer.Qx, layer.Qp), both(layer.Kx, layer.Kp), 'exp', 1.0, (layer.output_var_x * layer.output_var_p) ** 2
+  q, k = layer.Q(x), layer.K(x)
+  if t == 'scaled_dot':
+    return q, k, 'dot', 1.0 / math.sqrt(layer.d_k), None
+  if t == 'exp_kernel':
+    return q / layer.lengthscale, k / layer.lengthscale, 'exp', 1.0, layer.output_var ** 2
+  qh, kh = _heads(q, h), _heads(k, h)
+  if t == 'pearson':
+    qh = qh - qh.mean(dim=2, keepdim=True)
+    kh = kh - kh.mean(dim=2, keepdim=True)
+  # cosine of the reference clamps |q||k| jointly at 1e-5 (degenerate rows only); the derivative is taken off the clamp
+  qh = qh / qh.norm(dim=2, keepdim=True).clamp_min(1e-20)
+  kh = kh / kh.norm(dim=2, keepdim=True).clamp_min(1e-20)
+  return qh.reshape(q.shape), kh.reshape(k.shape), 'dot', 1.0, None
+
+
+class _EdgeAttention(torch.autograd.Function):
+  """att [E,h] (edge order) from node-level (qt, kt): forward = the inference kernels on the layer's own descriptor (values
+  unchanged), backward = native per-edge work, see the section comment."""
+
+  @staticmethod
+  def forward(ctx, qt, kt, amp, struct_fn, graph, kind, scale, heads):
+    with torch.no_grad():
+      st, keep = struct_fn()
+      _, att, _ = ops.edge_attention(graph, st, want_w_mean=False, want_att=True, like=qt)
+    ctx.struct_fn, ctx.graph, ctx.kind, ctx.scale, ctx.heads = struct_fn, graph, kind, scale, heads
+    ctx.has_amp = amp is not None
+    ctx.save_for_backward(qt, kt, amp if amp is not None else qt.new_zeros(0))
+    return att
+
+  @staticmethod
+  def backward(ctx, datt):
+    qt, kt, amp = ctx.saved_tensors
+    graph, kind, h = ctx.graph, ctx.kind, ctx.heads
+    dk = qt.shape[1] // h
+    with torch.no_grad():
+      st, keep = ctx.struct_fn()
+      ds = ops.edge_attention_bwd_heads(graph, st, datt, post=1 if kind == 'exp' else 0)
+      qc, kc = _lib.f32c(qt.detach()), _lib.f32c(kt.detach())
+      damp = None
+      if kind == 'dot':
+        dq = ops.head_spmm(graph, ds, kc, h, dk, ctx.scale, by_column=False)
+        dkk = ops.head_spmm(graph, ds, qc, h, dk, ctx.scale, by_column=True)
+      else:
+        ones = torch.ones_like(qc)
+        dq = ops.head_spmm(graph, ds, kc, h, dk, 1.0, by_column=False) - ops.head_spmm(graph, ds, ones, h, dk, 1.0, by_column=False) * qc
+        dkk = ops.head_spmm(graph, ds, qc, h, dk, 1.0, by_column=True) - ops.head_spmm(graph, ds, ones, h, dk, 1.0, by_column=True) * kc
+        if ctx.has_amp and ctx.needs_input_grad[2]:
+          damp = (ds[:graph.e].sum() / amp.reshape(())).reshape(amp.shape)
+    return dq, dkk, damp, None, None, None, None, None
+
+
+class _GatAttention(torch.autograd.Function):
+  """GAT attention [E,h] from the node-level terms ts, td [N,h] (forward: the inference kernels on wx and a)."""
+
+  @staticmethod
+  def forward(ctx, ts, td, struct_fn, graph, heads):
+    with torch.no_grad():
+      st, keep = struct_fn()
+      _, att, _ = ops.edge_attention(graph, st, want_w_mean=False, want_att=True, like=ts)
+    ctx.struct_fn, ctx.graph, ctx.heads = struct_fn, graph, heads
+    return att
+
+  @staticmethod
+  def backward(ctx, datt):
+    graph, h = ctx.graph, ctx.heads
+    with torch.no_grad():
+      st, keep = ctx.struct_fn()
+      c = ops.edge_attention_bwd_heads(graph, st, datt, post=2)
+      ones = torch.ones(graph.n, 4 * h, dtype=torch.float32, device=datt.device)     # head sums through the float4 head-SpMM
+      dts = ops.head_spmm(graph, c, ones, h, 4, 1.0, by_column=False)[:, ::4].contiguous()
+      dtd = ops.head_spmm(graph, c, ones, h, 4, 1.0, by_column=True)[:, ::4].contiguous()
+    return dts, dtd, None, None, None
+
+
+class _AggregateRhs(torch.autograd.Function):
+  """f = a (A x - x) + b x0 with A given by a per-edge attention [E,h] (or [E]) that carries gradients: native forward and
+  backward (A^T g on the transposed CSR, d att = SDDMM / H, d alpha, d beta) without touching a function object's caches."""
+
+  @staticmethod
+  def forward(ctx, x, att, alpha_train, beta_train, x0, graph, sig):
+    with torch.no_grad():
+      w_csr = ops.edge_to_csr_mean(graph, att)
+      f = ops.spmm_rhs(graph, w_csr, x, alpha_train, beta_train if x0 is not None else None, x0, sig)
+    ctx.graph, ctx.sig, ctx.has_source = graph, sig, x0 is not None
+    ctx.att_shape = tuple(att.shape)
+    ctx.save_for_backward(x, w_csr, alpha_train, beta_train, x0 if x0 is not None else x.new_zeros(0), f)
+    return f
+
+  @staticmethod
+  def backward(ctx, g):
+    x, w_csr, alpha_train, beta_train, x0, f = ctx.saved_tensors
+    graph, sig = ctx.graph, ctx.sig
+    need = ctx.needs_input_grad
+    g = _lib.f32c(g)
+    dx = datt = dalpha = dbeta = None
+    with torch.no_grad():
+      if need[0]:
+        gt = graph.transposed()
+        w_edge = torch.empty(graph.e, dtype=torch.float32, device=g.device)
+        w_edge[graph.perm_long] = w_csr[:graph.e]
+        dx = ops.spmm_rhs(gt, ops.edge_to_csr_mean(gt, w_edge), g, alpha_train, None, None, sig)
+      if need[1]:
+        dw_csr = ops.sddmm(graph, g, x, scale=alpha_train, scale_sigmoid=sig)
+        dw_e = torch.empty(graph.e, dtype=torch.float32, device=g.device)
+        dw_e[graph.perm_long] = dw_csr[:graph.e]
+        if len(ctx.att_shape) == 2:
+          datt = (dw_e / ctx.att_shape[1]).unsqueeze(1).expand(ctx.att_shape).contiguous()
+        else:
+          datt = dw_e
+      gx0 = _dot(g, x0) if ctx.has_source and (need[2] or need[3]) else None
+      if need[2]:
+        dalpha = _dalpha(g, f, x, alpha_train, beta_train, gx0, sig, lambda: ops.spmm(graph, w_csr, x)).reshape(alpha_train.shape)
+      if need[3] and ctx.has_source:
+        dbeta = gx0.reshape(beta_train.shape)
+    return dx, datt, dalpha, dbeta, None, None, None
+
+
+def native_layer_attention(layer, x, edge):
+  """(attention [E,h], prods placeholder) of SpGraphTransAttentionLayer with autograd history, per-edge work native."""
+  xc = _lib.f32c(x)
+  graph = graph_of(edge, xc.shape[0], xc.device)
+  qt, kt, kind, scale, amp = transformed_qk(layer, xc)
+  A = layer.kernel_att_dim
+
+  def struct_fn():    # the layer's own inference descriptor (raw projections, its score type): unchanged forward values
+    wqk, bqk = layer.qk_weights()
+    qk = ops.linear(xc.detach(), wqk, bqk)
+    return layer.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
+
+  return _EdgeAttention.apply(_lib.f32c(qt), _lib.f32c(kt), amp, struct_fn, graph, kind, scale, layer.h)
+
+
+def _native_layer_vjp_ok(layer):
+  A, h = layer.kernel_att_dim, layer.h
+  dk, a4 = A // h, A // 4
+  return dk % 4 == 0 and A % 4 == 0 and a4 <= 64 and (a4 & (a4 - 1)) == 0
+
+
+def native_gat_attention(layer, x, edge):
+  """GAT attention [E,h] and wx with autograd history (per-edge work native)."""
+  xc = _lib.f32c(x)
+  graph = graph_of(edge, xc.shape[0], xc.device)
+  h, dk = layer.h, layer.d_k
+  wx = torch.mm(xc, layer.W)                                           # [N, A]; head j owns columns [j d_k, (j+1) d_k)
+  hx = wx.view(-1, h, dk)
+  a = layer.a.reshape(2 * dk)
+  ts = (hx * a[:dk].view(1, 1, dk)).sum(dim=2)                          # [N,h]
+  td = (hx * a[dk:].view(1, 1, dk)).sum(dim=2)
+
+  def struct_fn():
+    wxn = ops.linear(xc.detach(), layer.proj_weight())
+    return layer.attention_struct(graph, q=wxn, ldqk=layer.attention_dim)
+
+  return _GatAttention.apply(ts.contiguous(), td.contiguous(), struct_fn, graph, h), wx
+
+
+# --------------------------------------------------------------------------------------------------
+# composites of PyTorch device ops: twice-differentiable form for the second-order regularisers, and the fallback for
+# head shapes the float4 head-SpMM does not cover
 # --------------------------------------------------------------------------------------------------
 def _segment_softmax(src, index, n):
   mx = torch.full((n,) + tuple(src.shape[1:]), float('-inf'), dtype=src.dtype, device=src.device)
@@ -290,6 +482,8 @@ class _CompositeBackwardRhs(torch.autograd.Function):
 def layer_attention_with_grad(layer, x, edge):
   """(attention [E,h], prods [E,h]) of SpGraphTransAttentionLayer with autograd history (composite); used
   when a block differentiates through the attention it computes once per forward pass."""
+  if _native_layer_vjp_ok(layer) and not layer.opt.get('gnpde_composite_backward', False):
+    return native_layer_attention(layer, x, edge), None
   _announce('SpGraphTransAttentionLayer')
   return _layer_attention(layer, x, edge)
 
@@ -349,10 +543,30 @@ def rhs_with_grad(func, x):
       lay = func.multihead_att_layer
       return _TransformerRhs.apply(x, lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias, func.alpha_train,
                                    func.beta_train, func._source(x), func)
+    lay = func.multihead_att_layer
+    if _native_layer_vjp_ok(lay) and not func.opt['mix_features'] and not func.opt.get('gnpde_composite_backward', False):
+      # any other score function: node-level transforms in PyTorch, everything per edge native (section comment above)
+      att = native_layer_attention(lay, x, func.edge_index)
+      return _AggregateRhs.apply(x, att, func.alpha_train, func.beta_train, func._source(x), func._graph(x),
+                                 not func.opt['no_alpha_sigmoid'])
     composite = composite_transformer
   elif kind == 'ODEFuncAtt':
+    lay = func.multihead_att_layer
+    pow2 = lay.h >= 1 and (lay.h & (lay.h - 1)) == 0 and lay.h <= 64
+    if pow2 and not func.opt.get('gnpde_composite_backward', False):
+      att, wx = native_gat_attention(lay, x, func.edge_index)
+      graph, sig = func._graph(x), not func.opt['no_alpha_sigmoid']
+      if not func.opt['mix_features']:
+        return _AggregateRhs.apply(x, att, func.alpha_train, func.beta_train, func._source(x), graph, sig)
+      # mix_features (reference src/function_GAT_attention.py:33-38): A(x) (x W) Wout replaces A(x) x
+      zero = torch.zeros((), device=x.device)
+      ax = _AggregateRhs.apply(wx.contiguous(), att, torch.ones((), device=x.device), zero, None, graph, False) + wx   # = A wx
+      f = _alpha(func) * (torch.mm(ax, lay.Wout) - x)
+      if func.opt['add_source']:
+        f = f + func.beta_train * func.x0
+      return f
     if func.opt['mix_features']:
-      raise NotImplementedError('training with mix_features is not supported yet')
+      raise NotImplementedError('mix_features has no composite backward')
     composite = composite_gat
   else:
     raise NotImplementedError('no backward for %s' % kind)

@@ -394,6 +394,57 @@ __device__ __forceinline__ void hub_scores_partial_body(const AttArgs& a, float*
   }
 }
 
+// Head-parallel form for H in {1,2,4,8} (the hot case): lane = (entry, head) with the head fastest, so the H lanes of an entry
+// read ONE contiguous A-float row of k (round 1 looped over the heads and gathered every k row H times, 64 B at a time: 6.9 ms
+// for the 99.5 k hub chunks of the R-MAT graph); the scores of the PER passes stay in registers, the per-head maximum / sum
+// are xor butterflies over the lanes with equal head and a fold over the four waves in LDS.
+template <int TYPE, bool VEC4, int H>
+__device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float* __restrict__ part, int chunk) {
+  constexpr int EPB = kBlock / H;                 // entries per block pass
+  constexpr int PER = GNPDE_LONG_ROW / EPB;       // passes
+  __shared__ float red[kWavesPerBlock][H];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int head = threadIdx.x % H, slot = threadIdx.x / H;
+  const int b = a.chunk_begin[chunk], e = a.chunk_end[chunk];
+  const int row = a.rowidx[b];
+  float* out = part + static_cast<size_t>(chunk) * 2 * H;
+  int cols[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {                 // all column ids first, then all k gathers
+    const int p = b + i * EPB + slot;
+    cols[i] = p < e ? a.colidx[p] : -1;
+  }
+  float sv[PER];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = b + i * EPB + slot;
+    sv[i] = -INFINITY;
+    if (cols[i] >= 0) {
+      sv[i] = edge_score<TYPE, VEC4>(a, p, row, cols[i], head);
+      a.scores[static_cast<size_t>(p) * H + head] = sv[i];
+      mx = fmaxf(mx, sv[i]);
+    }
+  }
+#pragma unroll
+  for (int off = H; off < kWave; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+  if (lane < H) red[wave][lane] = mx;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0][head], red[1][head]), fmaxf(red[2][head], red[3][head]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) sum += expf(sv[i] - m);      // exp(-inf) = 0 for the absent entries
+#pragma unroll
+  for (int off = H; off < kWave; off <<= 1) sum += __shfl_xor(sum, off, kWave);
+  if (lane < H) red[wave][lane] = sum;
+  __syncthreads();
+  if (threadIdx.x < H) {
+    out[threadIdx.x] = m;
+    out[H + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 template <int TYPE, bool VEC4>
 __global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArgs a, float* __restrict__ part) {
   hub_scores_partial_body<TYPE, VEC4>(a, part, blockIdx.x);
@@ -509,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
                                                                  int hub_phase, float* __restrict__ part,
                                                                  const int* __restrict__ chunk_first) {
   if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_body<GNPDE_ATT_SCALED_DOT, true>(a, part, blockIdx.x);
+    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
     else hub_normalise_body(a, part, chunk_first, blockIdx.x);
     return;
   }
@@ -934,13 +985,22 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
 namespace {
 
 struct BwdArgs {
-  const float* __restrict__ dw;      // [e]
+  const float* __restrict__ dw;      // [e] CSR order: gradient of the HEAD MEAN (shared by the heads), or
+  const float* __restrict__ datt;    // [E,h] caller's edge order: gradient of every head's attention (then dw == nullptr)
+  const int* __restrict__ perm;      // CSR position -> edge id (for datt)
+  int post;                          // 0: ds w.r.t. the raw scores (times edge_w); 1: (ds w.r.t. the score) * score  -- the
+                                     //    common factor of every derivative of an exp kernel; 2: ds * leaky'(score) (GAT)
+  float leaky_slope;
   float* t;                          // [n,h]
   float* ds;                         // [e,h]
   float* partial;                    // [grid,2]: sum dz, count of maxima
   const float* __restrict__ scale_ptr;
   int scale_sigmoid;
 };
+
+__device__ __forceinline__ float grad_in(const BwdArgs& b, long long p, int head, int h) {
+  return b.dw != nullptr ? b.dw[p] : b.datt[static_cast<long long>(b.perm[p]) * h + head];
+}
 
 __device__ __forceinline__ float att_value(const AttArgs& a, float s, int seg, int head, float gmax) {
   const float den = a.seg_den[static_cast<size_t>(seg) * a.h + head];
@@ -970,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) void seg_dot_kernel(const AttArgs a, const 
     float sum = 0.f;
     for (int t = s0 + first; t < s1; t += step) {
       const int p = a.segpos ? a.segpos[t] : t;
-      sum += att_value(a, a.scores[static_cast<size_t>(p) * a.h + head], seg, head, gmax) * b.dw[p];
+      sum += att_value(a, a.scores[static_cast<size_t>(p) * a.h + head], seg, head, gmax) * grad_in(b, p, head, a.h);
     }
     sum = wave_sum(sum);
     if (BLOCK) {
@@ -984,6 +1044,13 @@ __global__ __launch_bounds__(kBlock) void seg_dot_kernel(const AttArgs a, const 
   }
 }
 
+// what multiplies d L / d score: edge_w (raw-score gradient), the score itself (exp kernels), or LeakyReLU' (GAT)
+__device__ __forceinline__ float post_factor(const BwdArgs& b, float s, float ew) {
+  if (b.post == 1) return s;
+  if (b.post == 2) return s > 0.f ? 1.0f : b.leaky_slope;
+  return ew;
+}
+
 __global__ __launch_bounds__(kBlock) void att_bwd_edge_kernel(const AttArgs a, const BwdArgs b) {
   __shared__ float rs[kWavesPerBlock], rc[kWavesPerBlock];
   float scale = 1.0f;
@@ -991,17 +1058,16 @@ __global__ __launch_bounds__(kBlock) void att_bwd_edge_kernel(const AttArgs a, c
     scale = *b.scale_ptr;
     if (b.scale_sigmoid) scale = 1.0f / (1.0f + expf(-scale));
   }
-  const float c = scale / static_cast<float>(a.h);
+  const float c = b.dw != nullptr ? scale / static_cast<float>(a.h) : scale;   // the head mean's 1/H only for a shared dw
   const float gmax = a.square_plus ? ord2f(*a.gmax) : 0.f;
   float lsum = 0.f, lcnt = 0.f;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   for (long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.e; p += stride) {
     const int seg = a.norm_idx == 0 ? a.rowidx[p] : a.colidx[p];
-    const float dwp = b.dw[p];
     const float ew = a.edge_w != nullptr ? a.edge_w[p] : 1.0f;
     for (int head = 0; head < a.h; ++head) {
       const float s = a.scores[p * a.h + head];
-      const float v = dwp - b.t[static_cast<size_t>(seg) * a.h + head];
+      const float v = grad_in(b, p, head, a.h) - b.t[static_cast<size_t>(seg) * a.h + head];
       float out;
       if (a.square_plus) {
         const float z = s - gmax;
@@ -1013,7 +1079,7 @@ __global__ __launch_bounds__(kBlock) void att_bwd_edge_kernel(const AttArgs a, c
       } else {
         out = c * att_value(a, s, seg, head, gmax) * v;
       }
-      b.ds[p * a.h + head] = out * ew;
+      b.ds[p * a.h + head] = out * post_factor(b, s, ew);
     }
   }
   if (a.square_plus) {   // block partials, folded in block order by att_bwd_max_share_kernel
@@ -1044,7 +1110,7 @@ __global__ __launch_bounds__(kBlock) void att_bwd_max_share_kernel(const AttArgs
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
     if (a.scores[i] == gmax) {
       const float ew = a.edge_w != nullptr ? a.edge_w[i / a.h] : 1.0f;
-      b.ds[i] -= share * ew;
+      b.ds[i] -= share * post_factor(b, a.scores[i], ew);
     }
   }
 }
@@ -1057,9 +1123,11 @@ size_t attention_bwd_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
   return align_up(attention_workspace_bytes(g, h, gat), 256) + align_up(static_cast<size_t>(g->n) * h * 4, 256) + kBwdPartials * 2 * 4;
 }
 
-int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* dw_csr, const float* scale,
-                              int scale_sigmoid, float* ds_csr, void* ws, size_t ws_bytes, hipStream_t stream) {
-  GNPDE_CHECK_ARG(g && at && dw_csr && ds_csr, GNPDE_EINVAL, "edge_attention_bwd: null argument");
+int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* dw_csr, const float* datt_edge,
+                              int post, const float* scale, int scale_sigmoid, float* ds_csr, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  GNPDE_CHECK_ARG(g && at && ds_csr && ((dw_csr != nullptr) != (datt_edge != nullptr)) && post >= 0 && post <= 2, GNPDE_EINVAL,
+                  "edge_attention_bwd: need exactly one of dw_csr / datt_edge, post in 0..2");
   if (g->e == 0 || g->n == 0) return 0;
   const bool gat = at->type == GNPDE_ATT_GAT;
   const size_t fwd = align_up(attention_workspace_bytes(g, at->heads, gat), 256);
@@ -1070,6 +1138,10 @@ int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a
   if (rc) return rc;
   BwdArgs b{};
   b.dw = dw_csr;
+  b.datt = datt_edge;
+  b.perm = g->perm;
+  b.post = post;
+  b.leaky_slope = at->leaky_slope;
   b.ds = ds_csr;
   b.t = reinterpret_cast<float*>(static_cast<char*>(ws) + fwd);
   b.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + fwd + align_up(static_cast<size_t>(g->n) * at->heads * 4, 256));
@@ -1118,7 +1190,13 @@ extern "C" size_t gnpde_attention_bwd_workspace_bytes(const gnpde_graph_t* g, co
 
 extern "C" int gnpde_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* dw_csr, const float* scale,
                                         int32_t scale_sigmoid, float* ds_csr, void* workspace, size_t workspace_bytes, void* stream) {
-  return gnpde::launch_edge_attention_bwd(g, a, dw_csr, scale, scale_sigmoid, ds_csr, workspace, workspace_bytes,
+  return gnpde::launch_edge_attention_bwd(g, a, dw_csr, nullptr, 0, scale, scale_sigmoid, ds_csr, workspace, workspace_bytes,
+                                          static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnpde_edge_attention_bwd_heads(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* datt_edge,
+                                              int32_t post, float* ds_csr, void* workspace, size_t workspace_bytes, void* stream) {
+  return gnpde::launch_edge_attention_bwd(g, a, nullptr, datt_edge, post, nullptr, 0, ds_csr, workspace, workspace_bytes,
                                           static_cast<hipStream_t>(stream));
 }
 

@@ -64,8 +64,9 @@ class SpGraphAttentionLayer(nn.Module):
   def forward(self, x, edge):
     """(attention [E,h] in the order of `edge`, wx [N,A])  (reference :105-115)."""
     _lib.require_hip(x, edge)
-    if torch.is_grad_enabled() and x.requires_grad:
-      raise NotImplementedError('differentiating through the attention layer itself is SURVEY.md 8f row 1 (next)')
+    if torch.is_grad_enabled() and (x.requires_grad or self.W.requires_grad or self.a.requires_grad):
+      from .autograd import native_gat_attention      # training: node-level terms in PyTorch, per-edge work native
+      return native_gat_attention(self, x, edge)
     with torch.no_grad():
       xc = _lib.f32c(x)
       graph = graph_of(edge, xc.shape[0], xc.device)
@@ -111,7 +112,8 @@ class ODEFuncAtt(ODEFunc):
     # the elementwise tail is three tiny torch ops on [N,d] (this option is off in every best_params)
     self._check_nfe()
     if self._needs_grad(x):
-      raise NotImplementedError('training with mix_features is SURVEY.md 8f row 1 (next)')
+      from .autograd import rhs_with_grad
+      return rhs_with_grad(self, x)
     with torch.no_grad():
       attention, wx = self.multihead_att_layer(x, self.edge_index)
       ax = self.multiply_attention(x, attention, wx)

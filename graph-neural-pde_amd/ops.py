@@ -183,6 +183,19 @@ def threshold_edges(edge_index, score, threshold, norm_idx, n_nodes):
   return out_ei[:, :k].contiguous(), out_w[:k].clone()
 
 
+def edge_attention_bwd_heads(graph, att, datt_edge, post=0):
+  """ds [E,h] (CSR order) from a per-head gradient in edge order (gnpde_edge_attention_bwd_heads); post: 0 raw-score gradient,
+  1 times the score (exp kernels), 2 times LeakyReLU' (GAT)."""
+  require_hip(datt_edge)
+  datt_edge = f32c(datt_edge, 'attention gradient')
+  L = _lib.lib()
+  ds = torch.empty(max(graph.e, 1), att.heads, dtype=torch.float32, device=datt_edge.device)
+  ws = graph.workspace('att_bwd', L.gnpde_attention_bwd_workspace_bytes(graph.ref(), ctypes.byref(att)))
+  check(L.gnpde_edge_attention_bwd_heads(graph.ref(), ctypes.byref(att), ptr(datt_edge), int(post), ptr(ds), ptr(ws), ws.numel(),
+                                         stream_of(datt_edge)))
+  return ds
+
+
 def lincomb(base, terms, out=None):
   """base + sum_j c_j v_j in one pass (gnpde_lincomb); terms = [(v_j, c_j), ...], all tensors contiguous float32 of
   base's shape.  `out` may be base (in-place update)."""

@@ -264,6 +264,15 @@ size_t gnpde_attention_bwd_workspace_bytes(const gnpde_graph_t* g, const gnpde_a
 int gnpde_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* dw_csr, const float* scale,
                              int32_t scale_sigmoid, float* ds_csr, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward for a gradient that arrives PER HEAD in the caller's edge order (datt_edge [E,h]: what autograd hands back
+ * for the [E,h] attention a block computes once per forward, reference src/block_transformer_attention.py:38-39), with the
+ * factor that turns d L / d score into what the score function's own derivative needs:
+ *   post 0: ds = d L / d raw score (times att->edge_w_csr)                      -- scaled dot, cosine, pearson
+ *   post 1: ds = (d L / d score) * score  -- the common factor of every derivative of var^2 exp(-|q-k|^2 / 2 l^2)
+ *   post 2: ds = (d L / d score) * LeakyReLU'(pre-activation)                   -- GAT */
+int gnpde_edge_attention_bwd_heads(const gnpde_graph_t* g, const gnpde_attention_t* a, const float* datt_edge, int32_t post,
+                                   float* ds_csr, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same ds as gnpde_softmax_rows_bwd, but computed from q and k in ONE pass (scores, row softmax and its
  * backward; no [E,h] attention array): att->type must be GNPDE_ATT_SCALED_DOT with norm_idx 0 and no squareplus,
  * heads in {1,2,4,8}, d_k in {4,8,16} (GNPDE_ESHAPE otherwise: use gnpde_edge_attention + gnpde_softmax_rows_bwd).

@@ -156,6 +156,154 @@ def test_native_vjp_every_normaliser_against_float64(dev, square_plus, norm_idx)
     assert e_gpu <= GTOL
 
 
+def _grad_close(name, got, ref64, ref32, scale=None):
+  scale = float(ref64.abs().max()) if scale is None else scale
+  e_gpu = float((got.detach().cpu().double().reshape(ref64.shape) - ref64).abs().max()) / scale
+  e_cpu = float((ref32.double() - ref64).abs().max()) / scale
+  assert e_gpu <= max(3 * e_cpu, 3e-5), '%s: GPU error %.2e vs float64, CPU fp32 error %.2e' % (name, e_gpu, e_cpu)
+
+
+@pytest.mark.parametrize('att_type,norm_idx,square_plus', [('cosine_sim', 0, False), ('pearson', 1, False), ('exp_kernel', 0, False),
+                                                          ('exp_kernel', 1, True), ('cosine_sim', 1, True)])
+def test_native_vjp_other_score_functions(dev, att_type, norm_idx, square_plus):
+  """cosine / pearson / exp_kernel attention: node-level transforms in PyTorch, every per-edge step native (no composite);
+  gradients of one evaluation of f against the float64 oracle."""
+  from gnpde_amd import autograd as AG
+  n, d = 400, 24
+  ei = random_graph(n, 6, seed=25, hubs=1, hub_deg=600)
+  g = torch.Generator().manual_seed(26)
+  x, go = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, attention_type=att_type, attention_norm_idx=norm_idx, square_plus=square_plus)
+  func = G.ODEFuncTransformerAtt(d, d, opt, Data(x.to(dev), ei.to(dev)), dev).to(dev)
+  _rand_params(func, 27, dev)
+  lay = func.multihead_att_layer
+  if att_type == 'exp_kernel':
+    with torch.no_grad():
+      lay.lengthscale.fill_(1.3)
+      lay.output_var.fill_(0.8)
+  AG._warned.clear()
+  xd = x.to(dev).requires_grad_(True)
+  func.x0 = x.to(dev)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  assert not AG._warned, 'a composite backward announced itself: %s' % AG._warned
+  edge = func.edge_index.cpu()
+  names = ['Q.weight', 'Q.bias', 'K.weight', 'K.bias'] + (['output_var', 'lengthscale'] if att_type == 'exp_kernel' else [])
+  ours = [dict(lay.named_parameters())[k] for k in names] + [func.alpha_train, func.beta_train]
+
+  def reference(dtype):
+    cast = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(True)   # noqa: E731
+    xc = cast(x)
+    ps = [cast(p) for p in ours]
+    kw = dict(attention_type=att_type, norm_idx=norm_idx, square_plus=square_plus)
+    if att_type == 'exp_kernel':
+      kw.update(output_var=ps[4], lengthscale=ps[5])
+    fr = R.rhs_transformer(xc, edge, ps[0], ps[1], ps[2], ps[3], 4, ps[-2], ps[-1], x.to(dtype), False, True, **kw)
+    fr.backward(go.to(dtype))
+    return fr.detach(), [xc.grad] + [p.grad for p in ps]
+
+  f64, g64 = reference(torch.float64)
+  f32, g32 = reference(torch.float32)
+  assert_parity(f, f64.float(), what='f')
+  scale = max(float(t.abs().max()) for t in g64[1:5])
+  for name, a, b32, b64 in zip(['dx'] + names + ['dalpha', 'dbeta'], [xd.grad] + [p.grad for p in ours], g32, g64):
+    own = name in ('dx', 'dalpha', 'dbeta', 'output_var', 'lengthscale')
+    _grad_close(name, a, b64, b32, None if own else scale)
+
+
+@pytest.mark.parametrize('mix', [False, True])
+def test_native_vjp_gat(dev, mix):
+  """GAT attention (and the mix_features aggregation A(x) (x W) Wout the reference trains with when asked to): per-edge
+  backward native, gradients against a float64 evaluation of the reference op sequence."""
+  from gnpde_amd import autograd as AG
+  n, d = 300, 16
+  ei = random_graph(n, 6, seed=35)
+  g = torch.Generator().manual_seed(36)
+  x, go = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, function='GAT', mix_features=mix, attention_dim=16, heads=4)
+  func = G.ODEFuncAtt(d, d, opt, Data(x.to(dev), ei.to(dev)), dev).to(dev)
+  _rand_params(func, 37, dev)
+  lay = func.multihead_att_layer
+  AG._warned.clear()
+  xd = x.to(dev).requires_grad_(True)
+  func.x0 = x.to(dev)
+  f = func(0.0, xd)
+  f.backward(go.to(dev))
+  assert not AG._warned
+  edge = func.edge_index.cpu()
+  ours = [lay.W, lay.a] + ([lay.Wout] if mix else []) + [func.alpha_train, func.beta_train]
+
+  def reference(dtype):
+    cast = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(True)   # noqa: E731
+    xc = cast(x)
+    ps = [cast(p) for p in ours]
+    if not mix:
+      fr = R.rhs_gat(xc, edge, ps[0], ps[1], 4, ps[-2], ps[-1], x.to(dtype), False, True, 0.2, 0)
+    else:      # reference src/function_GAT_attention.py:33-38,56-64
+      att, wx = R.gat_attention(xc, edge, ps[0], ps[1], 4, 0.2, 0)
+      ax = torch.mm(R.spmm(edge, att.mean(dim=1), n, wx), ps[2])
+      fr = torch.sigmoid(ps[-2]) * (ax - xc) + ps[-1] * x.to(dtype)
+    fr.backward(go.to(dtype))
+    return fr.detach(), [xc.grad] + [p.grad for p in ps]
+
+  f64, g64 = reference(torch.float64)
+  f32, g32 = reference(torch.float32)
+  assert_parity(f, f64.float(), what='f')
+  for name, a, b32, b64 in zip(['dx', 'dW', 'da'] + (['dWout'] if mix else []) + ['dalpha', 'dbeta'],
+                               [xd.grad] + [p.grad for p in ours], g32, g64):
+    _grad_close(name, a, b64, b32)
+
+
+def test_native_vjp_blend_attention_block(dev):
+  """AttODEblock + Laplacian function with the BLEND split kernel (exp kernels on feature and positional channels): the
+  attention computed ONCE per forward carries gradients back into Qx, Kx, Qp, Kp, both length scales and output variances --
+  per-edge work native (no composite), against float64 autograd through the oracle."""
+  from gnpde_amd import autograd as AG
+  n, f0, p0 = 300, 12, 8
+  d = f0 + p0
+  ei = random_graph(n, 6, seed=45)
+  g = torch.Generator().manual_seed(46)
+  x, c = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, function='laplacian', block='attention', method='euler', time=2.0, attention_type='exp_kernel',
+             beltrami=True, feat_hidden_dim=f0, pos_enc_hidden_dim=p0, attention_dim=16, heads=2)
+  block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, 2.0])).to(dev)
+  _rand_params(block, 47, dev)
+  lay = block.multihead_att_layer
+  with torch.no_grad():
+    for nm, v in (('lengthscale_x', 1.2), ('lengthscale_p', 0.9), ('output_var_x', 1.1), ('output_var_p', 0.7)):
+      getattr(lay, nm).fill_(v)
+  block.train()
+  AG._warned.clear()
+  xd = x.to(dev).requires_grad_(True)
+  block.set_x0(xd)
+  z = block(xd)
+  (z * c.to(dev)).sum().backward()
+  assert not AG._warned, AG._warned
+  f = block.odefunc
+  e_n = f.edge_index.cpu()
+  names = [k for k, _ in lay.named_parameters() if k.split('.')[0] in ('Qx', 'Kx', 'Qp', 'Kp') or 'lengthscale' in k or 'output_var' in k]
+  ours = [dict(lay.named_parameters())[k] for k in names]
+
+  def reference(dtype):
+    cast = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(True)   # noqa: E731
+    xc = cast(x)
+    P = {k: cast(p) for k, p in zip(names, ours)}
+    al, be = cast(f.alpha_train), cast(f.beta_train)
+    att, _ = R.transformer_attention_split(xc, e_n, P, 2, f0, p0, edge_weights=f.edge_weight.cpu().to(dtype), reweight=False)
+    rhs = lambda t, y: R.rhs_from_attention(y, e_n, att, al, be, xc, False, True)   # noqa: E731
+    zr = R.odeint_fixed(rhs, xc, 2.0, 1.0, 'euler')
+    (zr * c.to(dtype)).sum().backward()
+    return zr.detach(), [xc.grad] + [P[k].grad for k in names]
+
+  z64, g64 = reference(torch.float64)
+  z32, g32 = reference(torch.float32)
+  assert_parity(z, z64.float(), what='z')
+  wscale = max(float(t.abs().max()) for t in g64[1:] if t.dim() >= 2)
+  for name, a, b32, b64 in zip(['dx'] + names, [xd.grad] + [p.grad for p in ours], g32, g64):
+    assert a is not None, name
+    _grad_close(name, a, b64, b32, None if (name == 'dx' or b64.dim() < 2 and b64.numel() == 1) else wscale)
+
+
 def test_attention_block_training(dev):
   """AttODEblock in training mode: attention computed once (with history), Laplacian function native backward,
   edge-weight gradients through gnpde_sddmm into the attention layer's parameters."""
