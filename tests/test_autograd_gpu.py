@@ -290,7 +290,8 @@ def test_native_vjp_blend_attention_block(dev):
     P = {k: cast(p) for k, p in zip(names, ours)}
     al, be = cast(f.alpha_train), cast(f.beta_train)
     att, _ = R.transformer_attention_split(xc, e_n, P, 2, f0, p0, edge_weights=f.edge_weight.cpu().to(dtype), reweight=False)
-    rhs = lambda t, y: R.rhs_from_attention(y, e_n, att, al, be, xc, False, True)   # noqa: E731
+    x0 = x.to(dtype)                                    # ODEblock.set_x0 detaches the source term
+    rhs = lambda t, y: R.rhs_from_attention(y, e_n, att, al, be, x0, False, True)   # noqa: E731
     zr = R.odeint_fixed(rhs, xc, 2.0, 1.0, 'euler')
     (zr * c.to(dtype)).sum().backward()
     return zr.detach(), [xc.grad] + [P[k].grad for k in names]
