@@ -190,6 +190,81 @@ __global__ __launch_bounds__(kBlock) void linear_persistent_kernel(const float* 
   }
 }
 
+
+// Wide projections (m >= 64 output columns, e.g. the R-MAT configuration's [N,256] x [256,128]): linear_kernel re-reads all of
+// W (128 KB) from L2 for every 16-row tile -- 8x the bytes of the tile itself, 2.84 ms where the fp32 MFMA time is 0.9 ms.
+// Here W is staged ONCE per workgroup in LDS (rows padded by 4 floats, so the 16 lanes of a ds_read_b128 group hit 16
+// different 16-byte slots) and the 8 waves of the workgroup stride over the row tiles: per 16-K block a wave issues MT
+// B-operand reads from LDS and 4 MT MFMAs, with the A operands of the next K batch in flight from HBM.
+template <int MT, int DMAX>
+__global__ __launch_bounds__(512) void linear_lds_kernel(const float* __restrict__ x, int n, int d, int ldx,
+                                                         const float* __restrict__ W, int ldw, const float* __restrict__ b,
+                                                         float* __restrict__ out, int ldo, int col_base) {
+  constexpr int LDL = DMAX + 4;
+  constexpr int KU = 4;                                  // 16-wide K blocks per batch
+  __shared__ float lds[MT * 16 * LDL];
+  const int d4 = d >> 2;
+  for (int idx = threadIdx.x; idx < MT * 16 * d4; idx += 512) {
+    const int row = idx / d4, c4 = idx - row * d4;
+    *reinterpret_cast<float4*>(&lds[row * LDL + 4 * c4]) =
+        *reinterpret_cast<const float4*>(W + static_cast<size_t>(col_base + row) * ldw + 4 * c4);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = lane & 15, kq = lane >> 4;
+  float bias[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) bias[t] = b != nullptr ? b[col_base + t * 16 + r] : 0.0f;
+  const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
+  const long long stride = static_cast<long long>(gridDim.x) * 8;
+  const int nkb = d >> 4;
+  for (long long tile = static_cast<long long>(blockIdx.x) * 8 + (threadIdx.x >> 6); tile < n_tiles; tile += stride) {
+    long long row = tile * 16 + r;
+    if (row >= n) row = n - 1;                           // ragged last tile: clamp reads, mask writes
+    const float* xr = x + static_cast<size_t>(row) * ldx + 4 * kq;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cur[KU], nxt[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const float4 ta = u < nkb ? *reinterpret_cast<const float4*>(xr + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      cur[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+    }
+    for (int u0 = 0; u0 < nkb; u0 += KU) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {                     // next batch's A operands (wave-uniform guard)
+        const int kb = u0 + KU + u;
+        const float4 ta = kb < nkb ? *reinterpret_cast<const float4*>(xr + 16 * kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nxt[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (u0 + u < nkb) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const float4 tb = *reinterpret_cast<const float4*>(&lds[(t * 16 + r) * LDL + 16 * (u0 + u) + 4 * kq]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][0], tb.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][1], tb.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][2], tb.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][3], tb.w, acc[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) cur[u] = nxt[u];
+    }
+    const long long row0 = tile * 16;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long orow = row0 + 4 * kq + i;
+        if (orow < n) out[static_cast<size_t>(orow) * ldo + col_base + t * 16 + r] = acc[t][i] + bias[t];
+      }
+  }
+}
+
 template <int MT, bool ALIGNED>
 void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                  int ldo, int col, hipStream_t s) {
@@ -218,6 +293,23 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
         default: break;
       }
 #undef GNPDE_LP
+    }
+  }
+  if constexpr (MT >= 4 && ALIGNED) {
+    if (full_cols && d <= 256 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] == 0) {   // W staged in LDS, persistent workgroups
+      const long long need = (tiles + 7) / 8;
+      if (d <= 128) {
+        long long blocks = 256LL * (MT == 4 ? 4 : 2);
+        if (blocks > need) blocks = need;
+        hipLaunchKernelGGL((linear_lds_kernel<MT, 128>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, s, x, n, d, ldx, W, ldw, b,
+                           out, ldo, col);
+      } else {
+        long long blocks = 256LL * (MT == 4 ? 2 : 1);
+        if (blocks > need) blocks = need;
+        hipLaunchKernelGGL((linear_lds_kernel<MT, 256>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, s, x, n, d, ldx, W, ldw, b,
+                           out, ldo, col);
+      }
+      return;
     }
   }
   const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);

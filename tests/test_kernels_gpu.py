@@ -71,7 +71,9 @@ def test_spmm_unaligned_view(dev):
 
 
 @pytest.mark.parametrize('n,d,m', [(1, 8, 16), (37, 24, 32), (1000, 80, 256), (513, 128, 32), (300, 162, 64),
-                                   (129, 30, 20), (64, 5, 3), (2050, 128, 272)])
+                                   (129, 30, 20), (64, 5, 3), (2050, 128, 272),
+                                   # wide projections: W staged in LDS (linear_lds_kernel<8,256>, <4,256>, <8,128>, <4,128>)
+                                   (5003, 256, 128), (3000, 192, 64), (4100, 128, 128), (777, 64, 64), (9, 256, 192)])
 def test_linear(dev, n, d, m):
   g = torch.Generator().manual_seed(n + d + m)
   x = torch.randn(n, d, generator=g)
