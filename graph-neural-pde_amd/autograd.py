@@ -251,14 +251,15 @@ class _EdgeAttention(torch.autograd.Function):
   def forward(ctx, qt, kt, amp, struct_fn, graph, kind, scale, heads):
     with torch.no_grad():
       st, keep = struct_fn()
-      _, att, _ = ops.edge_attention(graph, st, want_w_mean=False, want_att=True, like=qt)
+      _, att, prods = ops.edge_attention(graph, st, want_w_mean=False, want_att=True, want_prods=True, like=qt)
     ctx.struct_fn, ctx.graph, ctx.kind, ctx.scale, ctx.heads = struct_fn, graph, kind, scale, heads
     ctx.has_amp = amp is not None
     ctx.save_for_backward(qt, kt, amp if amp is not None else qt.new_zeros(0))
-    return att
+    ctx.mark_non_differentiable(prods)      # the raw scores the reference also returns: values only
+    return att, prods
 
   @staticmethod
-  def backward(ctx, datt):
+  def backward(ctx, datt, _dprods):
     qt, kt, amp = ctx.saved_tensors
     graph, kind, h = ctx.graph, ctx.kind, ctx.heads
     dk = qt.shape[1] // h
@@ -357,7 +358,7 @@ def native_layer_attention(layer, x, edge):
     qk = ops.linear(xc.detach(), wqk, bqk)
     return layer.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
 
-  return _EdgeAttention.apply(_lib.f32c(qt), _lib.f32c(kt), amp, struct_fn, graph, kind, scale, layer.h)
+  return _EdgeAttention.apply(_lib.f32c(qt), _lib.f32c(kt), amp, struct_fn, graph, kind, scale, layer.h)   # (att, prods)
 
 
 def _native_layer_vjp_ok(layer):
@@ -483,7 +484,7 @@ def layer_attention_with_grad(layer, x, edge):
   """(attention [E,h], prods [E,h]) of SpGraphTransAttentionLayer with autograd history (composite); used
   when a block differentiates through the attention it computes once per forward pass."""
   if _native_layer_vjp_ok(layer) and not layer.opt.get('gnpde_composite_backward', False):
-    return native_layer_attention(layer, x, edge), None
+    return native_layer_attention(layer, x, edge)
   _announce('SpGraphTransAttentionLayer')
   return _layer_attention(layer, x, edge)
 
@@ -546,7 +547,7 @@ def rhs_with_grad(func, x):
     lay = func.multihead_att_layer
     if _native_layer_vjp_ok(lay) and not func.opt['mix_features'] and not func.opt.get('gnpde_composite_backward', False):
       # any other score function: node-level transforms in PyTorch, everything per edge native (section comment above)
-      att = native_layer_attention(lay, x, func.edge_index)
+      att, _ = native_layer_attention(lay, x, func.edge_index)
       return _AggregateRhs.apply(x, att, func.alpha_train, func.beta_train, func._source(x), func._graph(x),
                                  not func.opt['no_alpha_sigmoid'])
     composite = composite_transformer
