@@ -218,6 +218,9 @@ def main():
   import gnpde_amd as G
   if os.environ.get('GNPDE_ONE_PASS', '0') == '1':
     G.ops.tune(G._lib.TUNE_ONE_PASS, 1)
+  for kv in filter(None, os.environ.get('GNPDE_TUNE', '').split(',')):     # A/B knobs, e.g. GNPDE_TUNE=6=2 (separate kernels)
+    key, val = kv.split('=')
+    G.ops.tune(int(key), int(val))
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
   dev = torch.device('cuda', 0 if os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') == '1' else local_rank)

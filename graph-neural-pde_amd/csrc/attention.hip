@@ -814,8 +814,24 @@ bool launch_rows_t(const AttArgs& a, int n16, int n64, hipStream_t s) {
   }
 }
 
+template <int H>
+__global__ __launch_bounds__(kBlock) void hub_scores_partial_sd_kernel(const AttArgs a, float* __restrict__ part) {
+  hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
+}
+
 template <int TYPE>
 void launch_hub_a(const AttArgs& c, bool vec4, float* part, int n_chunks, hipStream_t s) {
+  if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
+    if (vec4) {
+      switch (c.h) {
+        case 1: hipLaunchKernelGGL(hub_scores_partial_sd_kernel<1>, dim3(n_chunks), dim3(kBlock), 0, s, c, part); return;
+        case 2: hipLaunchKernelGGL(hub_scores_partial_sd_kernel<2>, dim3(n_chunks), dim3(kBlock), 0, s, c, part); return;
+        case 4: hipLaunchKernelGGL(hub_scores_partial_sd_kernel<4>, dim3(n_chunks), dim3(kBlock), 0, s, c, part); return;
+        case 8: hipLaunchKernelGGL(hub_scores_partial_sd_kernel<8>, dim3(n_chunks), dim3(kBlock), 0, s, c, part); return;
+        default: break;
+      }
+    }
+  }
   if (vec4) hipLaunchKernelGGL((hub_scores_partial_kernel<TYPE, true>), dim3(n_chunks), dim3(kBlock), 0, s, c, part);
   else hipLaunchKernelGGL((hub_scores_partial_kernel<TYPE, false>), dim3(n_chunks), dim3(kBlock), 0, s, c, part);
 }
@@ -856,7 +872,7 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 // kernel arguments -- the backward pass continues from there
 static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                                float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork,
-                               bool stats_only, AttArgs* args_out) {
+                               bool stats_only, AttArgs* args_out, bool hubs_only = false) {
   GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
   GNPDE_CHECK_ARG(stats_only || w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
   GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
@@ -917,6 +933,15 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     c.chunk_begin = g->long_chunk_begin;
     c.chunk_end = g->long_chunk_end;
     c.long_segs = g->long_rows;
+    if (hubs_only) {   // head-mean weights of the entries of the long rows only (the short rows are attended elsewhere)
+      if (g->n_long_rows > 0) {
+        launch_hub_a_any(c, vec4, part, g->n_long_chunks, stream);
+        GNPDE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(hub_normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 0, stream, c, part, g->long_chunk_first);
+        GNPDE_LAUNCH_CHECK();
+      }
+      return 0;
+    }
     if (a.type == GNPDE_ATT_SCALED_DOT && vec4 && (fork == nullptr || fork->aux == nullptr) &&
         (g->n_long_rows == 0 || g->long_chunk_first != nullptr) &&
         launch_sd_with_hubs(c, g->n_bin16, g->n_bin64, g->n_long_rows > 0 ? g->n_long_chunks : 0, part, g->long_chunk_first,
@@ -968,6 +993,13 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork) {
   return edge_attention_impl(g, at, w_mean_csr, att_edge, prods_edge, ws, ws_bytes, stream, fork, false, nullptr);
+}
+
+// w_mean_csr[p] for the entries of the rows longer than GNPDE_LONG_ROW only (row softmax path); the caller attends the
+// other rows itself (attn_spmm_kernel)
+int launch_hub_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  return edge_attention_impl(g, at, w_mean_csr, nullptr, nullptr, ws, ws_bytes, stream, nullptr, false, nullptr, true);
 }
 
 // ------------------------------------------------------------------------------------------------

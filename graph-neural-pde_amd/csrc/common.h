@@ -67,7 +67,7 @@ enum {
   GNPDE_TUNE_FORK = 3,                 // 1: hub-row work on a second stream (fork / join)
   GNPDE_TUNE_ATT_GENERIC_ROWS = 4,     // 1: generic row-attention kernel instead of the scaled-dot specialisation
   GNPDE_TUNE_RK4_CLASSIC = 5,          // 1: torchdiffeq-order rk4 stages (k1..k3 stored) instead of the compact form
-  GNPDE_TUNE_RESERVED6 = 6,
+  GNPDE_TUNE_ROW_FUSION = 6,           // 2: GRAND-nl evaluations use the separate attention + aggregation kernels (A/B)
   GNPDE_TUNE_ONE_PASS_VARIANT = 7,     // register / unroll variants of the one-pass kernel (tools/onepass_ab.py)
   GNPDE_TUNE_LINEAR_STREAMING = 8,     // 1: one-tile-per-wave projection kernel instead of the persistent one
   GNPDE_TUNE_COUNT = 16
@@ -101,6 +101,14 @@ inline void fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
                     hipStream_t stream, const Fork* fork = nullptr, bool padded_rows = false);
+
+// attention + aggregation of the short rows in one kernel (spmm.hip) and the hub-row weights it needs (attention.hip)
+bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
+                         const gnpde_epilogue_t& e);
+int launch_attn_spmm(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* w_hub_csr, const float* u, int d, int ld,
+                     const gnpde_epilogue_t* epi, void* ws, size_t ws_bytes, hipStream_t stream, bool padded_rows);
+int launch_hub_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
 
 // early_stop.hip
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,

@@ -96,6 +96,15 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     at.ldqk = r.proj_m;
     at.q = proj;
     at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
+    const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0;
+    if (r.kind == GNPDE_RHS_TRANSFORMER && fork == nullptr && r.proj_row_end == 0 && r.n_state_rows <= g->n &&
+        (r.d % 4 == 0 || padded) && attn_spmm_supported(g, at, r.d, r.ld, u, epi)) {
+      // scaled-dot row softmax: the short rows are attended inside the aggregation kernel; only the hub rows' weights are
+      // computed ahead (two small launches)
+      rc = launch_hub_attention(g, &at, wmean, ws + L.att, L.att_bytes, s);
+      if (rc) return rc;
+      return launch_attn_spmm(g, &at, wmean, u, r.d, r.ld, &epi, ws + L.spmm, L.spmm_bytes, s, padded);
+    }
     rc = launch_edge_attention(g, &at, wmean, nullptr, nullptr, ws + L.att, L.att_bytes, s, fork);
     if (rc) return rc;
     w = wmean;

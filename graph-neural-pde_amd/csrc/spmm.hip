@@ -385,6 +385,223 @@ __global__ __launch_bounds__(BLK) void spmm_wide_kernel(const SpmmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row attention + aggregation in ONE kernel (scaled-dot scores, softmax over the row, head mean): what
+// row_attention_sd_kernel (two launches) + spmm_wide_kernel did, per row and per wave, without the [E] weight round trip,
+// the second read of the column ids and the two launch boundaries -- the attention's dependent gathers (ids -> k rows)
+// now overlap with the neighbouring waves' x-row gathers instead of running as a latency-bound kernel of their own.
+//   scores : lane = (entry slot, head), head fastest: the H lanes of an entry read ONE contiguous A-float row of k
+//            (DK4 16-byte loads each), 64 / H entries per pass; max / sum over the slots by xor butterflies with stride H
+//   weights: w_e = (1/H) sum_h exp(s_eh - m_h) / (l_h + 1e-16), summed over the H lanes of the entry, then redistributed
+//            so that lane e of the wave holds the weight of entry e of the 64-entry chunk (what gather_batch expects)
+//   rows with <= 64 entries keep their scores in registers; longer rows (<= 512) take an online-softmax pass over their
+//   chunks (running max / sum per lane) and RECOMPUTE the scores chunk by chunk in the aggregation pass (the k rows are
+//   64 B against 512 B of x per entry); hub chunks (rows > 512) take their weights from memory, written by the two small
+//   hub launches of attention.hip (launch_hub_attention) before this kernel.
+// ------------------------------------------------------------------------------------------------
+struct AttnSpmmArgs {
+  SpmmArgs s;
+  const float* __restrict__ q;       // [n, ldqk] row-side projection
+  const float* __restrict__ k;       // [n_cols, ldqk] column-side projection
+  int ldqk;
+  float inv_sqrt_dk;
+  const float* __restrict__ edge_w;  // CSR order or null (reweight_attention)
+};
+
+// scores of the 64-entry chunk starting at `base` for this lane's (slot, head): PASSES = H registers, entry = p * (64/H) + slot
+template <int H, int DK4>
+__device__ __forceinline__ void chunk_scores(const AttnSpmmArgs& fa, int cv, int base, int cnt, int slot, int head,
+                                             const float (&qv)[DK4 * 4], float (&sc)[H]) {
+  constexpr int ES = kWave / H;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    const int idx = p * ES + slot;
+    const int c = __shfl(cv, idx, kWave);
+    sc[p] = -INFINITY;
+    if (idx < cnt) {
+      const float* kp = fa.k + static_cast<size_t>(c) * fa.ldqk + head * (DK4 * 4);
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < DK4; ++j) {
+        const float4 kv = *reinterpret_cast<const float4*>(kp + 4 * j);
+        dot = fmaf(qv[4 * j + 0], kv.x, dot);
+        dot = fmaf(qv[4 * j + 1], kv.y, dot);
+        dot = fmaf(qv[4 * j + 2], kv.z, dot);
+        dot = fmaf(qv[4 * j + 3], kv.w, dot);
+      }
+      float sv = dot * fa.inv_sqrt_dk;
+      if (fa.edge_w != nullptr) sv *= fa.edge_w[base + idx];
+      sc[p] = sv;
+    }
+  }
+}
+
+template <int H>
+__device__ __forceinline__ float slots_max(float v) {
+#pragma unroll
+  for (int off = H; off < kWave; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+template <int H>
+__device__ __forceinline__ float slots_sum(float v) {
+#pragma unroll
+  for (int off = H; off < kWave; off <<= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// head-mean weights from the scores and the row statistics of this lane's head; returns the weight of entry `lane`
+template <int H>
+__device__ __forceinline__ float chunk_weights(const float (&sc)[H], float m, float inv_l, int lane) {
+  constexpr int ES = kWave / H;
+  float wv = 0.f;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    float a = expf(sc[p] - m) * inv_l;                 // exp(-inf) = 0 for the absent entries
+#pragma unroll
+    for (int off = 1; off < H; off <<= 1) a += __shfl_xor(a, off, kWave);   // sum over the H lanes of the entry
+    a *= (1.0f / static_cast<float>(H));
+    // entry p * ES + slot lives in the lanes slot * H ..: lane e of the wave wants entry e
+    const float got = __shfl(a, (lane % ES) * H, kWave);
+    if (lane / ES == p) wv = got;
+  }
+  return wv;
+}
+
+template <int VEC, int L, int U, int H, int DK4, bool NT, bool FULL>
+__global__ __launch_bounds__(kWave) void attn_spmm_kernel(const AttnSpmmArgs fa) {
+  const SpmmArgs& a = fa.s;
+  constexpr int G = kWave / L;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / L, cl = lane % L;
+  const int col = cl * VEC;
+  const bool col_ok = FULL ? true : col < a.d;
+  const int head = lane % H, slot = lane / H;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = static_cast<int>(blockIdx.x / kXcds);
+  const Item it = item_of(a, xcd, lw);
+  if (!it.valid) return;
+  const int row = it.row, e0 = it.e0, e1 = it.e1, chunk = it.chunk;
+  const size_t off = static_cast<size_t>(row) * a.ld + col;
+  const bool pre_ok = stage_prefetchable<VEC, NT>(a.ep.stage);
+
+  Pre<VEC, NT> pre;
+  const bool do_pre = pre_ok && chunk < 0 && sub == 0 && col_ok;
+  if (do_pre) {
+    auto ldp = [](const float* q, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(q, v); else load_vec<VEC>(q, v); };
+    load_vec<VEC>(a.u + off, pre.ui);
+    if (a.ep.x0 != nullptr) ldp(a.ep.x0 + off, pre.x0);
+    const int st = a.ep.stage;
+    if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) ldp(a.ep.y + off, pre.y);
+    if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) ldp(a.ep.k1 + off, pre.k1);
+  }
+
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+
+  auto aggregate = [&](int cv, float wv, int cnt) {
+    int t0 = 0;
+    for (; t0 + G * U <= cnt; t0 += G * U) gather_batch<VEC, L, U, false, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+    if (t0 < cnt) gather_batch<VEC, L, U, true, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+  };
+
+  if (chunk >= 0) {                               // hub chunk: weights were written by the hub launches
+    for (int base = e0; base < e1; base += kWave) {
+      const int me = base + lane;
+      const bool in = me < e1;
+      aggregate(in ? a.colidx[me] : 0, in ? a.w[me] : 0.0f, (e1 - base) < kWave ? (e1 - base) : kWave);
+    }
+  } else if (e1 > e0) {
+    float qv[DK4 * 4];
+    {
+      const float* qp = fa.q + static_cast<size_t>(row) * fa.ldqk + head * (DK4 * 4);
+#pragma unroll
+      for (int j = 0; j < DK4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + 4 * j);
+        qv[4 * j] = t.x; qv[4 * j + 1] = t.y; qv[4 * j + 2] = t.z; qv[4 * j + 3] = t.w;
+      }
+    }
+    float sc[H];
+    if (e1 - e0 <= kWave) {                       // one chunk: scores stay in registers
+      const int cnt = e1 - e0;
+      const int cv = lane < cnt ? a.colidx[e0 + lane] : 0;
+      chunk_scores<H, DK4>(fa, cv, e0, cnt, slot, head, qv, sc);
+      float m = sc[0];
+#pragma unroll
+      for (int p = 1; p < H; ++p) m = fmaxf(m, sc[p]);
+      m = slots_max<H>(m);
+      float l = 0.f;
+#pragma unroll
+      for (int p = 0; p < H; ++p) l += expf(sc[p] - m);
+      l = slots_sum<H>(l) + 1e-16f;
+      aggregate(cv, chunk_weights<H>(sc, m, 1.0f / l, lane), cnt);
+    } else {                                      // 65 .. 512 entries: online statistics, then recompute per chunk
+      float m = -INFINITY, l = 0.f;
+      for (int base = e0; base < e1; base += kWave) {
+        const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
+        const int cv = lane < cnt ? a.colidx[base + lane] : 0;
+        chunk_scores<H, DK4>(fa, cv, base, cnt, slot, head, qv, sc);
+        float mc = sc[0];
+#pragma unroll
+        for (int p = 1; p < H; ++p) mc = fmaxf(mc, sc[p]);
+        if (mc > m) {                             // (mc == -inf only for lanes without entries in this chunk)
+          l *= expf(m - mc);
+          m = mc;
+        }
+        if (m > -INFINITY) {
+#pragma unroll
+          for (int p = 0; p < H; ++p) l += expf(sc[p] - m);
+        }
+      }
+      const float mrow = slots_max<H>(m);
+      l = slots_sum<H>(m > -INFINITY ? l * expf(m - mrow) : 0.f) + 1e-16f;
+      const float inv_l = 1.0f / l;
+      for (int base = e0; base < e1; base += kWave) {
+        const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
+        const int cv = lane < cnt ? a.colidx[base + lane] : 0;
+        chunk_scores<H, DK4>(fa, cv, base, cnt, slot, head, qv, sc);
+        aggregate(cv, chunk_weights<H>(sc, mrow, inv_l, lane), cnt);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int o = L; o < kWave; o <<= 1)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], o, kWave);
+
+  if (sub != 0 || !col_ok) return;
+  if (chunk >= 0) {
+    store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);
+    return;
+  }
+  const float alpha = alpha_of(a.ep);
+  const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
+  if (pre_ok) {
+    epilogue_pre<VEC, NT>(a.ep, alpha, beta, off, acc, pre);
+  } else {
+    float ui[VEC];
+    load_vec<VEC>(a.u + off, ui);
+    epilogue<VEC, NT>(a.ep, alpha, beta, off, acc, ui);
+  }
+}
+
+template <int H, int DK4>
+bool launch_attn_spmm_hd(const AttnSpmmArgs& fa, hipStream_t st) {
+  const SpmmArgs& a = fa.s;
+  const int slots = (a.d + 3) / 4;
+  const unsigned grid = balanced_grid(a, 1);
+#define GNPDE_AS(LL)                                                                                                     \
+  if (a.d == LL * 4) hipLaunchKernelGGL((attn_spmm_kernel<4, LL, 8, H, DK4, true, true>), dim3(grid), dim3(kWave), 0, st, fa); \
+  else hipLaunchKernelGGL((attn_spmm_kernel<4, LL, 8, H, DK4, true, false>), dim3(grid), dim3(kWave), 0, st, fa);
+  if (slots <= 16) return false;
+  if (slots <= 32) { GNPDE_AS(32) return true; }
+  if (slots <= 64) { GNPDE_AS(64) return true; }
+#undef GNPDE_AS
+  return false;
+}
+
 // resident grid for the persistent variants: every CU filled with the waves its registers admit
 inline unsigned persistent_grid(int wpb) { return xcd_grid(256LL * 32 / wpb); }
 
@@ -712,6 +929,66 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
                        g->long_chunk_ptr);
     GNPDE_LAUNCH_CHECK();
     if (forked) fork_end(fork, stream, br);
+  }
+  return 0;
+}
+
+
+bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
+                         const gnpde_epilogue_t& e) {
+  if (g_tune[GNPDE_TUNE_ROW_FUSION] == 2) return false;                       // A/B: force the separate kernels
+  if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
+  const int dk = at.att_dim / at.heads;
+  if (!((at.heads == 4 && dk == 4) || (at.heads == 8 && dk == 16) || (at.heads == 4 && dk == 16) || (at.heads == 2 && dk == 16)))
+    return false;
+  const int slots = (d + 3) / 4;
+  if (ld % 4 != 0 || slots <= 16 || slots > 64 || g->row_begin != 0) return false;
+  if (e.stage == GNPDE_STAGE_LINCOMB) {
+    for (int j = 0; j < e.n_prev; ++j) if (!aligned(e.prev[j], 16)) return false;
+  }
+  const void* ptrs[] = {u, e.x0, e.y, e.k1, e.k2, e.k3, e.out_k, e.out_y};
+  for (const void* p : ptrs) if (!aligned(p, 16)) return false;
+  return true;
+}
+
+// rows: attention + aggregation in one kernel; hub chunks aggregate with the weights in w_hub_csr (written before by
+// launch_hub_attention); then the per-row fold of the chunk partials
+int launch_attn_spmm(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* w_hub_csr, const float* u, int d, int ld,
+                     const gnpde_epilogue_t* epi, void* ws, size_t ws_bytes, hipStream_t stream, bool padded_rows) {
+  GNPDE_CHECK_ARG(g && at && u && epi && at->q && at->k, GNPDE_EINVAL, "attn_spmm: null argument");
+  GNPDE_CHECK_ARG(d % 4 == 0 || padded_rows, GNPDE_ESHAPE, "attn_spmm: width %d needs padded rows", d);
+  GNPDE_CHECK_ARG(epi->alpha != nullptr && (epi->x0 == nullptr || epi->beta != nullptr), GNPDE_EINVAL, "attn_spmm: bad epilogue");
+  GNPDE_CHECK_ARG(epi->out_k != u && epi->out_y != u, GNPDE_EINVAL, "attn_spmm: output aliases the gathered operand");
+  if (g->n == 0) return 0;
+  AttnSpmmArgs fa{};
+  SpmmArgs& a = fa.s;
+  a.n = g->n; a.n_long_chunks = g->n_long_chunks;
+  a.rowptr = g->rowptr; a.colidx = g->colidx;
+  a.lc_row = g->long_chunk_row; a.lc_begin = g->long_chunk_begin; a.lc_end = g->long_chunk_end;
+  a.w = w_hub_csr; a.u = u; a.d = d; a.ld = ld; a.plain_out = nullptr;
+  a.ldp = static_cast<int>(align_up(static_cast<size_t>(d), 4));
+  a.partial = static_cast<float*>(ws);
+  a.ep = *epi;
+  a.chunk_begin = 0; a.chunk_end = g->n_long_chunks; a.row_begin = 0; a.row_end = g->n;
+  if (g->n_long_chunks > 0) {
+    const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
+    GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need && w_hub_csr != nullptr, GNPDE_EWS, "attn_spmm: workspace %zu < %zu bytes", ws_bytes, need);
+  }
+  fa.q = at->q; fa.k = at->k; fa.ldqk = at->ldqk;
+  const int dk = at->att_dim / at->heads;
+  fa.inv_sqrt_dk = 1.0f / sqrtf(static_cast<float>(dk));
+  fa.edge_w = at->edge_w_csr;
+  GNPDE_CHECK_ARG(at->ldqk % 4 == 0 && aligned(at->q, 16) && aligned(at->k, 16), GNPDE_EINVAL, "attn_spmm: q / k must be 16-byte aligned rows");
+  bool ok = false;
+  if (at->heads == 4 && dk == 4) ok = launch_attn_spmm_hd<4, 1>(fa, stream);
+  else if (at->heads == 8 && dk == 16) ok = launch_attn_spmm_hd<8, 4>(fa, stream);
+  else if (at->heads == 4 && dk == 16) ok = launch_attn_spmm_hd<4, 4>(fa, stream);
+  else if (at->heads == 2 && dk == 16) ok = launch_attn_spmm_hd<2, 4>(fa, stream);
+  GNPDE_CHECK_ARG(ok, GNPDE_ESHAPE, "attn_spmm: configuration not covered");
+  GNPDE_LAUNCH_CHECK();
+  if (g->n_long_rows > 0) {
+    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, stream, a, g->long_rows, g->long_chunk_ptr);
+    GNPDE_LAUNCH_CHECK();
   }
   return 0;
 }
