@@ -936,7 +936,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
 
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
                          const gnpde_epilogue_t& e) {
-  if (g_tune[GNPDE_TUNE_ROW_FUSION] == 2) return false;                       // A/B: force the separate kernels
+  if (g_tune[GNPDE_TUNE_ROW_FUSION] != 1) return false;   // opt-in: measured SLOWER than the separate kernels
   if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
   const int dk = at.att_dim / at.heads;
   if (!((at.heads == 4 && dk == 4) || (at.heads == 8 && dk == 16) || (at.heads == 4 && dk == 16) || (at.heads == 2 && dk == 16)))
