@@ -951,7 +951,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     }
     hipStream_t br = stream;
     if (g->n_long_rows > 0) {  // hubs: chunk passes, as a parallel branch when a fork stream is given
-      br = fork_begin(fork, stream);
+      { const int frc = fork_begin(fork, stream, &br); if (frc) return frc; }
       launch_hub_a_any(c, vec4, part, g->n_long_chunks, br);
       GNPDE_LAUNCH_CHECK();
       hipLaunchKernelGGL(hub_normalise_kernel, dim3(g->n_long_chunks), dim3(kBlock), 0, br, c, part, g->long_chunk_first);
@@ -959,7 +959,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     }
     launch_rows_any(a, g->n_bin16, g->n_bin64, stream);
     GNPDE_LAUNCH_CHECK();
-    if (g->n_long_rows > 0) fork_end(fork, stream, br);
+    if (g->n_long_rows > 0) { const int frc = fork_end(fork, stream, br); if (frc) return frc; }
     return 0;
   }
 

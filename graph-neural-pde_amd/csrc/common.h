@@ -84,17 +84,22 @@ struct Fork {
   hipEvent_t e_join = nullptr;
 };
 
-inline hipStream_t fork_begin(const Fork* f, hipStream_t s) {
-  if (f == nullptr || f->aux == nullptr) return s;
-  if (hipEventRecord(f->e_fork, s) != hipSuccess) return s;
-  if (hipStreamWaitEvent(f->aux, f->e_fork, 0) != hipSuccess) return s;
-  return f->aux;
+// Both report failures: a dropped record / wait would silently serialise the branch or -- worse -- let it race with
+// the main stream inside a captured graph.
+inline int fork_begin(const Fork* f, hipStream_t s, hipStream_t* branch) {
+  *branch = s;
+  if (f == nullptr || f->aux == nullptr) return 0;
+  GNPDE_HIP(hipEventRecord(f->e_fork, s));
+  GNPDE_HIP(hipStreamWaitEvent(f->aux, f->e_fork, 0));
+  *branch = f->aux;
+  return 0;
 }
 
-inline void fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
-  if (branch == s) return;
-  (void)hipEventRecord(f->e_join, branch);
-  (void)hipStreamWaitEvent(s, f->e_join, 0);
+inline int fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
+  if (branch == s) return 0;
+  GNPDE_HIP(hipEventRecord(f->e_join, branch));
+  GNPDE_HIP(hipStreamWaitEvent(s, f->e_join, 0));
+  return 0;
 }
 
 // internal launchers used by the solver (defined in the kernel translation units)

@@ -916,7 +916,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();
   if (g->n_long_rows > 0) {
-    hipStream_t br = forked ? fork_begin(fork, stream) : stream;
+    hipStream_t br = stream;
+    if (forked) { const int frc = fork_begin(fork, stream, &br); if (frc) return frc; }
     if (forked) {
       SpmmArgs c = a;
       c.chunk_end = g->n_long_chunks;
@@ -928,7 +929,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
     hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
                        g->long_chunk_ptr);
     GNPDE_LAUNCH_CHECK();
-    if (forked) fork_end(fork, stream, br);
+    if (forked) { const int frc = fork_end(fork, stream, br); if (frc) return frc; }
   }
   return 0;
 }
