@@ -516,3 +516,45 @@ def test_attention_rows_bwd_matches_two_step_path(dev, heads, dk, reweight):
   _, att_edge, _ = ops.edge_attention(graph, st, False, True, False, like=qk)
   ref = ops.softmax_rows_bwd(graph, att_edge, r_csr, edge_w_csr=ew_csr, scale=alpha, scale_sigmoid=True)
   assert_parity(fused[:graph.e], ref[:graph.e], tol=2e-5, what='ds')
+
+
+def test_weight_snapshot_survives_id_reuse(dev):
+  """Round-1 review: the backward snapshot of the Laplacian weights was keyed on id() of the attention tensor; a train ->
+  eval -> train sequence frees the first tensor and hands its id to the third, which made a stale snapshot compare equal.
+  The snapshot is keyed on a generation counter now: gradients of the third forward must use the third weights."""
+  n, d = 300, 16
+  ei = random_graph(n, 5, seed=71)
+  g = torch.Generator().manual_seed(72)
+  x, go = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, function='laplacian', block='attention')
+  func = G.LaplacianODEFunc(d, d, opt, Data(x.to(dev), ei.to(dev)), dev).to(dev)
+  func.edge_index = ei.to(dev)
+  func.x0 = x.to(dev)
+  E = ei.shape[1]
+
+  def grad_for(w):
+    func.attention_weights = w
+    xd = x.to(dev).requires_grad_(True)
+    func(0.0, xd).backward(go.to(dev))
+    return xd.grad.clone()
+
+  w1 = (torch.rand(E, 4, generator=g) + 0.1).to(dev).requires_grad_(True)
+  g1 = grad_for(w1)
+  del w1
+  with torch.no_grad():                                   # eval forward with other weights: replaces the live entry
+    func.attention_weights = (torch.rand(E, 4, generator=g) + 0.1).to(dev)
+    func(0.0, x.to(dev))
+  w3_cpu = torch.rand(E, 4, generator=g) + 0.1
+  got = []
+  for _ in range(8):                                      # new tensors until one reuses a freed id (usually the first)
+    w3 = w3_cpu.to(dev).requires_grad_(True)
+    got.append(grad_for(w3))
+    del w3
+  ref = R.rhs_laplacian(x.clone().requires_grad_(True), ei, w3_cpu.mean(dim=1), func.alpha_train.detach().cpu(),
+                        func.beta_train.detach().cpu(), x, False, True)
+  xr = x.clone().requires_grad_(True)
+  R.rhs_laplacian(xr, ei, w3_cpu.mean(dim=1), func.alpha_train.detach().cpu(), func.beta_train.detach().cpu(), x, False,
+                  True).backward(go)
+  for gg in got:
+    assert_parity(gg, xr.grad, tol=GTOL, what='dx with the CURRENT weights')
+  assert float((g1.cpu() - xr.grad).abs().max()) > 1e-3, 'the first weights must give a different gradient for the test to bite'

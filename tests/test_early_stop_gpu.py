@@ -249,3 +249,71 @@ def test_euler_is_refused(dev):
   with pytest.raises(AssertionError):
     with torch.no_grad():
       block(x)
+
+
+def test_index_valued_split_masks(dev):
+  """The reference's ogbn-arxiv Data carries NODE-INDEX tensors as masks (train_mask = split_idx['train'], reference
+  src/data.py:90); `logits[mask]` indexes either way.  Same counts as the equivalent boolean masks."""
+  n, d, c = 3000, 32, 9
+  g = torch.Generator().manual_seed(91)
+  y = torch.randn(n, d, generator=g).to(dev)
+  w = (torch.randn(c, d, generator=g) / np.sqrt(d)).to(dev)
+  labels = torch.randint(0, c, (n,), generator=g)
+  role = torch.randint(0, 3, (n,), generator=g)
+  bools = [role == 0, role == 1, role == 2]
+  idx = [torch.nonzero(m).flatten()[torch.randperm(int(m.sum()), generator=g)] for m in bools]   # shuffled index lists
+  a = ops.EarlyStopEvaluator(w, None, labels.to(dev), *[m.to(dev) for m in bools])
+  b = ops.EarlyStopEvaluator(w, None, labels.to(dev), *[i.to(dev) for i in idx])
+  assert a.sizes == b.sizes == [int(m.sum()) for m in bools]
+  for ev in (a, b):
+    ev.reset()
+    ev.evaluate(y, 1)
+  assert a.read()['best_hits'] == b.read()['best_hits']
+  with pytest.raises(G.GnpdeError):
+    ops.EarlyStopEvaluator(w, None, labels.to(dev), torch.tensor([0, n]).to(dev), idx[1].to(dev), idx[2].to(dev))
+
+
+def test_dopri5_rejections_before_the_first_accept_evaluate_the_initial_state(dev):
+  """Reference src/early_stop_solver.py:82-90 evaluates rk_state.y1 after EVERY trial step; after a rejection that is the
+  unchanged previous state, so trials rejected before the first accept evaluate y0 at t0 -- and y0 can be the best."""
+  from gnpde_amd import odeint as O
+  n, d, c = 400, 16, 5
+  g = torch.Generator().manual_seed(92)
+  y0 = torch.randn(n, d, generator=g).to(dev)
+  w = (torch.randn(c, d, generator=g) / np.sqrt(d)).to(dev)
+  labels = (torch.relu(y0) @ w.t()).argmax(1)                # y0 classifies every node correctly ...
+  role = torch.randint(0, 3, (n,), generator=g)
+  masks = [(role == i).to(dev) for i in range(3)]
+  calls = []
+
+  def stiff(t, y):                                          # ... and the dynamics scramble it; the first trial step is rejected
+    calls.append(float(t))
+    return -400.0 * y + 300.0 * torch.roll(y, 1, dims=1)
+
+  class Opt(dict):
+    pass
+  opt = Opt(method='dopri5', dataset='Cora', max_test_steps=100, earlystopxT=1)
+  integ = G.EarlyStopInt(1.0, opt, dev)
+
+  class D(object):
+    pass
+  data = D()
+  data.y, data.train_mask, data.val_mask, data.test_mask = labels, masks[0], masks[1], masks[2]
+  integ.data, integ.m2_weight, integ.m2_bias = data, w, None
+  rejected = []
+  orig = O._solve_dopri5
+
+  def spy(func, y0_, t, rtol, atol, **kw):
+    inner = kw.get('on_reject')
+    kw['on_reject'] = lambda y, tc: (rejected.append(tc), inner(y, tc))[1]
+    return orig(func, y0_, t, rtol, atol, **kw)
+  import gnpde_amd.early_stop_solver as ES
+  ES._solve_dopri5 = spy
+  try:
+    with torch.no_grad():
+      integ(stiff, y0, torch.tensor([0.0, 1.0], device=dev), method='dopri5', rtol=1e-6, atol=1e-8)
+  finally:
+    ES._solve_dopri5 = orig
+  assert rejected and rejected[0] == 0.0, 'the first trial step must have been rejected for this test to bite'
+  sol = integ.solver
+  assert sol.best_time == 0.0 and sol.best_val == 1.0 and sol.best_train == 1.0, (sol.best_time, sol.best_val)
