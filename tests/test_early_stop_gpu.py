@@ -286,9 +286,10 @@ def test_dopri5_rejections_before_the_first_accept_evaluate_the_initial_state(de
   masks = [(role == i).to(dev) for i in range(3)]
   calls = []
 
-  def stiff(t, y):                                          # ... and the dynamics scramble it; the first trial step is rejected
-    calls.append(float(t))
-    return -400.0 * y + 300.0 * torch.roll(y, 1, dims=1)
+  def stiff(t, y):          # ... and the dynamics scramble it; the rate jumps right after t0, so the first trial step (whose
+    calls.append(float(t))  # first stage was evaluated AT t0) has a large error estimate and is rejected
+    rate = 1.0 if float(t) < 1e-6 else 500.0
+    return -rate * y + 0.8 * rate * torch.roll(y, 1, dims=1)
 
   class Opt(dict):
     pass
