@@ -70,6 +70,7 @@ enum {
   GNPDE_TUNE_ROW_FUSION = 6,           // 1: row attention + aggregation in one kernel (attn_spmm_kernel; slower, kept for A/B)
   GNPDE_TUNE_ONE_PASS_VARIANT = 7,     // register / unroll variants of the one-pass kernel (tools/onepass_ab.py)
   GNPDE_TUNE_LINEAR_STREAMING = 8,     // 1: one-tile-per-wave projection kernel instead of the persistent one
+  GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)
   GNPDE_TUNE_COUNT = 16
 };
 extern int g_tune[GNPDE_TUNE_COUNT];

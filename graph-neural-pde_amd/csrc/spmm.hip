@@ -912,6 +912,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   a.chunk_end = forked ? 0 : g->n_long_chunks;
   a.row_begin = g->row_begin;
   a.row_end = g->n;
+  if (g_tune[GNPDE_TUNE_SPMM_PART] == 1) a.row_end = a.row_begin;       // (timing the two kinds of work items separately)
+  if (g_tune[GNPDE_TUNE_SPMM_PART] == 2) a.chunk_end = 0;
   int rc = run(a, stream);
   if (rc != 0) return rc;
   GNPDE_LAUNCH_CHECK();

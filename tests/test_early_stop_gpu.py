@@ -276,7 +276,8 @@ def test_index_valued_split_masks(dev):
 def test_dopri5_rejections_before_the_first_accept_evaluate_the_initial_state(dev):
   """Reference src/early_stop_solver.py:82-90 evaluates rk_state.y1 after EVERY trial step; after a rejection that is the
   unchanged previous state, so trials rejected before the first accept evaluate y0 at t0 -- and y0 can be the best."""
-  from gnpde_amd import odeint as O
+  import importlib
+  O = importlib.import_module('gnpde_amd.odeint')
   n, d, c = 400, 16, 5
   g = torch.Generator().manual_seed(92)
   y0 = torch.randn(n, d, generator=g).to(dev)
@@ -308,7 +309,7 @@ def test_dopri5_rejections_before_the_first_accept_evaluate_the_initial_state(de
     inner = kw.get('on_reject')
     kw['on_reject'] = lambda y, tc: (rejected.append(tc), inner(y, tc))[1]
     return orig(func, y0_, t, rtol, atol, **kw)
-  import gnpde_amd.early_stop_solver as ES
+  ES = importlib.import_module('gnpde_amd.early_stop_solver')
   ES._solve_dopri5 = spy
   try:
     with torch.no_grad():
