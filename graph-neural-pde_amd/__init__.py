@@ -20,6 +20,7 @@ from .block_transformer_hard_attention import HardAttODEblock
 from .block_transformer_rewiring import RewireAttODEblock
 from .early_stop_solver import EarlyStopInt, EarlyStopRK4, EarlyStopDopri5
 from .model_configurations import set_block, set_function, BlockNotDefined, FunctionNotDefined
+from .GNN import GNN, BaseGNN
 from . import synthetic
 
 __all__ = ['GnpdeError', 'build', 'lib', 'CSRGraph', 'graph_of', 'partition_rows', 'ops', 'MaxNFEException',

@@ -100,6 +100,8 @@ PROTOTYPES = {
                                      ctypes.c_int32, ctypes.c_float, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_linear': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32,
                                   ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_relu_linear': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32,
+                                       ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_attention_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),
   'gnpde_edge_attention': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct),
                                           c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),

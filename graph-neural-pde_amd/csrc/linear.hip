@@ -21,6 +21,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// relu on the A operand (the decoder of the reference's GNN.forward applies F.relu to the state before m2)
+__device__ __forceinline__ f32x4 relu_if(f32x4 v, int relu) {
+  if (relu) {
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  }
+  return v;
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ base, int k, int kmax, bool row_ok) {
   f32x4 r = {0.f, 0.f, 0.f, 0.f};
@@ -46,7 +54,7 @@ template <int MT, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int n, int d, int ldx,
                                                         const float* __restrict__ W, int m, int ldw,
                                                         const float* __restrict__ b, float* __restrict__ out,
-                                                        int ldo, int col_base, int row_base) {
+                                                        int ldo, int col_base, int row_base, int relu) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
       if constexpr (FULL) {
         if (kb + 16 * u < d) {  // d % 16 == 0: a K block is complete or absent -- a scalar (wave-uniform) test
           const float4 ta = *reinterpret_cast<const float4*>(xrow + k);
-          av[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+          av[u] = relu_if(f32x4{ta.x, ta.y, ta.z, ta.w}, relu);
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
             const float4 tb = *reinterpret_cast<const float4*>(W + static_cast<size_t>(col_base + t * 16 + r) * ldw + k);
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
           for (int t = 0; t < MT; ++t) bv[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       } else {
-        av[u] = load4_guard<ALIGNED>(xrow, k, d, arow_ok);
+        av[u] = relu_if(load4_guard<ALIGNED>(xrow, k, d, arow_ok), relu);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const int col = col_base + t * 16 + r;
@@ -129,7 +137,7 @@ template <int MT, int KB>
 __global__ __launch_bounds__(kBlock) void linear_persistent_kernel(const float* __restrict__ x, int n, int ldx,
                                                                    const float* __restrict__ W, int ldw,
                                                                    const float* __restrict__ b, float* __restrict__ out,
-                                                                   int ldo, int col_base) {
+                                                                   int ldo, int col_base, int relu) {
   const int lane = threadIdx.x & (kWave - 1);
   const int r = lane & 15, kq = lane >> 4;
   const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void linear_persistent_kernel(const float* 
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
       const float4 ta = *reinterpret_cast<const float4*>(xr + 16 * u);
-      av[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+      av[u] = relu_if(f32x4{ta.x, ta.y, ta.z, ta.w}, relu);
     }
   };
 
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void linear_persistent_kernel(const float* 
 template <int MT, int DMAX>
 __global__ __launch_bounds__(512) void linear_lds_kernel(const float* __restrict__ x, int n, int d, int ldx,
                                                          const float* __restrict__ W, int ldw, const float* __restrict__ b,
-                                                         float* __restrict__ out, int ldo, int col_base) {
+                                                         float* __restrict__ out, int ldo, int col_base, int relu) {
   constexpr int LDL = DMAX + 4;
   constexpr int KU = 4;                                  // 16-wide K blocks per batch
   __shared__ float lds[MT * 16 * LDL];
@@ -229,14 +237,14 @@ __global__ __launch_bounds__(512) void linear_lds_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const float4 ta = u < nkb ? *reinterpret_cast<const float4*>(xr + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-      cur[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+      cur[u] = relu_if(f32x4{ta.x, ta.y, ta.z, ta.w}, relu);
     }
     for (int u0 = 0; u0 < nkb; u0 += KU) {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {                     // next batch's A operands (wave-uniform guard)
         const int kb = u0 + KU + u;
         const float4 ta = kb < nkb ? *reinterpret_cast<const float4*>(xr + 16 * kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-        nxt[u] = f32x4{ta.x, ta.y, ta.z, ta.w};
+        nxt[u] = relu_if(f32x4{ta.x, ta.y, ta.z, ta.w}, relu);
       }
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(512) void linear_lds_kernel(const float* __restrict
 
 template <int MT, bool ALIGNED>
 void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
-                 int ldo, int col, hipStream_t s) {
+                 int ldo, int col, hipStream_t s, int relu) {
   // complete 16-row tiles with complete column tiles and d % 16 == 0 take the unguarded kernel
   const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
   const long long tiles = (static_cast<long long>(n) + 15) / 16;
@@ -280,7 +288,7 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
       if (blocks > need) blocks = need;
       const unsigned pg = static_cast<unsigned>(blocks);
 #define GNPDE_LP(KBV) \
-  hipLaunchKernelGGL((linear_persistent_kernel<MT, KBV>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col)
+  hipLaunchKernelGGL((linear_persistent_kernel<MT, KBV>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu)
       switch (d / 16) {
         case 1: GNPDE_LP(1); return;
         case 2: GNPDE_LP(2); return;
@@ -302,12 +310,12 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
         long long blocks = 256LL * (MT == 4 ? 4 : 2);
         if (blocks > need) blocks = need;
         hipLaunchKernelGGL((linear_lds_kernel<MT, 128>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, s, x, n, d, ldx, W, ldw, b,
-                           out, ldo, col);
+                           out, ldo, col, relu);
       } else {
         long long blocks = 256LL * (MT == 4 ? 2 : 1);
         if (blocks > need) blocks = need;
         hipLaunchKernelGGL((linear_lds_kernel<MT, 256>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, s, x, n, d, ldx, W, ldw, b,
-                           out, ldo, col);
+                           out, ldo, col, relu);
       }
       return;
     }
@@ -315,29 +323,29 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
   const unsigned grid = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (full_cols)
     hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, true>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo,
-                       col, 0);
+                       col, 0, relu);
   else
     hipLaunchKernelGGL((linear_kernel<MT, ALIGNED, false>), dim3(grid), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out,
-                       ldo, col, 0);
+                       ldo, col, 0, relu);
 }
 
 template <bool ALIGNED>
 void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
-                   int ldo, hipStream_t s) {
+                   int ldo, hipStream_t s, int relu) {
   int col = 0;
   while (col < m) {
     const int rem = (m - col + 15) / 16;
     if (rem >= 8) {
-      launch_tile<8, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
+      launch_tile<8, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s, relu);
       col += 128;
     } else if (rem >= 4) {
-      launch_tile<4, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
+      launch_tile<4, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s, relu);
       col += 64;
     } else if (rem >= 2) {
-      launch_tile<2, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
+      launch_tile<2, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s, relu);
       col += 32;
     } else {
-      launch_tile<1, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s);
+      launch_tile<1, ALIGNED>(x, n, d, ldx, W, m, ldw, b, out, ldo, col, s, relu);
       col += 16;
     }
   }
@@ -346,15 +354,15 @@ void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m,
 }  // namespace
 
 int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
-                      int ldo, hipStream_t s) {
+                      int ldo, hipStream_t s, int relu) {
   GNPDE_CHECK_ARG(x && W && out, GNPDE_EINVAL, "linear: null pointer");
   GNPDE_CHECK_ARG(n >= 0 && d >= 1 && m >= 1 && ldx >= d && ldw >= d && ldo >= m, GNPDE_EINVAL,
                   "linear: bad shape n=%d d=%d m=%d ldx=%d ldw=%d ldo=%d", n, d, m, ldx, ldw, ldo);
   if (n == 0) return 0;
   const bool al = (ldx % 4 == 0) && (ldw % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                   (reinterpret_cast<uintptr_t>(W) % 16 == 0);
-  if (al) launch_linear<true>(x, n, d, ldx, W, m, ldw, b, out, ldo, s);
-  else launch_linear<false>(x, n, d, ldx, W, m, ldw, b, out, ldo, s);
+  if (al) launch_linear<true>(x, n, d, ldx, W, m, ldw, b, out, ldo, s, relu);
+  else launch_linear<false>(x, n, d, ldx, W, m, ldw, b, out, ldo, s, relu);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -363,5 +371,10 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
 
 extern "C" int gnpde_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,
                             const float* b, float* out, int32_t ldo, void* stream) {
-  return gnpde::launch_linear_any(x, n, d, ldx, W, m, ldw, b, out, ldo, static_cast<hipStream_t>(stream));
+  return gnpde::launch_linear_any(x, n, d, ldx, W, m, ldw, b, out, ldo, static_cast<hipStream_t>(stream), 0);
+}
+
+extern "C" int gnpde_relu_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,
+                                 const float* b, float* out, int32_t ldo, void* stream) {
+  return gnpde::launch_linear_any(x, n, d, ldx, W, m, ldw, b, out, ldo, static_cast<hipStream_t>(stream), 1);
 }

@@ -14,7 +14,7 @@
 namespace gnpde {
 
 int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
-                      int ldo, hipStream_t s);
+                      int ldo, hipStream_t s, int relu = 0);
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);

@@ -15,10 +15,11 @@ def _scalar_dev(t, like):
   return t.reshape(-1)
 
 
-def linear(x, weight, bias=None, out=None):
-  """out = x @ weight.T + bias on the fp32 matrix cores (gnpde_linear)."""
+def linear(x, weight, bias=None, out=None, relu_input=False):
+  """out = x @ weight.T + bias on the fp32 matrix cores (gnpde_linear); relu_input: out = relu(x) @ weight.T + bias
+  (gnpde_relu_linear, the decoder of GNN.forward).  x may have padded rows (unit column stride)."""
   require_hip(x, weight, bias)
-  x, weight = f32c(x, 'x'), f32c(weight, 'weight')
+  x, weight = _lib.f32rows(x, 'x'), f32c(weight, 'weight')
   n, d = x.shape
   m = weight.shape[0]
   if weight.shape[1] != d:
@@ -26,8 +27,8 @@ def linear(x, weight, bias=None, out=None):
   if out is None:
     out = torch.empty(n, m, dtype=torch.float32, device=x.device)
   b = None if bias is None else f32c(bias, 'bias')
-  check(_lib.lib().gnpde_linear(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out),
-                                out.stride(0), stream_of(x)))
+  fn = _lib.lib().gnpde_relu_linear if relu_input else _lib.lib().gnpde_linear
+  check(fn(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out), out.stride(0), stream_of(x)))
   return out
 
 

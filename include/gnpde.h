@@ -212,6 +212,11 @@ int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const float* ds_c
 int gnpde_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m,
                  int32_t ldw, const float* b, float* out, int32_t ldo, void* stream);
 
+/* out = relu(x) W^T + b: the decoder of the reference's GNN.forward (F.relu -> [dropout, identity at test time] -> m2,
+ * src/GNN.py:61-71) in one pass; same kernels as gnpde_linear with the activation applied to the A operand. */
+int gnpde_relu_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,
+                      const float* b, float* out, int32_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Edge attention: per-edge scores -> per-node normalisation -> head-mean weights.
  * Replaces SpGraphTransAttentionLayer.forward (src/function_transformer_attention.py:190-213),

@@ -258,6 +258,42 @@ def gen_gnn():
                               'nfe': np.int64(model.getNFE())}, model)
 
 
+def gen_gnn_options():
+  """GNN.forward's optional branches at test time (GNN.py:17-72): use_mlp + fc_out, batch_norm (running statistics) +
+  augment, use_labels (label columns bypass the encoder), beltrami (separate feature / positional encoders)."""
+  n, feat, classes = 120, 40, 5
+  ei = make_graph(n, 6, 33)
+  g = torch.Generator().manual_seed(34)
+  cases = {
+    'mlp_fcout': (dict(use_mlp=True, fc_out=True, function='transformer', method='rk4', time=2.0), feat, 0),
+    'bn_augment': (dict(batch_norm=True, augment=True, function='laplacian', method='euler', time=3.0), feat, 0),
+    'labels': (dict(use_labels=True, function='laplacian', block='attention', method='rk4', time=2.0), feat + classes, 0),
+    'beltrami': (dict(beltrami=True, function='transformer', attention_type='exp_kernel', feat_hidden_dim=16,
+                      pos_enc_hidden_dim=8, pos_enc_dim=6, method='rk4', time=2.0), feat, 6),
+  }
+  for i, (name, (over, width, pos)) in enumerate(cases.items()):
+    opt = copy.deepcopy({**BASE, **over})
+    xin = torch.randn(n, width, generator=g)
+    if over.get('use_labels'):
+      xin[:, -classes:] = torch.nn.functional.one_hot(torch.randint(0, classes, (n,), generator=g), classes).float()
+    pe = torch.randn(n, pos, generator=g) if pos else None
+    data = data_of(ei, xin[:, :feat])
+    model = GNN(opt, DummyDataset(data, classes), torch.device('cpu'))
+    randomise(model, 520 + i)
+    if over.get('batch_norm'):
+      for bn in (model.bn_in, model.bn_out):
+        bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * 0.2)
+        bn.running_var.copy_(0.5 + torch.rand(bn.running_var.shape, generator=g))
+    model.eval()
+    with torch.no_grad():
+      out = model(xin, pe) if pe is not None else model(xin)
+    rec = {'edge_index': ei, 'x': xin, 'out': out, 'num_classes': np.int64(classes), 'num_features': np.int64(feat),
+           'nfe': np.int64(model.getNFE())}
+    if pe is not None:
+      rec['pos'] = pe
+    save('gnnopt_' + name, opt, rec, model)
+
+
 def gen_beltrami():
   """BLEND attention: separate exp kernels on the feature and positional channels, multiplied
   (function_transformer_attention.py:83-101, :133-171); with and without label columns after the positional block."""
@@ -500,6 +536,7 @@ if __name__ == '__main__':
   gen_funcs()
   gen_blocks()
   gen_gnn()
+  gen_gnn_options()
   gen_beltrami()
   gen_rewire()
   gen_early()

@@ -87,23 +87,33 @@ def test_block_forward(dev, name, use_graph):
     assert torch.equal(z, z2), 'replay is not deterministic'
 
 
-@pytest.mark.parametrize('name', fixtures('gnn_'))
+def _gnn_of(fx, dev):
+  feat = int(fx.arr['num_features']) if 'num_features' in fx.arr else fx.arr['x'].shape[1]
+  data = Data(fx.t('x', dev)[:, :feat], fx.t('edge_index', dev))
+  model = G.GNN(dict(fx.opt), G.DummyDataset(data, int(fx.arr['num_classes'])), dev).to(dev)
+  model.load_state_dict(fx.params, strict=True)
+  return model.eval()
+
+
+@pytest.mark.parametrize('name', fixtures('gnn_') + fixtures('gnnopt_'))
 def test_gnn_end_to_end(dev, name):
-  """Encoder -> ODE block -> decoder as in the reference's GNN.forward (src/GNN.py:17-72, eval mode)."""
+  """Encoder -> ODE block -> decoder of the reference's GNN.forward (src/GNN.py:17-72, eval mode) through gnpde_amd.GNN:
+  native encoder / relu+decoder launches around the native block, with the reference's state_dict loaded strictly.
+  gnnopt_*: use_mlp + fc_out, batch_norm + augment, use_labels, beltrami."""
   fx = Fixture(name)
-  xin = fx.t('x', dev)
-  p = {k: v.to(dev) for k, v in fx.params.items()}
-  h = torch.nn.functional.linear(xin, p['m1.weight'], p['m1.bias'])
-  data = Data(xin, fx.t('edge_index', dev))
-  block = BLOCKS[fx.opt['block']](FUNCS[fx.opt['function']], [], fx.opt, data, dev,
-                                  t=torch.tensor([0, fx.opt['time']])).to(dev)
-  block.load_state_dict({k[len('odeblock.'):]: v for k, v in fx.params.items() if k.startswith('odeblock.')}, strict=True)
-  block.eval()
-  block.set_x0(h)
+  model = _gnn_of(fx, dev)
+  pos = fx.t('pos', dev) if 'pos' in fx.arr else None
   with torch.no_grad():
-    z = block(h)
-  out = torch.nn.functional.linear(torch.relu(z), p['m2.weight'], p['m2.bias'])
+    out = model(fx.t('x', dev), pos)
   assert_parity(out, fx.t('out'), what=name)
+  assert model.getNFE() == int(fx.arr['nfe'])
+  model.resetNFE()
+  assert model.getNFE() == 0
+  # the autograd route (PyTorch encoder / decoder around the native block) gives the same answer
+  with torch.enable_grad():
+    out_t = model(fx.t('x', dev), pos)
+  assert out_t.requires_grad
+  assert_parity(out_t.detach(), fx.t('out'), what=name + ' (grad mode)')
 
 
 def test_max_nfe(dev):

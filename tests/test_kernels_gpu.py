@@ -86,6 +86,23 @@ def test_linear(dev, n, d, m):
   assert_parity(out2, torch.nn.functional.linear(x.double(), W.double()).float(), what='linear no bias')
 
 
+@pytest.mark.parametrize('n,d,m', [(1000, 128, 40), (169, 24, 5), (5003, 256, 128), (777, 64, 64), (64, 5, 3), (513, 81, 40)])
+def test_relu_linear(dev, n, d, m):
+  """Decoder of GNN.forward: relu on the A operand of every projection kernel; also from a row-strided input (the left
+  half of an augmented state, GNN.py:58-59)."""
+  g = torch.Generator().manual_seed(n + d + m + 1)
+  x = torch.randn(n, 2 * d, generator=g)
+  W = torch.randn(m, d, generator=g) / math.sqrt(d)
+  b = torch.randn(m, generator=g)
+  xd = x.to(dev)
+  ref = torch.nn.functional.linear(torch.relu(x[:, :d]).double(), W.double(), b.double()).float()
+  assert_parity(ops.linear(xd[:, :d].contiguous(), W.to(dev), b.to(dev), relu_input=True), ref, what='relu_linear')
+  assert_parity(ops.linear(xd[:, :d], W.to(dev), b.to(dev), relu_input=True), ref, what='relu_linear strided')
+  # the plain entry is unchanged by the flag's plumbing
+  ref0 = torch.nn.functional.linear(x[:, :d].double(), W.double(), b.double()).float()
+  assert_parity(ops.linear(xd[:, :d], W.to(dev), b.to(dev)), ref0, what='linear strided')
+
+
 ATT_CASES = [
   ('scaled_dot', 4, 16, 0, False), ('scaled_dot', 4, 16, 1, False), ('scaled_dot', 8, 128, 1, True),
   ('scaled_dot', 8, 128, 0, True), ('scaled_dot', 3, 21, 0, False), ('scaled_dot', 1, 24, 1, False),

@@ -23,7 +23,12 @@ sys.path.insert(0, os.path.join(ROOT, 'graph-neural-pde_amd', 'dropin'))
 ref_env.activate()                      # stand-ins + reference src appended AFTER the drop-in directory
 import torch
 from helpers import Fixture
-from GNN import GNN                     # the reference's model, unmodified
+import importlib.util
+spec = importlib.util.spec_from_file_location('_reference_GNN', os.path.join(ref_env.REFERENCE_ROOT, 'src', 'GNN.py'))
+ref_gnn = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_gnn)
+from GNN import GNN as NativeGNN        # dropin/GNN.py: fused encoder / decoder launches
+assert NativeGNN.__module__ == 'gnpde_amd.GNN'
+GNN = ref_gnn.GNN                       # the reference's model, unmodified, over the drop-in blocks / functions
 from utils import DummyDataset          # the reference's utils
 from torch_geometric.data import Data
 for name in ('gnn_constant_transformer_rk4', 'gnn_attention_laplacian_euler'):
@@ -38,6 +43,10 @@ for name in ('gnn_constant_transformer_rk4', 'gnn_attention_laplacian_euler'):
   assert ours == theirs, set(ours) ^ set(theirs)
   model.load_state_dict(fx.params, strict=True)
   print(model)                          # the reference's print(model) raises for --function transformer
+  native = NativeGNN(dict(fx.opt), DummyDataset(data, int(fx.arr['num_classes'])), torch.device('cpu'))
+  assert {k: tuple(v.shape) for k, v in native.state_dict().items()} == theirs
+  native.load_state_dict(model.state_dict(), strict=True)
+  assert native.regularization_coeffs == model.regularization_coeffs and repr(native) == repr(model)
 # the reference's early-stopping model (GNN_early.py) picks up the device evaluator, its registry the rewiring block
 from GNN_early import GNNEarly
 fx = Fixture('gnn_constant_transformer_rk4')
