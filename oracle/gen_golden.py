@@ -278,6 +278,7 @@ def gen_gnn_options():
       xin[:, -classes:] = torch.nn.functional.one_hot(torch.randint(0, classes, (n,), generator=g), classes).float()
     pe = torch.randn(n, pos, generator=g) if pos else None
     data = data_of(ei, xin[:, :feat])
+    opt_in = copy.deepcopy(opt)      # (the constructor rewrites opt['hidden_dim'] for use_labels / beltrami)
     model = GNN(opt, DummyDataset(data, classes), torch.device('cpu'))
     randomise(model, 520 + i)
     if over.get('batch_norm'):
@@ -291,7 +292,7 @@ def gen_gnn_options():
            'nfe': np.int64(model.getNFE())}
     if pe is not None:
       rec['pos'] = pe
-    save('gnnopt_' + name, opt, rec, model)
+    save('gnnopt_' + name, opt_in, rec, model)
 
 
 def gen_beltrami():
