@@ -138,6 +138,10 @@ PROTOTYPES = {
                                        ctypes.c_int32, c_vp]),
   'gnpde_quantile_workspace_bytes': (ctypes.c_size_t, []),
   'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_two_hop_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32]),
+  'gnpde_two_hop_count': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_two_hop_fill': (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp,
+                                        ctypes.c_size_t, c_vp]),
   'gnpde_threshold_edges_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),
   'gnpde_threshold_edges': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp,
                                            c_vp, ctypes.c_size_t, c_vp]),

@@ -3,8 +3,9 @@ neighbourhood of the current transition matrix), drops the weakest ones, renorma
 head-mean attention recomputed on the current edge set (reference src/block_transformer_rewiring.py:10-260,
 `--block rewire_attention`).
 
-The rewiring is once-per-forward host-side bookkeeping on device tensors (sort / unique / index_add); the attention
-and every evaluation of f inside the solver stay on the native kernels.  The function's CSR is rebuilt lazily because
+The rewiring is once-per-forward bookkeeping on the device: quantile, compaction + renormalisation (csrc/rewire.hip) and
+the two-hop densification (csrc/twohop.hip) are native kernels, random-edge de-duplication is torch.unique as in the
+reference; the attention and every evaluation of f inside the solver run on the native kernels.  The function's CSR is rebuilt lazily because
 `edge_index` is a new tensor after each rewiring."""
 import numpy as np
 import torch
@@ -75,6 +76,15 @@ class RewireAttODEblock(ODEblock):
     n = self.num_nodes
     for _ in range(k - 1):
       ei, ew = self.odefunc.edge_index, self.odefunc.edge_weight
+      if ew.is_cuda and ew.dtype == torch.float32:
+        # native: one row-wise kernel for spspmm -> remove_self_loops -> cat -> / 2 -> coalesce (csrc/twohop.hip)
+        from . import ops
+        from .graph import graph_of
+        ei, ew = ops.two_hop(graph_of(ei, n), ew)
+        self.data_edge_index = ei
+        self.odefunc.edge_index = self.data_edge_index
+        self.odefunc.attention_weights = ew
+        continue
       new_edges, new_weights = _spspmm(ei, ew, ei, ew, n)
       keep = new_edges[0] != new_edges[1]
       new_edges, new_weights = new_edges[:, keep], new_weights[keep]

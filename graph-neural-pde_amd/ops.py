@@ -184,6 +184,29 @@ def threshold_edges(edge_index, score, threshold, norm_idx, n_nodes):
   return out_ei[:, :k].contiguous(), out_w[:k].clone()
 
 
+def two_hop(graph, weight):
+  """(edge_index [2, nnz] int64, value [nnz]) of coalesce(A ++ offdiag(A A)) / 2 for the operator A = (graph, weight in the
+  caller's edge order): the densification step of the rewiring block (gnpde_two_hop_count / _fill); one host read for nnz."""
+  require_hip(weight)
+  w = f32c(weight.detach().reshape(-1), 'weight')
+  dev = w.device
+  if graph.e == 0:
+    return torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
+  L = _lib.lib()
+  w_csr = w[graph.perm_long].contiguous()
+  rowptr, col = graph.t['rowptr'], graph.t['colidx']
+  ws = torch.empty(int(L.gnpde_two_hop_workspace_bytes(graph.n)), dtype=torch.uint8, device=dev)
+  out_rowptr = torch.empty(graph.n + 1, dtype=torch.int64, device=dev)
+  check(L.gnpde_two_hop_count(ptr(rowptr), ptr(col), graph.n, ptr(out_rowptr), ptr(ws), ws.numel(), stream_of(w)))
+  nnz = int(out_rowptr[-1].item())
+  out_ei = torch.empty(2, nnz, dtype=torch.int64, device=dev)
+  out_w = torch.empty(nnz, dtype=torch.float32, device=dev)
+  if nnz > 0:
+    check(L.gnpde_two_hop_fill(ptr(rowptr), ptr(col), ptr(w_csr), graph.n, ptr(out_rowptr), ptr(out_ei), nnz, ptr(out_w),
+                               ptr(ws), ws.numel(), stream_of(w)))
+  return out_ei, out_w
+
+
 def edge_attention_bwd_heads(graph, att, datt_edge, post=0):
   """ds [E,h] (CSR order) from a per-head gradient in edge order (gnpde_edge_attention_bwd_heads); post: 0 raw-score gradient,
   1 times the score (exp kernels), 2 times LeakyReLU' (GAT)."""

@@ -446,6 +446,20 @@ int gnpde_threshold_edges(const int64_t* edge_index, const float* score, int64_t
                           int32_t norm_idx, int32_t n_nodes, int64_t* out_edge_index, float* out_weight, int64_t* out_count,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two-hop densification of the rewiring block (new_edges = 'k_hop_att', reference src/block_transformer_rewiring.py:68-86):
+ *   S = coalesce(A ++ offdiag(A A)) / 2, i.e. torch_sparse.spspmm(A, A) -> remove_self_loops -> cat with A -> / 2 ->
+ *   torch_sparse.coalesce(op='add'), in one row-wise kernel without materialising the products.  A is given in CSR (rowptr [n+1],
+ *   col, w in CSR order; duplicates allowed and summed).  Two phases, as the output size is data dependent:
+ *   gnpde_two_hop_count -> out_rowptr [n+1] (device int64; out_rowptr[n] = nnz(S)); the caller reads the total and allocates
+ *   gnpde_two_hop_fill  -> out_edge_index ([2, out_ld] int64, row-major, first nnz columns written) and out_weight, entries ordered
+ *                          by (row, col) as coalesce orders them.  Sums are formed in CSR order: run-to-run identical. */
+size_t gnpde_two_hop_workspace_bytes(int32_t n_nodes);
+int gnpde_two_hop_count(const int32_t* rowptr, const int32_t* col, int32_t n_nodes, int64_t* out_rowptr, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int gnpde_two_hop_fill(const int32_t* rowptr, const int32_t* col, const float* w, int32_t n_nodes, const int64_t* out_rowptr,
+                       int64_t* out_edge_index, int64_t out_ld, float* out_weight, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-partitioned solve over the GPUs of one node: one process per GPU, RCCL point-to-point halo exchange once per
  * evaluation of f, the whole solve (pack, grouped send/recv on a second stream, interior rows, boundary rows, every

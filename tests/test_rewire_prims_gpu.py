@@ -67,3 +67,58 @@ def test_threshold_from_quantile_keeps_the_requested_share(dev):
   kept, w = ops.threshold_edges(ei, score, thr, 0, 1000)
   assert abs(kept.shape[1] / E - 0.81) < 1e-3
   assert kept.shape[1] == int((score > torch.quantile(score, 1 - 0.81)).sum())
+
+
+def _two_hop_reference(ei, w, n):
+  """The reference's op sequence (block_transformer_rewiring.py:68-86) with dense float64 algebra: spspmm -> remove self
+  loops -> cat with A -> / 2 -> coalesce; structure from an integer product so zero-valued entries stay."""
+  A = torch.zeros(n, n, dtype=torch.float64)
+  A.index_put_((ei[0], ei[1]), w.double(), accumulate=True)
+  P = torch.zeros(n, n, dtype=torch.float64)
+  P.index_put_((ei[0], ei[1]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
+  A2, P2 = A @ A, P @ P
+  A2.fill_diagonal_(0)
+  P2.fill_diagonal_(0)
+  S, pattern = (A + A2) / 2, (P + P2) > 0
+  idx = pattern.nonzero().t()          # row-major = (row, col) order
+  return idx, S[idx[0], idx[1]]
+
+
+@pytest.mark.parametrize('n,deg,hub', [(1, 1, 0), (7, 2, 0), (300, 4, 150), (2049, 6, 900), (5000, 3, 0)])
+def test_two_hop_matches_reference_sequence(dev, n, deg, hub):
+  g = torch.Generator().manual_seed(n + deg)
+  e = n * deg
+  ei = torch.randint(0, n, (2, e), generator=g)
+  if hub:                                                    # a hub row and a hub column, duplicates, self loops
+    extra = torch.randint(0, n, (hub,), generator=g)
+    ei = torch.cat([ei, torch.stack([torch.zeros(hub, dtype=torch.long), extra]),
+                    torch.stack([extra, torch.full((hub,), 3)]), ei[:, :5], torch.tensor([[2, 5], [2, 5]])], dim=1)
+  w = torch.rand(ei.shape[1], generator=g)
+  w[::17] = 0.0                                              # explicit zeros keep their entry
+  from gnpde_amd.graph import CSRGraph
+  graph = CSRGraph(ei.to(dev), n)
+  got_ei, got_w = ops.two_hop(graph, w.to(dev))
+  ref_ei, ref_w = _two_hop_reference(ei, w, n)
+  assert got_ei.dtype == torch.int64 and got_ei.shape == ref_ei.shape, (got_ei.shape, ref_ei.shape)
+  assert torch.equal(got_ei.cpu(), ref_ei)                   # same entries in coalesce's (row, col) order
+  assert torch.allclose(got_w.cpu().double(), ref_w, rtol=2e-6, atol=1e-7)
+  again_ei, again_w = ops.two_hop(graph, w.to(dev))
+  assert torch.equal(again_ei, got_ei) and torch.equal(again_w, got_w), 'not run-to-run identical'
+
+
+def test_two_hop_agrees_with_the_expanded_list_path(dev):
+  """At a size the dense check cannot reach: against the block's torch composite (expand every product, sort, index_add)."""
+  import importlib
+  B = importlib.import_module('gnpde_amd.block_transformer_rewiring')
+  from gnpde_amd import synthetic
+  from gnpde_amd.graph import CSRGraph
+  n = 40_000
+  ei = synthetic.powerlaw_graph(n, 4 * n, seed=5, hub_degree=3000).to(dev)    # symmetric, skewed degrees, shuffled ids
+  w = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(6)).to(dev)
+  got_ei, got_w = ops.two_hop(CSRGraph(ei, n), w)
+  new_ei, new_w = B._spspmm(ei, w, ei, w, n)
+  keep = new_ei[0] != new_ei[1]
+  ref_ei, ref_w = B._coalesce(torch.cat([ei, new_ei[:, keep]], dim=1), torch.cat([w, new_w[keep]]) / 2, n)
+  assert torch.equal(got_ei, ref_ei)
+  assert torch.allclose(got_w, ref_w, rtol=1e-5, atol=1e-7)
+  assert got_ei.shape[1] > 20 * ei.shape[1]                  # a real densification
