@@ -43,7 +43,8 @@ class EpilogueStruct(ctypes.Structure):
   _fields_ = [('alpha', c_vp), ('beta', c_vp), ('x0', c_vp),
               ('alpha_sigmoid', ctypes.c_int32), ('stage', ctypes.c_int32), ('dt', ctypes.c_float),
               ('y', c_vp), ('k1', c_vp), ('k2', c_vp), ('k3', c_vp), ('out_k', c_vp), ('out_y', c_vp),
-              ('n_prev', ctypes.c_int32), ('pad_', ctypes.c_int32), ('prev', c_vp * 7), ('coef', ctypes.c_float * 8)]
+              ('n_prev', ctypes.c_int32), ('pad_', ctypes.c_int32), ('prev', c_vp * 7), ('coef', ctypes.c_float * 8),
+              ('coef_scale', c_vp)]
 
 
 class AttentionStruct(ctypes.Structure):
@@ -138,6 +139,12 @@ PROTOTYPES = {
                                        ctypes.c_int32, c_vp]),
   'gnpde_quantile_workspace_bytes': (ctypes.c_size_t, []),
   'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_dopri5_workspace_bytes': (ctypes.c_size_t, [c_vp]),
+  'gnpde_dopri5_create': (ctypes.c_int, [c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t]),
+  'gnpde_dopri5_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, c_vp, ctypes.c_int32,
+                                      ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_two_hop_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32]),
   'gnpde_two_hop_count': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_two_hop_fill': (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp,

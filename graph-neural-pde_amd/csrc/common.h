@@ -121,4 +121,15 @@ int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, 
                             int trace_capacity, hipStream_t st);
 int check_decoder(const gnpde_decoder_t* dec, int d_state);
 
+// Stage algebra and error norm of the adaptive solver with the step size optionally read from DEVICE memory when the kernel runs
+// (misc.hip): *scale multiplies every coefficient (NULL = the plain C entry points).  partial_blocks != NULL: only the block
+// partial sums are formed (workspace[0 .. *partial_blocks)), the caller folds them.
+int launch_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
+                   hipStream_t s, const float* scale);
+int launch_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k, float atol,
+                          float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace, hipStream_t s,
+                          const float* scale, int* partial_blocks);
+int launch_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h, float x,
+                         int64_t n, int32_t d, int32_t ld, float* out, hipStream_t stream);
+
 }  // namespace gnpde

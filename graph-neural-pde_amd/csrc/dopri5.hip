@@ -1,0 +1,466 @@
+// dopri5 with the step-size controller on the device (see gnpde.h, gnpde_dopri5_*): torchdiffeq 0.2.1's
+// RKAdaptiveStepsizeODESolver / Dopri5Solver as the reference reaches it with its default opt['method'] = 'dopri5'
+// (src/block_constant.py:57-62, src/block_transformer_attention.py:58-63; re-stated in src/early_stop_solver.py:30-128).
+//
+// torchdiffeq runs the accept / reject decision and the step-size update in Python: one device->host read of the error ratio and
+// ~40 eager launches per trial step.  Here ONE trial step is ONE hipGraph of 6 evaluations of f + 3 small kernels, which take
+// everything that depends on the step size from a 64-byte controller record in device memory:
+//     5 x f         k_i = f(u_i), the epilogue forms u_{i+1} = y + sum_j (b_ij h) k_j      (u_6 = y1; coef_scale -> h)
+//     f             k6 = f(y1)                                                              (first-same-as-last)
+//     error norm    block partial sums of ((sum_j e_j h k_j) / (atol + rtol max(|y|, |y1|)))^2
+//     control       fold -> ratio; accept = ratio <= 1; t += dt; end point reached -> interpolation fraction, done;
+//                   dt *= factor (float64); h' = fl32(dt) for the next trial step
+//     finish        (end point in this step) y_out = quartic through y, y1, y_mid, k0, k6 at t1;
+//                   u_1 = y' + (b10 h') k0' of the NEXT trial step, (y', k0') = (y1, k6) if accepted else (y, k0)
+// The graph exists in two parities that the host launches in turn: h and h' alternate between two slots of the record, and so
+// do the roles of the buffer pairs (y, y1) and (k0, k6) -- an accepted step hands its y1 / k6 to the next trial step as y / k0
+// without a copy; only a REJECTED step copies y and k0 across (finish kernel), which is the rare case.
+// The host queues as many trial steps as cannot overshoot the end point even if every one of them were accepted with the
+// largest growth the controller allows (factor 10), then reads the record once: no trial step is ever wasted, and a solve
+// of N trial steps synchronises O(log N) + (number near the end point) times instead of N.
+#include <cmath>
+#include <vector>
+#include "common.h"
+#include "rhs.h"
+
+namespace gnpde {
+namespace {
+
+// Dormand-Prince 5(4) as torchdiffeq 0.2.1 writes it (dopri5.py): stage weights, error weights (5th - 4th order solution,
+// Shampine's variant), mid-point weights of the quartic interpolant
+const double kB[6][6] = {
+  {1.0 / 5, 0, 0, 0, 0, 0},
+  {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+  {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+  {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+  {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+  {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+const double kE[7] = {35.0 / 384 - 1951.0 / 21600, 0.0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                      -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+const double kMid[7] = {6025192743.0 / 30085553152.0 / 2, 0.0, 51252292925.0 / 65400821598.0 / 2,
+                        -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                        -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+
+struct Ctl {            // the controller record (device; copied to the host once per batch of trial steps)
+  double t, dt, t1;
+  float h[2];           // fl32(dt) of the trial step in flight (slot = parity of the trial) and of the next one
+  float ratio;
+  float x;              // interpolation fraction (t1 - t) / dt of the step that contains the end point
+  int accept, interp, done;
+  int trials, accepted, rejected;
+};
+static_assert(sizeof(Ctl) == 64, "controller record");
+
+// fold of the error partial sums (as rk_error_final_kernel of misc.hip) + torchdiffeq rk_common.py _adaptive_step /
+// _optimal_step_size: safety 0.9, ifactor 10, dfactor 0.2, order 5
+__global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict__ ws, int nblocks, double count, Ctl* c,
+                                                        int parity) {
+  __shared__ double red[kBlock];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += static_cast<double>(ws[i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float ratio32 = static_cast<float>(sqrt(red[0] / count));
+  c->ratio = ratio32;
+  if (c->done) {                      // replayed past the end point (never queued by gnpde_dopri5_run): change nothing
+    c->accept = 0;
+    c->interp = 0;
+    c->h[1 - parity] = c->h[parity];
+    return;
+  }
+  const double ratio = static_cast<double>(ratio32);
+  const double dt = c->dt;
+  c->trials += 1;
+  int accept = 0, interp = 0;
+  if (ratio <= 1.0) {
+    const double t_next = c->t + dt;
+    if (t_next >= c->t1) {
+      c->x = static_cast<float>((c->t1 - c->t) / (t_next - c->t));
+      interp = 1;
+      c->done = 1;
+    }
+    c->t = t_next;
+    accept = 1;
+    c->accepted += 1;
+  } else {
+    c->rejected += 1;
+  }
+  double factor;
+  if (ratio == 0.0) {
+    factor = 10.0;
+  } else {
+    const double lo = ratio < 1.0 ? 1.0 : 0.2;
+    factor = fmin(10.0, fmax(0.9 / pow(ratio, 0.2), lo));
+  }
+  c->dt = dt * factor;
+  c->h[1 - parity] = static_cast<float>(c->dt);
+  c->accept = accept;
+  c->interp = interp;
+}
+
+// dst[r, 0:d] = src[r, 0:d] between two row strides (state in / result out; a pitched hipMemcpy2D is far slower)
+__global__ __launch_bounds__(kBlock) void copy_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                          int ld_dst, long long n, int d) {
+  const long long total = n * d;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long r = i / d;
+    const int c = static_cast<int>(i - r * d);
+    dst[static_cast<size_t>(r) * ld_dst + c] = src[static_cast<size_t>(r) * ld_src + c];
+  }
+}
+
+struct FinishArgs {
+  const float* y; float* y1;      // the next trial step reads its y from the y1 buffer and its k0 from the k6 buffer:
+  float* k[7];                    // written here only when this step was rejected
+  float* yout; float* u1;
+  float mid[7];                   // fl32(c_mid_j)
+  float b10;
+  long long n;
+  int d, ld;
+  const Ctl* c;
+  int parity;
+};
+
+// torchdiffeq's quartic end-point interpolation (_interp_fit + _interp_evaluate, as dopri5_interp_kernel of misc.hip), the commit
+// of an accepted step and the first stage input of the next trial step, one pass over the state
+__global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
+  const int accept = a.c->accept, interp = a.c->interp;
+  const float h = a.c->h[a.parity], hn = a.c->h[1 - a.parity], x = a.c->x;
+  const float cn = a.b10 * hn;
+  // flat over the padded storage (ld % 4 == 0, buffers 256-byte aligned; the padding columns hold zeros and stay zero)
+  const long long total4 = a.n * a.ld / 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total4;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const f4 ya = reinterpret_cast<const f4*>(a.y)[i], yb = reinterpret_cast<const f4*>(a.y1)[i];
+    const f4 fa = reinterpret_cast<const f4*>(a.k[0])[i], fb = reinterpret_cast<const f4*>(a.k[6])[i];
+    if (interp) {
+      f4 ym = ya;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const float m = a.mid[j] * h;
+        if (m != 0.0f) ym += reinterpret_cast<const f4*>(a.k[j])[i] * m;
+      }
+      const f4 ca = 2.0f * h * (fb - fa) - 8.0f * (yb + ya) + 16.0f * ym;
+      const f4 cb = h * (5.0f * fa - 3.0f * fb) + 18.0f * ya + 14.0f * yb - 32.0f * ym;
+      const f4 cc = h * (fb - 4.0f * fa) - 11.0f * ya - 5.0f * yb + 16.0f * ym;
+      const f4 cd = h * fa;
+      f4 tot = ya + x * cd;
+      float xp = x * x;
+      tot += xp * cc;
+      xp *= x;
+      tot += xp * cb;
+      xp *= x;
+      tot += xp * ca;
+      reinterpret_cast<f4*>(a.yout)[i] = tot;
+    }
+    const f4 yn = accept ? yb : ya, fn = accept ? fb : fa;
+    if (!accept) {
+      reinterpret_cast<f4*>(a.y1)[i] = yn;
+      reinterpret_cast<f4*>(a.k[6])[i] = fn;
+    }
+    f4 u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) u[t] = fmaf(cn, fn[t], yn[t]);
+    reinterpret_cast<f4*>(a.u1)[i] = u;
+  }
+}
+
+}  // namespace
+}  // namespace gnpde
+
+using namespace gnpde;
+
+struct gnpde_dopri5 {
+  gnpde_rhs_t rhs;
+  gnpde_graph_t graph;
+  RhsLayout L;
+  float rtol, atol;
+  char* ws;
+  size_t ws_bytes;
+  size_t state_bytes;     // one [n, ld] buffer, rounded up to 256 bytes
+  size_t off_ctl, off_err, off_rhs, off_state;
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph_obj[2] = {nullptr, nullptr};    // the trial step in its two parities (which slot of Ctl::h it reads)
+  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  bool padding_cleared = false;
+  Ctl* host_ctl = nullptr;   // pinned
+  int n_evals = 0, n_accepted = 0, n_rejected = 0, n_launches = 0, n_syncs = 0;
+  // buffers inside the workspace
+  float* Y[2];  float* KA[2];  float* km[5];  float* u[2];  float* yout;   // (y, y1) and (k0, k6) swap roles with the parity
+  Ctl* ctl;  float* err_ws;  float* scalar;
+};
+
+namespace {
+
+size_t dopri5_layout(const gnpde_rhs_t& r, gnpde_dopri5* s) {
+  const size_t state = align_up(static_cast<size_t>(r.graph->n) * r.ld * 4, 256);
+  size_t off = 0;
+  const size_t off_ctl = off;   off += 256;                 // Ctl + one scalar for the initial-step norms
+  const size_t off_err = off;   off += 4096 * 4;
+  const RhsLayout L = rhs_layout(r);
+  const size_t off_rhs = off;   off += align_up(L.total, 256);
+  const size_t off_state = off; off += 12 * state;
+  if (s) {
+    s->state_bytes = state;
+    s->off_ctl = off_ctl; s->off_err = off_err; s->off_rhs = off_rhs; s->off_state = off_state;
+  }
+  return off;
+}
+
+int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
+  const gnpde_rhs_t& r = s->rhs;
+  const long long n = r.graph->n;
+  char* rws = s->ws + s->off_rhs;
+  const float* h = &s->ctl->h[parity];
+  float* y = s->Y[parity];
+  float* y1 = s->Y[1 - parity];
+  float* k[7] = {s->KA[parity], s->km[0], s->km[1], s->km[2], s->km[3], s->km[4], s->KA[1 - parity]};
+  for (int i = 1; i < 6; ++i) {       // (u[0] = y + (b10 h) k0 was written by the previous trial step's finish kernel)
+    gnpde_epilogue_t e = base_epilogue(r);
+    e.stage = GNPDE_STAGE_LINCOMB;
+    e.y = y;
+    e.out_k = k[i];
+    e.out_y = i == 5 ? y1 : s->u[i % 2];
+    e.n_prev = i;
+    for (int j = 0; j < i; ++j) e.prev[j] = k[j];
+    for (int j = 0; j <= i; ++j) e.coef[j] = static_cast<float>(kB[i][j]);
+    e.coef_scale = h;
+    if (int rc = enqueue_rhs(r, s->u[(i - 1) % 2], e, rws, s->L, st)) return rc;
+  }
+  {
+    gnpde_epilogue_t e = base_epilogue(r);
+    e.stage = GNPDE_STAGE_RHS;
+    e.out_k = k[6];
+    if (int rc = enqueue_rhs(r, y1, e, rws, s->L, st)) return rc;
+  }
+  float ce[7];
+  for (int j = 0; j < 7; ++j) ce[j] = static_cast<float>(kE[j]);
+  int nblocks = 0;
+  if (int rc = launch_rk_error_ratio(y, y1, k, ce, 7, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
+    return rc;
+  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, s->err_ws, nblocks, static_cast<double>(n) * r.d, s->ctl, parity);
+  GNPDE_LAUNCH_CHECK();
+  FinishArgs fa{};
+  fa.y = y; fa.y1 = y1; fa.yout = s->yout; fa.u1 = s->u[0];
+  for (int j = 0; j < 7; ++j) {
+    fa.k[j] = k[j];
+    fa.mid[j] = static_cast<float>(kMid[j]);
+  }
+  fa.b10 = static_cast<float>(kB[0][0]);
+  fa.n = n; fa.d = r.d; fa.ld = r.ld; fa.c = s->ctl; fa.parity = parity;
+  long long blocks = (n * r.ld / 4 + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, fa);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+// rms(sum_j c_j v_j / (atol + rtol |y|)) read back to the host (initial step only)
+int scaled_rms(gnpde_dopri5* s, const float* const* v, const float* c, int n_v, hipStream_t st, double* out) {
+  const gnpde_rhs_t& r = s->rhs;
+  if (int rc = launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, r.graph->n, r.d, r.ld, s->scalar, s->err_ws, st,
+                                     nullptr, nullptr))
+    return rc;
+  float host = 0.f;
+  GNPDE_HIP(hipMemcpyAsync(&host, s->scalar, 4, hipMemcpyDeviceToHost, st));
+  GNPDE_HIP(hipStreamSynchronize(st));
+  s->n_syncs += 1;
+  *out = static_cast<double>(host);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t gnpde_dopri5_workspace_bytes(const gnpde_rhs_t* rhs) {
+  if (check_rhs(rhs)) return 0;
+  return dopri5_layout(*rhs, nullptr);
+}
+
+extern "C" int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs, float rtol, float atol, void* workspace,
+                                   size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "dopri5_create: out is null");
+  *out = nullptr;
+  if (int rc = check_rhs(rhs)) return rc;
+  GNPDE_CHECK_ARG(rtol >= 0.f && atol >= 0.f && rtol + atol > 0.f, GNPDE_EINVAL, "dopri5_create: bad tolerances");
+  GNPDE_CHECK_ARG(rhs->ld % 4 == 0, GNPDE_ESHAPE, "dopri5_create: the state row stride must be a multiple of 4 (pad the rows)");
+  gnpde_dopri5* s = new gnpde_dopri5();
+  s->rhs = *rhs;
+  s->graph = *rhs->graph;
+  s->rhs.graph = &s->graph;
+  s->rtol = rtol;
+  s->atol = atol;
+  s->L = rhs_layout(s->rhs);
+  const size_t need = dopri5_layout(s->rhs, s);
+  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
+    set_error("dopri5_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+    delete s;
+    return GNPDE_EWS;
+  }
+  s->ws = static_cast<char*>(workspace);
+  s->ws_bytes = workspace_bytes;
+  s->ctl = reinterpret_cast<Ctl*>(s->ws + s->off_ctl);
+  s->scalar = reinterpret_cast<float*>(s->ws + s->off_ctl + 128);
+  s->err_ws = reinterpret_cast<float*>(s->ws + s->off_err);
+  float* base = reinterpret_cast<float*>(s->ws + s->off_state);
+  const size_t stride = s->state_bytes / 4;
+  s->Y[0] = base; s->Y[1] = base + stride; s->u[0] = base + 2 * stride; s->u[1] = base + 3 * stride;
+  s->KA[0] = base + 4 * stride; s->KA[1] = base + 5 * stride;
+  for (int j = 0; j < 5; ++j) s->km[j] = base + (6 + j) * stride;
+  s->yout = base + 11 * stride;
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->host_ctl), sizeof(Ctl), hipHostMallocDefault) != hipSuccess) {
+    set_error("dopri5_create: pinned allocation failed");
+    delete s;
+    return GNPDE_EINVAL;
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y0, double t0, double t1, float* y_out,
+                                int32_t ld_out, int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream) {
+  GNPDE_CHECK_ARG(s && y0 && y_out, GNPDE_EINVAL, "dopri5_run: null argument");
+  const gnpde_rhs_t& r = s->rhs;
+  GNPDE_CHECK_ARG(ld_y0 >= r.d && ld_out >= r.d && t1 > t0, GNPDE_EINVAL, "dopri5_run: bad strides or time span");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (trials_per_sync < 1) trials_per_sync = 1;
+  const int n = r.graph->n;
+  s->n_evals = s->n_accepted = s->n_rejected = s->n_launches = s->n_syncs = 0;
+  if (finished) *finished = 0;
+  if (!s->padding_cleared) {   // once: the padding columns [d, ld) are never written with anything but what they hold
+    GNPDE_HIP(hipMemsetAsync(s->ws + s->off_state, 0, 12 * s->state_bytes, st));
+    s->padding_cleared = true;
+  }
+  long long copy_blocks = (static_cast<long long>(n) * r.d + kBlock - 1) / kBlock;
+  if (copy_blocks > 8192) copy_blocks = 8192;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, y0, ld_y0, s->Y[0], r.ld,
+                     static_cast<long long>(n), r.d);
+  GNPDE_LAUNCH_CHECK();
+  char* rws = s->ws + s->off_rhs;
+  auto feval = [&](const float* src, float* dst) -> int {
+    gnpde_epilogue_t e = base_epilogue(r);
+    e.stage = GNPDE_STAGE_RHS;
+    e.out_k = dst;
+    s->n_evals += 1;
+    return enqueue_rhs(r, src, e, rws, s->L, st);
+  };
+  if (int rc = feval(s->Y[0], s->KA[0])) return rc;
+  // initial step: torchdiffeq misc.py _select_initial_step (Hairer, Norsett & Wanner II.4), float32 arithmetic as there
+  const float one = 1.0f, minus = -1.0f;
+  double d0, d1, d2;
+  {
+    const float* v[1] = {s->Y[0]};
+    if (int rc = scaled_rms(s, v, &one, 1, st, &d0)) return rc;
+    const float* w[1] = {s->KA[0]};
+    if (int rc = scaled_rms(s, w, &one, 1, st, &d1)) return rc;
+  }
+  const float h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6f : 0.01f * static_cast<float>(d0) / static_cast<float>(d1);
+  {
+    const float* v[1] = {s->KA[0]};
+    const float c[1] = {h0};
+    if (int rc = launch_lincomb(s->Y[0], v, c, 1, static_cast<long long>(n) * r.ld, s->u[0], st, nullptr)) return rc;
+    if (int rc = feval(s->u[0], s->km[0])) return rc;
+    const float* w[2] = {s->km[0], s->KA[0]};
+    const float cw[2] = {one, minus};
+    if (int rc = scaled_rms(s, w, cw, 2, st, &d2)) return rc;
+    d2 /= static_cast<double>(h0);
+  }
+  double h1;
+  if (d1 <= 1e-15 && d2 <= 1e-15) {
+    h1 = std::fmax(1e-6, static_cast<double>(h0) * 1e-3);
+  } else {
+    const float big = static_cast<float>(std::fmax(d1, d2));
+    h1 = static_cast<double>(powf(0.01f / big, 1.0f / 5.0f));
+  }
+  Ctl init{};
+  init.t = t0;
+  init.t1 = t1;
+  init.dt = std::fmin(100.0 * static_cast<double>(h0), h1);
+  init.h[0] = static_cast<float>(init.dt);
+  *s->host_ctl = init;
+  GNPDE_HIP(hipMemcpyAsync(s->ctl, s->host_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
+  {   // first stage input of the first trial step (later ones come out of the finish kernel)
+    const float* v[1] = {s->KA[0]};
+    const float c[1] = {static_cast<float>(kB[0][0])};
+    if (int rc = launch_lincomb(s->Y[0], v, c, 1, static_cast<long long>(n) * r.ld, s->u[0], st, &s->ctl->h[0])) return rc;
+  }
+  GNPDE_HIP(hipStreamSynchronize(st));   // the pinned record is reused for the read-backs below
+  for (int parity = 0; parity < 2; ++parity) {
+    if (s->exec[parity] != nullptr) continue;
+    if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
+    GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_trial(s, parity, s->cap_stream);
+    hipGraph_t gobj = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
+    if (rc != 0) {
+      if (gobj) (void)hipGraphDestroy(gobj);
+      return rc;
+    }
+    if (ec != hipSuccess) {
+      set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+      return static_cast<int>(ec);
+    }
+    s->graph_obj[parity] = gobj;
+    GNPDE_HIP(hipGraphInstantiate(&s->exec[parity], gobj, nullptr, nullptr, 0));
+  }
+  const int base_evals = s->n_evals;
+  for (;;) {
+    // Queue as many trial steps as cannot pass t1 even if each were accepted with the controller's largest growth (x10):
+    // dt (10^m - 1) / 9 < t1 - t  =>  m steps cannot finish.  At most trials_per_sync, then one read of the record.
+    const Ctl& hc = *s->host_ctl;
+    int batch = 1;
+    double reach = hc.dt, step = hc.dt;
+    while (batch < trials_per_sync && hc.t + reach < hc.t1) {
+      step *= 10.0;
+      reach += step;
+      ++batch;
+    }
+    for (int b = 0; b < batch; ++b) GNPDE_HIP(hipGraphLaunch(s->exec[(s->n_launches + b) & 1], st));
+    s->n_launches += batch;
+    GNPDE_HIP(hipMemcpyAsync(s->host_ctl, s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+    GNPDE_HIP(hipStreamSynchronize(st));
+    s->n_syncs += 1;
+    s->n_evals = base_evals + 6 * hc.trials;
+    s->n_accepted = hc.accepted;
+    s->n_rejected = hc.rejected;
+    if (hc.done) break;
+    GNPDE_CHECK_ARG(hc.t + hc.dt > hc.t, GNPDE_EINVAL, "dopri5_run: underflow in dt %g at t %g", hc.dt, hc.t);
+    if (max_evals > 0 && s->n_evals > max_evals) return 0;   // *finished stays 0
+  }
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, s->yout, r.ld, y_out, ld_out,
+                     static_cast<long long>(n), r.d);
+  GNPDE_LAUNCH_CHECK();
+  GNPDE_HIP(hipStreamSynchronize(st));
+  if (finished) *finished = 1;
+  return 0;
+}
+
+extern "C" int gnpde_dopri5_stats(const gnpde_dopri5_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected,
+                                  int32_t* n_launches, int32_t* n_syncs) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "dopri5_stats: solver is null");
+  if (n_evals) *n_evals = s->n_evals;
+  if (n_accepted) *n_accepted = s->n_accepted;
+  if (n_rejected) *n_rejected = s->n_rejected;
+  if (n_launches) *n_launches = s->n_launches;
+  if (n_syncs) *n_syncs = s->n_syncs;
+  return 0;
+}
+
+extern "C" int gnpde_dopri5_destroy(gnpde_dopri5_t* s) {
+  if (!s) return 0;
+  for (int p = 0; p < 2; ++p) {
+    if (s->exec[p]) (void)hipGraphExecDestroy(s->exec[p]);
+    if (s->graph_obj[p]) (void)hipGraphDestroy(s->graph_obj[p]);
+  }
+  if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+  if (s->host_ctl) (void)hipHostFree(s->host_ctl);
+  delete s;
+  return 0;
+}

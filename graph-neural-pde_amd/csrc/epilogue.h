@@ -157,13 +157,16 @@ __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha
         ld(ep.y + off, y);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = 0.0f;
+        const float cs = ep.coef_scale != nullptr ? *ep.coef_scale : 1.0f;   // fl32(dt) kept on the device (gnpde_dopri5_*)
         for (int j = 0; j < ep.n_prev; ++j) {
           ld(ep.prev[j] + off, a);
+          const float cj = ep.coef[j] * cs;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) o[v] = fmaf(a[v], ep.coef[j], o[v]);
+          for (int v = 0; v < VEC; ++v) o[v] = fmaf(a[v], cj, o[v]);
         }
+        const float ck = ep.coef[ep.n_prev] * cs;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = y[v] + fmaf(k[v], ep.coef[ep.n_prev], o[v]);
+        for (int v = 0; v < VEC; ++v) o[v] = y[v] + fmaf(k[v], ck, o[v]);
         st(ep.out_y + off, o);
       }
       break;

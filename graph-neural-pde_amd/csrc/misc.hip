@@ -25,11 +25,16 @@ struct LinArgs {
   int n_v;
   long long n;
   float* out;
+  const float* scale;   // NULL or device scalar multiplied into every c[j] (fl32 product)
 };
 
 // out = base + sum_j c_j v_j over a flat array (stage algebra of host-driven Runge-Kutta loops in ONE pass)
 template <bool VEC4>
-__global__ __launch_bounds__(kBlock) void lincomb_kernel(const LinArgs a) {
+__global__ __launch_bounds__(kBlock) void lincomb_kernel(LinArgs a) {
+  if (a.scale != nullptr) {
+    const float s = *a.scale;
+    for (int j = 0; j < GNPDE_MAX_PREV; ++j) a.c[j] *= s;
+  }
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   if constexpr (VEC4) {
     const long long n4 = a.n / 4;
@@ -64,22 +69,57 @@ struct ErrArgs {
   float atol, rtol;
   long long n;
   int d, ld;
+  const float* scale;   // NULL or device scalar multiplied into every coef[j] (fl32 product)
 };
 
-// block partial sums of (err / tol)^2 in a fixed order -> ws[blockIdx]
-__global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(const ErrArgs a, float* __restrict__ ws) {
+// block partial sums of (err / tol)^2 in a fixed order -> ws[blockIdx].  VEC4: rows with a stride that is a multiple of 4
+// floats and 16-byte aligned operands are read as float4 (the padding columns [d, ld) are masked out).
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, float* __restrict__ ws) {
   __shared__ float red[kWavesPerBlock];
-  const long long total = a.n * a.d;
+  if (a.scale != nullptr) {
+    const float s = *a.scale;
+    for (int j = 0; j < GNPDE_MAX_PREV; ++j) a.coef[j] *= s;
+  }
   float acc = 0.f;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
-       i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const long long r = i / a.d;
-    const size_t off = static_cast<size_t>(r) * a.ld + static_cast<size_t>(i - r * a.d);
-    float err = 0.f;
-    for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j], err);
-    const float tol = a.atol + a.rtol * fmaxf(fabsf(a.y0[off]), fabsf(a.y1[off]));
-    const float q = err / tol;
-    acc = fmaf(q, q, acc);
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  if constexpr (VEC4) {
+    const int q = a.ld / 4;                       // float4 slots per row
+    const long long total = a.n * q;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const long long r = i / q;
+      const int c = static_cast<int>(i - r * q) * 4;
+      if (c >= a.d) continue;
+      float4 err = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < a.n_k; ++j) {
+        const float4 k = reinterpret_cast<const float4*>(a.k[j])[i];
+        err.x = fmaf(k.x, a.coef[j], err.x); err.y = fmaf(k.y, a.coef[j], err.y);
+        err.z = fmaf(k.z, a.coef[j], err.z); err.w = fmaf(k.w, a.coef[j], err.w);
+      }
+      const float4 u = reinterpret_cast<const float4*>(a.y0)[i];
+      const float4 v = reinterpret_cast<const float4*>(a.y1)[i];
+      const float e[4] = {err.x, err.y, err.z, err.w};
+      const float m[4] = {fmaxf(fabsf(u.x), fabsf(v.x)), fmaxf(fabsf(u.y), fabsf(v.y)), fmaxf(fabsf(u.z), fabsf(v.z)),
+                          fmaxf(fabsf(u.w), fabsf(v.w))};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c + t < a.d) {
+          const float qv = e[t] / (a.atol + a.rtol * m[t]);
+          acc = fmaf(qv, qv, acc);
+        }
+      }
+    }
+  } else {
+    const long long total = a.n * a.d;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const long long r = i / a.d;
+      const size_t off = static_cast<size_t>(r) * a.ld + static_cast<size_t>(i - r * a.d);
+      float err = 0.f;
+      for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j], err);
+      const float tol = a.atol + a.rtol * fmaxf(fabsf(a.y0[off]), fabsf(a.y1[off]));
+      const float qv = err / tol;
+      acc = fmaf(qv, qv, acc);
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
@@ -143,11 +183,9 @@ __global__ __launch_bounds__(kBlock) void dopri5_interp_kernel(const InterpArgs 
 }
 
 }  // namespace
-}  // namespace gnpde
 
-extern "C" int gnpde_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h,
-                                   float x, int64_t n, int32_t d, int32_t ld, float* out, void* stream) {
-  using namespace gnpde;
+int launch_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h, float x,
+                         int64_t n, int32_t d, int32_t ld, float* out, hipStream_t stream) {
   GNPDE_CHECK_ARG(y0 && y1 && k && mid_coef && out && n >= 1 && d >= 1 && ld >= d, GNPDE_EINVAL, "dopri5_interp: bad arguments");
   InterpArgs a{};
   a.y0 = y0; a.y1 = y1; a.h = h; a.x = x; a.n = n; a.d = d; a.ld = ld; a.out = out;
@@ -158,33 +196,55 @@ extern "C" int gnpde_dopri5_interp(const float* y0, const float* y1, const float
   }
   long long blocks = (n * d + kBlock - 1) / kBlock;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dopri5_interp_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(dopri5_interp_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a);
   GNPDE_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k, float atol,
+                          float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace, hipStream_t s,
+                          const float* scale, int* partial_blocks) {
+  GNPDE_CHECK_ARG(y0 && y1 && k && coef && (ratio || partial_blocks) && workspace && n_k >= 1 && n_k <= GNPDE_MAX_PREV && n >= 1 && d >= 1 && ld >= d,
+                  GNPDE_EINVAL, "rk_error_ratio: bad arguments");
+  ErrArgs a{};
+  a.y0 = y0; a.y1 = y1; a.atol = atol; a.rtol = rtol; a.n = n; a.d = d; a.ld = ld; a.scale = scale;
+  bool vec = ld % 4 == 0 && reinterpret_cast<uintptr_t>(y0) % 16 == 0 && reinterpret_cast<uintptr_t>(y1) % 16 == 0;
+  for (int j = 0; j < n_k; ++j) {
+    GNPDE_CHECK_ARG(k[j] != nullptr, GNPDE_EINVAL, "rk_error_ratio: k[%d] is null", j);
+    if (coef[j] == 0.0f) continue;              // (dopri5: the second stage has no weight in the error estimate)
+    a.k[a.n_k] = k[j];
+    a.coef[a.n_k] = coef[j];
+    a.n_k += 1;
+    vec = vec && reinterpret_cast<uintptr_t>(k[j]) % 16 == 0;
+  }
+  const long long items = vec ? n * (ld / 4) : n * d;
+  long long blocks = (items + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  if (vec) hipLaunchKernelGGL((rk_error_partial_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
+  else hipLaunchKernelGGL((rk_error_partial_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
+  GNPDE_LAUNCH_CHECK();
+  if (partial_blocks != nullptr) {   // the caller folds workspace[0 .. blocks) itself (sqrt(sum / (n d)))
+    *partial_blocks = static_cast<int>(blocks);
+    return 0;
+  }
+  hipLaunchKernelGGL(rk_error_final_kernel, dim3(1), dim3(kBlock), 0, s, workspace, static_cast<int>(blocks),
+                     static_cast<double>(n) * d, ratio);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gnpde
+
+extern "C" int gnpde_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* mid_coef, float h,
+                                   float x, int64_t n, int32_t d, int32_t ld, float* out, void* stream) {
+  return gnpde::launch_dopri5_interp(y0, y1, k, mid_coef, h, x, n, d, ld, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k,
                                     float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
                                     void* stream) {
-  using namespace gnpde;
-  GNPDE_CHECK_ARG(y0 && y1 && k && coef && ratio && workspace && n_k >= 1 && n_k <= GNPDE_MAX_PREV && n >= 1 && d >= 1 && ld >= d,
-                  GNPDE_EINVAL, "rk_error_ratio: bad arguments");
-  ErrArgs a{};
-  a.y0 = y0; a.y1 = y1; a.n_k = n_k; a.atol = atol; a.rtol = rtol; a.n = n; a.d = d; a.ld = ld;
-  for (int j = 0; j < n_k; ++j) {
-    GNPDE_CHECK_ARG(k[j] != nullptr, GNPDE_EINVAL, "rk_error_ratio: k[%d] is null", j);
-    a.k[j] = k[j];
-    a.coef[j] = coef[j];
-  }
-  long long blocks = (n * d + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(rk_error_partial_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
-  GNPDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rk_error_final_kernel, dim3(1), dim3(kBlock), 0, s, workspace, static_cast<int>(blocks),
-                     static_cast<double>(n) * d, ratio);
-  GNPDE_LAUNCH_CHECK();
-  return 0;
+  return gnpde::launch_rk_error_ratio(y0, y1, k, coef, n_k, atol, rtol, n, d, ld, ratio, workspace,
+                                      static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int32_t count, int32_t d,
@@ -198,14 +258,14 @@ extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t
   return 0;
 }
 
-extern "C" int gnpde_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
-                             void* stream) {
-  using namespace gnpde;
+namespace gnpde {
+int launch_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
+                   hipStream_t s, const float* scale) {
   GNPDE_CHECK_ARG(base && out && n >= 0 && n_v >= 0 && n_v <= GNPDE_MAX_PREV && (n_v == 0 || (v && coef)), GNPDE_EINVAL,
                   "lincomb: bad arguments");
   if (n == 0) return 0;
   LinArgs a;
-  a.base = base; a.n_v = n_v; a.n = n; a.out = out;
+  a.base = base; a.n_v = n_v; a.n = n; a.out = out; a.scale = scale;
   bool al = reinterpret_cast<uintptr_t>(base) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
   for (int j = 0; j < GNPDE_MAX_PREV; ++j) {
     a.v[j] = j < n_v ? v[j] : nullptr;
@@ -218,9 +278,14 @@ extern "C" int gnpde_lincomb(const float* base, const float* const* v, const flo
   long long blocks = (n / 4 + kBlock - 1) / kBlock;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (al) hipLaunchKernelGGL((lincomb_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((lincomb_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
   GNPDE_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace gnpde
+
+extern "C" int gnpde_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
+                             void* stream) {
+  return gnpde::launch_lincomb(base, v, coef, n_v, n, out, static_cast<hipStream_t>(stream), nullptr);
 }

@@ -330,6 +330,56 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   return out
 
 
+def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None):
+  """dopri5 with the controller on the device (csrc/dopri5.hip): a trial step is one hipGraph replay; accept / reject, the
+  step-size update, the end-point interpolation and the commit are decided by kernels from a record in device memory, which the
+  host reads once per `trials_per_sync` trial steps.  Same arithmetic as `_solve_dopri5_native` (which stays for callers that
+  hook into every step, e.g. the early-stopping integrator)."""
+  from . import ops
+  from .utils import MaxNFEException
+  room = func.opt['max_nfe'] + 1 - func.nfe          # evaluations the reference would still allow before it raises
+  if room <= 0:
+    raise MaxNFEException
+  st = func.__dict__.setdefault('_dopri5_device', {})
+  key = (tuple(y0.shape), str(y0.device), float(rtol), float(atol))
+  ent = st.get(key)
+  y0c = y0.detach()
+  if ent is None:
+    ent = {'y': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device),
+           'x0': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device) if func.opt['add_source'] else None,
+           'solver': None, 'sig': None}
+    for old in st.values():
+      if old['solver'] is not None:
+        old['solver'].close()
+    st.clear()   # one live solver per function object: its workspace is 12 state-sized buffers
+    st[key] = ent
+  if ent['x0'] is not None:
+    if func.x0 is None:
+      raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+    ent['x0'].copy_(func.x0)
+  desc = func._descriptor(ent['y'], x0_override=ent['x0'])     # (ent['y'] only fixes the row stride; the solver owns its buffers)
+  sig = func._descriptor_signature(desc)
+  if ent['solver'] is None or ent['sig'] != sig:
+    if ent['solver'] is not None:
+      ent['solver'].close()
+    ent['solver'] = ops.Dopri5Solver(desc, rtol, atol, y0.device)
+    ent['sig'] = sig
+  if trials_per_sync is None:
+    # launch-bound sizes: keep the queue full between reads; large states: a read per trial step costs nothing next to six
+    # evaluations and nothing is replayed past the end point
+    trials_per_sync = 8 if y0c.numel() < (1 << 22) else 1
+  out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+  out[0].copy_(y0c)
+  finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
+  spent = ent['solver'].stats()['evals']
+  func._dopri5_stats = ent['solver'].stats()
+  if not finished or spent > room:
+    func.nfe += min(spent, room)
+    raise MaxNFEException
+  func.nfe += spent
+  return out
+
+
 class _TupleFunc(object):
   """A function of a tuple state seen as a function of the flattened concatenation (torchdiffeq misc.py _TupleFunc):
   the regularised training state (x, r_1, ..., r_k) of reference src/block_constant.py:40-43."""
@@ -375,7 +425,9 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
     return _solve_fixed_host(func, y0, t, method, step_size)
   if method == 'dopri5':
     if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
-      return _solve_dopri5_native(func, y0, t, rtol, atol)
+      if options.get('eager_stages', False):      # controller on the host, one scalar read per trial step
+        return _solve_dopri5_native(func, y0, t, rtol, atol)
+      return _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=options.get('trials_per_sync'))
     return _solve_dopri5(func, y0, t, rtol, atol, norm=options.get('norm'))
   if method == 'adaptive_heun':
     return _solve_dopri5(func, y0, t, rtol, atol, tableau='adaptive_heun', norm=options.get('norm'))

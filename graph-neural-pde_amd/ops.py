@@ -366,6 +366,47 @@ def rhs_eval(desc, u, out=None):
   return out
 
 
+class Dopri5Solver(object):
+  """gnpde_dopri5_t: dopri5 with the step-size controller on the device; one trial step = one hipGraph replay, the host reads
+  the controller record once per `trials_per_sync` trial steps."""
+
+  def __init__(self, desc, rtol, atol, device):
+    self.desc = desc
+    L = _lib.lib()
+    nbytes = L.gnpde_dopri5_workspace_bytes(desc.ref())
+    self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    handle = ctypes.c_void_p()
+    check(L.gnpde_dopri5_create(ctypes.byref(handle), desc.ref(), float(rtol), float(atol), ptr(self.ws), self.ws.numel()))
+    self.handle = handle
+
+  def run(self, y0, t0, t1, out, trials_per_sync=1, max_evals=0):
+    """Integrate from y0 at t0 to t1 into `out`; False if it stopped because more than max_evals evaluations were spent."""
+    require_hip(y0, out)
+    y0, out_ = _lib.f32rows(y0, 'y0'), out
+    if out_.dtype != torch.float32 or out_.dim() != 2 or out_.stride(1) != 1 or out_.shape != y0.shape:
+      raise _lib.GnpdeError('dopri5 output must be float32 [n, d] with unit column stride')
+    fin = ctypes.c_int32(0)
+    check(_lib.lib().gnpde_dopri5_run(self.handle, ptr(y0), y0.stride(0), float(t0), float(t1), ptr(out_), out_.stride(0),
+                                      int(trials_per_sync), int(max_evals), ctypes.byref(fin), stream_of(y0)))
+    return bool(fin.value)
+
+  def stats(self):
+    v = [ctypes.c_int32(0) for _ in range(5)]
+    check(_lib.lib().gnpde_dopri5_stats(self.handle, *[ctypes.byref(x) for x in v]))
+    return dict(zip(('evals', 'accepted', 'rejected', 'launches', 'syncs'), [x.value for x in v]))
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      try:
+        _lib.lib().gnpde_dopri5_destroy(self.handle)
+      except Exception:
+        pass
+      self.handle = None
+
+  def __del__(self):
+    self.close()
+
+
 def rhs_stage(desc, u, stage, ws=None, **kw):
   """f(u) of a descriptor with an explicit stage epilogue (gnpde_rhs_stage); alpha / beta / x0 come from
   the descriptor."""
@@ -513,7 +554,7 @@ class FixedStepSolver(object):
         _lib.lib().gnpde_solver_destroy(self.handle)
       except Exception:
         pass
-      self.handle = ctypes.c_void_p()
+      self.handle = None
 
   def __del__(self):
     self.close()

@@ -133,7 +133,7 @@ typedef struct gnpde_graph {
  *   GNPDE_STAGE_LINCOMB  out_k = k (if non-NULL) ;
  *                        out_y = y + sum_{j < n_prev} coef[j] * prev[j] + coef[n_prev] * k   (if non-NULL)
  *                        with coef[j] = fl32(beta_j) * fl32(dt) prepared by the caller (torchdiffeq's
- *                        k.matmul(beta * dt) rounding).
+ *                        k.matmul(beta * dt) rounding), or coef[j] = fl32(beta_j) and coef_scale -> fl32(dt) on the device.
  * `u` is the stage input the operator is applied to, `y` the state at the start of the step.
  * ---------------------------------------------------------------------------------------------- */
 enum {
@@ -161,6 +161,9 @@ typedef struct gnpde_epilogue {
   int32_t pad_;
   const float* prev[GNPDE_MAX_PREV];   /* LINCOMB: [n, ld] each                             */
   float coef[GNPDE_MAX_PREV + 1];      /* LINCOMB: weights of prev[0..n_prev-1], then of k  */
+  const float* coef_scale; /* LINCOMB: NULL, or a DEVICE scalar every coef[] is multiplied by when the kernel runs
+                              (fl32 product): coef[] = fl32(beta_j), *coef_scale = fl32(dt) kept on the device by the
+                              adaptive controller (gnpde_dopri5_*), so that a captured step serves every step size */
 } gnpde_epilogue_t;
 
 /* Bytes of scratch gnpde_spmm_rhs needs for the long-row partial sums (0 if no long rows). */
@@ -421,6 +424,34 @@ int gnpde_lincomb(const float* base, const float* const* v, const float* coef, i
 
 int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s);
 int gnpde_solver_destroy(gnpde_solver_t* s);
+
+/* ------------------------------------------------------------------------------------------------
+ * dopri5 with the step-size controller ON THE DEVICE  [replaces torchdiffeq 0.2.1 Dopri5Solver / RKAdaptiveStepsizeODESolver as
+ * reached from ODEblock.forward with the reference's default opt['method'] = 'dopri5' (src/block_constant.py:57-62,
+ * src/block_transformer_attention.py:58-63; the loop the reference re-states in src/early_stop_solver.py:30-128)]
+ *
+ * One TRIAL step -- first stage input, five evaluations of f whose epilogues form the next stage input, f(y1) (first-same-
+ * as-last), the error ratio, the controller (accept / reject, step-size update in float64, end-point test), the quartic
+ * end-point interpolation and the commit of the accepted state -- is captured ONCE as a hipGraph: the step size, the time, the
+ * accept flag and the interpolation fraction live in device memory, the stage kernels read fl32(dt) through
+ * gnpde_epilogue_t.coef_scale, interpolation and commit are predicated on device flags.  gnpde_dopri5_run replays that graph
+ * `trials_per_sync` times between two reads of the controller state (one 64-byte copy), so the host neither launches kernels nor
+ * decides anything per step; trial steps replayed after the end point has been reached leave every result untouched (they are
+ * not counted).  Same rule as torchdiffeq: rms error norm, safety 0.9, factor limits 0.2 / 10, no shrinking after an accepted
+ * step, Shampine's error weights, initial step of Hairer's heuristic as torchdiffeq selects it.
+ *   y0 [n, ld_y0] in, y_out [n, ld_out] out (may alias y0); integrates from t0 to t1 > t0.
+ *   max_evals > 0: stop launching once more evaluations than that were spent (reference opt['max_nfe']); *finished tells.
+ * Synchronises the stream. */
+typedef struct gnpde_dopri5 gnpde_dopri5_t;
+size_t gnpde_dopri5_workspace_bytes(const gnpde_rhs_t* rhs);
+int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs, float rtol, float atol, void* workspace,
+                        size_t workspace_bytes);
+int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y0, double t0, double t1, float* y_out, int32_t ld_out,
+                     int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream);
+/* of the last run: evaluations of f, accepted and rejected steps, graph launches, host synchronisations */
+int gnpde_dopri5_stats(const gnpde_dopri5_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected, int32_t* n_launches,
+                       int32_t* n_syncs);
+int gnpde_dopri5_destroy(gnpde_dopri5_t* s);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU halo exchange helpers (row-partitioned graph, one process per GPU, RCCL between).

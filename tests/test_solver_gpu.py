@@ -281,6 +281,58 @@ def test_native_dopri5_matches_host_controller(dev, function):
   assert_parity(z_native, z_host, tol=2e-5, what='native vs host-controlled dopri5')
 
 
+@pytest.mark.parametrize('function,d', [('transformer', 64), ('laplacian', 64), ('GAT', 64), ('transformer', 81)])
+def test_device_controlled_dopri5(dev, function, d):
+  """dopri5 with accept / reject and the step-size update decided by kernels (gnpde_dopri5_*, one hipGraph replay per trial
+  step): same evaluations of f, same accepted and rejected steps and the same state as the path whose controller runs on the
+  host with one scalar read per trial step; the number of trial steps queued between two reads of the controller record does
+  not change a bit of the result, no trial step is replayed past the end point, and the host reads the record fewer times
+  than there are trial steps."""
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.05)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(21)).to(dev)
+  opt = dict(BASE, function=function, hidden_dim=d, method='dopri5', time=6.0, tol_scale=50.0)
+  block = _block(opt, ei.to(dev), n, x, dev)
+  f = block.odefunc
+  f.x0 = x
+  t = torch.tensor([0.0, 6.0], device=dev)
+  kw = dict(method='dopri5', atol=50.0 * 1e-7, rtol=50.0 * 1e-9)
+  runs = {}
+  with torch.no_grad():
+    for label, options in [('eager', {'eager_stages': True}), ('k1', {'trials_per_sync': 1}), ('k3', {'trials_per_sync': 3}),
+                           ('k8', {'trials_per_sync': 8}), ('k8 again', {'trials_per_sync': 8})]:
+      f.nfe = 0
+      z = G.odeint(f, x, t, options=options, **kw)[1]
+      runs[label] = (z.clone(), f.nfe, dict(getattr(f, '_dopri5_stats', {})))
+  z_eager, nfe_eager, _ = runs['eager']
+  assert nfe_eager >= 14
+  for label in ('k1', 'k3', 'k8', 'k8 again'):
+    z, nfe, stats = runs[label]
+    assert nfe == nfe_eager, (label, nfe, nfe_eager)
+    assert stats['evals'] == nfe and 6 * (stats['accepted'] + stats['rejected']) + 2 == nfe
+    assert_parity(z, z_eager, tol=2e-6, what='device vs host controller (%s)' % label)
+    assert torch.equal(z, runs['k1'][0]), 'the batch size changed the result (%s)' % label
+  trials = (nfe_eager - 2) // 6
+  assert runs['k1'][2]['syncs'] == 3 + trials                       # initial-step norms + one read per trial step
+  assert runs['k8'][2]['syncs'] < runs['k1'][2]['syncs']
+  for label in ('k1', 'k3', 'k8'):                                  # no trial step is queued that cannot be needed
+    assert runs[label][2]['launches'] == trials, (label, runs[label][2], trials)
+
+
+def test_device_controlled_dopri5_max_nfe(dev):
+  """opt['max_nfe'] with the device controller: MaxNFEException once the budget is spent, nfe past it as in the reference."""
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.02)
+  x = torch.randn(n, 32, generator=torch.Generator().manual_seed(2)).to(dev)
+  opt = dict(BASE, function='laplacian', hidden_dim=32, method='dopri5', time=50.0, tol_scale=1.0, max_nfe=20)
+  block = _block(opt, ei.to(dev), n, x, dev)
+  f = block.odefunc
+  f.x0 = x
+  with torch.no_grad(), pytest.raises(G.MaxNFEException):
+    G.odeint(f, x, torch.tensor([0.0, 50.0], device=dev), method='dopri5', atol=1e-7, rtol=1e-9, options={'trials_per_sync': 2})
+  assert f.nfe == 21
+  with torch.no_grad(), pytest.raises(G.MaxNFEException):
+    f(0.0, x)
+
+
 def test_blend_arxiv_config_c4(dev):
   """BASELINE configs[3] shape: ogbn-arxiv best_params -- hard_attention block (eval mode: all edges, head-mean
   attention computed once), Laplacian function, dopri5 with tol_scale 11353, T = 3.676, d = 162 = 64 + 98
