@@ -103,6 +103,39 @@ __global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict
   c->interp = interp;
 }
 
+// Initial step size, torchdiffeq misc.py _select_initial_step (Hairer, Norsett & Wanner II.4) with its float32 / float64 mix:
+//   d0 = rms(y / tol), d1 = rms(f0 / tol), h0 = 0.01 d0 / d1 (1e-6 if either is tiny), d2 = rms((f(y + h0 f0) - f0) / tol) / h0,
+//   h1 = (0.01 / max(d1, d2))^(1/5), dt = min(100 h0, h1).  The three norms land in `Init` straight from the error-norm kernels.
+struct Init {
+  float d0, d1, d2, h0;
+};
+
+__global__ void init_h0_kernel(Init* q) {
+  const double d0 = static_cast<double>(q->d0), d1 = static_cast<double>(q->d1);
+  q->h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6f : 0.01f * q->d0 / q->d1;
+}
+
+__global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1) {
+  const double h0 = static_cast<double>(q->h0), d1 = static_cast<double>(q->d1);
+  const double d2 = static_cast<double>(q->d2) / h0;
+  double h1;
+  if (d1 <= 1e-15 && d2 <= 1e-15) {
+    h1 = fmax(1e-6, h0 * 1e-3);
+  } else {
+    const float big = static_cast<float>(fmax(d1, d2));
+    h1 = static_cast<double>(static_cast<float>(pow(static_cast<double>(0.01f / big), static_cast<double>(1.0f / 5.0f))));
+  }
+  c->t = t0;
+  c->t1 = t1;
+  c->dt = fmin(100.0 * h0, h1);
+  c->h[0] = static_cast<float>(c->dt);
+  c->h[1] = 0.f;
+  c->ratio = 0.f;
+  c->x = 0.f;
+  c->accept = c->interp = c->done = 0;
+  c->trials = c->accepted = c->rejected = 0;
+}
+
 // dst[r, 0:d] = src[r, 0:d] between two row strides (state in / result out; a pitched hipMemcpy2D is far slower)
 __global__ __launch_bounds__(kBlock) void copy_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
                                                           int ld_dst, long long n, int d) {
@@ -194,7 +227,7 @@ struct gnpde_dopri5 {
   int n_evals = 0, n_accepted = 0, n_rejected = 0, n_launches = 0, n_syncs = 0;
   // buffers inside the workspace
   float* Y[2];  float* KA[2];  float* km[5];  float* u[2];  float* yout;   // (y, y1) and (k0, k6) swap roles with the parity
-  Ctl* ctl;  float* err_ws;  float* scalar;
+  Ctl* ctl;  float* err_ws;  Init* init;
 };
 
 namespace {
@@ -263,18 +296,11 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   return 0;
 }
 
-// rms(sum_j c_j v_j / (atol + rtol |y|)) read back to the host (initial step only)
-int scaled_rms(gnpde_dopri5* s, const float* const* v, const float* c, int n_v, hipStream_t st, double* out) {
+// rms(sum_j c_j v_j / (atol + rtol |y|)) -> *out (device)
+int scaled_rms(gnpde_dopri5* s, const float* const* v, const float* c, int n_v, hipStream_t st, float* out) {
   const gnpde_rhs_t& r = s->rhs;
-  if (int rc = launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, r.graph->n, r.d, r.ld, s->scalar, s->err_ws, st,
-                                     nullptr, nullptr))
-    return rc;
-  float host = 0.f;
-  GNPDE_HIP(hipMemcpyAsync(&host, s->scalar, 4, hipMemcpyDeviceToHost, st));
-  GNPDE_HIP(hipStreamSynchronize(st));
-  s->n_syncs += 1;
-  *out = static_cast<double>(host);
-  return 0;
+  return launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, r.graph->n, r.d, r.ld, out, s->err_ws, st, nullptr,
+                               nullptr);
 }
 
 }  // namespace
@@ -307,7 +333,7 @@ extern "C" int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs,
   s->ws = static_cast<char*>(workspace);
   s->ws_bytes = workspace_bytes;
   s->ctl = reinterpret_cast<Ctl*>(s->ws + s->off_ctl);
-  s->scalar = reinterpret_cast<float*>(s->ws + s->off_ctl + 128);
+  s->init = reinterpret_cast<Init*>(s->ws + s->off_ctl + 128);
   s->err_ws = reinterpret_cast<float*>(s->ws + s->off_err);
   float* base = reinterpret_cast<float*>(s->ws + s->off_state);
   const size_t stride = s->state_bytes / 4;
@@ -352,46 +378,27 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     return enqueue_rhs(r, src, e, rws, s->L, st);
   };
   if (int rc = feval(s->Y[0], s->KA[0])) return rc;
-  // initial step: torchdiffeq misc.py _select_initial_step (Hairer, Norsett & Wanner II.4), float32 arithmetic as there
+  // initial step size, entirely on the device (no read-back): see init_h0_kernel / init_dt_kernel
   const float one = 1.0f, minus = -1.0f;
-  double d0, d1, d2;
+  const long long flat = static_cast<long long>(n) * r.ld;
   {
     const float* v[1] = {s->Y[0]};
-    if (int rc = scaled_rms(s, v, &one, 1, st, &d0)) return rc;
+    if (int rc = scaled_rms(s, v, &one, 1, st, &s->init->d0)) return rc;
     const float* w[1] = {s->KA[0]};
-    if (int rc = scaled_rms(s, w, &one, 1, st, &d1)) return rc;
-  }
-  const float h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6f : 0.01f * static_cast<float>(d0) / static_cast<float>(d1);
-  {
-    const float* v[1] = {s->KA[0]};
-    const float c[1] = {h0};
-    if (int rc = launch_lincomb(s->Y[0], v, c, 1, static_cast<long long>(n) * r.ld, s->u[0], st, nullptr)) return rc;
+    if (int rc = scaled_rms(s, w, &one, 1, st, &s->init->d1)) return rc;
+    hipLaunchKernelGGL(init_h0_kernel, dim3(1), dim3(1), 0, st, s->init);
+    GNPDE_LAUNCH_CHECK();
+    if (int rc = launch_lincomb(s->Y[0], w, &one, 1, flat, s->u[0], st, &s->init->h0)) return rc;   // y + h0 f0
     if (int rc = feval(s->u[0], s->km[0])) return rc;
-    const float* w[2] = {s->km[0], s->KA[0]};
+    const float* dk[2] = {s->km[0], s->KA[0]};
     const float cw[2] = {one, minus};
-    if (int rc = scaled_rms(s, w, cw, 2, st, &d2)) return rc;
-    d2 /= static_cast<double>(h0);
-  }
-  double h1;
-  if (d1 <= 1e-15 && d2 <= 1e-15) {
-    h1 = std::fmax(1e-6, static_cast<double>(h0) * 1e-3);
-  } else {
-    const float big = static_cast<float>(std::fmax(d1, d2));
-    h1 = static_cast<double>(powf(0.01f / big, 1.0f / 5.0f));
-  }
-  Ctl init{};
-  init.t = t0;
-  init.t1 = t1;
-  init.dt = std::fmin(100.0 * static_cast<double>(h0), h1);
-  init.h[0] = static_cast<float>(init.dt);
-  *s->host_ctl = init;
-  GNPDE_HIP(hipMemcpyAsync(s->ctl, s->host_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
-  {   // first stage input of the first trial step (later ones come out of the finish kernel)
-    const float* v[1] = {s->KA[0]};
+    if (int rc = scaled_rms(s, dk, cw, 2, st, &s->init->d2)) return rc;
+    hipLaunchKernelGGL(init_dt_kernel, dim3(1), dim3(1), 0, st, s->init, s->ctl, t0, t1);
+    GNPDE_LAUNCH_CHECK();
+    // first stage input of the first trial step (later ones come out of the finish kernel)
     const float c[1] = {static_cast<float>(kB[0][0])};
-    if (int rc = launch_lincomb(s->Y[0], v, c, 1, static_cast<long long>(n) * r.ld, s->u[0], st, &s->ctl->h[0])) return rc;
+    if (int rc = launch_lincomb(s->Y[0], w, c, 1, flat, s->u[0], st, &s->ctl->h[0])) return rc;
   }
-  GNPDE_HIP(hipStreamSynchronize(st));   // the pinned record is reused for the read-backs below
   for (int parity = 0; parity < 2; ++parity) {
     if (s->exec[parity] != nullptr) continue;
     if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
@@ -411,13 +418,14 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     GNPDE_HIP(hipGraphInstantiate(&s->exec[parity], gobj, nullptr, nullptr, 0));
   }
   const int base_evals = s->n_evals;
+  bool have_record = false;   // nothing is known about dt on the host before the first read: one trial step, then look
   for (;;) {
     // Queue as many trial steps as cannot pass t1 even if each were accepted with the controller's largest growth (x10):
     // dt (10^m - 1) / 9 < t1 - t  =>  m steps cannot finish.  At most trials_per_sync, then one read of the record.
     const Ctl& hc = *s->host_ctl;
     int batch = 1;
     double reach = hc.dt, step = hc.dt;
-    while (batch < trials_per_sync && hc.t + reach < hc.t1) {
+    while (have_record && batch < trials_per_sync && hc.t + reach < hc.t1) {
       step *= 10.0;
       reach += step;
       ++batch;
@@ -427,6 +435,7 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     GNPDE_HIP(hipMemcpyAsync(s->host_ctl, s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     GNPDE_HIP(hipStreamSynchronize(st));
     s->n_syncs += 1;
+    have_record = true;
     s->n_evals = base_evals + 6 * hc.trials;
     s->n_accepted = hc.accepted;
     s->n_rejected = hc.rejected;
