@@ -326,12 +326,22 @@ class P2PContext(object):
     else:
       metas = [mine]
     blob = b''.join(m['handle'] for m in metas)
-    _lib.check(L.gnpde_p2p_connect(handle, ctypes.create_string_buffer(blob, len(blob))))
+    failure = None
+    try:
+      _lib.check(L.gnpde_p2p_connect(handle, ctypes.create_string_buffer(blob, len(blob))))
+    except _lib.GnpdeError as exc:     # e.g. the peers' memory cannot be mapped on this system
+      failure = str(exc)
     # where THIS rank's rows start inside peer p's stage buffers: after p's own rows and the rows p receives from lower ranks
     self.peer_row0 = [m['n_own'] + sum(m['recv_counts'][:s.rank]) for m in metas]
     self.peer_buffer_bytes = [m['buffer_bytes'] for m in metas]
     if s.world > 1:
-      dist.barrier(group=group)     # every rank has mapped every peer before anyone pushes
+      # every rank has mapped every peer before anyone pushes -- or every rank learns that one of them could not
+      outcomes = [None] * s.world
+      dist.all_gather_object(outcomes, failure, group=group)
+      failure = next((o for o in outcomes if o is not None), None)
+    if failure is not None:
+      self.close()
+      raise _lib.GnpdeError('p2p transport unavailable: %s' % failure)
 
   def close(self):
     if getattr(self, 'handle', None) is not None and self.handle.value:
@@ -459,10 +469,15 @@ def bench_main(args, rank, world, dev):
   # the host-side collectives -- the P2P transport does not care which device a peer's memory is on.  Functional runs of the
   # multi-rank bench path on a single-GPU box; the numbers are not a scaling measurement.
   shared = os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') == '1'
+  kw = {}
+  if 'RANK' not in os.environ:      # GNPDE_FORCE_SHARDED=1 python bench.py: the sharded driver as a single rank, no launcher
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    kw = dict(rank=0, world_size=1)
   if shared:
-    dist.init_process_group('gloo')
+    dist.init_process_group('gloo', **kw)
   else:
-    dist.init_process_group('nccl', device_id=dev)
+    dist.init_process_group('nccl', device_id=dev, **kw)
   red = torch.device('cpu') if shared else dev          # where the small result reductions live
   cfg = G.synthetic.CONFIGS[args.graph]
   ei, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
@@ -486,25 +501,112 @@ def bench_main(args, rank, world, dev):
   be = NativeBackend(shard, d, dev, kind, params, torch.tensor(0.0), torch.tensor(0.1), True)
   x_own = scatter_rows(x, shard).to(dev)
   K, W = args.steps, args.warmup
-  python_loop = os.environ.get('GNPDE_SHARDED_PYTHON_LOOP', '0') == '1'   # the round-1 driver, kept for A/B
   use_graph = not args.no_graph
+  from . import ops
+
+  def agree(ok):
+    """True iff every rank says so (host-side, any backend)."""
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    return all(flags)
+
+  # reference for the self-check: one evaluation f(x) on the unpartitioned graph, computed natively on this rank's GPU
   with torch.no_grad():
+    xg = x.to(dev)
+    alpha_d, beta_d = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
+    if kind == 'transformer':
+      full = CSRGraph(ei_loops.to(dev), n)
+      wqk = torch.cat([params['Wq'], params['Wk']]).to(dev).contiguous()
+      qk = ops.linear(xg, wqk, torch.zeros(2 * A, device=dev))
+      st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A)
+      w_full, _, _ = ops.edge_attention(full, st, True, False, False, like=xg)
+      f_full = ops.spmm_rhs(full, w_full, xg, alpha_d, beta_d, xg, True)
+      del qk, w_full
+    else:
+      e_rw, w_rw = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
+      full = CSRGraph(e_rw.to(dev), n)
+      f_full = ops.spmm_rhs(full, ops.edge_to_csr_mean(full, w_rw.to(dev)), xg, alpha_d, beta_d, xg, True)
+    ref_own = f_full[shard.own_old_ids.to(dev)].clone()
+    del full, f_full, xg
+
+  def one_eval_error(f_own):
+    return float((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30))
+
+  # Transports, best first; a transport is taken only if EVERY rank could set it up and reproduces f on the unpartitioned
+  # graph through it (one euler step of size 1, exchange included):
+  #   p2p    boundary rows pushed into the peers' IPC-mapped halo regions inside the per-rank hipGraph
+  #   rccl   the same native solver with grouped ncclSend / ncclRecv, eager launches (RCCL does not capture on this HIP)
+  #   torch  the Python-driven loop over torch.distributed.all_to_all_single (round 1)
+  ladder = [t for t in os.environ.get('GNPDE_BENCH_TRANSPORTS', 'p2p,rccl,torch').split(',') if t]
+  if os.environ.get('GNPDE_SHARDED_PYTHON_LOOP', '0') == '1':
+    ladder = ['torch']
+  chosen, notes = None, {}
+  ctx = solver = run = None
+  err_local = float('inf')
+  with torch.no_grad():
+    for cand in ladder:
+      ok, why = True, None
+      try:
+        if cand == 'torch':
+          chk = ShardedSolver(shard, be)
+          chk.y[:shard.n_own].copy_(x_own)
+          chk.exchange(chk.y)
+          f_own = be.empty(shard.n_own)
+          be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
+          torch.cuda.synchronize(dev)
+          err_local = one_eval_error(f_own)
+        else:
+          if cand == 'p2p' and ctx is None:
+            ctx = P2PContext(shard, d, 4)
+          chk = NativeShardedSolver(shard, be, 1.0, 1.0, 'euler', transport=cand, ctx=ctx if cand == 'p2p' else None)
+          f_own = chk.integrate(x_own, x_own, use_graph=False).clone() - x_own
+          torch.cuda.synchronize(dev)
+          timed_out = chk.status()[0]
+          err_local = one_eval_error(f_own)
+          if timed_out:
+            ok, why = False, 'a peer never published its boundary rows (exchange timed out)'
+        if ok and not (err_local <= 1e-4):
+          ok, why = False, 'one evaluation differs from the unpartitioned graph by %.3e' % err_local
+      except Exception as exc:   # noqa: BLE001 -- any failure of a transport means: try the next one
+        ok, why = False, '%s: %s' % (type(exc).__name__, str(exc)[:300])
+      if why:
+        notes[cand] = why
+      all_ok = agree(ok)
+      try:
+        if cand != 'torch':
+          chk.close()
+      except Exception:   # noqa: BLE001
+        pass
+      if all_ok:
+        chosen = cand
+        break
+      if ok:
+        notes[cand] = 'unavailable on another rank'
+      if cand == 'p2p' and ctx is not None:
+        try:
+          ctx.close()
+        except Exception:   # noqa: BLE001
+          pass
+        ctx = None
+    if chosen is None:
+      raise _lib.GnpdeError('no halo transport works on this system: %r' % (notes,))
+    python_loop = chosen == 'torch'
+    graph_mode = use_graph and chosen == 'p2p'
     if python_loop:
       solver = ShardedSolver(shard, be)
       run = lambda T: solver.integrate(x_own, x_own, float(T), 1.0, 'rk4')   # noqa: E731
       if W > 0:
         run(W)
     else:
-      ctx = P2PContext(shard, d, 4)
       if W > 0:
-        warm = NativeShardedSolver(shard, be, float(W), 1.0, 'rk4', ctx=ctx)
-        warm.integrate(x_own, x_own, use_graph=use_graph)
+        warm = NativeShardedSolver(shard, be, float(W), 1.0, 'rk4', transport=chosen, ctx=ctx)
+        warm.integrate(x_own, x_own, use_graph=graph_mode)
         torch.cuda.synchronize(dev)
         dist.barrier()
         warm.close()
-      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', ctx=ctx)
-      solver.integrate(x_own, x_own, use_graph=use_graph)                    # untimed: captures the K-step graph
-      run = lambda T: solver.integrate(x_own, x_own, use_graph=use_graph)   # noqa: E731
+      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', transport=chosen, ctx=ctx)
+      solver.integrate(x_own, x_own, use_graph=graph_mode)                    # untimed: captures the K-step graph
+      run = lambda T: solver.integrate(x_own, x_own, use_graph=graph_mode)   # noqa: E731
     times = []
     for _ in range(max(getattr(args, 'replays', 1), 1)):
       torch.cuda.synchronize(dev)
@@ -517,40 +619,9 @@ def bench_main(args, rank, world, dev):
       torch.cuda.synchronize(dev)
       times.append(time.perf_counter() - t0)
     elapsed = sorted(times)[len(times) // 2]
-  # self-check outside the timed region: one sharded evaluation f(x) (incl. the halo exchange) against the
-  # same evaluation on the unpartitioned graph, computed natively on this rank's GPU
-  with torch.no_grad():
-    from . import ops
     y = y.clone()
-    if python_loop:
-      chk = ShardedSolver(shard, be)
-      chk.y[:shard.n_own].copy_(x_own)
-      chk.exchange(chk.y)
-      f_own = be.empty(shard.n_own)
-      be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
-    else:     # one euler step of size 1 through the native solver (exchange included): f = y1 - y0
-      chk = NativeShardedSolver(shard, be, 1.0, 1.0, 'euler', ctx=ctx)
-      f_own = chk.integrate(x_own, x_own, use_graph=False).clone() - x_own
-      torch.cuda.synchronize(dev)
-      dist.barrier()
-      chk.close()
-    full = CSRGraph(ei_loops.to(dev), n) if kind == 'transformer' else None
-    xg = x.to(dev)
-    alpha_d, beta_d = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
-    if kind == 'transformer':
-      wqk = torch.cat([params['Wq'], params['Wk']]).to(dev).contiguous()
-      qk = ops.linear(xg, wqk, torch.zeros(2 * A, device=dev))
-      st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A)
-      w_full, _, _ = ops.edge_attention(full, st, True, False, False, like=xg)
-      f_full = ops.spmm_rhs(full, w_full, xg, alpha_d, beta_d, xg, True)
-    else:
-      e_rw, w_rw = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
-      full = CSRGraph(e_rw.to(dev), n)
-      f_full = ops.spmm_rhs(full, ops.edge_to_csr_mean(full, w_rw.to(dev)), xg, alpha_d, beta_d, xg, True)
-    ref_own = f_full[shard.own_old_ids.to(dev)]
-    err = ((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30)).reshape(1).float().to(red)
-    dist.all_reduce(err, op=dist.ReduceOp.MAX)
-    del chk, full, f_full, xg
+  err = torch.tensor([err_local], dtype=torch.float32).to(red)
+  dist.all_reduce(err, op=dist.ReduceOp.MAX)
   timed_out = False if python_loop else solver.status()[0]
   el = torch.tensor([elapsed], dtype=torch.float64, device=red)
   dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -569,15 +640,22 @@ def bench_main(args, rank, world, dev):
       'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': 'synthetic %s-shaped graph, GRAND-%s, rk4 3/8-rule, step_size 1, T=%d, rows '
-                             'partitioned over %d GPUs, boundary rows pushed into the peers\' halo regions (IPC-mapped, xGMI '
-                             'stores + epoch flags) once per evaluation inside the per-rank hipGraph'
+                             'partitioned over %d GPUs, %s'
                              % (names.get(args.graph, args.graph),
-                                'nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world),
+                                'nl scaled_dot softmax attention add_source' if kind == 'transformer' else 'l', K, world,
+                                {'p2p': 'boundary rows pushed into the peers\' halo regions (IPC-mapped, xGMI stores + epoch '
+                                        'flags) once per evaluation inside the per-rank hipGraph',
+                                 'rccl': 'boundary rows exchanged by grouped ncclSend / ncclRecv once per evaluation '
+                                         '(native solver, eager launches)',
+                                 'torch': 'boundary rows exchanged by torch.distributed.all_to_all_single once per '
+                                          'evaluation (Python-driven loop)'}[chosen]),
                  'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
                  'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
-                 'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared, 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % use_graph,
+                 'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared,
+                 'transport': chosen, 'transports_rejected': notes,
+                 'driver': 'python loop' if python_loop else 'native, hipGraph %s' % graph_mode,
                  'replays': len(times),
                  'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
       'roofline': None, 'cpu_baseline': None,

@@ -28,6 +28,27 @@ if parts[0] == 'uniform':
 elif parts[0] == 'rmat' and len(parts) > 1:
   ei, n = G.synthetic.make_graph('rmat', scale=float(parts[1]))
   d = 256
+elif parts[0] in ('arxiv_sorted', 'arxiv_part'):
+  # locality experiments on the arxiv shape: ids in community order (upper bound), or ordered by the native partitioner
+  import numpy as np
+  cfg = G.synthetic.CONFIGS['arxiv']
+  n, d = cfg['n'], cfg['d']
+  ei, relabel, comm = G.synthetic.community_powerlaw_graph(n, cfg['pairs'], 0)
+  if parts[0] == 'arxiv_sorted':
+    inv = np.empty(n, dtype=np.int64)
+    inv[relabel] = np.arange(n)
+    ei = torch.from_numpy(inv)[ei]
+  else:
+    k = int(parts[1]) if len(parts) > 1 else 64
+    tp = time.time()
+    g0 = G.CSRGraph(ei, n)
+    part = G.partition_rows(g0, k).long()
+    order = torch.argsort(part, stable=True)          # new position -> old id
+    inv = torch.empty(n, dtype=torch.long)
+    inv[order] = torch.arange(n)
+    ei = inv[ei]
+    cut = float((part[g0.t['rowidx'][:g0.e].long().cpu()] != part[g0.t['colidx'][:g0.e].long().cpu()]).float().mean())
+    print(json.dumps({'partition_s': round(time.time() - tp, 2), 'parts': k, 'edge_cut': round(cut, 3)}), flush=True)
 else:
   ei, n = G.synthetic.make_graph(parts[0])
   d = G.synthetic.CONFIGS[parts[0]]['d']
