@@ -244,6 +244,23 @@ def rhs_gat(x, edge, W, a, heads, alpha_train, beta_train, x0=None, no_alpha_sig
 # ------------------------------------------------------------------------------------------------
 # [3P] torchdiffeq 0.2.1 fixed-grid integrators, as called from block_constant.py:57-62
 # ------------------------------------------------------------------------------------------------
+def two_hop(edge_index, weight, n):
+  """S = coalesce(A ++ offdiag(A A)) / 2 of RewireAttODEblock.add_khop_edges (src/block_transformer_rewiring.py:68-86:
+  [3P] torch_sparse.spspmm(A, A, coalesced=True) -> torch_geometric remove_self_loops -> cat with A -> / 2 ->
+  [3P] torch_sparse.coalesce(op='add')), with dense float64 algebra; the structure comes from a product of the 0/1 patterns,
+  so entries whose value happens to be zero stay, as they do in the reference.  Returns (index [2, nnz] ordered by
+  (row, col), value float64)."""
+  A = torch.zeros(n, n, dtype=torch.float64)
+  A.index_put_((edge_index[0], edge_index[1]), weight.double(), accumulate=True)
+  P = torch.zeros(n, n, dtype=torch.float64)
+  P.index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.shape[1], dtype=torch.float64), accumulate=True)
+  A2, P2 = A @ A, P @ P
+  A2.fill_diagonal_(0)
+  P2.fill_diagonal_(0)
+  idx = ((P + P2) > 0).nonzero().t()
+  return idx, ((A + A2) / 2)[idx[0], idx[1]]
+
+
 def time_grid(T, step_size, dtype=torch.float32):
   """FixedGridODESolver._grid_constructor_from_step_size [3P]: niters = ceil(T/h + 1), last <- T."""
   t = torch.tensor([0, T], dtype=dtype)

@@ -316,3 +316,33 @@ def test_device_graph_build_equals_host_builder(seed, hubs):
   assert c0['n_bin16'] == 0 and empty['rowptr'].tolist() == [0] * 6
   with pytest.raises(G.GnpdeError):
     build_arrays_on_device(torch.tensor([[0], [9]]), 5)
+
+
+def test_new_entry_points_validate_their_arguments():
+  """Argument checks of the round-2 entry points run before anything touches a device: bad calls come back with an error
+  code and a message (gnpde_last_error), size queries are consistent."""
+  import ctypes
+  L = _lib.lib()
+  # two-hop densification
+  small, big = L.gnpde_two_hop_workspace_bytes(1), L.gnpde_two_hop_workspace_bytes(200_000)
+  assert 0 < small < big
+  assert L.gnpde_two_hop_workspace_bytes(2_000_000) <= (17 << 30)        # slabs are capped at 16 GiB
+  assert L.gnpde_two_hop_count(None, None, 10, None, None, 0, None) != 0
+  assert b'two_hop_count' in L.gnpde_last_error()
+  rowptr = (ctypes.c_int32 * 3)(0, 1, 2)
+  col = (ctypes.c_int32 * 2)(1, 0)
+  out = (ctypes.c_int64 * 3)()
+  dummy = (ctypes.c_char * 64)()
+  assert L.gnpde_two_hop_count(rowptr, col, 2, out, dummy, 64, None) != 0    # workspace too small
+  assert b'workspace' in L.gnpde_last_error()
+  # device-controlled dopri5
+  assert L.gnpde_dopri5_workspace_bytes(None) == 0
+  handle = ctypes.c_void_p()
+  assert L.gnpde_dopri5_create(ctypes.byref(handle), None, 1e-7, 1e-9, None, 0) != 0 and not handle.value
+  assert L.gnpde_dopri5_run(None, None, 0, 0.0, 1.0, None, 0, 1, 0, None, None) != 0
+  assert L.gnpde_dopri5_stats(None, None, None, None, None, None) != 0
+  assert L.gnpde_dopri5_destroy(None) == 0
+  # decoder projection, quantile / compaction
+  assert L.gnpde_relu_linear(None, 4, 4, 4, None, 4, 4, None, None, 4, None) != 0
+  assert L.gnpde_quantile(None, 5, 0.5, None, None, 0, None) != 0
+  assert L.gnpde_threshold_edges(None, None, 5, None, 0, 4, None, None, None, None, 0, None) != 0

@@ -79,3 +79,34 @@ def test_reference_unit_tests_pass_over_the_stand_ins():
                        text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
   assert 'ran 24, failures 0, errors 0' in res.stdout
+
+
+KHOP_SCRIPT = r'''
+import sys, os, types
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+from oracle import ref_env
+ref_env.activate()
+import torch
+from oracle import restate as R
+from block_transformer_rewiring import RewireAttODEblock       # the reference's block, unmodified
+g = torch.Generator().manual_seed(3)
+n = 60
+ei = torch.randint(0, n, (2, 300), generator=g)
+ei = torch.cat([ei, ei[:, :7], torch.tensor([[4, 9], [4, 9]])], dim=1)     # duplicates and self loops
+w = torch.rand(ei.shape[1], generator=g)
+fake = types.SimpleNamespace(num_nodes=n, odefunc=types.SimpleNamespace(edge_index=ei, edge_weight=w, attention_weights=None))
+RewireAttODEblock.add_khop_edges(fake, k=2)
+idx, val = R.two_hop(ei, w, n)
+assert torch.equal(fake.data_edge_index, idx), (fake.data_edge_index.shape, idx.shape)
+assert torch.allclose(fake.odefunc.attention_weights.double(), val, rtol=1e-5, atol=1e-7)
+print('KHOP_OK', idx.shape[1])
+'''
+
+
+@pytest.mark.skipif(not ref_env.available(), reason='reference tree not present')
+def test_oracle_two_hop_is_the_reference_blocks_add_khop_edges():
+  """Pins oracle.restate.two_hop (what the native two-hop kernel is tested against) on the reference's own
+  RewireAttODEblock.add_khop_edges run over the stand-ins."""
+  res = subprocess.run([sys.executable, '-c', KHOP_SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0 and 'KHOP_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

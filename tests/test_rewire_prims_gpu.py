@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from gnpde_amd import ops
+from oracle import restate as R
 
 pytestmark = pytest.mark.gpu
 
@@ -69,21 +70,6 @@ def test_threshold_from_quantile_keeps_the_requested_share(dev):
   assert kept.shape[1] == int((score > torch.quantile(score, 1 - 0.81)).sum())
 
 
-def _two_hop_reference(ei, w, n):
-  """The reference's op sequence (block_transformer_rewiring.py:68-86) with dense float64 algebra: spspmm -> remove self
-  loops -> cat with A -> / 2 -> coalesce; structure from an integer product so zero-valued entries stay."""
-  A = torch.zeros(n, n, dtype=torch.float64)
-  A.index_put_((ei[0], ei[1]), w.double(), accumulate=True)
-  P = torch.zeros(n, n, dtype=torch.float64)
-  P.index_put_((ei[0], ei[1]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
-  A2, P2 = A @ A, P @ P
-  A2.fill_diagonal_(0)
-  P2.fill_diagonal_(0)
-  S, pattern = (A + A2) / 2, (P + P2) > 0
-  idx = pattern.nonzero().t()          # row-major = (row, col) order
-  return idx, S[idx[0], idx[1]]
-
-
 @pytest.mark.parametrize('n,deg,hub', [(1, 1, 0), (7, 2, 0), (300, 4, 150), (2049, 6, 900), (5000, 3, 0)])
 def test_two_hop_matches_reference_sequence(dev, n, deg, hub):
   g = torch.Generator().manual_seed(n + deg)
@@ -98,7 +84,7 @@ def test_two_hop_matches_reference_sequence(dev, n, deg, hub):
   from gnpde_amd.graph import CSRGraph
   graph = CSRGraph(ei.to(dev), n)
   got_ei, got_w = ops.two_hop(graph, w.to(dev))
-  ref_ei, ref_w = _two_hop_reference(ei, w, n)
+  ref_ei, ref_w = R.two_hop(ei, w, n)          # the reference's op sequence in dense float64 (oracle/restate.py)
   assert got_ei.dtype == torch.int64 and got_ei.shape == ref_ei.shape, (got_ei.shape, ref_ei.shape)
   assert torch.equal(got_ei.cpu(), ref_ei)                   # same entries in coalesce's (row, col) order
   assert torch.allclose(got_w.cpu().double(), ref_w, rtol=2e-6, atol=1e-7)
