@@ -32,6 +32,7 @@ struct SpmmArgs {
   float* plain_out;      // != nullptr: write ax only (no epilogue)
   float* partial;        // [n_long_chunks, ldp]
   int ldp;
+  int short_rows;        // host-side hint: at least half of the rows have <= 16 entries (-> row pairs for d = 68..128)
   gnpde_epilogue_t ep;
 };
 
@@ -387,6 +388,175 @@ __global__ __launch_bounds__(BLK) void spmm_wide_kernel(const SpmmArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Row-PAIR variant of the wide-row kernel for rows of 17..32 16-byte lanes (d = 68..128, the ogbn-arxiv shape).
+// There a row occupies half a wavefront, and the wide kernel lets the two halves share ONE row (two neighbour slots):
+// with a median of 8 entries per row a wave then has 4 KB of neighbour rows in flight and runs its epilogue on 32 of its 64
+// lanes.  Here the two halves of a wave take two CONSECUTIVE rows when both have <= 32 entries (one coalesced 32-entry index
+// load each): twice the bytes in flight per wave for the same registers, half the waves, every lane busy in the epilogue.
+// Each half keeps the wide kernel's summation order -- even entries into one accumulator, odd entries into a second, in
+// CSR order, then even + odd -- so the result is bit-identical to the shared-row mode whatever row a row is paired with.
+// A pair with a longer row falls back to the shared-row mode for its two rows in turn; hub chunks are shared-row items.
+template <int VEC, int U, bool NT, bool FULL>
+__device__ __forceinline__ void shared_row_item(const SpmmArgs& a, int row, int e0, int e1, int chunk, int lane, int sub, int col,
+                                                bool col_ok, bool pre_ok, float alpha, float beta) {
+  constexpr int L = 32, G = 2;
+  const size_t off = static_cast<size_t>(row) * a.ld + col;
+  Pre<VEC, NT> pre;
+  const bool do_pre = pre_ok && chunk < 0 && sub == 0 && col_ok;
+  if (do_pre) {
+    auto ldp = [](const float* q, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(q, v); else load_vec<VEC>(q, v); };
+    load_vec<VEC>(a.u + off, pre.ui);
+    if (a.ep.x0 != nullptr) ldp(a.ep.x0 + off, pre.x0);
+    const int st = a.ep.stage;
+    if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) ldp(a.ep.y + off, pre.y);
+    if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) ldp(a.ep.k1 + off, pre.k1);
+  }
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+  for (int base = e0; base < e1; base += kWave) {
+    const int me = base + lane;
+    const bool in = me < e1;
+    const int cv = in ? a.colidx[me] : 0;
+    const float wv = in ? a.w[me] : 0.0f;
+    const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
+    int t0 = 0;
+    for (; t0 + G * U <= cnt; t0 += G * U) gather_batch<VEC, L, U, false, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+    if (t0 < cnt) gather_batch<VEC, L, U, true, FULL>(a, cv, wv, t0, cnt, sub, col, col_ok, acc);
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], L, kWave);
+  if (sub != 0 || !col_ok) return;
+  if (chunk >= 0) {
+    store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);
+    return;
+  }
+  if (a.plain_out != nullptr) {
+    store_vec<VEC>(a.plain_out + off, acc);
+    return;
+  }
+  if (pre_ok) {
+    epilogue_pre<VEC, NT>(a.ep, alpha, beta, off, acc, pre);
+  } else {
+    float ui[VEC];
+    load_vec<VEC>(a.u + off, ui);
+    epilogue<VEC, NT>(a.ep, alpha, beta, off, acc, ui);
+  }
+}
+
+template <int VEC, int U, int BLK, bool NT, bool FULL>
+__global__ __launch_bounds__(BLK) void spmm_pair_kernel(const SpmmArgs a) {
+  constexpr int L = 32;
+  constexpr int WPB = BLK / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int half = lane >> 5;
+  const int cl = lane & (L - 1);
+  const int col = cl * VEC;
+  const bool col_ok = FULL ? true : col < a.d;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * WPB + static_cast<int>(threadIdx.x >> 6));
+  const bool pre_ok = a.plain_out == nullptr && stage_prefetchable<VEC, NT>(a.ep.stage);
+  const float alpha = a.plain_out == nullptr ? alpha_of(a.ep) : 0.0f;
+  const float beta = (a.plain_out == nullptr && a.ep.x0 != nullptr) ? *a.ep.beta : 0.0f;
+
+  const int cx = chunks_of_xcd(a, xcd);
+  if (lw < cx) {   // hub chunk first (as item_of)
+    const int chunk = a.chunk_begin + lw * kXcds + xcd;
+    const int row = __builtin_amdgcn_readfirstlane(a.lc_row[chunk]);
+    const int e0 = __builtin_amdgcn_readfirstlane(a.lc_begin[chunk]);
+    const int e1 = __builtin_amdgcn_readfirstlane(a.lc_end[chunk]);
+    shared_row_item<VEC, U, NT, FULL>(a, row, e0, e1, chunk, lane, half, col, col_ok, pre_ok, alpha, beta);
+    return;
+  }
+  const int per = rows_per_xcd(a);
+  const int r0 = 2 * (lw - cx);
+  if (r0 >= per) return;
+  const int first = a.row_begin + xcd * per;
+  int last = first + per;                       // exclusive end of this XCD's rows
+  if (last > a.row_end) last = a.row_end;
+  int row = first + r0 + half;
+  bool have = row < last;
+  int e0 = 0, e1 = 0;
+  if (have) {
+    e0 = a.rowptr[row];
+    e1 = a.rowptr[row + 1];
+  }
+  if (e1 - e0 > GNPDE_LONG_ROW) have = false;   // processed as chunks
+  const int len = have ? e1 - e0 : 0;
+  const int len_a = __builtin_amdgcn_readlane(len, 0), len_b = __builtin_amdgcn_readlane(len, L);
+  if (len_a > L || len_b > L) {                 // a longer row in the pair: both halves share each row in turn
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int hv = __builtin_amdgcn_readlane(static_cast<int>(have), h * L);
+      if (!hv) continue;
+      const int hr = __builtin_amdgcn_readlane(row, h * L);
+      const int h0 = __builtin_amdgcn_readlane(e0, h * L), h1 = __builtin_amdgcn_readlane(e1, h * L);
+      shared_row_item<VEC, U, NT, FULL>(a, hr, h0, h1, -1, lane, half, col, col_ok, pre_ok, alpha, beta);
+    }
+    return;
+  }
+
+  const size_t off = static_cast<size_t>(row) * a.ld + col;
+  Pre<VEC, NT> pre;
+  const bool mine = have && col_ok;
+  if (pre_ok && mine) {
+    auto ldp = [](const float* q, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(q, v); else load_vec<VEC>(q, v); };
+    load_vec<VEC>(a.u + off, pre.ui);
+    if (a.ep.x0 != nullptr) ldp(a.ep.x0 + off, pre.x0);
+    const int st = a.ep.stage;
+    if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) ldp(a.ep.y + off, pre.y);
+    if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) ldp(a.ep.k1 + off, pre.k1);
+  }
+  const bool in = cl < len;
+  const int cv = in ? a.colidx[e0 + cl] : 0;     // the whole row: one coalesced load per half
+  const float wv = in ? a.w[e0 + cl] : 0.0f;
+  const int cmax = len_a > len_b ? len_a : len_b;
+  float acc0[VEC], acc1[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.0f;
+  for (int t0 = 0; t0 < cmax; t0 += U) {
+    float vals[U][VEC];
+    float ww[U];
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      const int idx = t0 + t;                    // < 32 (cmax <= 32, U divides 32)
+      const int c = __shfl(cv, (half << 5) + idx, kWave);
+      const float w = __shfl(wv, (half << 5) + idx, kWave);
+      const bool ok = col_ok && idx < len;
+      ww[t] = ok ? w : 0.0f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
+      if (ok) load_vec<VEC>(a.u + static_cast<size_t>(c) * a.ld + col, vals[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      if (t % 2 == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc0[v] = fmaf(ww[t], vals[t][v], acc0[v]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc1[v] = fmaf(ww[t], vals[t][v], acc1[v]);
+      }
+    }
+  }
+  if (!mine) return;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = acc0[v] + acc1[v];
+  if (a.plain_out != nullptr) {
+    store_vec<VEC>(a.plain_out + off, acc);
+    return;
+  }
+  if (pre_ok) {
+    epilogue_pre<VEC, NT>(a.ep, alpha, beta, off, acc, pre);
+  } else {
+    float ui[VEC];
+    load_vec<VEC>(a.u + off, ui);
+    epilogue<VEC, NT>(a.ep, alpha, beta, off, acc, ui);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row attention + aggregation in ONE kernel (scaled-dot scores, softmax over the row, head mean): what
 // row_attention_sd_kernel (two launches) + spmm_wide_kernel did, per row and per wave, without the [E] weight round trip,
 // the second read of the column ids and the two launch boundaries -- the attention's dependent gathers (ids -> k rows)
@@ -614,6 +784,174 @@ void launch_wide(const SpmmArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((spmm_wide_kernel<VEC, L, U, BLK, PERSIST, true, false>), dim3(grid), dim3(BLK), 0, s, a);
 }
 
+// Software-pipelined, resident form of the row-pair kernel.  A wave of the one-item-per-wave kernels pays three dependent memory
+// round trips per row (row pointer -> column ids / weights -> neighbour rows) and has data in flight during one of them only.
+// Here a resident wave strides over the pairs of its XCD and keeps three pairs in different stages: while the neighbour rows of
+// pair A are gathered, the column ids / weights of pair B and the row pointers of pair C are already on their way, so an
+// iteration waits for ONE round trip.  Same per-row arithmetic and summation order as spmm_pair_kernel (bit-identical).
+template <int VEC, int U, int BLK, bool NT, bool FULL>
+__global__ __launch_bounds__(BLK) void spmm_pair_pipe_kernel(const SpmmArgs a) {
+  constexpr int L = 32;
+  constexpr int WPB = BLK / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int half = lane >> 5;
+  const int cl = lane & (L - 1);
+  const int col = cl * VEC;
+  const bool col_ok = FULL ? true : col < a.d;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * WPB + static_cast<int>(threadIdx.x >> 6));
+  const int wpx = static_cast<int>(gridDim.x / kXcds) * WPB;       // waves of this XCD
+  const bool pre_ok = a.plain_out == nullptr && stage_prefetchable<VEC, NT>(a.ep.stage);
+  const float alpha = a.plain_out == nullptr ? alpha_of(a.ep) : 0.0f;
+  const float beta = (a.plain_out == nullptr && a.ep.x0 != nullptr) ? *a.ep.beta : 0.0f;
+
+  const int cx = chunks_of_xcd(a, xcd);
+  int j = lw;
+  for (; j < cx; j += wpx) {   // hub chunks first
+    const int chunk = a.chunk_begin + j * kXcds + xcd;
+    const int row = __builtin_amdgcn_readfirstlane(a.lc_row[chunk]);
+    const int e0 = __builtin_amdgcn_readfirstlane(a.lc_begin[chunk]);
+    const int e1 = __builtin_amdgcn_readfirstlane(a.lc_end[chunk]);
+    shared_row_item<VEC, U, NT, FULL>(a, row, e0, e1, chunk, lane, half, col, col_ok, pre_ok, alpha, beta);
+  }
+  const int per = rows_per_xcd(a);
+  const int first = a.row_begin + xcd * per;
+  int last = first + per;
+  if (last > a.row_end) last = a.row_end;
+  const int n_pairs = last > first ? (last - first + 1) / 2 : 0;
+  int p = j - cx;
+  if (p >= n_pairs) return;
+
+  // stage 1: row pointers of a pair (half h: row first + 2 p + h); rows longer than GNPDE_LONG_ROW are chunk items
+  auto header = [&](int pp, int& row, int& e0, int& len) {
+    row = first + 2 * pp + half;
+    const bool have = pp < n_pairs && row < last;
+    int b = 0, e = 0;
+    if (have) {
+      b = a.rowptr[row];
+      e = a.rowptr[row + 1];
+    }
+    e0 = b;
+    len = (have && e - b <= GNPDE_LONG_ROW) ? e - b : -1;      // -1: nothing to do for this half
+  };
+  // stage 2: the row's first 32 column ids / weights, one coalesced load per half
+  auto columns = [&](int e0, int len, int& cv, float& wv) {
+    const bool in = cl < len;
+    cv = in ? a.colidx[e0 + cl] : 0;
+    wv = in ? a.w[e0 + cl] : 0.0f;
+  };
+  int row_a, e0_a, len_a, row_b, e0_b, len_b, row_c, e0_c, len_c;
+  int cv_a, cv_b;
+  float wv_a, wv_b;
+  header(p, row_a, e0_a, len_a);
+  columns(e0_a, len_a, cv_a, wv_a);
+  header(p + wpx, row_b, e0_b, len_b);
+
+  for (;;) {
+    columns(e0_b, len_b, cv_b, wv_b);              // pair B: ids / weights on their way ...
+    header(p + 2 * wpx, row_c, e0_c, len_c);       // pair C: row pointers on their way ...
+    const int la = __builtin_amdgcn_readlane(len_a, 0), lb = __builtin_amdgcn_readlane(len_a, L);
+    if (la > L || lb > L) {                        // a longer row in the pair: both halves share each row in turn
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hl = h == 0 ? la : lb;
+        if (hl < 0) continue;
+        const int hr = __builtin_amdgcn_readlane(row_a, h * L), h0 = __builtin_amdgcn_readlane(e0_a, h * L);
+        shared_row_item<VEC, U, NT, FULL>(a, hr, h0, h0 + hl, -1, lane, half, col, col_ok, pre_ok, alpha, beta);
+      }
+    } else {                                       // ... while pair A gathers its neighbour rows
+      const size_t off = static_cast<size_t>(row_a) * a.ld + col;
+      Pre<VEC, NT> pre;
+      const bool mine = len_a >= 0 && col_ok;
+      if (pre_ok && mine) {
+        auto ldp = [](const float* q, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(q, v); else load_vec<VEC>(q, v); };
+        load_vec<VEC>(a.u + off, pre.ui);
+        if (a.ep.x0 != nullptr) ldp(a.ep.x0 + off, pre.x0);
+        const int st = a.ep.stage;
+        if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) ldp(a.ep.y + off, pre.y);
+        if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) ldp(a.ep.k1 + off, pre.k1);
+      }
+      const int cmax = la > lb ? la : lb;
+      float acc0[VEC], acc1[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.0f;
+      for (int t0 = 0; t0 < cmax; t0 += U) {
+        float vals[U][VEC];
+        float ww[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          const int idx = t0 + t;
+          const int c = __shfl(cv_a, (half << 5) + idx, kWave);
+          const float w = __shfl(wv_a, (half << 5) + idx, kWave);
+          const bool ok = col_ok && idx < len_a;
+          ww[t] = ok ? w : 0.0f;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
+          if (ok) load_vec<VEC>(a.u + static_cast<size_t>(c) * a.ld + col, vals[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (t % 2 == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc0[v] = fmaf(ww[t], vals[t][v], acc0[v]);
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc1[v] = fmaf(ww[t], vals[t][v], acc1[v]);
+          }
+        }
+      }
+      if (mine) {
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = acc0[v] + acc1[v];
+        if (a.plain_out != nullptr) {
+          store_vec<VEC>(a.plain_out + off, acc);
+        } else if (pre_ok) {
+          epilogue_pre<VEC, NT>(a.ep, alpha, beta, off, acc, pre);
+        } else {
+          float ui[VEC];
+          load_vec<VEC>(a.u + off, ui);
+          epilogue<VEC, NT>(a.ep, alpha, beta, off, acc, ui);
+        }
+      }
+    }
+    p += wpx;
+    if (p >= n_pairs) break;
+    row_a = row_b; e0_a = e0_b; len_a = len_b; cv_a = cv_b; wv_a = wv_b;
+    row_b = row_c; e0_b = e0_c; len_b = len_c;
+  }
+}
+
+// row pairs: one wave per two consecutive rows (hub chunks first, as balanced_grid)
+template <int VEC, int U, int BLK>
+void launch_pair(const SpmmArgs& a, hipStream_t s) {
+  constexpr int WPB = BLK / kWave;
+  const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
+  const long long per = (rn + kXcds - 1) / kXcds;
+  const long long per_xcd = (cn + kXcds - 1) / kXcds + (per + 1) / 2;
+  long long blocks = (per_xcd + WPB - 1) / WPB;
+  if (blocks < 1) blocks = 1;
+  const unsigned grid = static_cast<unsigned>(blocks * kXcds);
+  if (a.d == 32 * VEC) hipLaunchKernelGGL((spmm_pair_kernel<VEC, U, BLK, true, true>), dim3(grid), dim3(BLK), 0, s, a);
+  else hipLaunchKernelGGL((spmm_pair_kernel<VEC, U, BLK, true, false>), dim3(grid), dim3(BLK), 0, s, a);
+}
+
+// resident grid of the pipelined row-pair kernel: `waves_per_cu` waves on every CU, shrunk when there is less work than that
+template <int VEC, int U, int BLK>
+void launch_pair_pipe(const SpmmArgs& a, hipStream_t s, int waves_per_cu) {
+  constexpr int WPB = BLK / kWave;
+  const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
+  const long long per = (rn + kXcds - 1) / kXcds;
+  const long long per_xcd = (cn + kXcds - 1) / kXcds + (per + 1) / 2;
+  long long blocks = (per_xcd + WPB - 1) / WPB;             // per XCD, one item per wave
+  const long long resident = 256LL * waves_per_cu / WPB / kXcds;
+  if (blocks > resident) blocks = resident;
+  if (blocks < 1) blocks = 1;
+  const unsigned grid = static_cast<unsigned>(blocks * kXcds);
+  if (a.d == 32 * VEC) hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, true>), dim3(grid), dim3(BLK), 0, s, a);
+  else hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, false>), dim3(grid), dim3(BLK), 0, s, a);
+}
+
 // tune codes >= 100 (tools/spmm_ab.py): 100 + 10 * {0: U4, 1: U8, 2: U16} + {0: 256 thr, 1: 64 thr, 2: 256 thr persistent,
 // 3: 64 thr persistent}
 template <int VEC, int L>
@@ -652,8 +990,32 @@ int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
   // default for 16-byte lanes and rows of 17..64 lanes (d = 68..256): the wide-row kernel, 8 gathers in flight, one
   // wavefront per workgroup -- measured best at the ogbn-arxiv shape (178 vs 221 us) and within 1 % of the best at the
   // R-MAT d = 256 shape (16.6 vs 16.8 ms), tools/spmm_ab.py, profiles/r02_ab_*.log
+  // rows of 17..32 lanes (d = 68..128) in graphs whose rows are mostly short (the ogbn-arxiv shape: median 8 entries): two rows
+  // per wave, 16 gathers in flight per half (spmm_pair_kernel; bit-identical results): 171 vs 184 us at the ogbn-arxiv shape,
+  // 193 vs 230 us on a uniform degree-8 graph, but 2 % slower at degree 24 -- hence the hint (profiles/r02_ab_row_pairs.txt)
+  if (code == 0 && VEC == 4 && slots > 16 && slots <= 32 && a.short_rows) code = 133;
   if (code == 0 && VEC == 4 && slots > 16 && slots <= 64) code = 111;
   if (code == 99) code = 0;   // A/B: force the round-1 kernel
+  if (code >= 130 && code <= 149 && VEC == 4 && slots > 16 && slots <= 32) {   // row pairs (A/B)
+    if constexpr (VEC == 4) {
+      switch (code) {
+        case 140: launch_pair_pipe<4, 8, 64>(a, s, 16); return 0;
+        case 141: launch_pair_pipe<4, 16, 64>(a, s, 12); return 0;
+        case 142: launch_pair_pipe<4, 8, 256>(a, s, 16); return 0;
+        case 143: launch_pair_pipe<4, 16, 256>(a, s, 12); return 0;
+        case 144: launch_pair_pipe<4, 8, 64>(a, s, 20); return 0;
+        case 145: launch_pair_pipe<4, 16, 64>(a, s, 8); return 0;
+        case 146: launch_pair_pipe<4, 8, 64>(a, s, 32); return 0;
+        case 147: launch_pair_pipe<4, 16, 64>(a, s, 16); return 0;
+        case 130: launch_pair<4, 8, 64>(a, s); return 0;
+        case 131: launch_pair<4, 8, 256>(a, s); return 0;
+        case 132: launch_pair<4, 4, 64>(a, s); return 0;
+        case 133: launch_pair<4, 16, 64>(a, s); return 0;
+        case 134: launch_pair<4, 4, 256>(a, s); return 0;
+        default: launch_pair<4, 16, 256>(a, s); return 0;
+      }
+    }
+  }
   if (code >= 100) {
     bool done = false;
     if (slots <= 16) done = dispatch_wide<VEC, 16>(a, s, code);
@@ -910,6 +1272,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   GNPDE_CHECK_ARG(!(forked && g->row_begin > 0), GNPDE_EINVAL, "spmm: fork with row_begin");
   a.chunk_begin = 0;
   a.chunk_end = forked ? 0 : g->n_long_chunks;
+  a.short_rows = 2LL * g->n_bin16 >= g->n ? 1 : 0;
   a.row_begin = g->row_begin;
   a.row_end = g->n;
   if (g_tune[GNPDE_TUNE_SPMM_PART] == 1) a.row_end = a.row_begin;       // (timing the two kinds of work items separately)
