@@ -12,7 +12,7 @@ the launch is repeated `--replays` times (each bracketed by a device synchronisa
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row-partitioned, RCCL halo)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the CSR aggregation
-spmm_rows_kernel): algorithmic bytes of DESIGN.md section "Kernels" divided by its average launch duration,
+spmm_rows_kernel / spmm_pair_kernel): algorithmic bytes of DESIGN.md section "Kernels" divided by its average launch duration,
 measured here with HIP events on the launch stream over the four rk4-stage variants the solver runs.
 `cpu_baseline` times the CPU oracle (the reference's op sequence) on this host's cores on a bounded sample.
 """
@@ -149,8 +149,9 @@ def dominant_kernel_time(G, block, x, reps=10):
       ops.attn_rhs_fused(graph, att, wqk, bqk, u, alpha, beta, x0, True, dt=1.0, **kw)
   else:
     w = torch.rand(max(graph.e, 1), device=dev) / 16
-    name = ('CSR aggregation + fused epilogue / rk4 stage: spmm_wide_kernel (16-byte lanes, d = 68..256; spmm_rows_kernel '
-            'otherwise) + spmm_long_reduce_kernel (hub-row fold)')
+    name = ('CSR aggregation + fused epilogue / rk4 stage: spmm_pair_kernel (d = 68..128, mostly short rows: two rows per '
+            'wavefront) or spmm_wide_kernel (16-byte lanes, d = 68..256; spmm_rows_kernel otherwise) + spmm_long_reduce_kernel '
+            '(hub-row fold)')
 
     def launch(u, kw):
       ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)

@@ -55,7 +55,7 @@ def main():
       rec['utcl1_miss_rate'] = round(m['TCP_UTCL1_TRANSLATION_MISS_sum'] / m['TCP_UTCL1_REQUEST_sum'], 5)
     detail[k] = rec
   # dominant aggregation kernel = the spmm kernel with the most fetched bytes
-  agg = [k for k in detail if re.search(r'spmm_(rows|wide)_kernel', k) and 'bytes_per_launch' in detail[k]]
+  agg = [k for k in detail if re.search(r'spmm_(rows|wide|pair)_kernel', k) and 'bytes_per_launch' in detail[k]]
   data = {}
   if os.path.exists(out_path):
     try:
