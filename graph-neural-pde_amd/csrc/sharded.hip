@@ -172,7 +172,10 @@ __global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, in
   }
   __syncthreads();
   const int p = threadIdx.x;
-  if (p < world && p != rank) {
+  // once a wait has timed out the solve is lost (gnpde_sharded_solver_status reports it): the remaining waits of the queued
+  // evaluations return at once instead of each spinning to the bound -- a K-step graph then ends in milliseconds, not minutes
+  const bool lost = __hip_atomic_load(ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+  if (p < world && p != rank && !lost) {
     long long n = 0;
     // (signed distance: epochs wrap after 2^32 evaluations)
     while (static_cast<int>(__hip_atomic_load(ctl + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {

@@ -510,30 +510,65 @@ def bench_main(args, rank, world, dev):
     dist.all_gather_object(flags, bool(ok))
     return all(flags)
 
-  # reference for the self-check: one evaluation f(x) on the unpartitioned graph, computed natively on this rank's GPU
+  # reference for the self-checks: the SAME problem on the unpartitioned graph, computed natively on this rank's GPU --
+  # one evaluation f(x), and (unpartitioned_solve) whole rk4 solves, so that the sharded result is compared after every
+  # stage buffer has been pushed into, read and pushed into AGAIN (a stale halo line would not show in one evaluation)
+  own_ids = shard.own_old_ids.to(dev)
   with torch.no_grad():
     xg = x.to(dev)
     alpha_d, beta_d = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
     if kind == 'transformer':
       full = CSRGraph(ei_loops.to(dev), n)
       wqk = torch.cat([params['Wq'], params['Wk']]).to(dev).contiguous()
-      qk = ops.linear(xg, wqk, torch.zeros(2 * A, device=dev))
+      bqk = torch.zeros(2 * A, device=dev)
+      qk = ops.linear(xg, wqk, bqk)
       st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False, q=qk, k=qk[:, A:], ldqk=2 * A)
       w_full, _, _ = ops.edge_attention(full, st, True, False, False, like=xg)
       f_full = ops.spmm_rhs(full, w_full, xg, alpha_d, beta_d, xg, True)
-      del qk, w_full
+      full_kw = dict(proj_w=wqk, proj_b=bqk, att=ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, 0, False))
+      full_kind = _lib.RHS_TRANSFORMER
+      del qk, w_full, st
     else:
       e_rw, w_rw = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
       full = CSRGraph(e_rw.to(dev), n)
-      f_full = ops.spmm_rhs(full, ops.edge_to_csr_mean(full, w_rw.to(dev)), xg, alpha_d, beta_d, xg, True)
-    ref_own = f_full[shard.own_old_ids.to(dev)].clone()
-    del full, f_full, xg
+      w_full_csr = ops.edge_to_csr_mean(full, w_rw.to(dev))
+      f_full = ops.spmm_rhs(full, w_full_csr, xg, alpha_d, beta_d, xg, True)
+      full_kw = dict(w_csr=w_full_csr)
+      full_kind = _lib.RHS_LAPLACIAN
+    ref_own = f_full[own_ids].clone()
+    del f_full
+
+  def unpartitioned_solve(T):
+    """Owned rows of y(T), rk4 with step 1 from y(0) = x: the single-GPU solver (csrc/solver.hip) on the whole graph."""
+    grid = time_grid(torch.tensor([0.0, float(T)]), 1.0)
+    desc = ops.RhsDescriptor(full_kind, full, d, d, alpha_d, beta_d, xg, True, **full_kw)
+    sol = ops.FixedStepSolver(desc, 'rk4', (grid[1:] - grid[:-1]).tolist(), dev)
+    try:
+      yy = xg.clone()
+      sol.run(yy, use_graph=False)
+      torch.cuda.synchronize(dev)
+      return yy[own_ids].clone()
+    finally:
+      sol.close()
+
+  def solve_error(y_own, ref):
+    return float((y_own - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+  # two rk4 steps = 8 evaluations: each of the four stage buffers is the exchanged one twice
+  T_CHECK = 2.0
+  ref_check, ref_check_why = None, None
+  try:
+    with torch.no_grad():
+      ref_check = unpartitioned_solve(T_CHECK)
+  except Exception as exc:   # noqa: BLE001 -- the transports are then judged on the one-evaluation check alone
+    ref_check_why = '%s: %s' % (type(exc).__name__, str(exc)[:200])
 
   def one_eval_error(f_own):
     return float((f_own - ref_own).abs().max() / ref_own.abs().max().clamp_min(1e-30))
 
-  # Transports, best first; a transport is taken only if EVERY rank could set it up and reproduces f on the unpartitioned
-  # graph through it (one euler step of size 1, exchange included):
+  # Transports, best first; a transport is taken only if EVERY rank could set it up and reproduces the unpartitioned graph
+  # through it, exchange included -- first ONE evaluation of f (an euler step of size 1), then, ranks still in lockstep, a
+  # two-step rk4 solve in the launch mode the timed run will use (8 evaluations: every stage buffer exchanged twice):
   #   p2p    boundary rows pushed into the peers' IPC-mapped halo regions inside the per-rank hipGraph
   #   rccl   the same native solver with grouped ncclSend / ncclRecv, eager launches (RCCL does not capture on this HIP)
   #   torch  the Python-driven loop over torch.distributed.all_to_all_single (round 1)
@@ -543,9 +578,22 @@ def bench_main(args, rank, world, dev):
   chosen, notes = None, {}
   ctx = solver = run = None
   err_local = float('inf')
+  err_check = None
+  have_ref_check = agree(ref_check is not None)   # (every rank takes the same path through the checks)
+  if not have_ref_check:
+    notes['two_step_check'] = 'skipped: %s' % (ref_check_why or 'reference solve unavailable on another rank')
+
+  def close_quietly(obj):
+    try:
+      if obj is not None and hasattr(obj, 'close'):
+        obj.close()
+    except Exception:   # noqa: BLE001
+      pass
+
   with torch.no_grad():
     for cand in ladder:
       ok, why = True, None
+      chk = None
       try:
         if cand == 'torch':
           chk = ShardedSolver(shard, be)
@@ -572,21 +620,38 @@ def bench_main(args, rank, world, dev):
       if why:
         notes[cand] = why
       all_ok = agree(ok)
-      try:
-        if cand != 'torch':
-          chk.close()
-      except Exception:   # noqa: BLE001
-        pass
+      close_quietly(chk)
+      if not all_ok and ok:
+        notes[cand] = 'unavailable on another rank'
+      if all_ok and have_ref_check:
+        ok, why, chk = True, None, None
+        try:
+          if cand == 'torch':
+            chk = ShardedSolver(shard, be)
+            y2 = chk.integrate(x_own, x_own, T_CHECK, 1.0, 'rk4').clone()
+            torch.cuda.synchronize(dev)
+          else:
+            chk = NativeShardedSolver(shard, be, T_CHECK, 1.0, 'rk4', transport=cand, ctx=ctx if cand == 'p2p' else None)
+            y2 = chk.integrate(x_own, x_own, use_graph=bool(use_graph and cand == 'p2p')).clone()
+            torch.cuda.synchronize(dev)
+            if chk.status()[0]:
+              ok, why = False, 'two-step solve: a peer never published its boundary rows (exchange timed out)'
+          err_check = solve_error(y2, ref_check)
+          if ok and not (err_check <= 1e-4):
+            ok, why = False, 'two-step rk4 solve differs from the unpartitioned graph by %.3e' % err_check
+        except Exception as exc:   # noqa: BLE001
+          ok, why = False, 'two-step solve: %s: %s' % (type(exc).__name__, str(exc)[:300])
+        if why:
+          notes[cand] = why
+        all_ok = agree(ok)
+        close_quietly(chk)
+        if not all_ok and ok:
+          notes[cand] = 'two-step solve failed on another rank'
       if all_ok:
         chosen = cand
         break
-      if ok:
-        notes[cand] = 'unavailable on another rank'
       if cand == 'p2p' and ctx is not None:
-        try:
-          ctx.close()
-        except Exception:   # noqa: BLE001
-          pass
+        close_quietly(ctx)
         ctx = None
     if chosen is None:
       raise _lib.GnpdeError('no halo transport works on this system: %r' % (notes,))
@@ -620,6 +685,18 @@ def bench_main(args, rank, world, dev):
       times.append(time.perf_counter() - t0)
     elapsed = sorted(times)[len(times) // 2]
     y = y.clone()
+    # the TIMED solve against the same K steps on the unpartitioned graph (outside the timed region; the single-GPU solver
+    # on every rank's own device, compared on the rank's own rows)
+    err_solve, solve_why = 0.0, None
+    try:
+      err_solve = solve_error(y, unpartitioned_solve(K))
+    except Exception as exc:   # noqa: BLE001 -- reported, not fatal: the line still carries the one-evaluation check
+      solve_why = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+  have_solve = agree(solve_why is None)
+  es = torch.tensor([err_solve if solve_why is None and err_solve == err_solve else 3.0e38], dtype=torch.float32).to(red)
+  dist.all_reduce(es, op=dist.ReduceOp.MAX)
+  ec = torch.tensor([err_check if err_check is not None and err_check == err_check else -1.0], dtype=torch.float32).to(red)
+  dist.all_reduce(ec, op=dist.ReduceOp.MAX)
   err = torch.tensor([err_local], dtype=torch.float32).to(red)
   dist.all_reduce(err, op=dist.ReduceOp.MAX)
   timed_out = False if python_loop else solver.status()[0]
@@ -657,7 +734,11 @@ def bench_main(args, rank, world, dev):
                  'transport': chosen, 'transports_rejected': notes,
                  'driver': 'python loop' if python_loop else 'native, hipGraph %s' % graph_mode,
                  'replays': len(times),
-                 'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item())},
+                 'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item()),
+                 'sharded_vs_unpartitioned_two_step_rel_max': float(ec.item()) if float(ec.item()) >= 0 else None,
+                 'sharded_vs_unpartitioned_timed_solve_rel_max': float(es.item()) if have_solve else None,
+                 'timed_solve_check': ('own rows of y(T=%d) of the timed run against the single-GPU solver on the unpartitioned '
+                                       'graph (max over ranks)' % K) if have_solve else 'unavailable: %s' % (solve_why or 'failed on another rank')},
       'roofline': None, 'cpu_baseline': None,
     }
     print(json.dumps(out))

@@ -564,7 +564,8 @@ int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnpde_p2p_t* p
  * once per y pointer and replayed (P2P transport only).  Every rank must call it (the exchange is collective). */
 int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_graph, void* stream);
 /* Synchronises.  *timed_out != 0: a wait kernel gave up polling a peer's epoch flag (results are invalid);
- * *epochs = evaluations this rank has published so far. */
+ * *epochs = evaluations this rank has published so far.  After the first time-out the waits of the evaluations still
+ * queued return without polling (the flag is sticky for the lifetime of the gnpde_p2p_t), so a lost solve ends quickly. */
 int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* timed_out, int64_t* epochs);
 int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins);
 int gnpde_sharded_solver_num_rhs_evals(const gnpde_sharded_solver_t* s);
