@@ -11,9 +11,12 @@ classes.  The FORWARD value is always the native kernels' (identical to inferenc
   recompute q||k and the attention (native), then  A^T g  (aggregation on the transposed CSR), dw = SDDMM,
   ds = gnpde_softmax_rows_bwd, dq / dk = gnpde_head_spmm over rows / columns, dx += [dq dk] [Wq; Wk] on
   the MFMA projection kernel; the [A,N]x[N,d] weight-gradient GEMMs go to the vendor BLAS through torch.
-* the remaining score functions (cosine / pearson / exp_kernel incl. the BLEND split kernel, GAT): the
-  backward RECOMPUTES f from PyTorch device ops and differentiates that composite (index_select / index_add,
-  the reference's op sequence).  Interim; it announces itself once.
+* the other score functions (cosine / pearson / exp_kernel incl. the BLEND split kernel, GAT incl. mix_features): node-level
+  transforms in PyTorch with autograd, everything per edge native (section "Native VJP of the attention for EVERY score
+  function" below).
+* what is left to the composite of PyTorch device ops (index_select / index_add, the reference's op sequence; it announces
+  itself once): head shapes the float4 head-SpMM does not cover, the second-order regularisers (a kernel-backed autograd
+  function is not twice differentiable), and opt['gnpde_composite_backward'] (the A/B reference of the gradient tests).
 """
 import logging
 import math
