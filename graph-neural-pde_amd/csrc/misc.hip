@@ -31,10 +31,10 @@ struct LinArgs {
 // out = base + sum_j c_j v_j over a flat array (stage algebra of host-driven Runge-Kutta loops in ONE pass)
 template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void lincomb_kernel(LinArgs a) {
-  if (a.scale != nullptr) {
-    const float s = *a.scale;
-    for (int j = 0; j < GNPDE_MAX_PREV; ++j) a.c[j] *= s;
-  }
+  // The argument struct is only READ (pointers and coefficients stay in the kernel-argument segment, fetched by scalar loads
+  // with a wave-uniform index); scaling the coefficients in place would force the whole struct into scratch memory and every
+  // v[j] / c[j] of the inner loops with it.  c[j] * s is the same fl32 product wherever it is formed.
+  const float s = a.scale != nullptr ? *a.scale : 1.f;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   if constexpr (VEC4) {
     const long long n4 = a.n / 4;
@@ -42,19 +42,20 @@ __global__ __launch_bounds__(kBlock) void lincomb_kernel(LinArgs a) {
       float4 r = reinterpret_cast<const float4*>(a.base)[i];
       for (int j = 0; j < a.n_v; ++j) {
         const float4 t = reinterpret_cast<const float4*>(a.v[j])[i];
-        r.x = fmaf(a.c[j], t.x, r.x); r.y = fmaf(a.c[j], t.y, r.y); r.z = fmaf(a.c[j], t.z, r.z); r.w = fmaf(a.c[j], t.w, r.w);
+        const float c = a.c[j] * s;
+        r.x = fmaf(c, t.x, r.x); r.y = fmaf(c, t.y, r.y); r.z = fmaf(c, t.z, r.z); r.w = fmaf(c, t.w, r.w);
       }
       reinterpret_cast<float4*>(a.out)[i] = r;
     }
     for (long long i = n4 * 4 + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
       float r = a.base[i];
-      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j], a.v[j][i], r);
+      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j] * s, a.v[j][i], r);
       a.out[i] = r;
     }
   } else {
     for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
       float r = a.base[i];
-      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j], a.v[j][i], r);
+      for (int j = 0; j < a.n_v; ++j) r = fmaf(a.c[j] * s, a.v[j][i], r);
       a.out[i] = r;
     }
   }
@@ -77,10 +78,7 @@ struct ErrArgs {
 template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, float* __restrict__ ws) {
   __shared__ float red[kWavesPerBlock];
-  if (a.scale != nullptr) {
-    const float s = *a.scale;
-    for (int j = 0; j < GNPDE_MAX_PREV; ++j) a.coef[j] *= s;
-  }
+  const float s = a.scale != nullptr ? *a.scale : 1.f;   // (applied at the use: the argument struct stays read-only, see lincomb_kernel)
   float acc = 0.f;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   if constexpr (VEC4) {
@@ -93,8 +91,9 @@ __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, flo
       float4 err = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = 0; j < a.n_k; ++j) {
         const float4 k = reinterpret_cast<const float4*>(a.k[j])[i];
-        err.x = fmaf(k.x, a.coef[j], err.x); err.y = fmaf(k.y, a.coef[j], err.y);
-        err.z = fmaf(k.z, a.coef[j], err.z); err.w = fmaf(k.w, a.coef[j], err.w);
+        const float cj = a.coef[j] * s;
+        err.x = fmaf(k.x, cj, err.x); err.y = fmaf(k.y, cj, err.y);
+        err.z = fmaf(k.z, cj, err.z); err.w = fmaf(k.w, cj, err.w);
       }
       const float4 u = reinterpret_cast<const float4*>(a.y0)[i];
       const float4 v = reinterpret_cast<const float4*>(a.y1)[i];
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, flo
       const long long r = i / a.d;
       const size_t off = static_cast<size_t>(r) * a.ld + static_cast<size_t>(i - r * a.d);
       float err = 0.f;
-      for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j], err);
+      for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j] * s, err);
       const float tol = a.atol + a.rtol * fmaxf(fabsf(a.y0[off]), fabsf(a.y1[off]));
       const float qv = err / tol;
       acc = fmaf(qv, qv, acc);
