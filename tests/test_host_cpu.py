@@ -3,6 +3,7 @@ helpers, the host integrator loops, parameter-name parity and loud failure witho
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -227,8 +228,8 @@ def test_early_stop_integrator_surface():
   bad = G.EarlyStopInt(1.0, dict(fx.opt, method='euler'), torch.device('cpu'))
   with pytest.raises(AssertionError):
     bad(lambda t, y: y, x, bad.t, method='euler', options={'step_size': 1.0})
-  sys_path = os.path.join(ROOT, 'graph-neural-pde_amd', 'dropin')
-  assert os.path.exists(os.path.join(sys_path, 'early_stop_solver.py'))
+  from gnpde_amd import dropin
+  assert dropin.MODULES['early_stop_solver'] == 'gnpde_amd.early_stop_solver'
 
 
 def test_product_does_not_import_oracle():
@@ -346,3 +347,54 @@ def test_new_entry_points_validate_their_arguments():
   assert L.gnpde_relu_linear(None, 4, 4, 4, None, 4, 4, None, None, 4, None) != 0
   assert L.gnpde_quantile(None, 5, 0.5, None, None, 0, None) != 0
   assert L.gnpde_threshold_edges(None, None, 5, None, 0, 4, None, None, None, None, 0, None) != 0
+
+
+def test_dropin_launcher_serves_the_reference_module_names(tmp_path):
+  """python -m gnpde_amd.dropin SCRIPT: the script's imports of the reference's module names get this package's classes;
+  `base_classes` is the script directory's own file with ODEFunc / ODEblock / RegularizedODEfunc replaced (no reference
+  tree needed: a stand-in base_classes.py plays its part)."""
+  import subprocess
+  src = tmp_path / 'src'
+  src.mkdir()
+  (src / 'base_classes.py').write_text(
+    'class ODEFunc(object):\n  pass\nclass ODEblock(object):\n  pass\nclass BaseGNN(object):\n  marker = 41\nREGISTRY = {"k": 1}\n')
+  (src / 'run_it.py').write_text(
+    'import sys\n'
+    'from base_classes import BaseGNN, ODEFunc, ODEblock, RegularizedODEfunc, REGISTRY\n'
+    'from block_constant import ConstantODEblock\n'
+    'from function_transformer_attention import ODEFuncTransformerAtt, SpGraphTransAttentionLayer\n'
+    'from early_stop_solver import EarlyStopInt, SOLVERS\n'
+    'import gnpde_amd\n'
+    'assert ODEFunc is gnpde_amd.base_classes.ODEFunc and issubclass(ODEFuncTransformerAtt, ODEFunc)\n'
+    'assert ODEblock is gnpde_amd.base_classes.ODEblock and issubclass(ConstantODEblock, ODEblock)\n'
+    'assert BaseGNN.marker == 41 and REGISTRY == {"k": 1} and BaseGNN.__module__ == "_reference_base_classes"\n'
+    'assert "GNN" not in sys.modules or not sys.modules["GNN"].__name__.startswith("gnpde_amd")\n'
+    'assert __name__ == "__main__" and sys.argv[1:] == ["--dataset", "Cora"]\n'
+    'print("LAUNCHED_OK")\n')
+  env = dict(os.environ, PYTHONPATH=ROOT)
+  res = subprocess.run([sys.executable, '-m', 'gnpde_amd.dropin', str(src / 'run_it.py'), '--dataset', 'Cora'], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+  assert res.returncode == 0 and 'LAUNCHED_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+  res = subprocess.run([sys.executable, '-m', 'gnpde_amd.dropin', '--bogus', str(src / 'run_it.py')], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+  assert res.returncode != 0 and 'unknown option' in res.stderr
+
+
+def test_dropin_install_refuses_after_a_foreign_import(tmp_path, monkeypatch):
+  """install() after a reference module of the same name was already imported from elsewhere: refused, not half-applied."""
+  import types
+  from gnpde_amd import dropin
+  assert not dropin.installed()
+  monkeypatch.setitem(sys.modules, 'block_constant', types.ModuleType('block_constant'))
+  with pytest.raises(ImportError):
+    dropin.install()
+  assert not dropin.installed()
+  monkeypatch.delitem(sys.modules, 'block_constant')
+  try:
+    served = dropin.install(native_gnn=True)
+    assert 'GNN' in served and sys.modules['block_mixed'] is G.block_mixed
+    import base_classes                                   # no reference file on sys.path: this package's types alone
+    assert base_classes.ODEblock is G.ODEblock and base_classes.__gnpde_reference__ is None
+  finally:
+    dropin.uninstall()
+  assert not dropin.installed() and 'block_mixed' not in sys.modules and 'base_classes' not in sys.modules

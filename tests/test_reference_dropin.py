@@ -1,7 +1,6 @@
-"""Container-only: the reference's own GNN.py / model_configurations.py pick up the MI355X classes when
-graph-neural-pde_amd/dropin precedes the reference's src/ on sys.path, and the resulting model's state_dict
-interchanges with the fixture recorded from the pure reference model.  Skipped where /root/reference is
-absent (the GPU box)."""
+"""Container-only: the reference's own GNN.py / GNN_early.py / model_configurations.py pick up the MI355X classes once
+gnpde_amd.dropin.install() answers the reference's module names, and the resulting model's state_dict interchanges
+with the fixture recorded from the pure reference model.  Skipped where /root/reference is absent (the GPU box)."""
 import os
 import subprocess
 import sys
@@ -19,14 +18,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import ref_env
 import gnpde_amd
-sys.path.insert(0, os.path.join(ROOT, 'graph-neural-pde_amd', 'dropin'))
-ref_env.activate()                      # stand-ins + reference src appended AFTER the drop-in directory
+import gnpde_amd.dropin as dropin
+ref_env.activate()                      # stand-ins + reference src on sys.path
+served = dropin.install(native_gnn=True)
+assert 'base_classes' in served and 'block_constant' in served and dropin.installed()
 import torch
 from helpers import Fixture
 import importlib.util
 spec = importlib.util.spec_from_file_location('_reference_GNN', os.path.join(ref_env.REFERENCE_ROOT, 'src', 'GNN.py'))
 ref_gnn = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_gnn)
-from GNN import GNN as NativeGNN        # dropin/GNN.py: fused encoder / decoder launches
+from GNN import GNN as NativeGNN        # install(native_gnn=True): fused encoder / decoder launches
 assert NativeGNN.__module__ == 'gnpde_amd.GNN'
 GNN = ref_gnn.GNN                       # the reference's model, unmodified, over the drop-in blocks / functions
 from utils import DummyDataset          # the reference's utils
@@ -61,6 +62,10 @@ early.set_solver_m2()
 assert integ.m2_weight.shape == early.m2.weight.shape
 from model_configurations import set_block
 assert set_block(dict(opt, block='rewire_attention')).__module__.startswith('gnpde_amd')
+import base_classes                      # merged: the reference's BaseGNN / registry, this package's hot-path types
+assert base_classes.ODEFunc is gnpde_amd.base_classes.ODEFunc and base_classes.ODEblock is gnpde_amd.base_classes.ODEblock
+assert base_classes.BaseGNN.__module__ == '_reference_base_classes' and base_classes.__gnpde_reference__.endswith('src/base_classes.py')
+assert issubclass(GNNEarly, base_classes.BaseGNN)
 print('DROPIN_OK')
 '''
 
