@@ -22,7 +22,7 @@ ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4 = range(2)
 TUNE_SPMM_VARIANT, TUNE_FUSED_BLOCKS_PER_CU, TUNE_ONE_PASS, TUNE_FORK, TUNE_ATT_GENERIC_ROWS, TUNE_RK4_CLASSIC = range(6)
-TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING = 6, 7, 8
+TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING, TUNE_SPMM_PART, TUNE_XCD_ROWS = 6, 7, 8, 9, 10
 
 ATT_TYPES = {'scaled_dot': ATT_SCALED_DOT, 'cosine_sim': ATT_COSINE, 'pearson': ATT_PEARSON,
              'exp_kernel': ATT_EXP_KERNEL}
@@ -36,7 +36,8 @@ class GraphStruct(ctypes.Structure):
               ('long_rows', c_vp), ('long_chunk_ptr', c_vp), ('long_chunk_row', c_vp),
               ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp),
               ('n_long_cols', ctypes.c_int32), ('n_bin16', ctypes.c_int32), ('n_bin64', ctypes.c_int32),
-              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('row_begin', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp)]
+              ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('row_begin', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp),
+              ('xcd_deal', ctypes.c_int32)]
 
 
 class EpilogueStruct(ctypes.Structure):
@@ -74,6 +75,7 @@ class HaloStruct(ctypes.Structure):
               ('send_idx', c_vp), ('send_counts', c_int_p), ('recv_counts', c_int_p)]
 
 
+XCD_CONTIGUOUS, XCD_HASHED = 0, 1
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 128
 EARLY_STATE_INTS = 8 + 3 * 2048
@@ -87,6 +89,7 @@ PROTOTYPES = {
   'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 15),
   'gnpde_partition_rows': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_uint64, c_vp]),
+  'gnpde_xcd_row_map': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_int_p, c_int_p, c_vp]),
   'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),
   'gnpde_spmm_rhs': (ctypes.c_int, [ctypes.POINTER(GraphStruct), c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.POINTER(EpilogueStruct), c_vp, ctypes.c_size_t, c_vp]),

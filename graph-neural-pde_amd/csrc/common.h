@@ -59,6 +59,35 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
   return (b % kXcds) * per + (b / kXcds);
 }
 
+// Rows -> XCDs of the aggregation launches (csrc/spmm.hip explains why): the rows [row_begin, row_end) are dealt in blocks of
+// 2^shift consecutive rows; eight consecutive blocks form a group and the eight XCDs take the blocks of group j in an order
+// rotated by a hash of j:  block(x, j) = 8 j + ((x + hash(j)) mod 8)  -- a bijection for any hash.  shift < 0: contiguous
+// eighths.  Host + device, so that the host tests exercise the code the kernels run
+// (gnpde_xcd_row_map).
+static_assert((kXcds & (kXcds - 1)) == 0, "xcd_row_of rotates inside groups of kXcds blocks");
+
+// length of an XCD's row list (an upper bound with hashed blocks: entries past the last row are invalid)
+__host__ __device__ __forceinline__ int xcd_rows_per(int rn, int shift) {
+  if (shift < 0) return (rn + kXcds - 1) / kXcds;
+  const int nb = (rn + (1 << shift) - 1) >> shift;
+  return ((nb + kXcds - 1) / kXcds) << shift;
+}
+
+// r-th row of the list of XCD x, or -1
+__host__ __device__ __forceinline__ int xcd_row_of(int row_begin, int row_end, int shift, int x, int r) {
+  if (shift < 0) {
+    const int per = (row_end - row_begin + kXcds - 1) / kXcds;
+    if (r >= per) return -1;
+    const int row = row_begin + x * per + r;
+    return row < row_end ? row : -1;
+  }
+  const int j = r >> shift, i = r & ((1 << shift) - 1);
+  const unsigned rot = (static_cast<unsigned>(j) * 2654435761u) >> 29;                 // top bits of a multiplicative hash: 0..7
+  const int b = j * kXcds + static_cast<int>((static_cast<unsigned>(x) + rot) & static_cast<unsigned>(kXcds - 1));
+  const long long row = static_cast<long long>(row_begin) + (static_cast<long long>(b) << shift) + i;
+  return row < row_end ? static_cast<int>(row) : -1;
+}
+
 // kernel-variant knobs for A/B measurements (gnpde_tune); 0 = the default variant
 enum {
   GNPDE_TUNE_SPMM_VARIANT = 0,         // aggregation kernel <L,K,U,nontemporal> variant (tools/spmm_ab.py)
@@ -71,6 +100,7 @@ enum {
   GNPDE_TUNE_ONE_PASS_VARIANT = 7,     // register / unroll variants of the one-pass kernel (tools/onepass_ab.py)
   GNPDE_TUNE_LINEAR_STREAMING = 8,     // 1: one-tile-per-wave projection kernel instead of the persistent one
   GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)
+  GNPDE_TUNE_XCD_ROWS = 10,            // 0: as gnpde_graph_t.xcd_deal says; 1: contiguous eighths for every graph; 2: hashed blocks for every graph
   GNPDE_TUNE_COUNT = 16
 };
 extern int g_tune[GNPDE_TUNE_COUNT];

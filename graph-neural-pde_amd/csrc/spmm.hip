@@ -33,21 +33,35 @@ struct SpmmArgs {
   float* partial;        // [n_long_chunks, ldp]
   int ldp;
   int short_rows;        // host-side hint: at least half of the rows have <= 16 entries (-> row pairs for d = 68..128)
+  int row_shift;         // rows are dealt to the XCDs in blocks of 2^row_shift rows (xcd_row); < 0: contiguous eighths
   gnpde_epilogue_t ep;
 };
 
 
 // Work item of wave `lw` (index local to the XCD) of a block that runs on XCD x = blockIdx % 8.  Every XCD gets every
 // 8th long-row chunk FIRST (512 entries each = the longest-running waves: they start at time 0 and overlap with
-// everything else instead of forming the kernel's tail) and then a CONTIGUOUS eighth of the rows, so that rows that are
-// neighbours in the (locality-ordered) graph share that XCD's 4 MiB L2.  (Handing the chunks out contiguously put all
-// of them -- 58 % of the entries of the R-MAT graph, 10 % at the ogbn-arxiv shape -- on XCD 0: 42 ms instead of 18.)
+// everything else instead of forming the kernel's tail) and then its share of the rows.  (Handing the chunks out
+// contiguously put all of them -- 58 % of the entries of the R-MAT graph, 10 % at the ogbn-arxiv shape -- on XCD 0: 42 ms
+// instead of 18.)
+//
+// Rows -> XCDs (gnpde_graph_t.xcd_deal).  CONTIGUOUS: every XCD takes a contiguous eighth of the rows, so that rows that are
+// neighbours in a locality-ordered graph share that XCD's 4 MiB L2.  That is only balanced when the row length does not
+// depend on the row id: in an R-MAT graph the expected degree falls by a factor 0.32 with every set bit of the id, so
+// the eighth with the top bits 000 holds 7.5x the entries of the eighth with 111 (8.9 M vs 1.2 M non-hub entries at the 2^21
+// shape) and the launch lasts as long as XCD 0 needs: 1.46x the balanced time by the work model (entries + 3 per row, hub
+// chunks included; tools/xcd_balance.py).  Real graphs have the same trait (ids in order of publication, crawl or degree).
+// HASHED (chosen by the graph builder when the contiguous deal is more than 3 % out of balance): the rows are dealt in BLOCKS of B = 2^row_shift consecutive rows (16 .. 128: the rows of a pair, and a stretch of
+// neighbouring rows, stay on one XCD), eight consecutive blocks form a group, and the eight XCDs take the blocks of group j in an order
+// rotated by a hash of j:   block(x, j) = 8 j + ((x + hash(j)) mod 8).   A fixed rotation (plain round robin) would keep the
+// R-MAT skew -- it only selects three OTHER id bits -- the hashed one leaves 0.1 - 0.5 % (same tool).  A bijection for any
+// hash, so every row is still taken exactly once; which XCD takes it does not enter the arithmetic (bit-identical results).
 struct Item { int row, e0, e1, chunk; bool valid; };
 
 __device__ __forceinline__ int chunks_of_xcd(const SpmmArgs& a, int x) {
   return (a.chunk_end - a.chunk_begin + kXcds - 1 - x) / kXcds;
 }
-__device__ __forceinline__ int rows_per_xcd(const SpmmArgs& a) { return (a.row_end - a.row_begin + kXcds - 1) / kXcds; }
+__device__ __forceinline__ int rows_per_xcd(const SpmmArgs& a) { return xcd_rows_per(a.row_end - a.row_begin, a.row_shift); }
+__device__ __forceinline__ int xcd_row(const SpmmArgs& a, int x, int r) { return xcd_row_of(a.row_begin, a.row_end, a.row_shift, x, r); }
 
 __device__ __forceinline__ Item item_of(const SpmmArgs& a, int x, int lw) {
   Item it;
@@ -63,21 +77,31 @@ __device__ __forceinline__ Item item_of(const SpmmArgs& a, int x, int lw) {
     it.valid = true;
     return it;
   }
-  const int per = rows_per_xcd(a);
-  const int r = lw - cx;
-  if (r >= per) return it;
-  it.row = a.row_begin + x * per + r;
-  if (it.row >= a.row_end) return it;
+  const int row = xcd_row(a, x, lw - cx);
+  if (row < 0) return it;
+  it.row = row;
   it.e0 = __builtin_amdgcn_readfirstlane(a.rowptr[it.row]);
   it.e1 = __builtin_amdgcn_readfirstlane(a.rowptr[it.row + 1]);
   it.valid = it.e1 - it.e0 <= GNPDE_LONG_ROW;   // longer rows are processed as chunks
   return it;
 }
 
+// Block size of the row -> XCD deal: blocks of 16 .. 128 rows, >= 8192 of them where the graph is large enough (the more
+// blocks an XCD draws, the closer the hash brings heavy-tailed row lengths to the mean: 0.2 % at the R-MAT shape with
+// 16 384 blocks of 128, 5 % with 2 048 blocks of 1 024); always even (row pairs stay together).
+inline int choose_row_shift(long long rn, int graph_deal) {
+  const int knob = g_tune[GNPDE_TUNE_XCD_ROWS];           // A/B: 1 = contiguous eighths, 2 = hashed blocks, whatever the graph says
+  const bool hashed = knob == 2 || (knob != 1 && graph_deal == GNPDE_XCD_HASHED);
+  if (!hashed) return -1;
+  int s = 4;
+  while (s < 7 && (rn >> (s + 1)) >= 8192) ++s;
+  return s;
+}
+
 // blocks of WPB waves so that every XCD can reach the end of its local list
 inline unsigned balanced_grid(const SpmmArgs& a, int wpb) {
   const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
-  const long long per_xcd = (cn + kXcds - 1) / kXcds + (rn + kXcds - 1) / kXcds;
+  const long long per_xcd = (cn + kXcds - 1) / kXcds + xcd_rows_per(static_cast<int>(rn), a.row_shift);
   long long blocks = (per_xcd + wpb - 1) / wpb;
   if (blocks < 1) blocks = 1;
   return static_cast<unsigned>(blocks * kXcds);
@@ -471,11 +495,9 @@ __global__ __launch_bounds__(BLK) void spmm_pair_kernel(const SpmmArgs a) {
   const int per = rows_per_xcd(a);
   const int r0 = 2 * (lw - cx);
   if (r0 >= per) return;
-  const int first = a.row_begin + xcd * per;
-  int last = first + per;                       // exclusive end of this XCD's rows
-  if (last > a.row_end) last = a.row_end;
-  int row = first + r0 + half;
-  bool have = row < last;
+  int row = xcd_row(a, xcd, r0 + half);         // r0 is even and the blocks have an even size: both rows of a pair are consecutive
+  bool have = row >= 0;
+  if (!have) row = 0;
   int e0 = 0, e1 = 0;
   if (have) {
     e0 = a.rowptr[row];
@@ -927,7 +949,7 @@ template <int VEC, int U, int BLK>
 void launch_pair(const SpmmArgs& a, hipStream_t s) {
   constexpr int WPB = BLK / kWave;
   const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
-  const long long per = (rn + kXcds - 1) / kXcds;
+  const long long per = xcd_rows_per(static_cast<int>(rn), a.row_shift);
   const long long per_xcd = (cn + kXcds - 1) / kXcds + (per + 1) / 2;
   long long blocks = (per_xcd + WPB - 1) / WPB;
   if (blocks < 1) blocks = 1;
@@ -948,8 +970,10 @@ void launch_pair_pipe(const SpmmArgs& a, hipStream_t s, int waves_per_cu) {
   if (blocks > resident) blocks = resident;
   if (blocks < 1) blocks = 1;
   const unsigned grid = static_cast<unsigned>(blocks * kXcds);
-  if (a.d == 32 * VEC) hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, true>), dim3(grid), dim3(BLK), 0, s, a);
-  else hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, false>), dim3(grid), dim3(BLK), 0, s, a);
+  SpmmArgs c = a;
+  c.row_shift = -1;   // this (A/B only) kernel walks a contiguous range of row pairs per XCD
+  if (a.d == 32 * VEC) hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, true>), dim3(grid), dim3(BLK), 0, s, c);
+  else hipLaunchKernelGGL((spmm_pair_pipe_kernel<VEC, U, BLK, true, false>), dim3(grid), dim3(BLK), 0, s, c);
 }
 
 // tune codes >= 100 (tools/spmm_ab.py): 100 + 10 * {0: U4, 1: U8, 2: U16} + {0: 256 thr, 1: 64 thr, 2: 256 thr persistent,
@@ -1275,6 +1299,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
   a.short_rows = 2LL * g->n_bin16 >= g->n ? 1 : 0;
   a.row_begin = g->row_begin;
   a.row_end = g->n;
+  a.row_shift = choose_row_shift(static_cast<long long>(a.row_end) - a.row_begin, g->xcd_deal);
   if (g_tune[GNPDE_TUNE_SPMM_PART] == 1) a.row_end = a.row_begin;       // (timing the two kinds of work items separately)
   if (g_tune[GNPDE_TUNE_SPMM_PART] == 2) a.chunk_end = 0;
   int rc = run(a, stream);
@@ -1336,6 +1361,7 @@ int launch_attn_spmm(const gnpde_graph_t* g, const gnpde_attention_t* at, const 
   a.partial = static_cast<float*>(ws);
   a.ep = *epi;
   a.chunk_begin = 0; a.chunk_end = g->n_long_chunks; a.row_begin = 0; a.row_end = g->n;
+  a.row_shift = choose_row_shift(g->n, g->xcd_deal);
   if (g->n_long_chunks > 0) {
     const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
     GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need && w_hub_csr != nullptr, GNPDE_EWS, "attn_spmm: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1360,6 +1386,20 @@ int launch_attn_spmm(const gnpde_graph_t* g, const gnpde_attention_t* at, const 
 }
 
 }  // namespace gnpde
+
+extern "C" int gnpde_xcd_row_map(int32_t row_begin, int32_t row_end, int32_t deal, int32_t* row_shift, int32_t* rows_per_xcd,
+                                 int32_t* map) {
+  GNPDE_CHECK_ARG(row_begin >= 0 && row_end >= row_begin && row_shift && rows_per_xcd &&
+                  (deal == GNPDE_XCD_CONTIGUOUS || deal == GNPDE_XCD_HASHED), GNPDE_EINVAL, "xcd_row_map: bad arguments");
+  const int shift = gnpde::choose_row_shift(static_cast<long long>(row_end) - row_begin, deal);
+  const int per = gnpde::xcd_rows_per(row_end - row_begin, shift);
+  *row_shift = shift;
+  *rows_per_xcd = per;
+  if (map != nullptr)
+    for (int x = 0; x < gnpde::kXcds; ++x)
+      for (int r = 0; r < per; ++r) map[static_cast<size_t>(x) * per + r] = gnpde::xcd_row_of(row_begin, row_end, shift, x, r);
+  return 0;
+}
 
 extern "C" size_t gnpde_spmm_workspace_bytes(const gnpde_graph_t* g, int32_t d) {
   if (!g || d < 1) return 0;

@@ -112,18 +112,16 @@ class NativeBackend(object):
     self.ops, self.dev, self.kind, self.d = ops, torch.device(device), kind, d
     self.shard = shard
     self.graph = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
-    self.graph.struct.n = shard.n_own            # rows to process; columns may address halo rows
-    self.graph.n = shard.n_own
+    self.graph.set_row_range(0, shard.n_own)     # rows to process; columns may address halo rows
     # interior / boundary views for the overlapped evaluation: the same local numbering, each holding only its
     # rows' edges; the boundary view aggregates rows [n_interior, n_own)
     inter = shard.edge_index[0] < shard.n_interior
     self.eid_int = torch.nonzero(inter).flatten()
     self.eid_bnd = torch.nonzero(~inter).flatten()
     self.g_int = CSRGraph(shard.edge_index[:, inter], shard.n_local, device=self.dev)
-    self.g_int.struct.n = self.g_int.n = shard.n_interior
+    self.g_int.set_row_range(0, shard.n_interior)
     self.g_bnd = CSRGraph(shard.edge_index[:, ~inter], shard.n_local, device=self.dev)
-    self.g_bnd.struct.n = self.g_bnd.n = shard.n_own
-    self.g_bnd.struct.row_begin = shard.n_interior
+    self.g_bnd.set_row_range(shard.n_interior, shard.n_own)
     self.supports_split = True
     self.alpha = alpha.detach().to(self.dev, torch.float32).reshape(-1)
     self.beta = beta.detach().to(self.dev, torch.float32).reshape(-1)

@@ -108,7 +108,18 @@ typedef struct gnpde_graph {
   const int32_t* long_cols;          /* [n_long_cols] or NULL                                */
   const int32_t* bin_rows;           /* [(n_bin16 + n_bin64) * 4] records {row, begin, len, 0} */
   const int32_t* long_chunk_first;   /* [n_long_chunks] index of the first chunk of the same row */
+  int32_t xcd_deal;                  /* how the aggregation launches deal the rows to the 8 XCDs (gnpde_xcd_row_map):
+                                        GNPDE_XCD_CONTIGUOUS or GNPDE_XCD_HASHED; chosen per graph by whoever builds it */
 } gnpde_graph_t;
+
+/* gnpde_graph_t.xcd_deal.  CONTIGUOUS: XCD x takes the x-th eighth of the rows -- neighbouring rows share an XCD's L2, and the
+ * deal is balanced as long as the row length does not depend on the row id.  HASHED: blocks of 16 .. 128 consecutive rows, the
+ * eight blocks of a group taken by the eight XCDs in an order rotated by a hash of the group -- balanced whatever the ids mean
+ * (R-MAT: the expected degree falls 3x with every set id bit, contiguous eighths leave the launch 1.46x out of balance; ids in
+ * order of time, crawl or degree do the same to real graphs).  The Python layer measures the contiguous deal's imbalance when it
+ * builds a graph (work model: entries + 3 per row) and switches to HASHED above 3 %. */
+#define GNPDE_XCD_CONTIGUOUS 0
+#define GNPDE_XCD_HASHED     1
 
 /* ------------------------------------------------------------------------------------------------
  * Epilogue of one right-hand-side evaluation, optionally fused with the solver's stage algebra.
@@ -165,6 +176,16 @@ typedef struct gnpde_epilogue {
                               (fl32 product): coef[] = fl32(beta_j), *coef_scale = fl32(dt) kept on the device by the
                               adaptive controller (gnpde_dopri5_*), so that a captured step serves every step size */
 } gnpde_epilogue_t;
+
+/* Host-side query of the work distribution of the aggregation launches (no reference equivalent; used by the host tests and
+ * by tools/xcd_balance.py).  Workgroup b of a launch runs on XCD b % 8; every XCD walks its own list of rows.  deal =
+ * GNPDE_XCD_HASHED: the rows [row_begin, row_end) are dealt in blocks of 2^*row_shift consecutive rows, eight consecutive blocks
+ * form a group and XCD x takes block 8 j + ((x + hash(j)) mod 8) of group j; GNPDE_XCD_CONTIGUOUS: *row_shift = -1, XCD x takes
+ * the x-th eighth (gnpde_tune(10, 1 / 2) overrides the argument with CONTIGUOUS / HASHED, as it overrides gnpde_graph_t.xcd_deal
+ * in the launches).  *rows_per_xcd: length of every XCD's list; map (NULL, or [8 * *rows_per_xcd]): map[x * *rows_per_xcd + r]
+ * = the r-th row of XCD x, or -1 past the end.  Every row appears exactly once; the two rows of an even-aligned pair (r, r + 1)
+ * are consecutive. */
+int gnpde_xcd_row_map(int32_t row_begin, int32_t row_end, int32_t deal, int32_t* row_shift, int32_t* rows_per_xcd, int32_t* map);
 
 /* Bytes of scratch gnpde_spmm_rhs needs for the long-row partial sums (0 if no long rows). */
 size_t gnpde_spmm_workspace_bytes(const gnpde_graph_t* g, int32_t d);
