@@ -205,7 +205,7 @@ def lib():
       fn = getattr(handle, name)
       fn.restype = res
       fn.argtypes = args
-    if handle.gnpde_abi_version() != 1:
+    if handle.gnpde_abi_version() != 2:
       raise RuntimeError('libgnpde_hip.so ABI version mismatch')
     _lib = handle
   return _lib

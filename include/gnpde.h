@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 1
+#define GNPDE_ABI_VERSION 2   /* 2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map */
 
 #define GNPDE_EINVAL   (-1)  /* bad argument                                  */
 #define GNPDE_ESHAPE   (-2)  /* shape not supported by any kernel variant     */

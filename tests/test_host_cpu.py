@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), 'libgnpde_hip.so does not export %s' % name
   assert declared == set(_lib.PROTOTYPES), 'ctypes prototypes out of sync with gnpde.h'
-  assert G.lib().gnpde_abi_version() == 1
+  assert G.lib().gnpde_abi_version() == 2
 
 
 def test_every_entry_point_is_documented():
