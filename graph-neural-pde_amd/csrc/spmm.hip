@@ -1111,22 +1111,21 @@ struct SddmmArgs {
   const float* __restrict__ scale_ptr;
   int scale_sigmoid;
   float* __restrict__ out;
+  int row_shift;         // rows -> XCDs as in the aggregation (xcd_row_of): < 0 contiguous eighths, else hashed blocks of 2^row_shift rows
 };
 
 template <int VEC, int L, int K, int U>
 __global__ __launch_bounds__(kBlock) void sddmm_kernel(const SddmmArgs s) {
   constexpr int G = kWave / L;
   const int lane = threadIdx.x & (kWave - 1);
-  // same XCD-balanced work list as the aggregation (item_of): every 8th chunk first, then a contiguous eighth of the rows
+  // same XCD-balanced work list as the aggregation (item_of): every 8th chunk first, then this XCD's share of the rows
   const int x = static_cast<int>(blockIdx.x % kXcds);
   const int lw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / kXcds) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
   const int cx = (s.n_long_chunks + kXcds - 1 - x) / kXcds;
-  const int per = (s.n + kXcds - 1) / kXcds;
   int row, e0, e1;
   if (lw >= cx) {
-    if (lw - cx >= per) return;
-    row = x * per + (lw - cx);
-    if (row >= s.n) return;
+    row = xcd_row_of(0, s.n, s.row_shift, x, lw - cx);
+    if (row < 0) return;
     e0 = s.rowptr[row];
     e1 = s.rowptr[row + 1];
     if (e1 - e0 > GNPDE_LONG_ROW) return;  // processed as chunks
@@ -1191,7 +1190,8 @@ int dispatch_sddmm(const gnpde_graph_t* g, const float* a, const float* b, int d
   s.rowptr = g->rowptr; s.colidx = g->colidx;
   s.lc_row = g->long_chunk_row; s.lc_begin = g->long_chunk_begin; s.lc_end = g->long_chunk_end;
   s.a = a; s.b = b; s.d = d; s.lda = lda; s.ldb = ldb; s.scale_ptr = scale; s.scale_sigmoid = scale_sigmoid; s.out = out;
-  const long long per_xcd = (static_cast<long long>(g->n_long_chunks) + kXcds - 1) / kXcds + (static_cast<long long>(g->n) + kXcds - 1) / kXcds;
+  s.row_shift = choose_row_shift(g->n, g->xcd_deal);
+  const long long per_xcd = (static_cast<long long>(g->n_long_chunks) + kXcds - 1) / kXcds + xcd_rows_per(g->n, s.row_shift);
   const unsigned grid = static_cast<unsigned>(((per_xcd + kWavesPerBlock - 1) / kWavesPerBlock) * kXcds);
   const int slots = (d + VEC - 1) / VEC;
 #define GNPDE_SDDMM(LL, KK, UU) hipLaunchKernelGGL((sddmm_kernel<VEC, LL, KK, UU>), dim3(grid), dim3(kBlock), 0, st, s)
