@@ -220,9 +220,12 @@ def main():
   import gnpde_amd as G
   if os.environ.get('GNPDE_ONE_PASS', '0') == '1':
     G.ops.tune(G._lib.TUNE_ONE_PASS, 1)
+  xcd_knob = 0
   for kv in filter(None, os.environ.get('GNPDE_TUNE', '').split(',')):     # A/B knobs, e.g. GNPDE_TUNE=6=2 (separate kernels)
     key, val = kv.split('=')
     G.ops.tune(int(key), int(val))
+    if int(key) == G._lib.TUNE_XCD_ROWS:
+      xcd_knob = int(val)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a HIP device: there is no CPU fallback for the measured path')
   dev = torch.device('cuda', 0 if os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') == '1' else local_rank)
@@ -315,7 +318,13 @@ def main():
                'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
                'attention_norm_idx': args.norm_idx, 'square_plus': args.square_plus,
                'early_stop_evaluator': bool(args.early_stop),
-               'long_rows': graph.n_long_rows, 'algorithmic_bytes_per_rhs_eval': bytes_eval,
+               'long_rows': graph.n_long_rows,
+               # how the aggregation launches deal the rows to the 8 XCDs (gnpde_graph_t.xcd_deal, chosen per graph from the
+               # measured imbalance of contiguous eighths; GNPDE_TUNE=10=1 / 10=2 force one or the other for A/B runs)
+               'xcd_row_deal': {0: 'hashed_blocks' if graph.struct.xcd_deal == 1 else 'contiguous_eighths',
+                                1: 'contiguous_eighths (forced)', 2: 'hashed_blocks (forced)'}.get(xcd_knob, '?'),
+               'xcd_contiguous_imbalance': round(graph.xcd_imbalance_contiguous, 4),
+               'algorithmic_bytes_per_rhs_eval': bytes_eval,
                'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
     'roofline': {'kernel': kname, 'bound': 'hbm',
                  'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
