@@ -275,3 +275,46 @@ def test_lincomb(dev, n):
     inplace = base.clone()
     ops.lincomb(inplace, [(vs[0], 2.0)], out=inplace)
     assert torch.allclose(inplace, base + 2.0 * vs[0], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('d', [64, 128, 256])
+def test_spmm_row_deal_over_the_xcds(dev, d):
+  """Which XCD takes a row does not enter the arithmetic: on a graph whose row length depends on the bits of the row id (as
+  in an R-MAT graph) the builder picks the hashed-block deal, and the aggregation gives the SAME bits as with contiguous
+  eighths forced (gnpde_tune(10, 1)), hub rows and rk4 stage epilogue included, and agrees with the oracle (csrc/spmm.hip
+  "Rows -> XCDs", tools/xcd_check.py; the builder's choice itself is covered on the host, tests/test_host_cpu.py)."""
+  import numpy as np
+  n = 1 << 16
+  ids = np.arange(n)
+  pop = np.zeros(n, dtype=np.int64)
+  for b in range(16):
+    pop += (ids >> b) & 1
+  deg = np.minimum(np.maximum((2000.0 * 0.316 ** pop).astype(np.int64), 1), 700)     # 17 hub rows (> 512 entries)
+  gen = np.random.default_rng(d)
+  row = np.repeat(ids, deg)
+  col = gen.integers(0, n, row.size)
+  ei = torch.from_numpy(np.stack([row, col]))
+  g = torch.Generator().manual_seed(d)
+  w = _weights(ei.size(1), d)
+  x, x0, y = (torch.randn(n, d, generator=g) for _ in range(3))
+  alpha, beta = torch.tensor(0.3), torch.tensor(-0.7)
+  graph = G.CSRGraph(ei.to(dev), n)
+  assert graph.struct.xcd_deal == _lib.XCD_HASHED and graph.xcd_imbalance_contiguous > 1.5 and graph.n_long_rows > 0
+  w_csr = ops.edge_to_csr_mean(graph, w.to(dev))
+  xd, x0d, yd = x.to(dev), x0.to(dev), y.to(dev)
+
+  def run():
+    f = ops.spmm_rhs(graph, w_csr, xd, alpha.to(dev), beta.to(dev), x0d, True).clone()
+    u2 = torch.empty_like(xd)
+    ops.spmm_rhs(graph, w_csr, xd, alpha.to(dev), beta.to(dev), x0d, True, stage=_lib.STAGE_RK2C, dt=0.7, y=yd, out_y=u2)
+    return f, u2
+  hashed = run()
+  try:
+    _lib.check(_lib.lib().gnpde_tune(_lib.TUNE_XCD_ROWS, 1))
+    contiguous = run()
+  finally:
+    _lib.check(_lib.lib().gnpde_tune(_lib.TUNE_XCD_ROWS, 0))
+  assert torch.equal(hashed[0], contiguous[0]) and torch.equal(hashed[1], contiguous[1])
+  ref = R.rhs_laplacian(x, ei, w, alpha, beta, x0, no_alpha_sigmoid=False, add_source=True)
+  assert_parity(hashed[0], ref, what='spmm_rhs, hashed row deal, d=%d' % d)
+  assert_parity(hashed[1], (2 * y - x) + 0.7 * ref, what='RK2C stage, hashed row deal, d=%d' % d)
