@@ -55,6 +55,7 @@ struct AttArgs {
   const int* __restrict__ long_segs;
   const int* __restrict__ rowptr;
   const int* __restrict__ bin_rows;
+  int hub_fold_lds;   // gnpde_tune(11, 1): see hub_normalise_body
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -454,18 +455,40 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
                                                    const int* __restrict__ long_chunk_row_first, int c) {
   // long_chunk_row_first[c] = index of the first chunk of the row chunk c belongs to
   __shared__ float st[2 * 64];  // [2h]: row maximum and denominator per head
+  constexpr int kStage = 2048;  // floats of chunk partials staged through LDS (a row of up to 2048 / 2h chunks)
+  __shared__ float sp[kStage];
   const int b = a.chunk_begin[c], e = a.chunk_end[c];
   const int row = a.rowidx[b];
   const int c0 = long_chunk_row_first[c];
   const int nch = (a.rowptr[row + 1] - a.rowptr[row] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+  // The fold below is a chain of 2 nch DEPENDENT-latency loads issued by h threads (the compiler keeps two in flight): 22
+  // chunks of the largest hub of the ogbn-arxiv shape = ~20 round trips before any of the block's 512 weights can be written,
+  // repeated by every chunk block of the row.  Staged form (opt-in until it has been timed, gnpde_tune(11, 1)): the whole
+  // block fetches the row's partials in ONE round trip into LDS and the h folding threads read them from there -- the same
+  // values combined in the same order, so the weights are bit-identical.
+  const int nval = nch * 2 * a.h;                   // block-uniform
+  const bool staged = a.hub_fold_lds != 0 && nval <= kStage;
+  if (staged) {
+    const float* src = part + static_cast<size_t>(c0) * 2 * a.h;
+    for (int t = threadIdx.x; t < nval; t += kBlock) sp[t] = src[t];
+    __syncthreads();
+  }
   if (threadIdx.x < a.h) {
     const int head = threadIdx.x;
     float m = -INFINITY;
-    for (int i = 0; i < nch; ++i) m = fmaxf(m, part[static_cast<size_t>(c0 + i) * 2 * a.h + head]);
     float l = 0.f;
-    for (int i = 0; i < nch; ++i) {
-      const float* q = part + static_cast<size_t>(c0 + i) * 2 * a.h;
-      l += q[a.h + head] * expf(q[head] - m);
+    if (staged) {
+      for (int i = 0; i < nch; ++i) m = fmaxf(m, sp[i * 2 * a.h + head]);
+      for (int i = 0; i < nch; ++i) {
+        const float* q = sp + i * 2 * a.h;
+        l += q[a.h + head] * expf(q[head] - m);
+      }
+    } else {
+      for (int i = 0; i < nch; ++i) m = fmaxf(m, part[static_cast<size_t>(c0 + i) * 2 * a.h + head]);
+      for (int i = 0; i < nch; ++i) {
+        const float* q = part + static_cast<size_t>(c0 + i) * 2 * a.h;
+        l += q[a.h + head] * expf(q[head] - m);
+      }
     }
     st[head] = m;
     st[a.h + head] = l + 1e-16f;
@@ -913,6 +936,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.gmax = reinterpret_cast<unsigned*>(base + L.gmax);
   a.gat_terms = reinterpret_cast<float*>(base + L.gat);
   a.w_mean = w_mean_csr; a.att_edge = att_edge; a.prods_edge = prods_edge;
+  a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 1 ? 1 : 0;
   float* part = reinterpret_cast<float*>(base + L.part);
 
   if (a.square_plus) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
