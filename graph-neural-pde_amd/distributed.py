@@ -702,7 +702,8 @@ def bench_main(args, rank, world, dev):
   dist.all_reduce(el, op=dist.ReduceOp.MAX)
   finite = torch.tensor([1.0 if bool(torch.isfinite(y).all()) else 0.0], device=red)
   dist.all_reduce(finite, op=dist.ReduceOp.MIN)
-  halo = torch.tensor([float(shard.n_halo), float(shard.n_own), float(shard.edge_index.shape[1])], device=red)
+  halo = torch.tensor([float(shard.n_halo), float(shard.n_own), float(shard.edge_index.shape[1]),
+                       float(max(shard.recv_counts) if shard.recv_counts else 0), float(shard.n_interior)], device=red)
   halo_max = halo.clone()
   dist.all_reduce(halo_max, op=dist.ReduceOp.MAX)
   if rank == 0:
@@ -727,7 +728,13 @@ def bench_main(args, rank, world, dev):
                  'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
                  'rhs_evals_per_step': 4, 'edge_cut': round(plan.edge_cut(), 4),
                  'max_halo_rows': int(halo_max[0].item()), 'max_owned_rows': int(halo_max[1].item()),
-                 'max_local_edges': int(halo_max[2].item()), 'partition_seconds': round(t_plan, 2),
+                 'max_local_edges': int(halo_max[2].item()),
+                 # what one evaluation moves: every rank receives its halo rows (4 d bytes each) before its boundary rows can be
+                 # evaluated; xGMI is point to point, so the rows that come from ONE peer share one link
+                 'max_rows_from_one_peer': int(halo_max[3].item()),
+                 'max_bytes_on_one_link_per_evaluation': int(halo_max[3].item()) * 4 * d,
+                 'max_interior_rows': int(halo_max[4].item()),
+                 'partition_seconds': round(t_plan, 2),
                  'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared,
                  'transport': chosen, 'transports_rejected': notes,
                  'driver': 'python loop' if python_loop else 'native, hipGraph %s' % graph_mode,
