@@ -61,3 +61,38 @@ def test_native_backend_refuses_cpu():
   plan = D.PartitionPlan(ei, n, 2)
   with pytest.raises(G.GnpdeError):
     D.NativeBackend(plan.shard(0), 8, 'cpu', 'laplacian', dict(edge_weight=torch.ones(1)), torch.tensor(0.), torch.tensor(0.))
+
+
+@pytest.mark.parametrize('world', [2, 3, 5, 8])
+def test_push_lands_every_boundary_row_in_the_peers_halo_slot(world):
+  """The P2P transport of the native sharded solver (csrc/sharded.hip, distributed.P2PContext) on the host: rank p pushes
+  the rows send_idx[segment of q] into peer q's stage buffer starting at row n_own_q + sum(recv_counts_q[:p]).  For every
+  pair the counts must agree and the rows that arrive must be, in order, the global nodes q's local graph expects in those
+  halo slots -- simulated here with a global tag per row and NaN-poisoned halos, then checked against the local edge lists."""
+  n = 1200
+  ei = random_graph(n, 7, seed=31 + world, hubs=2, hub_deg=400)
+  plan = D.PartitionPlan(ei, n, world)
+  shards = [plan.shard(r) for r in range(world)]
+  tag = torch.arange(n, dtype=torch.float64) * 3.0 + 1.0                    # a value that identifies the global node
+  bufs = []
+  for s in shards:
+    b = torch.full((s.n_local,), float('nan'), dtype=torch.float64)
+    b[:s.n_own] = tag[s.own_old_ids]
+    bufs.append(b)
+  for p, sp in enumerate(shards):
+    assert sp.send_counts[p] == 0 and sp.recv_counts[p] == 0
+    seg = 0
+    for q, sq in enumerate(shards):
+      cnt = sp.send_counts[q]
+      assert cnt == sq.recv_counts[p], (p, q)
+      row0 = sq.n_own + sum(sq.recv_counts[:p])                                 # P2PContext.peer_row0
+      rows = sp.send_idx[seg:seg + cnt]
+      assert rows.numel() == cnt and (cnt == 0 or int(rows.max()) < sp.n_own)
+      bufs[q][row0:row0 + cnt] = bufs[p][rows]                                  # push_rows_kernel
+      seg += cnt
+    assert seg == int(sp.send_idx.numel())
+  for s, b in zip(shards, bufs):
+    assert not torch.isnan(b).any(), 'a halo slot was never written'
+    # every local column -- owned or halo -- now holds the tag of the global node the edge points to
+    assert torch.equal(b[s.edge_index[1]], tag[ei[1][s.edge_ids]])
+    assert sum(s.recv_counts) == s.n_halo
