@@ -123,11 +123,31 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
       bin_rows[4 * slot + 2] = dg;
       bin_rows[4 * slot + 3] = 0;
     };
+    // Rows of 17..GNPDE_LONG_ROW entries: LONGEST FIRST (ties in row order; a counting sort over the length).  A wavefront
+    // takes one such row and needs one pair of dependent round trips per 64 entries, so a 512-entry row runs ~8x as long as
+    // the typical one: in row order the long rows that happen to start late form the tail of the row-attention launch,
+    // longest-first they start at time 0 and the short rows fill in behind them (ogbn-arxiv shape, wave-slot model of the
+    // launch: 30.6 -> 20.8 us).  The records are processed independently of one another, so their
+    // order does not enter any result.
+    std::vector<int32_t> start(GNPDE_LONG_ROW + 2, 0);
+    for (int32_t i = 0; i < n_nodes; ++i) {
+      const int32_t dg = rowptr[i + 1] - rowptr[i];
+      if (dg > 16 && dg <= GNPDE_LONG_ROW) ++start[dg];
+    }
+    {
+      int32_t pos = n16;                              // slots of length GNPDE_LONG_ROW first, then downwards
+      for (int32_t len = GNPDE_LONG_ROW; len > 16; --len) {
+        const int32_t cnt = start[len];
+        start[len] = pos;
+        pos += cnt;
+      }
+    }
     for (int32_t i = 0; i < n_nodes; ++i) {
       const int32_t dg = rowptr[i + 1] - rowptr[i];
       if (dg >= 1 && dg <= 16) put(p16++, i, dg);
-      else if (dg > 16 && dg <= GNPDE_LONG_ROW) put(p64++, i, dg);
+      else if (dg > 16 && dg <= GNPDE_LONG_ROW) put(start[dg]++, i, dg);
     }
+    (void)p64;
     bin_counts[0] = n16;
     bin_counts[1] = n64;
   }

@@ -70,6 +70,9 @@ def build_arrays_on_device(edge_index, n):
   chunk_end = torch.minimum(chunk_begin + LONG_ROW, rowptr[chunk_row + 1])
   rows16 = torch.nonzero((deg >= 1) & (deg <= 16)).flatten()
   rows64 = torch.nonzero((deg > 16) & (deg <= LONG_ROW)).flatten()
+  # longest first, ties in row order (as csrc/graph_prep.cpp: the long rows of this class start at time 0 of the
+  # row-attention launch instead of forming its tail; the records are independent, their order enters no result)
+  rows64 = rows64[torch.sort(deg[rows64], descending=True, stable=True).indices]
   listed = torch.cat([rows16, rows64])
   bins = torch.stack([listed, rowptr[listed], deg[listed], torch.zeros_like(listed)], dim=1).reshape(-1)
 

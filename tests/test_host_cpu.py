@@ -78,7 +78,9 @@ def test_graph_build_matches_numpy(seed):
   assert np.array_equal(rec[:, 1], g.rowptr.numpy()[rec[:, 0]]) and np.array_equal(rec[:, 2], deg[rec[:, 0]])
   b16, b64 = rec[:g.n_bin16, 0], rec[g.n_bin16:, 0]
   assert np.array_equal(b16, np.nonzero((deg >= 1) & (deg <= 16))[0])
-  assert np.array_equal(b64, np.nonzero((deg > 16) & (deg <= _lib.LONG_ROW))[0])
+  # rows of 17..512 entries: longest first, ties in row order (the long rows start the row-attention launch, not its tail)
+  in64 = np.nonzero((deg > 16) & (deg <= _lib.LONG_ROW))[0]
+  assert np.array_equal(b64, in64[np.argsort(-deg[in64], kind='stable')])
   cdeg = np.bincount(col, minlength=n)
   assert np.array_equal(g.t['long_cols'][:g.n_long_cols].numpy(), np.nonzero(cdeg > _lib.LONG_ROW)[0])
 
@@ -487,3 +489,29 @@ def test_xcd_deal_is_chosen_per_graph():
   assert g_skewed.struct.xcd_deal == _lib.XCD_CONTIGUOUS and g_skewed.xcd_imbalance_contiguous == 1.0
   with pytest.raises(G.GnpdeError):
     g_skewed.set_row_range(5, n + 1)
+
+
+def test_row_records_of_the_wave_per_row_class_are_longest_first():
+  """Rows of 17..512 entries in a heavy-tailed graph: both builders (host C++ and the torch ops of the device builder) list
+  them by descending length, ties in row order; rows of 1..16 entries stay in row order; every row appears once."""
+  from gnpde_amd.graph import build_arrays_on_device
+  n = 4000
+  gen = np.random.default_rng(3)
+  deg = np.minimum((gen.pareto(1.2, n) * 6 + 1).astype(np.int64), 600)
+  deg[:5] = 0
+  row = np.repeat(np.arange(n), deg)
+  ei = torch.from_numpy(np.stack([row, gen.integers(0, n, row.size)]))
+  ei = ei[:, torch.from_numpy(gen.permutation(row.size))]
+  g = G.CSRGraph(ei, n, device='cpu')
+  rec = g.t['bin_rows'].numpy().reshape(-1, 4)[:g.n_bin16 + g.n_bin64]
+  r16, r64 = rec[:g.n_bin16], rec[g.n_bin16:]
+  assert np.all(np.diff(r16[:, 0]) > 0) and np.all((r16[:, 2] >= 1) & (r16[:, 2] <= 16))
+  assert np.all((r64[:, 2] > 16) & (r64[:, 2] <= _lib.LONG_ROW)) and len(np.unique(r64[:, 2])) > 20
+  assert np.all(np.diff(r64[:, 2]) <= 0)                                       # descending length ...
+  same = np.diff(r64[:, 2]) == 0
+  assert np.all(np.diff(r64[:, 0])[same] > 0)                                  # ... ties in row order
+  assert np.array_equal(np.sort(rec[:, 0]), np.nonzero((deg >= 1) & (deg <= _lib.LONG_ROW))[0])
+  assert np.array_equal(rec[:, 2], deg[rec[:, 0]]) and np.array_equal(rec[:, 1], g.rowptr.numpy()[rec[:, 0]])
+  arrays, counts = build_arrays_on_device(ei, n)
+  assert counts['n_bin16'] == g.n_bin16 and counts['n_bin64'] == g.n_bin64
+  assert np.array_equal(arrays['bin_rows'].numpy()[:4 * len(rec)].reshape(-1, 4), rec)
