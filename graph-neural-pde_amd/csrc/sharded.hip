@@ -123,6 +123,7 @@ struct PushArgs {
   const float* src;            // local stage buffer
   int ld, d, n_send, rank, world;
   const int32_t* send_idx;     // [n_send] local rows, grouped by destination
+  const int32_t* order;        // [n_send] or NULL: the w-th wavefront of the launch copies send slot order[w] (push_order)
   const int32_t* seg;          // [world+1] prefix of the send counts
   float* const* dst;           // [world] base of the SAME stage buffer on every peer
   const long long* dst_row0;   // [world] first halo row of this rank's rows on peer p
@@ -134,8 +135,12 @@ struct PushArgs {
 // the new epoch in every peer's flag array (system-scope release after all row stores of all blocks).
 __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int i = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
-  if (i < a.n_send) {
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  if (w < a.n_send) {
+    // The send list is grouped by destination.  Walked in that order, everything in flight at any moment targets ONE peer:
+    // one xGMI link carries the whole push while the other six idle, and the exchange takes the SUM of the per-link times.
+    // order[] interleaves the destinations (in proportion to their row counts, so that all links finish together).
+    const int i = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[w]) : w;
     int p = 0;
     while (p + 1 < a.world && i >= a.seg[p + 1]) ++p;
     const float* src = a.src + static_cast<size_t>(a.send_idx[i]) * a.ld;
@@ -198,6 +203,7 @@ struct gnpde_sharded_solver {
   long long* d_dst_row0 = nullptr;     // [world]
   float** d_dst[4] = {nullptr, nullptr, nullptr, nullptr};   // per stage buffer: [world] peer bases
   uint32_t** d_peer_ctl = nullptr;     // [world]
+  int32_t* d_order = nullptr;          // [n_send] destination-interleaved walk of the send list (P2P)
   size_t off_tables = 0;
   gnpde_rhs_t rhs_int, rhs_bnd;
   gnpde_graph_t g_int, g_bnd;
@@ -237,7 +243,8 @@ size_t sharded_layout(const gnpde_rhs_t& ri, const gnpde_rhs_t& rb, int method, 
     send = off; off += align_up(static_cast<size_t>(n_send > 0 ? n_send : 1) * ri.d * 4, 256);
   }
   const size_t tables = off;
-  if (p2p) off += align_up(static_cast<size_t>(world + 1) * 4, 256) + 6 * align_up(static_cast<size_t>(world) * 8, 256);
+  if (p2p) off += align_up(static_cast<size_t>(world + 1) * 4, 256) + 6 * align_up(static_cast<size_t>(world) * 8, 256) +
+                  align_up(static_cast<size_t>(n_send > 0 ? n_send : 1) * 4, 256);
   const size_t rhs_off = off;
   const size_t ti = rhs_layout(ri).total, tb = rhs_layout(rb).total;
   off += ti > tb ? ti : tb;
@@ -294,7 +301,7 @@ int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   GNPDE_HIP(hipStreamWaitEvent(x->stream, s->e_pack, 0));
   PushArgs a;
   a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = u != nullptr ? s->n_send : 0; a.rank = x->rank; a.world = x->world;
-  a.send_idx = s->send_idx; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
+  a.send_idx = s->send_idx; a.order = s->d_order; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
   a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl;
   const unsigned grid = static_cast<unsigned>(a.n_send > 0 ? (a.n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
   hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
@@ -531,6 +538,36 @@ extern "C" int gnpde_comm_destroy(gnpde_comm_t* c) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ push order
+// order[w] = slot of the destination-grouped send list that the w-th wavefront of the push copies: the slots of all
+// destinations merged by their relative position (j + 1/2) / count_p inside their own segment (ties: lower rank first), so
+// that at any moment the rows in flight go to ALL peers in proportion to what each is owed and every link finishes at the
+// same time.  A permutation of [0, sum counts); each destination's own rows keep their order.  Host only.
+extern "C" int gnpde_push_order(const int32_t* send_counts, int32_t world, int32_t* order) {
+  GNPDE_CHECK_ARG(send_counts && order && world >= 1 && world <= kMaxWorld, GNPDE_EINVAL, "push_order: bad arguments");
+  std::vector<long long> next(world, 0), base(world, 0);
+  long long total = 0;
+  for (int p = 0; p < world; ++p) {
+    GNPDE_CHECK_ARG(send_counts[p] >= 0, GNPDE_EINVAL, "push_order: negative count");
+    base[p] = total;
+    total += send_counts[p];
+  }
+  for (long long w = 0; w < total; ++w) {
+    int best = -1;
+    for (int p = 0; p < world; ++p) {
+      if (next[p] >= send_counts[p]) continue;
+      if (best < 0) { best = p; continue; }
+      // (2 j_p + 1) / count_p < (2 j_best + 1) / count_best, in integers
+      const long long lhs = (2 * next[p] + 1) * static_cast<long long>(send_counts[best]);
+      const long long rhs = (2 * next[best] + 1) * static_cast<long long>(send_counts[p]);
+      if (lhs < rhs) best = p;
+    }
+    order[w] = static_cast<int32_t>(base[best] + next[best]);
+    ++next[best];
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ P2P shared memory
 extern "C" int gnpde_p2p_create(gnpde_p2p_t** out, int32_t rank, int32_t world, size_t buffer_bytes, int32_t n_buffers) {
   GNPDE_CHECK_ARG(out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n_buffers >= 1 && n_buffers <= 4 &&
@@ -662,6 +699,16 @@ extern "C" int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnp
   hipError_t e = hipMemcpy(s->d_seg, seg.data(), (W + 1) * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_dst_row0, row0.data(), W * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_peer_ctl, pctl.data(), W * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && s->n_send > 0) {
+    s->d_order = reinterpret_cast<int32_t*>(t + seg_bytes + 6 * tab);
+    std::vector<int32_t> order(static_cast<size_t>(s->n_send));
+    const int orc = gnpde_push_order(halo->send_counts, W, order.data());
+    if (orc != 0) {
+      gnpde_sharded_solver_destroy(s);
+      return orc;
+    }
+    e = hipMemcpy(s->d_order, order.data(), static_cast<size_t>(s->n_send) * 4, hipMemcpyHostToDevice);
+  }
   for (int b = 0; b < 4 && e == hipSuccess; ++b) {
     s->d_dst[b] = reinterpret_cast<float**>(t + seg_bytes + (2 + b) * tab);
     std::vector<float*> dst(W);

@@ -584,6 +584,12 @@ int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnpde_p2p_t* p
  * the halo rows are scratch; P2P: [>= n_own, d], copied into / out of the shared stage buffer).  use_graph != 0: captured
  * once per y pointer and replayed (P2P transport only).  Every rank must call it (the exchange is collective). */
 int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_graph, void* stream);
+/* Host-side: the order in which the P2P push walks a destination-grouped send list of send_counts[0..world) rows --
+ * order[w] = slot copied by the w-th wavefront; the destinations are interleaved in proportion to their counts so that every
+ * xGMI link of the rank is busy for the whole push (walked group by group, one link would carry it all while six idle).  A
+ * permutation of [0, sum send_counts) that keeps each destination's rows in order.  What gnpde_sharded_solver_create_p2p uses;
+ * exported for the host tests. */
+int gnpde_push_order(const int32_t* send_counts, int32_t world, int32_t* order);
 /* Synchronises.  *timed_out != 0: a wait kernel gave up polling a peer's epoch flag (results are invalid);
  * *epochs = evaluations this rank has published so far.  After the first time-out the waits of the evaluations still
  * queued return without polling (the flag is sticky for the lifetime of the gnpde_p2p_t), so a lost solve ends quickly. */

@@ -96,3 +96,35 @@ def test_push_lands_every_boundary_row_in_the_peers_halo_slot(world):
     # every local column -- owned or halo -- now holds the tag of the global node the edge points to
     assert torch.equal(b[s.edge_index[1]], tag[ei[1][s.edge_ids]])
     assert sum(s.recv_counts) == s.n_halo
+
+
+def test_push_order_interleaves_the_destinations():
+  """gnpde_push_order (what the P2P push walks, csrc/sharded.hip): a permutation of the destination-grouped send list that
+  keeps each destination's rows in order and, at every moment of the walk, has taken from destination p its share
+  count_p / total of the rows so far (within one row) -- so all xGMI links of the rank are busy from the first row to the last
+  instead of one after the other."""
+  import ctypes
+  import numpy as np
+  from gnpde_amd import _lib
+  L = _lib.lib()
+  for counts in ([0, 5], [7, 0, 7], [0, 17537, 9000, 12000, 1, 0, 15000, 16000], [3, 0, 0, 0], [0, 0], [0, 1, 1, 1, 1, 1, 1, 1],
+                 [100000, 0, 3]):
+    c = np.asarray(counts, dtype=np.int32)
+    total = int(c.sum())
+    order = np.full(max(total, 1), -1, dtype=np.int32)
+    _lib.check(L.gnpde_push_order(c.ctypes.data_as(_lib.c_int_p), len(counts), order.ctypes.data_as(_lib.c_int_p)))
+    order = order[:total]
+    assert np.array_equal(np.sort(order), np.arange(total))
+    seg = np.concatenate([[0], np.cumsum(c)])
+    dest = np.searchsorted(seg, order, side='right') - 1
+    for p in range(len(counts)):
+      mine = order[dest == p]
+      assert np.all(np.diff(mine) == 1) and (mine.size == 0 or mine[0] == seg[p])       # own rows in order
+      if total:
+        taken = np.cumsum(dest == p)                                                     # after w + 1 rows of the walk
+        share = (np.arange(total) + 1) * (c[p] / total)
+        assert np.all(np.abs(taken - share) <= 1.0 + 1e-9), (counts, p)
+  bad = np.asarray([1, -2], dtype=np.int32)
+  out = np.zeros(4, dtype=np.int32)
+  with pytest.raises(G.GnpdeError):
+    _lib.check(L.gnpde_push_order(bad.ctypes.data_as(_lib.c_int_p), 2, out.ctypes.data_as(_lib.c_int_p)))
