@@ -50,11 +50,12 @@ struct SpmmArgs {
 // the eighth with the top bits 000 holds 7.5x the entries of the eighth with 111 (8.9 M vs 1.2 M non-hub entries at the 2^21
 // shape) and the launch lasts as long as XCD 0 needs: 1.46x the balanced time by the work model (entries + 3 per row, hub
 // chunks included; tools/xcd_balance.py).  Real graphs have the same trait (ids in order of publication, crawl or degree).
-// HASHED (chosen by the graph builder when the contiguous deal is more than 3 % out of balance): the rows are dealt in BLOCKS of B = 2^row_shift consecutive rows (16 .. 128: the rows of a pair, and a stretch of
-// neighbouring rows, stay on one XCD), eight consecutive blocks form a group, and the eight XCDs take the blocks of group j in an order
-// rotated by a hash of j:   block(x, j) = 8 j + ((x + hash(j)) mod 8).   A fixed rotation (plain round robin) would keep the
-// R-MAT skew -- it only selects three OTHER id bits -- the hashed one leaves 0.1 - 0.5 % (same tool).  A bijection for any
-// hash, so every row is still taken exactly once; which XCD takes it does not enter the arithmetic (bit-identical results).
+// HASHED (chosen by the graph builder when the contiguous deal is more than 3 % out of balance): the rows are dealt in BLOCKS
+// of B = 2^row_shift consecutive rows (16 .. 128: the rows of a pair, and a stretch of neighbouring rows, stay on one XCD),
+// eight consecutive blocks form a group, and the eight XCDs take the blocks of group j in an order rotated by a hash of j:
+// block(x, j) = 8 j + ((x + hash(j)) mod 8).  A fixed rotation (plain round robin) would keep the R-MAT skew -- it only
+// selects three OTHER id bits -- the hashed one leaves 0.1 - 0.5 % (same tool).  A bijection for any hash, so every row is
+// still taken exactly once; which XCD takes it does not enter the arithmetic (bit-identical results, tools/xcd_check.py).
 struct Item { int row, e0, e1, chunk; bool valid; };
 
 __device__ __forceinline__ int chunks_of_xcd(const SpmmArgs& a, int x) {
