@@ -127,7 +127,7 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
     // takes one such row and needs one pair of dependent round trips per 64 entries, so a 512-entry row runs ~8x as long as
     // the typical one: in row order the long rows that happen to start late form the tail of the row-attention launch,
     // longest-first they start at time 0 and the short rows fill in behind them (ogbn-arxiv shape, wave-slot model of the
-    // launch: 30.6 -> 20.8 us).  The records are processed independently of one another, so their
+    // launch: 30.6 -> 21.9 us, tools/attention_slot_model.py).  The records are processed independently of one another, so their
     // order does not enter any result.
     std::vector<int32_t> start(GNPDE_LONG_ROW + 2, 0);
     for (int32_t i = 0; i < n_nodes; ++i) {
