@@ -173,7 +173,8 @@ extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx
     std::fill(part, part + n, 0);
     return 0;
   }
-  auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + 1; };
+  const int64_t row_weight = gnpde::g_tune[gnpde::GNPDE_TUNE_PART_ROW_WEIGHT] > 0 ? gnpde::g_tune[gnpde::GNPDE_TUNE_PART_ROW_WEIGHT] : 1;
+  auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + row_weight; };
   int64_t total = 0, maxw = 0;
   for (int32_t v = 0; v < n; ++v) {
     total += work(v);

@@ -30,13 +30,58 @@ from .odeint import time_grid
 # --------------------------------------------------------------------------------------------------
 # partition plan (host, deterministic: every rank computes the same plan from the same inputs)
 # --------------------------------------------------------------------------------------------------
+def pair_traffic(edge_index, part, world):
+  """M[r, q] = rows of part q that the rows of part r reference (distinct nodes): what rank r receives from rank q in every
+  evaluation, i.e. the load of the xGMI link q -> r."""
+  row, col = edge_index
+  pr, pc = part[row], part[col]
+  cut = pr != pc
+  key = torch.unique(pr[cut] * part.numel() + col[cut])          # distinct (receiving part, node)
+  recv, node = key // part.numel(), key % part.numel()
+  m = torch.zeros(world * world, dtype=torch.long)
+  m.index_add_(0, recv * world + part[node], torch.ones_like(recv))
+  return m.view(world, world)
+
+
+# relative cost of one received row (4 d bytes over one xGMI link) and one unit of aggregation work (an entry gathered at the
+# GPU's aggregate bandwidth): both scale with d, their ratio does not
+LINK_ROW_COST = 64
+
+
 class PartitionPlan(object):
+  """Rows -> ranks.  The native partitioner is a heuristic (label propagation + packing + refinement) whose outcome moves by
+  tens of per cent with its tie-breaking; what a partitioned evaluation pays for is (i) the busiest xGMI link -- the exchange
+  ends when the LAST link has delivered, and every pair of ranks has its own link -- and (ii) the busiest rank's aggregation.
+  So a few candidates (row weight of the balance constraint x seed) are scored by  LINK_ROW_COST * max link rows + max part
+  work  and the best is taken; every rank computes the same candidates from the same inputs and reaches the same choice."""
+
+  CANDIDATES = ((1, 0), (4, 0), (16, 0), (1, 1), (4, 1), (16, 1))     # (row_weight, seed)
+  MAX_EDGES_FOR_SEARCH = 20_000_000                                      # beyond: one partition (they cost minutes there)
+
   def __init__(self, edge_index, n, world, part=None, refine_iters=8):
     ei = edge_index.detach().cpu().long()
     self.n, self.world = int(n), int(world)
+    self.candidates = None
     if part is None:
       g = CSRGraph(ei, n, device='cpu')
-      part = partition_rows(g, world, refine_iters=refine_iters)
+      cands = self.CANDIDATES if (world > 2 and ei.shape[1] <= self.MAX_EDGES_FOR_SEARCH) else self.CANDIDATES[:1]
+      if world == 2 and ei.shape[1] <= self.MAX_EDGES_FOR_SEARCH:
+        cands = self.CANDIDATES[:3]
+      deg = torch.bincount(ei[0], minlength=self.n)
+      best, self.candidates = None, []
+      for row_weight, seed in cands:
+        cand = partition_rows(g, world, refine_iters=refine_iters, seed=seed, row_weight=row_weight).long()
+        if len(cands) == 1:
+          best = (0, cand)
+          break
+        links = pair_traffic(ei, cand, world)
+        work = torch.zeros(world, dtype=torch.long).index_add_(0, cand, deg + 3)
+        cost = LINK_ROW_COST * int(links.max()) + int(work.max())
+        self.candidates.append({'row_weight': row_weight, 'seed': seed, 'max_link_rows': int(links.max()),
+                                'max_halo_rows': int(links.sum(dim=1).max()), 'max_part_work': int(work.max()), 'cost': cost})
+        if best is None or cost < best[0]:
+          best = (cost, cand)
+      part = best[1]
     self.part = part.long()
     key = self.part * self.n + torch.arange(self.n)
     self.order = torch.argsort(key)                      # new position -> old node id
@@ -735,6 +780,8 @@ def bench_main(args, rank, world, dev):
                  'max_bytes_on_one_link_per_evaluation': int(halo_max[3].item()) * 4 * d,
                  'max_interior_rows': int(halo_max[4].item()),
                  'partition_seconds': round(t_plan, 2),
+                 'partition_candidates': plan.candidates,    # (row weight, seed) tried; the cheapest by busiest link + busiest rank is used
+
                  'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared,
                  'transport': chosen, 'transports_rejected': notes,
                  'driver': 'python loop' if python_loop else 'native, hipGraph %s' % graph_mode,

@@ -128,3 +128,26 @@ def test_push_order_interleaves_the_destinations():
   out = np.zeros(4, dtype=np.int32)
   with pytest.raises(G.GnpdeError):
     _lib.check(L.gnpde_push_order(bad.ctypes.data_as(_lib.c_int_p), 2, out.ctypes.data_as(_lib.c_int_p)))
+
+
+def test_partition_plan_takes_the_candidate_with_the_cheapest_busiest_link():
+  """PartitionPlan scores a few runs of the heuristic partitioner by what a partitioned evaluation waits for -- the busiest
+  xGMI link (rows one rank receives from ONE peer) and the busiest rank -- and keeps the cheapest; the scoring function agrees
+  with the shards' own receive counts, and two ranks building the plan independently reach the same partition."""
+  n = 3000
+  ei = random_graph(n, 8, seed=77, hubs=3, hub_deg=500)
+  plan = D.PartitionPlan(ei, n, 4)
+  assert plan.candidates is not None and len(plan.candidates) == len(D.PartitionPlan.CANDIDATES)
+  links = D.pair_traffic(plan.edge_index, plan.part, 4)
+  for r in range(4):
+    assert links[r].tolist() == plan.shard(r).recv_counts
+  best = min(plan.candidates, key=lambda c: c['cost'])
+  assert int(links.max()) == best['max_link_rows'] and int(links.sum(dim=1).max()) == best['max_halo_rows']
+  assert all(c['cost'] == D.LINK_ROW_COST * c['max_link_rows'] + c['max_part_work'] for c in plan.candidates)
+  again = D.PartitionPlan(ei, n, 4)
+  assert torch.equal(again.part, plan.part)
+  assert torch.bincount(plan.part, minlength=4).min() > 0
+  # a given partition is taken as it is; one part needs no search
+  fixed = D.PartitionPlan(ei, n, 4, part=plan.part)
+  assert fixed.candidates is None and torch.equal(fixed.part, plan.part)
+  assert len(D.PartitionPlan(ei, n, 1).candidates or []) == 0
