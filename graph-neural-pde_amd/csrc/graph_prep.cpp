@@ -204,7 +204,8 @@ extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx
     label[v] = v;
     cw[v] = work(v);
   }
-  const int64_t cap = std::max<int64_t>(static_cast<int64_t>(avg / 4), maxw);
+  const int cluster_div = gnpde::g_tune[gnpde::GNPDE_TUNE_PART_CLUSTER_DIV] > 0 ? gnpde::g_tune[gnpde::GNPDE_TUNE_PART_CLUSTER_DIV] : 4;
+  const int64_t cap = std::max<int64_t>(static_cast<int64_t>(avg / cluster_div), maxw);
   std::vector<int32_t> cnt(n, 0), touched;
   touched.reserve(256);
   const int cluster_iters = std::max(4, refine_iters);

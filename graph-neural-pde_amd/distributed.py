@@ -52,10 +52,12 @@ class PartitionPlan(object):
   """Rows -> ranks.  The native partitioner is a heuristic (label propagation + packing + refinement) whose outcome moves by
   tens of per cent with its tie-breaking; what a partitioned evaluation pays for is (i) the busiest xGMI link -- the exchange
   ends when the LAST link has delivered, and every pair of ranks has its own link -- and (ii) the busiest rank's aggregation.
-  So a few candidates (row weight of the balance constraint x seed) are scored by  LINK_ROW_COST * max link rows + max part
-  work  and the best is taken; every rank computes the same candidates from the same inputs and reaches the same choice."""
+  So a few candidates (row weight of the balance constraint x size cap of the packed clusters) are scored by
+  LINK_ROW_COST * max link rows + max part work  and the best is taken; every rank computes the same candidates from the
+  same inputs and reaches the same choice."""
 
-  CANDIDATES = ((1, 0), (4, 0), (16, 0), (1, 1), (4, 1), (16, 1))     # (row_weight, seed)
+  # (row_weight, seed, cluster_div); the first is the partitioner's default
+  CANDIDATES = ((1, 0, 4), (4, 0, 4), (1, 0, 8), (4, 0, 8), (1, 0, 16), (4, 0, 32), (1, 0, 2), (16, 0, 4))
   MAX_EDGES_FOR_SEARCH = 20_000_000                                      # beyond: one partition (they cost minutes there)
 
   def __init__(self, edge_index, n, world, part=None, refine_iters=8):
@@ -64,20 +66,19 @@ class PartitionPlan(object):
     self.candidates = None
     if part is None:
       g = CSRGraph(ei, n, device='cpu')
-      cands = self.CANDIDATES if (world > 2 and ei.shape[1] <= self.MAX_EDGES_FOR_SEARCH) else self.CANDIDATES[:1]
-      if world == 2 and ei.shape[1] <= self.MAX_EDGES_FOR_SEARCH:
-        cands = self.CANDIDATES[:3]
+      cands = self.CANDIDATES if (world >= 2 and ei.shape[1] <= self.MAX_EDGES_FOR_SEARCH) else self.CANDIDATES[:1]
       deg = torch.bincount(ei[0], minlength=self.n)
       best, self.candidates = None, []
-      for row_weight, seed in cands:
-        cand = partition_rows(g, world, refine_iters=refine_iters, seed=seed, row_weight=row_weight).long()
+      for row_weight, seed, cluster_div in cands:
+        cand = partition_rows(g, world, refine_iters=refine_iters, seed=seed, row_weight=row_weight,
+                              cluster_div=cluster_div).long()
         if len(cands) == 1:
           best = (0, cand)
           break
         links = pair_traffic(ei, cand, world)
         work = torch.zeros(world, dtype=torch.long).index_add_(0, cand, deg + 3)
         cost = LINK_ROW_COST * int(links.max()) + int(work.max())
-        self.candidates.append({'row_weight': row_weight, 'seed': seed, 'max_link_rows': int(links.max()),
+        self.candidates.append({'row_weight': row_weight, 'seed': seed, 'cluster_div': cluster_div, 'max_link_rows': int(links.max()),
                                 'max_halo_rows': int(links.sum(dim=1).max()), 'max_part_work': int(work.max()), 'cost': cost})
         if best is None or cost < best[0]:
           best = (cost, cand)

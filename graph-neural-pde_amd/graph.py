@@ -261,11 +261,12 @@ def graph_of(edge_index, num_nodes, device=None):
   return GRAPHS.get(edge_index, int(num_nodes), edge_index.device if device is None else device)
 
 
-def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1):
+def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1, cluster_div=4):
   """Balanced k-way row partition (native, csrc/graph_prep.cpp).  Accepts a CSRGraph or a
   (rowptr, colidx) pair of int32 CPU tensors; returns an int32 CPU tensor [n].  The parts are balanced on
   entries + row_weight per row: 1 follows the aggregation time, larger values even out the NODE counts (and with them the
-  rows a part has to send to its peers)."""
+  rows a part has to send to its peers); the label-propagation clusters that are packed into parts are capped at a part's
+  work / cluster_div."""
   if isinstance(graph_or_csr, CSRGraph):
     rowptr = graph_or_csr.t['rowptr'].cpu()
     colidx = graph_or_csr.t['colidx'].cpu()
@@ -277,9 +278,11 @@ def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1):
   part = torch.zeros(n, dtype=torch.int32)
   L = _lib.lib()
   _lib.check(L.gnpde_tune(_lib.TUNE_PART_ROW_WEIGHT, max(int(row_weight), 1)))
+  _lib.check(L.gnpde_tune(_lib.TUNE_PART_CLUSTER_DIV, max(int(cluster_div), 1)))
   try:
     _lib.check(L.gnpde_partition_rows(rowptr.data_ptr(), colidx.data_ptr(), n, int(n_parts), int(refine_iters), int(seed),
                                       part.data_ptr()))
   finally:
     _lib.check(L.gnpde_tune(_lib.TUNE_PART_ROW_WEIGHT, 0))
+    _lib.check(L.gnpde_tune(_lib.TUNE_PART_CLUSTER_DIV, 0))
   return part
