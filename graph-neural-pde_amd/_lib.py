@@ -22,7 +22,7 @@ ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4 = range(2)
 TUNE_SPMM_VARIANT, TUNE_FUSED_BLOCKS_PER_CU, TUNE_ONE_PASS, TUNE_FORK, TUNE_ATT_GENERIC_ROWS, TUNE_RK4_CLASSIC = range(6)
-TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING, TUNE_SPMM_PART, TUNE_XCD_ROWS, TUNE_HUB_FOLD, TUNE_PART_ROW_WEIGHT, TUNE_PART_CLUSTER_DIV = 6, 7, 8, 9, 10, 11, 12, 13
+TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING, TUNE_SPMM_PART, TUNE_XCD_ROWS, TUNE_HUB_FOLD = 6, 7, 8, 9, 10, 11
 
 ATT_TYPES = {'scaled_dot': ATT_SCALED_DOT, 'cosine_sim': ATT_COSINE, 'pearson': ATT_PEARSON,
              'exp_kernel': ATT_EXP_KERNEL}
@@ -89,6 +89,8 @@ PROTOTYPES = {
   'gnpde_graph_build': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 15),
   'gnpde_partition_rows': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_uint64, c_vp]),
+  'gnpde_partition_rows_ex': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, c_vp]),
   'gnpde_push_order': (ctypes.c_int, [c_int_p, ctypes.c_int32, c_int_p]),
   'gnpde_xcd_row_map': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_int_p, c_int_p, c_vp]),
   'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),

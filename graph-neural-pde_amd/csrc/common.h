@@ -102,8 +102,6 @@ enum {
   GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)
   GNPDE_TUNE_XCD_ROWS = 10,            // 0: as gnpde_graph_t.xcd_deal says; 1: contiguous eighths for every graph; 2: hashed blocks for every graph
   GNPDE_TUNE_HUB_FOLD = 11,            // 1: phase 1 of the hub-row attention stages the row's chunk partials through LDS (one round trip) before the fold
-  GNPDE_TUNE_PART_ROW_WEIGHT = 12,     // partitioner: work of a row = entries + this (0: the default, see gnpde_partition_rows)
-  GNPDE_TUNE_PART_CLUSTER_DIV = 13,    // partitioner: clusters are capped at a part's work / this (0: the default 4)
   GNPDE_TUNE_COUNT = 16
 };
 extern int g_tune[GNPDE_TUNE_COUNT];

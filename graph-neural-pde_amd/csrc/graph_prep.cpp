@@ -155,10 +155,10 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// k-way row partition (METIS is not available offline).  Work of a row = its nnz + 1, i.e. balance on
+// k-way row partition (METIS is not available offline).  Work of a row = its nnz + row_weight; row_weight = 1 balances on
 // EDGES, which is what the aggregation time follows.
 //   A. size-constrained label propagation: every node joins the cluster most of its neighbours are in,
-//      clusters capped at a quarter of a part  -> communities (hubs do not glue everything together
+//      clusters capped at a part / cluster_div (default a quarter)  -> communities (hubs do not glue everything together
 //      because a full cluster stops accepting members);
 //   B. clusters, heaviest first, are packed into the part they are most connected to that still has room;
 //   C. balance-constrained label propagation on single nodes across parts.
@@ -166,14 +166,21 @@ extern "C" int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t
 // ------------------------------------------------------------------------------------------------
 extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes,
                                     int32_t n_parts, int32_t refine_iters, uint64_t seed, int32_t* part) {
-  GNPDE_CHECK_ARG(rowptr && part && n_nodes >= 0 && n_parts >= 1, GNPDE_EINVAL, "partition_rows: bad args");
+  return gnpde_partition_rows_ex(rowptr, colidx, n_nodes, n_parts, refine_iters, seed, 1, 4, part);
+}
+
+extern "C" int gnpde_partition_rows_ex(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes, int32_t n_parts,
+                                       int32_t refine_iters, uint64_t seed, int32_t row_weight_arg, int32_t cluster_div_arg,
+                                       int32_t* part) {
+  GNPDE_CHECK_ARG(rowptr && part && n_nodes >= 0 && n_parts >= 1 && row_weight_arg >= 1 && cluster_div_arg >= 1, GNPDE_EINVAL,
+                  "partition_rows: bad args");
   GNPDE_CHECK_ARG(colidx || rowptr[n_nodes] == 0, GNPDE_EINVAL, "partition_rows: null colidx");
   const int32_t n = n_nodes, P = n_parts;
   if (P == 1 || n == 0) {
     std::fill(part, part + n, 0);
     return 0;
   }
-  const int64_t row_weight = gnpde::g_tune[gnpde::GNPDE_TUNE_PART_ROW_WEIGHT] > 0 ? gnpde::g_tune[gnpde::GNPDE_TUNE_PART_ROW_WEIGHT] : 1;
+  const int64_t row_weight = row_weight_arg;
   auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + row_weight; };
   int64_t total = 0, maxw = 0;
   for (int32_t v = 0; v < n; ++v) {
@@ -204,7 +211,7 @@ extern "C" int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx
     label[v] = v;
     cw[v] = work(v);
   }
-  const int cluster_div = gnpde::g_tune[gnpde::GNPDE_TUNE_PART_CLUSTER_DIV] > 0 ? gnpde::g_tune[gnpde::GNPDE_TUNE_PART_CLUSTER_DIV] : 4;
+  const int cluster_div = cluster_div_arg;
   const int64_t cap = std::max<int64_t>(static_cast<int64_t>(avg / cluster_div), maxw);
   std::vector<int32_t> cnt(n, 0), touched;
   touched.reserve(256);

@@ -276,13 +276,6 @@ def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1, 
   colidx = colidx.to(torch.int32).contiguous()
   n = rowptr.numel() - 1
   part = torch.zeros(n, dtype=torch.int32)
-  L = _lib.lib()
-  _lib.check(L.gnpde_tune(_lib.TUNE_PART_ROW_WEIGHT, max(int(row_weight), 1)))
-  _lib.check(L.gnpde_tune(_lib.TUNE_PART_CLUSTER_DIV, max(int(cluster_div), 1)))
-  try:
-    _lib.check(L.gnpde_partition_rows(rowptr.data_ptr(), colidx.data_ptr(), n, int(n_parts), int(refine_iters), int(seed),
-                                      part.data_ptr()))
-  finally:
-    _lib.check(L.gnpde_tune(_lib.TUNE_PART_ROW_WEIGHT, 0))
-    _lib.check(L.gnpde_tune(_lib.TUNE_PART_CLUSTER_DIV, 0))
+  _lib.check(_lib.lib().gnpde_partition_rows_ex(rowptr.data_ptr(), colidx.data_ptr(), n, int(n_parts), int(refine_iters),
+                                                int(seed), int(row_weight), int(cluster_div), part.data_ptr()))
   return part

@@ -66,8 +66,9 @@ int gnpde_graph_count_long(const int64_t* row, const int64_t* col, int64_t n_edg
  *   long_cols[n_long_cols] (NULL without the CSC view);
  *   bin_rows[4n]: one int32x4 record {row, first CSR position, length, 0} per listed row, grouped by
  *   degree class -- first the rows with 1..16 entries, then those with 17..GNPDE_LONG_ROW (empty and
- *   long rows are not listed); bin_counts[2] = sizes of the two classes.  Within a class rows keep
- *   ascending order.  (One 16-byte load replaces the rowptr indirection in the row-attention kernels.)
+ *   long rows are not listed); bin_counts[2] = sizes of the two classes.  The first class is in ascending row
+ *   order, the second LONGEST FIRST (ties in row order): a wavefront takes one such row, and the long ones should start the
+ *   row-attention launch, not end it.  (One 16-byte load replaces the rowptr indirection in the row-attention kernels.)
  * Returns GNPDE_EINVAL if an index is outside [0, n_nodes). */
 int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes,
                       int32_t* rowptr, int32_t* colidx, int32_t* perm, int32_t* rowidx,
@@ -76,10 +77,17 @@ int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, i
                       int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
                       int32_t* bin_rows, int32_t* bin_counts, int32_t* long_chunk_first);
 
-/* Balanced k-way row partition for the multi-GPU path (no METIS offline): BFS-grown parts balanced
- * on nnz, refined by label propagation.  part[n] receives values in [0, n_parts).  Host only. */
+/* Balanced k-way row partition for the multi-GPU path (no METIS offline; no reference equivalent): size-capped
+ * label-propagation clusters packed into parts, then node-level refinement under the balance constraint.  The parts are
+ * balanced (3 %) on  entries + row_weight  per row -- 1 follows the aggregation time, larger values even out the node counts --
+ * and the clusters are capped at a part's work / cluster_div.  part[n] receives values in [0, n_parts).  Host only,
+ * deterministic for given arguments.  gnpde_partition_rows = row_weight 1, cluster_div 4.  The outcome of the heuristic moves
+ * by tens of per cent with these two; the Python layer scores a few combinations by the busiest xGMI link and the busiest
+ * rank they produce and keeps the cheapest (distributed.PartitionPlan). */
 int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes,
                          int32_t n_parts, int32_t refine_iters, uint64_t seed, int32_t* part);
+int gnpde_partition_rows_ex(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes, int32_t n_parts,
+                            int32_t refine_iters, uint64_t seed, int32_t row_weight, int32_t cluster_div, int32_t* part);
 
 /* Device view of a prepared graph (all pointers device memory). */
 typedef struct gnpde_graph {
