@@ -101,8 +101,9 @@ def test_push_lands_every_boundary_row_in_the_peers_halo_slot(world):
 def test_push_order_interleaves_the_destinations():
   """gnpde_push_order (what the P2P push walks, csrc/sharded.hip): a permutation of the destination-grouped send list that
   keeps each destination's rows in order and, at every moment of the walk, has taken from destination p its share
-  count_p / total of the rows so far (within one row) -- so all xGMI links of the rank are busy from the first row to the last
-  instead of one after the other."""
+  count_p / total of the rows so far (within a row or so: 1/2 + (P / 2) count_p / total, checked on arbitrary counts in
+  tests/test_properties_cpu.py) -- so all xGMI links of the rank are busy from the first row to the last instead of one after
+  the other."""
   import ctypes
   import numpy as np
   from gnpde_amd import _lib

@@ -1,0 +1,123 @@
+"""Property tests (hypothesis) of the host-side logic on arbitrary small inputs: graph preparation (both builders), the rows ->
+XCD deal, the push order and the partition plan / shard index maps -- sizes 0 and 1, empty rows, duplicates, self loops, more
+ranks than nodes."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+import gnpde_amd as G
+from gnpde_amd import _lib, distributed as D
+from gnpde_amd.graph import build_arrays_on_device, contiguous_deal_imbalance
+
+FAST = settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+@st.composite
+def edge_lists(draw, max_n=40, max_e=160):
+  n = draw(st.integers(1, max_n))
+  e = draw(st.integers(0, max_e))
+  rows = draw(st.lists(st.integers(0, n - 1), min_size=e, max_size=e))
+  cols = draw(st.lists(st.integers(0, n - 1), min_size=e, max_size=e))
+  return n, torch.tensor([rows, cols], dtype=torch.long).reshape(2, e)
+
+
+@FAST
+@given(edge_lists())
+def test_graph_builders_agree_and_are_consistent(g):
+  n, ei = g
+  host = G.CSRGraph(ei, n, device='cpu')
+  row, col = ei[0].numpy(), ei[1].numpy()
+  order = np.argsort(row, kind='stable')
+  assert np.array_equal(host.perm.numpy(), order) and np.array_equal(host.colidx.numpy(), col[order])
+  deg = np.bincount(row, minlength=n)
+  assert np.array_equal(host.rowptr.numpy(), np.concatenate([[0], np.cumsum(deg)]))
+  rec = host.t['bin_rows'].numpy().reshape(-1, 4)[:host.n_bin16 + host.n_bin64]
+  assert np.array_equal(np.sort(rec[:, 0]), np.nonzero((deg >= 1) & (deg <= _lib.LONG_ROW))[0])
+  assert np.array_equal(rec[:, 2], deg[rec[:, 0]]) and np.array_equal(rec[:, 1], host.rowptr.numpy()[rec[:, 0]])
+  arrays, counts = build_arrays_on_device(ei, n)
+  for key in ('rowptr', 'cscptr'):
+    assert np.array_equal(arrays[key].numpy(), host.t[key].numpy())
+  for key, size in (('colidx', host.e), ('perm', host.e), ('rowidx', host.e), ('cscpos', host.e), ('bin_rows', 4 * len(rec))):
+    assert np.array_equal(arrays[key].numpy()[:size], host.t[key].numpy()[:size]), key
+  assert counts['n_bin16'] == host.n_bin16 and counts['n_bin64'] == host.n_bin64 and counts['n_long_rows'] == host.n_long_rows
+  assert host.struct.xcd_deal in (_lib.XCD_CONTIGUOUS, _lib.XCD_HASHED) and host.xcd_imbalance_contiguous >= 1.0 - 1e-12
+  assert abs(contiguous_deal_imbalance(arrays['rowptr'], 0, n) - host.xcd_imbalance_contiguous) < 1e-9
+
+
+@FAST
+@given(st.integers(0, 5000), st.integers(0, 5000), st.sampled_from([_lib.XCD_CONTIGUOUS, _lib.XCD_HASHED]))
+def test_xcd_row_map_is_a_bijection_for_any_range(a, b, deal):
+  rb, re_ = min(a, b), max(a, b)
+  L = _lib.lib()
+  shift, per = ctypes.c_int32(0), ctypes.c_int32(0)
+  _lib.check(L.gnpde_xcd_row_map(rb, re_, deal, ctypes.byref(shift), ctypes.byref(per), None))
+  m = np.full((8, max(per.value, 1)), -7, dtype=np.int32)
+  _lib.check(L.gnpde_xcd_row_map(rb, re_, deal, ctypes.byref(shift), ctypes.byref(per), m.ctypes.data))
+  m = m[:, :per.value]
+  rows = m[m >= 0]
+  assert np.array_equal(np.sort(rows), np.arange(rb, re_)) and np.all((m >= 0) | (m == -1))
+  even, odd = m[:, 0:per.value - per.value % 2:2], m[:, 1:per.value - per.value % 2 + 1:2]
+  both = (even >= 0) & (odd >= 0)
+  assert np.all(odd[both] == even[both] + 1)
+
+
+@FAST
+@given(st.lists(st.integers(0, 300), min_size=1, max_size=9))
+def test_push_order_is_a_proportional_interleaving(counts):
+  L = _lib.lib()
+  c = np.asarray(counts, dtype=np.int32)
+  total = int(c.sum())
+  order = np.full(max(total, 1), -1, dtype=np.int32)
+  _lib.check(L.gnpde_push_order(c.ctypes.data_as(_lib.c_int_p), len(counts), order.ctypes.data_as(_lib.c_int_p)))
+  order = order[:total]
+  assert np.array_equal(np.sort(order), np.arange(total))
+  seg = np.concatenate([[0], np.cumsum(c)])
+  dest = np.searchsorted(seg, order, side='right') - 1
+  for p in range(len(counts)):
+    assert np.all(np.diff(order[dest == p]) == 1)
+    if total:
+      taken = np.cumsum(dest == p)
+      # merging by (j + 1/2) / count_p keeps every destination within  1/2 + (P / 2) (count_p / total)  rows of its share
+      bound = 0.5 + 0.5 * len(counts) * (c[p] / total)
+      assert np.all(np.abs(taken - (np.arange(total) + 1) * (c[p] / total)) <= bound + 1e-9)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(edge_lists(max_n=60, max_e=300), st.integers(1, 6))
+def test_partition_plan_and_shards_cover_the_graph(g, world):
+  n, ei = g
+  plan = D.PartitionPlan(ei, n, world)
+  assert plan.part.numel() == n and int(plan.part.min()) >= 0 and int(plan.part.max()) < world
+  assert torch.equal(torch.sort(plan.order)[0], torch.arange(n))
+  shards = [plan.shard(r) for r in range(world)]
+  seen = torch.zeros(ei.shape[1], dtype=torch.long)
+  tag = torch.arange(n, dtype=torch.float64) + 0.5
+  bufs = []
+  for s in shards:
+    seen[s.edge_ids] += 1
+    assert s.n_own == int((plan.part == s.rank).sum()) and s.n_local == s.n_own + s.n_halo and 0 <= s.n_interior <= s.n_own
+    b = torch.full((s.n_local,), float('nan'), dtype=torch.float64)
+    b[:s.n_own] = tag[s.own_old_ids]
+    bufs.append(b)
+  assert torch.all(seen == 1)
+  for p, sp in enumerate(shards):           # the push of csrc/sharded.hip, on the host
+    seg = 0
+    for q, sq in enumerate(shards):
+      cnt = sp.send_counts[q]
+      assert cnt == sq.recv_counts[p]
+      row0 = sq.n_own + sum(sq.recv_counts[:p])
+      bufs[q][row0:row0 + cnt] = bufs[p][sp.send_idx[seg:seg + cnt]]
+      seg += cnt
+    assert seg == int(sp.send_idx.numel())
+  for s, b in zip(shards, bufs):
+    assert not torch.isnan(b).any()
+    assert torch.equal(b[s.edge_index[1]], tag[ei[1][s.edge_ids]]) and torch.equal(b[s.edge_index[0]], tag[ei[0][s.edge_ids]])
+    if s.edge_index.shape[1]:
+      halo_rows = torch.unique(s.edge_index[0][s.edge_index[1] >= s.n_own])
+      assert halo_rows.numel() == s.n_own - s.n_interior and (halo_rows.numel() == 0 or int(halo_rows.min()) >= s.n_interior)
+  links = D.pair_traffic(plan.edge_index, plan.part, world)
+  for r, s in enumerate(shards):
+    assert links[r].tolist() == s.recv_counts
