@@ -121,3 +121,48 @@ def test_partition_plan_and_shards_cover_the_graph(g, world):
   links = D.pair_traffic(plan.edge_index, plan.part, world)
   for r, s in enumerate(shards):
     assert links[r].tolist() == s.recv_counts
+
+
+@st.composite
+def weighted_edges(draw, max_n=25, max_e=80):
+  n, ei = draw(edge_lists(max_n=max_n, max_e=max_e))
+  e = ei.shape[1]
+  weighted = draw(st.booleans())
+  w = None
+  if weighted:
+    w = torch.tensor(draw(st.lists(st.floats(0.125, 4.0, width=32), min_size=e, max_size=e)), dtype=torch.float32)
+  return n, ei, w
+
+
+@FAST
+@given(weighted_edges(), st.sampled_from([0, 1]), st.sampled_from([0.0, 1.0, 2.0]))
+def test_normalisation_helpers_match_the_oracle(g, norm_dim, fill):
+  """get_rw_adj / gcn_norm_fill_val / add_remaining_self_loops (utils.py: the blocks' graph preparation, reference
+  src/utils.py:55-123) against the oracle on arbitrary edge lists -- duplicates, existing self loops (their weight is kept),
+  isolated nodes (inf -> 0 in the symmetric normalisation)."""
+  from oracle import restate as R
+  n, ei, w = g
+  a_i, a_w = G.add_remaining_self_loops(ei, w, 1.0 if fill == 0.0 else fill, n)
+  b_i, b_w = R.add_remaining_self_loops(ei, w, 1.0 if fill == 0.0 else fill, n)
+  assert torch.equal(a_i, b_i) and ((a_w is None and b_w is None) or torch.allclose(a_w, b_w))
+  a_i, a_w = G.get_rw_adj(ei, w, norm_dim=norm_dim, fill_value=fill, num_nodes=n, dtype=torch.float32)
+  b_i, b_w = R.get_rw_adj(ei, w, norm_dim=norm_dim, fill_value=fill, num_nodes=n, dtype=torch.float32)
+  assert torch.equal(a_i, b_i) and torch.allclose(a_w, b_w, rtol=1e-6, atol=1e-7, equal_nan=True)
+  a_i, a_w = G.gcn_norm_fill_val(ei, w, fill_value=fill, num_nodes=n, dtype=torch.float32)
+  b_i, b_w = R.gcn_norm_fill_val(ei, w, fill_value=fill, num_nodes=n, dtype=torch.float32)
+  assert torch.equal(a_i, b_i) and torch.allclose(a_w, b_w, rtol=1e-6, atol=1e-7, equal_nan=True)
+
+
+@FAST
+@given(st.floats(0.05, 40.0), st.floats(0.05, 3.0))
+def test_time_grid_is_torchdiffeqs(T, h):
+  """odeint.time_grid: ceil(T / h + 1) points t0 + i h with the last one replaced by T, in float32 like torchdiffeq's
+  FixedGridODESolver (so the final step may be short, never long, never missing)."""
+  from gnpde_amd.odeint import time_grid
+  from oracle import restate as R
+  t = torch.tensor([0.0, T], dtype=torch.float32)
+  grid = time_grid(t, h)
+  assert torch.equal(grid, R.time_grid(T, h))
+  assert float(grid[0]) == 0.0 and grid[-1] == t[-1] and grid.numel() >= 2
+  steps = grid[1:] - grid[:-1]
+  assert bool((steps[:-1] > 0).all()) and float(steps.max()) <= h + 1e-6 * max(T, 1.0)      # (grid points are float32)
