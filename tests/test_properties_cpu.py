@@ -166,3 +166,25 @@ def test_time_grid_is_torchdiffeqs(T, h):
   assert float(grid[0]) == 0.0 and grid[-1] == t[-1] and grid.numel() >= 2
   steps = grid[1:] - grid[:-1]
   assert bool((steps[:-1] > 0).all()) and float(steps.max()) <= h + 1e-6 * max(T, 1.0)      # (grid points are float32)
+
+
+@FAST
+@given(edge_lists(max_n=15, max_e=60), edge_lists(max_n=15, max_e=60), st.integers(0, 2 ** 31 - 1))
+def test_rewiring_sparse_helpers_match_dense(a, b, seed):
+  """Host helpers of the rewiring block (what torch_sparse.spspmm / coalesce compute for the reference,
+  src/block_transformer_rewiring.py:68-86): COO product and duplicate-summing coalesce against dense matrices, the result
+  sorted row-major without duplicates."""
+  from gnpde_amd.block_transformer_rewiring import _spspmm, _coalesce
+  n = max(a[0], b[0])
+  ia, ib = a[1], b[1]
+  g = torch.Generator().manual_seed(seed)
+  va, vb = torch.rand(ia.shape[1], generator=g), torch.rand(ib.shape[1], generator=g)
+  dense = lambda i, v: torch.zeros(n, n, dtype=torch.float64).index_put_((i[0], i[1]), v.double(), accumulate=True)  # noqa: E731
+  ic, vc = _spspmm(ia, va, ib, vb, n)
+  assert torch.allclose(dense(ic, vc), dense(ia, va) @ dense(ib, vb), atol=1e-5)
+  key = ic[0] * n + ic[1]
+  assert ic.shape[1] <= 1 or bool((key[1:] > key[:-1]).all())
+  id_, vd = _coalesce(torch.cat([ia, ib], dim=1), torch.cat([va, vb]), n)
+  assert torch.allclose(dense(id_, vd), dense(ia, va) + dense(ib, vb), atol=1e-5)
+  key = id_[0] * n + id_[1]
+  assert id_.shape[1] <= 1 or bool((key[1:] > key[:-1]).all())
