@@ -93,6 +93,51 @@ class PartitionPlan(object):
     self.offsets[1:] = torch.cumsum(self.counts, 0)
     self.edge_index = ei
 
+  # the settings a search draws from: (row_weight, cluster_div, seed), a fixed order
+  SEARCH_SPACE = tuple((w, dv, sd) for sd in (0, 1, 2) for w in (1, 2, 4, 8) for dv in (2, 4, 8, 16, 32, 64))
+
+  @staticmethod
+  def score(ei, part, world, deg=None):
+    """(cost, busiest link rows, largest halo, busiest rank's work) of a partition: what a partitioned evaluation waits for."""
+    if deg is None:
+      deg = torch.bincount(ei[0], minlength=part.numel())
+    links = pair_traffic(ei, part, world)
+    work = torch.zeros(world, dtype=torch.long).index_add_(0, part, deg + 3)
+    return LINK_ROW_COST * int(links.max()) + int(work.max()), int(links.max()), int(links.sum(dim=1).max()), int(work.max())
+
+  @classmethod
+  def search(cls, edge_index, n, world, rank=0, group_size=1, per_rank=9, refine_iters=8, group=None):
+    """The ranks of a job share the search: rank r scores the settings r, r + group_size, ... of SEARCH_SPACE (per_rank of
+    them, ~0.5 s each at the ogbn-arxiv shape), the scores are all-gathered (host-side objects, any backend), the cheapest
+    setting wins (ties: the earlier one) and every rank recomputes THAT partition itself -- the partitioner is deterministic,
+    so nothing but a few numbers travels.  group_size = 1: a plain local search over the first per_rank settings."""
+    ei = edge_index.detach().cpu().long()
+    world, group_size = int(world), max(int(group_size), 1)
+    if world == 1 or ei.shape[1] > cls.MAX_EDGES_FOR_SEARCH:
+      return cls(ei, n, world, refine_iters=refine_iters)
+    g = CSRGraph(ei, n, device='cpu')
+    deg = torch.bincount(ei[0], minlength=int(n))
+    mine = []
+    for idx in range(int(rank), len(cls.SEARCH_SPACE), group_size)[:max(int(per_rank), 1)]:
+      w, dv, sd = cls.SEARCH_SPACE[idx]
+      cand = partition_rows(g, world, refine_iters=refine_iters, seed=sd, row_weight=w, cluster_div=dv).long()
+      cost, link, halo, work = cls.score(ei, cand, world, deg)
+      mine.append({'index': idx, 'row_weight': w, 'cluster_div': dv, 'seed': sd, 'max_link_rows': link, 'max_halo_rows': halo,
+                   'max_part_work': work, 'cost': cost})
+    if group_size > 1:
+      gathered = [None] * group_size
+      dist.all_gather_object(gathered, mine, group=group)
+      scored = [c for part_list in gathered for c in part_list]
+    else:
+      scored = mine
+    scored.sort(key=lambda c: (c['cost'], c['index']))
+    best = scored[0]
+    part = partition_rows(g, world, refine_iters=refine_iters, seed=best['seed'], row_weight=best['row_weight'],
+                          cluster_div=best['cluster_div'])
+    plan = cls(ei, n, world, part=part)
+    plan.candidates = scored
+    return plan
+
   def edge_cut(self):
     r, c = self.edge_index
     return float((self.part[r] != self.part[c]).float().mean())
@@ -531,7 +576,9 @@ def bench_main(args, rank, world, dev):
   if args.function == 'laplacian':                                  # the block's rw-normalised edge list (same loops)
     ei_loops, w_loops = G.get_rw_adj(ei, None, norm_dim=1, fill_value=1.0, num_nodes=n, dtype=torch.float32)
   t0 = time.perf_counter()
-  plan = PartitionPlan(ei_loops, n, world)
+  # the ranks share the search for the partition (PartitionPlan.search): 9 settings each at 8 ranks = all 72
+  per_rank = max(1, min(12, len(PartitionPlan.SEARCH_SPACE) // max(world, 1)))
+  plan = PartitionPlan.search(ei_loops, n, world, rank=rank, group_size=world, per_rank=per_rank)
   shard = plan.shard(rank)
   t_plan = time.perf_counter() - t0
   g = torch.Generator().manual_seed(args.seed)
@@ -781,7 +828,10 @@ def bench_main(args, rank, world, dev):
                  'max_bytes_on_one_link_per_evaluation': int(halo_max[3].item()) * 4 * d,
                  'max_interior_rows': int(halo_max[4].item()),
                  'partition_seconds': round(t_plan, 2),
-                 'partition_candidates': plan.candidates,    # (row weight, seed) tried; the cheapest by busiest link + busiest rank is used
+                 # settings of the partitioner scored by the ranks (busiest link, busiest rank), cheapest first: the one used, and the spread
+                 'partition_search': None if not plan.candidates else {
+                   'scored': len(plan.candidates), 'used': plan.candidates[0], 'median_cost': plan.candidates[len(plan.candidates) // 2]['cost'],
+                   'worst_cost': plan.candidates[-1]['cost']},
 
                  'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared,
                  'transport': chosen, 'transports_rejected': notes,

@@ -84,7 +84,17 @@ def main():
   params = dict(Wq=torch.randn(A, d, generator=g) / d ** 0.5, Wk=torch.randn(A, d, generator=g) / d ** 0.5,
                 bq=torch.randn(A, generator=g) * 0.1, bk=torch.randn(A, generator=g) * 0.1, heads=h)
   alpha, beta = torch.tensor(0.3), torch.tensor(0.2)
-  plan = D.PartitionPlan(ei, n, world)
+  # the ranks share the search for the partition: every rank scores its slice of the settings, the scores are all-gathered,
+  # everybody recomputes the winner -- and must end up with the same partition, no worse than the partitioner's default
+  plan = D.PartitionPlan.search(ei, n, world, rank=rank, group_size=world, per_rank=4)
+  assert len(plan.candidates) == 4 * world and plan.candidates == sorted(plan.candidates, key=lambda c: (c['cost'], c['index']))
+  assert sorted(c['index'] for c in plan.candidates) == list(range(4 * world))
+  parts = [torch.zeros(n, dtype=torch.long) for _ in range(world)]
+  dist.all_gather(parts, plan.part)
+  assert all(torch.equal(p_, plan.part) for p_ in parts), 'the ranks disagree on the partition'
+  assert D.PartitionPlan.score(plan.edge_index, plan.part, world)[0] == plan.candidates[0]['cost']
+  default = D.PartitionPlan(ei, n, world, part=D.partition_rows(D.CSRGraph(ei, n, device='cpu'), world))
+  assert plan.candidates[0]['cost'] <= D.PartitionPlan.score(default.edge_index, default.part, world)[0]
   shard = plan.shard(rank)
   # index-map invariants
   assert shard.n_own == int((plan.part == rank).sum())
