@@ -8,7 +8,7 @@ TAG=$1; COMMIT=$2; GRAPH=$3; STEPS=$4; shift 4
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python bench.py --graph $GRAPH --steps $STEPS --warmup 0 --no-cpu-baseline --replays 1 $*"
+BENCH="python bench.py --graph $GRAPH --steps $STEPS --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $BENCH > "$OUT/stats.log" 2>&1
 python tools/prof_summary.py "$(find $OUT/stats -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" \
   "rocprofv3 --kernel-trace --stats -- $BENCH   (commit $COMMIT)" > /dev/null

@@ -11,7 +11,7 @@ TAG=$1; COMMIT=$2; TSEC=${3:-300}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python bench.py --graph arxiv --steps 20 --warmup 0 --no-cpu-baseline --replays 1"
+BENCH="python bench.py --graph arxiv --steps 20 --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1"
 date +%s > "$OUT/t0"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $BENCH > "$OUT/stats.log" 2>&1
 python tools/prof_summary.py "$(find $OUT/stats -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" \
