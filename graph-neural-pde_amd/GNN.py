@@ -14,6 +14,7 @@ from torch import nn
 from . import _lib, ops
 from .base_classes import create_regularization_fns
 from .model_configurations import set_block, set_function
+from .utils import Meter
 
 
 class BaseGNN(nn.Module):
@@ -25,6 +26,8 @@ class BaseGNN(nn.Module):
     self.num_features = dataset.data.num_features
     self.num_nodes = dataset.data.num_nodes
     self.device = device
+    self.fm = Meter()   # forward / backward NFE tallies that run_GNN.py's train() updates (src/base_classes.py:107-108)
+    self.bm = Meter()
     if opt['beltrami']:
       self.mx = nn.Linear(self.num_features, opt['feat_hidden_dim'])
       self.mp = nn.Linear(opt['pos_enc_dim'], opt['pos_enc_hidden_dim'])

@@ -7,7 +7,7 @@ from . import _lib
 from ._lib import GnpdeError, build, lib
 from .graph import CSRGraph, graph_of, partition_rows
 from . import ops
-from .utils import MaxNFEException, get_rw_adj, gcn_norm_fill_val, add_remaining_self_loops, DummyData, DummyDataset
+from .utils import MaxNFEException, get_rw_adj, gcn_norm_fill_val, add_remaining_self_loops, DummyData, DummyDataset, Meter
 from .odeint import odeint, odeint_adjoint, time_grid
 from .base_classes import ODEFunc, ODEblock, RegularizedODEfunc, REGULARIZATION_FNS, create_regularization_fns
 from .function_laplacian_diffusion import LaplacianODEFunc

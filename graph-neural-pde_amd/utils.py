@@ -65,6 +65,30 @@ def gcn_norm_fill_val(edge_index, edge_weight=None, fill_value=0., num_nodes=Non
   return edge_index, dis[row] * edge_weight * dis[col]
 
 
+class Meter(object):
+  """Running tally of function evaluations: run_GNN.py's train() feeds `model.fm` / `model.bm` after every forward /
+  backward pass and prints their `.sum` per epoch (reference src/utils.py:212-233, used at src/run_GNN.py:90-95)."""
+
+  def __init__(self):
+    self.reset()
+
+  def reset(self):
+    self.val = None
+    self.sum = 0
+    self.cnt = 0
+
+  def update(self, val):
+    self.val = val
+    self.sum += val
+    self.cnt += 1
+
+  def get_average(self):
+    return self.sum / self.cnt if self.cnt else 0
+
+  def get_value(self):
+    return self.val
+
+
 class DummyDataset(object):
   def __init__(self, data, num_classes):
     self.data = data

@@ -116,6 +116,42 @@ def test_gnn_end_to_end(dev, name):
   assert_parity(out_t.detach(), fx.t('out'), what=name + ' (grad mode)')
 
 
+def test_gnn_runs_the_reference_train_and_test_step(dev):
+  """run_GNN.py's train() / test() protocol on the native GNN (src/run_GNN.py:62-96, 137-148): forward in train mode,
+  loss, `model.fm.update(model.getNFE())`, resetNFE, backward, optimiser step, `model.bm.update(...)`; then an eval
+  forward.  The meters are what the epoch log prints (`model.fm.sum`, `model.bm.sum`)."""
+  fx = Fixture('gnn_constant_transformer_rk4')
+  model = _gnn_of(fx, dev)
+  n, c = fx.arr['x'].shape[0], int(fx.arr['num_classes'])
+  gen = torch.Generator().manual_seed(0)
+  y = torch.randint(0, c, (n, 1), generator=gen).to(dev)
+  mask = (torch.rand(n, generator=gen) < 0.5).to(dev)
+  optim = torch.optim.Adam(model.parameters(), lr=1e-3)
+  assert isinstance(model.fm, G.Meter) and model.fm.cnt == 0 and model.bm.sum == 0
+  before = [p.detach().clone() for p in model.parameters()]
+  for step in range(2):
+    model.train()
+    optim.zero_grad()
+    out = model(fx.t('x', dev), None)
+    loss = torch.nn.CrossEntropyLoss()(out[mask], y.squeeze()[mask])
+    model.fm.update(model.getNFE())
+    model.resetNFE()
+    loss.backward()
+    optim.step()
+    model.bm.update(model.getNFE())
+    model.resetNFE()
+    assert torch.isfinite(loss)
+  assert model.fm.cnt == 2 and model.fm.sum == 2 * int(fx.arr['nfe']) and model.fm.get_value() == int(fx.arr['nfe'])
+  assert model.fm.get_average() == int(fx.arr['nfe']) and model.bm.cnt == 2
+  assert any(not torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+  model.eval()
+  with torch.no_grad():
+    logits = model(fx.t('x', dev), None)
+  pred = logits[mask].max(1)[1]
+  acc = pred.eq(y.squeeze()[mask]).sum().item() / mask.sum().item()
+  assert 0.0 <= acc <= 1.0
+
+
 def test_max_nfe(dev):
   fx = Fixture('block_constant_transformer_rk4')
   opt = dict(fx.opt, max_nfe=5)

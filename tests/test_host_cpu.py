@@ -515,3 +515,30 @@ def test_row_records_of_the_wave_per_row_class_are_longest_first():
   arrays, counts = build_arrays_on_device(ei, n)
   assert counts['n_bin16'] == g.n_bin16 and counts['n_bin64'] == g.n_bin64
   assert np.array_equal(arrays['bin_rows'].numpy()[:4 * len(rec)].reshape(-1, 4), rec)
+
+
+def test_meter_matches_the_reference_meter():
+  """gnpde_amd.Meter = src/utils.py:212-233 (what run_GNN.py's train() calls on model.fm / model.bm); the native BaseGNN
+  carries both.  Compared with the reference's own class where the reference tree is present."""
+  import gnpde_amd as G
+  m = G.Meter()
+  assert (m.val, m.sum, m.cnt, m.get_average(), m.get_value()) == (None, 0, 0, 0, None)
+  for v in (16, 8, 0):
+    m.update(v)
+  assert (m.val, m.sum, m.cnt, m.get_average(), m.get_value()) == (0, 24, 3, 8.0, 0)
+  m.reset()
+  assert (m.val, m.sum, m.cnt) == (None, 0, 0)
+  path = '/root/reference/src/utils.py'
+  if os.path.exists(path):
+    src = open(path).read()
+    body = src[src.index('class Meter(object):'):src.index('class DummyDataset')]
+    ns = {}
+    exec(body, ns)
+    ref = ns['Meter']()
+    ours = G.Meter()
+    for v in (3, 5.5, 0):
+      ref.update(v)
+      ours.update(v)
+      assert vars(ref) == vars(ours) and ref.get_average() == ours.get_average() and ref.get_value() == ours.get_value()
+  import inspect
+  assert 'self.fm = Meter()' in inspect.getsource(G.BaseGNN.__init__) and 'self.bm = Meter()' in inspect.getsource(G.BaseGNN.__init__)
