@@ -30,12 +30,6 @@ class HardAttODEblock(ODEblock):
     layer = self.multihead_att_layer if self._own_layer else self.odefunc.multihead_att_layer
     return layer(x, self.data_edge_index)[0]
 
-  def renormalise_attention(self, attention):
-    """attention / (its sum over the edges that share the normalisation endpoint + 1e-16)."""
-    endpoint = self.odefunc.edge_index[self.opt['attention_norm_idx']]
-    total = attention.new_zeros(self.num_nodes).index_add_(0, endpoint, attention)
-    return attention / (total[endpoint] + 1e-16)
-
   def _edge_scores(self, x, attention):
     score = attention.mean(dim=1)
     if self.opt['use_flux']:
@@ -45,17 +39,13 @@ class HardAttODEblock(ODEblock):
 
   def _sample_edges(self, x, attention):
     """Keep the edges whose score exceeds the (1 - att_samp_pct) quantile (reference :48-66)."""
-    score = self._edge_scores(x, attention)
-    if score.is_cuda and score.dtype == torch.float32:
-      # native: radix-select quantile (same float32 rank arithmetic as torch.quantile), stable compaction, renormalisation
-      from . import ops
-      thr = ops.quantile(score, 1 - self.opt['att_samp_pct'])
-      self.odefunc.edge_index, self.odefunc.attention_weights = ops.threshold_edges(
-        self.data_edge_index, score, thr, self.opt['attention_norm_idx'], self.num_nodes)
-      return
-    keep = score > torch.quantile(score, 1 - self.opt['att_samp_pct'])
-    self.odefunc.edge_index = self.data_edge_index[:, keep]
-    self.odefunc.attention_weights = self.renormalise_attention(score[keep])
+    from . import ops
+    from .block_transformer_rewiring import _device_f32
+    score = _device_f32(self._edge_scores(x, attention), 'hard attention edge scores')
+    # radix-select quantile (same float32 rank arithmetic as torch.quantile), stable compaction, renormalisation
+    thr = ops.quantile(score, 1 - self.opt['att_samp_pct'])
+    self.odefunc.edge_index, self.odefunc.attention_weights = ops.threshold_edges(
+      self.data_edge_index, score, thr, self.opt['attention_norm_idx'], self.num_nodes)
 
   def forward(self, x):
     attention = self.get_attention_weights(x)

@@ -14,26 +14,14 @@ from .base_classes import ODEblock
 from .function_transformer_attention import SpGraphTransAttentionLayer
 
 
-def _coalesce(index, value, n):
-  """Sum duplicates, entries ordered by (row, col) -- torch_sparse.coalesce(op='add')."""
-  key = index[0] * n + index[1]
-  uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
-  out = torch.zeros(uniq.numel(), dtype=value.dtype, device=value.device).index_add_(0, inverse, value)
-  return torch.stack([torch.div(uniq, n, rounding_mode='floor'), uniq % n]), out
-
-
-def _spspmm(index_a, value_a, index_b, value_b, n):
-  """C = A B for COO operands, coalesced (torch_sparse.spspmm(..., coalesced=True)): every entry (i, k) of A is
-  paired with row k of B through B's row pointer."""
-  order = torch.argsort(index_b[0] * n + index_b[1])
-  b_row, b_col, b_val = index_b[0][order], index_b[1][order], value_b[order]
-  rowptr = torch.zeros(n + 1, dtype=torch.long, device=b_row.device)
-  rowptr[1:] = torch.cumsum(torch.bincount(b_row, minlength=n), 0)
-  counts = rowptr[index_a[1] + 1] - rowptr[index_a[1]]
-  src = torch.repeat_interleave(torch.arange(index_a.shape[1], device=counts.device), counts)
-  first = torch.cumsum(counts, 0) - counts
-  pos = torch.arange(src.numel(), device=counts.device) - first[src] + rowptr[index_a[1]][src]
-  return _coalesce(torch.stack([index_a[0][src], b_col[pos]]), value_a[src] * b_val[pos], n)
+def _device_f32(t, what):
+  """The rewiring bookkeeping has no host / PyTorch path: anything but a float32 HIP tensor is refused, like every
+  other entry of the package (GnpdeError)."""
+  if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32):
+    from ._lib import GnpdeError
+    raise GnpdeError('%s: needs a float32 tensor on a HIP device, got %s on %s (there is no CPU / PyTorch fallback)'
+                     % (what, getattr(t, 'dtype', type(t)), getattr(t, 'device', 'host')))
+  return t
 
 
 class RewireAttODEblock(ODEblock):
@@ -56,11 +44,6 @@ class RewireAttODEblock(ODEblock):
       attention, values = self.odefunc.multihead_att_layer(x, self.data_edge_index)
     return attention
 
-  def renormalise_attention(self, attention):
-    index = self.odefunc.edge_index[self.opt['attention_norm_idx']]
-    sums = torch.zeros(self.num_nodes, dtype=attention.dtype, device=attention.device).index_add_(0, index, attention)
-    return attention / (sums[index] + 1e-16)
-
   def add_random_edges(self):
     """M uniformly random (ordered) node pairs, duplicates of existing edges dropped (reference :52-66; same numpy
     generator call, so a seeded run draws the same pairs)."""
@@ -75,22 +58,11 @@ class RewireAttODEblock(ODEblock):
     """(A + A^2 without its diagonal) / 2 on the current transition matrix (reference :68-86)."""
     n = self.num_nodes
     for _ in range(k - 1):
-      ei, ew = self.odefunc.edge_index, self.odefunc.edge_weight
-      if ew.is_cuda and ew.dtype == torch.float32:
-        # native: one row-wise kernel for spspmm -> remove_self_loops -> cat -> / 2 -> coalesce (csrc/twohop.hip)
-        from . import ops
-        from .graph import graph_of
-        ei, ew = ops.two_hop(graph_of(ei, n), ew)
-        self.data_edge_index = ei
-        self.odefunc.edge_index = self.data_edge_index
-        self.odefunc.attention_weights = ew
-        continue
-      new_edges, new_weights = _spspmm(ei, ew, ei, ew, n)
-      keep = new_edges[0] != new_edges[1]
-      new_edges, new_weights = new_edges[:, keep], new_weights[keep]
-      both_index = torch.cat([ei, new_edges], dim=1)
-      both_value = torch.cat([ew, new_weights], dim=0) / 2
-      ei, ew = _coalesce(both_index, both_value, n)
+      ei, ew = self.odefunc.edge_index, _device_f32(self.odefunc.edge_weight, 'add_khop_edges')
+      # one row-wise kernel for spspmm -> remove_self_loops -> cat -> / 2 -> coalesce (csrc/twohop.hip)
+      from . import ops
+      from .graph import graph_of
+      ei, ew = ops.two_hop(graph_of(ei, n), ew)
       self.data_edge_index = ei
       self.odefunc.edge_index = self.data_edge_index
       self.odefunc.attention_weights = ew
@@ -116,16 +88,12 @@ class RewireAttODEblock(ODEblock):
       delta = torch.linalg.norm(x[self.data_edge_index[0, :], :] - x[self.data_edge_index[1, :], :], dim=1)
       mean_att = mean_att * delta
     total = self.data_edge_index.shape[1]
-    if mean_att.is_cuda and mean_att.dtype == torch.float32 and torch.is_tensor(threshold):
-      from . import ops          # native: stable compaction + renormalisation (csrc/rewire.hip)
-      kept, sampled_attention_weights = ops.threshold_edges(self.data_edge_index, mean_att, threshold,
-                                                            self.opt['attention_norm_idx'], self.num_nodes)
-      self.odefunc.edge_index = kept
-    else:
-      mask = mean_att > threshold
-      self.odefunc.edge_index = self.data_edge_index[:, mask]
-      sampled_attention_weights = self.renormalise_attention(mean_att[mask])
-      kept = self.data_edge_index[:, mask]
+    from . import ops          # stable compaction + renormalisation (csrc/rewire.hip)
+    if not torch.is_tensor(threshold):
+      threshold = torch.tensor(float(threshold), dtype=torch.float32, device=mean_att.device)
+    kept, sampled_attention_weights = ops.threshold_edges(self.data_edge_index, _device_f32(mean_att, 'threshold_edges'),
+                                                          threshold, self.opt['attention_norm_idx'], self.num_nodes)
+    self.odefunc.edge_index = kept
     print('retaining {} of {} edges'.format(self.odefunc.edge_index.shape[1], total))
     self.data_edge_index = kept
     self.odefunc.edge_weight = sampled_attention_weights
@@ -141,12 +109,8 @@ class RewireAttODEblock(ODEblock):
         post_count = self.odefunc.edge_index.shape[1]
         pc_change = post_count / pre_count - 1
         q = 1 / (pc_change - self.opt['rw_addD'])
-        ew = self.odefunc.edge_weight
-        if ew.is_cuda and ew.dtype == torch.float32:
-          from . import ops
-          threshold = ops.quantile(ew, q)          # radix select, same float32 rank arithmetic as torch.quantile
-        else:
-          threshold = torch.quantile(ew, q)
+        from . import ops
+        threshold = ops.quantile(_device_f32(self.odefunc.edge_weight, 'rewiring quantile'), q)   # radix select, same float32 rank arithmetic as torch.quantile
         self.threshold_edges(x, threshold)
     self.odefunc.edge_index = self.data_edge_index
     mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)

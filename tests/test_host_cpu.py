@@ -208,6 +208,25 @@ def test_cpu_tensors_fail_loudly():
   with torch.no_grad(), pytest.raises(G.GnpdeError):
     func(0.0, x)
   assert not os.path.exists(os.path.join(ROOT, 'graph-neural-pde_amd', 'fallback.py'))
+  # the rewiring / hard-attention bookkeeping has no PyTorch branch either: host tensors are refused
+  fx = Fixture('rewire_khop_shat')
+  x = fx.t('x')
+  block = G.RewireAttODEblock(G.LaplacianODEFunc, [], dict(fx.opt), Data(x, fx.t('edge_index')), torch.device('cpu'),
+                              t=torch.tensor([0, fx.opt['time']]))
+  with pytest.raises(G.GnpdeError):
+    block.add_khop_edges(k=2)
+  block.odefunc.attention_weights = block.odefunc.edge_weight
+  with pytest.raises(G.GnpdeError):
+    block.threshold_edges(x, 0.5)
+  hard = G.HardAttODEblock(G.LaplacianODEFunc, [], dict(fx.opt, att_samp_pct=0.5), Data(x, fx.t('edge_index')),
+                           torch.device('cpu'), t=torch.tensor([0, fx.opt['time']]))
+  with pytest.raises(G.GnpdeError):
+    hard._sample_edges(x, torch.rand(hard.data_edge_index.shape[1], 4))
+  import inspect
+  from gnpde_amd import block_transformer_rewiring as B
+  src = inspect.getsource(B)
+  for gone in ('_spspmm', '_coalesce', 'torch.quantile(', 'index_add_'):
+    assert gone not in src, 'PyTorch branch %r is back in the rewiring block' % gone
 
 
 def test_early_stop_integrator_surface():
@@ -248,9 +267,9 @@ def test_product_does_not_import_oracle():
 
 
 def test_rewiring_sparse_helpers_match_dense():
-  """Host helpers of the rewiring block: COO product through the row pointer and duplicate-summing coalesce,
+  """Test-side composite of the rewiring block's two-hop step (tests/sparse_composite.py): COO product through the row pointer and duplicate-summing coalesce,
   against dense matrices (what torch_sparse.spspmm / coalesce compute for the reference)."""
-  from gnpde_amd.block_transformer_rewiring import _spspmm, _coalesce
+  from sparse_composite import _spspmm, _coalesce
   g = torch.Generator().manual_seed(0)
   n = 23
   ia = torch.randint(0, n, (2, 90), generator=g)

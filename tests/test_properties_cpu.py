@@ -171,10 +171,10 @@ def test_time_grid_is_torchdiffeqs(T, h):
 @FAST
 @given(edge_lists(max_n=15, max_e=60), edge_lists(max_n=15, max_e=60), st.integers(0, 2 ** 31 - 1))
 def test_rewiring_sparse_helpers_match_dense(a, b, seed):
-  """Host helpers of the rewiring block (what torch_sparse.spspmm / coalesce compute for the reference,
+  """Test-side composite of the rewiring block's two-hop step (tests/sparse_composite.py) (what torch_sparse.spspmm / coalesce compute for the reference,
   src/block_transformer_rewiring.py:68-86): COO product and duplicate-summing coalesce against dense matrices, the result
   sorted row-major without duplicates."""
-  from gnpde_amd.block_transformer_rewiring import _spspmm, _coalesce
+  from sparse_composite import _spspmm, _coalesce
   n = max(a[0], b[0])
   ia, ib = a[1], b[1]
   g = torch.Generator().manual_seed(seed)

@@ -93,9 +93,8 @@ def test_two_hop_matches_reference_sequence(dev, n, deg, hub):
 
 
 def test_two_hop_agrees_with_the_expanded_list_path(dev):
-  """At a size the dense check cannot reach: against the block's torch composite (expand every product, sort, index_add)."""
-  import importlib
-  B = importlib.import_module('gnpde_amd.block_transformer_rewiring')
+  """At a size the dense check cannot reach: against the test-side torch composite (tests/sparse_composite.py) (expand every product, sort, index_add)."""
+  import sparse_composite as B
   from gnpde_amd import synthetic
   from gnpde_amd.graph import CSRGraph
   n = 40_000

@@ -24,7 +24,8 @@ for rep in range(3):
   torch.cuda.synchronize()
   t1 = time.perf_counter()
   print('native two_hop: n %d, nnz(A) %d -> nnz(S) %d, %.2f ms' % (n, ei.shape[1], out_ei.shape[1], (t1 - t0) * 1e3), flush=True)
-B = importlib.import_module('gnpde_amd.block_transformer_rewiring')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import sparse_composite as B
 try:
   for rep in range(2):
     torch.cuda.synchronize()
