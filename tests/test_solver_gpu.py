@@ -5,6 +5,7 @@ import torch
 
 import gnpde_amd as G
 from oracle import restate as R
+from oracle.shims import install as REF_TORCHDIFFEQ   # restated torchdiffeq 0.2.1 (test infrastructure): the independent integrator
 from helpers import Data, assert_parity, random_graph
 
 pytestmark = pytest.mark.gpu
@@ -337,7 +338,7 @@ def test_blend_arxiv_config_c4(dev):
   """BASELINE configs[3] shape: ogbn-arxiv best_params -- hard_attention block (eval mode: all edges, head-mean
   attention computed once), Laplacian function, dopri5 with tol_scale 11353, T = 3.676, d = 162 = 64 + 98
   (features + positional encoding), attention_dim 32 / 2 heads -- at 1/10 of the node count, against the
-  host dopri5 loop driven by the CPU oracle."""
+  restated torchdiffeq dopri5 of oracle/shims (not the product's integrator) driven by the CPU oracle."""
   ei, n = G.synthetic.make_graph('arxiv', scale=0.1)
   d = 162
   x = torch.randn(n, d, generator=torch.Generator().manual_seed(31)) * 0.5
@@ -367,7 +368,7 @@ def test_blend_arxiv_config_c4(dev):
     calls[0] += 1
     return R.rhs_laplacian(y, e_n, att.mean(dim=1), cpu(f.alpha_train), cpu(f.beta_train), None, False, False)
 
-  ref = G.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
+  ref = REF_TORCHDIFFEQ.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
                  atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
   assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
   assert_parity(z, ref, tol=1e-4, what='C4 (solver tolerance 1.1e-3)')
@@ -378,7 +379,7 @@ def test_blend_arxiv_config_c4_full_size(dev):
   d 162, one exp kernel per channel group multiplied -- reference src/function_transformer_attention.py:133-171),
   `block_transformer_rewiring` (RewireAttODEblock, eval mode: head-mean attention recomputed on the full rw-normalised
   edge set, reference src/block_transformer_rewiring.py:185-241), Laplacian function, dopri5 with tol_scale 11353,
-  T = 3.676.  Against the host dopri5 loop driven by the CPU oracle (split-kernel attention + reference SpMM sequence):
+  T = 3.676.  Against the restated torchdiffeq dopri5 of oracle/shims (not the product's integrator) driven by the CPU oracle (split-kernel attention + reference SpMM sequence):
   same number of evaluations (= same accept / reject decisions) and the same state within the solver's tolerance."""
   ei, n = G.synthetic.make_graph('arxiv')
   assert n == 169343
@@ -419,7 +420,7 @@ def test_blend_arxiv_config_c4_full_size(dev):
     calls[0] += 1
     return R.rhs_laplacian(y, e_n, w_mean, cpu(f.alpha_train), cpu(f.beta_train), None, False, False)
 
-  ref = G.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
+  ref = REF_TORCHDIFFEQ.odeint(rhs, x, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
                  atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
   assert nfe == calls[0], 'different number of accepted / rejected steps: %d vs %d evaluations' % (nfe, calls[0])
   assert_parity(z, ref, tol=1e-4, what='C4 full size (solver tolerance 1.1e-3)')
@@ -449,7 +450,7 @@ def test_padded_rows_for_widths_not_multiple_of_four(dev, function, d, method):
   else:
     rhs = _oracle_rhs(block, x)
   if method == 'dopri5':
-    ref = G.odeint(rhs, x, torch.tensor([0, T], dtype=torch.float32), method='dopri5', options={}, atol=opt['tol_scale'] * 1e-7,
+    ref = REF_TORCHDIFFEQ.odeint(rhs, x, torch.tensor([0, T], dtype=torch.float32), method='dopri5', options={}, atol=opt['tol_scale'] * 1e-7,
                    rtol=opt['tol_scale'] * 1e-9)[1]
     assert_parity(z, ref, tol=2e-5, what='padded dopri5 d=%d' % d)
   else:
