@@ -55,9 +55,6 @@ def parse():
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
   ap.add_argument('--square-plus', action='store_true', help='squareplus normalisation (Cora best_params)')
-  ap.add_argument('--projection-refresh', type=int, default=None,
-                  help='steps between fresh q||k projections of the state (gnpde_solver_set_projection_refresh; 0: project in '
-                       'every evaluation; default: the library default)')
   ap.add_argument('--early-stop', action='store_true',
                   help='run the test-time early-stopping evaluator (40-class decoder, arg-max, split accuracies) after '
                        'every step inside the hipGraph, as the reference does at evaluation time (not the headline metric)')
@@ -71,8 +68,7 @@ def build_opt(cfg, args):
               beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True,
               no_alpha_sigmoid=False, mix_features=False, hidden_dim=cfg['d'], augment=False, adjoint=False,
               tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
-              function=args.function, time=float(args.steps),
-              **({} if getattr(args, 'projection_refresh', None) is None else {'gnpde_projection_refresh': args.projection_refresh}))
+              function=args.function, time=float(args.steps))
 
 
 class _Data(object):

@@ -140,8 +140,6 @@ PROTOTYPES = {
   'gnpde_solver_set_early_stop': (ctypes.c_int, [c_vp, ctypes.POINTER(DecoderStruct), c_vp, c_vp, ctypes.c_int32]),
   'gnpde_lincomb': (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_int32, ctypes.c_int64, c_vp, c_vp]),
   'gnpde_solver_num_rhs_evals': (ctypes.c_int, [c_vp]),
-  'gnpde_solver_set_projection_refresh': (ctypes.c_int, [c_vp, ctypes.c_int32]),
-  'gnpde_solver_tracks_projection': (ctypes.c_int, [c_vp]),
   'gnpde_solver_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_gather_rows': (ctypes.c_int, [c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp,
                                        ctypes.c_int32, c_vp]),

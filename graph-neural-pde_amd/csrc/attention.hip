@@ -578,75 +578,21 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
 // The first `n_hub` blocks of the launch do the hub-row work instead (phase 0: chunk scores + partial
 // statistics, phase 1: fold partials + normalise), so the long rows ride along with the row kernels rather
 // than costing two extra serialised launches.
-// Projection tracking (TRACK): the q||k table of the NEXT stage input comes out of this kernel, so the fixed-step solver
-// runs the dense projection once per refresh interval instead of once per evaluation.  The projection is linear and the stage
-// input is an affine combination (coefficients summing to one) of earlier stage inputs plus dt * f(u), f(u) = alpha (A u - u)
-// + beta x0, so with P(v) = W v + b:
-//   P(u_next)_i = comb(P(y)_i, P(u2)_i, ...) + dt * [ alpha ((sum_e w_e P(u)_{col e} - b sum_e w_e) - (P(u)_i - b)) + beta W x0_i ]
-// The row's wave already gathers the k half of every neighbour's P row for the scores; the q half sits in the same 128-byte
-// line.  It accumulates sum_e w_e P(u)_col for its slice (w_e = the head-mean weight it writes for the aggregation), the
-// slots are folded by an xor butterfly, and the lanes of slot 0 / 1 finish the q / k part of the row with the same stage
-// formulas as the aggregation epilogue (epilogue.h).  Exact in exact arithmetic; in fp32 the tracked table differs from a
-// fresh projection by rounding that a refresh (gnpde_solver_set_projection_refresh) resets.  Rows longer than GNPDE_LONG_ROW
-// get their P row from the state row itself in spmm_long_reduce_proj_kernel.
-struct TrackArgs {
-  int stage;               // GNPDE_STAGE_EULER or RK1C .. RK4C
-  float dt;
-  const float* alpha;      // device scalars of the epilogue
-  const float* beta;       // null: no source term
-  int alpha_sigmoid;
-  const float* bias;       // [ld] q bias then k bias, or null
-  const float* p0;         // [n, ld]  W x0 (no bias), or null
-  const float* py;         // [n, ld]  P(y)            (EULER, RK2C, RK4C)
-  const float* pk1;        // [n, ld]  P(k1 operand)   (RK3C: u2, RK4C: u3)
-  float* pout;             // [n, ld]  P(stage output)
-  int ld;                  // row stride of all tables = AttArgs::ldqk
-  int att_dim;             // A: the k part starts at column A
-};
-
-__device__ __forceinline__ float4 f4_fma(float w, const float4& v, const float4& acc) {
-  return make_float4(fmaf(w, v.x, acc.x), fmaf(w, v.y, acc.y), fmaf(w, v.z, acc.z), fmaf(w, v.w, acc.w));
-}
-
-// q / k part of the tracked row `row` for the 4 columns starting at `col`: aq = sum_e w_e P(u)_col, sw = sum_e w_e
-__device__ __forceinline__ void track_store(const AttArgs& a, const TrackArgs& t, float alpha, float beta, int row, int col,
-                                            const float4& aq, float sw) {
-  const size_t off = static_cast<size_t>(row) * t.ld + col;
-  const float4 pu = *reinterpret_cast<const float4*>(a.q + off);
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f), s0 = b, y = b, k1 = b;
-  if (t.bias != nullptr) b = *reinterpret_cast<const float4*>(t.bias + col);
-  if (t.p0 != nullptr) s0 = *reinterpret_cast<const float4*>(t.p0 + off);
-  const int st = t.stage;
-  if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) y = *reinterpret_cast<const float4*>(t.py + off);
-  if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) k1 = *reinterpret_cast<const float4*>(t.pk1 + off);
-  const float dt = t.dt;
-  constexpr float kThird = 1.0f / 3.0f;
-  auto one = [&](float aqv, float puv, float bv, float s0v, float yv, float k1v) -> float {
-    float k = alpha * ((aqv - sw * bv) - (puv - bv));
-    if (t.p0 != nullptr) k = k + beta * s0v;
-    switch (st) {
-      case GNPDE_STAGE_EULER: return yv + dt * k;
-      case GNPDE_STAGE_RK1C: return puv + (dt * k) * kThird;
-      case GNPDE_STAGE_RK2C: return (2.0f * yv - puv) + dt * k;
-      case GNPDE_STAGE_RK3C: return (2.0f * k1v - puv) + dt * k;
-      default: return (((6.0f * k1v + 3.0f * puv) - yv) + dt * k) * 0.125f;   // RK4C
-    }
-  };
-  const float4 o = make_float4(one(aq.x, pu.x, b.x, s0.x, y.x, k1.x), one(aq.y, pu.y, b.y, s0.y, y.y, k1.y),
-                               one(aq.z, pu.z, b.z, s0.z, y.z, k1.z), one(aq.w, pu.w, b.w, s0.w, y.w, k1.w));
-  *reinterpret_cast<float4*>(t.pout + off) = o;
-}
-
-// Rows [first_row, first_row + n_rows) of the degree-class records; `wave_index` numbers the wavefronts of this class.
-template <int H, int DK4, int GL, int RI, int PB, int NB, bool TRACK>
-__device__ __forceinline__ void sd_rows_body(const AttArgs& a, const TrackArgs& t, int first_row, int n_rows, long long wave_index) {
+template <int H, int DK4, int GL, int RI, int PB, int NB>
+__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
+                                                                 int hub_phase, float* __restrict__ part,
+                                                                 const int* __restrict__ chunk_first) {
+  if (static_cast<int>(blockIdx.x) < n_hub) {
+    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
+    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
+    return;
+  }
   constexpr int RPW = kWave / GL;
   constexpr int GE = GL / H;
-  static_assert(!TRACK || GE >= 2, "tracking finishes the q part on slot 0 and the k part on slot 1");
   const int lane = threadIdx.x & (kWave - 1);
   const int gi = lane % GL;
   const int slot = gi / H, head = gi % H;
-  const long long rbase = (wave_index * RPW + lane / GL) * RI;
+  const long long rbase = ((static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL) * RI;
 
   int row[RI], e0[RI], e1[RI];
   bool live[RI];
@@ -676,11 +622,6 @@ __device__ __forceinline__ void sd_rows_body(const AttArgs& a, const TrackArgs& 
   int nbatch = NB;
   if constexpr (GL == kWave && RI == 1) nbatch = (e1[0] - e0[0] + PB * GE - 1) / (PB * GE);  // wave-uniform
 
-  // TRACK: the neighbour rows of the FIRST batch stay in registers (k half for the scores, q half from the same line); rows
-  // with more than PB * GE entries fetch the later batches a second time once the weights are known
-  float4 kv0[TRACK ? RI : 1][TRACK ? PB : 1][DK4];
-  float4 qj0[TRACK ? RI : 1][TRACK ? PB : 1][DK4];
-
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     if (nb < nbatch) {
@@ -698,15 +639,8 @@ __device__ __forceinline__ void sd_rows_body(const AttArgs& a, const TrackArgs& 
 #pragma unroll
         for (int i = 0; i < PB; ++i)
 #pragma unroll
-          for (int j = 0; j < DK4; ++j) {
+          for (int j = 0; j < DK4; ++j)
             kv[r][i][j] = *reinterpret_cast<const float4*>(a.k + static_cast<size_t>(c[r][i]) * a.ldqk + head * a.dk + 4 * j);
-            if constexpr (TRACK) {
-              if (nb == 0) {
-                kv0[r][i][j] = kv[r][i][j];
-                qj0[r][i][j] = *reinterpret_cast<const float4*>(a.q + static_cast<size_t>(c[r][i]) * a.ldqk + head * a.dk + 4 * j);
-              }
-            }
-          }
 #pragma unroll
       for (int r = 0; r < RI; ++r)
 #pragma unroll
@@ -733,12 +667,6 @@ __device__ __forceinline__ void sd_rows_body(const AttArgs& a, const TrackArgs& 
         for (int i = 0; i < PB; ++i) s[r][nb * PB + i] = -INFINITY;
     }
   }
-  float alpha = 0.f, beta = 0.f;
-  if constexpr (TRACK) {
-    const float av = *t.alpha;
-    alpha = t.alpha_sigmoid ? 1.0f / (1.0f + expf(-av)) : av;
-    beta = (t.beta != nullptr && t.p0 != nullptr) ? *t.beta : 0.0f;
-  }
 #pragma unroll
   for (int r = 0; r < RI; ++r) {
 #pragma unroll
@@ -756,117 +684,19 @@ __device__ __forceinline__ void sd_rows_body(const AttArgs& a, const TrackArgs& 
 #pragma unroll
     for (int off = H; off < GL; off <<= 1) l += __shfl_xor(l, off, kWave);
     const float den = l + 1e-16f;
-    float4 aqq[DK4], aqk[DK4];
-    float sw = 0.f;
-#pragma unroll
-    for (int j = 0; j < DK4; ++j) aqq[j] = aqk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (nb < nbatch) {
-        // TRACK, later batches: fetch the neighbour rows again (ids from L1 / L2, rows from L2: they were read a moment ago)
-        float4 kr[TRACK && NB > 1 ? PB : 1][DK4], qr[TRACK && NB > 1 ? PB : 1][DK4];
-        if constexpr (TRACK && NB > 1) {
-          if (nb > 0) {
-            int c2[PB];
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-              const int e = e0[r] + (nb * PB + i) * GE + slot;
-              c2[i] = a.colidx[e < e1[r] ? e : e1[r] - 1];
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-#pragma unroll
-              for (int j = 0; j < DK4; ++j) {
-                const size_t o = static_cast<size_t>(c2[i]) * a.ldqk + head * a.dk + 4 * j;
-                kr[i][j] = *reinterpret_cast<const float4*>(a.k + o);
-                qr[i][j] = *reinterpret_cast<const float4*>(a.q + o);
-              }
-          }
-        }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           float v = s[r][nb * PB + i] / den;
 #pragma unroll
           for (int off = 1; off < H; off <<= 1) v += __shfl_xor(v, off, kWave);
           const int e = e0[r] + (nb * PB + i) * GE + slot;
-          const float wm = v / static_cast<float>(H);
-          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = wm;
-          if constexpr (TRACK) {
-            sw += wm;            // 0 for the slots past the end of the row (their score was -inf)
-#pragma unroll
-            for (int j = 0; j < DK4; ++j) {
-              if (NB > 1 && nb > 0) {
-                aqk[j] = f4_fma(wm, kr[i][j], aqk[j]);
-                aqq[j] = f4_fma(wm, qr[i][j], aqq[j]);
-              } else {
-                aqk[j] = f4_fma(wm, kv0[r][i][j], aqk[j]);
-                aqq[j] = f4_fma(wm, qj0[r][i][j], aqq[j]);
-              }
-            }
-          }
+          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = v / static_cast<float>(H);
         }
       }
-    if constexpr (TRACK) {
-      // fold the slots (lanes with equal head): afterwards every lane holds the row's sums for its head slice
-#pragma unroll
-      for (int off = H; off < GL; off <<= 1) {
-        sw += __shfl_xor(sw, off, kWave);
-#pragma unroll
-        for (int j = 0; j < DK4; ++j) {
-          aqq[j].x += __shfl_xor(aqq[j].x, off, kWave); aqq[j].y += __shfl_xor(aqq[j].y, off, kWave);
-          aqq[j].z += __shfl_xor(aqq[j].z, off, kWave); aqq[j].w += __shfl_xor(aqq[j].w, off, kWave);
-          aqk[j].x += __shfl_xor(aqk[j].x, off, kWave); aqk[j].y += __shfl_xor(aqk[j].y, off, kWave);
-          aqk[j].z += __shfl_xor(aqk[j].z, off, kWave); aqk[j].w += __shfl_xor(aqk[j].w, off, kWave);
-        }
-      }
-      if (live[r] && slot < 2) {
-#pragma unroll
-        for (int j = 0; j < DK4; ++j)
-          track_store(a, t, alpha, beta, row[r], slot * t.att_dim + head * a.dk + 4 * j, slot == 0 ? aqq[j] : aqk[j], sw);
-      }
-    }
   }
-}
-
-template <int H, int DK4, int GL, int RI, int PB, int NB>
-__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
-                                                                 int hub_phase, float* __restrict__ part,
-                                                                 const int* __restrict__ chunk_first) {
-  if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
-    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
-    return;
-  }
-  const TrackArgs none{};
-  sd_rows_body<H, DK4, GL, RI, PB, NB, false>(a, none, first_row, n_rows,
-                                             static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6));
-}
-
-// Both degree classes and phase 0 of the hub rows in ONE launch: [hub chunks | rows of 17 .. GNPDE_LONG_ROW entries, longest
-// first, a wavefront each | rows of <= 16 entries].  The two classes are latency-bound tails of their own when launched one
-// after the other (30 + 23 us at the ogbn-arxiv shape); in one grid the short rows fill the slots the long ones leave.
-// Phase 1 of the hub rows (fold of the chunk partials + normalisation) follows as hub_normalise_kernel.
-template <int H, int DK4, bool TRACK>
-__global__ __launch_bounds__(kBlock) void row_attention_all_kernel(const AttArgs a, const TrackArgs t, int n16, int n64, int n_hub,
-                                                                  int blocks64, float* __restrict__ part) {
-  constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;
-  constexpr int P16 = (16 * H + GL16 - 1) / GL16;
-  constexpr int RI16 = TRACK ? (P16 == 1 ? 2 : 1) : ((DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1));
-  constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);
-  constexpr int PB64 = (DK4 == 1) ? 4 : 2;
-  int b = static_cast<int>(blockIdx.x);
-  if (b < n_hub) {
-    hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, b);
-    return;
-  }
-  b -= n_hub;
-  const int wave = threadIdx.x >> 6;
-  if (b < blocks64) {
-    sd_rows_body<H, DK4, kWave, 1, PB64, P64 / PB64, TRACK>(a, t, n16, n64, static_cast<long long>(b) * kWavesPerBlock + wave);
-    return;
-  }
-  b -= blocks64;
-  sd_rows_body<H, DK4, GL16, RI16, P16, 1, TRACK>(a, t, 0, n16, static_cast<long long>(b) * kWavesPerBlock + wave);
 }
 
 __global__ __launch_bounds__(kBlock) void edge_to_csr_mean_kernel(const int* __restrict__ perm, const float* __restrict__ src,
@@ -956,49 +786,20 @@ void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub
   }
 }
 
-// One launch for hub phase 0 + both degree classes (row_attention_all_kernel), then hub phase 1 on its own.
-template <int H, int DK4, bool TRACK>
-void launch_all_sd(const AttArgs& a, const TrackArgs& t, int n16, int n64, int n_hub, float* part, const int* chunk_first,
-                   hipStream_t s) {
-  constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;
-  constexpr int P16 = (16 * H + GL16 - 1) / GL16;
-  constexpr int RPW16 = kWave / GL16;
-  constexpr int RI16 = TRACK ? (P16 == 1 ? 2 : 1) : ((DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1));   // as in the kernel
-  const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
-  const int blocks64 = (n64 + kWavesPerBlock - 1) / kWavesPerBlock;
-  const long long grid = n_hub + blocks64 + (n16 + rows_per_block - 1) / rows_per_block;
-  if (grid > 0)
-    hipLaunchKernelGGL((row_attention_all_kernel<H, DK4, TRACK>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, s, a, t, n16,
-                       n64, n_hub, blocks64, part);
-  if (n_hub > 0) hipLaunchKernelGGL(hub_normalise_kernel, dim3(n_hub), dim3(kBlock), 0, s, a, part, chunk_first);
-}
-
-// scaled-dot rows + hub chunks in two launches; false if this (heads, d_k) has no specialised kernel.  track != nullptr:
-// the launch also writes the q||k table of the next stage input (TrackArgs).
-bool launch_sd_with_hubs(const AttArgs& c, int n16, int n64, int n_hub, float* part, const int* chunk_first, hipStream_t s,
-                         const TrackArgs* track = nullptr) {
+// scaled-dot rows + hub chunks in two launches; false if this (heads, d_k) has no specialised kernel
+bool launch_sd_with_hubs(const AttArgs& c, int n16, int n64, int n_hub, float* part, const int* chunk_first, hipStream_t s) {
   if (g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] != 0) return false;
-  const bool merged = track != nullptr || g_tune[GNPDE_TUNE_ATT_TWO_LAUNCHES] == 0;
-  const TrackArgs none{};
-#define GNPDE_SD_ONE(HH, DD)                                                                      \
-  {                                                                                               \
-    if (track != nullptr) launch_all_sd<HH, DD, true>(c, *track, n16, n64, n_hub, part, chunk_first, s);      \
-    else if (merged) launch_all_sd<HH, DD, false>(c, none, n16, n64, n_hub, part, chunk_first, s);            \
-    else launch_rows_sd<HH, DD>(c, n16, n64, s, n_hub, part, chunk_first);                         \
-    return true;                                                                                  \
-  }
-#define GNPDE_SD(HH)                  \
-  case HH:                            \
-    if (c.dk == 4) GNPDE_SD_ONE(HH, 1) \
-    if (c.dk == 8) GNPDE_SD_ONE(HH, 2) \
-    if (c.dk == 16) GNPDE_SD_ONE(HH, 4) \
+#define GNPDE_SD(HH)                                                                              \
+  case HH:                                                                                        \
+    if (c.dk == 4) { launch_rows_sd<HH, 1>(c, n16, n64, s, n_hub, part, chunk_first); return true; }  \
+    if (c.dk == 8) { launch_rows_sd<HH, 2>(c, n16, n64, s, n_hub, part, chunk_first); return true; }  \
+    if (c.dk == 16) { launch_rows_sd<HH, 4>(c, n16, n64, s, n_hub, part, chunk_first); return true; } \
     return false;
   switch (c.h) {
     GNPDE_SD(1) GNPDE_SD(2) GNPDE_SD(4) GNPDE_SD(8)
     default: return false;
   }
 #undef GNPDE_SD
-#undef GNPDE_SD_ONE
 }
 
 template <int TYPE, int H, bool VEC4>
@@ -1094,7 +895,7 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 // kernel arguments -- the backward pass continues from there
 static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                                float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork,
-                               bool stats_only, AttArgs* args_out, bool hubs_only = false, const TrackArgs* track = nullptr) {
+                               bool stats_only, AttArgs* args_out, bool hubs_only = false) {
   GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
   GNPDE_CHECK_ARG(stats_only || w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
   GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
@@ -1151,7 +952,6 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   const bool fused = !stats_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
                      g->bin_rows != nullptr && fused_supported(a, vec4);
   GNPDE_CHECK_ARG(g->row_begin == 0 || fused, GNPDE_EINVAL, "edge_attention: a row sub-range needs the fused row path");
-  GNPDE_CHECK_ARG(track == nullptr || (fused && !hubs_only), GNPDE_ESHAPE, "edge_attention: projection tracking needs the row-softmax path");
   if (fused) {
     AttArgs c = a;
     c.chunk_begin = g->long_chunk_begin;
@@ -1169,11 +969,10 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     if (a.type == GNPDE_ATT_SCALED_DOT && vec4 && (fork == nullptr || fork->aux == nullptr) &&
         (g->n_long_rows == 0 || g->long_chunk_first != nullptr) &&
         launch_sd_with_hubs(c, g->n_bin16, g->n_bin64, g->n_long_rows > 0 ? g->n_long_chunks : 0, part, g->long_chunk_first,
-                            stream, track)) {
+                            stream)) {
       GNPDE_LAUNCH_CHECK();
       return 0;
     }
-    GNPDE_CHECK_ARG(track == nullptr, GNPDE_ESHAPE, "edge_attention: no projection-tracking kernel for heads %d, d_k %d", a.h, a.dk);
     hipStream_t br = stream;
     if (g->n_long_rows > 0) {  // hubs: chunk passes, as a parallel branch when a fork stream is given
       { const int frc = fork_begin(fork, stream, &br); if (frc) return frc; }
@@ -1225,33 +1024,6 @@ int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, f
 int launch_hub_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, void* ws, size_t ws_bytes,
                          hipStream_t stream) {
   return edge_attention_impl(g, at, w_mean_csr, nullptr, nullptr, ws, ws_bytes, stream, nullptr, false, nullptr, true);
-}
-
-// Row attention of the fixed-step solver with projection tracking (TrackArgs above; solver.hip decides when): the q||k table
-// of the stage input is at->q / at->k (row stride at->ldqk = 2A), tr.pout receives the table of the stage output for every
-// row of at most GNPDE_LONG_ROW entries.
-bool attention_track_supported(const gnpde_graph_t* g, const gnpde_attention_t& at) {
-  if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
-  if (!(at.heads == 1 || at.heads == 2 || at.heads == 4 || at.heads == 8) || at.att_dim % at.heads != 0) return false;
-  const int dk = at.att_dim / at.heads;
-  if (!(dk == 4 || dk == 8 || dk == 16)) return false;
-  if (g->bin_rows == nullptr || g->row_begin != 0 || (g->n_long_rows > 0 && g->long_chunk_first == nullptr)) return false;
-  // every row needs a record: a row without entries is in no degree class and would keep a stale table row
-  return static_cast<long long>(g->n_bin16) + g->n_bin64 + g->n_long_rows == g->n && g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] == 0;
-}
-
-int launch_edge_attention_tracked(const gnpde_graph_t* g, const gnpde_attention_t* at, const gnpde_epilogue_t& epi,
-                                  const float* bias, const float* p0, const float* py, const float* pk1, float* pout,
-                                  float* w_mean_csr, void* ws, size_t ws_bytes, hipStream_t stream) {
-  TrackArgs t{};
-  t.stage = epi.stage; t.dt = epi.dt; t.alpha = epi.alpha; t.beta = epi.x0 != nullptr ? epi.beta : nullptr;
-  t.alpha_sigmoid = epi.alpha_sigmoid; t.bias = bias; t.p0 = epi.x0 != nullptr ? p0 : nullptr;
-  t.py = py; t.pk1 = pk1; t.pout = pout; t.ld = at->ldqk; t.att_dim = at->att_dim;
-  GNPDE_CHECK_ARG(epi.stage == GNPDE_STAGE_EULER || (epi.stage >= GNPDE_STAGE_RK1C && epi.stage <= GNPDE_STAGE_RK4C), GNPDE_EINVAL,
-                  "tracked attention: stage %d has no projected form", epi.stage);
-  GNPDE_CHECK_ARG(pout != nullptr && at->k == at->q + at->att_dim && at->ldqk == 2 * at->att_dim, GNPDE_EINVAL,
-                  "tracked attention: needs one [n, 2A] q||k table");
-  return edge_attention_impl(g, at, w_mean_csr, nullptr, nullptr, ws, ws_bytes, stream, nullptr, false, nullptr, false, &t);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -102,8 +102,6 @@ enum {
   GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)
   GNPDE_TUNE_XCD_ROWS = 10,            // 0: as gnpde_graph_t.xcd_deal says; 1: contiguous eighths for every graph; 2: hashed blocks for every graph
   GNPDE_TUNE_HUB_FOLD = 11,            // 1: phase 1 of the hub-row attention stages the row's chunk partials through LDS (one round trip) before the fold
-  GNPDE_TUNE_ATT_TWO_LAUNCHES = 12,    // 1: row attention as two launches (one per degree class, hub phases riding) instead of one + hub phase 1
-  GNPDE_TUNE_NO_PROJ_TRACKING = 13,    // 1: the fixed-step solver projects q||k in every evaluation (no tracking through the attention kernel)
   GNPDE_TUNE_COUNT = 16
 };
 extern int g_tune[GNPDE_TUNE_COUNT];
@@ -136,17 +134,10 @@ inline int fork_end(const Fork* f, hipStream_t s, hipStream_t branch) {
   return 0;
 }
 
-struct HubProj {           // spmm_long_reduce: also project the finished state row of every long row, P = W o + b
-  const float* w;          // [m, ldw]
-  const float* b;          // [m] or null
-  float* out;              // [n, ldo]
-  int m, ldw, ldo;
-};
-
 // internal launchers used by the solver (defined in the kernel translation units)
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes,
-                    hipStream_t stream, const Fork* fork = nullptr, bool padded_rows = false, const HubProj* hub_proj = nullptr);
+                    hipStream_t stream, const Fork* fork = nullptr, bool padded_rows = false);
 
 // attention + aggregation of the short rows in one kernel (spmm.hip) and the hub-row weights it needs (attention.hip)
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
@@ -155,11 +146,6 @@ int launch_attn_spmm(const gnpde_graph_t* g, const gnpde_attention_t* at, const 
                      const gnpde_epilogue_t* epi, void* ws, size_t ws_bytes, hipStream_t stream, bool padded_rows);
 int launch_hub_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, void* ws, size_t ws_bytes,
                          hipStream_t stream);
-// projection tracking through the row attention (attention.hip) and the hub rows' table rows from the long-row fold (spmm.hip)
-bool attention_track_supported(const gnpde_graph_t* g, const gnpde_attention_t& at);
-int launch_edge_attention_tracked(const gnpde_graph_t* g, const gnpde_attention_t* at, const gnpde_epilogue_t& epi,
-                                  const float* bias, const float* p0, const float* py, const float* pk1, float* pout,
-                                  float* w_mean_csr, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // early_stop.hip
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,

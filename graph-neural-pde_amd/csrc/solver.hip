@@ -113,35 +113,6 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
                          (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0);
 }
 
-// One evaluation of the fixed-step solver with projection tracking (attention.hip, TrackArgs): the q||k table `pu` of the
-// stage input u exists already, the row attention writes the table `pout` of the stage output next to the weights, the hub
-// rows' table rows come from the long-row fold of the aggregation.  No projection launch.
-int enqueue_rhs_tracked(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, const float* pu, const float* p0,
-                        const float* py, const float* pk1, float* pout, char* ws, const RhsLayout& L, hipStream_t s) {
-  const gnpde_graph_t* g = r.graph;
-  float* wmean = reinterpret_cast<float*>(ws + L.wmean);
-  gnpde_attention_t at = r.att;
-  at.ldqk = r.proj_m;
-  at.q = pu;
-  at.k = pu + r.att.att_dim;
-  int rc = launch_edge_attention_tracked(g, &at, epi, r.proj_b, p0, py, pk1, pout, wmean, ws + L.att, L.att_bytes, s);
-  if (rc) return rc;
-  HubProj hp{r.proj_w, r.proj_b, pout, r.proj_m, r.d, r.proj_m};
-  return launch_spmm_rhs(g, wmean, u, r.d, r.ld, &epi, nullptr, ws + L.spmm, L.spmm_bytes, s, nullptr,
-                         (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0, g->n_long_rows > 0 ? &hp : nullptr);
-}
-
-// The tracked form exists for GRAND-nl with scaled-dot scores and a row softmax on an unpartitioned graph whose rows all
-// have entries (attention_track_supported), state rows the hub fold can stage (d <= 2048), and when neither the one-pass
-// kernel nor the row-fusion variant is selected.
-bool tracking_supported(const gnpde_rhs_t& r) {
-  if (g_tune[GNPDE_TUNE_NO_PROJ_TRACKING] != 0 || g_tune[GNPDE_TUNE_ONE_PASS] != 0 || g_tune[GNPDE_TUNE_ROW_FUSION] != 0) return false;
-  if (r.kind != GNPDE_RHS_TRANSFORMER || r.proj_m != 2 * r.att.att_dim || r.d > 2048) return false;
-  if (r.n_state_rows > r.graph->n || r.proj_row_end > 0) return false;
-  if (reinterpret_cast<uintptr_t>(r.proj_w) % 16 != 0) return false;
-  return attention_track_supported(r.graph, r.att);
-}
-
 gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r) {
   gnpde_epilogue_t e{};
   e.alpha = r.alpha;
@@ -164,9 +135,6 @@ struct gnpde_solver {
   size_t ws_bytes;
   RhsLayout L;
   size_t off_k1, off_k2, off_k3, off_ua, off_ub, off_rhs;
-  size_t off_track = 0, track_table = 0;   // 5 (rk4) / 3 (euler) q||k tables of [n, 2A] floats behind the evaluation scratch
-  bool track_ok = false;     // the descriptor has a tracked form (tracking_supported)
-  int track_refresh = 1;     // fresh projection of the state every this many steps (0: project in every evaluation, no tracking)
   hipStream_t cap_stream = nullptr;
   Fork fork;                 // second stream + events for the hub-row branch
   hipGraph_t graph_obj = nullptr;
@@ -195,15 +163,8 @@ size_t solver_layout(const gnpde_rhs_t& r, int method, gnpde_solver* s) {
   }
   const size_t rhs_off = off;
   off += rhs_layout(r).total;
-  const size_t track_off = off;
-  size_t table = 0;
-  if (tracking_supported(r)) {
-    table = align_up(static_cast<size_t>(r.graph->n) * r.proj_m * 4, 256);
-    off += (method == GNPDE_METHOD_RK4 ? 5 : 3) * table;
-  }
   if (s) {
     s->off_ua = ua; s->off_ub = ub; s->off_k1 = k1; s->off_k2 = k2; s->off_k3 = k3; s->off_rhs = rhs_off;
-    s->off_track = track_off; s->track_table = table; s->track_ok = table != 0;
   }
   return off;
 }
@@ -233,34 +194,13 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
                                    s->early_trace, s->early_trace_capacity, st);
   };
   if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, 8 * sizeof(int32_t), st));
-  // projection tracking: tables P0 = W x0 (no bias) | Py | Pa | Pb | Pc (rk4) resp. P0 | Pcur | Pnxt (euler)
-  const bool track = s->track_ok && s->track_refresh > 0 && fk == nullptr && tracking_supported(r) &&
-                     (s->method == GNPDE_METHOD_EULER || g_tune[GNPDE_TUNE_RK4_CLASSIC] == 0);
-  auto table = [&](int i) { return reinterpret_cast<float*>(s->ws + s->off_track + static_cast<size_t>(i) * s->track_table); };
-  auto project = [&](const float* state, const float* bias, float* out) -> int {
-    return launch_linear_any(state, r.graph->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, bias, out, r.proj_m, st);
-  };
-  if (track && r.x0 != nullptr) {
-    const int rc = project(r.x0, nullptr, table(0));
-    if (rc) return rc;
-  }
   if (s->method == GNPDE_METHOD_EULER) {
     float* cur = y;
     float* nxt = ua;
-    float* pcur = track ? table(1) : nullptr;
-    float* pnxt = track ? table(2) : nullptr;
     for (float dt : s->dts) {
       gnpde_epilogue_t e = base_epilogue(r);
       e.stage = GNPDE_STAGE_EULER; e.dt = dt; e.y = cur; e.out_y = nxt;
-      int rc = 0;
-      if (track) {
-        if ((step % s->track_refresh) == 0) rc = project(cur, r.proj_b, pcur);
-        if (rc) return rc;
-        rc = enqueue_rhs_tracked(r, cur, e, pcur, table(0), pcur, nullptr, pnxt, rws, s->L, st);
-        float* tp = pcur; pcur = pnxt; pnxt = tp;
-      } else {
-        rc = enqueue_rhs(r, cur, e, rws, s->L, st, fk);
-      }
+      int rc = enqueue_rhs(r, cur, e, rws, s->L, st, fk);
       if (rc) return rc;
       float* t = cur; cur = nxt; nxt = t;
       rc = evaluate(cur);
@@ -277,30 +217,20 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
   if (g_tune[GNPDE_TUNE_RK4_CLASSIC] == 0) {
     // compact stages: y, u2 (ua), u3 (ub), u4 (the k1 slot); k1..k3 are never materialised
     float* uc = k1;
-    float* p0 = table(0);
-    float* py = table(1);
-    float* pa = table(2);
-    float* pb = table(3);
-    float* pc = table(4);
     for (float dt : s->dts) {
       gnpde_epilogue_t e = base_epilogue(r);
       e.dt = dt;
-      int rc = 0;
-      if (track && (step % s->track_refresh) == 0) {   // fresh table of the step's first stage input
-        rc = project(y, r.proj_b, py);
-        if (rc) return rc;
-      }
       e.stage = GNPDE_STAGE_RK1C; e.out_y = ua;
-      rc = track ? enqueue_rhs_tracked(r, y, e, py, p0, nullptr, nullptr, pa, rws, s->L, st) : enqueue_rhs(r, y, e, rws, s->L, st, fk);
+      int rc = enqueue_rhs(r, y, e, rws, s->L, st, fk);
       if (rc) return rc;
       e.stage = GNPDE_STAGE_RK2C; e.y = y; e.out_y = ub;
-      rc = track ? enqueue_rhs_tracked(r, ua, e, pa, p0, py, nullptr, pb, rws, s->L, st) : enqueue_rhs(r, ua, e, rws, s->L, st, fk);
+      rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
       if (rc) return rc;
       e.stage = GNPDE_STAGE_RK3C; e.k1 = ua; e.out_y = uc;
-      rc = track ? enqueue_rhs_tracked(r, ub, e, pb, p0, nullptr, pa, pc, rws, s->L, st) : enqueue_rhs(r, ub, e, rws, s->L, st, fk);
+      rc = enqueue_rhs(r, ub, e, rws, s->L, st, fk);
       if (rc) return rc;
       e.stage = GNPDE_STAGE_RK4C; e.k1 = ub; e.out_y = y;
-      rc = track ? enqueue_rhs_tracked(r, uc, e, pc, p0, py, pb, py, rws, s->L, st) : enqueue_rhs(r, uc, e, rws, s->L, st, fk);
+      rc = enqueue_rhs(r, uc, e, rws, s->L, st, fk);
       if (rc) return rc;
       rc = evaluate(y);
       if (rc) return rc;
@@ -450,17 +380,6 @@ extern "C" int gnpde_solver_set_early_stop(gnpde_solver_t* s, const gnpde_decode
   s->early_trace_capacity = trace_capacity;
   s->early = true;
   return 0;
-}
-
-extern "C" int gnpde_solver_set_projection_refresh(gnpde_solver_t* s, int32_t every_n_steps) {
-  GNPDE_CHECK_ARG(s != nullptr && every_n_steps >= 0, GNPDE_EINVAL, "solver_set_projection_refresh: bad argument");
-  if (s->track_refresh != every_n_steps) drop_graph(s);
-  s->track_refresh = every_n_steps;
-  return 0;
-}
-
-extern "C" int gnpde_solver_tracks_projection(const gnpde_solver_t* s) {
-  return (s != nullptr && s->track_ok && s->track_refresh > 0 && g_tune[GNPDE_TUNE_NO_PROJ_TRACKING] == 0) ? s->track_refresh : 0;
 }
 
 extern "C" int gnpde_solver_num_rhs_evals(const gnpde_solver_t* s) { return s ? s->n_evals : 0; }

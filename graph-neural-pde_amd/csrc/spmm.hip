@@ -221,38 +221,6 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(const SpmmArgs
 }
 
 
-// The same fold for a solver that tracks the q||k projection of its stage inputs (attention.hip, TrackArgs): the block also
-// projects the finished state row, P_i = W o_i + b, which is the table row the next evaluation's attention reads for this
-// (hub) node -- the rows of at most GNPDE_LONG_ROW entries get theirs from the attention kernel's recurrence.
-constexpr int kHubProjMaxD = 2048;
-__global__ __launch_bounds__(kBlock) void spmm_long_reduce_proj_kernel(const SpmmArgs a, const int* __restrict__ long_rows,
-                                                                      const int* __restrict__ long_chunk_ptr, const HubProj hp) {
-  __shared__ float orow[kHubProjMaxD];
-  const int lr = blockIdx.x;
-  const int row = long_rows[lr];
-  const int c0 = long_chunk_ptr[lr], c1 = long_chunk_ptr[lr + 1];
-  const float alpha = alpha_of(a.ep);
-  const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
-  for (int col = threadIdx.x; col < a.d; col += blockDim.x) {
-    float s = 0.0f;
-    for (int c = c0; c < c1; ++c) s += a.partial[static_cast<size_t>(c) * a.ldp + col];
-    const size_t off = static_cast<size_t>(row) * a.ld + col;
-    const float ax[1] = {s};
-    const float ui[1] = {a.u[off]};
-    epilogue<1, false>(a.ep, alpha, beta, off, ax, ui);
-    orow[col] = a.ep.out_y[off];      // this thread's own store, read back
-  }
-  __syncthreads();
-  for (int m = threadIdx.x; m < hp.m; m += blockDim.x) {
-    const float* wr = hp.w + static_cast<size_t>(m) * hp.ldw;
-    float acc = 0.0f;
-    for (int c = 0; c < a.d; ++c) acc = fmaf(wr[c], orow[c], acc);
-    if (hp.b != nullptr) acc += hp.b[m];
-    hp.out[static_cast<size_t>(row) * hp.ldo + m] = acc;
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Wide-row variant (state widths whose row fits ONE wave instruction: d <= 64 VEC).  Differences from
 // spmm_rows_kernel, all aimed at the HBM-bound shapes (RMAT, d = 256: 1-KB rows, table >> Infinity Cache):
@@ -1247,11 +1215,8 @@ inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpr
 
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
                     const gnpde_epilogue_t* epi, float* plain_out, void* ws, size_t ws_bytes, hipStream_t stream,
-                    const Fork* fork, bool padded_rows, const HubProj* hub_proj) {
+                    const Fork* fork, bool padded_rows) {
   GNPDE_CHECK_ARG(g && u && (w_csr || g->e == 0), GNPDE_EINVAL, "spmm: null pointer");
-  GNPDE_CHECK_ARG(hub_proj == nullptr || (epi != nullptr && epi->out_y != nullptr && epi->stage != GNPDE_STAGE_RHS &&
-                                          epi->stage != GNPDE_STAGE_LINCOMB && d <= kHubProjMaxD && fork == nullptr),
-                  GNPDE_EINVAL, "spmm: hub projection needs a fixed-step stage epilogue and d <= %d", kHubProjMaxD);
   GNPDE_CHECK_ARG(d >= 1 && ld >= d, GNPDE_EINVAL, "spmm: bad d=%d ld=%d", d, ld);
   GNPDE_CHECK_ARG((epi != nullptr) != (plain_out != nullptr), GNPDE_EINVAL, "spmm: need exactly one of epilogue / plain output");
   if (g->n == 0) return 0;
@@ -1352,12 +1317,8 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
       if (rc != 0) return rc;
       GNPDE_LAUNCH_CHECK();
     }
-    if (hub_proj != nullptr)
-      hipLaunchKernelGGL(spmm_long_reduce_proj_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
-                         g->long_chunk_ptr, *hub_proj);
-    else
-      hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
-                         g->long_chunk_ptr);
+    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
+                       g->long_chunk_ptr);
     GNPDE_LAUNCH_CHECK();
     if (forked) { const int frc = fork_end(fork, stream, br); if (frc) return frc; }
   }

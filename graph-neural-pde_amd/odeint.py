@@ -32,14 +32,6 @@ def _native_ok(func, y0, t):
           and len(t) == 2 and not func._needs_grad(y0))
 
 
-def _projection_refresh(func):
-  """opt['gnpde_projection_refresh'] / GNPDE_PROJECTION_REFRESH: steps between fresh q||k projections of the state in the
-  fixed-step solver (0: every evaluation); None leaves the library default."""
-  import os
-  v = func.opt.get('gnpde_projection_refresh', os.environ.get('GNPDE_PROJECTION_REFRESH'))
-  return None if v is None or v == '' else int(v)
-
-
 def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None):
   from . import ops
   grid = time_grid(t.detach().to('cpu'), step_size)
@@ -52,8 +44,7 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
     from .utils import MaxNFEException
     raise MaxNFEException
   st = func.__dict__.setdefault('_solver_state', {})
-  refresh = _projection_refresh(func)
-  key = (method, tuple(dts), tuple(y0.shape), str(y0.device), refresh)
+  key = (method, tuple(dts), tuple(y0.shape), str(y0.device))
   ent = st.get(key)
   y0c = y0.detach()
   if ent is None:
@@ -73,7 +64,7 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
   if ent['solver'] is None or ent['sig'] != sig:
     if ent['solver'] is not None:
       ent['solver'].close()
-    ent['solver'] = ops.FixedStepSolver(desc, method, dts, y0.device, projection_refresh=refresh)
+    ent['solver'] = ops.FixedStepSolver(desc, method, dts, y0.device)
     ent['sig'] = sig
   if getattr(ent['solver'], 'evaluator', None) is not evaluator:
     ent['solver'].set_early_stop(evaluator)     # per-step early-stopping evaluation inside the same hipGraph

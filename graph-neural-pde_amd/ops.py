@@ -515,10 +515,7 @@ class EarlyStopEvaluator(object):
 class FixedStepSolver(object):
   """gnpde_solver_t: euler / rk4 over a fixed grid, the whole loop captured in one hipGraph."""
 
-  def __init__(self, desc, method, dts, device, projection_refresh=None):
-    """projection_refresh (GRAND-nl, scaled-dot scores, row softmax): the q||k projection of the state is computed afresh
-    every that many steps and carried through the stages in between by the attention kernel (gnpde_solver_set_projection_refresh);
-    0 = project in every evaluation; None = the library default (every step)."""
+  def __init__(self, desc, method, dts, device):
     self.desc = desc
     self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
     self.dts = [float(v) for v in dts]
@@ -531,9 +528,6 @@ class FixedStepSolver(object):
                                 self.ws.numel()))
     self.handle = handle
     self.n_rhs_evals = L.gnpde_solver_num_rhs_evals(handle)
-    if projection_refresh is not None:
-      check(L.gnpde_solver_set_projection_refresh(handle, int(projection_refresh)))
-    self.projection_refresh = int(L.gnpde_solver_tracks_projection(handle))   # 0: no tracking on this descriptor
 
   def set_early_stop(self, evaluator):
     """Evaluate `evaluator` (EarlyStopEvaluator or None) after every step, inside the same hipGraph."""

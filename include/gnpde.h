@@ -387,21 +387,6 @@ int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs, int32_t me
  * captured once into a hipGraph (keyed on the y pointer) and replayed. */
 int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* stream);
 
-/* Projection tracking of the fixed-step solver  [what it removes: the nn.Linear Q and K of every evaluation,
- * src/function_transformer_attention.py:174-175, 4 x per rk4 step]
- * For GRAND-nl with scaled-dot scores and a softmax over the row (attention_norm_idx 0, no squareplus; heads in {1,2,4,8},
- * d_k in {4,8,16}; unpartitioned graph without empty rows) the q||k table of the NEXT stage input is produced by the row-
- * attention kernel of the current evaluation instead of a projection launch: P(v) = W v + b is affine and the stage input is
- * an affine combination of earlier stage inputs plus dt f(u), f(u) = alpha (A u - u) + beta x0, so
- *   P(u_next)_i = comb(P(y)_i, ...) + dt [ alpha (sum_e w_e (P(u)_col(e) - b) - (P(u)_i - b)) + beta W x0_i ],
- * and the wave that attends row i already holds the rows P(u)_col(e) it needs.  Rows longer than GNPDE_LONG_ROW get their
- * table row from the state row in the long-row fold.  Exact in exact arithmetic; the fp32 difference to a fresh projection
- * is reset every `every_n_steps` steps by projecting the state at the start of the step (default 1: one projection launch
- * per step instead of four; 0: no tracking, project in every evaluation).  Drops a captured graph when the value changes.
- * gnpde_solver_tracks_projection: the interval in use, 0 when the descriptor has no tracked form. */
-int gnpde_solver_set_projection_refresh(gnpde_solver_t* s, int32_t every_n_steps);
-int gnpde_solver_tracks_projection(const gnpde_solver_t* s);
-
 /* One un-fused evaluation out = f(u) of the same descriptor (what ODEFunc.forward returns). */
 int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);
