@@ -257,6 +257,65 @@ extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py's roofline): what the memory system gives a perfectly BALANCED gather of whole state rows.
+// out[i] = sum_{t < k} table[idx[i * k + t]]: every output row gathers exactly k rows of d floats by index, adds them (one VALU
+// add per loaded value, nothing else: no weights, no epilogue operands, no stage algebra) and is stored once.  Same row width,
+// same table and the launch geometry of the aggregation kernels -- LPR = 32 or 64 lanes of 16 bytes own an output row, one
+// wavefront per workgroup, XCD x takes the x-th eighth of the rows -- with all k (<= 16 per batch) row loads of a lane in
+// flight before the first add.  Uniform k: no degree skew, no hub rows, no tail.  The aggregation cannot gather faster than
+// this; how close it comes is roofline.frac when the table is cache-resident and HBM's 8 TB/s is not the ceiling.
+namespace gnpde {
+template <int LPR>
+__global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __restrict__ table, int ld, int d,
+                                                               const int* __restrict__ idx, int k, float* __restrict__ out,
+                                                               int n_out) {
+  constexpr int RPW = kWave / LPR;          // output rows per wavefront
+  const int lane = threadIdx.x;
+  const int sub = lane / LPR, cl = lane % LPR;
+  const int col = cl * 4;
+  const unsigned nb = gridDim.x;
+  const unsigned item = xcd_swizzle(blockIdx.x, nb);
+  const long long row = static_cast<long long>(item) * RPW + sub;
+  if (row >= n_out || col >= d) return;
+  const int* my = idx + row * k;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t0 = 0; t0 < k; t0 += 16) {
+    float4 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t0 + t < k) v[t] = *reinterpret_cast<const float4*>(table + static_cast<size_t>(my[t0 + t]) * ld + col);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w;
+    }
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 o = {acc.x, acc.y, acc.z, acc.w};
+  __builtin_nontemporal_store(o, reinterpret_cast<f4*>(out + static_cast<size_t>(row) * ld + col));
+}
+}  // namespace gnpde
+
+extern "C" int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t d, int32_t ld, const int32_t* idx, int32_t k,
+                                    float* out, int32_t n_out, void* stream) {
+  GNPDE_CHECK_ARG(table && idx && out && n_rows >= 1 && n_out >= 1 && k >= 1, GNPDE_EINVAL, "gather_ceiling: bad arguments");
+  GNPDE_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256 && ld >= d && ld % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % 16 == 0, GNPDE_ESHAPE,
+                  "gather_ceiling: rows of 4..256 floats in 16-byte lanes (d %% 4 == 0, aligned)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d <= 128) {
+    const unsigned grid = gnpde::xcd_grid((static_cast<long long>(n_out) + 1) / 2);
+    hipLaunchKernelGGL(gnpde::gather_ceiling_kernel<32>, dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+  } else {
+    const unsigned grid = gnpde::xcd_grid(n_out);
+    hipLaunchKernelGGL(gnpde::gather_ceiling_kernel<64>, dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+  }
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
 namespace gnpde {
 int launch_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
                    hipStream_t s, const float* scale) {

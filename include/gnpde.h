@@ -489,6 +489,14 @@ int gnpde_dopri5_destroy(gnpde_dopri5_t* s);
 int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int32_t count, int32_t d,
                       float* dst, int32_t ld_dst, void* stream);
 
+/* Measurement aid, no reference equivalent (bench.py's `roofline.ceiling`): out[i] = sum_{t<k} table[idx[i*k + t]] for
+ * i < n_out -- a perfectly balanced gather of whole rows of d floats (d % 4 == 0, <= 256) with the row width, table and launch
+ * geometry of the aggregation kernels and no arithmetic but the adds.  Its rate on the table and mean degree of a workload is
+ * the ceiling the aggregation is reported against when the gathered table is cache-resident (torch_sparse.spmm's gather,
+ * src/function_transformer_attention.py:25-36, stripped of everything else). */
+int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t d, int32_t ld, const int32_t* idx, int32_t k,
+                         float* out, int32_t n_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Edge-set bookkeeping of the hard-attention / rewiring blocks (once per training forward):
  *   threshold = torch.quantile(score, q);  mask = score > threshold;  edge_index[:, mask];  kept scores renormalised by their

@@ -68,7 +68,10 @@ def main():
   if agg:
     k = max(agg, key=lambda n: detail[n]['bytes_per_launch'] * detail[n]['launches'])
     rec = dict(detail[k])
-    rec.update(kernel=k, commit=commit, command=cmd, method='rocprofv3 --pmc, mean over the launches of the command')
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'graph-neural-pde_amd', 'csrc', 'spmm.hip')
+    rec.update(kernel=k, commit=commit, command=cmd, method='rocprofv3 --pmc, mean over the launches of the command',
+               source_sha16=hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16])   # bench.py marks the record stale when spmm.hip changes
     data[key] = rec
   data.setdefault('detail', {})[key] = {'commit': commit, 'command': cmd, 'kernels': detail}
   json.dump(data, open(out_path, 'w'), indent=1)
