@@ -55,7 +55,7 @@ struct AttArgs {
   const int* __restrict__ long_segs;
   const int* __restrict__ rowptr;
   const int* __restrict__ bin_rows;
-  int hub_fold_lds;   // gnpde_tune(11, 1): see hub_normalise_body
+  int hub_fold_lds;   // default on; gnpde_tune(11, 2) folds straight from memory: see hub_normalise_body
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -463,7 +463,8 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
   const int nch = (a.rowptr[row + 1] - a.rowptr[row] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
   // The fold below is a chain of 2 nch DEPENDENT-latency loads issued by h threads (the compiler keeps two in flight): 22
   // chunks of the largest hub of the ogbn-arxiv shape = ~20 round trips before any of the block's 512 weights can be written,
-  // repeated by every chunk block of the row.  Staged form (opt-in until it has been timed, gnpde_tune(11, 1)): the whole
+  // repeated by every chunk block of the row.  Staged form (the default; measured round 3, profiles/r03_v0_blind_changes_measured.txt: equal at the ogbn-arxiv shape,
+  // 4.85 -> 4.68 ms per attention at the R-MAT shape; gnpde_tune(11, 2) selects the fold from memory): the whole
   // block fetches the row's partials in ONE round trip into LDS and the h folding threads read them from there -- the same
   // values combined in the same order, so the weights are bit-identical.
   const int nval = nch * 2 * a.h;                   // block-uniform
@@ -936,7 +937,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.gmax = reinterpret_cast<unsigned*>(base + L.gmax);
   a.gat_terms = reinterpret_cast<float*>(base + L.gat);
   a.w_mean = w_mean_csr; a.att_edge = att_edge; a.prods_edge = prods_edge;
-  a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 1 ? 1 : 0;
+  a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 2 ? 0 : 1;   // default since round 3 (bit-identical; -3.4 % on the R-MAT launch)
   float* part = reinterpret_cast<float*>(base + L.part);
 
   if (a.square_plus) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));

@@ -266,7 +266,7 @@ extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t
 // flight before the first add.  Uniform k: no degree skew, no hub rows, no tail.  The aggregation cannot gather faster than
 // this; how close it comes is roofline.frac when the table is cache-resident and HBM's 8 TB/s is not the ceiling.
 namespace gnpde {
-template <int LPR>
+template <int LPR, bool SHUFFLE>
 __global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __restrict__ table, int ld, int d,
                                                                const int* __restrict__ idx, int k, float* __restrict__ out,
                                                                int n_out) {
@@ -282,10 +282,16 @@ __global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __re
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t0 = 0; t0 < k; t0 += 16) {
     float4 v[16];
+    // SHUFFLE: the 16 ids of the batch by ONE coalesced load per row group (lane cl < 16 holds id t0 + cl), handed out by
+    // ds_bpermute; otherwise every lane of the group loads each id itself (same address: one request)
+    int mine = 0;
+    if constexpr (SHUFFLE) mine = (cl < 16 && t0 + cl < k) ? my[t0 + cl] : 0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t0 + t < k) v[t] = *reinterpret_cast<const float4*>(table + static_cast<size_t>(my[t0 + t]) * ld + col);
+      int c;
+      if constexpr (SHUFFLE) c = __shfl(mine, sub * LPR + t, kWave); else c = t0 + t < k ? my[t0 + t] : 0;
+      if (t0 + t < k) v[t] = *reinterpret_cast<const float4*>(table + static_cast<size_t>(c) * ld + col);
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -299,18 +305,21 @@ __global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __re
 }  // namespace gnpde
 
 extern "C" int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t d, int32_t ld, const int32_t* idx, int32_t k,
-                                    float* out, int32_t n_out, void* stream) {
+                                    float* out, int32_t n_out, int32_t variant, void* stream) {
   GNPDE_CHECK_ARG(table && idx && out && n_rows >= 1 && n_out >= 1 && k >= 1, GNPDE_EINVAL, "gather_ceiling: bad arguments");
   GNPDE_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256 && ld >= d && ld % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(out) % 16 == 0, GNPDE_ESHAPE,
                   "gather_ceiling: rows of 4..256 floats in 16-byte lanes (d %% 4 == 0, aligned)");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  GNPDE_CHECK_ARG(variant == 0 || variant == 1, GNPDE_EINVAL, "gather_ceiling: variant 0 (ids loaded per lane) or 1 (coalesced + shuffle)");
   if (d <= 128) {
     const unsigned grid = gnpde::xcd_grid((static_cast<long long>(n_out) + 1) / 2);
-    hipLaunchKernelGGL(gnpde::gather_ceiling_kernel<32>, dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+    if (variant == 0) hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<32, false>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+    else hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<32, true>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
   } else {
     const unsigned grid = gnpde::xcd_grid(n_out);
-    hipLaunchKernelGGL(gnpde::gather_ceiling_kernel<64>, dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+    if (variant == 0) hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<64, false>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+    else hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<64, true>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
   }
   GNPDE_LAUNCH_CHECK();
   return 0;

@@ -296,6 +296,59 @@ __device__ __forceinline__ void epilogue_pre(const gnpde_epilogue_t& ep, float a
 }
 
 
+// The long-row fold on 16-byte lanes: one wavefront per long row, the epilogue operands requested before the chunk loop and the
+// chunk partials fetched eight at a time (the scalar kernel above walks a chain of dependent-latency loads: 8.4 us for the 204
+// hub rows of the ogbn-arxiv shape, 99 us for the 27 896 of the R-MAT shape).  Same summation: the chunks of a row in chunk order.
+__global__ __launch_bounds__(kWave) void spmm_long_reduce4_kernel(const SpmmArgs a, const int* __restrict__ long_rows,
+                                                                 const int* __restrict__ long_chunk_ptr) {
+  constexpr int VEC = 4;
+  const int lr = blockIdx.x;
+  const int row = long_rows[lr];
+  const int c0 = long_chunk_ptr[lr], c1 = long_chunk_ptr[lr + 1];
+  const bool plain = a.plain_out != nullptr;
+  const float alpha = plain ? 0.0f : alpha_of(a.ep);
+  const float beta = (!plain && a.ep.x0 != nullptr) ? *a.ep.beta : 0.0f;
+  const bool pre_ok = !plain && stage_prefetchable<VEC, false>(a.ep.stage);
+  for (int col = static_cast<int>(threadIdx.x) * VEC; col < a.d; col += kWave * VEC) {
+    const size_t off = static_cast<size_t>(row) * a.ld + col;
+    Pre<VEC, false> pre;
+    if (pre_ok) {
+      load_vec<VEC>(a.u + off, pre.ui);
+      if (a.ep.x0 != nullptr) load_vec<VEC>(a.ep.x0 + off, pre.x0);
+      const int st = a.ep.stage;
+      if (st == GNPDE_STAGE_EULER || st == GNPDE_STAGE_RK2C || st == GNPDE_STAGE_RK4C) load_vec<VEC>(a.ep.y + off, pre.y);
+      if (st == GNPDE_STAGE_RK3C || st == GNPDE_STAGE_RK4C) load_vec<VEC>(a.ep.k1 + off, pre.k1);
+    }
+    float acc[VEC] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* p = a.partial + static_cast<size_t>(c0) * a.ldp + col;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8, p += 8 * static_cast<size_t>(a.ldp)) {
+      float v[8][VEC];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) load_vec<VEC>(p + t * static_cast<size_t>(a.ldp), v[t]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += v[t][q];
+    }
+    for (; c < c1; ++c, p += a.ldp) {
+      float v[VEC];
+      load_vec<VEC>(p, v);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+    }
+    if (plain) {
+      store_vec<VEC>(a.plain_out + off, acc);
+    } else if (pre_ok) {
+      epilogue_pre<VEC, false>(a.ep, alpha, beta, off, acc, pre);
+    } else {
+      float ui[VEC];
+      load_vec<VEC>(a.u + off, ui);
+      epilogue<VEC, false>(a.ep, alpha, beta, off, acc, ui);
+    }
+  }
+}
+
 // U gathers of one wave (G neighbours each) from the 64 (column id, weight) pairs held one per lane in cv / wv.
 // G == 1: the entry is wave-uniform -> v_readlane, row base address in SGPRs.  TAIL: entries >= cnt are skipped.
 template <int VEC, int L, int U, bool TAIL, bool FULL>
@@ -1317,8 +1370,11 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
       if (rc != 0) return rc;
       GNPDE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
-                       g->long_chunk_ptr);
+    if (a16)
+      hipLaunchKernelGGL(spmm_long_reduce4_kernel, dim3(g->n_long_rows), dim3(kWave), 0, br, a, g->long_rows, g->long_chunk_ptr);
+    else
+      hipLaunchKernelGGL(spmm_long_reduce_kernel, dim3(g->n_long_rows), dim3(kBlock), 0, br, a, g->long_rows,
+                         g->long_chunk_ptr);
     GNPDE_LAUNCH_CHECK();
     if (forked) { const int frc = fork_end(fork, stream, br); if (frc) return frc; }
   }

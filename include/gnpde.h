@@ -495,7 +495,7 @@ int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int3
  * the ceiling the aggregation is reported against when the gathered table is cache-resident (torch_sparse.spmm's gather,
  * src/function_transformer_attention.py:25-36, stripped of everything else). */
 int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t d, int32_t ld, const int32_t* idx, int32_t k,
-                         float* out, int32_t n_out, void* stream);
+                         float* out, int32_t n_out, int32_t variant /* 0: ids loaded per lane, 1: coalesced + shuffle */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge-set bookkeeping of the hard-attention / rewiring blocks (once per training forward):

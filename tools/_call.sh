@@ -1,5 +1,15 @@
 set -u
-OUT=gpurun_out/r03b; mkdir -p $OUT
-timeout 300 python -m pytest tests/test_tracking_gpu.py -x -q -p no:cacheprovider > $OUT/pytest_tracking.log 2>&1; echo "rc $?" >> $OUT/pytest_tracking.log; tail -15 $OUT/pytest_tracking.log
-timeout 200 python tools/tracking_ab.py arxiv 100 > $OUT/tracking_ab_arxiv.log 2>&1; echo "rc $?" >> $OUT/tracking_ab_arxiv.log; tail -8 $OUT/tracking_ab_arxiv.log
-timeout 400 python -m pytest tests -m gpu -x -q -p no:cacheprovider --deselect tests/test_tracking_gpu.py > $OUT/pytest.log 2>&1; echo "rc $?" >> $OUT/pytest.log; tail -8 $OUT/pytest.log
+OUT=gpurun_out/r03c; mkdir -p $OUT
+timeout 200 python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_arxiv.json 2> $OUT/bench_arxiv.err; echo "rc $?"; tail -3 $OUT/bench_arxiv.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03c/bench_arxiv.json').read().strip().split('\n')[-1])
+r=d['roofline']; print(d['value'], d['ms_per_step']); print({k:r[k] for k in ('bound','achieved','peak','frac','avg_launch_us','traffic_gbs')}); print(r['ceiling']); print(r['secondary']); print(r.get('traffic_source'))
+PY
+timeout 500 python -m pytest tests/test_solver_gpu.py tests/test_golden_gpu.py tests/test_rewiring_gpu.py tests/test_rewire_prims_gpu.py tests/test_autograd_gpu.py -x -q -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "rc $?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log
+timeout 400 python bench.py --graph rmat --steps 4 --warmup 1 > $OUT/bench_rmat.json 2> $OUT/bench_rmat.err; echo "rc $?"; tail -3 $OUT/bench_rmat.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03c/bench_rmat.json').read().strip().split('\n')[-1])
+r=d['roofline']; print(d['value'], d['ms_per_step']); print({k:r[k] for k in ('bound','achieved','peak','frac','frac_of_hbm_peak','avg_launch_us','traffic_gbs')}); print(r['ceiling']); print(r['secondary'])
+PY

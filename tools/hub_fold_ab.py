@@ -1,5 +1,5 @@
-"""A/B of the hub-row attention's phase 1 (GPU box only): chunk partials folded straight from memory (default) against the
-LDS-staged fold (gnpde_tune(11, 1), csrc/attention.hip::hub_normalise_body).  Same values combined in the same order, so the
+"""A/B of the hub-row attention's phase 1 (GPU box only): chunk partials folded straight from memory (gnpde_tune(11, 2)) against the
+LDS-staged fold (the default since round 3, csrc/attention.hip::hub_normalise_body).  Same values combined in the same order, so the
 head-mean weights must be BIT-identical; prints the time of the attention launches (projection excluded) for both.
 
   python tools/hub_fold_ab.py [arxiv|rmat|...]
@@ -47,15 +47,16 @@ def timed(reps=50):
 
 res = {'graph': name, 'hub_rows': graph.n_long_rows, 'hub_chunks': int(graph.struct.n_long_chunks), 'max_row_len': graph.max_row_len,
        'from_memory_us': [], 'lds_staged_us': []}
+_lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 2))
 w0 = attend().clone()
-_lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 1))
+_lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 0))
 w1 = attend().clone()
 _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 0))
 res['bit_equal'] = bool(torch.equal(w0, w1))
 for _ in range(3):
-  _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 0))
+  _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 2))
   res['from_memory_us'].append(round(timed(), 1))
-  _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 1))
+  _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 0))
   res['lds_staged_us'].append(round(timed(), 1))
 _lib.check(L.gnpde_tune(_lib.TUNE_HUB_FOLD, 0))
 print(json.dumps(res))
