@@ -91,6 +91,8 @@ PROTOTYPES = {
                                           ctypes.c_uint64, c_vp]),
   'gnpde_partition_rows_ex': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, c_vp]),
+  'gnpde_partition_refine_links': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  c_vp, c_vp]),
   'gnpde_push_order': (ctypes.c_int, [c_int_p, ctypes.c_int32, c_int_p]),
   'gnpde_xcd_row_map': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_int_p, c_int_p, c_vp]),
   'gnpde_spmm_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.c_int32]),

@@ -327,3 +327,157 @@ extern "C" int gnpde_partition_rows_ex(const int32_t* rowptr, const int32_t* col
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Communication refinement of a k-way row partition (round 3).  What a partitioned evaluation pays for is not the edge cut
+// but the ROWS each rank receives: M[r][q] = number of distinct nodes of part q that rows of part r reference = the rows that
+// cross the xGMI link q -> r in every evaluation; the exchange ends when the busiest link has delivered.  The label-propagation
+// partition above minimises cut edges only.  This pass moves single nodes between parts when that lowers the TOTAL number of
+// received rows (sum of M) without raising the busiest link, keeping the parts inside the balance window of the partitioner
+// (3 % on entries + row_weight per row); then a second phase works on the busiest links alone and accepts moves that lower
+// sum_{links} max(0, M - 0.9 max M) even when the total does not fall.  Both phases are plain hill climbing with exact
+// bookkeeping: ref[u][p] = rows of part p that reference node u (self references never travel and are ignored), from which M
+// follows; a move v: a -> b changes (i) who receives v (the parts whose rows reference v: from a's link to b's link) and (ii)
+// what a and b receive (the nodes row v references).  Deterministic.  stats (nullable): [0] busiest link before, [1] after,
+// [2] total rows received before, [3] after, [4] moves applied.
+// ------------------------------------------------------------------------------------------------
+extern "C" int gnpde_partition_refine_links(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes, int32_t n_parts,
+                                            int32_t row_weight_arg, int32_t max_passes, int32_t* part, int64_t* stats) {
+  GNPDE_CHECK_ARG(rowptr && part && n_nodes >= 0 && n_parts >= 1 && row_weight_arg >= 1 && max_passes >= 0, GNPDE_EINVAL,
+                  "partition_refine_links: bad args");
+  GNPDE_CHECK_ARG(colidx || rowptr[n_nodes] == 0, GNPDE_EINVAL, "partition_refine_links: null colidx");
+  const int32_t n = n_nodes, P = n_parts;
+  if (stats) std::fill(stats, stats + 5, 0);
+  if (P == 1 || n == 0 || max_passes == 0) return 0;
+  GNPDE_CHECK_ARG(static_cast<int64_t>(n) * P <= (int64_t(1) << 31), GNPDE_ESHAPE,
+                  "partition_refine_links: %d nodes x %d parts exceeds the dense reference table", n, P);
+  for (int32_t v = 0; v < n; ++v)
+    GNPDE_CHECK_ARG(part[v] >= 0 && part[v] < P, GNPDE_EINVAL, "partition_refine_links: part[%d] = %d", v, part[v]);
+  const int64_t row_weight = row_weight_arg;
+  auto work = [&](int32_t v) -> int64_t { return int64_t(rowptr[v + 1] - rowptr[v]) + row_weight; };
+  std::vector<int64_t> load(P, 0);
+  int64_t total = 0, maxw = 0;
+  for (int32_t v = 0; v < n; ++v) {
+    load[part[v]] += work(v);
+    total += work(v);
+    maxw = std::max(maxw, work(v));
+  }
+  const double avg = double(total) / P;
+  const int64_t hi = std::max<int64_t>(static_cast<int64_t>(avg * 1.03) + maxw / 8 + 1, *std::max_element(load.begin(), load.end()));
+  const int64_t lo = std::min<int64_t>(static_cast<int64_t>(avg * 0.97) - maxw / 8, *std::min_element(load.begin(), load.end()));
+
+  // ref[u * P + p]: rows of part p referencing node u
+  std::vector<int32_t> ref(static_cast<size_t>(n) * P, 0);
+  for (int32_t v = 0; v < n; ++v)
+    for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e)
+      if (colidx[e] != v) ++ref[static_cast<size_t>(colidx[e]) * P + part[v]];
+  std::vector<int64_t> M(static_cast<size_t>(P) * P, 0);   // M[r * P + q]
+  for (int32_t u = 0; u < n; ++u)
+    for (int32_t r = 0; r < P; ++r)
+      if (r != part[u] && ref[static_cast<size_t>(u) * P + r] > 0) ++M[static_cast<size_t>(r) * P + part[u]];
+  auto max_link = [&]() { return *std::max_element(M.begin(), M.end()); };
+  auto volume = [&]() { int64_t s = 0; for (int64_t x : M) s += x; return s; };
+  const int64_t link0 = max_link(), vol0 = volume();
+
+  // apply v: a -> b with exact bookkeeping; returns the change of the total volume.  `inc` collects the links that grew.
+  std::vector<int32_t> inc;
+  auto apply = [&](int32_t v, int32_t a, int32_t b) -> int64_t {
+    int64_t dv = 0;
+    const int32_t* rv = &ref[static_cast<size_t>(v) * P];
+    for (int32_t r = 0; r < P; ++r) {          // (i) who receives v
+      if (rv[r] <= 0) continue;
+      if (r != a) { --M[static_cast<size_t>(r) * P + a]; --dv; }
+      if (r != b) { ++M[static_cast<size_t>(r) * P + b]; ++dv; inc.push_back(r * P + b); }
+    }
+    for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {   // (ii) what a and b receive
+      const int32_t u = colidx[e];
+      if (u == v) continue;
+      const int32_t pu = part[u];              // (u != v, so pu is u's current part)
+      int32_t* ru = &ref[static_cast<size_t>(u) * P];
+      if (--ru[a] == 0 && pu != a) { --M[static_cast<size_t>(a) * P + pu]; --dv; }
+      if (ru[b]++ == 0 && pu != b) { ++M[static_cast<size_t>(b) * P + pu]; ++dv; inc.push_back(b * P + pu); }
+    }
+    part[v] = b;
+    const int64_t w = work(v);
+    load[a] -= w;
+    load[b] += w;
+    return dv;
+  };
+
+  // visiting order: a fixed stride permutation
+  std::vector<int32_t> order(n);
+  {
+    uint64_t stride = (2654435761ULL + 40503ULL) % std::max<int64_t>(n, 1);
+    if (stride == 0) stride = 1;
+    auto gcd = [](uint64_t x, uint64_t y) { while (y) { uint64_t t = x % y; x = y; y = t; } return x; };
+    while (gcd(stride, static_cast<uint64_t>(n)) != 1) ++stride;
+    uint64_t cur = 0;
+    for (int32_t i = 0; i < n; ++i) { order[i] = static_cast<int32_t>(cur); cur = (cur + stride) % n; }
+  }
+  std::vector<int32_t> cand;
+  std::vector<char> seen(P, 0);
+  int64_t moves = 0;
+  // excess over a threshold, summed over the links: the quantity phase 2 lowers
+  auto excess = [&](int64_t thr) { int64_t s = 0; for (int64_t x : M) s += std::max<int64_t>(0, x - thr); return s; };
+
+  for (int phase = 0; phase < 2; ++phase) {
+    for (int32_t pass = 0; pass < max_passes; ++pass) {
+      const int64_t cap = max_link();
+      const int64_t thr = phase == 0 ? 0 : cap - cap / 10;
+      int64_t pass_moves = 0;
+      for (int32_t oi = 0; oi < n; ++oi) {
+        const int32_t v = order[oi];
+        const int32_t a = part[v];
+        // candidate parts: those of the nodes v references and of the rows that reference v
+        cand.clear();
+        for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+          const int32_t p = part[colidx[e]];
+          if (p != a && !seen[p]) { seen[p] = 1; cand.push_back(p); }
+        }
+        const int32_t* rv = &ref[static_cast<size_t>(v) * P];
+        for (int32_t r = 0; r < P; ++r)
+          if (r != a && rv[r] > 0 && !seen[r]) { seen[r] = 1; cand.push_back(r); }
+        for (int32_t p : cand) seen[p] = 0;
+        if (cand.empty()) continue;
+        if (phase == 1) {   // only nodes that sit on a link above the threshold
+          bool hot = false;
+          for (int32_t r = 0; r < P && !hot; ++r)
+            if (r != a && rv[r] > 0 && M[static_cast<size_t>(r) * P + a] > thr) hot = true;
+          for (int32_t e = rowptr[v]; e < rowptr[v + 1] && !hot; ++e) {
+            const int32_t pu = part[colidx[e]];
+            if (pu != a && M[static_cast<size_t>(a) * P + pu] > thr) hot = true;
+          }
+          if (!hot) continue;
+        }
+        const int64_t w = work(v);
+        int32_t best = -1;
+        int64_t best_gain = 0;
+        for (int32_t b : cand) {
+          if (load[b] + w > hi || load[a] - w < lo) continue;
+          inc.clear();
+          const int64_t ex0 = phase == 1 ? excess(thr) : 0;
+          const int64_t dv = apply(v, a, b);
+          bool ok = true;
+          for (int32_t l : inc)
+            if (M[l] > cap) { ok = false; break; }
+          int64_t gain = 0;
+          if (ok) gain = phase == 0 ? -dv : (ex0 - excess(thr)) * 4 - dv;   // phase 2: excess first, volume as the tie-break
+          inc.clear();
+          (void)apply(v, b, a);     // undo
+          if (ok && gain > best_gain) { best_gain = gain; best = b; }
+        }
+        if (best >= 0) {
+          inc.clear();
+          (void)apply(v, a, best);
+          ++pass_moves;
+        }
+      }
+      moves += pass_moves;
+      if (pass_moves == 0) break;
+    }
+  }
+  if (stats) {
+    stats[0] = link0; stats[1] = max_link(); stats[2] = vol0; stats[3] = volume(); stats[4] = moves;
+  }
+  return 0;
+}

@@ -261,12 +261,13 @@ def graph_of(edge_index, num_nodes, device=None):
   return GRAPHS.get(edge_index, int(num_nodes), edge_index.device if device is None else device)
 
 
-def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1, cluster_div=4):
+def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1, cluster_div=4, refine_links=6, stats=None):
   """Balanced k-way row partition (native, csrc/graph_prep.cpp).  Accepts a CSRGraph or a
   (rowptr, colidx) pair of int32 CPU tensors; returns an int32 CPU tensor [n].  The parts are balanced on
   entries + row_weight per row: 1 follows the aggregation time, larger values even out the NODE counts (and with them the
   rows a part has to send to its peers); the label-propagation clusters that are packed into parts are capped at a part's
-  work / cluster_div."""
+  work / cluster_div.  refine_links > 0: that many passes per phase of the communication refinement afterwards (rows received
+  per rank and the busiest link instead of cut edges; `stats` dict receives before / after)."""
   if isinstance(graph_or_csr, CSRGraph):
     rowptr = graph_or_csr.t['rowptr'].cpu()
     colidx = graph_or_csr.t['colidx'].cpu()
@@ -278,4 +279,12 @@ def partition_rows(graph_or_csr, n_parts, refine_iters=8, seed=0, row_weight=1, 
   part = torch.zeros(n, dtype=torch.int32)
   _lib.check(_lib.lib().gnpde_partition_rows_ex(rowptr.data_ptr(), colidx.data_ptr(), n, int(n_parts), int(refine_iters),
                                                 int(seed), int(row_weight), int(cluster_div), part.data_ptr()))
+  if refine_links and n_parts > 1 and n * int(n_parts) <= 2 ** 31:
+    # communication refinement (gnpde_partition_refine_links): fewer received rows, lower busiest link, same balance window
+    st = torch.zeros(5, dtype=torch.int64)
+    _lib.check(_lib.lib().gnpde_partition_refine_links(rowptr.data_ptr(), colidx.data_ptr(), n, int(n_parts), int(row_weight),
+                                                       int(refine_links), part.data_ptr(), st.data_ptr()))
+    if stats is not None:
+      stats.update(max_link_before=int(st[0]), max_link_after=int(st[1]), received_rows_before=int(st[2]),
+                   received_rows_after=int(st[3]), moves=int(st[4]))
   return part

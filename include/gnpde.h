@@ -89,6 +89,15 @@ int gnpde_partition_rows(const int32_t* rowptr, const int32_t* colidx, int32_t n
 int gnpde_partition_rows_ex(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes, int32_t n_parts,
                             int32_t refine_iters, uint64_t seed, int32_t row_weight, int32_t cluster_div, int32_t* part);
 
+/* Communication refinement of a row partition (no reference equivalent).  A partitioned evaluation waits for the rows each rank
+ * RECEIVES, not for cut edges: M[r][q] = distinct nodes of part q referenced by rows of part r = rows on the link q -> r per
+ * evaluation.  Hill climbing on single-node moves with exact bookkeeping: phase 1 lowers the total of M without raising the
+ * busiest link, phase 2 lowers the excess of the links above 90 % of the busiest; the parts stay inside the balance window of
+ * gnpde_partition_rows_ex (entries + row_weight per row).  part[n] in / out.  stats (nullable, int64[5]): busiest link before /
+ * after, total received rows before / after, moves.  Host only, deterministic. */
+int gnpde_partition_refine_links(const int32_t* rowptr, const int32_t* colidx, int32_t n_nodes, int32_t n_parts,
+                                 int32_t row_weight, int32_t max_passes, int32_t* part, int64_t* stats);
+
 /* Device view of a prepared graph (all pointers device memory). */
 typedef struct gnpde_graph {
   int32_t n;                         /* nodes (square operator)                              */

@@ -561,3 +561,50 @@ def test_meter_matches_the_reference_meter():
       assert vars(ref) == vars(ours) and ref.get_average() == ours.get_average() and ref.get_value() == ours.get_value()
   import inspect
   assert 'self.fm = Meter()' in inspect.getsource(G.BaseGNN.__init__) and 'self.bm = Meter()' in inspect.getsource(G.BaseGNN.__init__)
+
+
+@pytest.mark.parametrize('parts', [2, 3, 8])
+def test_partition_link_refinement_invariants(parts):
+  """gnpde_partition_refine_links: the rows a rank RECEIVES (distinct referenced nodes per peer) are what an evaluation waits
+  for.  The refinement must (i) report the same busiest link / total as an independent recount (distributed.pair_traffic),
+  (ii) never raise the busiest link or the total, (iii) keep every part inside the partitioner's balance window, (iv) keep
+  part ids valid, (v) be deterministic."""
+  from gnpde_amd import distributed as D
+  from gnpde_amd.graph import CSRGraph, partition_rows
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.05)
+  ei2, _ = G.add_remaining_self_loops(ei, None, 1.0, n)
+  g = CSRGraph(ei2, n, device='cpu')
+  before = partition_rows(g, parts, refine_links=0).long()
+  st = {}
+  after = partition_rows(g, parts, refine_links=6, stats=st).long()
+  again = partition_rows(g, parts, refine_links=6).long()
+  assert torch.equal(after, again)
+  assert int(after.min()) >= 0 and int(after.max()) < parts
+  m0, m1 = D.pair_traffic(ei2, before, parts), D.pair_traffic(ei2, after, parts)
+  assert st['max_link_before'] == int(m0.max()) and st['received_rows_before'] == int(m0.sum())
+  assert st['max_link_after'] == int(m1.max()) and st['received_rows_after'] == int(m1.sum())
+  assert int(m1.max()) <= int(m0.max()) and st['moves'] > 0
+  assert int(m1.max()) < int(m0.max()) or int(m1.sum()) < int(m0.sum()), 'the refinement found nothing to improve on a community graph'
+  deg = torch.bincount(ei2[0], minlength=n) + 1
+  load = torch.zeros(parts, dtype=torch.long).index_add_(0, after, deg)
+  load0 = torch.zeros(parts, dtype=torch.long).index_add_(0, before, deg)
+  avg = float(deg.sum()) / parts
+  hi = max(int(avg * 1.03) + int(deg.max()) // 8 + 1, int(load0.max()))
+  lo = min(int(avg * 0.97) - int(deg.max()) // 8, int(load0.min()))
+  assert int(load.max()) <= hi and int(load.min()) >= lo, (load.tolist(), lo, hi)
+
+
+def test_partition_link_refinement_handles_directed_graphs_and_loops():
+  """Self references never travel (a node's own row reads it locally); a directed graph's received rows follow the row ->
+  column direction only."""
+  from gnpde_amd import distributed as D
+  from gnpde_amd.graph import CSRGraph, partition_rows
+  g0 = torch.Generator().manual_seed(5)
+  n = 400
+  ei = torch.cat([torch.randint(0, n, (2, 2400), generator=g0), torch.arange(n).repeat(2, 1)], dim=1)   # directed + loops
+  g = CSRGraph(ei, n, device='cpu')
+  st = {}
+  part = partition_rows(g, 4, refine_links=4, stats=st).long()
+  m = D.pair_traffic(ei, part, 4)
+  assert st['max_link_after'] == int(m.max()) and st['received_rows_after'] == int(m.sum())
+  assert int(torch.diagonal(m).sum()) == 0
