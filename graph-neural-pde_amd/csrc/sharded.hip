@@ -129,6 +129,7 @@ struct PushArgs {
   const long long* dst_row0;   // [world] first halo row of this rank's rows on peer p
   uint32_t* const* peer_ctl;   // [world]
   uint32_t* ctl;               // local
+  unsigned long long* stamp;   // NULL or [2]: wall clock when the push started / when its epoch was published
 };
 
 // One wavefront per row: copy it into the owner-side halo slot on the peer (xGMI stores), then -- last block -- publish
@@ -136,6 +137,7 @@ struct PushArgs {
 __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  if (a.stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamp[0] = wall_clock64();
   if (w < a.n_send) {
     // The send list is grouped by destination.  Walked in that order, everything in flight at any moment targets ONE peer:
     // one xGMI link carries the whole push while the other six idle, and the exchange takes the SUM of the per-link times.
@@ -163,14 +165,17 @@ __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
       __threadfence_system();
       for (int p = 0; p < a.world; ++p)
         if (p != a.rank) __hip_atomic_store(a.peer_ctl[p] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.stamp != nullptr) a.stamp[1] = wall_clock64();
     }
   }
 }
 
 // In front of the boundary pass: wait until every peer has published the epoch of THIS evaluation.  Bounded spin: a
 // peer that never arrives sets the error word instead of hanging the GPU (gnpde_sharded_solver_status).
-__global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, int rank, int world, long long max_spins) {
+__global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, int rank, int world, long long max_spins,
+                                                               unsigned long long* stamp) {
   __shared__ unsigned expect;
+  if (stamp != nullptr && threadIdx.x == 0) stamp[0] = wall_clock64();   // the main stream arrives (interior pass done)
   if (threadIdx.x == 0) {
     expect = __hip_atomic_load(ctl + kCtlWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     __hip_atomic_store(ctl + kCtlWait, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, in
     }
   }
   __threadfence_system();
+  __syncthreads();
+  if (stamp != nullptr && threadIdx.x == 0) stamp[1] = wall_clock64();   // every peer's rows have landed
 }
 
 }  // namespace
@@ -223,6 +230,10 @@ struct gnpde_sharded_solver {
   bool exchanges = false;           // an exchange (and, with P2P, an epoch handshake with every peer) per evaluation
   long long max_spins = 1LL << 24;  // bound of the wait kernel's poll loop (~1 us per poll): a lost peer cannot hang the GPU
   int n_evals = 0;
+  // P2P: wall-clock stamps of every evaluation of the last run, [n_evals + 1][4] = push start, epoch published, main stream
+  // at the wait, all peers' rows landed (gnpde_sharded_solver_timing); the extra row is the end-of-solve rendezvous
+  unsigned long long* d_stamps = nullptr;
+  int eval_cursor = 0;              // evaluation being enqueued
 };
 
 namespace {
@@ -303,6 +314,7 @@ int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = u != nullptr ? s->n_send : 0; a.rank = x->rank; a.world = x->world;
   a.send_idx = s->send_idx; a.order = s->d_order; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
   a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl;
+  a.stamp = s->d_stamps != nullptr ? s->d_stamps + 4 * static_cast<size_t>(s->eval_cursor) : nullptr;
   const unsigned grid = static_cast<unsigned>(a.n_send > 0 ? (a.n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
   hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
   GNPDE_LAUNCH_CHECK();
@@ -326,10 +338,11 @@ int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStrea
     GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
     if (s->p2p) {   // the peers' rows have landed once every peer has published this evaluation's epoch
       hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, s->p2p->ctl, s->p2p->rank, s->p2p->world,
-                         s->max_spins);
+                         s->max_spins, s->d_stamps != nullptr ? s->d_stamps + 4 * static_cast<size_t>(s->eval_cursor) + 2 : nullptr);
       GNPDE_LAUNCH_CHECK();
     }
   }
+  ++s->eval_cursor;
   if (s->g_bnd.n > s->g_bnd.row_begin) {
     const int rc = enqueue_rhs(s->rhs_bnd, u, e, rws, s->L_bnd, st);
     if (rc) return rc;
@@ -378,6 +391,7 @@ int enqueue_sharded_solve(gnpde_sharded_solver* s, float* y, hipStream_t st) {
 
 // the whole solve of the caller's y: with P2P the state is copied into / out of the shared stage buffer 0
 int enqueue_run(gnpde_sharded_solver* s, float* y, hipStream_t st) {
+  s->eval_cursor = 0;
   if (!s->p2p) return enqueue_sharded_solve(s, y, st);
   float* y0 = stage_buffer(s, 0);
   const size_t bytes = static_cast<size_t>(s->n_own) * s->ld * 4;
@@ -394,7 +408,8 @@ int enqueue_run(gnpde_sharded_solver* s, float* y, hipStream_t st) {
     rc = enqueue_exchange_p2p(s, nullptr, st);
     if (rc) return rc;
     GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
-    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, s->p2p->ctl, s->p2p->rank, s->p2p->world, s->max_spins);
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, s->p2p->ctl, s->p2p->rank, s->p2p->world, s->max_spins,
+                       s->d_stamps != nullptr ? s->d_stamps + 4 * static_cast<size_t>(s->eval_cursor) + 2 : nullptr);
     GNPDE_LAUNCH_CHECK();
   }
   return 0;
@@ -681,6 +696,12 @@ extern "C" int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnp
   gnpde_sharded_solver* s = nullptr;
   int rc = create_common(&s, nullptr, p2p, halo, rhs_interior, rhs_boundary, method, dts, n_steps, workspace, workspace_bytes);
   if (rc) return rc;
+  if (hipMalloc(reinterpret_cast<void**>(&s->d_stamps), (static_cast<size_t>(s->n_evals) + 1) * 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(s->d_stamps, 0, (static_cast<size_t>(s->n_evals) + 1) * 4 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (s->d_stamps) (void)hipFree(s->d_stamps);
+    s->d_stamps = nullptr;        // timing is an extra: the solver works without it
+  }
   // device tables of the push kernel
   const int W = halo->world;
   char* t = s->ws + s->off_tables;
@@ -764,6 +785,23 @@ extern "C" int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* t
   return 0;
 }
 
+extern "C" int gnpde_sharded_solver_timing(gnpde_sharded_solver_t* s, int64_t* stamps, int32_t capacity_evals, int32_t* n_evals,
+                                           int64_t* ticks_per_second) {
+  GNPDE_CHECK_ARG(s != nullptr && (stamps != nullptr || capacity_evals == 0) && capacity_evals >= 0, GNPDE_EINVAL,
+                  "sharded_solver_timing: bad arguments");
+  if (n_evals) *n_evals = s->d_stamps != nullptr && s->exchanges ? s->n_evals : 0;
+  if (ticks_per_second) {
+    int khz = 0, dev = 0;
+    GNPDE_HIP(hipGetDevice(&dev));
+    GNPDE_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    *ticks_per_second = static_cast<int64_t>(khz) * 1000;
+  }
+  if (s->d_stamps == nullptr || !s->exchanges || capacity_evals == 0) return 0;
+  const int n = s->n_evals < capacity_evals ? s->n_evals : capacity_evals;
+  GNPDE_HIP(hipMemcpy(stamps, s->d_stamps, static_cast<size_t>(n) * 4 * sizeof(int64_t), hipMemcpyDeviceToHost));   // synchronises
+  return 0;
+}
+
 extern "C" int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins) {
   GNPDE_CHECK_ARG(s != nullptr && max_spins > 0, GNPDE_EINVAL, "sharded_solver_set_spin_limit: bad argument");
   drop_sharded_graph(s);
@@ -779,6 +817,7 @@ extern "C" int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s) {
   if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
   if (s->e_pack) (void)hipEventDestroy(s->e_pack);
   if (s->e_recv) (void)hipEventDestroy(s->e_recv);
+  if (s->d_stamps) (void)hipFree(s->d_stamps);
   delete s;
   return 0;
 }

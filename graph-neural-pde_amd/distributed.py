@@ -145,6 +145,14 @@ class PartitionPlan(object):
   def shard(self, rank):
     return LocalShard(self, rank)
 
+  def shard_ids(self, rank):
+    """own_old_ids of LocalShard(self, rank) -- the original node ids of part `rank` in that shard's local row order
+    (interior rows first) -- memoised: every rank needs every part's order to put gathered rows back."""
+    memo = self.__dict__.setdefault('_shard_ids', {})
+    if rank not in memo:
+      memo[rank] = LocalShard(self, rank).own_old_ids
+    return memo[rank]
+
 
 class LocalShard(object):
   """Everything rank `rank` needs: local edge list (rows local, columns local incl. halo), ids of its
@@ -238,6 +246,20 @@ class NativeBackend(object):
     self._desc = {}
     self._ws = None
     self._src, self._src_version = None, -1
+
+  def refresh(self, alpha, beta, params):
+    """New values of the scalars / weights IN PLACE (captured graphs and descriptors keep their pointers): what changes
+    between two forwards of a block -- trained parameters, attention weights recomputed per forward."""
+    self.alpha.copy_(alpha.detach().reshape(-1))
+    self.beta.copy_(beta.detach().reshape(-1))
+    if self.kind == 'laplacian':
+      ew = params['edge_weight'].to(self.dev, torch.float32)
+      self.ops.edge_to_csr_mean(self.graph, ew, out=self.w_csr)
+      self.ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)], out=self.w_int)
+      self.ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)], out=self.w_bnd)
+    else:
+      self.wqk.copy_(torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32))
+      self.bqk.copy_(torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32))
 
   def _descriptor(self, with_source, part=None):
     """gnpde_rhs_t over the local shard: aggregation on the n_own rows (or the interior / boundary rows),
@@ -403,17 +425,26 @@ class P2PContext(object):
     self.shard, self.d = shard, d
     self.buffer_bytes = (max(s.n_local, 1) * d * 4 + 255) // 256 * 256
     handle = ctypes.c_void_p()
-    _lib.check(L.gnpde_p2p_create(ctypes.byref(handle), s.rank, s.world, self.buffer_bytes, n_buffers))
-    self.handle = handle
+    self.handle = None
     buf = ctypes.create_string_buffer(_lib.P2P_HANDLE_BYTES)
-    _lib.check(L.gnpde_p2p_get_handle(handle, buf))
+    create_failure = None
+    try:     # a rank that cannot allocate / export its block must not leave its peers waiting in the gather below
+      _lib.check(L.gnpde_p2p_create(ctypes.byref(handle), s.rank, s.world, self.buffer_bytes, n_buffers))
+      self.handle = handle
+      _lib.check(L.gnpde_p2p_get_handle(handle, buf))
+    except _lib.GnpdeError as exc:
+      create_failure = str(exc)
     mine = dict(handle=bytes(buf.raw), n_own=s.n_own, recv_counts=[int(v) for v in s.recv_counts],
-                buffer_bytes=self.buffer_bytes)
+                buffer_bytes=self.buffer_bytes, failure=create_failure)
     if s.world > 1:
       metas = [None] * s.world
       dist.all_gather_object(metas, mine, group=group)
     else:
       metas = [mine]
+    bad = next((m['failure'] for m in metas if m.get('failure')), None)
+    if bad is not None:
+      self.close()
+      raise _lib.GnpdeError('p2p transport unavailable: %s' % bad)
     blob = b''.join(m['handle'] for m in metas)
     failure = None
     try:
@@ -451,6 +482,7 @@ class NativeShardedSolver(object):
     L = _lib.lib()
     grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
     dts = (grid[1:] - grid[:-1]).tolist()
+    self.dts = tuple(dts)
     self.d_int = backend._descriptor(with_source, 'interior')
     self.d_bnd = backend._descriptor(with_source, 'boundary')
     self.send_counts = (ctypes.c_int32 * s.world)(*[int(v) for v in s.send_counts])
@@ -492,11 +524,22 @@ class NativeShardedSolver(object):
   def integrate(self, y_own, x0_own=None, use_graph=True):
     """Owned rows of y(T) (a view of an internal buffer).  x0_own refreshes the persistent source term in place."""
     be = self.be
+    if getattr(self, '_ran', False) and self.status()[0]:
+      # the PREVIOUS solve lost a peer (its remaining waits returned at once, the result used stale halo rows): say so before
+      # anything else is computed on it -- callers that need the verdict of the current solve call check() after it
+      raise _lib.GnpdeError('sharded solve: a peer never published its boundary rows (exchange timed out); the result of the '
+                            'previous integrate() is invalid')
     if x0_own is not None:
       be.x0.copy_(x0_own)
     self.y[:self.shard.n_own].copy_(y_own)
     _lib.check(_lib.lib().gnpde_sharded_solver_run(self.handle, _lib.ptr(self.y), int(bool(use_graph)), _lib.stream_of(self.y)))
+    self._ran = True
     return self.y[:self.shard.n_own]
+
+  def check(self):
+    """Synchronise and raise if the solve that just ran lost a peer (P2P transport: bounded wait expired)."""
+    if self.status()[0]:
+      raise _lib.GnpdeError('sharded solve: a peer never published its boundary rows (exchange timed out)')
 
   def status(self):
     """(timed_out, epochs) -- synchronises; timed_out means a peer never published an evaluation's epoch."""
@@ -504,6 +547,30 @@ class NativeShardedSolver(object):
     t, e = ctypes.c_int32(0), ctypes.c_int64(0)
     _lib.check(_lib.lib().gnpde_sharded_solver_status(self.handle, ctypes.byref(t), ctypes.byref(e)))
     return bool(t.value), int(e.value)
+
+  def timing(self):
+    """Exchange timing of the last run (gnpde_sharded_solver_timing): dict with per-evaluation push durations and waits in
+    microseconds (lists), or None when the solver does not exchange / has no stamps.  Synchronises."""
+    import ctypes
+    n, rate = ctypes.c_int32(0), ctypes.c_int64(0)
+    L = _lib.lib()
+    _lib.check(L.gnpde_sharded_solver_timing(self.handle, None, 0, ctypes.byref(n), ctypes.byref(rate)))
+    if n.value == 0 or rate.value <= 0:
+      return None
+    buf = (ctypes.c_int64 * (4 * n.value))()
+    _lib.check(L.gnpde_sharded_solver_timing(self.handle, buf, n.value, ctypes.byref(n), ctypes.byref(rate)))
+    t = torch.tensor(list(buf), dtype=torch.float64).view(n.value, 4)
+    us = 1e6 / float(rate.value)
+    ok = (t[:, 1] >= t[:, 0]) & (t[:, 3] >= t[:, 2]) & (t[:, 0] > 0)
+    if not bool(ok.any()):
+      return None
+    t = t[ok]
+    span = ((t[-1, 3] - t[0, 0]) * us / max(int(ok.sum()) - 0, 1)) if t.shape[0] > 1 else None
+    return {'evaluations': int(ok.sum()), 'ticks_per_second': int(rate.value),
+            'push_us': ((t[:, 1] - t[:, 0]) * us).tolist(), 'wait_us': ((t[:, 3] - t[:, 2]) * us).tolist(),
+            # from the push of this evaluation to the moment every peer's rows are here: the exchange as the boundary pass sees it
+            'push_to_landed_us': ((t[:, 3] - t[:, 0]) * us).tolist(),
+            'per_evaluation_us': None if span is None else float(span)}
 
   def set_spin_limit(self, n):
     _lib.check(_lib.lib().gnpde_sharded_solver_set_spin_limit(self.handle, int(n)))
@@ -521,6 +588,143 @@ class NativeShardedSolver(object):
       self.close()
     except Exception:
       pass
+
+
+# --------------------------------------------------------------------------------------------------
+# the operator surface: ODEblock -> odeint -> here, when torch.distributed is initialised and sharding is requested
+# --------------------------------------------------------------------------------------------------
+def shard_requested(func):
+  """opt['gnpde_shard'] (or GNPDE_SHARD=1) with an initialised process group: the fixed-step solves of this function run
+  row-partitioned over the ranks of the default group (one process per GPU)."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  v = func.opt.get('gnpde_shard', os.environ.get('GNPDE_SHARD', '0'))
+  return str(v).lower() not in ('0', '', 'false', 'none')
+
+
+def _host_group_gather(t_dev, group=None):
+  """all_gather of equally shaped device tensors over whatever backend the group has (gloo: staged through the host)."""
+  world = dist.get_world_size(group)
+  if dist.get_backend(group) == 'nccl':
+    parts = [torch.empty_like(t_dev) for _ in range(world)]
+    dist.all_gather(parts, t_dev, group=group)
+    return parts
+  host = t_dev.cpu()
+  parts = [torch.empty_like(host) for _ in range(world)]
+  dist.all_gather(parts, host, group=group)
+  return [p.to(t_dev.device) for p in parts]
+
+
+def _sharded_problem(func):
+  """(kind, params) of a function object for NativeBackend, or GnpdeError if the row-partitioned solver does not cover it."""
+  from .function_laplacian_diffusion import LaplacianODEFunc
+  from .function_transformer_attention import ODEFuncTransformerAtt
+  if isinstance(func, LaplacianODEFunc):
+    w = func._edge_values()
+    if w.dim() == 2:
+      w = w.mean(dim=1)
+    return 'laplacian', dict(edge_weight=w.detach())
+  if isinstance(func, ODEFuncTransformerAtt):
+    o, lay = func.opt, func.multihead_att_layer
+    if (o['attention_type'] != 'scaled_dot' or o['attention_norm_idx'] != 0 or o['square_plus'] or o['reweight_attention']
+        or getattr(lay, 'split_kernel', False) or o['mix_features']):
+      raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with scaled-dot scores and a softmax over '
+                            'the row (attention_norm_idx 0, no squareplus / reweighting / beltrami split kernel); this '
+                            'configuration runs on one GPU only -- unset gnpde_shard')
+    return 'transformer', dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(),
+                               bk=lay.K.bias.detach(), heads=lay.h)
+  raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc and ODEFuncTransformerAtt, not %s' % type(func).__name__)
+
+
+def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
+  """torchdiffeq.odeint(func, y0, t, method='euler'|'rk4') of a block of this package on a row-partitioned graph, one
+  process per GPU: every rank calls with the SAME replicated y0 / func (as the reference's model is replicated by
+  nn.DataParallel, src/ray_tune.py:65-66, which cannot split a full-graph model); the graph is partitioned once per
+  edge_index (the ranks share the search, PartitionPlan.search), each rank integrates its rows with the native sharded
+  solver (csrc/sharded.hip, P2P transport inside one hipGraph per rank), and the rows are all-gathered so that every rank
+  returns the full [2, n, d] result the block expects (reference call: src/block_constant.py:57-62)."""
+  rank, world = dist.get_rank(group), dist.get_world_size(group)
+  if not (y0.is_cuda and y0.dtype == torch.float32 and y0.dim() == 2):
+    raise _lib.GnpdeError('sharded solve: the state must be a float32 [n, d] tensor on a HIP device')
+  if func._needs_grad(y0):
+    raise _lib.GnpdeError('sharded solve: inference only (no autograd through the partitioned solver); call under torch.no_grad()')
+  dev, (n, d) = y0.device, y0.shape
+  grid = time_grid(t.detach().to('cpu'), step_size)
+  dts = tuple((grid[1:] - grid[:-1]).tolist())
+  n_evals = len(dts) * (4 if method == 'rk4' else 1)
+  room = func.opt['max_nfe'] + 1 - func.nfe
+  if n_evals > room:
+    func.nfe += max(room, 0)
+    from .utils import MaxNFEException
+    raise MaxNFEException
+  kind, params = _sharded_problem(func)
+  ei = func.edge_index
+  st = func.__dict__.setdefault('_shard_state', {})
+  key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev))
+  ent = st.get(key)
+  if ent is None:
+    for old in st.values():
+      old['close']()
+    st.clear()
+    per_rank = max(1, min(12, len(PartitionPlan.SEARCH_SPACE) // max(world, 1)))
+    plan = PartitionPlan.search(ei, n, world, rank=rank, group_size=world, per_rank=per_rank, group=group)
+    shard = plan.shard(rank)
+    local = dict(params)
+    if kind == 'laplacian':
+      local['edge_weight'] = params['edge_weight'][shard.edge_ids.to(params['edge_weight'].device)]
+    be = NativeBackend(shard, d, dev, kind, local, func.alpha_train, func.beta_train, not func.opt['no_alpha_sigmoid'])
+    ctx = P2PContext(shard, d, 4, group=group)
+    ent = dict(edge_index=ei, plan=plan, shard=shard, be=be, ctx=ctx, solvers={}, own_ids=shard.own_old_ids.to(dev))
+
+    def close(ent=ent):
+      for sol in ent['solvers'].values():
+        sol.close()
+      ent['solvers'].clear()
+      ent['ctx'].close()
+    ent['close'] = close
+    st[key] = ent
+  plan, shard, be = ent['plan'], ent['shard'], ent['be']
+  local = dict(params)
+  if kind == 'laplacian':
+    local['edge_weight'] = params['edge_weight'][shard.edge_ids.to(params['edge_weight'].device)]
+  be.refresh(func.alpha_train, func.beta_train, local)
+  with_source = bool(func.opt['add_source'])
+  skey = (method, dts, with_source)
+  sol = ent['solvers'].get(skey)
+  if sol is None:
+    for old in ent['solvers'].values():     # one live solver per function: its stage buffers are the shared P2P block
+      old.close()
+    ent['solvers'].clear()
+    T = float(sum(dts))
+    sol = NativeShardedSolver(shard, be, T, step_size, method, with_source=with_source, ctx=ent['ctx'], group=group)
+    if tuple(sol_dts(sol)) != dts:
+      sol.close()
+      raise _lib.GnpdeError('sharded solve: internal time grid mismatch')
+    ent['solvers'][skey] = sol
+  y_own = y0.detach()[ent['own_ids']]
+  x0_own = None
+  if with_source:
+    if func.x0 is None:
+      raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+    x0_own = func.x0.detach()[ent['own_ids']]
+  z_own = sol.integrate(y_own, x0_own, use_graph=use_graph)
+  sol.check()                                       # synchronises; a lost peer raises here, on every rank that saw it
+  # every rank gets the whole state back: pad to the largest part, all-gather rows and their original ids
+  m = int(plan.counts.max())
+  pad = torch.zeros(m, d, dtype=torch.float32, device=dev)
+  pad[:shard.n_own] = z_own
+  out = torch.empty(2, n, d, dtype=y0.dtype, device=dev)
+  out[0].copy_(y0.detach())
+  parts = _host_group_gather(pad, group)
+  for p in range(world):
+    ids = plan.shard_ids(p).to(dev)
+    out[1][ids] = parts[p][:ids.numel()]
+  func.nfe += n_evals
+  return out
+
+
+def sol_dts(solver):
+  return solver.dts
 
 
 def scatter_rows(x_global, shard):
@@ -779,10 +983,44 @@ def bench_main(args, rank, world, dev):
     # the TIMED solve against the same K steps on the unpartitioned graph (outside the timed region; the single-GPU solver
     # on every rank's own device, compared on the rank's own rows)
     err_solve, solve_why = 0.0, None
+    t_single = None
     try:
-      err_solve = solve_error(y, unpartitioned_solve(K))
+      torch.cuda.synchronize(dev)
+      t0 = time.perf_counter()
+      ref_K = unpartitioned_solve(K)
+      t_single = time.perf_counter() - t0       # eager launches of the single-GPU solver on this rank's device (incl. set-up)
+      err_solve = solve_error(y, ref_K)
     except Exception as exc:   # noqa: BLE001 -- reported, not fatal: the line still carries the one-evaluation check
       solve_why = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+    # exchange timing of the last timed replay, written by the kernels inside the graph (P2P transport)
+    exch = None if python_loop else solver.timing()
+    # this rank's aggregation on its shard (all local rows, one launch per stage variant), by the gather model
+    shard_roof = None
+    try:
+      E_loc = int(shard.edge_index.shape[1])
+      ub = [torch.randn(shard.n_local, d, device=dev) for _ in range(4)]
+      wl = torch.rand(max(E_loc, 1), device=dev) / 16
+      a0, b0 = torch.tensor([0.0], device=dev), torch.tensor([0.1], device=dev)
+      x0l = torch.randn(shard.n_own, d, device=dev)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+      def agg():
+        ops.spmm_rhs(be.graph, wl, ub[0], a0, b0, x0l, True, out=ub[1][:shard.n_own])
+      agg()
+      torch.cuda.synchronize(dev)
+      e0.record()
+      for _ in range(10):
+        agg()
+      e1.record()
+      torch.cuda.synchronize(dev)
+      t_agg = e0.elapsed_time(e1) * 1e-3 / 10
+      b_agg = E_loc * (8 + 4 * d) + shard.n_own * (4 + 8 * d) + 4 * d * shard.n_own
+      shard_roof = {'avg_launch_us': round(t_agg * 1e6, 2), 'algorithmic_bytes_per_launch': b_agg,
+                    'gather_model_gbs': round(b_agg / t_agg / 1e9, 1), 'local_rows': shard.n_own, 'local_entries': E_loc,
+                    'local_table_mib': round(shard.n_local * d * 4 / 2 ** 20, 1)}
+      del ub, wl, x0l
+    except Exception as exc:   # noqa: BLE001
+      shard_roof = {'error': repr(exc)[:200]}
   have_solve = agree(solve_why is None)
   es = torch.tensor([err_solve if solve_why is None and err_solve == err_solve else 3.0e38], dtype=torch.float32).to(red)
   dist.all_reduce(es, op=dist.ReduceOp.MAX)
@@ -799,6 +1037,17 @@ def bench_main(args, rank, world, dev):
                        float(max(shard.recv_counts) if shard.recv_counts else 0), float(shard.n_interior)], device=red)
   halo_max = halo.clone()
   dist.all_reduce(halo_max, op=dist.ReduceOp.MAX)
+  # exchange timing: mean over the evaluations of the last replay on every rank, then max / mean over the ranks
+  import statistics
+  ex_loc = [-1.0, -1.0, -1.0, -1.0]
+  if exch:
+    ex_loc = [statistics.fmean(exch['push_us']), statistics.fmean(exch['wait_us']), statistics.fmean(exch['push_to_landed_us']),
+              exch['per_evaluation_us'] or -1.0]
+  ex = torch.tensor(ex_loc, dtype=torch.float64, device=red)
+  ex_max = ex.clone()
+  dist.all_reduce(ex_max, op=dist.ReduceOp.MAX)
+  ex_sum = ex.clone()
+  dist.all_reduce(ex_sum, op=dist.ReduceOp.SUM)
   if rank == 0:
     elapsed = float(el.item())
     E = int(ei_loops.shape[1])
@@ -844,5 +1093,47 @@ def bench_main(args, rank, world, dev):
                                        'graph (max over ranks)' % K) if have_solve else 'unavailable: %s' % (solve_why or 'failed on another rank')},
       'roofline': None, 'cpu_baseline': None,
     }
+    link_rows = int(halo_max[3].item())
+    link_bytes = link_rows * 4 * d
+    # ---- the exchange as measured by the kernels (P2P transport), next to what DESIGN.md section 6 predicts from the partition
+    if exch and float(ex_max[0].item()) >= 0:
+      push_max, wait_max, landed_max = float(ex_max[0].item()), float(ex_max[1].item()), float(ex_max[2].item())
+      out['exchange'] = {
+        'source': 'wall-clock stamps written inside the hipGraph by push_rows_kernel / wait_flags_kernel of the last timed replay '
+                  '(gnpde_sharded_solver_timing); means over the evaluations, then max / mean over the ranks',
+        'push_us_max_rank': round(push_max, 2), 'push_us_mean_rank': round(float(ex_sum[0].item()) / world, 2),
+        'wait_us_max_rank': round(wait_max, 2), 'wait_us_mean_rank': round(float(ex_sum[1].item()) / world, 2),
+        'push_to_all_landed_us_max_rank': round(landed_max, 2),
+        'per_evaluation_us_max_rank': round(float(ex_max[3].item()), 2) if float(ex_max[3].item()) > 0 else None,
+        'busiest_link_bytes_per_evaluation': link_bytes,
+        # the busiest link's rows over the slowest rank's push: a LOWER bound of that link's rate (the push kernel serves all
+        # links at once and ends when the slowest of them has taken its rows)
+        'busiest_link_gbs_lower_bound': round(link_bytes / (push_max * 1e-6) / 1e9, 2) if push_max > 0 else None,
+        'ranks_share_one_device': shared}
+    else:
+      out['exchange'] = None
+    per_eval_1 = None if t_single is None else t_single / (4.0 * K)
+    out['model'] = {
+      'what': 'DESIGN.md section 6: per evaluation a rank waits for max(interior compute, busiest link) and then runs its boundary '
+              'rows; compute = the single-GPU evaluation split evenly over the ranks; xGMI link at 50 / 76 GB/s per direction',
+      'single_gpu_us_per_evaluation_eager': None if per_eval_1 is None else round(per_eval_1 * 1e6, 2),
+      'compute_us_per_evaluation_per_rank': None if per_eval_1 is None else round(per_eval_1 * 1e6 / world, 2),
+      'busiest_link_us_at_50_gbs': round(link_bytes / 50e9 * 1e6, 2), 'busiest_link_us_at_76_gbs': round(link_bytes / 76e9 * 1e6, 2),
+      'interior_row_share': round(float(halo_max[4].item()) / max(float(halo_max[1].item()), 1.0), 3),
+      'predicted_speedup_range': None if per_eval_1 is None else [
+        round(per_eval_1 / max(per_eval_1 / world, link_bytes / gbs + (1.0 - float(halo_max[4].item()) / max(float(halo_max[1].item()), 1.0)) * per_eval_1 / world), 2)
+        for gbs in (50e9, 76e9)],
+      'measured_us_per_evaluation': round(1e6 * elapsed / (4.0 * K), 2)}
+    if shard_roof is not None and 'error' not in shard_roof:
+      resident = shard_roof['local_table_mib'] < 256
+      out['roofline'] = dict(shard_roof, kernel='CSR aggregation + fused epilogue on rank 0\'s shard (all local rows in one launch)',
+                             bound='l2-miss/MALL' if resident else 'hbm', achieved=shard_roof['gather_model_gbs'], peak=8000.0,
+                             unit='GB/s', frac=None if resident else round(shard_roof['gather_model_gbs'] / 8000.0, 4),
+                             note='per-GPU figure of rank 0; the gathered table of a shard (own + halo rows) '
+                                  + ('fits the Infinity Cache, so HBM\'s peak is not its ceiling (see the 1-GPU line\'s measured '
+                                     'ceiling)' if resident else 'exceeds the Infinity Cache: fraction of the HBM peak'))
+    else:
+      out['roofline'] = shard_roof
+    out['cpu_baseline'] = None     # (timed on rank 0 at N = 1 only, by contract)
     print(json.dumps(out))
   dist.destroy_process_group()

@@ -421,6 +421,9 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
     if step_size is None:
       raise ValueError('fixed-grid methods need options["step_size"]')
     if _native_ok(func, y0, t):
+      from . import distributed as D
+      if D.shard_requested(func):     # one process per GPU, rows partitioned over the ranks (distributed.solve_sharded)
+        return D.solve_sharded(func, y0, t, method, step_size, use_graph=use_graph)
       return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
     return _solve_fixed_host(func, y0, t, method, step_size)
   if method == 'dopri5':

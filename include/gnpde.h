@@ -615,6 +615,15 @@ int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_gr
  * permutation of [0, sum send_counts) that keeps each destination's rows in order.  What gnpde_sharded_solver_create_p2p uses;
  * exported for the host tests. */
 int gnpde_push_order(const int32_t* send_counts, int32_t world, int32_t* order);
+/* Exchange timing of the LAST run (P2P transport): for every evaluation four wall-clock stamps (s_memrealtime ticks, rate in
+ * *ticks_per_second) written by the kernels themselves inside the hipGraph -- [0] the push kernel starts, [1] its last block has
+ * published the epoch (all boundary rows stored into the peers' halo regions), [2] the main stream reaches the wait (interior
+ * rows done), [3] every peer's rows have landed.  [1]-[0] = push duration (xGMI stores), [3]-[2] = time the boundary pass waited
+ * for the exchange, i.e. the part of the exchange that compute did not hide.  stamps: int64[capacity_evals][4]; *n_evals: the
+ * evaluations of a run (0 when the solver does not exchange).  Synchronises.  No reference equivalent (measurement). */
+int gnpde_sharded_solver_timing(gnpde_sharded_solver_t* s, int64_t* stamps, int32_t capacity_evals, int32_t* n_evals,
+                                int64_t* ticks_per_second);
+
 /* Synchronises.  *timed_out != 0: a wait kernel gave up polling a peer's epoch flag (results are invalid);
  * *epochs = evaluations this rank has published so far.  After the first time-out the waits of the evaluations still
  * queued return without polling (the flag is sticky for the lifetime of the gnpde_p2p_t), so a lost solve ends quickly. */

@@ -1,0 +1,64 @@
+"""Worker for tests/test_sharded_gpu.py::test_blocks_run_sharded_from_the_operator_surface (torch.distributed.run, gloo
+bootstrap, every rank on cuda:0): the reference-recorded block fixtures through ODEblock.forward with opt['gnpde_shard'] set --
+the block partitions its graph over the ranks, every rank integrates its rows with the native sharded solver and gets the
+whole state back.  Must reproduce the fixture (reference output) like the single-GPU block does."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import gnpde_amd as G  # noqa: E402
+from helpers import Fixture, Data, parity  # noqa: E402
+
+BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
+FUNCS = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc}
+
+
+def main():
+  out_path, names = sys.argv[1], sys.argv[2].split(',')
+  dist.init_process_group('gloo')
+  rank, world = dist.get_rank(), dist.get_world_size()
+  dev = torch.device('cuda:0')
+  torch.cuda.set_device(dev)
+  res = {}
+  for name in names:
+    fx = Fixture(name)
+    x = fx.t('x', dev)
+    opt = dict(fx.opt, gnpde_shard=1)
+    block = BLOCKS[opt['block']](FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev)), dev,
+                                 t=torch.tensor([0, opt['time']])).to(dev)
+    block.load_state_dict(fx.params, strict=True)
+    block.eval()
+    block.set_x0(x)
+    with torch.no_grad():
+      z = block(x)
+      nfe = block.odefunc.nfe
+      block.set_x0(x)
+      z2 = block(x)                      # cached partition, solver and graph
+    e_inf, e_2 = parity(z, fx.t('z'))
+    ent = next(iter(block.odefunc._shard_state.values()))
+    sh = ent['shard']
+    # every rank holds the same full result
+    mine = z.cpu()
+    allz = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allz, mine)
+    res[name] = dict(rel_max=e_inf, rel_l2=e_2, nfe=nfe, ref_nfe=int(fx.arr['nfe']), replay_equal=bool(torch.equal(z, z2)),
+                     ranks_agree=all(torch.equal(a, mine) for a in allz), own_rows=sh.n_own, halo_rows=sh.n_halo,
+                     world=world)
+    dist.barrier()
+    for e in block.odefunc._shard_state.values():
+      e['close']()
+    block.odefunc._shard_state.clear()
+  if rank == 0:
+    json.dump(res, open(out_path, 'w'))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -107,6 +107,55 @@ def test_ranks_sharing_one_gpu(dev, tmp_path, world, kind, method, T):
   assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
+  """opt['gnpde_shard'] + an initialised process group: ODEblock.forward (the call the reference makes at
+  src/block_constant.py:57-62) partitions the graph over the ranks and runs the native sharded solver -- against the
+  reference-recorded fixtures, with the reference's NFE, every rank holding the whole result (tests/dist_block_worker.py)."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / 'blocks.json')
+  names = 'block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler'
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+         '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  r = json.load(open(out))
+  for name in names.split(','):
+    e = r[name]
+    assert e['world'] == world and e['halo_rows'] > 0, e
+    assert e['rel_max'] < 1e-5 and e['rel_l2'] < 1e-5, (name, e)
+    assert e['nfe'] == e['ref_nfe'] and e['replay_equal'] and e['ranks_agree'], (name, e)
+
+
+def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
+  """gnpde_shard on a configuration the partitioned solver does not cover (squareplus) raises instead of silently running on
+  one GPU; without a process group the request is ignored (single-GPU solve)."""
+  import torch.distributed as dist
+  from helpers import Fixture, Data
+  fx = Fixture('block_constant_transformer_sqp_n1_rk4')
+  x = fx.t('x', dev)
+  opt = dict(fx.opt, gnpde_shard=1)
+  block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], opt, Data(x, fx.t('edge_index', dev)), dev,
+                             t=torch.tensor([0, opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  block.eval()
+  block.set_x0(x)
+  assert not dist.is_initialized()
+  with torch.no_grad():
+    z = block(x)                                   # no process group: the request is void
+  assert_parity(z, fx.t('z'), what='unsharded')
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  os.environ.setdefault('MASTER_PORT', '29677')
+  dist.init_process_group('gloo', rank=0, world_size=1)
+  try:
+    block.set_x0(x)
+    with torch.no_grad(), pytest.raises(_lib.GnpdeError):
+      block(x)
+  finally:
+    dist.destroy_process_group()
+
+
 def test_no_exchange_world1_matches_single_gpu_solver(dev):
   """A world-1 shard without halo (comm NULL): interior = all rows; must equal the single-GPU solver bit for bit."""
   n, d, ei, x, p, alpha, beta, rhs = _problem('transformer', seed=5)
