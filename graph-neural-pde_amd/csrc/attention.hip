@@ -28,6 +28,7 @@ namespace {
 struct AttArgs {
   int n, e, h, dk, type, norm_idx, square_plus;
   float inv_sqrt_dk_den;  // sqrt(d_k), divisor of the scaled dot product
+  float scale_mul;        // fl32(1 / sqrt(d_k)): the row kernels multiply (exactly the quotient when sqrt(d_k) is a power of two: d_k = 4, 16, 64; within 1 ulp of it otherwise)
   float leaky_slope;
   const int* __restrict__ rowidx;
   const int* __restrict__ colidx;
@@ -655,7 +656,9 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
             dot = fmaf(qv[r][j].w, kv[r][i][j].w, dot);
           }
           const int e = e0[r] + (nb * PB + i) * GE + slot;
-          float sv = dot / a.inv_sqrt_dk_den;
+          // (this kernel is bound by VALU issue, not by memory: ~580 wave instructions per 4 rows, a fifth of them the IEEE
+          //  division sequences and the full-range expf -- round 3: exact power-of-two scale, one reciprocal per row, v_exp)
+          float sv = dot * a.scale_mul;
           if (a.edge_w != nullptr) sv = sv * a.edge_w[e < e1[r] ? e : e1[r] - 1];
           sv = e < e1[r] ? sv : -INFINITY;
           s[r][nb * PB + i] = sv;
@@ -678,19 +681,20 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
       if (nb < nbatch) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-          s[r][nb * PB + i] = expf(s[r][nb * PB + i] - m[r]);
+          s[r][nb * PB + i] = __builtin_amdgcn_exp2f((s[r][nb * PB + i] - m[r]) * 1.44269504088896341f);   // v_exp_f32: arguments are <= 0, -inf -> 0
           l += s[r][nb * PB + i];
         }
       }
 #pragma unroll
     for (int off = H; off < GL; off <<= 1) l += __shfl_xor(l, off, kWave);
     const float den = l + 1e-16f;
+    const float rden = __builtin_amdgcn_rcpf(den);      // v_rcp_f32 (1 ulp), one per (row, head); a multiplication per entry
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (nb < nbatch) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-          float v = s[r][nb * PB + i] / den;
+          float v = s[r][nb * PB + i] * rden;
 #pragma unroll
           for (int off = 1; off < H; off <<= 1) v += __shfl_xor(v, off, kWave);
           const int e = e0[r] + (nb * PB + i) * GE + slot;
@@ -924,6 +928,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.n = g->n; a.e = g->e; a.h = at->heads; a.dk = at->att_dim / at->heads;
   a.type = at->type; a.norm_idx = at->norm_idx; a.square_plus = at->square_plus ? 1 : 0;
   a.inv_sqrt_dk_den = static_cast<float>(std::sqrt(static_cast<double>(a.dk)));
+  a.scale_mul = static_cast<float>(1.0 / std::sqrt(static_cast<double>(a.dk)));
   a.leaky_slope = at->leaky_slope;
   a.rowidx = g->rowidx; a.colidx = g->colidx; a.perm = g->perm;
   a.rowptr = g->rowptr; a.bin_rows = g->bin_rows;

@@ -23,9 +23,8 @@ OPT = dict(heads=4, attention_dim=64, attention_type='scaled_dot', attention_nor
            function='transformer', time=1.0)
 
 
-@pytest.fixture(scope='module')
-def rmat(dev):
-  ei, n = G.synthetic.make_graph('rmat', seed=1, scale=0.5)     # 2^20 nodes, ~38 M edges
+def _build(dev, scale):
+  ei, n = G.synthetic.make_graph('rmat', seed=1, scale=scale)     # 0.5: 2^20 nodes, ~38 M edges; 1.0: BASELINE configs[4]
   d = 256
   x = torch.randn(n, d, generator=torch.Generator().manual_seed(5))
   xd = x.to(dev)
@@ -43,6 +42,11 @@ def rmat(dev):
   block.eval()
   block.set_x0(xd)
   return block, x, xd, n
+
+
+@pytest.fixture(scope='module')
+def rmat(dev):
+  return _build(dev, 0.5)
 
 
 def _subset_oracle(block, x, rows):
@@ -66,11 +70,33 @@ def _subset_oracle(block, x, rows):
 
 
 def test_rmat_d256_rows_against_oracle(rmat):
+  _rows_against_oracle(rmat, 2 ** 30, 1000)
+
+
+def test_rmat_full_scale_rows_against_oracle(dev):
+  """The SAME check on the graph BASELINE configs[4] names, at full size: 2^21 nodes, 77 M entries, 2-GiB state -- the graph
+  `bench.py --graph rmat` times: hashed XCD row deal with 128-row blocks, 27.9 k hub rows, the 227-chunk hub."""
+  import gc
+  built = _build(dev, 1.0)
+  try:
+    block, x, xd, n = built
+    assert n == 2 ** 21
+    graph = block.odefunc._graph(xd)
+    assert graph.struct.xcd_deal == 1, 'the R-MAT row lengths depend on the row id: the builder must pick hashed blocks'
+    assert graph.max_row_len > 100 * 512, 'expected a hub of more than 100 chunks (got %d entries)' % graph.max_row_len
+    _rows_against_oracle(built, 2 ** 31, 20000)
+  finally:
+    del built
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _rows_against_oracle(rmat, min_state_bytes, min_long_rows):
   block, x, xd, n = rmat
   f = block.odefunc
   graph = f._graph(xd)
-  assert n * 256 * 4 >= 2 ** 30, 'state must exceed the Infinity Cache by a wide margin'
-  assert graph.n_long_rows > 1000, 'the R-MAT graph should be hub-heavy (got %d long rows)' % graph.n_long_rows
+  assert n * 256 * 4 >= min_state_bytes, 'state must exceed the Infinity Cache by a wide margin'
+  assert graph.n_long_rows > min_long_rows, 'the R-MAT graph should be hub-heavy (got %d long rows)' % graph.n_long_rows
   deg = torch.bincount(f.edge_index[0].cpu(), minlength=n)
   g = torch.Generator().manual_seed(9)
   hubs = torch.topk(deg, 6).indices                                   # many 512-entry chunks each
