@@ -153,6 +153,8 @@ PROTOTYPES = {
   'gnpde_dopri5_create': (ctypes.c_int, [c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t]),
   'gnpde_dopri5_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, c_vp, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_dopri5_set_early_stop': (ctypes.c_int, [c_vp, ctypes.POINTER(DecoderStruct), c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32,
+                                                 ctypes.c_int32]),
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_two_hop_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32]),

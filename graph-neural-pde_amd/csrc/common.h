@@ -148,8 +148,10 @@ int launch_hub_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, fl
                          hipStream_t stream);
 
 // early_stop.hip
+// gate / tag (nullable device ints): *gate == 0 skips the evaluation when the kernels run, *tag replaces `step` (the
+// device-controlled dopri5 decides both per trial step)
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,
-                            int trace_capacity, hipStream_t st);
+                            int trace_capacity, hipStream_t st, const int* gate = nullptr, const int* tag = nullptr);
 int check_decoder(const gnpde_decoder_t* dec, int d_state);
 
 // Stage algebra and error norm of the adaptive solver with the step size optionally read from DEVICE memory when the kernel runs

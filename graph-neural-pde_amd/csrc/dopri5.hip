@@ -48,13 +48,21 @@ struct Ctl {            // the controller record (device; copied to the host onc
   float x;              // interpolation fraction (t1 - t) / dt of the step that contains the end point
   int accept, interp, done;
   int trials, accepted, rejected;
+  // early stopping (gnpde_dopri5_set_early_stop): the test-time integrator of the reference evaluates the decoder after EVERY
+  // trial step and gives up after max_test_steps of them (src/early_stop_solver.py:82-98)
+  int max_trials;       // 0: no limit
+  int stopped;          // the trial budget ran out: y_out = the state where it stopped, not an interpolation
+  int eval_now;         // gate of the evaluator kernels appended to this trial step
+  int eval_tag;         // step tag of that evaluation: number of accepted steps (0 = the initial state)
+  int initial_done;     // the initial state has been evaluated (trials rejected before the first accept do that once)
+  int pad_[3];
 };
-static_assert(sizeof(Ctl) == 64, "controller record");
+static_assert(sizeof(Ctl) == 96, "controller record");
 
 // fold of the error partial sums (as rk_error_final_kernel of misc.hip) + torchdiffeq rk_common.py _adaptive_step /
 // _optimal_step_size: safety 0.9, ifactor 10, dfactor 0.2, order 5
 __global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict__ ws, int nblocks, double count, Ctl* c,
-                                                        int parity) {
+                                                        int parity, double* __restrict__ times, int times_capacity) {
   __shared__ double red[kBlock];
   double acc = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += static_cast<double>(ws[i]);
@@ -70,6 +78,7 @@ __global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict
   if (c->done) {                      // replayed past the end point (never queued by gnpde_dopri5_run): change nothing
     c->accept = 0;
     c->interp = 0;
+    c->eval_now = 0;
     c->h[1 - parity] = c->h[parity];
     return;
   }
@@ -99,6 +108,27 @@ __global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict
   }
   c->dt = dt * factor;
   c->h[1 - parity] = static_cast<float>(c->dt);
+  // early stopping: which state the evaluator kernels behind this trial step see.  Accepted: the new state, tagged with the
+  // number of accepted steps (its time goes to times[tag]).  Rejected: the unchanged previous state -- counted already, it
+  // cannot win the strict `val > best` -- except before the first accept, when it is the INITIAL state (tag 0), once.
+  int eval_now = 0;
+  if (c->max_trials > 0) {
+    if (accept) {
+      eval_now = 1;
+      c->eval_tag = c->accepted;
+      if (times != nullptr && c->accepted < times_capacity) times[c->accepted] = c->t;
+    } else if (c->accepted == 0 && !c->initial_done) {
+      eval_now = 1;
+      c->eval_tag = 0;
+      c->initial_done = 1;
+    }
+    if (c->trials >= c->max_trials) {   // the budget of trial steps is spent: the result is the state reached, as it stands
+      c->done = 1;
+      c->stopped = 1;
+      interp = 0;
+    }
+  }
+  c->eval_now = eval_now;
   c->accept = accept;
   c->interp = interp;
 }
@@ -115,7 +145,7 @@ __global__ void init_h0_kernel(Init* q) {
   q->h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6f : 0.01f * q->d0 / q->d1;
 }
 
-__global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1) {
+__global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1, int max_trials, double* times, int times_capacity) {
   const double h0 = static_cast<double>(q->h0), d1 = static_cast<double>(q->d1);
   const double d2 = static_cast<double>(q->d2) / h0;
   double h1;
@@ -134,6 +164,9 @@ __global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1) {
   c->x = 0.f;
   c->accept = c->interp = c->done = 0;
   c->trials = c->accepted = c->rejected = 0;
+  c->max_trials = max_trials;
+  c->stopped = c->eval_now = c->eval_tag = c->initial_done = 0;
+  if (times != nullptr && times_capacity > 0) times[0] = t0;
 }
 
 // dst[r, 0:d] = src[r, 0:d] between two row strides (state in / result out; a pitched hipMemcpy2D is far slower)
@@ -163,7 +196,7 @@ struct FinishArgs {
 // torchdiffeq's quartic end-point interpolation (_interp_fit + _interp_evaluate, as dopri5_interp_kernel of misc.hip), the commit
 // of an accepted step and the first stage input of the next trial step, one pass over the state
 __global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
-  const int accept = a.c->accept, interp = a.c->interp;
+  const int accept = a.c->accept, interp = a.c->interp, stopped = a.c->stopped;
   const float h = a.c->h[a.parity], hn = a.c->h[1 - a.parity], x = a.c->x;
   const float cn = a.b10 * hn;
   // flat over the padded storage (ld % 4 == 0, buffers 256-byte aligned; the padding columns hold zeros and stay zero)
@@ -194,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
       reinterpret_cast<f4*>(a.yout)[i] = tot;
     }
     const f4 yn = accept ? yb : ya, fn = accept ? fb : fa;
+    if (stopped) reinterpret_cast<f4*>(a.yout)[i] = yn;     // trial budget spent: the state where the integration stopped
     if (!accept) {
       reinterpret_cast<f4*>(a.y1)[i] = yn;
       reinterpret_cast<f4*>(a.k[6])[i] = fn;
@@ -228,6 +262,15 @@ struct gnpde_dopri5 {
   // buffers inside the workspace
   float* Y[2];  float* KA[2];  float* km[5];  float* u[2];  float* yout;   // (y, y1) and (k0, k6) swap roles with the parity
   Ctl* ctl;  float* err_ws;  Init* init;
+  // early stopping
+  bool early = false;
+  gnpde_decoder_t dec{};
+  int* early_state = nullptr;
+  int* early_trace = nullptr;
+  int early_trace_capacity = 0;
+  double* times = nullptr;
+  int times_capacity = 0;
+  int max_trials = 0;
 };
 
 namespace {
@@ -278,7 +321,8 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   int nblocks = 0;
   if (int rc = launch_rk_error_ratio(y, y1, k, ce, 7, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
     return rc;
-  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, s->err_ws, nblocks, static_cast<double>(n) * r.d, s->ctl, parity);
+  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, s->err_ws, nblocks, static_cast<double>(n) * r.d, s->ctl, parity,
+                     s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
   GNPDE_LAUNCH_CHECK();
   FinishArgs fa{};
   fa.y = y; fa.y1 = y1; fa.yout = s->yout; fa.u1 = s->u[0];
@@ -293,6 +337,13 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, fa);
   GNPDE_LAUNCH_CHECK();
+  if (s->early) {
+    // After the finish kernel the y1 buffer holds the state the NEXT trial step starts from, whatever was decided: the
+    // accepted y1, or the copy of y.  The evaluator kernels read it; the controller's gate and tag decide if and as what.
+    if (int rc = enqueue_early_stop_eval(s->dec, y1, r.ld, static_cast<int>(n), 0, s->early_state, s->early_trace,
+                                         s->early_trace_capacity, st, &s->ctl->eval_now, &s->ctl->eval_tag))
+      return rc;
+  }
   return 0;
 }
 
@@ -360,6 +411,7 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
   const int n = r.graph->n;
   s->n_evals = s->n_accepted = s->n_rejected = s->n_launches = s->n_syncs = 0;
   if (finished) *finished = 0;
+  if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, 8 * sizeof(int32_t), st));
   if (!s->padding_cleared) {   // once: the padding columns [d, ld) are never written with anything but what they hold
     GNPDE_HIP(hipMemsetAsync(s->ws + s->off_state, 0, 12 * s->state_bytes, st));
     s->padding_cleared = true;
@@ -393,7 +445,8 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     const float* dk[2] = {s->km[0], s->KA[0]};
     const float cw[2] = {one, minus};
     if (int rc = scaled_rms(s, dk, cw, 2, st, &s->init->d2)) return rc;
-    hipLaunchKernelGGL(init_dt_kernel, dim3(1), dim3(1), 0, st, s->init, s->ctl, t0, t1);
+    hipLaunchKernelGGL(init_dt_kernel, dim3(1), dim3(1), 0, st, s->init, s->ctl, t0, t1, s->early ? s->max_trials : 0,
+                       s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
     GNPDE_LAUNCH_CHECK();
     // first stage input of the first trial step (later ones come out of the finish kernel)
     const float c[1] = {static_cast<float>(kB[0][0])};
@@ -430,6 +483,8 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
       reach += step;
       ++batch;
     }
+    if (have_record && hc.max_trials > 0 && batch > hc.max_trials - hc.trials) batch = hc.max_trials - hc.trials;   // trial budget
+    if (batch < 1) batch = 1;
     for (int b = 0; b < batch; ++b) GNPDE_HIP(hipGraphLaunch(s->exec[(s->n_launches + b) & 1], st));
     s->n_launches += batch;
     GNPDE_HIP(hipMemcpyAsync(s->host_ctl, s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
@@ -448,6 +503,32 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
   GNPDE_LAUNCH_CHECK();
   GNPDE_HIP(hipStreamSynchronize(st));
   if (finished) *finished = 1;
+  return 0;
+}
+
+extern "C" int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
+                                           int32_t trace_capacity, double* times, int32_t times_capacity, int32_t max_trial_steps) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "dopri5_set_early_stop: solver is null");
+  for (int p = 0; p < 2; ++p) {      // the evaluator kernels are part of the captured trial step
+    if (s->exec[p]) { (void)hipGraphExecDestroy(s->exec[p]); s->exec[p] = nullptr; }
+    if (s->graph_obj[p]) { (void)hipGraphDestroy(s->graph_obj[p]); s->graph_obj[p] = nullptr; }
+  }
+  if (dec == nullptr) {
+    s->early = false;
+    return 0;
+  }
+  if (int rc = check_decoder(dec, s->rhs.d)) return rc;
+  GNPDE_CHECK_ARG(state != nullptr && max_trial_steps >= 1, GNPDE_EINVAL, "dopri5_set_early_stop: state is null or no trial steps allowed");
+  GNPDE_CHECK_ARG((trace != nullptr || trace_capacity == 0) && (times != nullptr || times_capacity == 0) && trace_capacity >= 0 &&
+                  times_capacity >= 0, GNPDE_EINVAL, "dopri5_set_early_stop: capacity without an array");
+  s->dec = *dec;
+  s->early_state = state;
+  s->early_trace = trace;
+  s->early_trace_capacity = trace_capacity;
+  s->times = times;
+  s->times_capacity = times_capacity;
+  s->max_trials = max_trial_steps;
+  s->early = true;
   return 0;
 }
 

@@ -35,10 +35,12 @@ struct DecArgs {
   int n, ld, d, c;
   int d16, dpad;
   bool vec;
+  const int* gate;   // NULL, or a device flag: 0 = this evaluation is skipped (device-controlled dopri5: rejected trial steps)
 };
 
 template <int CT>
 __global__ __launch_bounds__(kBlock) void decode_count_kernel(const DecArgs a) {
+  if (a.gate != nullptr && *a.gate == 0) return;   // (uniform over the grid)
   extern __shared__ float w_lds[];   // [16 * CT][dpad], zero padded in both directions
   for (int row = threadIdx.x >> 6; row < 16 * CT; row += kWavesPerBlock)
     for (int k = threadIdx.x & (kWave - 1); k < a.dpad; k += kWave)
@@ -160,7 +162,10 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const DecArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void early_stop_update_kernel(int* __restrict__ state, int n_parts, int step,
-                                                                   int* __restrict__ trace, int trace_capacity) {
+                                                                   int* __restrict__ trace, int trace_capacity,
+                                                                   const int* __restrict__ gate, const int* __restrict__ tag) {
+  if (gate != nullptr && *gate == 0) return;
+  if (tag != nullptr) step = *tag;               // the step tag lives on the device (accepted-step count of the controller)
   __shared__ int red[kBlock][3];
   int s0 = 0, s1 = 0, s2 = 0;
   for (int i = threadIdx.x; i < n_parts; i += kBlock) {
@@ -214,10 +219,11 @@ int launch_decode(const DecArgs& a, hipStream_t st, int* n_parts) {
 }  // namespace
 
 int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, int n, int step, int* state, int* trace,
-                            int trace_capacity, hipStream_t st) {
+                            int trace_capacity, hipStream_t st, const int* gate, const int* tag) {
   int n_parts = 0;
   if (n > 0) {
     DecArgs a;
+    a.gate = gate;
     a.y = y; a.weight = dec.weight; a.bias = dec.bias; a.labels = dec.labels; a.split = dec.split; a.state = state;
     a.n = n; a.ld = ld; a.d = dec.d_dec; a.c = dec.n_classes;
     a.d16 = (dec.d_dec + 15) / 16 * 16;
@@ -236,7 +242,7 @@ int enqueue_early_stop_eval(const gnpde_decoder_t& dec, const float* y, int ld, 
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(early_stop_update_kernel, dim3(1), dim3(kBlock), 0, st, state, n_parts, step, trace, trace_capacity);
+  hipLaunchKernelGGL(early_stop_update_kernel, dim3(1), dim3(kBlock), 0, st, state, n_parts, step, trace, trace_capacity, gate, tag);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }

@@ -17,7 +17,8 @@ before the first accept evaluate the initial state once, at t0, as the reference
 import torch
 
 from . import _lib
-from .odeint import time_grid, _native_ok, _solve_native, _solve_fixed_host, _solve_dopri5, _solve_dopri5_native
+from .odeint import (time_grid, _native_ok, _solve_native, _solve_fixed_host, _solve_dopri5, _solve_dopri5_native,
+                     _solve_dopri5_device)
 from . import ops
 
 
@@ -90,12 +91,23 @@ class EarlyStopDopri5(_EarlyStopSolver):
   """Adaptive Dormand-Prince with the evaluator after every step (reference early_stop_solver.py:30-128)."""
   order = 5
 
-  def __init__(self, func, y0, rtol, atol, opt, **unused):
+  def __init__(self, func, y0, rtol, atol, opt, eager_stages=False, host_controller=False, trials_per_sync=None, **unused):
     super(EarlyStopDopri5, self).__init__(func, y0, opt)
     self.rtol, self.atol = rtol, atol
     self.max_test_steps = opt['max_test_steps']
+    # options={'eager_stages': True} (or 'host_controller'): the step-size controller on the host, one scalar read per
+    # trial step -- kept for A/B runs; the default is the device controller with the evaluator inside the trial-step graph
+    self.host_loop = bool(eager_stages or host_controller)
+    self.trials_per_sync = trials_per_sync
 
   def integrate(self, t):
+    if (not self.host_loop and _native_ok(self.func, self.y0, t) and t.dtype == torch.float32 and int(self.max_test_steps) >= 1):
+      # the reference's default evaluation path (dopri5 + early stopping) without a host read per trial step: accept /
+      # reject, the trial budget, which state is evaluated and under which tag are all decided on the device
+      sol, times = _solve_dopri5_device(self.func, self.y0, t, self.rtol, self.atol, trials_per_sync=self.trials_per_sync,
+                                        evaluator=self.evaluator, stop_after=int(self.max_test_steps))
+      self._collect(times)
+      return t[-1], sol
     times = [float(t[0])]
 
     def on_accept(y, t1):

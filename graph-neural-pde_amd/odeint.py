@@ -330,11 +330,13 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   return out
 
 
-def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None):
+def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluator=None, stop_after=None):
   """dopri5 with the controller on the device (csrc/dopri5.hip): a trial step is one hipGraph replay; accept / reject, the
   step-size update, the end-point interpolation and the commit are decided by kernels from a record in device memory, which the
   host reads once per `trials_per_sync` trial steps.  Same arithmetic as `_solve_dopri5_native` (which stays for callers that
-  hook into every step, e.g. the early-stopping integrator)."""
+  hook into every step).  evaluator + stop_after: the early-stopping test integrator -- the decoder / arg-max / split counts run
+  as kernels behind every trial step, gated by the controller, and the solve gives up after `stop_after` trial steps
+  (gnpde_dopri5_set_early_stop); returns (out, times of the accepted steps) then."""
   from . import ops
   from .utils import MaxNFEException
   room = func.opt['max_nfe'] + 1 - func.nfe          # evaluations the reference would still allow before it raises
@@ -364,6 +366,12 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None):
       ent['solver'].close()
     ent['solver'] = ops.Dopri5Solver(desc, rtol, atol, y0.device)
     ent['sig'] = sig
+  sol = ent['solver']
+  if evaluator is not None:
+    if getattr(sol, 'evaluator', None) is not evaluator or getattr(sol, 'max_trial_steps', None) != int(stop_after):
+      sol.set_early_stop(evaluator, int(stop_after))
+  elif getattr(sol, 'evaluator', None) is not None:
+    sol.set_early_stop(None)
   if trials_per_sync is None:
     # launch-bound sizes: keep the queue full between reads; large states: a read per trial step costs nothing next to six
     # evaluations and nothing is replayed past the end point
@@ -377,6 +385,9 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None):
     func.nfe += min(spent, room)
     raise MaxNFEException
   func.nfe += spent
+  if evaluator is not None:
+    n_acc = ent['solver'].stats()['accepted']
+    return out, ent['solver'].times[:n_acc + 1].tolist()
   return out
 
 

@@ -390,6 +390,22 @@ class Dopri5Solver(object):
                                       int(trials_per_sync), int(max_evals), ctypes.byref(fin), stream_of(y0)))
     return bool(fin.value)
 
+  def set_early_stop(self, evaluator, max_trial_steps=None):
+    """Evaluate `evaluator` (EarlyStopEvaluator or None) after the trial steps, inside the captured trial-step graph, gated by
+    the device controller, and stop after `max_trial_steps` trial steps (gnpde_dopri5_set_early_stop).  `self.times` then
+    holds the time of every accepted step (index = step tag; [0] = t0) after a run."""
+    L = _lib.lib()
+    if evaluator is None:
+      check(L.gnpde_dopri5_set_early_stop(self.handle, None, None, None, 0, None, 0, 0))
+      self.evaluator, self.times = None, None
+      return
+    cap = int(max_trial_steps) + 2
+    self.times = torch.zeros(cap, dtype=torch.float64, device=evaluator.state.device)
+    check(L.gnpde_dopri5_set_early_stop(self.handle, evaluator.ref(), ptr(evaluator.state),
+                                        ptr(evaluator.trace) if evaluator.trace_capacity else None, evaluator.trace_capacity,
+                                        ptr(self.times), cap, int(max_trial_steps)))
+    self.evaluator, self.max_trial_steps = evaluator, int(max_trial_steps)
+
   def stats(self):
     v = [ctypes.c_int32(0) for _ in range(5)]
     check(_lib.lib().gnpde_dopri5_stats(self.handle, *[ctypes.byref(x) for x in v]))

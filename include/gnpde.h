@@ -486,6 +486,17 @@ int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs, float rtol
                         size_t workspace_bytes);
 int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y0, double t0, double t1, float* y_out, int32_t ld_out,
                      int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream);
+/* Early stopping on the device controller  [replaces EarlyStopDopri5.advance + evaluate, reference src/early_stop_solver.py:
+ * 82-128: the decoder, arg-max and split accuracies after EVERY trial step with three .item() reads, and the max_test_steps
+ * cut].  The evaluator kernels (gnpde_early_stop_eval) are appended to the captured trial step and gated by the controller
+ * record: an accepted step evaluates the new state with tag = number of accepted steps and its time goes to times[tag]
+ * (times[0] = t0); trial steps rejected before the first accept evaluate the initial state once (tag 0); other rejected steps
+ * re-evaluate nothing (the unchanged state cannot win the strict `val > best`).  After max_trial_steps trial steps the solve
+ * stops and y_out is the state reached (reference :93-98), not an interpolation.  The host still only replays graphs and reads
+ * the 96-byte record once per batch.  state / trace as in gnpde_solver_set_early_stop; dec == NULL detaches.  Call between
+ * runs (drops the captured trial steps). */
+int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
+                                int32_t trace_capacity, double* times, int32_t times_capacity, int32_t max_trial_steps);
 /* of the last run: evaluations of f, accepted and rejected steps, graph launches, host synchronisations */
 int gnpde_dopri5_stats(const gnpde_dopri5_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected, int32_t* n_launches,
                        int32_t* n_syncs);

@@ -319,3 +319,42 @@ def test_dopri5_rejections_before_the_first_accept_evaluate_the_initial_state(de
   assert rejected and rejected[0] == 0.0, 'the first trial step must have been rejected for this test to bite'
   sol = integ.solver
   assert sol.best_time == 0.0 and sol.best_val == 1.0 and sol.best_train == 1.0, (sol.best_time, sol.best_val)
+
+
+@pytest.mark.parametrize('name', [n for n in fixtures('early_') if 'dopri5' in n])
+def test_early_stop_dopri5_device_controller_equals_host_controller(dev, name):
+  """The reference's default evaluation path (dopri5 + early stopping, src/early_stop_solver.py:82-128) on the DEVICE
+  controller -- evaluator kernels inside the captured trial step, gated by the controller record, trial budget counted on the
+  device -- against the host-controlled loop (options={'eager_stages': True}: one scalar read per trial step): same accepted
+  times, same accuracies step by step, same best, same NFE, same state; and the host read the record once per BATCH of trial
+  steps, not once per step."""
+  fx = Fixture(name)
+  res = {}
+  for mode in ('device', 'host'):
+    block, integ, x = _install(fx, dev)
+    if mode == 'host':
+      inner = integ
+
+      class _Host(object):      # the block passes its own options; add the switch on the way through
+        def __call__(self, func, y0, t, **kw):
+          kw['options'] = dict(kw.get('options') or {}, eager_stages=True)
+          return inner(func, y0, t, **kw)
+      block.test_integrator = _Host()
+    block.set_x0(x)
+    with torch.no_grad():
+      z = block(x)
+    sol = integ.solver
+    res[mode] = dict(z=z.clone(), trace=[(r['time'], tuple(r['hits']), r['step']) for r in sol.trace],
+                     best=(sol.best_train, sol.best_val, sol.best_test, sol.best_time), nfe=block.odefunc.nfe,
+                     stats=getattr(block.odefunc, '_dopri5_stats', None))
+  a, b = res['device'], res['host']
+  assert a['nfe'] == b['nfe'] == int(fx.arr['nfe'])
+  assert len(a['trace']) == len(b['trace'])
+  for (ta, ha, sa), (tb, hb, sb) in zip(a['trace'], b['trace']):
+    assert sa == sb and ha == hb and abs(ta - tb) <= 1e-6 * max(abs(tb), 1e-3), ((ta, ha, sa), (tb, hb, sb))
+  assert a['best'][:3] == b['best'][:3] and abs(a['best'][3] - b['best'][3]) <= 1e-6 * max(abs(b['best'][3]), 1e-3)
+  assert_parity(a['z'], b['z'], tol=2e-6, what=name + ': device vs host controller')
+  st = a['stats']
+  trials = st['accepted'] + st['rejected']
+  assert st['launches'] == trials, 'no trial step may be replayed past the end of the solve'
+  assert st['syncs'] <= trials and (trials < 6 or st['syncs'] < trials), st      # batches, not one read per trial step
