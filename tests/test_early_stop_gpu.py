@@ -335,8 +335,8 @@ def test_early_stop_dopri5_device_controller_equals_host_controller(dev, name):
     if mode == 'host':
       inner = integ
 
-      class _Host(object):      # the block passes its own options; add the switch on the way through
-        def __call__(self, func, y0, t, **kw):
+      class _Host(torch.nn.Module):      # the block passes its own options; add the switch on the way through
+        def forward(self, func, y0, t, **kw):
           kw['options'] = dict(kw.get('options') or {}, eager_stages=True)
           return inner(func, y0, t, **kw)
       block.test_integrator = _Host()
