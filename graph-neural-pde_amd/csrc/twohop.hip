@@ -21,7 +21,7 @@ namespace gnpde {
 namespace {
 
 constexpr int kGroupCols = 2048;             // columns per group: 64 bitmap words, one per lane
-constexpr size_t kSlabBudget = size_t(16) << 30;
+constexpr size_t kSlabBudget = size_t(4) << 30;   // (was 16 GiB: 1.4 GB at the ogbn-arxiv size either way, 4 GB instead of 17 at 2 M nodes)
 
 struct TwoHopLayout {
   int words;        // bitmap words per slab (multiple of 64)
@@ -38,9 +38,11 @@ TwoHopLayout two_hop_layout(int n) {
   l.words = l.groups * 64;
   l.flag_words = ((l.groups + 3) / 4 + 63) / 64 * 64;
   l.slab_bytes = align_up(size_t(l.words) * 4 + size_t(l.flag_words) * 4 + size_t(l.words) * 32 * 4, 256);
+  // slabs = wavefronts in flight: enough to fill the 256 CUs a few times over, inside the byte budget -- the budget wins over
+  // the floor (2 M nodes: 8.4-MB slabs; 64 of them would be 0.5 GB, the old floor of 64 x 4.1 n bytes passed 16 GB there)
   size_t w = kSlabBudget / l.slab_bytes;
   if (w > 2048) w = 2048;
-  if (w < 64) w = 64;
+  if (w < 1) w = 1;
   if (w > size_t(n)) w = size_t(n > 0 ? n : 1);
   l.waves = int(w);
   l.counter_off = 0;

@@ -52,7 +52,16 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
     ent = {'y': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device),
            'x0': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device) if func.opt['add_source'] else None,
            'solver': None, 'sig': None}
-    st.clear()  # one live solver per function object: buffers are state-sized
+    for old in st.values():     # one live solver per function object: its buffers are state-sized
+      if old.get('solver') is not None:
+        old['solver'].close()
+    st.clear()
+    dd = func.__dict__.get('_dopri5_device')      # ... shared with the adaptive path: an eval that alternates methods
+    if dd:                                        # must not hold a fixed-step AND a 12-buffer dopri5 workspace
+      for old in dd.values():
+        if old.get('solver') is not None:
+          old['solver'].close()
+      dd.clear()
     st[key] = ent
   ent['y'].copy_(y0c)
   if ent['x0'] is not None:
@@ -354,6 +363,12 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
       if old['solver'] is not None:
         old['solver'].close()
     st.clear()   # one live solver per function object: its workspace is 12 state-sized buffers
+    fs = func.__dict__.get('_solver_state')       # ... shared with the fixed-step path
+    if fs:
+      for old in fs.values():
+        if old.get('solver') is not None:
+          old['solver'].close()
+      fs.clear()
     st[key] = ent
   if ent['x0'] is not None:
     if func.x0 is None:

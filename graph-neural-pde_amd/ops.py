@@ -195,7 +195,7 @@ def two_hop(graph, weight):
   L = _lib.lib()
   w_csr = w[graph.perm_long].contiguous()
   rowptr, col = graph.t['rowptr'], graph.t['colidx']
-  ws = torch.empty(int(L.gnpde_two_hop_workspace_bytes(graph.n)), dtype=torch.uint8, device=dev)
+  ws = graph.workspace('two_hop', int(L.gnpde_two_hop_workspace_bytes(graph.n)))   # kept on the graph: a training forward re-runs this
   out_rowptr = torch.empty(graph.n + 1, dtype=torch.int64, device=dev)
   check(L.gnpde_two_hop_count(ptr(rowptr), ptr(col), graph.n, ptr(out_rowptr), ptr(ws), ws.numel(), stream_of(w)))
   nnz = int(out_rowptr[-1].item())
@@ -357,9 +357,16 @@ class RhsDescriptor(object):
 def rhs_eval(desc, u, out=None):
   """One evaluation f(u) of a descriptor (gnpde_rhs_eval)."""
   require_hip(u)
-  u = _lib.f32rows(u, 'u') if desc.struct.flags & _lib.RHS_PADDED_ROWS else f32c(u, 'u')
+  padded = bool(desc.struct.flags & _lib.RHS_PADDED_ROWS)
+  u = _lib.f32rows(u, 'u') if padded else f32c(u, 'u')
+  if u.stride(0) != desc.struct.ld:
+    raise _lib.GnpdeError('rhs_eval: the state has row stride %d but the descriptor was built for %d' % (u.stride(0), desc.struct.ld))
   if out is None:
-    out = torch.empty_like(u)
+    # every operand of a descriptor shares ONE row stride: a padded view [n, ld][:, :d] needs a padded result buffer
+    # (torch.empty_like would hand back a dense [n, d] one and the kernel would write past its end)
+    out = _lib.alloc_state(u.shape[0], u.shape[1], u.device) if padded and _lib.is_padded(u) else torch.empty_like(u)
+  elif out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.stride(0) != desc.struct.ld or out.shape != u.shape:
+    raise _lib.GnpdeError('rhs_eval: out must be float32 %s with the descriptor\'s row stride %d' % (tuple(u.shape), desc.struct.ld))
   L = _lib.lib()
   ws = desc.graph.workspace('rhs%d_%d' % (desc.struct.kind, desc.struct.d), L.gnpde_rhs_workspace_bytes(desc.ref()))
   check(L.gnpde_rhs_eval(desc.ref(), ptr(u), ptr(out), ptr(ws), ws.numel(), stream_of(u)))
