@@ -137,7 +137,7 @@ __device__ __forceinline__ float edge_score(const AttArgs& a, int p, int r, int 
       for (int j = 0; j < a.dk; ++j) term(qp[j], kp[j]);
     }
     if constexpr (TYPE == GNPDE_ATT_SCALED_DOT) {
-      s = dot / a.inv_sqrt_dk_den;
+      s = dot * a.scale_mul;      // fl32(1 / sqrt(d_k)): exactly the quotient for d_k = 4, 16, 64, within 1 ulp otherwise
     } else if constexpr (TYPE == GNPDE_ATT_EXP_KERNEL) {
       const float ov = *a.output_var, ls = *a.lengthscale;
       s = (ov * ov) * expf(-(dot / (2.0f * (ls * ls))));
@@ -436,7 +436,7 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
   __syncthreads();
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) sum += expf(sv[i] - m);      // exp(-inf) = 0 for the absent entries
+  for (int i = 0; i < PER; ++i) sum += __builtin_amdgcn_exp2f((sv[i] - m) * 1.44269504088896341f);   // v_exp_f32; exp(-inf) = 0 for the absent entries
 #pragma unroll
   for (int off = H; off < kWave; off <<= 1) sum += __shfl_xor(sum, off, kWave);
   if (lane < H) red[wave][lane] = sum;
@@ -493,13 +493,13 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
       }
     }
     st[head] = m;
-    st[a.h + head] = l + 1e-16f;
+    st[a.h + head] = __builtin_amdgcn_rcpf(l + 1e-16f);     // one reciprocal per (row, head), a multiplication per entry
   }
   __syncthreads();
   for (int p = b + threadIdx.x; p < e; p += kBlock) {
     float acc = 0.f;
     for (int head = 0; head < a.h; ++head)
-      acc += expf(a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) / st[a.h + head];
+      acc += __builtin_amdgcn_exp2f((a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) * 1.44269504088896341f) * st[a.h + head];
     a.w_mean[p] = acc / static_cast<float>(a.h);
   }
 }
