@@ -598,12 +598,19 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 
   int row[RI], e0[RI], e1[RI];
   bool live[RI];
+  // all RI records are requested before the first one is used (round 3: with the load, its wait and the readfirstlane inside
+  // one loop body the four record fetches of a wave were four dependent round trips); a slot past the end re-reads the
+  // class's last record -- valid addresses, nothing written (live[r])
+  int4 info[RI];
 #pragma unroll
   for (int r = 0; r < RI; ++r) {
     live[r] = rbase + r < n_rows;
-    int4 info = make_int4(0, 0, 1, 0);  // dead slot: reads position 0, writes nothing
-    if (live[r]) info = reinterpret_cast<const int4*>(a.bin_rows)[first_row + rbase + r];
-    row[r] = info.x; e0[r] = info.y; e1[r] = info.y + info.z;
+    const long long idx = live[r] ? rbase + r : static_cast<long long>(n_rows) - 1;
+    info[r] = reinterpret_cast<const int4*>(a.bin_rows)[first_row + (idx < 0 ? 0 : idx)];
+  }
+#pragma unroll
+  for (int r = 0; r < RI; ++r) {
+    row[r] = info[r].x; e0[r] = info[r].y; e1[r] = info[r].y + info[r].z;
     if constexpr (GL == kWave) {
       row[r] = __builtin_amdgcn_readfirstlane(row[r]);
       e0[r] = __builtin_amdgcn_readfirstlane(e0[r]);
@@ -624,6 +631,19 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
   int nbatch = NB;
   if constexpr (GL == kWave && RI == 1) nbatch = (e1[0] - e0[0] + PB * GE - 1) / (PB * GE);  // wave-uniform
 
+  // column ids of the batch AFTER the current one are requested before the current batch's k rows are used, so that a row of
+  // several batches pays one dependent round trip per batch (k rows), not two (ids -> k rows)
+  int cn[RI][PB];
+  auto load_ids = [&](int nb) {
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int e = e0[r] + (nb * PB + i) * GE + slot;
+        cn[r][i] = a.colidx[e < e1[r] ? e : e1[r] - 1];
+      }
+  };
+  load_ids(0);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     if (nb < nbatch) {
@@ -631,10 +651,8 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 #pragma unroll
       for (int r = 0; r < RI; ++r)
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-          const int e = e0[r] + (nb * PB + i) * GE + slot;
-          c[r][i] = a.colidx[e < e1[r] ? e : e1[r] - 1];
-        }
+        for (int i = 0; i < PB; ++i) c[r][i] = cn[r][i];
+      if (NB > 1 && nb + 1 < nbatch) load_ids(nb + 1);
       float4 kv[RI][PB][DK4];
 #pragma unroll
       for (int r = 0; r < RI; ++r)
