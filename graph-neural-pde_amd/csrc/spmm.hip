@@ -358,26 +358,32 @@ __device__ __forceinline__ void gather_batch(const SpmmArgs& a, int cv, float wv
   constexpr int G = kWave / L;
   float vals[U][VEC];
   float ww[U];
+  int cs[U];
+  bool oks[U];
+  // ids / weights of the whole batch first, then the row loads (one loop made the predicated tail a chain of LDS round trips)
 #pragma unroll
   for (int t = 0; t < U; ++t) {
-    int c;
     bool ok = col_ok;
     if constexpr (G == 1) {
       const int idx = t0 + t;
-      c = __builtin_amdgcn_readlane(cv, idx & (kWave - 1));
+      cs[t] = __builtin_amdgcn_readlane(cv, idx & (kWave - 1));
       ww[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), idx & (kWave - 1)));   // bit pattern, not a numeric conversion
       if constexpr (TAIL) ok = ok && idx < cnt;
     } else {
       const int idx = t0 + t * G + sub;
-      c = __shfl(cv, idx & (kWave - 1), kWave);
+      cs[t] = __shfl(cv, idx & (kWave - 1), kWave);
       ww[t] = __shfl(wv, idx & (kWave - 1), kWave);
       if constexpr (TAIL) ok = ok && idx < cnt;
     }
     if constexpr (TAIL) ww[t] = ok ? ww[t] : 0.0f;
+    oks[t] = ok;
+  }
+#pragma unroll
+  for (int t = 0; t < U; ++t) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
-    const float* rowp = a.u + static_cast<size_t>(c) * a.ld;
-    if (ok) load_vec<VEC>(rowp + col, vals[t]);
+    const float* rowp = a.u + static_cast<size_t>(cs[t]) * a.ld;
+    if (oks[t]) load_vec<VEC>(rowp + col, vals[t]);
   }
 #pragma unroll
   for (int t = 0; t < U; ++t)
@@ -593,16 +599,23 @@ __global__ __launch_bounds__(BLK) void spmm_pair_kernel(const SpmmArgs a) {
   for (int t0 = 0; t0 < cmax; t0 += U) {
     float vals[U][VEC];
     float ww[U];
+    // (round 3) all ids / weights of the batch are handed out FIRST, then the row loads: written as one loop, the compiler
+    // emitted bpermute, bpermute, wait, predicated load per entry -- sixteen LDS round trips between the first and the last
+    // gather of a wave
+    int cs[U];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
       const int idx = t0 + t;                    // < 32 (cmax <= 32, U divides 32)
-      const int c = __shfl(cv, (half << 5) + idx, kWave);
+      cs[t] = __shfl(cv, (half << 5) + idx, kWave);
       const float w = __shfl(wv, (half << 5) + idx, kWave);
-      const bool ok = col_ok && idx < len;
-      ww[t] = ok ? w : 0.0f;
+      ww[t] = (col_ok && idx < len) ? w : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      const bool ok = col_ok && t0 + t < len;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
-      if (ok) load_vec<VEC>(a.u + static_cast<size_t>(c) * a.ld + col, vals[t]);
+      if (ok) load_vec<VEC>(a.u + static_cast<size_t>(cs[t]) * a.ld + col, vals[t]);
     }
 #pragma unroll
     for (int t = 0; t < U; ++t) {
