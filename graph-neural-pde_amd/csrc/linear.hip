@@ -273,6 +273,98 @@ __global__ __launch_bounds__(512) void linear_lds_kernel(const float* __restrict
   }
 }
 
+// Round 3: the same persistent kernel with the A operand fetched in FULL LINES and transposed through LDS.  The kernel above
+// loads fragment-shaped -- lane (r, kq) reads 16 bytes of row r, so one load instruction touches 16 rows x 64 B, half a cache
+// line each -- and streams x at 3.7 TB/s with the MFMA pipe 30 % busy.  Here lane l of load `it` reads chunk it * 64 + l of the
+// tile's 16 x d floats (two whole rows, 1 KB contiguous, per instruction), the wave writes the chunks into its own LDS slab
+// (chunk (r, j) at r * d/4 + (j ^ (r & 7)): the xor keeps both the row-linear writes and the column-strided fragment reads
+// free of bank conflicts) and reads the fragments back as ds_read_b128.  Wave-private slabs: no barrier, LDS operations of a
+// wave execute in order.  Same MFMA sequence, same k order, same results bit for bit.
+template <int MT, int KB>
+__global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __restrict__ x, int n, int ldx,
+                                                               const float* __restrict__ W, int ldw,
+                                                               const float* __restrict__ b, float* __restrict__ out,
+                                                               int ldo, int col_base, int relu) {
+  constexpr int CPR = KB * 4;                 // 16-byte chunks per row (d = 16 KB floats)
+  constexpr int CHUNKS = 16 * CPR;            // per tile
+  constexpr int PER_LANE = CHUNKS / kWave;    // = KB
+  __shared__ f32x4 slab[kWavesPerBlock][CHUNKS];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
+  const long long stride = static_cast<long long>(gridDim.x) * kWavesPerBlock;
+  long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
+  if (tile >= n_tiles) return;
+
+  f32x4 bv[KB][MT];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const float4 tb = *reinterpret_cast<const float4*>(W + static_cast<size_t>(col_base + t * 16 + r) * ldw + 16 * u + 4 * kq);
+      bv[u][t] = f32x4{tb.x, tb.y, tb.z, tb.w};
+    }
+  float bias[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) bias[t] = b != nullptr ? b[col_base + t * 16 + r] : 0.0f;
+
+  // chunk c = it * 64 + lane of a tile: row c / CPR, column chunk c % CPR
+  auto load_tile = [&](long long tl, f32x4 (&g)[PER_LANE]) {
+#pragma unroll
+    for (int it = 0; it < PER_LANE; ++it) {
+      const int c = it * kWave + lane;
+      long long row = tl * 16 + c / CPR;
+      if (row >= n) row = n - 1;               // ragged last tile: clamp reads, mask writes
+      const float4 ta = *reinterpret_cast<const float4*>(x + static_cast<size_t>(row) * ldx + 4 * (c % CPR));
+      g[it] = f32x4{ta.x, ta.y, ta.z, ta.w};
+    }
+  };
+  f32x4* my = slab[wave];
+  f32x4 g[PER_LANE];
+  load_tile(tile, g);
+  while (true) {
+#pragma unroll
+    for (int it = 0; it < PER_LANE; ++it) {
+      const int c = it * kWave + lane;
+      const int rr = c / CPR, j = c % CPR;
+      my[rr * CPR + (j ^ (rr & 7))] = g[it];
+    }
+    const long long next = tile + stride;
+    const bool more = next < n_tiles;
+    if (more) load_tile(next, g);              // in flight during the MFMAs of this tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments two K blocks at a time: the reads of the next pair are in flight during the MFMAs of this one
+#pragma unroll
+    for (int u = 0; u < KB; u += 2) {
+      f32x4 cu[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cu[q] = relu_if(my[r * CPR + ((4 * (u + q) + kq) ^ (r & 7))], relu);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[q][i], bv[u + q][t][i], acc[t], 0, 0, 0);
+    }
+    const long long row0 = tile * 16;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long orow = row0 + 4 * kq + i;
+        if (orow < n) out[static_cast<size_t>(orow) * ldo + col_base + t * 16 + r] = acc[t][i] + bias[t];
+      }
+    if (!more) break;
+    __builtin_amdgcn_wave_barrier();           // the fragment reads above precede the next tile's slab writes
+    tile = next;
+  }
+}
+
 template <int MT, bool ALIGNED>
 void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                  int ldo, int col, hipStream_t s, int relu) {
@@ -280,13 +372,22 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
   const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
   const long long tiles = (static_cast<long long>(n) + 15) / 16;
   if constexpr (MT <= 2) {
-    if (full_cols && d <= 128 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] == 0) {
+    if (full_cols && d <= 128 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 1) {
       // persistent grid: enough wavefronts to fill the chip (8 per SIMD at these register counts would be
       // ideal; W fragments + double-buffered A cost ~150 VGPRs -> 3 per SIMD), each striding over tiles
       long long blocks = 256LL * 3;
       const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
       if (blocks > need) blocks = need;
       const unsigned pg = static_cast<unsigned>(blocks);
+      // d = 64 / 128 (4 or 8 chunks per lane and tile): full-line loads transposed through LDS (linear_staged_kernel);
+      // gnpde_tune(8, 2) keeps the fragment-shaped loads for A/B runs
+      if ((d == 128 || d == 64) && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 2) {
+        if (d == 128)
+          hipLaunchKernelGGL((linear_staged_kernel<MT, 8>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+        else
+          hipLaunchKernelGGL((linear_staged_kernel<MT, 4>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+        return;
+      }
 #define GNPDE_LP(KBV) \
   hipLaunchKernelGGL((linear_persistent_kernel<MT, KBV>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu)
       switch (d / 16) {
