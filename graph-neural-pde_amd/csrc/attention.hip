@@ -689,37 +689,56 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
         for (int i = 0; i < PB; ++i) s[r][nb * PB + i] = -INFINITY;
     }
   }
+  // The reductions run LEVEL by level over all RI rows of the wave, not row by row: every xor step is a dependent LDS round
+  // trip (ds_bpermute + wait), and written row by row the 10 steps of a row x RI rows formed one chain of 40 (round 3, from the
+  // ISA); level-synchronous there are RI independent exchanges in flight per step.  Same operations per row, same order.
+#pragma unroll
+  for (int off = H; off < GL; off <<= 1)
+#pragma unroll
+    for (int r = 0; r < RI; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, kWave));
+  float l[RI];
 #pragma unroll
   for (int r = 0; r < RI; ++r) {
-#pragma unroll
-    for (int off = H; off < GL; off <<= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, kWave));
-    float l = 0.f;
+    l[r] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (nb < nbatch) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           s[r][nb * PB + i] = __builtin_amdgcn_exp2f((s[r][nb * PB + i] - m[r]) * 1.44269504088896341f);   // v_exp_f32: arguments are <= 0, -inf -> 0
-          l += s[r][nb * PB + i];
-        }
-      }
-#pragma unroll
-    for (int off = H; off < GL; off <<= 1) l += __shfl_xor(l, off, kWave);
-    const float den = l + 1e-16f;
-    const float rden = __builtin_amdgcn_rcpf(den);      // v_rcp_f32 (1 ulp), one per (row, head); a multiplication per entry
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (nb < nbatch) {
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-          float v = s[r][nb * PB + i] * rden;
-#pragma unroll
-          for (int off = 1; off < H; off <<= 1) v += __shfl_xor(v, off, kWave);
-          const int e = e0[r] + (nb * PB + i) * GE + slot;
-          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = v / static_cast<float>(H);
+          l[r] += s[r][nb * PB + i];
         }
       }
   }
+#pragma unroll
+  for (int off = H; off < GL; off <<= 1)
+#pragma unroll
+    for (int r = 0; r < RI; ++r) l[r] += __shfl_xor(l[r], off, kWave);
+  float rden[RI];
+#pragma unroll
+  for (int r = 0; r < RI; ++r) rden[r] = __builtin_amdgcn_rcpf(l[r] + 1e-16f);   // v_rcp_f32 (1 ulp), one per (row, head); a multiplication per entry
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    if (nb < nbatch) {
+      float v[RI][PB];
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) v[r][i] = s[r][nb * PB + i] * rden[r];
+#pragma unroll
+      for (int off = 1; off < H; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+          for (int i = 0; i < PB; ++i) v[r][i] += __shfl_xor(v[r][i], off, kWave);
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int e = e0[r] + (nb * PB + i) * GE + slot;
+          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = v[r][i] / static_cast<float>(H);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void edge_to_csr_mean_kernel(const int* __restrict__ perm, const float* __restrict__ src,
