@@ -266,7 +266,9 @@ extern "C" int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t
 // flight before the first add.  Uniform k: no degree skew, no hub rows, no tail.  The aggregation cannot gather faster than
 // this; how close it comes is roofline.frac when the table is cache-resident and HBM's 8 TB/s is not the ceiling.
 namespace gnpde {
-template <int LPR, bool SHUFFLE>
+// (variant 2, experiment: ids with the top bit set are fetched with the nontemporal hint -- rows referenced once should not
+//  evict the often-referenced ones from the XCD's L2)
+template <int LPR, bool SHUFFLE, bool HINT = false>
 __global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __restrict__ table, int ld, int d,
                                                                const int* __restrict__ idx, int k, float* __restrict__ out,
                                                                int n_out) {
@@ -291,7 +293,20 @@ __global__ __launch_bounds__(kWave) void gather_ceiling_kernel(const float* __re
       v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       int c;
       if constexpr (SHUFFLE) c = __shfl(mine, sub * LPR + t, kWave); else c = t0 + t < k ? my[t0 + t] : 0;
-      if (t0 + t < k) v[t] = *reinterpret_cast<const float4*>(table + static_cast<size_t>(c) * ld + col);
+      if constexpr (HINT) {
+        if (t0 + t < k) {
+          const float* src = table + static_cast<size_t>(c & 0x7fffffff) * ld + col;
+          if (c < 0) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+            v[t] = make_float4(q[0], q[1], q[2], q[3]);
+          } else {
+            v[t] = *reinterpret_cast<const float4*>(src);
+          }
+        }
+      } else {
+        if (t0 + t < k) v[t] = *reinterpret_cast<const float4*>(table + static_cast<size_t>(c) * ld + col);
+      }
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -311,7 +326,14 @@ extern "C" int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t 
                   reinterpret_cast<uintptr_t>(out) % 16 == 0, GNPDE_ESHAPE,
                   "gather_ceiling: rows of 4..256 floats in 16-byte lanes (d %% 4 == 0, aligned)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  GNPDE_CHECK_ARG(variant == 0 || variant == 1, GNPDE_EINVAL, "gather_ceiling: variant 0 (ids loaded per lane) or 1 (coalesced + shuffle)");
+  GNPDE_CHECK_ARG(variant >= 0 && variant <= 2, GNPDE_EINVAL, "gather_ceiling: variant 0 (ids loaded per lane), 1 (coalesced + shuffle) or 2 (0 with the nontemporal hint on ids whose top bit is set)");
+  if (variant == 2) {
+    GNPDE_CHECK_ARG(d <= 128, GNPDE_ESHAPE, "gather_ceiling: variant 2 covers d <= 128");
+    const unsigned grid = gnpde::xcd_grid((static_cast<long long>(n_out) + 1) / 2);
+    hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<32, false, true>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
+    GNPDE_LAUNCH_CHECK();
+    return 0;
+  }
   if (d <= 128) {
     const unsigned grid = gnpde::xcd_grid((static_cast<long long>(n_out) + 1) / 2);
     if (variant == 0) hipLaunchKernelGGL((gnpde::gather_ceiling_kernel<32, false>), dim3(grid), dim3(gnpde::kWave), 0, s, table, ld, d, idx, k, out, n_out);
