@@ -203,20 +203,28 @@ def timed_replay(fn, reps, replays=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def gather_ceiling(G, x, n, E):
-  """Rate of a perfectly balanced gather of whole state rows from the SAME table (gnpde_gather_ceiling): k = round(E / n) random
-  rows per output row, no weights, no epilogue, no skew.  Bytes by the same gather model as the aggregation's
-  (ids + gathered rows + one row written)."""
+def gather_ceiling(G, x, n, E, graph=None):
+  """Rate of a perfectly balanced gather of whole state rows from the SAME table (gnpde_gather_ceiling), no weights, no
+  epilogue streams, no degree skew.  With `graph`: the graph's OWN column ids in CSR order, k = floor(E / n) consecutive ids per
+  output row -- the same references in the same order as the aggregation makes them, so the L2 hits that the graph's hot
+  columns earn are in the ceiling too; without: k uniformly random rows per output row (no reuse at all).  Bytes by the same
+  gather model as the aggregation's (ids + gathered rows + one row written)."""
   from gnpde_amd import _lib
   d, ld = x.shape[1], x.stride(0)
   if d % 4 != 0 or d > 256 or ld % 4 != 0:
     return None
-  k = max(1, int(round(E / float(n))))
-  gen = torch.Generator(device=x.device).manual_seed(1234)
-  idx = torch.randint(0, n, (n * k,), device=x.device, dtype=torch.int32, generator=gen)
-  out = torch.empty_like(x)
   L = _lib.lib()
-
+  out = torch.empty_like(x)
+  if graph is not None and E >= n:
+    k = max(1, E // n)
+    idx = graph.t['colidx'][: n * k].contiguous()
+    what = ('gnpde_gather_ceiling: out[i] = sum of rows colidx[i k .. i k + k) of the same [n, d] table -- the graph\'s own column '
+            'ids in CSR order, k = floor(E / n) per output row (same references, same order, perfectly balanced)')
+  else:
+    k = max(1, int(round(E / float(n))))
+    gen = torch.Generator(device=x.device).manual_seed(1234)
+    idx = torch.randint(0, n, (n * k,), device=x.device, dtype=torch.int32, generator=gen)
+    what = 'gnpde_gather_ceiling: out[i] = sum of k uniformly random rows of the same [n, d] table'
   best = None
   for variant in (0, 1):      # ids loaded per lane / one coalesced id load + shuffle: the faster one is the ceiling
     def call():
@@ -229,9 +237,8 @@ def gather_ceiling(G, x, n, E):
   return {'row_gather_gbs': round(n * k * 4 * d / t / 1e9, 1), 'gather_model_gbs': round(nbytes / t / 1e9, 1),
           'avg_launch_us': round(t * 1e6, 2), 'rows_gathered_per_output_row': k, 'variant': variant,
           'gathered_row_bytes_per_launch': n * k * 4 * d, 'bytes_per_launch': nbytes,
-          'what': 'gnpde_gather_ceiling: out[i] = sum of k uniformly random rows of the same [n, d] table, 16-byte lanes, one '
-                  'wavefront per workgroup, no weights / epilogue operands / degree skew / hub rows; measured in this run; '
-                  'row_gather_gbs = bytes of the gathered rows alone / time'}
+          'what': what + '; 16-byte lanes, one wavefront per workgroup, no weights / epilogue operands / degree skew / hub rows; '
+                         'measured in this run; row_gather_gbs = bytes of the gathered rows alone / time'}
 
 
 def secondary_kernels(G, block, x, E, n, ceiling):
@@ -398,7 +405,8 @@ def main():
   bytes_nl = E * (4 + 4 * A + 4 * d) + n * (4 + 12 * A + 12 * d) + 4 * d * n   # SURVEY.md 8d, B_nl + source
   bytes_spmm = bytes_nl if fused else bytes_l
   achieved = bytes_spmm / t_spmm / 1e9
-  ceiling = gather_ceiling(G, x, n, E)
+  ceiling = gather_ceiling(G, x, n, E, graph)          # the graph's own references, balanced
+  ceiling_uniform = gather_ceiling(G, x, n, E)       # no reuse at all (what round 3's first lines were quoted against)
   try:
     secondary = [] if fused else secondary_kernels(G, main_block, x, E, n, ceiling)
   except Exception as exc:   # (a probe that cannot run must not cost the line)
@@ -422,9 +430,10 @@ def main():
   #  * Table inside the 256-MiB Infinity Cache (ogbn-arxiv, 83 MiB): the gathered rows come from L2 / MALL and HBM's rate does
   #    not bound them (a fraction of it can exceed 1 and means nothing).  The bound is the rate at which the memory system
   #    delivers randomly addressed rows of this table: achieved = bytes of the E gathered rows alone / launch duration,
-  #    peak = the same quantity of a perfectly balanced gather of rows of the same table measured in this run
-  #    (gnpde_gather_ceiling: no weights, no epilogue streams, no skew) -- the aggregation also streams 4 N d-float operands on
-  #    top of its gathers, so it cannot exceed that rate.
+  #    peak = the same quantity of a perfectly balanced gather of THE SAME column ids in CSR order measured in this run
+  #    (gnpde_gather_ceiling: no weights, no epilogue streams, no skew) -- the aggregation also streams 3 N d-float operands on
+  #    average on top of its gathers (x0 in and one row out in every stage, y and k1 in two of four: 11 us per 87-MB stream at
+  #    this shape, tools/agg_streams.py), so it cannot reach that rate; the gap IS mostly those streams.
   row_gather = E * 4 * d / t_spmm / 1e9
   if resident and ceiling is not None:
     bound, ach, peak = 'l2-miss/MALL', row_gather, ceiling['row_gather_gbs']
@@ -464,7 +473,8 @@ def main():
                  'hbm_peak': HBM_PEAK_GBS,
                  'frac_of_hbm_peak': None if resident else round(achieved / HBM_PEAK_GBS, 4),
                  'hbm_copy_rate': HBM_COPY_GBS,
-                 'ceiling': ceiling,
+                 'ceiling': ceiling, 'ceiling_uniform_random_ids': ceiling_uniform,
+                 'epilogue_stream_bytes_per_launch_avg': 4 * d * n * 3,   # x0 + out every stage, y and k1 in two of four: 12 per step
                  'traffic': None, 'traffic_gbs': None,
                  'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2),
                  'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d),
