@@ -580,16 +580,21 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
 // The first `n_hub` blocks of the launch do the hub-row work instead (phase 0: chunk scores + partial
 // statistics, phase 1: fold partials + normalise), so the long rows ride along with the row kernels rather
 // than costing two extra serialised launches.
-// Rows [first_row, first_row + n_rows) of a degree class; `wave_index` numbers the wavefronts that work on the class (a
-// wavefront takes RI records per GL-lane group).
 template <int H, int DK4, int GL, int RI, int PB, int NB>
-__device__ __forceinline__ void sd_rows_body(const AttArgs& a, int first_row, int n_rows, long long wave_index) {
+__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
+                                                                 int hub_phase, float* __restrict__ part,
+                                                                 const int* __restrict__ chunk_first) {
+  if (static_cast<int>(blockIdx.x) < n_hub) {
+    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
+    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
+    return;
+  }
   constexpr int RPW = kWave / GL;
   constexpr int GE = GL / H;
   const int lane = threadIdx.x & (kWave - 1);
   const int gi = lane % GL;
   const int slot = gi / H, head = gi % H;
-  const long long rbase = (wave_index * RPW + lane / GL) * RI;
+  const long long rbase = ((static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / GL) * RI;
 
   int row[RI], e0[RI], e1[RI];
   bool live[RI];
@@ -736,49 +741,6 @@ __device__ __forceinline__ void sd_rows_body(const AttArgs& a, int first_row, in
     }
 }
 
-template <int H, int DK4, int GL, int RI, int PB, int NB>
-__global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
-                                                                 int hub_phase, float* __restrict__ part,
-                                                                 const int* __restrict__ chunk_first) {
-  if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
-    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
-    return;
-  }
-  sd_rows_body<H, DK4, GL, RI, PB, NB>(a, first_row, n_rows,
-                                      static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6));
-}
-
-// The class of 17 .. GNPDE_LONG_ROW entries, a wavefront per row, records longest first.  Most of these rows have at most
-// PB * 64 / H entries (one batch); a wavefront that owns one such row spends its life in a chain of dependent round trips
-// (record -> q, ids -> k rows -> 10 exchange steps -> store) with one row's worth of work in flight.  Here a wavefront takes
-// TWO consecutive records: both short -> the two rows run interleaved through the one-batch instantiation (RI = 2, NB = 1: the
-// register budget of the long-row path covers it); otherwise one after the other through the general path.
-template <int H, int DK4>
-__global__ __launch_bounds__(kBlock) void row_attention_sd64_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
-                                                                   int hub_phase, float* __restrict__ part,
-                                                                   const int* __restrict__ chunk_first) {
-  if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
-    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
-    return;
-  }
-  constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);
-  constexpr int PB64 = (DK4 == 1) ? 4 : 2;
-  constexpr int ONE_BATCH = PB64 * (kWave / H);     // entries one batch covers
-  const long long w = static_cast<long long>(blockIdx.x - n_hub) * kWavesPerBlock + (threadIdx.x >> 6);
-  const long long r0 = 2 * w;
-  if (r0 >= n_rows) return;
-  const int len0 = __builtin_amdgcn_readfirstlane(a.bin_rows[4 * (first_row + r0) + 2]);
-  const int len1 = r0 + 1 < n_rows ? __builtin_amdgcn_readfirstlane(a.bin_rows[4 * (first_row + r0 + 1) + 2]) : 0;
-  if (len0 <= ONE_BATCH && len1 <= ONE_BATCH) {
-    sd_rows_body<H, DK4, kWave, 2, PB64, 1>(a, first_row, n_rows, w);
-  } else {
-    sd_rows_body<H, DK4, kWave, 1, PB64, P64 / PB64>(a, first_row, n_rows, r0);
-    if (r0 + 1 < n_rows) sd_rows_body<H, DK4, kWave, 1, PB64, P64 / PB64>(a, first_row, n_rows, r0 + 1);
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void edge_to_csr_mean_kernel(const int* __restrict__ perm, const float* __restrict__ src,
                                                                  int h, int e, float* __restrict__ w) {
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -860,14 +822,9 @@ void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub
                        0, part, chunk_first);
   }
   if (n64 > 0 || n_hub > 0) {
-    if (g_tune[GNPDE_TUNE_ATT_ONE_ROW_PER_WAVE] == 0) {     // two records per wavefront (row_attention_sd64_kernel)
-      const unsigned grid = static_cast<unsigned>((n64 + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock)) + n_hub;
-      hipLaunchKernelGGL((row_attention_sd64_kernel<H, DK4>), dim3(grid), dim3(kBlock), 0, s, a, n16, n64, n_hub, 1, part, chunk_first);
-    } else {
-      const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub;
-      hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16,
-                         n64, n_hub, 1, part, chunk_first);
-    }
+    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub;
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16,
+                       n64, n_hub, 1, part, chunk_first);
   }
 }
 
