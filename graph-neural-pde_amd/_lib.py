@@ -112,6 +112,10 @@ PROTOTYPES = {
   'gnpde_relu_linear': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32,
                                        ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_attention_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),
+  'gnpde_edge_attention_pass': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), ctypes.c_int32, c_vp, c_vp,
+                                               ctypes.c_size_t, c_vp]),
+  'gnpde_attention_workspace_regions': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct), c_vp]),
+  'gnpde_segment_stats_merge': (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_edge_attention': (ctypes.c_int, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct),
                                           c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_attention_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(GraphStruct), ctypes.POINTER(AttentionStruct)]),

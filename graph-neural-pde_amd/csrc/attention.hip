@@ -937,7 +937,7 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 // kernel arguments -- the backward pass continues from there
 static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                                float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork,
-                               bool stats_only, AttArgs* args_out, bool hubs_only = false) {
+                               bool stats_only, AttArgs* args_out, bool hubs_only = false, int pass_only = 0) {
   GNPDE_CHECK_ARG(g && at, GNPDE_EINVAL, "edge_attention: null descriptor");
   GNPDE_CHECK_ARG(stats_only || w_mean_csr || att_edge || prods_edge, GNPDE_EINVAL, "edge_attention: no output requested");
   GNPDE_CHECK_ARG(at->heads >= 1 && at->att_dim >= at->heads && at->att_dim % at->heads == 0, GNPDE_EINVAL,
@@ -982,7 +982,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 2 ? 0 : 1;   // default since round 3 (bit-identical; -3.4 % on the R-MAT launch)
   float* part = reinterpret_cast<float*>(base + L.part);
 
-  if (a.square_plus) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
+  if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
   if (gat) {
     const long long items = static_cast<long long>(g->n) * a.h;
     hipLaunchKernelGGL(gat_terms_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
@@ -992,8 +992,8 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(a.k) % 16 == 0);
 
-  const bool fused = !stats_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr && prods_edge == nullptr &&
-                     g->bin_rows != nullptr && fused_supported(a, vec4);
+  const bool fused = !stats_only && pass_only == 0 && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr &&
+                     prods_edge == nullptr && g->bin_rows != nullptr && fused_supported(a, vec4);
   GNPDE_CHECK_ARG(g->row_begin == 0 || fused, GNPDE_EINVAL, "edge_attention: a row sub-range needs the fused row path");
   if (fused) {
     AttArgs c = a;
@@ -1030,10 +1030,12 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     return 0;
   }
 
-  launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
-  GNPDE_LAUNCH_CHECK();
+  if (pass_only == 0 || pass_only == 1) {
+    launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
+    GNPDE_LAUNCH_CHECK();
+  }
   a.long_segs = (n_long > 0 && long_list != nullptr) ? long_list : nullptr;
-  {
+  if (pass_only == 0 || pass_only == 2) {
     const dim3 sgrid((g->n + kWavesPerBlock - 1) / kWavesPerBlock);
     switch (a.h) {
       case 1: hipLaunchKernelGGL(seg_stats_heads_kernel<1>, sgrid, dim3(kBlock), 0, stream, a); break;
@@ -1044,7 +1046,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     }
   }
   GNPDE_LAUNCH_CHECK();
-  if (a.long_segs != nullptr) {
+  if (a.long_segs != nullptr && (pass_only == 0 || pass_only == 2)) {
     hipLaunchKernelGGL(seg_stats_long_partial_kernel, dim3(n_long, max_chunks), dim3(kBlock), 0, stream, a, part, max_chunks);
     GNPDE_LAUNCH_CHECK();
     hipLaunchKernelGGL(seg_stats_long_combine_kernel, dim3(n_long), dim3(kWave), 0, stream, a, part, max_chunks);
@@ -1052,9 +1054,41 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   }
   if (args_out != nullptr) *args_out = a;
   if (stats_only) return 0;
-  hipLaunchKernelGGL(normalise_kernel, dim3(stream_grid(a.e)), dim3(kBlock), 0, stream, a);
-  GNPDE_LAUNCH_CHECK();
+  if (pass_only == 0 || pass_only == 3) {
+    hipLaunchKernelGGL(normalise_kernel, dim3(stream_grid(a.e)), dim3(kBlock), 0, stream, a);
+    GNPDE_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+// One pass of the general path at a time (the row-partitioned solver exchanges between them: the global maximum of squareplus
+// after pass 1, the per-column partial statistics of attention_norm_idx = 1 after pass 2)
+int launch_edge_attention_pass(const gnpde_graph_t* g, const gnpde_attention_t* at, int pass, float* w_mean_csr, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
+  GNPDE_CHECK_ARG(pass >= 1 && pass <= 3, GNPDE_EINVAL, "edge_attention_pass: pass must be 1 (scores), 2 (segment statistics) or 3 (normalise)");
+  GNPDE_CHECK_ARG(pass != 3 || w_mean_csr != nullptr, GNPDE_EINVAL, "edge_attention_pass: pass 3 writes w_mean_csr");
+  float dummy_out = 0.f;   // (the impl wants an output to be named; passes 1 and 2 write none)
+  return edge_attention_impl(g, at, pass == 3 ? w_mean_csr : &dummy_out, nullptr, nullptr, ws, ws_bytes, stream, nullptr, false, nullptr,
+                             false, pass);
+}
+
+// merge of segment statistics (m, den) <- (m, den) (+) (m_in, den_in) for the rows listed: the online-softmax combination,
+// or the plain sum for squareplus (its statistics carry no maximum)
+__global__ __launch_bounds__(kBlock) void stats_merge_kernel(float* __restrict__ m, float* __restrict__ den, const int* __restrict__ rows,
+                                                            int n_rows, int h, const float* __restrict__ m_in,
+                                                            const float* __restrict__ den_in, int square_plus) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<long long>(n_rows) * h) return;
+  const int i = static_cast<int>(idx / h), head = static_cast<int>(idx % h);
+  const size_t o = static_cast<size_t>(rows != nullptr ? rows[i] : i) * h + head;
+  if (square_plus) {
+    den[o] = den[o] + den_in[idx];
+    return;
+  }
+  const float ma = m[o], mb = m_in[idx];
+  const float mm = fmaxf(ma, mb);
+  den[o] = den[o] * expf(ma - mm) + den_in[idx] * expf(mb - mm);
+  m[o] = mm;
 }
 
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
@@ -1274,6 +1308,30 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
 extern "C" size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a) {
   if (!g || !a || a->heads < 1) return 0;
   return gnpde::attention_workspace_bytes(g, a->heads, a->type == GNPDE_ATT_GAT);
+}
+
+extern "C" int gnpde_edge_attention_pass(const gnpde_graph_t* g, const gnpde_attention_t* a, int32_t pass, float* w_mean_csr,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return gnpde::launch_edge_attention_pass(g, a, pass, w_mean_csr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnpde_attention_workspace_regions(const gnpde_graph_t* g, const gnpde_attention_t* a, size_t* offsets) {
+  GNPDE_CHECK_ARG(g && a && offsets && a->heads >= 1, GNPDE_EINVAL, "attention_workspace_regions: bad arguments");
+  const gnpde::AttLayout L = gnpde::att_layout(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT, gnpde::long_slots_of(g));
+  offsets[0] = L.scores; offsets[1] = L.seg_m; offsets[2] = L.seg_den; offsets[3] = L.gmax;
+  return 0;
+}
+
+extern "C" int gnpde_segment_stats_merge(float* seg_m, float* seg_den, const int32_t* rows, int32_t n_rows, int32_t heads,
+                                         const float* m_in, const float* den_in, int32_t square_plus, void* stream) {
+  GNPDE_CHECK_ARG(n_rows >= 0 && heads >= 1, GNPDE_EINVAL, "segment_stats_merge: bad shape");
+  if (n_rows == 0) return 0;
+  GNPDE_CHECK_ARG(seg_den && den_in && (square_plus || (seg_m && m_in)), GNPDE_EINVAL, "segment_stats_merge: null pointer");
+  const long long items = static_cast<long long>(n_rows) * heads;
+  hipLaunchKernelGGL(gnpde::stats_merge_kernel, dim3(static_cast<unsigned>((items + gnpde::kBlock - 1) / gnpde::kBlock)),
+                     dim3(gnpde::kBlock), 0, static_cast<hipStream_t>(stream), seg_m, seg_den, rows, n_rows, heads, m_in, den_in, square_plus);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a, float* w_mean_csr, float* att_edge,

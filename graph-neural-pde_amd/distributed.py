@@ -239,8 +239,15 @@ class NativeBackend(object):
       self.bqk = torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32).contiguous()
       self.heads = int(params['heads'])
       self.A = self.wqk.shape[0] // 2
+      self.norm_idx = int(params.get('norm_idx', 0))
+      self.square_plus = bool(params.get('square_plus', False))
+      self.general = self.norm_idx != 0 or self.square_plus      # needs exchanges BETWEEN the attention passes (rhs_stage_general)
       att = ops.attention_struct(_lib.ATT_SCALED_DOT, self.heads, self.A, 0, False)
       self._kw = dict(kind=_lib.RHS_TRANSFORMER, proj_w=self.wqk, proj_b=self.bqk, att=att)
+      if self.general:
+        # the attention passes see ALL local nodes as segments (a halo column is a segment of attention_norm_idx = 1)
+        self.g_att = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
+        self.supports_split = False
     else:
       raise ValueError(kind)
     self._desc = {}
@@ -311,6 +318,77 @@ class NativeBackend(object):
     desc = self._descriptor(x0 is not None, part)
     self.ops.rhs_stage(desc, u, stage, ws=self._ws, **stage_kw)
 
+  # ---- attention_norm_idx = 1 and / or squareplus: exchanges between the attention passes --------------------------
+  def rhs_stage_general(self, u, x0, stage, group=None, **stage_kw):
+    """One evaluation (halo rows of u already refreshed) for the normalisers that are not row-local:
+       pass 1  scores of the local entries (+ the local maximum)          -> squareplus: MAX all-reduce of one word
+       pass 2  statistics per local segment (rows, or own + halo COLUMNS)  -> norm_idx 1: partial statistics of the halo columns
+               go to their owners (the reverse of the halo exchange), are merged there peer by peer in rank order
+               (gnpde_segment_stats_merge) and come back with the state's exchange pattern
+       pass 3  normalise + head mean, then the aggregation with the fused stage on the owned rows.
+    Reference: src/function_transformer_attention.py:190-213 (softmax / squareplus over edge[attention_norm_idx]),
+    src/utils.py:179-208 (squareplus' global maximum)."""
+    import ctypes
+    ops, L, sh = self.ops, _lib.lib(), self.shard
+    if x0 is not None and (x0 is not self._src or x0._version != self._src_version):
+      self.x0.copy_(x0)
+      self._src, self._src_version = x0, x0._version
+    h, A, n_own, n_loc = self.heads, self.A, sh.n_own, sh.n_local
+    qk = ops.linear(u, self.wqk, self.bqk)                               # own AND halo rows (keys of halo rows recomputed locally)
+    st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A)
+    g = self.g_att
+    ws = g.workspace('att', L.gnpde_attention_workspace_bytes(g.ref(), ctypes.byref(st)))
+    offs = (ctypes.c_size_t * 4)()
+    _lib.check(L.gnpde_attention_workspace_regions(g.ref(), ctypes.byref(st), offs))
+    stream = _lib.stream_of(u)
+
+    def run_pass(k, w=None):
+      _lib.check(L.gnpde_edge_attention_pass(g.ref(), ctypes.byref(st), k, _lib.ptr(w), _lib.ptr(ws), ws.numel(), stream))
+    run_pass(1)
+    world = sh.world
+    if self.square_plus and world > 1:
+      # the maximum lives as an order-preserving uint32: MAX over the ranks on its unsigned value
+      word = ws[offs[3]:offs[3] + 4].view(torch.int32)
+      val = word.to(torch.int64) & 0xffffffff
+      if dist.get_backend(group) != 'nccl':
+        hv = val.cpu()
+        dist.all_reduce(hv, op=dist.ReduceOp.MAX, group=group)
+        val = hv.to(self.dev)
+      else:
+        dist.all_reduce(val, op=dist.ReduceOp.MAX, group=group)
+      word.copy_(torch.where(val >= 2 ** 31, val - 2 ** 32, val).to(torch.int32))
+    run_pass(2)
+    if self.norm_idx == 1 and world > 1:
+      m = ws[offs[1]:offs[1] + 4 * n_loc * h].view(torch.float32).view(n_loc, h)
+      den = ws[offs[2]:offs[2] + 4 * n_loc * h].view(torch.float32).view(n_loc, h)
+      n_send = int(sum(sh.send_counts))
+      # (i) partial statistics of the halo columns -> their owners
+      out_part = torch.cat([m[n_own:], den[n_own:]], dim=1).contiguous()
+      in_part = torch.empty(n_send, 2 * h, dtype=torch.float32, device=self.dev)
+      _all_to_all_rows(in_part, out_part, sh.send_counts, sh.recv_counts, group)
+      # (ii) merge at the owner, peer by peer in rank order (the peers' lists of my rows are unique: one call per peer)
+      pos = 0
+      for p in range(world):
+        cnt = int(sh.send_counts[p])
+        if cnt:
+          seg = in_part[pos:pos + cnt]
+          _lib.check(L.gnpde_segment_stats_merge(_lib.ptr(m), _lib.ptr(den), _lib.ptr(self.send_idx[pos:pos + cnt]), cnt, h,
+                                                 _lib.ptr(seg[:, :h].contiguous()), _lib.ptr(seg[:, h:].contiguous()),
+                                                 int(self.square_plus), stream))
+        pos += cnt
+      # (iii) the totals travel back like the state's boundary rows
+      tot = torch.cat([m[:n_own], den[:n_own]], dim=1)[self.send_idx.long()].contiguous()
+      back = torch.empty(sh.n_halo, 2 * h, dtype=torch.float32, device=self.dev)
+      _all_to_all_rows(back, tot, sh.recv_counts, sh.send_counts, group)
+      m[n_own:].copy_(back[:, :h])
+      den[n_own:].copy_(back[:, h:])
+    if getattr(self, '_w_general', None) is None:
+      self._w_general = torch.empty(max(g.e, 1), dtype=torch.float32, device=self.dev)
+    run_pass(3, self._w_general)
+    beta = self.beta if x0 is not None else None
+    ops.spmm_rhs(self.graph, self._w_general, u, self.alpha, beta, self.x0 if x0 is not None else None, self.alpha_sigmoid,
+                 stage=stage, **stage_kw)
+
   def sync(self):
     torch.cuda.synchronize(self.dev)
 
@@ -338,12 +416,18 @@ class ShardedSolver(object):
     self.be.pack(u, self.send)
     recv = u[s.n_own:]
     self.n_exchanges += 1
+    if not async_op and dist.get_backend(self.group) != 'nccl' and recv.is_cuda:
+      _all_to_all_rows(recv, self.send, s.recv_counts, s.send_counts, self.group)
+      return None
     return dist.all_to_all_single(recv, self.send, s.recv_counts, s.send_counts, group=self.group, async_op=async_op)
 
   def evaluate(self, u, x0, stage, **kw):
     """Exchange + f(u) with the fused stage.  When the backend can split the rows, the interior rows (no halo
     neighbour) are evaluated while the all-to-all is in flight and the boundary rows after it has landed."""
-    if getattr(self.be, 'supports_split', False) and self.overlap:
+    if getattr(self.be, 'general', False):
+      self.exchange(u)
+      self.be.rhs_stage_general(u, x0, stage, group=self.group, **kw)
+    elif getattr(self.be, 'supports_split', False) and self.overlap:
       work = self.exchange(u, async_op=True)
       self.be.rhs_stage(u, x0, stage, part='interior', **kw)
       if work is not None:
@@ -602,6 +686,17 @@ def shard_requested(func):
   return str(v).lower() not in ('0', '', 'false', 'none')
 
 
+def _all_to_all_rows(out, inp, out_splits, in_splits, group=None):
+  """all_to_all_single of row blocks over whatever backend the group has (gloo: staged through the host)."""
+  if dist.get_backend(group) == 'nccl' or not inp.is_cuda:
+    dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
+    return out
+  o = torch.empty(out.shape, dtype=out.dtype)
+  dist.all_to_all_single(o, inp.cpu(), list(out_splits), list(in_splits), group=group)
+  out.copy_(o)
+  return out
+
+
 def _host_group_gather(t_dev, group=None):
   """all_gather of equally shaped device tensors over whatever backend the group has (gloo: staged through the host)."""
   world = dist.get_world_size(group)
@@ -626,13 +721,13 @@ def _sharded_problem(func):
     return 'laplacian', dict(edge_weight=w.detach())
   if isinstance(func, ODEFuncTransformerAtt):
     o, lay = func.opt, func.multihead_att_layer
-    if (o['attention_type'] != 'scaled_dot' or o['attention_norm_idx'] != 0 or o['square_plus'] or o['reweight_attention']
-        or getattr(lay, 'split_kernel', False) or o['mix_features']):
-      raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with scaled-dot scores and a softmax over '
-                            'the row (attention_norm_idx 0, no squareplus / reweighting / beltrami split kernel); this '
+    if (o['attention_type'] != 'scaled_dot' or o['reweight_attention'] or getattr(lay, 'split_kernel', False) or o['mix_features']):
+      raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with scaled-dot scores (softmax or squareplus, '
+                            'over rows or columns; no reweighting / beltrami split kernel / other score functions); this '
                             'configuration runs on one GPU only -- unset gnpde_shard')
     return 'transformer', dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(),
-                               bk=lay.K.bias.detach(), heads=lay.h)
+                               bk=lay.K.bias.detach(), heads=lay.h, norm_idx=int(o['attention_norm_idx']),
+                               square_plus=bool(o['square_plus']))
   raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc and ODEFuncTransformerAtt, not %s' % type(func).__name__)
 
 
@@ -660,7 +755,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
   kind, params = _sharded_problem(func)
   ei = func.edge_index
   st = func.__dict__.setdefault('_shard_state', {})
-  key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev))
+  key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev), params.get('norm_idx', 0), params.get('square_plus', False))
   ent = st.get(key)
   if ent is None:
     for old in st.values():
@@ -673,14 +768,18 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
     if kind == 'laplacian':
       local['edge_weight'] = params['edge_weight'][shard.edge_ids.to(params['edge_weight'].device)]
     be = NativeBackend(shard, d, dev, kind, local, func.alpha_train, func.beta_train, not func.opt['no_alpha_sigmoid'])
-    ctx = P2PContext(shard, d, 4, group=group)
+    # normalisers that are not row-local (attention_norm_idx 1, squareplus) exchange BETWEEN the attention passes: they run the
+    # Python-driven loop over torch.distributed (ShardedSolver + NativeBackend.rhs_stage_general), not the in-graph P2P solver
+    ctx = None if getattr(be, 'general', False) else P2PContext(shard, d, 4, group=group)
     ent = dict(edge_index=ei, plan=plan, shard=shard, be=be, ctx=ctx, solvers={}, own_ids=shard.own_old_ids.to(dev))
 
     def close(ent=ent):
       for sol in ent['solvers'].values():
-        sol.close()
+        if hasattr(sol, 'close'):
+          sol.close()
       ent['solvers'].clear()
-      ent['ctx'].close()
+      if ent['ctx'] is not None:
+        ent['ctx'].close()
     ent['close'] = close
     st[key] = ent
   plan, shard, be = ent['plan'], ent['shard'], ent['be']
@@ -691,6 +790,19 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
   with_source = bool(func.opt['add_source'])
   skey = (method, dts, with_source)
   sol = ent['solvers'].get(skey)
+  if getattr(be, 'general', False):
+    if sol is None:
+      ent['solvers'].clear()
+      sol = ShardedSolver(shard, be, group)
+      ent['solvers'][skey] = sol
+    y_own = y0.detach()[ent['own_ids']]
+    x0_own = None
+    if with_source:
+      if func.x0 is None:
+        raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+      x0_own = func.x0.detach()[ent['own_ids']].contiguous()
+    z_own = sol.integrate(y_own, x0_own, float(sum(dts)), step_size, method).clone()
+    return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, n_evals)
   if sol is None:
     for old in ent['solvers'].values():     # one live solver per function: its stage buffers are the shared P2P block
       old.close()
@@ -709,7 +821,11 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
     x0_own = func.x0.detach()[ent['own_ids']]
   z_own = sol.integrate(y_own, x0_own, use_graph=use_graph)
   sol.check()                                       # synchronises; a lost peer raises here, on every rank that saw it
-  # every rank gets the whole state back: pad to the largest part, all-gather rows and their original ids
+  return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, n_evals)
+
+
+def _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, n_evals):
+  """Every rank gets the whole state back: pad to the largest part, all-gather the rows, put them at their original ids."""
   m = int(plan.counts.max())
   pad = torch.zeros(m, d, dtype=torch.float32, device=dev)
   pad[:shard.n_own] = z_own

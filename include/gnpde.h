@@ -299,6 +299,21 @@ int gnpde_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* a,
                          float* w_mean_csr, float* att_edge, float* prods_edge,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The general attention path one pass at a time, for callers that must exchange between the passes (the row-partitioned solver,
+ * SURVEY 8e):  pass 1 scores [e,h] into the workspace (+ the global maximum for squareplus, an order-preserving uint32 word),
+ * pass 2 segment statistics m[n,h], den[n,h] (per row for attention_norm_idx 0, per column for 1; den includes the + 1e-16),
+ * pass 3 normalise with the statistics / maximum CURRENTLY in the workspace and write w_mean_csr.  Same kernels and arithmetic
+ * as gnpde_edge_attention's general path (reference src/function_transformer_attention.py:190-213, src/utils.py:179-208).
+ * gnpde_attention_workspace_regions: byte offsets {scores, seg_m, seg_den, gmax} inside the workspace.
+ * gnpde_segment_stats_merge: (m, den)[rows[i]] <- merge with (m_in, den_in)[i], i < n_rows (rows NULL: i itself) -- softmax:
+ * M = max(m, m_in), den = den e^(m-M) + den_in e^(m_in-M); squareplus: den += den_in.  Partial statistics of a column whose
+ * entries live on several ranks are combined with it, peer by peer in a fixed order. */
+int gnpde_edge_attention_pass(const gnpde_graph_t* g, const gnpde_attention_t* a, int32_t pass, float* w_mean_csr,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int gnpde_attention_workspace_regions(const gnpde_graph_t* g, const gnpde_attention_t* a, size_t* offsets);
+int gnpde_segment_stats_merge(float* seg_m, float* seg_den, const int32_t* rows, int32_t n_rows, int32_t heads,
+                              const float* m_in, const float* den_in, int32_t square_plus, void* stream);
+
 /* Backward of the normalisation + head mean of gnpde_edge_attention for EVERY normaliser the reference has (softmax or
  * squareplus, opt['attention_norm_idx'] 0 or 1; reference src/function_transformer_attention.py:210-213, src/utils.py:179-208,
  * torch_geometric.utils.softmax):  dw_csr[p] = g_row . x_col (gnpde_sddmm without scale, CSR order);

@@ -36,15 +36,36 @@ def main():
   alpha, beta = torch.tensor(0.3), torch.tensor(0.2)
   plan = D.PartitionPlan(ei, n, world)
   sh = plan.shard(rank)
+  general = kind.startswith('transformer_')          # transformer_n1 / transformer_sqp / transformer_sqp_n1
+  norm_idx, square_plus = int('n1' in kind), 'sqp' in kind
   if kind == 'laplacian':
     _, w = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
     p = dict(edge_weight=w[sh.edge_ids])
   else:
-    p = params
-  be = D.NativeBackend(sh, d, dev, kind, p, alpha, beta, True)
-  ctx = D.P2PContext(sh, d, 4)
+    p = dict(params, norm_idx=norm_idx, square_plus=square_plus)
+  be = D.NativeBackend(sh, d, dev, 'transformer' if general else kind, p, alpha, beta, True)
   x_own = D.scatter_rows(x, sh).to(dev)
   res = {}
+  if general:
+    # normalisers that are not row-local: the Python-driven loop with exchanges between the attention passes
+    assert be.general
+    with torch.no_grad():
+      solver = D.ShardedSolver(sh, be)
+      z1 = solver.integrate(x_own, x_own, T, 1.0, method).clone()
+      z2 = solver.integrate(x_own, x_own, T, 1.0, method).clone()
+    assert torch.equal(z1, z2), 'rank %d: repeated solve differs' % rank
+    full = D.gather_rows_all(z1.cpu(), plan, sh)
+    if rank == 0:
+      rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
+                                           x, False, True, norm_idx=norm_idx, square_plus=square_plus)
+      ref = R.odeint_fixed(rhs, x, T, 1.0, method)
+      e_inf, e_2 = parity(full, ref)
+      json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
+                 'interior_rows': sh.n_interior, 'own_rows': sh.n_own}, open(out_path, 'w'))
+    dist.barrier()
+    dist.destroy_process_group()
+    return
+  ctx = D.P2PContext(sh, d, 4)
   with torch.no_grad():
     for use_graph in (False, True):
       solver = D.NativeShardedSolver(sh, be, T, 1.0, method, ctx=ctx)

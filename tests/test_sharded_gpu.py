@@ -114,7 +114,7 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
   reference-recorded fixtures, with the reference's NFE, every rank holding the whole result (tests/dist_block_worker.py)."""
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   out = str(tmp_path / 'blocks.json')
-  names = 'block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler'
+  names = 'block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4'
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
@@ -129,11 +129,11 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
 
 
 def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
-  """gnpde_shard on a configuration the partitioned solver does not cover (squareplus) raises instead of silently running on
-  one GPU; without a process group the request is ignored (single-GPU solve)."""
+  """gnpde_shard on a configuration the partitioned solver does not cover (a score function other than the scaled dot product)
+  raises instead of silently running on one GPU; without a process group the request is ignored (single-GPU solve)."""
   import torch.distributed as dist
   from helpers import Fixture, Data
-  fx = Fixture('block_constant_transformer_sqp_n1_rk4')
+  fx = Fixture('block_constant_transformer_rk4')
   x = fx.t('x', dev)
   opt = dict(fx.opt, gnpde_shard=1)
   block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], opt, Data(x, fx.t('edge_index', dev)), dev,
@@ -149,11 +149,30 @@ def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
   os.environ.setdefault('MASTER_PORT', '29677')
   dist.init_process_group('gloo', rank=0, world_size=1)
   try:
+    block.odefunc.opt = dict(block.odefunc.opt, attention_type='cosine_sim')      # not covered by the partitioned solver
     block.set_x0(x)
     with torch.no_grad(), pytest.raises(_lib.GnpdeError):
       block(x)
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('kind', ['transformer_n1', 'transformer_sqp', 'transformer_sqp_n1'])
+def test_normalisers_that_are_not_row_local(dev, tmp_path, world, kind):
+  """attention_norm_idx = 1 needs the column sums (partial statistics of the halo columns go to their owners, are
+  merged there and come back), squareplus the global maximum (a scalar MAX all-reduce) -- real partitions, `world` processes on
+  this one GPU, against the unpartitioned CPU oracle (reference src/function_transformer_attention.py:210-213, src/utils.py:196)."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / 'result.json')
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+         '--master-port', str(29660 + world), os.path.join(root, 'tests', 'dist_gpu_worker.py'), out, kind, 'rk4', '2.5']
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  r = json.load(open(out))
+  assert r['world'] == world and r['halo_rows'] > 0
+  assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
 
 
 def test_no_exchange_world1_matches_single_gpu_solver(dev):
