@@ -28,7 +28,9 @@ def main():
   dev = torch.device('cuda:0')
   torch.cuda.set_device(dev)
   n, d, A, h = 5000, 128, 16, 4
-  ei = random_graph(n, 8, seed=21, hubs=2, hub_deg=1200)
+  # (column normalisation gives a hub ROW the weight sum of all its columns -- 1200 / 8 here: the explicit solve would diverge, in
+  #  the oracle as well; the attention_norm_idx = 1 cases run on the graph without hubs)
+  ei = random_graph(n, 8, seed=21, hubs=0 if 'n1' in kind else 2, hub_deg=1200)
   g = torch.Generator().manual_seed(22)
   x = torch.randn(n, d, generator=g)
   params = dict(Wq=torch.randn(A, d, generator=g) / d ** 0.5, Wk=torch.randn(A, d, generator=g) / d ** 0.5,
@@ -53,17 +55,21 @@ def main():
       solver = D.ShardedSolver(sh, be)
       z1 = solver.integrate(x_own, x_own, T, 1.0, method).clone()
       z2 = solver.integrate(x_own, x_own, T, 1.0, method).clone()
-    assert torch.equal(z1, z2), 'rank %d: repeated solve differs' % rank
+    same = torch.equal(z1, z2)
+    if not same:
+      print('rank %d: repeated solve differs: max |d| %g, finite %s / %s' % (rank, float((z1 - z2).abs().max()), bool(torch.isfinite(z1).all()), bool(torch.isfinite(z2).all())), flush=True)
     full = D.gather_rows_all(z1.cpu(), plan, sh)
     if rank == 0:
       rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
                                            x, False, True, norm_idx=norm_idx, square_plus=square_plus)
       ref = R.odeint_fixed(rhs, x, T, 1.0, method)
       e_inf, e_2 = parity(full, ref)
+      print('general %s: rel_max %g rel_l2 %g' % (kind, e_inf, e_2), flush=True)
       json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
                  'interior_rows': sh.n_interior, 'own_rows': sh.n_own}, open(out_path, 'w'))
     dist.barrier()
     dist.destroy_process_group()
+    assert same, 'rank %d: repeated solve differs' % rank
     return
   ctx = D.P2PContext(sh, d, 4)
   with torch.no_grad():
