@@ -372,8 +372,9 @@ class NativeBackend(object):
         cnt = int(sh.send_counts[p])
         if cnt:
           seg = in_part[pos:pos + cnt]
-          _lib.check(L.gnpde_segment_stats_merge(_lib.ptr(m), _lib.ptr(den), _lib.ptr(self.send_idx[pos:pos + cnt]), cnt, h,
-                                                 _lib.ptr(seg[:, :h].contiguous()), _lib.ptr(seg[:, h:].contiguous()),
+          m_in, den_in, rows = seg[:, :h].contiguous(), seg[:, h:].contiguous(), self.send_idx[pos:pos + cnt]
+          # (named: a temporary handed to ptr() is freed at once and the next temporary takes its memory)
+          _lib.check(L.gnpde_segment_stats_merge(_lib.ptr(m), _lib.ptr(den), _lib.ptr(rows), cnt, h, _lib.ptr(m_in), _lib.ptr(den_in),
                                                  int(self.square_plus), stream))
         pos += cnt
       # (iii) the totals travel back like the state's boundary rows

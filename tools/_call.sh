@@ -1,1 +1,3 @@
-GNPDE_DEBUG_GENERAL=1 MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=4 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 tests/dist_gpu_worker.py /tmp/o.json transformer_n1 rk4 1.0 2>&1 | grep "^rank\|general" | head -24
+for W in 1 2; do
+MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=4 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node $W --master-addr 127.0.0.1 --master-port 2967$W tools/_dbg_general.py 2>&1 | grep "^world\|Error" | head
+done
