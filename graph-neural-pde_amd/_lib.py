@@ -186,6 +186,7 @@ PROTOTYPES = {
   'gnpde_sharded_solver_status': (ctypes.c_int, [c_vp, c_int_p, ctypes.POINTER(ctypes.c_int64)]),
   'gnpde_sharded_solver_timing': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_sharded_solver_set_spin_limit': (ctypes.c_int, [c_vp, ctypes.c_int64]),
+  'gnpde_sharded_solver_set_boundary_chunks': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.POINTER(RhsStruct)), ctypes.c_int32, c_int_p, c_int_p]),
   'gnpde_sharded_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(HaloStruct),
                                                  ctypes.POINTER(RhsStruct), ctypes.POINTER(RhsStruct), ctypes.c_int32,
                                                  c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),

@@ -129,7 +129,10 @@ struct PushArgs {
   const long long* dst_row0;   // [world] first halo row of this rank's rows on peer p
   uint32_t* const* peer_ctl;   // [world]
   uint32_t* ctl;               // local
-  unsigned long long* stamp;   // NULL or [2]: wall clock when the push started / when its epoch was published
+  int w_begin;                 // this launch copies the slots order[w_begin .. w_begin + n_send) (a chunk of the walk)
+  int publish;                 // 1: the last block raises the epoch flags (the last chunk of an evaluation's push), 0: rows only
+  unsigned long long* stamp_start;   // NULL or where block 0 stamps the wall clock when the push starts
+  unsigned long long* stamp_end;     // NULL or where the publishing block stamps it after the flags are up
 };
 
 // One wavefront per row: copy it into the owner-side halo slot on the peer (xGMI stores), then -- last block -- publish
@@ -137,12 +140,12 @@ struct PushArgs {
 __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
-  if (a.stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamp[0] = wall_clock64();
+  if (a.stamp_start != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *a.stamp_start = wall_clock64();
   if (w < a.n_send) {
     // The send list is grouped by destination.  Walked in that order, everything in flight at any moment targets ONE peer:
     // one xGMI link carries the whole push while the other six idle, and the exchange takes the SUM of the per-link times.
     // order[] interleaves the destinations (in proportion to their row counts, so that all links finish together).
-    const int i = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[w]) : w;
+    const int i = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[a.w_begin + w]) : a.w_begin + w;
     int p = 0;
     while (p + 1 < a.world && i >= a.seg[p + 1]) ++p;
     const float* src = a.src + static_cast<size_t>(a.send_idx[i]) * a.ld;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
     }
   }
   __threadfence_system();
+  if (!a.publish) return;      // rows only: a later launch on the same stream publishes (its blocks start after these stores)
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(a.ctl + kCtlDone, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
       __threadfence_system();
       for (int p = 0; p < a.world; ++p)
         if (p != a.rank) __hip_atomic_store(a.peer_ctl[p] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (a.stamp != nullptr) a.stamp[1] = wall_clock64();
+      if (a.stamp_end != nullptr) *a.stamp_end = wall_clock64();
     }
   }
 }
@@ -234,6 +238,13 @@ struct gnpde_sharded_solver {
   // at the wait, all peers' rows landed (gnpde_sharded_solver_timing); the extra row is the end-of-solve rendezvous
   unsigned long long* d_stamps = nullptr;
   int eval_cursor = 0;              // evaluation being enqueued
+  size_t ws_bytes = 0;
+  // Boundary pass in chunks with the push of each chunk's rows right behind it (gnpde_sharded_solver_set_boundary_chunks): the
+  // rows of the NEXT stage input travel while the remaining boundary rows are still being computed
+  std::vector<gnpde_rhs_t> rhs_chunk;
+  std::vector<gnpde_graph_t> g_chunk;
+  std::vector<RhsLayout> L_chunk;
+  std::vector<int> push_chunk_ptr;  // [n_chunks + 1] into the walk order
 };
 
 namespace {
@@ -303,30 +314,44 @@ int enqueue_exchange_rccl(gnpde_sharded_solver* s, float* u, hipStream_t st) {
 }
 
 // P2P: push kernel on the side stream (rows into the peers' halo regions, then the epoch flags); e_recv = push issued.
-// u == nullptr: publish the epoch only (the end-of-solve rendezvous).
-int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
+// u == nullptr: publish the epoch only (the end-of-solve rendezvous).  [w_begin, w_end): the part of the walk to copy (whole
+// list: 0, n_send); publish: raise the epoch flags after it; stamp_row: evaluation whose INPUT this push delivers (timing).
+int enqueue_push_p2p(gnpde_sharded_solver* s, float* u, int w_begin, int w_end, bool publish, int stamp_row, bool stamp_start,
+                     hipStream_t st) {
   gnpde_p2p* x = s->p2p;
   const int b = u != nullptr ? buffer_index(s, u) : 0;
   GNPDE_CHECK_ARG(b >= 0, GNPDE_ESTATE, "sharded solver: stage input is not a shared stage buffer");
   GNPDE_HIP(hipEventRecord(s->e_pack, st));
   GNPDE_HIP(hipStreamWaitEvent(x->stream, s->e_pack, 0));
   PushArgs a;
-  a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = u != nullptr ? s->n_send : 0; a.rank = x->rank; a.world = x->world;
+  a.src = u; a.ld = s->ld; a.d = s->d; a.n_send = u != nullptr ? w_end - w_begin : 0; a.rank = x->rank; a.world = x->world;
   a.send_idx = s->send_idx; a.order = s->d_order; a.seg = s->d_seg; a.dst = s->d_dst[b]; a.dst_row0 = s->d_dst_row0;
   a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl;
-  a.stamp = s->d_stamps != nullptr ? s->d_stamps + 4 * static_cast<size_t>(s->eval_cursor) : nullptr;
-  const unsigned grid = static_cast<unsigned>(a.n_send > 0 ? (a.n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
-  hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
-  GNPDE_LAUNCH_CHECK();
+  a.w_begin = w_begin; a.publish = publish ? 1 : 0;
+  unsigned long long* row = (s->d_stamps != nullptr && stamp_row >= 0 && stamp_row <= s->n_evals)
+                                ? s->d_stamps + 4 * static_cast<size_t>(stamp_row) : nullptr;
+  a.stamp_start = (row != nullptr && stamp_start) ? row : nullptr;
+  a.stamp_end = (row != nullptr && publish) ? row + 1 : nullptr;
+  if (a.n_send > 0 || publish) {
+    const unsigned grid = static_cast<unsigned>(a.n_send > 0 ? (a.n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
+    hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
+    GNPDE_LAUNCH_CHECK();
+  }
   GNPDE_HIP(hipEventRecord(s->e_recv, x->stream));
   return 0;
+}
+
+int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
+  return enqueue_push_p2p(s, u, 0, s->n_send, true, s->eval_cursor, true, st);
 }
 
 // exchange + f(u) with the fused stage: interior rows overlap the exchange, boundary rows follow it
 int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStream_t st) {
   char* rws = s->ws + s->off_rhs;
   const bool exch = s->exchanges;
-  if (exch) {
+  const bool chunked = s->p2p != nullptr && exch && !s->rhs_chunk.empty();
+  const bool first = s->eval_cursor == 0, last = s->eval_cursor == s->n_evals - 1;
+  if (exch && (!chunked || first)) {      // (chunked: the input of every later evaluation was pushed during the previous one)
     const int rc = s->p2p ? enqueue_exchange_p2p(s, u, st) : enqueue_exchange_rccl(s, u, st);
     if (rc) return rc;
   }
@@ -342,11 +367,26 @@ int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStrea
       GNPDE_LAUNCH_CHECK();
     }
   }
-  ++s->eval_cursor;
-  if (s->g_bnd.n > s->g_bnd.row_begin) {
+  if (chunked) {
+    // boundary rows chunk by chunk; behind each chunk its rows of the stage OUTPUT (= the next evaluation's input) go to the
+    // peers on the side stream while the next chunk is computed; the last chunk's push publishes the next evaluation's epoch
+    float* out = e.out_y;
+    const int K = static_cast<int>(s->rhs_chunk.size());
+    for (int c = 0; c < K; ++c) {
+      if (s->g_chunk[c].n > s->g_chunk[c].row_begin) {
+        const int rc = enqueue_rhs(s->rhs_chunk[c], u, e, rws, s->L_chunk[c], st);
+        if (rc) return rc;
+      }
+      if (!last) {
+        const int rc = enqueue_push_p2p(s, out, s->push_chunk_ptr[c], s->push_chunk_ptr[c + 1], c == K - 1, s->eval_cursor + 1, c == 0, st);
+        if (rc) return rc;
+      }
+    }
+  } else if (s->g_bnd.n > s->g_bnd.row_begin) {
     const int rc = enqueue_rhs(s->rhs_bnd, u, e, rws, s->L_bnd, st);
     if (rc) return rc;
   }
+  ++s->eval_cursor;
   return 0;
 }
 
@@ -489,6 +529,7 @@ int create_common(gnpde_sharded_solver** out, gnpde_comm* comm, gnpde_p2p* p2p, 
     return GNPDE_EWS;
   }
   s->ws = static_cast<char*>(workspace);
+  s->ws_bytes = workspace_bytes;
   s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
   hipError_t e = hipEventCreateWithFlags(&s->e_pack, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->e_recv, hipEventDisableTiming);
@@ -782,6 +823,52 @@ extern "C" int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* t
   if (s->p2p) GNPDE_HIP(hipMemcpy(w, s->p2p->ctl + kCtlPush, sizeof(w), hipMemcpyDeviceToHost));   // synchronises
   if (timed_out) *timed_out = static_cast<int32_t>(w[kCtlErr - kCtlPush]);
   if (epochs) *epochs = static_cast<int64_t>(w[0]);
+  return 0;
+}
+
+extern "C" int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* s, const gnpde_rhs_t* const* rhs_chunks,
+                                                        int32_t n_chunks, const int32_t* push_order,
+                                                        const int32_t* push_chunk_ptr) {
+  GNPDE_CHECK_ARG(s != nullptr && n_chunks >= 0, GNPDE_EINVAL, "sharded_solver_set_boundary_chunks: bad arguments");
+  drop_sharded_graph(s);
+  s->rhs_chunk.clear(); s->g_chunk.clear(); s->L_chunk.clear(); s->push_chunk_ptr.clear();
+  if (n_chunks == 0) return 0;                     // back to one boundary pass + one push per evaluation
+  GNPDE_CHECK_ARG(s->p2p != nullptr, GNPDE_ESTATE, "sharded_solver_set_boundary_chunks: P2P transport only");
+  GNPDE_CHECK_ARG(rhs_chunks && push_chunk_ptr && (push_order || s->n_send == 0), GNPDE_EINVAL,
+                  "sharded_solver_set_boundary_chunks: null argument");
+  GNPDE_CHECK_ARG(push_chunk_ptr[0] == 0 && push_chunk_ptr[n_chunks] == s->n_send, GNPDE_EINVAL,
+                  "sharded_solver_set_boundary_chunks: the chunks must tile the %d send slots", s->n_send);
+  int row = s->g_bnd.row_begin;
+  s->g_chunk.resize(n_chunks);                     // (sized first: the descriptors point into it)
+  for (int c = 0; c < n_chunks; ++c) {
+    GNPDE_CHECK_ARG(rhs_chunks[c] != nullptr && push_chunk_ptr[c] <= push_chunk_ptr[c + 1], GNPDE_EINVAL,
+                    "sharded_solver_set_boundary_chunks: bad chunk %d", c);
+    if (int rc = check_rhs(rhs_chunks[c])) return rc;
+    const gnpde_rhs_t& r = *rhs_chunks[c];
+    GNPDE_CHECK_ARG(r.kind == s->rhs_bnd.kind && r.d == s->d && r.ld == s->ld && r.graph->row_begin == row &&
+                    r.graph->n >= row && r.graph->n <= s->n_own, GNPDE_EINVAL,
+                    "sharded_solver_set_boundary_chunks: chunk %d must continue the boundary rows at row %d", c, row);
+    row = r.graph->n;
+    s->g_chunk[c] = *r.graph;
+    s->rhs_chunk.push_back(r);
+    s->rhs_chunk.back().graph = &s->g_chunk[c];
+    s->L_chunk.push_back(rhs_layout(s->rhs_chunk.back()));
+    GNPDE_CHECK_ARG(s->off_rhs + s->L_chunk.back().total <= s->ws_bytes, GNPDE_EWS,
+                    "sharded_solver_set_boundary_chunks: chunk %d needs %zu bytes of scratch, the workspace has %zu", c,
+                    s->L_chunk.back().total, s->ws_bytes - s->off_rhs);
+    s->push_chunk_ptr.push_back(push_chunk_ptr[c]);
+  }
+  s->push_chunk_ptr.push_back(push_chunk_ptr[n_chunks]);
+  GNPDE_CHECK_ARG(row == s->n_own, GNPDE_EINVAL, "sharded_solver_set_boundary_chunks: the chunks end at row %d of %d", row, s->n_own);
+  if (s->n_send > 0) {
+    std::vector<char> seen(static_cast<size_t>(s->n_send), 0);
+    for (int w = 0; w < s->n_send; ++w) {
+      GNPDE_CHECK_ARG(push_order[w] >= 0 && push_order[w] < s->n_send && !seen[push_order[w]], GNPDE_EINVAL,
+                      "sharded_solver_set_boundary_chunks: push_order is not a permutation of the send slots");
+      seen[push_order[w]] = 1;
+    }
+    GNPDE_HIP(hipMemcpy(s->d_order, push_order, static_cast<size_t>(s->n_send) * 4, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 

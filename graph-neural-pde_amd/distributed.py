@@ -230,6 +230,7 @@ class NativeBackend(object):
     self.has_source = False
     if kind == 'laplacian':
       ew = params['edge_weight'].to(self.dev, torch.float32)
+      self._edge_weight = ew
       self.w_csr = ops.edge_to_csr_mean(self.graph, ew)
       self.w_int = ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)])
       self.w_bnd = ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)])
@@ -253,6 +254,39 @@ class NativeBackend(object):
     self._desc = {}
     self._ws = None
     self._src, self._src_version = None, -1
+    self.chunk_sets = {}        # boundary rows in k row ranges (split_boundary): k -> [(row_begin, row_end, graph, eid, w_csr)]
+
+  def split_boundary(self, n_chunks):
+    """The boundary rows [n_interior, n_own) as up to n_chunks consecutive row ranges of about equal edge counts, each with
+    its own view of the local graph (same numbering, only its rows' edges): the passes of the chunked boundary evaluation
+    (NativeShardedSolver(boundary_chunks=...)).  Returns [(row_begin, row_end, graph, edge ids, w_csr)], kept per n_chunks."""
+    if int(n_chunks) in self.chunk_sets:
+      return self.chunk_sets[int(n_chunks)]
+    sh = self.shard
+    b0, b1 = int(sh.n_interior), int(sh.n_own)
+    rows = sh.edge_index[0]
+    k = max(1, min(int(n_chunks), b1 - b0))
+    bounds = [b0]
+    if b1 > b0:
+      deg = torch.bincount(rows[rows >= b0] - b0, minlength=b1 - b0).to(torch.float64)
+      cum = torch.cumsum(deg + 1e-3, 0)      # (+eps: rows without edges still advance, so no chunk is empty)
+      for c in range(1, k):
+        cut = b0 + int(torch.searchsorted(cum, cum[-1] * c / k).item()) + 1
+        bounds.append(min(max(cut, bounds[-1] + 1), b1 - (k - c)))
+    bounds.append(b1)
+    chunks = []
+    for c in range(len(bounds) - 1):
+      lo, hi = bounds[c], bounds[c + 1]
+      m = (rows >= lo) & (rows < hi)
+      g = CSRGraph(sh.edge_index[:, m], sh.n_local, device=self.dev)
+      g.set_row_range(lo, hi)
+      eid = torch.nonzero(m).flatten()
+      w = None
+      if self.kind == 'laplacian':
+        w = self.ops.edge_to_csr_mean(g, self._edge_weight[eid.to(self.dev)])
+      chunks.append((lo, hi, g, eid, w))
+    self.chunk_sets[int(n_chunks)] = chunks
+    return chunks
 
   def refresh(self, alpha, beta, params):
     """New values of the scalars / weights IN PLACE (captured graphs and descriptors keep their pointers): what changes
@@ -264,6 +298,10 @@ class NativeBackend(object):
       self.ops.edge_to_csr_mean(self.graph, ew, out=self.w_csr)
       self.ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)], out=self.w_int)
       self.ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)], out=self.w_bnd)
+      self._edge_weight = ew
+      for chunks in self.chunk_sets.values():
+        for (_, _, g, eid, w) in chunks:
+          self.ops.edge_to_csr_mean(g, ew[eid.to(self.dev)], out=w)
     else:
       self.wqk.copy_(torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32))
       self.bqk.copy_(torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32))
@@ -277,9 +315,14 @@ class NativeBackend(object):
       kw = dict(self._kw)
       kind = kw.pop('kind')
       sh = self.shard
-      graph = {None: self.graph, 'interior': self.g_int, 'boundary': self.g_bnd}[part]
+      # ('chunk', k, c): the c-th of the k row ranges of the boundary rows (split_boundary)
+      chunk, chunks = (part[2], self.chunk_sets[part[1]]) if isinstance(part, tuple) else (None, None)
+      graph = chunks[chunk][2] if chunk is not None else {None: self.graph, 'interior': self.g_int, 'boundary': self.g_bnd}[part]
       if kind == _lib.RHS_LAPLACIAN:
-        kw['w_csr'] = {None: self.w_csr, 'interior': self.w_int, 'boundary': self.w_bnd}[part]
+        kw['w_csr'] = chunks[chunk][4] if chunk is not None else {None: self.w_csr, 'interior': self.w_int, 'boundary': self.w_bnd}[part]
+      elif chunk is not None:
+        # the first chunk projects the halo rows that just arrived, the later ones nothing (an empty slice)
+        kw['proj_rows'] = (sh.n_own, sh.n_local) if chunk == 0 else (sh.n_local, sh.n_local)
       else:
         # interior pass: keys / queries of the own rows; boundary pass: keys of the halo rows that just arrived
         # (an empty slice when there is no halo)
@@ -560,7 +603,10 @@ class NativeShardedSolver(object):
   IPC-mapped halo regions by a kernel inside the graph; 'rccl': grouped ncclSend / ncclRecv, eager launches only."""
 
   def __init__(self, shard, backend, T, step_size=1.0, method='rk4', with_source=True, transport='p2p', ctx=None,
-               comm=None, group=None):
+               comm=None, group=None, boundary_chunks=None):
+    """boundary_chunks (P2P only; default GNPDE_BOUNDARY_CHUNKS or 1): k > 1 computes the boundary rows in k row ranges and
+    pushes each range's rows of the NEXT stage input to the peers right behind it, so that only the last range's push is
+    left to hide behind the next interior pass (same arithmetic in the same order: results are bit-identical to k = 1)."""
     import ctypes
     self.shard, self.be, self.transport = shard, backend, transport
     s = shard
@@ -580,7 +626,17 @@ class NativeShardedSolver(object):
     need = L.gnpde_sharded_solver_workspace_bytes(ctypes.byref(self.halo), self.d_int.ref(), self.d_bnd.ref(), self.method, int(p2p))
     if need == 0:
       raise _lib.GnpdeError('sharded solver: %s' % L.gnpde_last_error().decode(errors='replace'))
-    self.ws = torch.empty(int(need), dtype=torch.uint8, device=backend.dev)
+    if boundary_chunks is None:
+      boundary_chunks = int(os.environ.get('GNPDE_BOUNDARY_CHUNKS', '1'))
+    self.boundary_chunks = 1
+    self.d_chunks, self.chunks = [], []
+    slack = 0
+    if p2p and int(boundary_chunks) > 1 and s.world > 1 and s.n_own > s.n_interior:
+      self.chunks = backend.split_boundary(int(boundary_chunks))
+      self.d_chunks = [backend._descriptor(with_source, ('chunk', int(boundary_chunks), c)) for c in range(len(self.chunks))]
+      both = max(L.gnpde_rhs_workspace_bytes(self.d_int.ref()), L.gnpde_rhs_workspace_bytes(self.d_bnd.ref()))
+      slack = max(0, max(L.gnpde_rhs_workspace_bytes(dc.ref()) for dc in self.d_chunks) - both) + 256
+    self.ws = torch.empty(int(need) + slack, dtype=torch.uint8, device=backend.dev)
     arr = (ctypes.c_float * len(dts))(*dts)
     handle = ctypes.c_void_p()
     self.ctx = self.comm = None
@@ -603,8 +659,41 @@ class NativeShardedSolver(object):
     else:
       raise ValueError(transport)
     self.handle = handle
+    if len(self.d_chunks) > 1:
+      order, ptr = self._chunked_push_order(self.chunks)
+      refs = (ctypes.POINTER(_lib.RhsStruct) * len(self.d_chunks))(*[ctypes.pointer(dc.struct) for dc in self.d_chunks])
+      _lib.check(L.gnpde_sharded_solver_set_boundary_chunks(handle, refs, len(self.d_chunks),
+                                                           (ctypes.c_int32 * len(order))(*order), (ctypes.c_int32 * len(ptr))(*ptr)))
+      self.boundary_chunks = len(self.d_chunks)
     self.y = backend.empty(s.n_local)
     self.n_rhs_evals = L.gnpde_sharded_solver_num_rhs_evals(handle)
+
+  def _chunked_push_order(self, chunks):
+    """(order, chunk_ptr): the send slots grouped by the boundary chunk that computes their row (interior rows that peers
+    read -- directed graphs -- ride with the first chunk), and inside a chunk merged over the destinations in proportion to
+    what each is owed, like gnpde_push_order does for the whole list."""
+    s = self.shard
+    send_rows = s.send_idx.to(torch.int64).cpu()
+    counts = [int(v) for v in s.send_counts]
+    dest = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts, dtype=torch.int64))
+    uppers = torch.tensor([c[1] for c in chunks], dtype=torch.int64)
+    chunk_of = torch.searchsorted(uppers, send_rows, right=True).clamp_(max=len(chunks) - 1)
+    order, ptr = [], [0]
+    for c in range(len(chunks)):
+      slots = torch.nonzero(chunk_of == c).flatten()
+      if slots.numel():
+        dc = dest[slots]
+        per = torch.bincount(dc, minlength=len(counts)).to(torch.float64)
+        # position (j + 1/2) / count inside the destination's own run of this chunk; stable sort keeps each run's order
+        start = torch.zeros(len(counts), dtype=torch.int64)
+        start[1:] = torch.cumsum(per.to(torch.int64), 0)[:-1]
+        by_dest = torch.argsort(dc, stable=True)
+        j = torch.empty(slots.numel(), dtype=torch.float64)
+        j[by_dest] = (torch.arange(slots.numel()) - start[dc[by_dest]]).to(torch.float64)
+        key = (j + 0.5) / per[dc]
+        order += slots[torch.argsort(key, stable=True)].tolist()
+      ptr.append(len(order))
+    return order, ptr
 
   def integrate(self, y_own, x0_own=None, use_graph=True):
     """Owned rows of y(T) (a view of an internal buffer).  x0_own refreshes the persistent source term in place."""
@@ -1081,8 +1170,32 @@ def bench_main(args, rank, world, dev):
         torch.cuda.synchronize(dev)
         dist.barrier()
         warm.close()
-      solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', transport=chosen, ctx=ctx)
-      solver.integrate(x_own, x_own, use_graph=graph_mode)                    # untimed: captures the K-step graph
+      # P2P: how many row ranges the boundary pass is cut into (each range's rows of the next stage input are pushed right
+      # behind it; NativeShardedSolver) is chosen by the clock -- more ranges hide more of the exchange but add launches
+      cands = [1]
+      if chosen == 'p2p':
+        cands = [int(v) for v in os.environ.get('GNPDE_BOUNDARY_CHUNKS', os.environ.get('GNPDE_BENCH_CHUNKS', '1,2,4')).split(',') if v]
+      solver, solver_kc, chunk_ms = None, None, {}
+      for kc in cands:
+        cand_solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', transport=chosen, ctx=ctx, boundary_chunks=kc)
+        cand_solver.integrate(x_own, x_own, use_graph=graph_mode)             # untimed: captures the K-step graph
+        best = float('inf')
+        for _ in range(2 if len(cands) > 1 else 0):
+          torch.cuda.synchronize(dev)
+          dist.barrier()
+          t0 = time.perf_counter()
+          cand_solver.integrate(x_own, x_own, use_graph=graph_mode)
+          torch.cuda.synchronize(dev)
+          dist.barrier()
+          best = min(best, time.perf_counter() - t0)
+        tb = torch.tensor([best if best < float('inf') else 0.0], dtype=torch.float64, device=red)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        chunk_ms[kc] = round(float(tb.item()) * 1e3 / K, 4)
+        if solver is None or chunk_ms[kc] < chunk_ms[solver_kc]:    # (the same verdict on every rank: the times are the max over ranks)
+          close_quietly(solver)
+          solver, solver_kc = cand_solver, kc
+        else:
+          close_quietly(cand_solver)
       run = lambda T: solver.integrate(x_own, x_own, use_graph=graph_mode)   # noqa: E731
     times = []
     for _ in range(max(getattr(args, 'replays', 1), 1)):
@@ -1201,6 +1314,8 @@ def bench_main(args, rank, world, dev):
 
                  'finite': bool(finite.item() == 1.0), 'exchange_timed_out': timed_out, 'ranks_share_one_device': shared,
                  'transport': chosen, 'transports_rejected': notes,
+                 'boundary_chunks': None if python_loop else solver_kc,
+                 'boundary_chunks_ms_per_step': None if python_loop or len(chunk_ms) < 2 else {str(k): v for k, v in chunk_ms.items()},
                  'driver': 'python loop' if python_loop else 'native, hipGraph %s' % graph_mode,
                  'replays': len(times),
                  'sharded_vs_unpartitioned_one_eval_rel_max': float(err.item()),

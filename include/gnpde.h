@@ -641,6 +641,20 @@ int gnpde_sharded_solver_run(gnpde_sharded_solver_t* s, float* y, int32_t use_gr
  * permutation of [0, sum send_counts) that keeps each destination's rows in order.  What gnpde_sharded_solver_create_p2p uses;
  * exported for the host tests. */
 int gnpde_push_order(const int32_t* send_counts, int32_t world, int32_t* order);
+/* P2P transport: compute the boundary rows in n_chunks consecutive row ranges and push each range's rows of the stage OUTPUT --
+ * the next evaluation's input -- into the peers' halo regions right behind it, on the side stream, while the next range is
+ * computed; the last range's push raises the next evaluation's epoch.  The first evaluation of a solve still pushes its whole
+ * input, the last one pushes nothing.  What is left to hide behind the next interior pass is one range's push instead of the
+ * whole exchange.  rhs_chunks[c]: descriptor of range c (same kind / d / ld as the boundary descriptor; graph rows
+ * [row_begin, n) continue where range c-1 ended, the ranges tile [n_interior, n_own); for the transformer kind range 0
+ * projects the halo rows and the later ones an empty slice).  push_order: permutation of the send slots grouped by range --
+ * slots [push_chunk_ptr[c], push_chunk_ptr[c+1]) hold the rows range c computes (rows of the interior pass that peers read
+ * ride with range 0).  Same arithmetic in the same order as the unchunked solve: results are bit-identical.  n_chunks = 0
+ * restores the single boundary pass.  GNPDE_EWS when the workspace has no room for a range's scratch
+ * (gnpde_rhs_workspace_bytes of the range descriptors beyond the interior / boundary ones).  Drops a captured graph.
+ * No reference equivalent (the reference is single-device). */
+int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* s, const gnpde_rhs_t* const* rhs_chunks, int32_t n_chunks,
+                                             const int32_t* push_order, const int32_t* push_chunk_ptr);
 /* Exchange timing of the LAST run (P2P transport): for every evaluation four wall-clock stamps (s_memrealtime ticks, rate in
  * *ticks_per_second) written by the kernels themselves inside the hipGraph -- [0] the push kernel starts, [1] its last block has
  * published the epoch (all boundary rows stored into the peers' halo regions), [2] the main stream reaches the wait (interior

@@ -131,6 +131,40 @@ def test_push_order_interleaves_the_destinations():
     _lib.check(L.gnpde_push_order(bad.ctypes.data_as(_lib.c_int_p), 2, out.ctypes.data_as(_lib.c_int_p)))
 
 
+def test_chunked_push_order_groups_the_send_slots_by_the_row_range_that_computes_them():
+  """NativeShardedSolver._chunked_push_order (the walk of gnpde_sharded_solver_set_boundary_chunks): a permutation of the send
+  slots; slots [ptr[c], ptr[c+1]) hold exactly the rows of boundary range c (rows of the interior pass ride with range 0);
+  inside a range every destination keeps its own order and the destinations are interleaved in proportion."""
+  n, world = 3000, 4
+  ei = random_graph(n, 6, seed=5, hubs=1, hub_deg=300)
+  plan = D.PartitionPlan(ei, n, world)
+  for rank in range(world):
+    sh = plan.shard(rank)
+    solver = D.NativeShardedSolver.__new__(D.NativeShardedSolver)
+    solver.shard = sh
+    b0, b1 = sh.n_interior, sh.n_own
+    cuts = [b0, b0 + (b1 - b0) // 5, b0 + (b1 - b0) // 2, b1]
+    chunks = [(cuts[c], cuts[c + 1], None, None, None) for c in range(3)]
+    order, ptr = solver._chunked_push_order(chunks)
+    n_send = int(sum(sh.send_counts))
+    assert sorted(order) == list(range(n_send)) and ptr[0] == 0 and ptr[-1] == n_send and len(ptr) == 4
+    rows = sh.send_idx.to(torch.int64)
+    seg = torch.cumsum(torch.tensor([0] + [int(v) for v in sh.send_counts]), 0)
+    for c in range(3):
+      slots = torch.tensor(order[ptr[c]:ptr[c + 1]], dtype=torch.int64)
+      r = rows[slots]
+      lo = 0 if c == 0 else cuts[c]
+      assert bool(((r >= lo) & (r < cuts[c + 1])).all())
+      dest = torch.searchsorted(seg, slots, right=True) - 1
+      for p in range(world):
+        mine = slots[dest == p]
+        assert bool((mine[1:] > mine[:-1]).all())                      # a destination's rows keep their order
+        if mine.numel() and slots.numel():
+          taken = torch.cumsum((dest == p).to(torch.float64), 0)
+          share = (torch.arange(slots.numel()) + 1) * (mine.numel() / slots.numel())
+          assert float((taken - share).abs().max()) <= 1.0 + 1e-9
+
+
 def test_partition_plan_takes_the_candidate_with_the_cheapest_busiest_link():
   """PartitionPlan scores a few runs of the heuristic partitioner by what a partitioned evaluation waits for -- the busiest
   xGMI link (rows one rank receives from ONE peer) and the busiest rank -- and keeps the cheapest; the scoring function agrees
