@@ -125,6 +125,13 @@ def make_block(G, opt, ei, n, x, dev, T, seed):
   return block
 
 
+def solver_graph(f, x):
+  """The CSR the fused solves of `f` launch on: the locality view of its graph when the solver uses one (same operator, nodes
+  relabelled part by part), else the graph as given."""
+  view = f._locality_view(x) if hasattr(f, '_locality_view') else None
+  return (view.graph if view is not None else f._graph(x)), view
+
+
 def dominant_kernel_time(G, block, x, reps=10):
   """Average duration of one launch of the dominant kernel over the 4 rk4 stage epilogues the solver runs,
   HIP events on the launch stream (torch's current stream, which is the stream the C ABI is handed).
@@ -132,7 +139,7 @@ def dominant_kernel_time(G, block, x, reps=10):
   import ctypes
   from gnpde_amd import ops, _lib
   f = block.odefunc
-  graph = f._graph(x)
+  graph, _ = solver_graph(f, x)
   dev = x.device
   bufs = [torch.randn_like(x) for _ in range(7)]
   y, k1, k2, k3, ua, ub, x0 = bufs
@@ -249,7 +256,7 @@ def secondary_kernels(G, block, x, E, n, ceiling):
   if not hasattr(f, 'multihead_att_layer'):
     return []
   lay = f.multihead_att_layer
-  graph = f._graph(x)
+  graph, _ = solver_graph(f, x)
   wqk, bqk = lay.qk_weights()
   A, h = lay.attention_dim, lay.h
   d = x.shape[1]
@@ -498,6 +505,26 @@ def main():
     src['stale'] = bool(traffic.get('source_sha16') is None or now is None or traffic.get('source_sha16') != now)
     src['spmm_hip_sha16_now'] = now
     out['roofline']['traffic_source'] = src
+  _, view = solver_graph(f, x)
+  if view is not None and early is None:
+    # the timed solve ran on the relabelled graph: the same K steps on the graph as given, outside the timed region, must agree
+    # bit for bit (the entries of a row keep their order, so every row sum is the same sum)
+    out['config']['node_relabelling'] = dict(view.stats, what='graph.LocalityView: nodes relabelled part by part (native label-propagation '
+                                             'partitioner), one-time graph preparation; the state is permuted on entry / exit of the solve, '
+                                             'inside the timed region')
+    try:
+      with torch.no_grad():
+        f.opt['gnpde_reorder'] = '0'
+        z_plain = main_block(x)
+        torch.cuda.synchronize()
+      out['config']['node_relabelling']['solve_equal_to_unrelabelled_bitwise'] = bool(torch.equal(z, z_plain))
+      del z_plain
+    except Exception as exc:   # noqa: BLE001
+      out['config']['node_relabelling']['check_error'] = repr(exc)[:200]
+    finally:
+      f.opt.pop('gnpde_reorder', None)
+  else:
+    out['config']['node_relabelling'] = None
   if early is not None:
     sol = early.solver
     out['early_stop'] = {'best_val': sol.best_val, 'best_test': sol.best_test, 'best_time': sol.best_time,

@@ -68,7 +68,7 @@ class _LaplacianRhs(torch.autograd.Function):
     # keyed on the graph OBJECT (held by the snapshot, compared with `is`) and the monotonically increasing generation
     # of the weight buffer's contents -- never on id(): the id of an attention tensor freed by an eval forward is
     # reused by the next training forward's tensor, which would make a stale snapshot compare equal
-    gen = func._cache['w_csr']['gen']
+    gen = next(e['gen'] for e in func._cache['w_csr'] if e['graph'] is graph)
     if snap is None or snap[0] is not graph or snap[3] != gen:
       snap = (graph, w_csr.clone(), {}, gen)
       func._cache['w_snapshot'] = snap

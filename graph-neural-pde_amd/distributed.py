@@ -1177,9 +1177,19 @@ def bench_main(args, rank, world, dev):
         cands = [int(v) for v in os.environ.get('GNPDE_BOUNDARY_CHUNKS', os.environ.get('GNPDE_BENCH_CHUNKS', '1,2,4')).split(',') if v]
       solver, solver_kc, chunk_ms = None, None, {}
       for kc in cands:
-        cand_solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', transport=chosen, ctx=ctx, boundary_chunks=kc)
-        cand_solver.integrate(x_own, x_own, use_graph=graph_mode)             # untimed: captures the K-step graph
-        best = float('inf')
+        cand_solver, best, why = None, float('inf'), None
+        try:
+          cand_solver = NativeShardedSolver(shard, be, float(K), 1.0, 'rk4', transport=chosen, ctx=ctx, boundary_chunks=kc)
+          cand_solver.integrate(x_own, x_own, use_graph=graph_mode)           # untimed: captures the K-step graph
+          torch.cuda.synchronize(dev)
+          if cand_solver.status()[0]:
+            why = 'a peer never published its boundary rows'
+        except Exception as exc:   # noqa: BLE001 -- a range count that cannot be set up is skipped, like a transport
+          why = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+        if not agree(why is None):
+          notes['boundary_chunks=%d' % kc] = why or 'failed on another rank'
+          close_quietly(cand_solver)
+          continue
         for _ in range(2 if len(cands) > 1 else 0):
           torch.cuda.synchronize(dev)
           dist.barrier()
@@ -1196,6 +1206,8 @@ def bench_main(args, rank, world, dev):
           solver, solver_kc = cand_solver, kc
         else:
           close_quietly(cand_solver)
+      if solver is None:
+        raise _lib.GnpdeError('no boundary range count of %r could be set up: %r' % (cands, notes))
       run = lambda T: solver.integrate(x_own, x_own, use_graph=graph_mode)   # noqa: E731
     times = []
     for _ in range(max(getattr(args, 'replays', 1), 1)):

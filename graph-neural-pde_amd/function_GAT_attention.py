@@ -123,10 +123,10 @@ class ODEFuncAtt(ODEFunc):
         f = f + self.beta_train * self.x0
     return f
 
-  def _descriptor(self, x, x0_override=None):
+  def _descriptor(self, x, x0_override=None, graph=None):
     if self.opt['mix_features']:
       raise NotImplementedError('mix_features has no fused descriptor')
-    graph = self._graph(x)
+    graph = self._graph(x) if graph is None else graph
     layer = self.multihead_att_layer
     x0 = x0_override if x0_override is not None else self._source(x)
     alpha = ops._scalar_dev(self.alpha_train, x)

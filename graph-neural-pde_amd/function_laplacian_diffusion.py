@@ -35,11 +35,13 @@ class LaplacianODEFunc(ODEFunc):
 
   def _weights_csr(self, graph):
     src = self._edge_values()
-    ent = self._cache.get('w_csr')
-    if ent is None or ent['graph'] is not graph:
+    # one buffer per graph OBJECT, the two newest kept (the solver may run on the locality view of the graph direct calls use)
+    ents = self._cache.setdefault('w_csr', [])
+    ent = next((e for e in ents if e['graph'] is graph), None)
+    if ent is None:
       ent = {'graph': graph, 'buf': torch.empty(max(graph.e, 1), dtype=torch.float32, device=graph.device),
              'sig': None, 'src': None, 'gen': 0}
-      self._cache['w_csr'] = ent
+      ents[:] = ents[-1:] + [ent]
     sig = (id(src), src._version)
     if ent['sig'] != sig:
       ops.edge_to_csr_mean(graph, src, out=ent['buf'])  # in place: captured graphs keep the pointer
@@ -55,8 +57,8 @@ class LaplacianODEFunc(ODEFunc):
     with torch.no_grad():
       return ops.spmm(graph, self._weights_csr(graph), _lib.f32c(x))
 
-  def _descriptor(self, x, x0_override=None):
-    graph = self._graph(x)
+  def _descriptor(self, x, x0_override=None, graph=None):
+    graph = self._graph(x) if graph is None else graph
     x0 = x0_override if x0_override is not None else self._source(x)
     alpha = ops._scalar_dev(self.alpha_train, x)
     beta = ops._scalar_dev(self.beta_train, x) if x0 is not None else None

@@ -132,12 +132,15 @@ class SpGraphTransAttentionLayer(nn.Module):
     if not (self.opt['reweight_attention'] and self.edge_weights is not None):
       return None
     ew = self.edge_weights
-    ent = self._bufs.get('rw')
-    # the entry holds graph and weight tensor themselves (compared with `is`): ids of freed objects get reused
-    if ent is None or ent[0] is not graph or ent[2] is not ew or ent[3] != ew._version:
-      ent = (graph, ops.edge_to_csr_mean(graph, ew.to(graph.device)), ew, ew._version)
-      self._bufs['rw'] = ent
-    return ent[1]
+    # one entry per graph OBJECT (the solver may run on the locality view of the graph the direct calls use; the two newest
+    # graphs are kept).  The entry holds graph and weight tensor themselves (compared with `is`): ids of freed objects get reused
+    ents = self._bufs.setdefault('rw', [])
+    for ent in ents:
+      if ent[0] is graph and ent[2] is ew and ent[3] == ew._version:
+        return ent[1]
+    ents[:] = [e for e in ents if e[0] is not graph][-1:]
+    ents.append((graph, ops.edge_to_csr_mean(graph, ew.to(graph.device)), ew, ew._version))
+    return ents[-1][1]
 
   def attention_struct(self, graph, q=None, k=None, ldqk=0):
     dev = graph.device
@@ -208,10 +211,10 @@ class ODEFuncTransformerAtt(ODEFunc):
     with torch.no_grad():
       return ops.spmm(graph, ops.edge_to_csr_mean(graph, attention), _lib.f32c(x))
 
-  def _descriptor(self, x, x0_override=None):
+  def _descriptor(self, x, x0_override=None, graph=None):
     if self.opt['mix_features']:
       raise NotImplementedError('mix_features is not runnable in the reference ODEFuncTransformerAtt either')
-    graph = self._graph(x)
+    graph = self._graph(x) if graph is None else graph
     layer = self.multihead_att_layer
     x0 = x0_override if x0_override is not None else self._source(x)
     alpha = ops._scalar_dev(self.alpha_train, x)

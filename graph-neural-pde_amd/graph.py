@@ -10,6 +10,9 @@ from . import _lib
 
 
 LONG_ROW = 512     # GNPDE_LONG_ROW
+L2_BYTES_TOTAL = 32 << 20          # 8 XCDs x 4 MiB
+LOCALITY_PART_BYTES = 5.5 * 2 ** 20   # table bytes per part of the locality relabelling (two parts per XCD at the ogbn-arxiv size)
+LOCALITY_MIN_GAIN = 1.02           # auto mode: keep the relabelled graph when a timed aggregation on it is at least this much faster
 XCD_IMBALANCE_LIMIT = 1.03   # contiguous eighths are kept while the slowest XCD has at most 3 % more than the mean
 
 
@@ -116,6 +119,7 @@ class CSRGraph(object):
     self.e = int(edge_index.size(1))
     self._ws = {}
     self._transposed = None
+    self._locality = {}
     if edge_index.is_cuda and edge_index.device == device:
       self._init_on_device(edge_index.detach())
       return
@@ -217,6 +221,58 @@ class CSRGraph(object):
       self._transposed = CSRGraph(self._edge_index.flip(0), self.n, self.device)
     return self._transposed
 
+  def locality_view(self, row_bytes, mode='auto'):
+    """LocalityView of this graph (nodes relabelled so that the rows the XCDs work on at the same time reference each other),
+    or None when it does not apply / does not pay.  row_bytes: bytes of one row of the table the aggregation gathers from.
+    mode '0': never.  '1': whenever the graph is whole.  'auto': only when the table does not fit the L2s, and then BY THE
+    CLOCK -- the clustering (host, native partitioner) and the relabelled CSR are built once per graph, a plain aggregation of
+    this width is timed on both, and the view is kept if it is at least LOCALITY_MIN_GAIN faster (a graph without communities,
+    R-MAT for one, gains nothing and keeps its ids)."""
+    mode = str(mode).lower()
+    if mode in ('0', 'false', 'off', 'none') or self.struct.row_begin != 0 or self.n != self.t['rowptr'].numel() - 1 or self.e == 0:
+      return None
+    force = mode in ('1', 'true', 'on', 'force')
+    table = float(self.n) * float(row_bytes)
+    if not force and (table <= L2_BYTES_TOTAL or self.n < 4096 or self.device.type != 'cuda'):
+      return None
+    n_parts = 8 * int(max(1, min(8, round(table / (8 * LOCALITY_PART_BYTES)))))
+    ent = self._locality.get(n_parts)
+    if ent is None:
+      ent = self._locality[n_parts] = {'view': None, 'gain': {}}
+      import time
+      t0 = time.perf_counter()
+      rowptr, colidx = self.t['rowptr'].cpu(), self.t['colidx'][:self.e].cpu()
+      part = partition_rows((rowptr, colidx), n_parts, refine_links=0)
+      rows = torch.repeat_interleave(torch.arange(self.n), (rowptr[1:] - rowptr[:-1]).long())
+      inside = float((part[rows] == part[colidx.long()]).double().mean())
+      order = torch.sort(part.long(), stable=True).indices     # new position -> old id; the old order is kept inside a part
+      ent['view'] = LocalityView(self, order, {'n_parts': n_parts, 'entries_inside_a_part': round(inside, 4),
+                                               'clustering_seconds': round(time.perf_counter() - t0, 3)})
+    view = ent['view']
+    if force:
+      return view
+    d = max(int(row_bytes) // 4, 1)
+    if d not in ent['gain']:
+      ent['gain'][d] = self._aggregation_time(d) / max(view.graph._aggregation_time(d), 1e-9)
+      view.stats['aggregation_speedup_measured'] = {str(k): round(v, 4) for k, v in ent['gain'].items()}
+    return view if ent['gain'][d] >= LOCALITY_MIN_GAIN else None
+
+  def _aggregation_time(self, d, reps=5):
+    """Seconds per plain aggregation A u of width d on this graph (HIP events, random operands)."""
+    from . import ops
+    u = torch.randn(self.n, d, device=self.device)
+    out = torch.empty_like(u)
+    w = torch.rand(max(self.e, 1), device=self.device)
+    for _ in range(2):
+      ops.spmm(self, w, u, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+      ops.spmm(self, w, u, out=out)
+    e1.record()
+    torch.cuda.synchronize(self.device)
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
   def workspace(self, tag, nbytes):
     """Persistent scratch keyed by use (stable addresses keep captured hipGraphs valid)."""
     nbytes = max(int(nbytes), 256)
@@ -225,6 +281,49 @@ class CSRGraph(object):
       buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
       self._ws[tag] = buf
     return buf
+
+
+class LocalityView(object):
+  """The same operator with the nodes relabelled part by part (parts of the native label-propagation partitioner, balanced on
+  entries, `n_parts` a multiple of the 8 XCDs): the contiguous eighth of the rows an XCD works through is then a few whole
+  parts, and the neighbours its rows gather are mostly rows of the same part -- lines its own L2 already holds -- instead of a
+  uniform sample of the table.  Measured at the ogbn-arxiv stand-in (40 shuffled communities, 65 % of the edges inside one):
+  aggregation 171 -> 157 us per launch with 16 parts, as much as relabelling by the generator's own communities gives
+  (profiles/r03_reorder_probe.txt).
+
+  graph: CSRGraph over the relabelled edge list IN THE CALLER'S EDGE ORDER, so `perm`, every per-edge array and -- because the
+  entries of a row keep their order -- every row sum are the same as on the original graph: results are bit-identical up to the
+  row permutation.  order[i] = original id of the node at position i; inv[v] = position of original node v.  A state x in the
+  original order enters as x[order] and leaves as y[inv].  No reference equivalent (torch_sparse.spmm takes the ids as
+  given, reference src/function_transformer_attention.py:35)."""
+
+  def __init__(self, base, order, stats):
+    dev = base.device
+    order = order.to(torch.int64)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), dtype=torch.int64)
+    self.order, self.inv = order.to(dev), inv.to(dev)
+    # (the relabelled CSR picks its rows -> XCDs deal like any graph: parts differ in density, so contiguous eighths by row
+    #  count are usually out of balance and the hashed blocks take over -- all eight XCDs then work through the same part at the
+    #  same time.  Work-balanced contiguous ranges, one part per XCD at a time, measured SLOWER: 172.6 vs 157.2 us,
+    #  profiles/r03_reorder_probe.txt -- the parts differ in how well they cache, and a launch lasts as long as its slowest XCD)
+    self.graph = CSRGraph(self.inv[base._edge_index.to(dev)], base.n, device=dev)
+    self.stats = dict(stats, xcd_imbalance_contiguous=round(float(self.graph.xcd_imbalance_contiguous), 4),
+                      xcd_deal='hashed_blocks' if self.graph.struct.xcd_deal == _lib.XCD_HASHED else 'contiguous_eighths')
+
+  def enter(self, x, out=None):
+    """x[order] (rows in the relabelled order)."""
+    if out is None:
+      return x.index_select(0, self.order)
+    out.copy_(x.index_select(0, self.order))
+    return out
+
+  def leave(self, y, out=None):
+    """y[inv] (rows back in the caller's order)."""
+    if out is None:
+      return y.index_select(0, self.inv)
+    out.copy_(y.index_select(0, self.inv))
+    return out
 
 
 class _GraphCache(object):

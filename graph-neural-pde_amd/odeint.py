@@ -44,14 +44,17 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
     from .utils import MaxNFEException
     raise MaxNFEException
   st = func.__dict__.setdefault('_solver_state', {})
-  key = (method, tuple(dts), tuple(y0.shape), str(y0.device))
+  # relabelled graph (graph.LocalityView): the state enters as y0[order] and leaves as y[inv]; not with the in-graph
+  # early-stopping evaluator, whose node masks address the caller's numbering
+  view = func._locality_view(y0) if evaluator is None and hasattr(func, '_locality_view') else None
+  key = (method, tuple(dts), tuple(y0.shape), str(y0.device), id(view))
   ent = st.get(key)
   y0c = y0.detach()
   if ent is None:
     # (rows padded to a multiple of 4 floats when the width is not one: 16-byte lanes for d = 162 etc.)
     ent = {'y': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device),
            'x0': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device) if func.opt['add_source'] else None,
-           'solver': None, 'sig': None}
+           'solver': None, 'sig': None, 'view': view}
     for old in st.values():     # one live solver per function object: its buffers are state-sized
       if old.get('solver') is not None:
         old['solver'].close()
@@ -63,12 +66,18 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
           old['solver'].close()
       dd.clear()
     st[key] = ent
-  ent['y'].copy_(y0c)
+  if view is None:
+    ent['y'].copy_(y0c)
+  else:
+    view.enter(y0c, out=ent['y'])
   if ent['x0'] is not None:
     if func.x0 is None:
       raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
-    ent['x0'].copy_(func.x0)
-  desc = func._descriptor(ent['y'], x0_override=ent['x0'])
+    if view is None:
+      ent['x0'].copy_(func.x0)
+    else:
+      view.enter(func.x0.detach(), out=ent['x0'])
+  desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=None if view is None else view.graph)
   sig = func._descriptor_signature(desc)
   if ent['solver'] is None or ent['sig'] != sig:
     if ent['solver'] is not None:
@@ -81,7 +90,10 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
   func.nfe += n_evals
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
   out[0].copy_(y0c)
-  out[1].copy_(ent['y'])
+  if view is None:
+    out[1].copy_(ent['y'])
+  else:
+    view.leave(ent['y'], out=out[1])
   return out
 
 

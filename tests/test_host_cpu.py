@@ -608,3 +608,32 @@ def test_partition_link_refinement_handles_directed_graphs_and_loops():
   m = D.pair_traffic(ei, part, 4)
   assert st['max_link_after'] == int(m.max()) and st['received_rows_after'] == int(m.sum())
   assert int(torch.diagonal(m).sum()) == 0
+
+
+def test_locality_view_relabels_without_touching_the_order_inside_a_row():
+  """graph.LocalityView (host parts of it: clustering, relabelled CSR): `order` is a permutation laid out part by part, the
+  relabelled CSR holds the caller's edges in the caller's order inside every row (same `perm` semantics, so per-edge arrays
+  and row sums carry over unchanged), and enter / leave are inverse permutations of the rows."""
+  from gnpde_amd import synthetic
+  n = 5000
+  ei_np, _, _ = synthetic.community_powerlaw_graph(n, 30000, seed=2, n_comm=10)
+  ei = torch.as_tensor(ei_np)
+  base = G.CSRGraph(ei, n, device='cpu')
+  assert base.locality_view(4 * 128) is None                 # automatic rule: small table (and no device to time on)
+  view = base.locality_view(4 * 128, '1')
+  assert view is base.locality_view(4 * 128, '1') and view.stats['n_parts'] == 8
+  order, inv = view.order, view.inv
+  assert torch.equal(torch.sort(order).values, torch.arange(n)) and torch.equal(inv[order], torch.arange(n))
+  g = view.graph
+  assert g.e == base.e and g.n == n
+  rp_b, rp_v = base.rowptr.long(), g.rowptr.long()
+  perm_b, perm_v = base.perm.long(), g.perm.long()
+  col_b, col_v = base.colidx.long(), g.colidx.long()
+  for i in range(0, n, 37):
+    v = int(order[i])
+    assert torch.equal(perm_v[rp_v[i]:rp_v[i + 1]], perm_b[rp_b[v]:rp_b[v + 1]])           # same edges, same order
+    assert torch.equal(order[col_v[rp_v[i]:rp_v[i + 1]]], col_b[rp_b[v]:rp_b[v + 1]])       # pointing at the same nodes
+  x = torch.randn(n, 7)
+  assert torch.equal(view.leave(view.enter(x)), x) and torch.equal(view.enter(x)[inv], x)
+  inside = view.stats['entries_inside_a_part']
+  assert 0.3 < inside <= 1.0                                   # ten planted communities, 65 % of the edges inside one
