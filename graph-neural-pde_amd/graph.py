@@ -222,40 +222,79 @@ class CSRGraph(object):
     return self._transposed
 
   def locality_view(self, row_bytes, mode='auto'):
-    """LocalityView of this graph (nodes relabelled so that the rows the XCDs work on at the same time reference each other),
-    or None when it does not apply / does not pay.  row_bytes: bytes of one row of the table the aggregation gathers from.
-    mode '0': never.  '1': whenever the graph is whole.  'auto': only when the table does not fit the L2s, and then BY THE
-    CLOCK -- the clustering (host, native partitioner) and the relabelled CSR are built once per graph, a plain aggregation of
-    this width is timed on both, and the view is kept if it is at least LOCALITY_MIN_GAIN faster (a graph without communities,
-    R-MAT for one, gains nothing and keeps its ids)."""
+    """LocalityView of this graph (the same operator with its nodes relabelled), or None when it does not apply / does not
+    pay.  row_bytes: bytes of one row of the table the aggregation gathers from.  Two orders are candidates:
+      'parts'  -- part by part (native label-propagation partitioner, parts of about LOCALITY_PART_BYTES of table): the rows
+                  the XCDs work on at the same time reference each other, so their neighbours are lines the L2s already
+                  hold.  Pays on graphs with communities (ogbn-arxiv stand-in: aggregation 171 -> 156 us).
+      'degree' -- rows by descending length: the most-referenced rows of a power-law graph end up next to each other, and ids
+                  whose BITS carry the degree (R-MAT: node 2^k is a hub for every k, so the hot rows sit at power-of-two
+                  strides and land on the same memory channels) lose that structure -- R-MAT 2^21, d = 256: 14.7 -> 9.4 ms,
+                  a random permutation alone gives 10.3 (profiles/r03_reorder_probe_rmat.txt).
+    mode '0': never.  'parts' / 'degree': that order.  '1': the faster of the two by the clock ('parts' without a device).
+    'auto' (default): only when the table does not fit the L2s, and then BY THE CLOCK -- a plain aggregation of this width is
+    timed on the graph as given and on both candidates, once per graph and width, and the fastest candidate is kept if it is at
+    least LOCALITY_MIN_GAIN faster than the graph as given."""
     mode = str(mode).lower()
     if mode in ('0', 'false', 'off', 'none') or self.struct.row_begin != 0 or self.n != self.t['rowptr'].numel() - 1 or self.e == 0:
       return None
+    if mode in ('parts', 'degree'):
+      return self._locality_candidate(mode, row_bytes)
     force = mode in ('1', 'true', 'on', 'force')
     table = float(self.n) * float(row_bytes)
-    if not force and (table <= L2_BYTES_TOTAL or self.n < 4096 or self.device.type != 'cuda'):
+    if self.device.type != 'cuda':
+      return self._locality_candidate('parts', row_bytes) if force else None
+    if not force and (table <= L2_BYTES_TOTAL or self.n < 4096):
       return None
-    n_parts = 8 * int(max(1, min(8, round(table / (8 * LOCALITY_PART_BYTES)))))
-    ent = self._locality.get(n_parts)
-    if ent is None:
-      ent = self._locality[n_parts] = {'view': None, 'gain': {}}
+    d = max(int(row_bytes) // 4, 1)
+    dec = self._locality.setdefault('decision', {})
+    if d not in dec:
+      t_base = self._aggregation_time(d)
+      gains = {}
+      for kind in ('parts', 'degree'):
+        view = self._locality_candidate(kind, row_bytes)
+        gains[kind] = t_base / max(view.graph._aggregation_time(d), 1e-9)
+      best = max(gains, key=lambda k: gains[k])
+      for kind in gains:                                   # the loser's CSR is state-sized at R-MAT scale: drop it
+        if kind != best:
+          self._locality['views'].pop(self._locality_key(kind, row_bytes), None)
+      dec[d] = (best, gains)
+      self._locality_candidate(best, row_bytes).stats.setdefault('aggregation_speedup_measured', {})[str(d)] = \
+          {k: round(v, 4) for k, v in gains.items()}
+    best, gains = dec[d]
+    if not force and gains[best] < LOCALITY_MIN_GAIN:
+      return None
+    return self._locality_candidate(best, row_bytes)
+
+  def _locality_key(self, kind, row_bytes):
+    if kind == 'degree':
+      return ('degree',)
+    table = float(self.n) * float(row_bytes)
+    return ('parts', 8 * int(max(1, min(8, round(table / (8 * LOCALITY_PART_BYTES))))))
+
+  def _locality_candidate(self, kind, row_bytes):
+    views = self._locality.setdefault('views', {})
+    key = self._locality_key(kind, row_bytes)
+    view = views.get(key)
+    if view is None:
       import time
       t0 = time.perf_counter()
-      rowptr, colidx = self.t['rowptr'].cpu(), self.t['colidx'][:self.e].cpu()
-      part = partition_rows((rowptr, colidx), n_parts, refine_links=0)
-      rows = torch.repeat_interleave(torch.arange(self.n), (rowptr[1:] - rowptr[:-1]).long())
-      inside = float((part[rows] == part[colidx.long()]).double().mean())
-      order = torch.sort(part.long(), stable=True).indices     # new position -> old id; the old order is kept inside a part
-      ent['view'] = LocalityView(self, order, {'n_parts': n_parts, 'entries_inside_a_part': round(inside, 4),
-                                               'clustering_seconds': round(time.perf_counter() - t0, 3)})
-    view = ent['view']
-    if force:
-      return view
-    d = max(int(row_bytes) // 4, 1)
-    if d not in ent['gain']:
-      ent['gain'][d] = self._aggregation_time(d) / max(view.graph._aggregation_time(d), 1e-9)
-      view.stats['aggregation_speedup_measured'] = {str(k): round(v, 4) for k, v in ent['gain'].items()}
-    return view if ent['gain'][d] >= LOCALITY_MIN_GAIN else None
+      rowptr = self.t['rowptr'].cpu()
+      lens = (rowptr[1:] - rowptr[:-1]).long()
+      if kind == 'degree':
+        order = torch.sort(lens, descending=True, stable=True).indices
+        stats = {'order': 'rows by descending length'}
+      else:
+        n_parts = key[1]
+        colidx = self.t['colidx'][:self.e].cpu()
+        part = partition_rows((rowptr, colidx), n_parts, refine_links=0)
+        rows = torch.repeat_interleave(torch.arange(self.n), lens)
+        inside = float((part[rows] == part[colidx.long()]).double().mean())
+        order = torch.sort(part.long(), stable=True).indices     # new position -> old id; the old order is kept inside a part
+        stats = {'order': 'part by part', 'n_parts': n_parts, 'entries_inside_a_part': round(inside, 4)}
+      view = views[key] = LocalityView(self, order, stats)
+      view.stats['preparation_seconds'] = round(time.perf_counter() - t0, 3)
+    return view
 
   def _aggregation_time(self, d, reps=5):
     """Seconds per plain aggregation A u of width d on this graph (HIP events, random operands)."""
@@ -284,11 +323,9 @@ class CSRGraph(object):
 
 
 class LocalityView(object):
-  """The same operator with the nodes relabelled part by part (parts of the native label-propagation partitioner, balanced on
-  entries, `n_parts` a multiple of the 8 XCDs): the contiguous eighth of the rows an XCD works through is then a few whole
-  parts, and the neighbours its rows gather are mostly rows of the same part -- lines its own L2 already holds -- instead of a
-  uniform sample of the table.  Measured at the ogbn-arxiv stand-in (40 shuffled communities, 65 % of the edges inside one):
-  aggregation 171 -> 157 us per launch with 16 parts, as much as relabelling by the generator's own communities gives
+  """The same operator with its nodes relabelled in a given order (CSRGraph.locality_view chooses it: part by part, or by
+  descending row length).  Part by part at the ogbn-arxiv stand-in (40 shuffled communities, 65 % of the edges inside one):
+  aggregation 171 -> 156 us per launch with 16 parts, as much as relabelling by the generator's own communities gives
   (profiles/r03_reorder_probe.txt).
 
   graph: CSRGraph over the relabelled edge list IN THE CALLER'S EDGE ORDER, so `perm`, every per-edge array and -- because the

@@ -460,9 +460,10 @@ def test_padded_rows_for_widths_not_multiple_of_four(dev, function, d, method):
 @pytest.mark.parametrize('function,method,d', [('transformer', 'rk4', 128), ('laplacian', 'euler', 64), ('GAT', 'rk4', 64),
                                                ('transformer', 'rk4', 90)])
 def test_solve_on_the_relabelled_graph_is_bit_identical(dev, function, method, d):
-  """graph.LocalityView: the fixed-step solve on the graph relabelled part by part (opt['gnpde_reorder'] = '1': forced, the
-  test graph is far too small for the automatic rule) returns bit for bit what the solve on the graph as given returns --
-  the entries of a row keep their order, so every row sum is the same sum -- and that is the oracle's solve to 1e-5."""
+  """graph.LocalityView: the fixed-step solve on the graph relabelled part by part or by descending row length
+  (opt['gnpde_reorder'] = 'parts' / 'degree': forced, the test graph is far too small for the automatic rule) returns bit for
+  bit what the solve on the graph as given returns -- the entries of a row keep their order, so every row sum is the same sum
+  -- and that is the oracle's solve to 1e-5."""
   from gnpde_amd import synthetic
   n = 6000
   ei_np, _, _ = synthetic.community_powerlaw_graph(n, 40000, seed=4, n_comm=12)
@@ -472,7 +473,7 @@ def test_solve_on_the_relabelled_graph_is_bit_identical(dev, function, method, d
   opt = dict(BASE, function=function, method=method, hidden_dim=d, time=3.0)
   block = _block(opt, ei, n, x, dev)          # ONE block (same parameters), the switch flipped between the solves
   block.set_x0(x)
-  for mode in ('0', '1'):
+  for mode in ('0', 'parts', 'degree'):
     block.odefunc.opt['gnpde_reorder'] = mode
     with torch.no_grad():
       z1 = block(x).clone()
@@ -481,7 +482,8 @@ def test_solve_on_the_relabelled_graph_is_bit_identical(dev, function, method, d
     view = block.odefunc._locality_view(x)
     assert (view is None) == (mode == '0')
     if view is not None:
-      assert view.stats['n_parts'] == 8 and torch.equal(torch.sort(view.order).values, torch.arange(n, device=dev))
+      assert view.stats['order'] == {'parts': 'part by part', 'degree': 'rows by descending length'}[mode]
+      assert torch.equal(torch.sort(view.order).values, torch.arange(n, device=dev))
       # the relabelled CSR lists the caller's edges in the caller's order inside every row
       base = block.odefunc._graph(x)
       rp_b, rp_v = base.rowptr.long().cpu(), view.graph.rowptr.long().cpu()
@@ -490,16 +492,17 @@ def test_solve_on_the_relabelled_graph_is_bit_identical(dev, function, method, d
         v = int(order[i])
         assert torch.equal(perm_v[rp_v[i]:rp_v[i + 1]], perm_b[rp_b[v]:rp_b[v + 1]])
     res[mode] = z1
-    if mode == '1' and function == 'transformer' and d == 128:
+    if mode == 'parts' and function == 'transformer' and d == 128:
       ref = R.odeint_fixed(_oracle_rhs(block, x.cpu()), x.cpu(), 3.0, 1.0, method)
       assert_parity(z1, ref, what='solve on the relabelled graph vs oracle')
-  assert torch.equal(res['0'], res['1']), float((res['0'] - res['1']).abs().max())
+  for mode in ('parts', 'degree'):
+    assert torch.equal(res['0'], res[mode]), (mode, float((res['0'] - res[mode]).abs().max()))
 
 
 def test_relabelling_is_automatic_only_where_it_can_pay(dev):
   """'auto': never for a state that fits the L2s (Cora, the test graphs); for a larger one the clock decides -- a plain
-  aggregation is timed on the graph as given and on the relabelled one, once per graph and width, and the relabelled graph is
-  kept when it is at least 2 % faster."""
+  aggregation is timed on the graph as given and on both candidate orders, once per graph and width, and the faster candidate
+  is kept when it is at least 2 % faster than the graph as given."""
   from gnpde_amd import synthetic
   from gnpde_amd.graph import LOCALITY_MIN_GAIN
   small = G.CSRGraph(random_graph(3000, 6, seed=1).to(dev), 3000)
@@ -507,13 +510,16 @@ def test_relabelling_is_automatic_only_where_it_can_pay(dev):
   n = 120000
   ei_np, _, _ = synthetic.community_powerlaw_graph(n, 800000, seed=3)
   comm = G.CSRGraph(torch.as_tensor(ei_np).to(dev), n)
-  forced = comm.locality_view(4 * 128, '1')
-  assert forced is not None and forced.stats['n_parts'] == 8 and forced.stats['entries_inside_a_part'] > 0.3
+  parts = comm.locality_view(4 * 128, 'parts')
+  assert parts.stats['n_parts'] == 8 and parts.stats['entries_inside_a_part'] > 0.3
   view = comm.locality_view(4 * 128)                    # 61-MB table: timed
-  gain = forced.stats['aggregation_speedup_measured']['128']
-  assert (view is forced) == (gain >= LOCALITY_MIN_GAIN), (gain, view)
-  assert comm.locality_view(4 * 128) is view            # clustered and timed once per graph
-  assert list(forced.stats['aggregation_speedup_measured']) == ['128']
+  best, gains = comm._locality['decision'][128]
+  assert set(gains) == {'parts', 'degree'} and gains[best] == max(gains.values())
+  assert (view is not None) == (gains[best] >= LOCALITY_MIN_GAIN), gains
+  if view is not None:
+    assert view.stats['order'] == {'parts': 'part by part', 'degree': 'rows by descending length'}[best]
+    assert view.stats['aggregation_speedup_measured']['128'][best] == round(gains[best], 4)
+  assert comm.locality_view(4 * 128) is view and comm.locality_view(4 * 128, '1') is comm.locality_view(4 * 128, best)   # decided once
   sub = G.CSRGraph(torch.as_tensor(ei_np).to(dev), n)
   sub.set_row_range(100, n)
   assert sub.locality_view(4 * 128, '1') is None        # a view of part of the rows keeps its numbering

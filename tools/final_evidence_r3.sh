@@ -3,12 +3,13 @@
 #   arxiv: rocprofv3 kernel stats of the solver's own launches, the default bench line (with the CPU baseline), two PMC passes
 #          (with the roofline probes, so that the gather-ceiling kernel is counted too) -> hbm_traffic.json
 #   rmat : kernel stats, two PMC passes -> hbm_traffic.json, bench line
+#   third argument: the graphs to cover (default "arxiv rmat")
 set -u
-TAG=$1; COMMIT=$2
+TAG=$1; COMMIT=$2; GRAPHS=${3:-"arxiv rmat"}
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cp profiles/hbm_traffic.json "$OUT/hbm_traffic.json"
-for G in arxiv rmat; do
+for G in $GRAPHS; do
   if [ $G = arxiv ]; then STEPS=20; PROBE=""; else STEPS=2; PROBE="--no-roofline-probe"; fi
   BENCH="python bench.py --graph $G --steps $STEPS --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$G" -o p -- $BENCH > "$OUT/stats_$G.log" 2>&1
@@ -29,5 +30,5 @@ for G in arxiv rmat; do
   find "$OUT" -name '*counter_collection.csv' -delete
 done
 cp "$OUT/hbm_traffic.json" profiles/hbm_traffic.json     # (so that the bench lines below carry the fresh record)
-timeout 300 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; echo "bench rc $?"; cut -c1-300 "$OUT/bench_default.json"
-timeout 400 python bench.py --graph rmat --steps 8 --warmup 1 > "$OUT/bench_rmat.json" 2> "$OUT/bench_rmat.err"; echo "bench rmat rc $?"; cut -c1-300 "$OUT/bench_rmat.json"
+case "$GRAPHS" in *arxiv*) timeout 300 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; echo "bench rc $?"; cut -c1-300 "$OUT/bench_default.json";; esac
+case "$GRAPHS" in *rmat*) timeout 400 python bench.py --graph rmat --steps 8 --warmup 1 > "$OUT/bench_rmat.json" 2> "$OUT/bench_rmat.err"; echo "bench rmat rc $?"; cut -c1-300 "$OUT/bench_rmat.json";; esac
