@@ -44,9 +44,11 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
     from .utils import MaxNFEException
     raise MaxNFEException
   st = func.__dict__.setdefault('_solver_state', {})
-  # relabelled graph (graph.LocalityView): the state enters as y0[order] and leaves as y[inv]; not with the in-graph
-  # early-stopping evaluator, whose node masks address the caller's numbering
-  view = func._locality_view(y0) if evaluator is None and hasattr(func, '_locality_view') else None
+  # relabelled graph (graph.LocalityView): the state enters as y0[order] and leaves as y[inv]; the in-graph early-stopping
+  # evaluator gets its labels and split masks in the same order (EarlyStopEvaluator.relabelled: shared counters and trace)
+  view = func._locality_view(y0) if hasattr(func, '_locality_view') else None
+  if evaluator is not None and view is not None:
+    evaluator = evaluator.relabelled(view)
   key = (method, tuple(dts), tuple(y0.shape), str(y0.device), id(view))
   ent = st.get(key)
   y0c = y0.detach()

@@ -512,6 +512,23 @@ class EarlyStopEvaluator(object):
   def ref(self):
     return ctypes.byref(self.struct)
 
+  def relabelled(self, view):
+    """The same evaluator for states whose rows are in the order of a graph.LocalityView: labels and split masks permuted,
+    decoder, best-so-far state and trace SHARED with this one (the hit counts are integers over the same nodes, so every
+    accuracy is unchanged and `read()` of either returns the same record)."""
+    views = self.__dict__.setdefault('_relabelled', [])
+    for v, ev in views:
+      if v is view:
+        return ev
+    ev = object.__new__(EarlyStopEvaluator)
+    ev.__dict__.update({k: v for k, v in self.__dict__.items() if k != '_relabelled'})
+    ev.labels = self.labels.index_select(0, view.order).contiguous()
+    ev.split = self.split.index_select(0, view.order).contiguous()
+    ev.struct = _lib.DecoderStruct(weight=ptr(self.weight), bias=ptr(self.bias), labels=ptr(ev.labels), split=ptr(ev.split),
+                                   n_classes=int(self.weight.shape[0]), d_dec=int(self.weight.shape[1]))
+    views[:] = views[-1:] + [(view, ev)]
+    return ev
+
   def reset(self):
     check(_lib.lib().gnpde_early_stop_reset(ptr(self.state), stream_of(self.state)))
 

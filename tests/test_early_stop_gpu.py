@@ -241,6 +241,49 @@ def test_early_stop_vs_oracle_larger(dev):
   assert abs(integ.solver.best_val - best[1]) <= 2.0 / 900 + 1e-12
 
 
+@pytest.mark.parametrize('function', ['laplacian', 'transformer'])
+def test_early_stop_on_the_relabelled_graph(dev, function):
+  """rk4 with the in-graph evaluator on the relabelled graph (graph.LocalityView; EarlyStopEvaluator.relabelled permutes labels
+  and split masks, counters and trace are shared): state bit-identical, every per-step hit count and the best step equal."""
+  from gnpde_amd import synthetic
+  n, d, c = 5000, 64, 40
+  ei = torch.as_tensor(synthetic.community_powerlaw_graph(n, 30000, seed=6, n_comm=10)[0])
+  g = torch.Generator().manual_seed(9)
+  x = torch.randn(n, d, generator=g)
+  labels = torch.randint(0, c, (n,), generator=g)
+  role = torch.randperm(n, generator=g)
+  masks = [role < 1000, (role >= 1000) & (role < 2500), role >= 2500]
+  fx = Fixture('early_rk4_laplacian_arxiv')
+  opt = dict(fx.opt, block='constant', function=function, time=4.0, step_size=1.0, hidden_dim=d, dataset='Cora',
+             heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+             beltrami=False, mix_features=False)
+  data = Data(x.to(dev), ei.to(dev))
+  data.y = labels.to(dev)
+  data.train_mask, data.val_mask, data.test_mask = [m.to(dev) for m in masks]
+  fcls = G.LaplacianODEFunc if function == 'laplacian' else G.ODEFuncTransformerAtt
+  block = G.ConstantODEblock(fcls, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
+  with torch.no_grad():
+    block.odefunc.alpha_train.fill_(0.3)
+    block.odefunc.beta_train.fill_(0.2)
+  integ = G.EarlyStopInt(opt['time'], opt, dev)
+  integ.keep_trace = True
+  integ.data, integ.m2_weight, integ.m2_bias = data, torch.randn(c, d, generator=g).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev)
+  block.test_integrator = integ
+  block.eval()
+  block.set_x0(x.to(dev))
+  res = {}
+  for mode in ('0', 'parts', 'degree'):
+    block.odefunc.opt['gnpde_reorder'] = mode
+    with torch.no_grad():
+      z = block(x.to(dev)).clone()
+    sol = integ.solver
+    res[mode] = (z, [(r['time'], tuple(r['hits'])) for r in sol.trace], (sol.best_val, sol.best_test, sol.best_time))
+    assert len(sol.trace) == int(opt['earlystopxT'] * opt['time']) and all(sum(r['hits']) > 0 for r in sol.trace)
+  for mode in ('parts', 'degree'):
+    assert torch.equal(res['0'][0], res[mode][0])
+    assert res['0'][1] == res[mode][1] and res['0'][2] == res[mode][2], (mode, res['0'][1:], res[mode][1:])
+
+
 def test_euler_is_refused(dev):
   fx = Fixture('early_rk4_transformer')
   fx.opt['method'] = 'euler'

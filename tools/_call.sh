@@ -1,5 +1,4 @@
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r03c
-timeout 300 python tools/_probe_att.py > gpurun_out/r03c/probe_att.txt 2>&1; echo "rc $?" >> gpurun_out/r03c/probe_att.txt
-tail -14 gpurun_out/r03c/probe_att.txt | cut -c1-200
+timeout 600 python -m pytest tests/test_early_stop_gpu.py tests/test_solver_gpu.py -m gpu -x -q -p no:cacheprovider -k "relabel or early_stop" > gpurun_out/r03c/pytest_es.log 2>&1; echo "rc $?" >> gpurun_out/r03c/pytest_es.log; tail -15 gpurun_out/r03c/pytest_es.log
