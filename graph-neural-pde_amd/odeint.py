@@ -366,13 +366,21 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
   if room <= 0:
     raise MaxNFEException
   st = func.__dict__.setdefault('_dopri5_device', {})
-  key = (tuple(y0.shape), str(y0.device), float(rtol), float(atol))
+  # Relabelled graph (graph.LocalityView) only on request -- opt['gnpde_reorder'] / GNPDE_REORDER = '1', 'parts' or 'degree', not
+  # 'auto': the error norm of a trial step is a sum over the rows, so on the relabelled graph it is rounded differently, the step
+  # sizes differ in their last bits and the result is equal to the unrelabelled solve to rounding, not bit for bit
+  import os
+  mode = str(func.opt.get('gnpde_reorder', os.environ.get('GNPDE_REORDER', 'auto'))).lower()
+  view = func._locality_view(y0) if mode in ('1', 'true', 'on', 'force', 'parts', 'degree') and hasattr(func, '_locality_view') else None
+  if evaluator is not None and view is not None:
+    evaluator = evaluator.relabelled(view)
+  key = (tuple(y0.shape), str(y0.device), float(rtol), float(atol), id(view))
   ent = st.get(key)
   y0c = y0.detach()
   if ent is None:
     ent = {'y': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device),
            'x0': _lib.alloc_state(y0c.shape[0], y0c.shape[1], y0c.device) if func.opt['add_source'] else None,
-           'solver': None, 'sig': None}
+           'solver': None, 'sig': None, 'view': view}
     for old in st.values():
       if old['solver'] is not None:
         old['solver'].close()
@@ -387,8 +395,12 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
   if ent['x0'] is not None:
     if func.x0 is None:
       raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
-    ent['x0'].copy_(func.x0)
-  desc = func._descriptor(ent['y'], x0_override=ent['x0'])     # (ent['y'] only fixes the row stride; the solver owns its buffers)
+    if view is None:
+      ent['x0'].copy_(func.x0)
+    else:
+      view.enter(func.x0.detach(), out=ent['x0'])
+  # (ent['y'] only fixes the row stride; the solver owns its buffers)
+  desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=None if view is None else view.graph)
   sig = func._descriptor_signature(desc)
   if ent['solver'] is None or ent['sig'] != sig:
     if ent['solver'] is not None:
@@ -407,7 +419,12 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
     trials_per_sync = 8 if y0c.numel() < (1 << 22) else 1
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
   out[0].copy_(y0c)
-  finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
+  if view is None:
+    finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
+  else:
+    y1 = torch.empty_like(y0c)
+    finished = ent['solver'].run(view.enter(y0c), float(t[0]), float(t[-1]), y1, trials_per_sync=trials_per_sync, max_evals=room)
+    view.leave(y1, out=out[1])
   spent = ent['solver'].stats()['evals']
   func._dopri5_stats = ent['solver'].stats()
   if not finished or spent > room:

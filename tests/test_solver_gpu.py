@@ -319,6 +319,35 @@ def test_device_controlled_dopri5(dev, function, d):
     assert runs[label][2]['launches'] == trials, (label, runs[label][2], trials)
 
 
+@pytest.mark.parametrize('function', ['transformer', 'laplacian'])
+def test_device_controlled_dopri5_on_the_relabelled_graph(dev, function):
+  """Device dopri5 on the relabelled graph -- on request only (opt['gnpde_reorder'] = 'parts' / 'degree'; 'auto' leaves dopri5
+  alone): the error norm sums over the rows in another order, so the solve equals the unrelabelled one to rounding (1e-5), with
+  the same accepted / rejected step counts here, not bit for bit."""
+  from gnpde_amd import synthetic
+  n, d = 8000, 64
+  ei = torch.as_tensor(synthetic.community_powerlaw_graph(n, 50000, seed=8, n_comm=12)[0]).to(dev)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(21)).to(dev)
+  opt = dict(BASE, function=function, hidden_dim=d, method='dopri5', time=6.0, tol_scale=50.0)
+  block = _block(opt, ei, n, x, dev)
+  f = block.odefunc
+  f.x0 = x
+  t = torch.tensor([0.0, 6.0], device=dev)
+  kw = dict(method='dopri5', atol=50.0 * 1e-7, rtol=50.0 * 1e-9)
+  runs = {}
+  with torch.no_grad():
+    for mode in ('auto', '0', 'parts', 'degree'):
+      f.opt['gnpde_reorder'] = mode
+      f.nfe = 0
+      z = G.odeint(f, x, t, **kw)[1]
+      runs[mode] = (z.clone(), f.nfe, dict(f._dopri5_stats))
+  assert torch.equal(runs['auto'][0], runs['0'][0])
+  for mode in ('parts', 'degree'):
+    assert_parity(runs[mode][0], runs['0'][0], what='dopri5 on the relabelled graph (%s)' % mode)
+    assert runs[mode][1] == runs['0'][1] and runs[mode][2]['accepted'] == runs['0'][2]['accepted'], (mode, runs[mode][1:], runs['0'][1:])
+    assert not torch.equal(runs[mode][0], torch.zeros_like(runs[mode][0]))
+
+
 def test_device_controlled_dopri5_max_nfe(dev):
   """opt['max_nfe'] with the device controller: MaxNFEException once the budget is spent, nfe past it as in the reference."""
   ei, n = G.synthetic.make_graph('arxiv', scale=0.02)
