@@ -140,10 +140,15 @@ class ODEFunc(nn.Module):
   def _locality_view(self, x):
     """graph.LocalityView the fused solves of this function run on (nodes relabelled part by part or by descending row
     length, whichever a timed aggregation prefers; results bit-identical up to the row permutation, which the solver undoes), or
-    None.  opt['gnpde_reorder'] / GNPDE_REORDER: 'auto' (default: when the state does not fit the L2s and a candidate is at
-    least 2 % faster), '1' (the faster candidate, always), 'parts' / 'degree' (that order), '0' (never)."""
+    None.  opt['gnpde_reorder'] / GNPDE_REORDER: 'auto' (default: in evaluation mode, when the state does not fit the L2s and a
+    candidate is at least 2 % faster), '1' (the faster candidate, always), 'parts' / 'degree' (that order), '0' (never)."""
     import os
-    mode = self.opt.get('gnpde_reorder', os.environ.get('GNPDE_REORDER', 'auto'))
+    mode = str(self.opt.get('gnpde_reorder', os.environ.get('GNPDE_REORDER', 'auto'))).lower()
+    if mode == 'auto' and self.training:
+      # training forwards may hand over a NEW edge set every step (hard attention, rewiring: reference
+      # src/block_transformer_hard_attention.py:55-61) -- a clustering and a timing run per step would cost more than any order
+      # can return; the automatic rule is for evaluation (module.eval()), where the graph stays
+      return None
     return self._graph(x).locality_view(4 * int(x.shape[1]), mode)
 
   def _check_nfe(self):
