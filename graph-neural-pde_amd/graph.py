@@ -349,9 +349,11 @@ class LocalityView(object):
                       xcd_deal='hashed_blocks' if self.graph.struct.xcd_deal == _lib.XCD_HASHED else 'contiguous_eighths')
 
   def enter(self, x, out=None):
-    """x[order] (rows in the relabelled order)."""
+    """x[order] (rows in the relabelled order); written straight into `out` when that is a dense [n, d] buffer."""
     if out is None:
       return x.index_select(0, self.order)
+    if out.is_contiguous() and out.dtype == x.dtype and out.shape == x.shape:
+      return torch.index_select(x, 0, self.order, out=out)
     out.copy_(x.index_select(0, self.order))
     return out
 
@@ -359,6 +361,8 @@ class LocalityView(object):
     """y[inv] (rows back in the caller's order)."""
     if out is None:
       return y.index_select(0, self.inv)
+    if out.is_contiguous() and out.dtype == y.dtype and out.shape == y.shape:
+      return torch.index_select(y, 0, self.inv, out=out)
     out.copy_(y.index_select(0, self.inv))
     return out
 

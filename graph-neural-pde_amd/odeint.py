@@ -75,10 +75,15 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
   if ent['x0'] is not None:
     if func.x0 is None:
       raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
-    if view is None:
-      ent['x0'].copy_(func.x0)
-    else:
-      view.enter(func.x0.detach(), out=ent['x0'])
+    # the solver's copy of the source term is refreshed only when the caller's tensor is another one or was written to (keyed on
+    # the tensor OBJECT, kept alive here so that its address cannot be handed to another tensor, and its version counter)
+    src = func.x0
+    if ent.get('x0_src') is not src or ent.get('x0_version') != src._version:
+      if view is None:
+        ent['x0'].copy_(src)
+      else:
+        view.enter(src.detach(), out=ent['x0'])
+      ent['x0_src'], ent['x0_version'] = src, src._version
   desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=None if view is None else view.graph)
   sig = func._descriptor_signature(desc)
   if ent['solver'] is None or ent['sig'] != sig:

@@ -552,3 +552,28 @@ def test_relabelling_is_automatic_only_where_it_can_pay(dev):
   sub = G.CSRGraph(torch.as_tensor(ei_np).to(dev), n)
   sub.set_row_range(100, n)
   assert sub.locality_view(4 * 128, '1') is None        # a view of part of the rows keeps its numbering
+
+
+@pytest.mark.parametrize('mode', ['0', 'parts'])
+def test_source_term_copy_follows_the_callers_tensor(dev, mode):
+  """The fused solver keeps its own (possibly relabelled) copy of the source term x0 and refreshes it only when the caller's
+  tensor is another object or was written to: a new tensor, and an in-place update of the same tensor, must both be seen."""
+  n, d = 3000, 64
+  ei = random_graph(n, 6, seed=2).to(dev)
+  g = torch.Generator().manual_seed(3)
+  x, a, b = [torch.randn(n, d, generator=g).to(dev) for _ in range(3)]
+  opt = dict(BASE, function='laplacian', method='rk4', hidden_dim=d, time=2.0, gnpde_reorder=mode)
+  block = _block(opt, ei, n, x, dev)
+  fresh = _block(dict(opt), ei, n, x, dev)
+
+  def solve(blk, src):
+    blk.set_x0(src)
+    with torch.no_grad():
+      return blk(x).clone()
+  za = solve(block, a)
+  assert torch.equal(solve(block, a), za)                 # same tensor, untouched: the copy is reused
+  zb = solve(block, b)                                    # another tensor
+  assert torch.equal(zb, solve(fresh, b)) and not torch.equal(zb, za)
+  b.mul_(2.0)                                             # the same tensor, written in place
+  zb2 = solve(block, b)
+  assert torch.equal(zb2, solve(fresh, b)) and not torch.equal(zb2, zb)
