@@ -659,8 +659,11 @@ int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* s, const gn
  * *ticks_per_second) written by the kernels themselves inside the hipGraph -- [0] the push kernel starts, [1] its last block has
  * published the epoch (all boundary rows stored into the peers' halo regions), [2] the main stream reaches the wait (interior
  * rows done), [3] every peer's rows have landed.  [1]-[0] = push duration (xGMI stores), [3]-[2] = time the boundary pass waited
- * for the exchange, i.e. the part of the exchange that compute did not hide.  stamps: int64[capacity_evals][4]; *n_evals: the
- * evaluations of a run (0 when the solver does not exchange).  Synchronises.  No reference equivalent (measurement). */
+ * for the exchange, i.e. the part of the exchange that compute did not hide.  With gnpde_sharded_solver_set_boundary_chunks the
+ * rows of evaluation s travel during evaluation s - 1: [0] = the push behind the FIRST row range starts, [1] = the push behind
+ * the last range has published the epoch, both stamped in the row of the evaluation whose INPUT they deliver.  stamps:
+ * int64[capacity_evals][4]; *n_evals: the evaluations of a run (0 when the solver does not exchange).  Synchronises.  No reference
+ * equivalent (measurement). */
 int gnpde_sharded_solver_timing(gnpde_sharded_solver_t* s, int64_t* stamps, int32_t capacity_evals, int32_t* n_evals,
                                 int64_t* ticks_per_second);
 
