@@ -200,6 +200,22 @@ class LocalShard(object):
 # --------------------------------------------------------------------------------------------------
 # product backend: HIP kernels through the C ABI
 # --------------------------------------------------------------------------------------------------
+def boundary_cuts(rows, n_interior, n_own, n_chunks):
+  """Row boundaries [b_0 = n_interior, ..., b_k = n_own] that cut the boundary rows into k <= n_chunks consecutive, non-empty
+  ranges of about equal entry counts (`rows`: the row index of every local entry).  Host arithmetic only."""
+  b0, b1 = int(n_interior), int(n_own)
+  k = max(1, min(int(n_chunks), b1 - b0))
+  bounds = [b0]
+  if b1 > b0:
+    deg = torch.bincount(rows[rows >= b0] - b0, minlength=b1 - b0).to(torch.float64)
+    cum = torch.cumsum(deg + 1e-3, 0)      # (+eps: rows without entries still advance, so no range is empty)
+    for c in range(1, k):
+      cut = b0 + int(torch.searchsorted(cum, cum[-1] * c / k).item()) + 1
+      bounds.append(min(max(cut, bounds[-1] + 1), b1 - (k - c)))
+  bounds.append(b1)
+  return bounds
+
+
 class NativeBackend(object):
   """f(u) with fused solver stage on the local shard.  kind = 'laplacian' (params: edge_weight over
   the LOCAL edges) or 'transformer' (params: Wq, bq, Wk, bk, heads; scaled-dot, softmax over rows)."""
@@ -263,17 +279,8 @@ class NativeBackend(object):
     if int(n_chunks) in self.chunk_sets:
       return self.chunk_sets[int(n_chunks)]
     sh = self.shard
-    b0, b1 = int(sh.n_interior), int(sh.n_own)
     rows = sh.edge_index[0]
-    k = max(1, min(int(n_chunks), b1 - b0))
-    bounds = [b0]
-    if b1 > b0:
-      deg = torch.bincount(rows[rows >= b0] - b0, minlength=b1 - b0).to(torch.float64)
-      cum = torch.cumsum(deg + 1e-3, 0)      # (+eps: rows without edges still advance, so no chunk is empty)
-      for c in range(1, k):
-        cut = b0 + int(torch.searchsorted(cum, cum[-1] * c / k).item()) + 1
-        bounds.append(min(max(cut, bounds[-1] + 1), b1 - (k - c)))
-    bounds.append(b1)
+    bounds = boundary_cuts(rows, int(sh.n_interior), int(sh.n_own), n_chunks)
     chunks = []
     for c in range(len(bounds) - 1):
       lo, hi = bounds[c], bounds[c + 1]

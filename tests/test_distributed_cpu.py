@@ -131,6 +131,29 @@ def test_push_order_interleaves_the_destinations():
     _lib.check(L.gnpde_push_order(bad.ctypes.data_as(_lib.c_int_p), 2, out.ctypes.data_as(_lib.c_int_p)))
 
 
+def test_boundary_cuts_tile_the_boundary_rows_with_even_entry_counts():
+  """distributed.boundary_cuts (the row ranges of the chunked boundary pass): consecutive, non-empty, tiling
+  [n_interior, n_own); entry counts within one row's worth of even; degenerate inputs (fewer rows than ranges, no boundary
+  rows, rows without entries) handled."""
+  n, world = 4000, 4
+  ei = random_graph(n, 7, seed=8, hubs=1, hub_deg=500)
+  plan = D.PartitionPlan(ei, n, world)
+  for rank in range(world):
+    sh = plan.shard(rank)
+    rows = sh.edge_index[0]
+    deg = torch.bincount(rows, minlength=sh.n_own)
+    for k in (1, 2, 3, 7):
+      b = D.boundary_cuts(rows, sh.n_interior, sh.n_own, k)
+      assert b[0] == sh.n_interior and b[-1] == sh.n_own and len(b) == k + 1 and all(x < y for x, y in zip(b, b[1:]))
+      per = [int(deg[b[c]:b[c + 1]].sum()) for c in range(k)]
+      total = sum(per)
+      assert max(abs(p - total / k) for p in per) <= int(deg[sh.n_interior:sh.n_own].max()) + 1, (k, per)
+  rows = torch.tensor([0, 0, 1, 5, 5, 5], dtype=torch.int64)
+  assert D.boundary_cuts(rows, 4, 6, 8) == [4, 5, 6]          # two boundary rows: at most two ranges
+  assert D.boundary_cuts(rows, 6, 6, 3) == [6, 6]             # no boundary rows: one empty range
+  assert D.boundary_cuts(rows, 2, 6, 2) in ([2, 5, 6], [2, 6 - 1, 6])   # rows 2..4 have no entries: the cut still advances
+
+
 def test_chunked_push_order_groups_the_send_slots_by_the_row_range_that_computes_them():
   """NativeShardedSolver._chunked_push_order (the walk of gnpde_sharded_solver_set_boundary_chunks): a permutation of the send
   slots; slots [ptr[c], ptr[c+1]) hold exactly the rows of boundary range c (rows of the interior pass ride with range 0);
