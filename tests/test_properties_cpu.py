@@ -188,3 +188,36 @@ def test_rewiring_sparse_helpers_match_dense(a, b, seed):
   assert torch.allclose(dense(id_, vd), dense(ia, va) + dense(ib, vb), atol=1e-5)
   key = id_[0] * n + id_[1]
   assert id_.shape[1] <= 1 or bool((key[1:] > key[:-1]).all())
+
+
+@FAST
+@given(edge_lists(), st.randoms(use_true_random=False))
+def test_relabelled_graph_keeps_every_rows_edges_in_the_callers_order(g, rnd):
+  """graph.LocalityView under an ARBITRARY permutation of the nodes (duplicates, self loops, empty rows): row inv[v] of the
+  relabelled CSR lists the same caller edges in the same order as row v of the original (equal `perm` slices -- this is what makes
+  every row sum on the relabelled graph the same sum), its column ids are the relabelled neighbours, and the dense operator is
+  P A P^T."""
+  from gnpde_amd.graph import LocalityView
+  n, ei = g
+  order = list(range(n))
+  rnd.shuffle(order)
+  order = torch.tensor(order, dtype=torch.int64)
+  base = G.CSRGraph(ei, n, device='cpu')
+  view = LocalityView(base, order, {})
+  v = view.graph
+  assert torch.equal(view.inv[view.order], torch.arange(n)) and v.e == base.e and v.n == n
+  rp_b, rp_v = base.rowptr.long(), v.rowptr.long()
+  for i in range(n):
+    old = int(order[i])
+    assert torch.equal(v.perm.long()[rp_v[i]:rp_v[i + 1]], base.perm.long()[rp_b[old]:rp_b[old + 1]])
+    assert torch.equal(order[v.colidx.long()[rp_v[i]:rp_v[i + 1]]], base.colidx.long()[rp_b[old]:rp_b[old + 1]])
+  w = torch.arange(1, base.e + 1, dtype=torch.float64)        # a weight per CALLER edge
+  dense = lambda gr: torch.zeros(n, n, dtype=torch.float64).index_put_(   # noqa: E731
+      (torch.repeat_interleave(torch.arange(n), (gr.rowptr.long()[1:] - gr.rowptr.long()[:-1])), gr.colidx.long()),
+      w[gr.perm.long()], accumulate=True)
+  a, b = dense(base), dense(v)
+  assert torch.equal(b, a[order][:, order])
+  x = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
+  assert torch.equal(view.leave(view.enter(x)), x)
+  buf = torch.empty(n, 4)[:, :3]                               # a padded (non-contiguous) destination
+  assert torch.equal(view.enter(x, out=buf), x[order]) and torch.equal(view.leave(buf, out=torch.empty(n, 3)), x)
