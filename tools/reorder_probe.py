@@ -45,10 +45,10 @@ def run(label, order, extra=None, knob=0):
   if order is None:
     g = G.CSRGraph(e.to(dev), n)
   else:
-    view = LocalityView(base, order, {})       # relabelled CSR + work-balanced contiguous ranges (GNPDE_XCD_RANGES)
+    view = LocalityView(base, order, {})       # relabelled CSR in the caller's edge order
     g = view.graph
   ops.tune(_lib.TUNE_XCD_ROWS, knob)
-  extra = dict(extra or {}, xcd_deal={0: ['contiguous', 'hashed', 'ranges'][g.struct.xcd_deal], 1: 'contiguous (forced)', 2: 'hashed (forced)'}[knob],
+  extra = dict(extra or {}, xcd_deal={0: ['contiguous', 'hashed'][g.struct.xcd_deal], 1: 'contiguous (forced)', 2: 'hashed (forced)'}[knob],
                xcd_imbalance_contiguous=round(g.xcd_imbalance_contiguous, 3))
   xd = xs.to(dev)
   x0 = xd.clone()
