@@ -102,7 +102,6 @@ enum {
   GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)
   GNPDE_TUNE_XCD_ROWS = 10,            // 0: as gnpde_graph_t.xcd_deal says; 1: contiguous eighths for every graph; 2: hashed blocks for every graph
   GNPDE_TUNE_HUB_FOLD = 11,            // 2: phase 1 of the hub-row attention folds the row's chunk partials straight from memory instead of staging them through LDS (default: staged)
-  GNPDE_TUNE_ROW_SHIFT = 12,           // A/B: 4 .. 10 = hashed blocks of 2^value rows instead of the size choose_row_shift picks (0: default)
   GNPDE_TUNE_COUNT = 16
 };
 extern int g_tune[GNPDE_TUNE_COUNT];

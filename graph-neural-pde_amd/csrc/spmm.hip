@@ -94,7 +94,6 @@ inline int choose_row_shift(long long rn, int graph_deal) {
   const int knob = g_tune[GNPDE_TUNE_XCD_ROWS];           // A/B: 1 = contiguous eighths, 2 = hashed blocks, whatever the graph says
   const bool hashed = knob == 2 || (knob != 1 && graph_deal == GNPDE_XCD_HASHED);
   if (!hashed) return -1;
-  if (g_tune[GNPDE_TUNE_ROW_SHIFT] >= 4 && g_tune[GNPDE_TUNE_ROW_SHIFT] <= 10) return g_tune[GNPDE_TUNE_ROW_SHIFT];
   int s = 4;
   while (s < 7 && (rn >> (s + 1)) >= 8192) ++s;
   return s;

@@ -1,5 +1,10 @@
 """Block size of the hashed rows -> XCDs deal on the relabelled ogbn-arxiv stand-in (gnpde_tune(12, s): blocks of 2^s rows; default
-s = 4 at this size).  GPU box only."""
+s = 4 at this size).  GPU box only.
+
+The knob this script drives was taken out again after the measurement (no effect: profiles/r03_row_shift_ab.txt) so that
+csrc/spmm.hip stays byte for byte the file the PMC records of profiles/hbm_traffic.json were taken with.  To repeat the run, add
+to choose_row_shift (csrc/spmm.hip), before `int s = 4;`:
+    if (g_tune[12] >= 4 && g_tune[12] <= 10) return g_tune[12];"""
 import json
 import os
 import sys
