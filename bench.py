@@ -418,6 +418,20 @@ def main():
     secondary = [] if fused else secondary_kernels(G, main_block, x, E, n, ceiling)
   except Exception as exc:   # (a probe that cannot run must not cost the line)
     secondary = [{'error': repr(exc)[:200]}]
+  try:
+    # counter traffic of the same launches from the PMC record of this shape (profiles/hbm_traffic.json, `detail`): what the
+    # kernels really moved next to what the model says they need
+    det = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))['detail']['%s_d%d_spmm' % (args.graph, d)]
+    for ent, pat in zip(secondary, ('row_attention_sd_kernel', 'linear_')):
+      recs = [v for k, v in det['kernels'].items() if pat in k and 'bytes_per_launch' in v]
+      if recs and 'avg_us' in ent:
+        tb = sum(r['bytes_per_launch'] for r in recs) if pat.startswith('row') else max(r['bytes_per_launch'] for r in recs)
+        ent['traffic'] = round(tb)
+        ent['traffic_gbs'] = round(tb / (ent['avg_us'] * 1e-6) / 1e9, 1)
+        ent['l2_hit_rate'] = [r.get('l2_hit_rate') for r in recs]
+        ent['traffic_commit'] = det.get('commit')
+  except Exception:   # noqa: BLE001 -- no record for this shape
+    pass
   traffic = None
   tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   if os.path.exists(tpath):
