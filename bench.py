@@ -11,13 +11,19 @@ the launch is repeated `--replays` times (each bracketed by a device synchronisa
   python bench.py --graph rmat --steps 8 --warmup 1        (BASELINE configs[4] shape on ONE GPU: 2 M nodes, d = 256)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row-partitioned, RCCL halo)
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the CSR aggregation
-spmm_rows_kernel / spmm_pair_kernel): algorithmic bytes of DESIGN.md section "Kernels" divided by its average launch duration,
-measured here with HIP events around a captured graph of the four rk4-stage variants the solver runs.  `roofline.frac` is
-against HBM's 8 TB/s when the gathered table exceeds the Infinity Cache (R-MAT) and against the rate of a perfectly balanced
-row gather from the same table measured in the same run (`roofline.ceiling`, gnpde_gather_ceiling) when it is cache-resident
-(ogbn-arxiv); `roofline.secondary` times the projection and the row attention.
-`cpu_baseline` times the CPU oracle (the reference's op sequence) on this host's cores on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the CSR aggregation spmm_pair_kernel / spmm_wide_kernel
++ the hub-row fold): `achieved` = algorithmic bytes of DESIGN.md section 4 (SURVEY 8d's gather model) / its average launch
+duration, measured here with HIP events around a captured graph of the four rk4-stage variants the solver runs; `peak` = HBM's
+8 TB/s; `frac_algorithmic` = achieved / peak (exceeds 1 when the gathered table is resident in the Infinity Cache: the model
+charges every cache-served row to HBM); `traffic` = the L2 -> fabric bytes of the same launches from rocprofv3 PMC passes that
+THIS run makes over a child process of itself (`--pmc-child`; separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+prescribes; the stored record of profiles/hbm_traffic.json only when the passes cannot run, marked as such);
+`frac_traffic` = traffic / duration / peak; `frac` = frac_traffic when the table is cache-resident (`bound: "mall"`) and
+frac_algorithmic when it is not.  `stream_read_probe` = a coalesced L2-cold streaming read of the same table,
+`hbm_bound_probe` = the same aggregation kernel on a device-generated 2-GiB table (d = 256, uniform degree 16), where every
+gathered row comes from DRAM and algorithmic bytes / time / 8 TB/s is a true HBM fraction.  `roofline.secondary` times the
+projection and the row attention.  `cpu_baseline` times the CPU oracle (the reference's op sequence) on this host's cores on a
+bounded sample.
 """
 import argparse
 import ctypes
@@ -54,6 +60,12 @@ def parse():
   ap.add_argument('--cpu-evals', type=int, default=None,
                   help='full-size evaluations of f timed on the host (default 6; the rmat shape needs ~100 GB of '
                        'host temporaries per evaluation and is skipped unless a count is given)')
+  ap.add_argument('--no-live-pmc', action='store_true',
+                  help='do not run the rocprofv3 --pmc passes over a child process (roofline.traffic then comes from the stored '
+                       'record of profiles/hbm_traffic.json, marked as such)')
+  ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
+  ap.add_argument('--pmc-child', action='store_true',
+                  help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
   ap.add_argument('--replays', type=int, default=5, help='timed launches of the K-step solve (median reported)')
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
@@ -283,6 +295,205 @@ def source_sha16(rel):
     return None
 
 
+KERNEL_SOURCES = ('graph-neural-pde_amd/csrc/spmm.hip', 'graph-neural-pde_amd/csrc/attention.hip', 'graph-neural-pde_amd/csrc/linear.hip',
+                  'graph-neural-pde_amd/csrc/epilogue.h')
+
+
+def kernel_sources_sha16():
+  """One hash over every source file a kernel of the evaluation is compiled from: a stored PMC record is stale as soon as any
+  of them changes (round 3 hashed spmm.hip only)."""
+  import hashlib
+  h = hashlib.sha256()
+  for rel in KERNEL_SOURCES:
+    try:
+      h.update(open(os.path.join(ROOT, rel), 'rb').read())
+    except OSError:
+      return None
+  return h.hexdigest()[:16]
+
+
+def stream_read_probe(x):
+  """Coalesced streaming read of the SAME table (gnpde_stream_read: 16-byte lanes, grid stride, eight loads in flight, nothing
+  written but one float per workgroup), repeated back to back.  The table exceeds the L2s (32 MiB), so every pass finds its
+  lines L2-cold; when it fits the 256-MiB Infinity Cache they come from there -- the rate the memory side can deliver this
+  table's lines at, a hardware figure next to the aggregation's gather of them."""
+  from gnpde_amd import _lib
+  flat = x if x.is_contiguous() else x.contiguous()
+  nfl = flat.numel() // 4 * 4
+  sink = torch.empty(2048, dtype=torch.float32, device=x.device)
+  L = _lib.lib()
+
+  passes = max(1, min(64, int(2 ** 31 // max(nfl * 4, 1))))      # ~2 GiB read per launch
+
+  def call():
+    _lib.check(L.gnpde_stream_read(_lib.ptr(flat), nfl, passes, _lib.ptr(sink), sink.numel(), _lib.stream_of(flat)))
+  t = timed_replay(call, 4)
+  return {'gbs': round(passes * nfl * 4 / t / 1e9, 1), 'bytes_per_pass': nfl * 4, 'passes_per_launch': passes,
+          'us_per_pass': round(t * 1e6 / passes, 2),
+          'what': 'gnpde_stream_read: coalesced read of the same [n, d] table (16-byte lanes, 8 loads in flight per lane), %d whole-table '
+                  'passes inside one launch: every pass is L2-cold (table > 32 MiB of L2), served by the Infinity Cache when the table '
+                  'fits its 256 MiB, by DRAM otherwise' % passes}
+
+
+def hbm_bound_probe(G, dev, log_n=21, d=256, k=16, reps=3):
+  """The SAME aggregation entry (gnpde_spmm_rhs: what the solver launches, plain f = alpha (A u - u) + beta x0 epilogue) on a
+  device-generated graph whose gathered table cannot sit in any cache: 2^log_n rows of d floats (2 GiB at the defaults, 8x the
+  Infinity Cache), k uniformly random neighbours per row.  Every gathered row is DRAM traffic, so algorithmic bytes / time /
+  8 TB/s is a fraction of the HBM roofline in the strict sense -- the driver-witnessed HBM-bound figure of the kernel whose
+  headline shape (ogbn-arxiv, 83 MiB) is cache-resident."""
+  from gnpde_amd import ops, graph as Gr
+  n = 1 << log_n
+  gen = torch.Generator(device=dev).manual_seed(4321)
+  row = torch.arange(n, device=dev, dtype=torch.int64).repeat_interleave(k)
+  col = torch.randint(0, n, (n * k,), device=dev, dtype=torch.int64, generator=gen)
+  ei = torch.stack([row, col])
+  del row, col
+  t0 = time.perf_counter()
+  g = Gr.CSRGraph(ei, n, device=dev)
+  torch.cuda.synchronize()
+  build_s = time.perf_counter() - t0
+  E = g.e
+  u = torch.empty(n, d, device=dev).normal_(generator=gen)
+  x0 = torch.empty(n, d, device=dev).normal_(generator=gen)
+  out = torch.empty_like(u)
+  w = torch.empty(E, device=dev).uniform_(generator=gen) / k
+  alpha = torch.zeros(1, device=dev)
+  beta = torch.full((1,), 0.1, device=dev)
+  t = timed_replay(lambda: ops.spmm_rhs(g, w, u, alpha, beta, x0, True, out=out), reps)
+  nbytes = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n       # SURVEY 8d: B_l + source
+  res = {'nodes': n, 'entries': E, 'd': d, 'neighbours_per_row': k, 'table_gib': round(n * d * 4 / 2 ** 30, 2),
+         'graph_build_seconds': round(build_s, 2), 'avg_launch_us': round(t * 1e6, 1),
+         'algorithmic_bytes_per_launch': nbytes, 'achieved': round(nbytes / t / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), 'frac_of_copy_rate': round(nbytes / t / 1e9 / HBM_COPY_GBS, 4),
+         'what': 'gnpde_spmm_rhs (the aggregation + epilogue the solver launches) on a device-generated graph: %d rows of %d floats '
+                 '(%.1f GiB table, %.0fx the Infinity Cache), %d uniformly random neighbours per row; algorithmic bytes '
+                 'E (8 + 4 d) + N (4 + 8 d) + 4 d N / launch time / 8 TB/s' % (n, d, n * d * 4 / 2 ** 30, n * d * 4 / 2 ** 28, k)}
+  del g, u, x0, out, w, ei
+  torch.cuda.empty_cache()
+  return res
+
+
+def pmc_child(G, block, x, reps=3):
+  """--pmc-child: the launches of one evaluation of f, eagerly, `reps` times -- the projection, the row attention and the four
+  rk4-stage variants of the aggregation on the solver's own graph -- and nothing else on the device afterwards (the parent folds
+  the counters of the gnpde:: kernels by name)."""
+  from gnpde_amd import ops, _lib
+  f = block.odefunc
+  graph, _ = solver_graph(f, x)
+  dev = x.device
+  bufs = [torch.randn_like(x) for _ in range(7)]
+  y, k1, k2, k3, ua, ub, x0 = bufs
+  alpha, beta = ops._scalar_dev(f.alpha_train, x), ops._scalar_dev(f.beta_train, x)
+  stages = [dict(stage=_lib.STAGE_RK1C, out_y=ua, u=y), dict(stage=_lib.STAGE_RK2C, y=y, out_y=ub, u=ua),
+            dict(stage=_lib.STAGE_RK3C, k1=ua, out_y=k1, u=ub), dict(stage=_lib.STAGE_RK4C, y=y, k1=ub, out_y=y, u=k1)]
+  w = torch.rand(max(graph.e, 1), device=dev) / 16
+  att = None
+  if hasattr(f, 'multihead_att_layer'):
+    lay = f.multihead_att_layer
+    wqk, bqk = lay.qk_weights()
+    A, h = lay.attention_dim, lay.h
+    qk = ops.linear(x, wqk, bqk)
+    att = ops.attention_struct(_lib.ATT_TYPES[f.opt['attention_type']], h, A, f.opt['attention_norm_idx'], f.opt['square_plus'],
+                               q=qk, k=qk[:, A:], ldqk=2 * A)
+  for _ in range(reps):
+    if att is not None:
+      ops.linear(x, wqk, bqk, out=qk)
+      ops.edge_attention(graph, att, True, False, False, like=x)
+    for st in stages:
+      kw = dict(st)
+      u = kw.pop('u')
+      ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
+  torch.cuda.synchronize()
+  print(json.dumps({'pmc_child': 'done', 'aggregation_calls': 4 * reps, 'evaluations': reps}))
+
+
+def live_pmc_traffic(args, reorder_mode, timeout_s=150):
+  """L2 -> fabric bytes of the evaluation's kernels, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE
+  TCC_HIT_sum TCC_MISS_sum -- separate passes, with --kernel-trace only, as MI355X_MICROARCH.md section "rocprofv3 PMC slots"
+  prescribes) over a child process of this script (--pmc-child) that launches the projection, the row attention and the four
+  stage variants of the aggregation three times on the same graph.  bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is in
+  KiB and tallies the 128-B requests of wide coalesced reads at 64 B on gfx950 (same guide, section HBM).  Returns
+  {kernel name: {...}} + '_calls', or {'error': ...}."""
+  import csv
+  import glob
+  import re
+  import shutil
+  import subprocess
+  import tempfile
+  exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+  if not os.path.exists(exe):
+    return {'error': 'rocprofv3 not found'}
+  base = tempfile.mkdtemp(prefix='gnpde_pmc_', dir='/tmp')
+  child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--graph', args.graph, '--scale', str(args.scale), '--seed', str(args.seed),
+           '--function', args.function, '--norm-idx', str(args.norm_idx), '--steps', '1', '--warmup', '0']
+  if args.att_dim:
+    child += ['--att-dim', str(args.att_dim)]
+  if args.heads:
+    child += ['--heads', str(args.heads)]
+  if args.square_plus:
+    child += ['--square-plus']
+  env = dict(os.environ, TMPDIR='/tmp', GNPDE_BENCH_REORDER=reorder_mode)
+  acc, calls = {}, None
+  t0 = time.perf_counter()
+  try:
+    for i, counters in enumerate((['FETCH_SIZE'], ['WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'])):
+      out_dir = os.path.join(base, 'pass%d' % i)
+      cmd = [exe, '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', out_dir, '-o', 'p', '--'] + child
+      res = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+      if res.returncode != 0:
+        return {'error': 'rocprofv3 pass %d exited with %d: %s' % (i, res.returncode, (res.stderr or res.stdout)[-300:])}
+      for line in res.stdout.splitlines():
+        if line.startswith('{"pmc_child"'):
+          calls = json.loads(line)
+      found = glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True)
+      if not found:
+        return {'error': 'rocprofv3 pass %d wrote no counter_collection.csv' % i}
+      for path in found:
+        for r in csv.DictReader(open(path)):
+          name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+          name = re.sub(r'^void ', '', name).split('(')[0]
+          if not name.startswith('gnpde::'):
+            continue
+          ent = acc.setdefault(name, {}).setdefault(r['Counter_Name'], [0, 0.0])
+          ent[0] += 1
+          ent[1] += float(r['Counter_Value'])
+  except subprocess.TimeoutExpired:
+    return {'error': 'rocprofv3 pass timed out after %d s' % timeout_s}
+  except Exception as exc:   # noqa: BLE001 -- the line must not be lost to a profiler problem
+    return {'error': repr(exc)[:300]}
+  finally:
+    shutil.rmtree(base, ignore_errors=True)
+  out = {}
+  for name, cs in acc.items():
+    launches = max(v[0] for v in cs.values())
+    tot = {c: v[1] for c, v in cs.items()}
+    rec = {'launches': launches}
+    if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
+      rec['fetch_bytes_total'] = 2.0 * tot['FETCH_SIZE'] * 1024
+      rec['write_bytes_total'] = tot['WRITE_SIZE'] * 1024
+      rec['bytes_per_launch'] = (rec['fetch_bytes_total'] + rec['write_bytes_total']) / launches
+    if tot.get('TCC_HIT_sum', 0) + tot.get('TCC_MISS_sum', 0) > 0:
+      rec['l2_hit_rate'] = round(tot['TCC_HIT_sum'] / (tot['TCC_HIT_sum'] + tot['TCC_MISS_sum']), 4)
+    out[name] = rec
+  out['_calls'] = calls
+  out['_seconds'] = round(time.perf_counter() - t0, 1)
+  return out
+
+
+def traffic_of(pmc, pattern, calls):
+  """Bytes per call of the kernels whose name holds `pattern` (a call of the aggregation = its row kernel + the hub-row fold)."""
+  recs = [(k, v) for k, v in pmc.items() if not k.startswith('_') and pattern in k and 'bytes_per_launch' in v]
+  if not recs or not calls:
+    return None
+  total = sum(v['fetch_bytes_total'] + v['write_bytes_total'] for _, v in recs)
+  big = max(recs, key=lambda kv: kv[1]['fetch_bytes_total'])
+  return {'bytes_per_call': total / calls, 'fetch_bytes_per_call': sum(v['fetch_bytes_total'] for _, v in recs) / calls,
+          'write_bytes_per_call': sum(v['write_bytes_total'] for _, v in recs) / calls,
+          'kernels': {k: {'launches': v['launches'], 'bytes_per_launch': round(v['bytes_per_launch']), 'l2_hit_rate': v.get('l2_hit_rate')}
+                      for k, v in recs},
+          'l2_hit_rate': big[1].get('l2_hit_rate')}
+
+
 def cpu_baseline(block, x_cpu, evals):
   """Reference op sequence (oracle) on the host cores: a bounded number of full-size evaluations of f."""
   from oracle import restate as R
@@ -296,27 +507,29 @@ def cpu_baseline(block, x_cpu, evals):
   else:
     w = cpu(f.edge_weight)
     rhs = lambda y: R.rhs_laplacian(y, edge, w, cpu(f.alpha_train), cpu(f.beta_train), x_cpu, False, True)
-  # torch's CPU scatter/gather ops do not scale to every core of a large host: try a few thread counts
-  # (one evaluation each) and time the sample at the best one, so the baseline is not handicapped
+  # torch's CPU scatter/gather ops do not scale to every core of a large host: the thread count is chosen from the MEDIAN of
+  # three evaluations per candidate (one sample each made the choice -- 8 or 32 threads -- a coin toss, +-15 % on the baseline)
   ncpu = os.cpu_count() or 1
   cands = sorted({c for c in (ncpu, 64, 32, 16, 8) if c <= ncpu}, reverse=True)
-  best_t, best_c = None, ncpu
+  trials = {}
   with torch.no_grad():
     torch.set_num_threads(cands[0])
     out = rhs(x_cpu)  # warm-up, also the parity reference
     for c in cands:
       torch.set_num_threads(c)
-      t0 = time.perf_counter()
-      rhs(x_cpu)
-      t = time.perf_counter() - t0
-      if best_t is None or t < best_t:
-        best_t, best_c = t, c
+      ts = []
+      for _ in range(3):
+        t0 = time.perf_counter()
+        rhs(x_cpu)
+        ts.append(time.perf_counter() - t0)
+      trials[c] = sorted(ts)[1]
+    best_c = min(trials, key=lambda c: trials[c])
     torch.set_num_threads(best_c)
     t0 = time.perf_counter()
     for _ in range(evals):
       rhs(x_cpu)
     dt = (time.perf_counter() - t0) / evals
-  return dt, out
+  return dt, out, {str(c): round(v * 1e3, 1) for c, v in trials.items()}
 
 
 def main():
@@ -354,8 +567,14 @@ def main():
   K, W = args.steps, args.warmup
   use_graph = not args.no_graph
 
+  if os.environ.get('GNPDE_BENCH_REORDER'):      # the PMC child runs on the node order its parent's solver chose
+    opt['gnpde_reorder'] = os.environ['GNPDE_BENCH_REORDER']
   main_block = make_block(G, opt, ei, n, x, dev, float(K), args.seed)
   main_block.set_x0(x)
+  if args.pmc_child:
+    with torch.no_grad():
+      pmc_child(G, main_block, x)
+    return
   early = None
   if args.early_stop:
     gen = torch.Generator().manual_seed(args.seed + 1)
@@ -398,7 +617,7 @@ def main():
   E = int(f.edge_index.shape[1])
   A, h = opt['attention_dim'], opt['heads']
 
-  # roofline of the dominant kernel (DESIGN.md: B_spmm = E (4 + 4 + 4d) + N (4 + 8d) + 4dN with add_source)
+  # roofline of the dominant kernel (DESIGN.md section 4: B_spmm = E (4 + 4 + 4d) + N (4 + 8d) + 4dN with add_source)
   if args.no_roofline_probe:
     print(json.dumps({'metric': metric_name(args.graph, d), 'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1,
                       'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
@@ -412,60 +631,82 @@ def main():
   bytes_nl = E * (4 + 4 * A + 4 * d) + n * (4 + 12 * A + 12 * d) + 4 * d * n   # SURVEY.md 8d, B_nl + source
   bytes_spmm = bytes_nl if fused else bytes_l
   achieved = bytes_spmm / t_spmm / 1e9
-  ceiling = gather_ceiling(G, x, n, E, graph)          # the graph's own references, balanced
-  ceiling_uniform = gather_ceiling(G, x, n, E)       # no reuse at all (what round 3's first lines were quoted against)
+  ceiling = gather_ceiling(G, x, n, E, graph)          # informational only (a kernel of this repository, not a roofline)
+  try:
+    stream = stream_read_probe(x)
+  except Exception as exc:   # noqa: BLE001
+    stream = {'error': repr(exc)[:200]}
   try:
     secondary = [] if fused else secondary_kernels(G, main_block, x, E, n, ceiling)
   except Exception as exc:   # (a probe that cannot run must not cost the line)
     secondary = [{'error': repr(exc)[:200]}]
-  try:
-    # counter traffic of the same launches from the PMC record of this shape (profiles/hbm_traffic.json, `detail`): what the
-    # kernels really moved next to what the model says they need
-    det = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))['detail']['%s_d%d_spmm' % (args.graph, d)]
-    for ent, pat in zip(secondary, ('row_attention_sd_kernel', 'linear_')):
-      recs = [v for k, v in det['kernels'].items() if pat in k and 'bytes_per_launch' in v]
-      if recs and 'avg_us' in ent:
-        tb = sum(r['bytes_per_launch'] for r in recs) if pat.startswith('row') else max(r['bytes_per_launch'] for r in recs)
-        ent['traffic'] = round(tb)
-        ent['traffic_gbs'] = round(tb / (ent['avg_us'] * 1e-6) / 1e9, 1)
-        ent['l2_hit_rate'] = [r.get('l2_hit_rate') for r in recs]
-        ent['traffic_commit'] = det.get('commit')
-  except Exception:   # noqa: BLE001 -- no record for this shape
-    pass
-  traffic = None
-  tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-  if os.path.exists(tpath):
-    try:
-      traffic = json.load(open(tpath)).get('%s_d%d_%s' % (args.graph, d, 'fused' if fused else 'spmm'))
-    except Exception:
-      traffic = None
   bytes_eval = bytes_nl if args.function == 'transformer' else bytes_l
   # compulsory DRAM bytes of one aggregation launch with perfect reuse of gathered rows (SURVEY 8d B_min without the
   # projection): colidx + w + one read of u + the per-row streams (x0 in, out)
   dram_floor = E * 8 + n * (4 + 12 * d)
   state_mb = n * d * 4 / 2 ** 20
   resident = bool(state_mb < 256)
-  # What `achieved`, `peak` and `frac` are.
-  #  * Table >> Infinity Cache (R-MAT): every gathered row comes from DRAM.  achieved = gather-model (algorithmic) bytes of one
-  #    launch / its duration, peak = HBM's 8 TB/s (the task's definition).
-  #  * Table inside the 256-MiB Infinity Cache (ogbn-arxiv, 83 MiB): the gathered rows come from L2 / MALL and HBM's rate does
-  #    not bound them (a fraction of it can exceed 1 and means nothing).  The bound is the rate at which the memory system
-  #    delivers randomly addressed rows of this table: achieved = bytes of the E gathered rows alone / launch duration,
-  #    peak = the same quantity of a perfectly balanced gather of THE SAME column ids in CSR order measured in this run
-  #    (gnpde_gather_ceiling: no weights, no epilogue streams, no skew) -- the aggregation also streams 3 N d-float operands on
-  #    average on top of its gathers (x0 in and one row out in every stage, y and k1 in two of four: 11 us per 87-MB stream at
-  #    this shape, tools/agg_streams.py), so it cannot reach that rate; the gap IS mostly those streams.
-  row_gather = E * 4 * d / t_spmm / 1e9
-  if resident and ceiling is not None:
-    bound, ach, peak = 'l2-miss/MALL', row_gather, ceiling['row_gather_gbs']
-    peak_src = 'measured in this run: row-gather rate of gnpde_gather_ceiling on the same table (see `ceiling`)'
-    ach_is = ('bytes of the gathered neighbour rows alone (E * 4 d) of one aggregation launch / its average duration over the four '
-              'rk4 stage variants, timed in this run (HIP events around a captured graph of the launches); the gather-model rate '
-              'with every stream counted is `gather_model_gbs`')
-  else:
-    bound, ach, peak, peak_src = 'hbm', achieved, HBM_PEAK_GBS, 'HBM3E peak, MI355X_MICROARCH.md'
-    ach_is = ('gather-model (algorithmic) bytes of one aggregation launch / its average duration over the four rk4 stage variants, '
-              'timed in this run (HIP events around a captured graph of the launches)')
+  _, view = solver_graph(f, x)
+  reorder_mode = '0' if view is None else ('degree' if 'descending' in str(view.stats.get('order', '')) else 'parts')
+
+  # ---- counter traffic: live PMC passes over a child of this script; the stored record only as a marked fallback ----
+  now_hash = kernel_sources_sha16()
+  traffic, traffic_src = None, None
+  pmc = None if (args.no_live_pmc or fused) else live_pmc_traffic(args, reorder_mode)
+  if isinstance(pmc, dict) and 'error' not in pmc and pmc.get('_calls'):
+    agg = traffic_of(pmc, 'spmm_', pmc['_calls']['aggregation_calls'])
+    if agg is not None:
+      traffic = agg['bytes_per_call']
+      traffic_src = {'how': 'measured in this run: rocprofv3 --pmc (two passes: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, --kernel-trace '
+                            'only) over a child process of bench.py that launches one evaluation\'s kernels %d times on the same graph; '
+                            'bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024 per call of the aggregation (row kernel + hub-row fold)'
+                            % pmc['_calls']['evaluations'],
+                     'live': True, 'stale': False, 'seconds': pmc.get('_seconds'), 'fetch_bytes': round(agg['fetch_bytes_per_call']),
+                     'write_bytes': round(agg['write_bytes_per_call']), 'l2_hit_rate': agg['l2_hit_rate'], 'kernels': agg['kernels'],
+                     'kernel_sources_sha16': now_hash}
+      for ent, pat, ncalls in zip(secondary, ('row_attention', 'linear_'), (pmc['_calls']['evaluations'],) * 2):
+        rec = traffic_of(pmc, pat, ncalls)
+        if rec is not None and 'avg_us' in ent:
+          ent['traffic'] = round(rec['bytes_per_call'])
+          ent['traffic_gbs'] = round(rec['bytes_per_call'] / (ent['avg_us'] * 1e-6) / 1e9, 1)
+          ent['frac_traffic'] = round(ent['traffic_gbs'] / HBM_PEAK_GBS, 4)
+          ent['l2_hit_rate'] = [v.get('l2_hit_rate') for v in rec['kernels'].values()]
+          ent['traffic_is'] = 'live PMC passes of this run'
+  pmc_error = pmc.get('error') if isinstance(pmc, dict) and 'error' in pmc else None
+  if traffic is None:
+    tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+      stored = json.load(open(tpath)).get('%s_d%d_%s' % (args.graph, d, 'fused' if fused else 'spmm'))
+    except Exception:   # noqa: BLE001
+      stored = None
+    if isinstance(stored, dict) and stored.get('bytes_per_launch'):
+      traffic = stored['bytes_per_launch']
+      traffic_src = {k: stored.get(k) for k in ('kernel', 'commit', 'fetch_bytes', 'write_bytes', 'l2_hit_rate', 'method')}
+      rec_hash = stored.get('kernel_sources_sha16')
+      traffic_src.update(how='STORED record of profiles/hbm_traffic.json (an earlier run of tools/pmc_traffic.py), not measured in this run',
+                         live=False, kernel_sources_sha16=now_hash, record_kernel_sources_sha16=rec_hash,
+                         # stale unless the record carries the hash of ALL kernel sources as they are now (spmm / attention / linear / epilogue)
+                         stale=bool(rec_hash is None or now_hash is None or rec_hash != now_hash))
+      if pmc_error:
+        traffic_src['live_pmc_error'] = pmc_error
+  elif pmc_error:
+    traffic_src['live_pmc_error'] = pmc_error
+
+  # What `achieved`, `peak` and `frac` are (the task's contract):
+  #   achieved         = algorithmic (gather-model) bytes of one aggregation call / its measured duration
+  #   peak             = HBM3E's 8 TB/s
+  #   frac_algorithmic = achieved / peak.  Exceeds 1 when the gathered table sits in the 256-MiB Infinity Cache (ogbn-arxiv: 83 MiB):
+  #                      the model charges every cache-served row to HBM.
+  #   frac_traffic     = counter bytes that crossed the L2 -> fabric boundary (Infinity-Cache hits included) / duration / peak
+  #   frac             = frac_traffic for a cache-resident table (bound "mall"), frac_algorithmic for a DRAM-resident one (bound "hbm");
+  #                      without any counter record, frac_algorithmic in both cases -- never a ceiling of our own making.
+  frac_alg = achieved / HBM_PEAK_GBS
+  frac_traffic = None if traffic is None else traffic / t_spmm / 1e9 / HBM_PEAK_GBS
+  use_traffic = resident and frac_traffic is not None and not traffic_src.get('stale', True)
+  try:
+    hbm_probe = None if args.no_hbm_probe else hbm_bound_probe(G, dev)
+  except Exception as exc:   # noqa: BLE001
+    hbm_probe = {'error': repr(exc)[:200]}
   out = {
     'metric': metric_name(args.graph, d),
     'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
@@ -486,57 +727,36 @@ def main():
                'xcd_contiguous_imbalance': round(graph.xcd_imbalance_contiguous, 4),
                'algorithmic_bytes_per_rhs_eval': bytes_eval,
                'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
-    'roofline': {'kernel': kname, 'bound': bound,
-                 'achieved': round(ach, 1), 'peak': peak, 'unit': 'GB/s',
-                 'frac': round(ach / peak, 4), 'peak_source': peak_src, 'achieved_is': ach_is,
-                 'gather_model_gbs': round(achieved, 1), 'row_gather_gbs': round(row_gather, 1),
-                 'frac_of_row_gather_ceiling': None if ceiling is None else round(row_gather / ceiling['row_gather_gbs'], 4),
-                 'hbm_peak': HBM_PEAK_GBS,
-                 'frac_of_hbm_peak': None if resident else round(achieved / HBM_PEAK_GBS, 4),
-                 'hbm_copy_rate': HBM_COPY_GBS,
-                 'ceiling': ceiling, 'ceiling_uniform_random_ids': ceiling_uniform,
-                 'epilogue_stream_bytes_per_launch_avg': 4 * d * n * 3,   # x0 + out every stage, y and k1 in two of four: 12 per step
-                 'traffic': None, 'traffic_gbs': None,
+    'roofline': {'kernel': kname, 'bound': 'mall' if resident else 'hbm',
+                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': round(frac_traffic if use_traffic else frac_alg, 4),
+                 'frac_is': ('frac_traffic: L2 -> fabric bytes of one aggregation call (counter record, `traffic`; includes Infinity-Cache hits) / '
+                             'its duration / the 8 TB/s HBM peak -- the gathered table (%.0f MiB) is resident in the 256-MiB Infinity Cache, so '
+                             'the gather model (`achieved`, `frac_algorithmic`) charges cache-served rows to HBM and exceeds the peak' % state_mb)
+                 if use_traffic else 'frac_algorithmic: algorithmic bytes / duration / the 8 TB/s HBM peak (SURVEY 8d)',
+                 'frac_algorithmic': round(frac_alg, 4),
+                 'frac_algorithmic_is': 'gather model (every non-zero fetches its neighbour row, no cache reuse credited) / duration / 8 TB/s'
+                                        + ('; table cache-resident: not a fraction of anything physical' if resident else ''),
+                 'frac_traffic': None if frac_traffic is None else round(frac_traffic, 4),
+                 'traffic': None if traffic is None else round(traffic),
+                 'traffic_gbs': None if traffic is None else round(traffic / t_spmm / 1e9, 1),
+                 'traffic_is': 'L2 -> fabric bytes per aggregation call (includes Infinity-Cache hits: MI355X_MICROARCH.md section HBM)',
+                 'traffic_source': traffic_src,
+                 'achieved_is': 'algorithmic (gather-model) bytes of one aggregation call / its average duration over the four rk4 stage '
+                                'variants, timed in this run (HIP events around a captured graph of the launches on the launch stream)',
                  'algorithmic_bytes_per_launch': bytes_spmm, 'avg_launch_us': round(t_spmm * 1e6, 2),
+                 'hbm_copy_rate': HBM_COPY_GBS, 'frac_algorithmic_of_copy_rate': round(achieved / HBM_COPY_GBS, 4),
                  'compulsory_gather_bytes_per_launch': E * (4 + 4 * d) + n * (4 + 12 * d),
-                 'dram_floor_bytes': dram_floor,
-                 'gathered_table_mib': round(state_mb, 1),
-                 'table_fits_infinity_cache': resident,
-                 'secondary': secondary,
-                 'note': ('the gathered state (%.0f MiB) fits the 256 MiB Infinity Cache: the gather-model bytes are served by '
-                          'L2 / MALL, so HBM bandwidth is not their ceiling; `frac` = row-gather rate of the aggregation / row-gather '
-                          'rate of a perfectly balanced gather from the same table measured in this run' % state_mb) if resident else
-                         ('the gathered state (%.0f MiB) exceeds the 256 MiB Infinity Cache: gathers are DRAM traffic '
-                          'except for hub columns; `frac` is against the HBM peak' % state_mb)},
+                 'dram_floor_bytes': dram_floor, 'frac_dram_floor': round(dram_floor / t_spmm / 1e9 / HBM_PEAK_GBS, 4),
+                 'gathered_table_mib': round(state_mb, 1), 'table_fits_infinity_cache': resident,
+                 'stream_read_probe': stream,
+                 'hbm_bound_probe': hbm_probe,
+                 'row_gather_gbs': round(E * 4 * d / t_spmm / 1e9, 1),
+                 'own_gather_kernel': None if ceiling is None else dict(
+                   ceiling, note='informational: a kernel of this repository (balanced gather of the same column ids), NOT the roofline'),
+                 'epilogue_stream_bytes_per_launch_avg': 4 * d * n * 3,   # x0 + out every stage, y and k1 in two of four: 12 per step
+                 'secondary': secondary},
   }
-  if isinstance(traffic, dict):   # measured PMC record (tools/pmc_traffic.py): bytes + provenance
-    tb = traffic.get('bytes_per_launch')
-    out['roofline']['traffic'] = tb
-    out['roofline']['traffic_gbs'] = round(tb / t_spmm / 1e9, 1) if tb else None
-    if tb and not resident:
-      out['roofline']['traffic_frac_of_hbm_peak'] = round(tb / t_spmm / 1e9 / HBM_PEAK_GBS, 4)
-    src = {k: traffic.get(k) for k in ('kernel', 'commit', 'fetch_bytes', 'write_bytes', 'l2_hit_rate', 'method', 'source_sha16')}
-    now = source_sha16('graph-neural-pde_amd/csrc/spmm.hip')
-    # the record is stale when csrc/spmm.hip is no longer the file it was measured with (hash stored by tools/pmc_traffic.py)
-    src['stale'] = bool(traffic.get('source_sha16') is None or now is None or traffic.get('source_sha16') != now)
-    src['spmm_hip_sha16_now'] = now
-    out['roofline']['traffic_source'] = src
-  rf = out['roofline']
-  if not resident and rf['frac'] > 1.0:
-    # The gather model charges every neighbour row to HBM; when the hot rows of a power-law graph hit in L2 the model's bytes
-    # exceed what crosses the memory interface and "algorithmic bytes / HBM peak" is no longer a fraction of anything.  Then
-    # `frac` = bytes that DID cross it (PMC record of the same command, `traffic`) / launch duration / HBM peak; without a
-    # fresh record, the row-gather rate against the measured gather ceiling.  The contract's ratio stays in `frac_algorithmic`.
-    rf['frac_algorithmic'] = rf['frac']
-    fresh = isinstance(traffic, dict) and traffic.get('bytes_per_launch') and not rf.get('traffic_source', {}).get('stale', True)
-    if fresh:
-      rf['frac'] = rf['traffic_frac_of_hbm_peak']
-      rf['frac_is'] = ('measured HBM-side bytes of one launch (rocprofv3 PMC record of the same command, `traffic`) / its duration / the '
-                       '8 TB/s HBM peak: the gather model (`achieved`, `frac_algorithmic`) exceeds the peak because %.0f %% of the gathered '
-                       'lines hit in L2' % (100.0 * (traffic.get('l2_hit_rate') or 0.0)))
-    elif rf.get('frac_of_row_gather_ceiling') is not None:
-      rf['frac'] = rf['frac_of_row_gather_ceiling']
-      rf['frac_is'] = 'row-gather rate of the launch / row-gather rate of the balanced gather of the same column ids measured in this run (`ceiling`)'
   _, view = solver_graph(f, x)
   if view is not None and early is None:
     # the timed solve ran on the relabelled graph: the same K steps on the graph as given, outside the timed region, must agree
@@ -570,7 +790,7 @@ def main():
                                       '[E,d] temporaries of %.0f GB each (SURVEY 8d: "reference path OOM"); pass '
                                       '--cpu-evals N to time it on a host that has the memory' % (E * d * 4 / 1e9))
   elif not args.no_cpu_baseline:
-    t_eval, ref = cpu_baseline(main_block, x_cpu, cpu_evals)
+    t_eval, ref, thread_trials = cpu_baseline(main_block, x_cpu, cpu_evals)
     with torch.no_grad():
       f.x0 = x
       got = f(0.0, x)
@@ -582,8 +802,9 @@ def main():
       'kind_note': 'oracle/restate.py = the reference op sequence (index_select -> mul -> scatter_add, PyG softmax) in '
                    'torch CPU; the reference src/ itself needs /root/reference and third-party wheels that do not exist '
                    'on the GPU box',
-      'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the best of a few torch thread '
-                'counts (`threads_used` of `host_cores`); steps/s = 1 / (4 t_eval)' % (cpu_evals, cpu_evals / 4.0),
+      'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the torch thread count with the best median '
+                'of three evaluations (`thread_trials_ms`: median ms per evaluation by thread count); steps/s = 1 / (4 t_eval)' % (cpu_evals, cpu_evals / 4.0),
+      'thread_trials_ms': thread_trials,
       'ms_per_rhs_eval': round(t_eval * 1e3, 2)})
     out['parity_vs_oracle_one_eval'] = {'rel_max': e_inf, 'rel_l2': e_2}
     out['speedup_vs_cpu'] = round(steps_per_s / out['cpu_baseline']['value'], 1)

@@ -151,6 +151,7 @@ PROTOTYPES = {
                                        ctypes.c_int32, c_vp]),
   'gnpde_gather_ceiling': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp,
                                           ctypes.c_int32, ctypes.c_int32, c_vp]),
+  'gnpde_stream_read': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_quantile_workspace_bytes': (ctypes.c_size_t, []),
   'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_dopri5_workspace_bytes': (ctypes.c_size_t, [c_vp]),

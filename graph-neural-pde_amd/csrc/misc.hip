@@ -347,6 +347,58 @@ extern "C" int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py's roofline, `stream_read_probe`): a coalesced streaming READ of a table -- every 16-byte lane of
+// the grid walks the table with a grid stride, eight loads in flight, one add per loaded value, one float per workgroup
+// written.  On a table that exceeds the L2s (32 MiB) but fits the Infinity Cache this is the rate the memory side delivers
+// L2-cold lines at: a hardware number for the cache-resident regime, not a gather.
+namespace gnpde {
+__global__ __launch_bounds__(kBlock) void stream_read_kernel(const float4* __restrict__ src, long long n4, int passes,
+                                                             float* __restrict__ sink) {
+  const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < passes; ++p) {   // whole-table passes inside ONE launch: the ramp of a 15-us kernel is not in the rate
+    long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+      float4 v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = src[i + t * stride];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w; }
+    }
+    for (; i < n4; i += stride) {
+      const float4 v = src[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    asm volatile("" ::: "memory");     // the next pass re-reads memory
+  }
+  float s = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+  __shared__ float part[kWavesPerBlock];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
+    sink[blockIdx.x] = t;
+  }
+}
+}  // namespace gnpde
+
+extern "C" int gnpde_stream_read(const float* table, int64_t n_floats, int32_t passes, float* sink, int32_t n_sink, void* stream) {
+  GNPDE_CHECK_ARG(table && sink && passes >= 1 && n_floats >= 4 && n_floats % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0, GNPDE_EINVAL,
+                  "stream_read: a 16-byte aligned table of a multiple of 4 floats");
+  long long blocks = (n_floats / 4 + gnpde::kBlock * 8 - 1) / (gnpde::kBlock * 8);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  GNPDE_CHECK_ARG(n_sink >= blocks, GNPDE_EWS, "stream_read: sink of %d floats < %lld workgroups", n_sink, blocks);
+  hipLaunchKernelGGL(gnpde::stream_read_kernel, dim3(static_cast<unsigned>(blocks)), dim3(gnpde::kBlock), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(table), static_cast<long long>(n_floats / 4), passes, sink);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
 namespace gnpde {
 int launch_lincomb(const float* base, const float* const* v, const float* coef, int32_t n_v, int64_t n, float* out,
                    hipStream_t s, const float* scale) {

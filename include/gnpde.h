@@ -532,6 +532,14 @@ int gnpde_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int3
 int gnpde_gather_ceiling(const float* table, int32_t n_rows, int32_t d, int32_t ld, const int32_t* idx, int32_t k,
                          float* out, int32_t n_out, int32_t variant /* 0: ids loaded per lane, 1: coalesced + shuffle */, void* stream);
 
+/* Measurement aid, no reference equivalent (bench.py's `roofline.stream_read_probe`): a coalesced streaming read of
+ * n_floats floats, `passes` times inside one launch (16-byte lanes, grid stride, eight loads in flight per lane), one float
+ * per workgroup written to sink
+ * (n_sink >= 2048).  The rate the memory side delivers L2-cold lines of a table at -- the hardware ceiling next to which the
+ * aggregation's gather of the same table (torch_sparse.spmm's index_select, src/function_transformer_attention.py:25-36) is
+ * reported when that table is resident in the Infinity Cache. */
+int gnpde_stream_read(const float* table, int64_t n_floats, int32_t passes, float* sink, int32_t n_sink, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Edge-set bookkeeping of the hard-attention / rewiring blocks (once per training forward):
  *   threshold = torch.quantile(score, q);  mask = score > threshold;  edge_index[:, mask];  kept scores renormalised by their
