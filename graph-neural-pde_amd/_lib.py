@@ -133,6 +133,13 @@ PROTOTYPES = {
   'gnpde_solver_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.c_int32,
                                          c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
   'gnpde_solver_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_adjoint_grad_floats': (ctypes.c_int, [ctypes.POINTER(RhsStruct)]),
+  'gnpde_adjoint_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), ctypes.c_int32]),
+  'gnpde_adjoint_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, c_vp, c_vp,
+                                          ctypes.c_int32, c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
+  'gnpde_adjoint_run': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_adjoint_num_rhs_evals': (ctypes.c_int, [c_vp]),
+  'gnpde_adjoint_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_rhs_eval': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_rhs_stage': (ctypes.c_int, [ctypes.POINTER(RhsStruct), c_vp, ctypes.POINTER(EpilogueStruct), c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_rk_error_ratio': (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_float_p, ctypes.c_int32, ctypes.c_float,

@@ -147,8 +147,14 @@ class ODEFunc(nn.Module):
     if mode == 'auto' and self.training:
       # training forwards may hand over a NEW edge set every step (hard attention, rewiring: reference
       # src/block_transformer_hard_attention.py:55-61) -- a clustering and a timing run per step would cost more than any order
-      # can return; the automatic rule is for evaluation (module.eval()), where the graph stays
-      return None
+      # can return.  So the automatic rule applies in training only from the SECOND solve on the same edge_index tensor
+      # (identity and version unchanged since the previous solve: constant / attention blocks, every epoch after the first)
+      ei = self.edge_index
+      key = (ei, ei._version) if ei is not None else None
+      last = self.__dict__.get('_reorder_seen')
+      self.__dict__['_reorder_seen'] = key          # (holds the tensor itself: its id cannot be reused while it is remembered)
+      if key is None or last is None or last[0] is not key[0] or last[1] != key[1]:
+        return None
     return self._graph(x).locality_view(4 * int(x.shape[1]), mode)
 
   def _check_nfe(self):

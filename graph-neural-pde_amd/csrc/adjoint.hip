@@ -1,0 +1,572 @@
+// Native adjoint solve: the backward pass of ODEblock.forward when opt['adjoint'] is set (reference src/base_classes.py:44-47,
+// src/block_constant.py:45-55 hand the integration to torchdiffeq.odeint_adjoint) for the fixed-grid adjoint methods
+// (`adjoint_method` euler / rk4 == 3/8 rule, `adjoint_step_size`).  torchdiffeq integrates the augmented system
+//     y' = f(y),   a' = -a^T df/dy,   g' = -a^T df/dtheta
+// backwards in time through the substitution s = -t and evaluates f and its vector-Jacobian products with autograd -- per stage
+// one forward of ODEFunc.forward (reference src/function_transformer_attention.py:38-53, src/function_laplacian_diffusion.py:38-51),
+// one autograd backward through index_select / scatter_add / softmax, and a dozen elementwise launches of stage algebra.
+// Here one stage is a fixed sequence of this library's kernels and the whole backward solve is ONE captured hipGraph:
+//   q||k = u_y [Wq;Wk]^T + b                     (fp32 MFMA projection, linear.hip)
+//   w    = head mean of the normalised attention (attention.hip, the inference kernels)
+//   F    = alpha (A u_y - u_y) + beta x0         (aggregation, spmm.hip) -- its epilogue forms the NEXT stage input u_y
+//   r_e  = u_a[row] . u_y[col]                   (SDDMM)
+//   ds   = normaliser backward (alpha / H folded in); dq = sum_row ds k, dk = sum_col ds q  (backward.hip)
+//   P    = [dq dk] [Wq;Wk]                       (projection kernel on the transposed weights)
+//   V    = alpha (A^T u_a - u_a) + P             (aggregation on the transposed CSR with the weights permuted) -- its epilogue
+//                                                  forms the NEXT stage input u_a
+//   g   += c ([dq dk]^T u_y, colsum [dq dk], d alpha, d beta)   (one pass over the rows + a fold, below)
+// No PyTorch op runs inside the solve.  GRAND-l (constant weights) is the same without the attention steps.
+#include <vector>
+#include "common.h"
+#include "rhs.h"
+#include "epilogue.h"
+
+namespace gnpde {
+
+int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                      int ldo, hipStream_t s, int relu = 0);
+int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
+                          float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
+size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
+
+namespace {
+
+constexpr int kParamBlocks = 1024;      // row slabs of the parameter-gradient pass
+constexpr int kGramTile = 32;          // rows of the Gram block (m) one workgroup accumulates
+
+struct ParamArgs {
+  const float* __restrict__ dqk;   // [n, M] or null (GRAND-l)
+  const float* __restrict__ uy;    // [n, ld] stage input of the state
+  const float* __restrict__ ua;    // [n, ld] stage input of the adjoint
+  const float* __restrict__ F;     // [n, ld] f(u_y) of this stage
+  const float* __restrict__ x0;    // [n, ld] or null
+  int n, d, ld, M;
+  int rows_per_block;
+  int stride;                      // floats per block partial: M d + M + 2
+  float* __restrict__ partial;     // [gridDim.x, stride]
+};
+
+// partial[b][m, c] = sum_{i in slab b} dqk[i, m] u_y[i, c]   and   partial[b][M d + m] = sum_i dqk[i, m]
+// The weight gradients d[Wq;Wk] = [dq dk]^T u_y are a [M, n] x [n, d] product with n >> M, d: every workgroup takes a slab of rows
+// and a tile of kGramTile m's; its four wavefronts walk the slab's rows interleaved.  A lane owns VC consecutive columns of the
+// state row (one coalesced load per row and wave); the row of dqk is wave-uniform, so its kGramTile values arrive by SCALAR loads
+// and feed the FMAs as SGPR operands: kGramTile x VC accumulators per lane, no cross-lane traffic until the four waves fold their
+// blocks through the LDS (fixed order).  Lanes 0..kGramTile-1 also keep the column sums of dqk (the bias gradients).
+template <int VC>
+__global__ __launch_bounds__(kBlock) void adjoint_gram_kernel(const ParamArgs p) {
+  __shared__ float fold[3][8][kWave * VC];
+  __shared__ float bfold[3][kGramTile];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int col = lane * VC;
+  const int m0 = static_cast<int>(blockIdx.y) * kGramTile;
+  const int mt = p.M - m0 < kGramTile ? p.M - m0 : kGramTile;     // live m's of this tile (a multiple of 4)
+  const int r0 = static_cast<int>(blockIdx.x) * p.rows_per_block;
+  int r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  float acc[kGramTile][VC];
+#pragma unroll
+  for (int m = 0; m < kGramTile; ++m)
+#pragma unroll
+    for (int c = 0; c < VC; ++c) acc[m][c] = 0.f;
+  float bsum = 0.f;
+  float cm[VC];
+#pragma unroll
+  for (int c = 0; c < VC; ++c) cm[c] = col + c < p.d ? 1.0f : 0.0f;   // padded rows: columns [d, ld) are not data
+  const bool col_ok = col < p.d;
+  // two rows per iteration: both rows' loads (vector and scalar) are issued before the first FMA
+  for (int i = r0 + wave; i < r1; i += 2 * kWavesPerBlock) {
+    const int i2 = i + kWavesPerBlock;
+    const bool two = i2 < r1;                                                        // wave-uniform
+    const float* __restrict__ qa = p.dqk + static_cast<size_t>(i) * p.M + m0;       // wave-uniform addresses
+    const float* __restrict__ qb = p.dqk + static_cast<size_t>(two ? i2 : i) * p.M + m0;
+    float xa[VC], xb[VC];
+#pragma unroll
+    for (int c = 0; c < VC; ++c) xa[c] = xb[c] = 0.f;
+    if (col_ok) {
+      load_vec<VC>(p.uy + static_cast<size_t>(i) * p.ld + col, xa);
+      if (two) load_vec<VC>(p.uy + static_cast<size_t>(i2) * p.ld + col, xb);
+    }
+    float ql = lane < mt ? qa[lane] : 0.f;
+    if (two && lane < mt) ql += qb[lane];
+    const float sb = two ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < VC; ++c) { xa[c] *= cm[c]; xb[c] *= cm[c] * sb; }
+    bsum += ql;
+#pragma unroll
+    for (int m = 0; m < kGramTile; ++m) {
+      const float q1 = m < mt ? qa[m] : 0.f;
+      const float q2 = m < mt ? qb[m] : 0.f;
+#pragma unroll
+      for (int c = 0; c < VC; ++c) acc[m][c] = fmaf(q2, xb[c], fmaf(q1, xa[c], acc[m][c]));
+    }
+  }
+  // fold the four waves in slices of 8 m's
+  float* out = p.partial + static_cast<size_t>(blockIdx.x) * p.stride;
+#pragma unroll
+  for (int s = 0; s < kGramTile / 8; ++s) {
+    if (wave > 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int c = 0; c < VC; ++c) fold[wave - 1][m][c * kWave + lane] = acc[s * 8 + m][c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int mm = s * 8 + m;
+#pragma unroll
+        for (int c = 0; c < VC; ++c) {
+          const float v = ((acc[mm][c] + fold[0][m][c * kWave + lane]) + fold[1][m][c * kWave + lane]) + fold[2][m][c * kWave + lane];
+          if (mm < mt && col + c < p.d) out[static_cast<size_t>(m0 + mm) * p.d + col + c] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave > 0 && lane < kGramTile) bfold[wave - 1][lane] = bsum;
+  __syncthreads();
+  if (wave == 0 && lane < mt) out[static_cast<size_t>(p.M) * p.d + m0 + lane] = ((bsum + bfold[0][lane]) + bfold[1][lane]) + bfold[2][lane];
+}
+
+// partial[b][M d + M + {0, 1}] = sum over slab b of u_a . F and u_a . x0  (d alpha_train, d beta_train come from them in the fold)
+__global__ __launch_bounds__(kBlock) void adjoint_dots_kernel(const ParamArgs p) {
+  __shared__ float red[kWavesPerBlock][2];
+  const int r0 = static_cast<int>(blockIdx.x) * p.rows_per_block;
+  int r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  const int d4 = (p.d + 3) / 4;                  // 16-byte lanes per row
+  const long long items = static_cast<long long>(r1 > r0 ? r1 - r0 : 0) * d4;
+  float d1 = 0.f, d2 = 0.f;
+  for (long long it = threadIdx.x; it < items; it += kBlock) {
+    const int i = r0 + static_cast<int>(it / d4), col = static_cast<int>(it % d4) * 4;
+    const size_t off = static_cast<size_t>(i) * p.ld + col;
+    const float4 g = *reinterpret_cast<const float4*>(p.ua + off);
+    const float4 f = *reinterpret_cast<const float4*>(p.F + off);
+    const float gg[4] = {g.x, col + 1 < p.d ? g.y : 0.f, col + 2 < p.d ? g.z : 0.f, col + 3 < p.d ? g.w : 0.f};
+    d1 = fmaf(gg[0], f.x, d1); d1 = fmaf(gg[1], f.y, d1); d1 = fmaf(gg[2], f.z, d1); d1 = fmaf(gg[3], f.w, d1);
+    if (p.x0 != nullptr) {
+      const float4 s = *reinterpret_cast<const float4*>(p.x0 + off);
+      d2 = fmaf(gg[0], s.x, d2); d2 = fmaf(gg[1], s.y, d2); d2 = fmaf(gg[2], s.z, d2); d2 = fmaf(gg[3], s.w, d2);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    d1 += __shfl_xor(d1, off, kWave);
+    d2 += __shfl_xor(d2, off, kWave);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) { red[threadIdx.x >> 6][0] = d1; red[threadIdx.x >> 6][1] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* out = p.partial + static_cast<size_t>(blockIdx.x) * p.stride + static_cast<size_t>(p.M) * p.d + p.M;
+    out[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    out[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+// grads[idx] += coef * sum_b partial[b][idx]; the two dot slots become  d alpha_train = (1 - sigma)(sum u_a.F - beta sum u_a.x0)
+// (f - beta x0 = sigma (A x - x), d sigma / d alpha_train = sigma (1 - sigma))  and  d beta_train = sum u_a.x0.
+// Block = 64 outputs x 4 slices of the slabs, slices folded through the LDS in order.
+__global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float* __restrict__ partial, int nb, int stride, int n_plain,
+                                                                   float coef, const float* __restrict__ alpha,
+                                                                   const float* __restrict__ beta, int has_source,
+                                                                   float* __restrict__ grads) {
+  __shared__ float part[4][64][2];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = static_cast<int>(blockIdx.x) * 64 + o;
+  const bool dot_slot = idx == n_plain;                       // this thread folds BOTH dot sums
+  const bool live = idx < n_plain || dot_slot;
+  float s1 = 0.f, s2 = 0.f;
+  if (live) {
+    const int per = (nb + 3) / 4;
+    int b0 = sl * per, b1 = b0 + per;
+    if (b1 > nb) b1 = nb;
+    const float* p = partial + static_cast<size_t>(b0) * stride + idx;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8, p += 8 * static_cast<size_t>(stride)) {
+      float v[8], w[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        v[t] = p[t * static_cast<size_t>(stride)];
+        w[t] = dot_slot ? p[t * static_cast<size_t>(stride) + 1] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { s1 += v[t]; s2 += w[t]; }
+    }
+    for (; b < b1; ++b, p += stride) {
+      s1 += p[0];
+      if (dot_slot) s2 += p[1];
+    }
+  }
+  part[sl][o][0] = s1;
+  part[sl][o][1] = s2;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  s1 = ((part[0][o][0] + part[1][o][0]) + part[2][o][0]) + part[3][o][0];
+  s2 = ((part[0][o][1] + part[1][o][1]) + part[2][o][1]) + part[3][o][1];
+  if (!dot_slot) {
+    grads[idx] = fmaf(coef, s1, grads[idx]);
+    return;
+  }
+  const float a = *alpha;
+  const float sig = 1.0f / (1.0f + expf(-a));
+  const float b = has_source ? *beta : 0.f;
+  grads[n_plain] = fmaf(coef, (1.0f - sig) * (s1 - b * s2), grads[n_plain]);
+  grads[n_plain + 1] = fmaf(coef, has_source ? s2 : 0.f, grads[n_plain + 1]);
+}
+
+__global__ __launch_bounds__(kBlock) void permute_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n,
+                                                            float* __restrict__ dst) {
+  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+}  // namespace
+}  // namespace gnpde
+
+using namespace gnpde;
+
+struct gnpde_adjoint {
+  gnpde_rhs_t rhs;
+  gnpde_graph_t graph, graph_t;
+  const int32_t* t_from_csr;
+  const float* proj_wt;
+  const float* w_t_fixed;
+  int method;
+  std::vector<float> dts;
+  char* ws;
+  size_t ws_bytes;
+  // workspace regions
+  size_t state_bytes;
+  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one;
+  char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
+  size_t att_bytes, attbwd_bytes, spmm_bytes, spmm_t_bytes;
+  int M, stride;
+  bool rows_bwd;             // one-pass row softmax backward (else the general normaliser backward)
+  bool zeroed = false;
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph_obj = nullptr;
+  hipGraphExec_t exec = nullptr;
+  float *cap_y = nullptr, *cap_a = nullptr, *cap_g = nullptr;
+  int n_evals = 0;
+};
+
+namespace {
+
+bool rows_bwd_shape(const gnpde_attention_t& at) {
+  if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
+  const int h = at.heads, dk = at.att_dim / at.heads;
+  return (h == 1 || h == 2 || h == 4 || h == 8) && (dk == 4 || dk == 8 || dk == 16);
+}
+
+int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
+  int rc = check_rhs(rhs);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(gt != nullptr && gt->n == rhs->graph->n && gt->e == rhs->graph->e, GNPDE_EINVAL,
+                  "adjoint: the transposed graph does not match the descriptor's graph");
+  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "adjoint: bad method %d", method);
+  GNPDE_CHECK_ARG(rhs->kind == GNPDE_RHS_LAPLACIAN || rhs->kind == GNPDE_RHS_TRANSFORMER, GNPDE_ESHAPE,
+                  "adjoint: GRAND-l and GRAND-nl (scaled-dot) only");
+  GNPDE_CHECK_ARG(rhs->alpha_sigmoid == 1, GNPDE_ESHAPE, "adjoint: the native solve needs alpha' = sigmoid(alpha_train)");
+  GNPDE_CHECK_ARG(rhs->ld % 4 == 0 && rhs->d <= 256 && (rhs->d % 4 == 0 || (rhs->flags & GNPDE_RHS_PADDED_ROWS)), GNPDE_ESHAPE,
+                  "adjoint: state rows of up to 256 floats in 16-byte lanes (d %% 4 == 0 or padded rows)");
+  GNPDE_CHECK_ARG(rhs->n_state_rows <= rhs->graph->n && rhs->proj_row_end == 0 && rhs->graph->row_begin == 0, GNPDE_ESHAPE,
+                  "adjoint: whole-graph descriptors only");
+  if (rhs->kind == GNPDE_RHS_TRANSFORMER) {
+    const gnpde_attention_t& at = rhs->att;
+    const int a4 = at.att_dim / 4;
+    GNPDE_CHECK_ARG(at.type == GNPDE_ATT_SCALED_DOT, GNPDE_ESHAPE, "adjoint: scaled-dot scores only");
+    GNPDE_CHECK_ARG(at.att_dim % at.heads == 0 && (at.att_dim / at.heads) % 4 == 0 && a4 <= 64 && (a4 & (a4 - 1)) == 0, GNPDE_ESHAPE,
+                    "adjoint: attention_dim / 4 must be a power of two <= 64 and d_k a multiple of 4");
+  }
+  return 0;
+}
+
+size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method, gnpde_adjoint* s) {
+  const gnpde_graph_t& g = *r.graph;
+  const size_t state = align_up(static_cast<size_t>(g.n) * r.ld * 4, 256);
+  const bool nl = r.kind == GNPDE_RHS_TRANSFORMER;
+  const int M = nl ? r.proj_m : 0;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0;
+  for (int i = 0; i < 2; ++i) { o_uy[i] = take(state); o_ua[i] = take(state); }
+  const int nF = method == GNPDE_METHOD_RK4 ? 4 : 1, nV = method == GNPDE_METHOD_RK4 ? 3 : 0;
+  for (int i = 0; i < 4; ++i) o_F[i] = i < nF ? take(state) : 0;
+  for (int i = 0; i < 3; ++i) o_V[i] = i < nV ? take(state) : 0;
+  const size_t o_one = take(256);
+  const size_t e4 = static_cast<size_t>(g.e > 0 ? g.e : 1) * 4;
+  size_t att_b = 0, attbwd_b = 0;
+  if (nl) {
+    o_P = take(state);
+    o_qk = take(static_cast<size_t>(g.n) * M * 4);
+    o_dqk = take(static_cast<size_t>(g.n) * M * 4);
+    o_w = take(e4); o_wt = take(e4); o_r = take(e4);
+    o_ds = take(e4 * r.att.heads);
+    att_b = attention_workspace_bytes(&g, r.att.heads, false);
+    attbwd_b = gnpde_attention_bwd_workspace_bytes(&g, &r.att);
+  }
+  const size_t o_att = take(att_b), o_attbwd = take(attbwd_b);
+  const size_t spmm_b = gnpde_spmm_workspace_bytes(&g, r.d), spmm_t_b = gnpde_spmm_workspace_bytes(&gt, r.d);
+  const size_t o_spmm = take(spmm_b), o_spmm_t = take(spmm_t_b);
+  const int stride = M * r.d + M + 2;
+  const size_t o_part = take(static_cast<size_t>(kParamBlocks) * stride * 4);
+  if (s) {
+    char* b = s->ws;
+    auto f = [&](size_t o) { return reinterpret_cast<float*>(b + o); };
+    for (int i = 0; i < 2; ++i) { s->uy[i] = f(o_uy[i]); s->ua[i] = f(o_ua[i]); }
+    for (int i = 0; i < 4; ++i) s->F[i] = i < nF ? f(o_F[i]) : nullptr;
+    for (int i = 0; i < 3; ++i) s->V[i] = i < nV ? f(o_V[i]) : nullptr;
+    s->one = f(o_one);
+    s->P = nl ? f(o_P) : nullptr; s->qk = nl ? f(o_qk) : nullptr; s->dqk = nl ? f(o_dqk) : nullptr;
+    s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = nl ? f(o_r) : nullptr; s->ds = nl ? f(o_ds) : nullptr;
+    s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
+    s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
+    s->partial = f(o_part);
+    s->state_bytes = state;
+    s->M = M; s->stride = stride;
+  }
+  return off;
+}
+
+// One stage: F = f(uy) with epilogue eF, V = (df/dy)^T ua with epilogue eV, parameter gradients accumulated with weight pcoef.
+int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fout, gnpde_epilogue_t eF, float* Vout,
+                  gnpde_epilogue_t eV, float pcoef, float* grads, hipStream_t st) {
+  const gnpde_rhs_t& r = s->rhs;
+  const gnpde_graph_t* g = &s->graph;
+  const gnpde_graph_t* gt = &s->graph_t;
+  const int n = g->n, d = r.d, ld = r.ld;
+  const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && ld % 4 == 0;
+  const bool nl = r.kind == GNPDE_RHS_TRANSFORMER;
+  const float* w = r.w_csr;
+  const float* wt = s->w_t_fixed;
+  int rc;
+  gnpde_attention_t at = r.att;
+  const int A = at.att_dim, M = s->M;
+  if (nl) {
+    rc = launch_linear_any(uy, n, d, ld, r.proj_w, M, d, r.proj_b, s->qk, M, st);
+    if (rc) return rc;
+    at.q = s->qk; at.k = s->qk + A; at.ldqk = M;
+    rc = launch_edge_attention(g, &at, s->w, nullptr, nullptr, s->ws_att, s->att_bytes, st, nullptr);
+    if (rc) return rc;
+    w = s->w;
+  }
+  eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
+  eF.stage = GNPDE_STAGE_LINCOMB; eF.out_k = Fout;
+  rc = launch_spmm_rhs(g, w, uy, d, ld, &eF, nullptr, s->ws_spmm, s->spmm_bytes, st, nullptr, padded);
+  if (rc) return rc;
+  const float* source = nullptr;
+  const float* source_scale = nullptr;
+  if (nl) {
+    rc = gnpde_sddmm(g, ua, ld, uy, ld, d, nullptr, 0, s->r, st);
+    if (rc) return rc;
+    if (s->rows_bwd) rc = gnpde_attention_rows_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, st);
+    else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
+    if (rc) return rc;
+    const int h = at.heads, dk = A / h;
+    const float inv = 1.0f / sqrtf(static_cast<float>(dk));
+    rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+    if (rc) return rc;
+    rc = gnpde_head_spmm(g, 1, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+    if (rc) return rc;
+    rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
+    if (rc) return rc;
+    if (g->e > 0) {
+      hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->w, s->t_from_csr, g->e, s->w_t);
+      GNPDE_LAUNCH_CHECK();
+    }
+    wt = s->w_t;
+    source = s->P;
+    source_scale = s->one;
+  }
+  // V = alpha (A^T ua - ua) [+ 1 * P]
+  eV.alpha = r.alpha; eV.beta = source_scale; eV.x0 = source; eV.alpha_sigmoid = r.alpha_sigmoid;
+  eV.stage = GNPDE_STAGE_LINCOMB; eV.out_k = Vout;
+  rc = launch_spmm_rhs(gt, wt, ua, d, ld, &eV, nullptr, s->ws_spmm_t, s->spmm_t_bytes, st, nullptr, padded);
+  if (rc) return rc;
+  // parameter gradients
+  ParamArgs p{};
+  p.dqk = nl ? s->dqk : nullptr; p.uy = uy; p.ua = ua; p.F = Fout; p.x0 = r.x0;
+  p.n = n; p.d = d; p.ld = ld; p.M = M;
+  p.rows_per_block = (n + kParamBlocks - 1) / kParamBlocks;
+  if (p.rows_per_block < 4) p.rows_per_block = 4;
+  const int nb = (n + p.rows_per_block - 1) / p.rows_per_block;
+  p.stride = s->stride; p.partial = s->partial;
+  if (nl) {
+    const unsigned gy = static_cast<unsigned>((M + kGramTile - 1) / kGramTile);
+    if (d <= 64) hipLaunchKernelGGL(adjoint_gram_kernel<1>, dim3(nb, gy), dim3(kBlock), 0, st, p);
+    else if (d <= 128) hipLaunchKernelGGL(adjoint_gram_kernel<2>, dim3(nb, gy), dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL(adjoint_gram_kernel<4>, dim3(nb, gy), dim3(kBlock), 0, st, p);
+    GNPDE_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(adjoint_dots_kernel, dim3(nb), dim3(kBlock), 0, st, p);
+  GNPDE_LAUNCH_CHECK();
+  const int n_plain = M * d + M;
+  hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 63) / 64), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
+                     pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, grads);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStream_t st) {
+  const gnpde_rhs_t& r = s->rhs;
+  const size_t nbytes = static_cast<size_t>(r.graph->n) * r.ld * 4;
+  GNPDE_HIP(hipMemsetAsync(grads, 0, static_cast<size_t>(s->stride) * 4, st));
+  if (s->method == GNPDE_METHOD_EULER) {
+    float* cy = y; float* ca = a;
+    int flip = 0;
+    for (float dt : s->dts) {
+      gnpde_epilogue_t eF{}, eV{};
+      eF.y = cy; eF.out_y = s->uy[flip]; eF.n_prev = 0; eF.coef[0] = -dt;
+      eV.y = ca; eV.out_y = s->ua[flip]; eV.n_prev = 0; eV.coef[0] = dt;
+      int rc = enqueue_stage(s, cy, ca, s->F[0], eF, nullptr, eV, dt, grads, st);
+      if (rc) return rc;
+      cy = s->uy[flip]; ca = s->ua[flip];
+      flip ^= 1;
+    }
+    if (cy != y) {
+      GNPDE_HIP(hipMemcpyAsync(y, cy, nbytes, hipMemcpyDeviceToDevice, st));
+      GNPDE_HIP(hipMemcpyAsync(a, ca, nbytes, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+  }
+  float** F = s->F; float** V = s->V;
+  for (float dtf : s->dts) {
+    const double dt = dtf;
+    const float c3 = static_cast<float>(dt / 3.0), c8 = static_cast<float>(dt * 0.125), c38 = static_cast<float>(3.0 * (dt * 0.125));
+    gnpde_epilogue_t eF{}, eV{};
+    // stage 1: (y, a)
+    eF.y = y; eF.out_y = s->uy[0]; eF.n_prev = 0; eF.coef[0] = -c3;
+    eV.y = a; eV.out_y = s->ua[0]; eV.n_prev = 0; eV.coef[0] = c3;
+    int rc = enqueue_stage(s, y, a, F[0], eF, V[0], eV, c8, grads, st);
+    if (rc) return rc;
+    // stage 2: u = y - dt/3 F1, a + dt/3 V1  ->  next: y - dt F2 + dt/3 F1
+    eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
+    eF.y = y; eF.out_y = s->uy[1]; eF.n_prev = 1; eF.prev[0] = F[0]; eF.coef[0] = c3; eF.coef[1] = -dtf;
+    eV.y = a; eV.out_y = s->ua[1]; eV.n_prev = 1; eV.prev[0] = V[0]; eV.coef[0] = -c3; eV.coef[1] = dtf;
+    rc = enqueue_stage(s, s->uy[0], s->ua[0], F[1], eF, V[1], eV, c38, grads, st);
+    if (rc) return rc;
+    // stage 3  ->  next: y - dt F1 + dt F2 - dt F3
+    eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
+    eF.y = y; eF.out_y = s->uy[0]; eF.n_prev = 2; eF.prev[0] = F[0]; eF.prev[1] = F[1];
+    eF.coef[0] = -dtf; eF.coef[1] = dtf; eF.coef[2] = -dtf;
+    eV.y = a; eV.out_y = s->ua[0]; eV.n_prev = 2; eV.prev[0] = V[0]; eV.prev[1] = V[1];
+    eV.coef[0] = dtf; eV.coef[1] = -dtf; eV.coef[2] = dtf;
+    rc = enqueue_stage(s, s->uy[1], s->ua[1], F[2], eF, V[2], eV, c38, grads, st);
+    if (rc) return rc;
+    // stage 4  ->  y += -dt/8 (F1 + 3 F2 + 3 F3 + F4),  a += dt/8 (V1 + 3 V2 + 3 V3 + V4)   (in place: y and a are not gathered here)
+    eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
+    eF.y = y; eF.out_y = y; eF.n_prev = 3; eF.prev[0] = F[0]; eF.prev[1] = F[1]; eF.prev[2] = F[2];
+    eF.coef[0] = -c8; eF.coef[1] = -c38; eF.coef[2] = -c38; eF.coef[3] = -c8;
+    eV.y = a; eV.out_y = a; eV.n_prev = 3; eV.prev[0] = V[0]; eV.prev[1] = V[1]; eV.prev[2] = V[2];
+    eV.coef[0] = c8; eV.coef[1] = c38; eV.coef[2] = c38; eV.coef[3] = c8;
+    rc = enqueue_stage(s, s->uy[0], s->ua[0], F[3], eF, nullptr, eV, c8, grads, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+void drop_adjoint_graph(gnpde_adjoint* s) {
+  if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+  if (s->graph_obj) { (void)hipGraphDestroy(s->graph_obj); s->graph_obj = nullptr; }
+  s->cap_y = s->cap_a = s->cap_g = nullptr;
+}
+
+}  // namespace
+
+extern "C" int gnpde_adjoint_grad_floats(const gnpde_rhs_t* rhs) {
+  if (!rhs) return 0;
+  const int M = rhs->kind == GNPDE_RHS_TRANSFORMER ? rhs->proj_m : 0;
+  return M * rhs->d + M + 2;
+}
+
+extern "C" size_t gnpde_adjoint_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, int32_t method) {
+  if (check_adjoint(rhs, graph_t, method)) return 0;
+  return adjoint_layout(*rhs, *graph_t, method, nullptr);
+}
+
+extern "C" int gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t,
+                                    const int32_t* t_from_csr, const float* proj_wt, const float* w_t_csr, int32_t method,
+                                    const float* dts, int32_t n_steps, void* workspace, size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "adjoint_create: out is null");
+  *out = nullptr;
+  int rc = check_adjoint(rhs, graph_t, method);
+  if (rc) return rc;
+  GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "adjoint_create: bad time grid");
+  if (rhs->kind == GNPDE_RHS_TRANSFORMER)
+    GNPDE_CHECK_ARG(t_from_csr != nullptr && proj_wt != nullptr && reinterpret_cast<uintptr_t>(proj_wt) % 16 == 0, GNPDE_EINVAL,
+                    "adjoint_create: GRAND-nl needs the position map of the transposed graph and the transposed projection weights");
+  else
+    GNPDE_CHECK_ARG(w_t_csr != nullptr || rhs->graph->e == 0, GNPDE_EINVAL, "adjoint_create: GRAND-l needs the weights in the transposed graph's order");
+  gnpde_adjoint* s = new gnpde_adjoint();
+  s->rhs = *rhs;
+  s->graph = *rhs->graph;
+  s->rhs.graph = &s->graph;
+  s->graph_t = *graph_t;
+  s->t_from_csr = t_from_csr;
+  s->proj_wt = proj_wt;
+  s->w_t_fixed = w_t_csr;
+  s->method = method;
+  s->dts.assign(dts, dts + n_steps);
+  s->rows_bwd = rhs->kind == GNPDE_RHS_TRANSFORMER && rows_bwd_shape(rhs->att) && rhs->proj_m % 4 == 0;
+  const size_t need = adjoint_layout(s->rhs, s->graph_t, method, nullptr);
+  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
+    set_error("adjoint_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+    delete s;
+    return GNPDE_EWS;
+  }
+  s->ws = static_cast<char*>(workspace);
+  s->ws_bytes = workspace_bytes;
+  adjoint_layout(s->rhs, s->graph_t, method, s);
+  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
+  *out = s;
+  return 0;
+}
+
+extern "C" int gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* grads, int32_t use_graph, void* stream) {
+  GNPDE_CHECK_ARG(s && y && a && grads && y != a, GNPDE_EINVAL, "adjoint_run: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!s->zeroed) {
+    // stage buffers start as zeros (the padding columns of padded rows are never written by the projection kernel) and the
+    // unit scale of the V epilogue's source term is set once; ordered before everything else on the caller's stream
+    const size_t head = static_cast<size_t>(reinterpret_cast<char*>(s->partial) - s->ws);
+    GNPDE_HIP(hipMemsetAsync(s->ws, 0, head, st));
+    const float one = 1.0f;
+    GNPDE_HIP(hipMemcpyAsync(s->one, &one, sizeof(float), hipMemcpyHostToDevice, st));
+    GNPDE_HIP(hipStreamSynchronize(st));   // (the host scalar above must not go out of scope before the copy ran)
+    s->zeroed = true;
+  }
+  if (!use_graph) return enqueue_adjoint(s, y, a, grads, st);
+  if (s->exec == nullptr || s->cap_y != y || s->cap_a != a || s->cap_g != grads) {
+    drop_adjoint_graph(s);
+    if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
+    GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_adjoint(s, y, a, grads, s->cap_stream);
+    hipGraph_t gobj = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
+    if (rc != 0) {
+      if (gobj) (void)hipGraphDestroy(gobj);
+      return rc;
+    }
+    if (ec != hipSuccess) {
+      set_error("adjoint_run: hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+      return static_cast<int>(ec);
+    }
+    s->graph_obj = gobj;
+    GNPDE_HIP(hipGraphInstantiate(&s->exec, s->graph_obj, nullptr, nullptr, 0));
+    s->cap_y = y; s->cap_a = a; s->cap_g = grads;
+  }
+  GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int gnpde_adjoint_num_rhs_evals(const gnpde_adjoint_t* s) { return s ? s->n_evals : 0; }
+
+extern "C" int gnpde_adjoint_destroy(gnpde_adjoint_t* s) {
+  if (!s) return 0;
+  drop_adjoint_graph(s);
+  if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+  delete s;
+  return 0;
+}

@@ -572,6 +572,128 @@ def _adjoint_fixed_grid(func, params, y, a, gparams, span, method, step_size):
   return a, gparams
 
 
+def _adjoint_native_ok(func, y, method):
+  """The fixed-grid adjoint solve runs as ONE native object (csrc/adjoint.hip) for GRAND-l and for GRAND-nl with scaled-dot
+  scores (any normaliser) when alpha' = sigmoid(alpha_train); everything else keeps the stage-by-stage loop above."""
+  if method not in ('euler', 'rk4') or not hasattr(func, '_descriptor'):
+    return False
+  if not (y.is_cuda and y.dim() == 2 and y.dtype == torch.float32 and y.shape[1] <= 256):
+    return False
+  opt = func.opt
+  if opt.get('no_alpha_sigmoid') or opt.get('gnpde_composite_backward') or opt.get('gnpde_host_adjoint'):
+    return False
+  kind = func.__class__.__name__
+  if kind == 'LaplacianODEFunc':
+    return True       # the weights are constants of the solve: torchdiffeq's adjoint returns gradients for y0 and func.parameters() only
+  if kind == 'ODEFuncTransformerAtt':
+    from .autograd import _native_transformer_vjp_ok
+    lay = func.multihead_att_layer
+    return bool(_native_transformer_vjp_ok(func)) and (2 * lay.attention_dim) % 4 == 0
+  return False
+
+
+def _transposed_positions(graph):
+  """(graph_t, t_from_csr): CSR of the transposed operator over the same edge list, and for every position of graph_t the CSR
+  position of the same entry in `graph` (both stable sorts of one edge list: composed through the edge ids)."""
+  hit = graph.__dict__.get('_t_from_csr')
+  if hit is None:
+    gt = graph.transposed()
+    inv = torch.empty(graph.e, dtype=torch.int64, device=graph.device)
+    inv[graph.perm_long] = torch.arange(graph.e, dtype=torch.int64, device=graph.device)
+    t_from_csr = inv[gt.perm_long].to(torch.int32).contiguous() if graph.e > 0 else torch.zeros(1, dtype=torch.int32, device=graph.device)
+    hit = graph.__dict__['_t_from_csr'] = (gt, t_from_csr)
+  return hit
+
+
+def _adjoint_native(func, params, y, a, span, method, step_size):
+  """(a at the earlier time, [gradient contribution per entry of `params`]) of one backward interval, by the native solver."""
+  from . import ops
+  from .utils import MaxNFEException
+  grid = time_grid(span.detach().to('cpu'), step_size)
+  dts = (grid[1:] - grid[:-1]).tolist()
+  n_evals = len(dts) * (4 if method == 'rk4' else 1)
+  room = func.opt['max_nfe'] + 1 - func.nfe
+  if n_evals > room:
+    func.nfe += max(room, 0)
+    raise MaxNFEException
+  st = func.__dict__.setdefault('_adjoint_state', {})
+  view = func._locality_view(y) if hasattr(func, '_locality_view') else None
+  key = (method, tuple(dts), tuple(y.shape), str(y.device), id(view))
+  ent = st.get(key)
+  if ent is None:
+    for old in st.values():
+      if old.get('solver') is not None:
+        old['solver'].close()
+    st.clear()
+    n, d = y.shape
+    ent = st[key] = {'y': _lib.alloc_state(n, d, y.device), 'a': _lib.alloc_state(n, d, y.device),
+                     'x0': _lib.alloc_state(n, d, y.device) if func.opt['add_source'] else None,
+                     'solver': None, 'sig': None, 'view': view, 'extra': {}}
+  yb, ab = ent['y'], ent['a']
+  if view is None:
+    yb.copy_(y.detach())
+    ab.copy_(a.detach())
+  else:
+    view.enter(y.detach(), out=yb)
+    view.enter(a.detach(), out=ab)
+  if ent['x0'] is not None:
+    if func.x0 is None:
+      raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+    if view is None:
+      ent['x0'].copy_(func.x0.detach())
+    else:
+      view.enter(func.x0.detach(), out=ent['x0'])
+  graph = func._graph(y) if view is None else view.graph
+  desc = func._descriptor(yb, x0_override=ent['x0'], graph=graph)
+  gt, t_from_csr = _transposed_positions(graph)
+  nl = func.__class__.__name__ == 'ODEFuncTransformerAtt'
+  ex = ent['extra']
+  proj_wt = w_t = None
+  if nl:
+    wqk, _ = func.multihead_att_layer.qk_weights()
+    if ex.get('proj_wt') is None or ex['proj_wt'].shape != (wqk.shape[1], wqk.shape[0]):
+      ex['proj_wt'] = torch.empty(wqk.shape[1], wqk.shape[0], dtype=torch.float32, device=y.device)
+    ex['proj_wt'].copy_(wqk.t())                 # refreshed in place: the captured graph keeps the pointer
+    proj_wt = ex['proj_wt']
+  else:
+    w_csr = func._weights_csr(graph)
+    if ex.get('w_t') is None or ex['w_t'].numel() != max(graph.e, 1):
+      ex['w_t'] = torch.empty(max(graph.e, 1), dtype=torch.float32, device=y.device)
+    if graph.e > 0:
+      torch.index_select(w_csr[:graph.e], 0, t_from_csr.long(), out=ex['w_t'][:graph.e])
+    w_t = ex['w_t']
+  sig = (func._descriptor_signature(desc), id(gt))
+  if ent['solver'] is None or ent['sig'] != sig:
+    if ent['solver'] is not None:
+      ent['solver'].close()
+    ent['solver'] = ops.AdjointSolver(desc, gt, t_from_csr if nl else None, proj_wt, w_t, method, dts, y.device)
+    ent['grads'] = torch.zeros(ent['solver'].n_grad, dtype=torch.float32, device=y.device)
+    ent['sig'] = sig
+  sol = ent['solver']
+  sol.run(yb, ab, ent['grads'])
+  func.nfe += n_evals
+  a_out = torch.empty_like(a, memory_format=torch.contiguous_format)
+  if view is None:
+    a_out.copy_(ab)
+  else:
+    view.leave(ab, out=a_out)
+  g = ent['grads']
+  by_param = {}
+  if nl:
+    lay = func.multihead_att_layer
+    A, d = lay.attention_dim, y.shape[1]
+    gram = g[:2 * A * d].view(2 * A, d)
+    gb = g[2 * A * d:2 * A * d + 2 * A]
+    by_param = {id(lay.Q.weight): gram[:A], id(lay.K.weight): gram[A:], id(lay.Q.bias): gb[:A], id(lay.K.bias): gb[A:]}
+    tail = 2 * A * d + 2 * A
+  else:
+    tail = 0
+  by_param[id(func.alpha_train)] = g[tail].reshape(func.alpha_train.shape)
+  if func.opt['add_source']:
+    by_param[id(func.beta_train)] = g[tail + 1].reshape(func.beta_train.shape)
+  return a_out, [by_param.get(id(p)) for p in params]
+
+
 class _AdjointSolve(torch.autograd.Function):
   """Forward: the plain solve WITHOUT a tape -- on this package's functions that is the native hipGraph solver, so
   the training forward runs at inference speed and stores two states, not the trajectory.  Backward: the augmented
@@ -622,7 +744,11 @@ class _AdjointSolve(torch.autograd.Function):
         raise ValueError('fixed-grid adjoint methods need adjoint_options["step_size"]')
       for i in range(len(t) - 1, 0, -1):
         span = -t[i - 1:i + 1].flip(0)
-        if fixed:
+        if fixed and _adjoint_native_ok(func, state[1], adj['method']):
+          # the whole interval as one native object (one hipGraph; no PyTorch op between the stages)
+          state[2], contrib = _adjoint_native(func, params, state[1], state[2], span, adj['method'], options['step_size'])
+          state = state[:3] + [gp if c is None else gp + c.reshape(gp.shape) for gp, c in zip(state[3:], contrib)]
+        elif fixed:
           state[2], gp = _adjoint_fixed_grid(func, params, state[1], state[2], state[3:], span, adj['method'],
                                              options['step_size'])
           state = state[:3] + list(gp)

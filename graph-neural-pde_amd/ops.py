@@ -598,3 +598,47 @@ class FixedStepSolver(object):
 
   def __del__(self):
     self.close()
+
+
+class AdjointSolver(object):
+  """gnpde_adjoint_t: the fixed-grid adjoint solve (state, adjoint and parameter gradients integrated backwards), one hipGraph."""
+
+  def __init__(self, desc, graph_t, t_from_csr, proj_wt, w_t, method, dts, device):
+    self.desc, self.graph_t = desc, graph_t
+    self.keep = [t_from_csr, proj_wt, w_t]
+    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
+    self.dts = [float(v) for v in dts]
+    L = _lib.lib()
+    nbytes = L.gnpde_adjoint_workspace_bytes(desc.ref(), graph_t.ref(), self.method)
+    if nbytes == 0:
+      raise _lib.GnpdeError('native adjoint: %s' % L.gnpde_last_error().decode(errors='replace'))
+    self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    self.n_grad = int(L.gnpde_adjoint_grad_floats(desc.ref()))
+    arr = (ctypes.c_float * len(self.dts))(*self.dts)
+    handle = ctypes.c_void_p()
+    check(L.gnpde_adjoint_create(ctypes.byref(handle), desc.ref(), graph_t.ref(), ptr(t_from_csr), ptr(proj_wt), ptr(w_t), self.method,
+                                 arr, len(self.dts), ptr(self.ws), self.ws.numel()))
+    self.handle = handle
+    self.n_rhs_evals = L.gnpde_adjoint_num_rhs_evals(handle)
+
+  def run(self, y, a, grads, use_graph=True):
+    """y, a [n, ld] integrated backwards in place; grads [n_grad] receives the parameter gradients."""
+    require_hip(y, a, grads)
+    ld = self.desc.struct.ld
+    for t in (y, a):
+      if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) != ld:
+        raise _lib.GnpdeError('adjoint solve: state and adjoint must be float32 [n, d] with the descriptor\'s row stride')
+    if grads.dtype != torch.float32 or not grads.is_contiguous() or grads.numel() < self.n_grad:
+      raise _lib.GnpdeError('adjoint solve: gradient buffer of %d floats needed' % self.n_grad)
+    check(_lib.lib().gnpde_adjoint_run(self.handle, ptr(y), ptr(a), ptr(grads), int(bool(use_graph)), stream_of(y)))
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      try:
+        _lib.lib().gnpde_adjoint_destroy(self.handle)
+      except Exception:
+        pass
+      self.handle = None
+
+  def __del__(self):
+    self.close()

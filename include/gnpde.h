@@ -416,6 +416,33 @@ int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* wor
                    size_t workspace_bytes, void* stream);
 size_t gnpde_rhs_workspace_bytes(const gnpde_rhs_t* rhs);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native adjoint solve: the backward pass of ODEblock.forward under opt['adjoint'] (reference src/base_classes.py:44-47,
+ * src/block_constant.py:45-55 -> torchdiffeq.odeint_adjoint) for the fixed-grid adjoint methods (opt['adjoint_method'] euler /
+ * rk4 == 3/8 rule, opt['adjoint_step_size']).  torchdiffeq integrates  y' = f,  a' = -a^T df/dy,  g' = -a^T df/dtheta  backwards
+ * in time (s = -t) and gets f and the vector-Jacobian products from autograd through ODEFunc.forward
+ * (src/function_transformer_attention.py:38-53, src/function_laplacian_diffusion.py:38-51); here one stage is a fixed sequence
+ * of this library's kernels (projection, attention, aggregation with the NEXT stage input formed in its epilogue, SDDMM,
+ * normaliser backward, head-SpMMs, aggregation on the transposed CSR, one pass for the parameter gradients) and the whole
+ * backward solve is one captured hipGraph.  rhs: GNPDE_RHS_LAPLACIAN (constant weights) or GNPDE_RHS_TRANSFORMER with
+ * scaled-dot scores (any normaliser), alpha_sigmoid = 1, d <= 256 in 16-byte lanes.
+ *   graph_t      CSR of the transposed operator over the SAME edge list;
+ *   t_from_csr   [e] device (GRAND-nl): CSR position in rhs->graph of the entry stored at position p of graph_t;
+ *   proj_wt      [d, 2A] device (GRAND-nl): rhs->proj_w transposed;   w_t_csr  [e] device (GRAND-l): the weights in graph_t's order.
+ * gnpde_adjoint_run: y [n, ld] in: y(t1), out: the state integrated back to t0;  a [n, ld] in: dL/dy(t1), out: dL/dy(t0);
+ * grads [gnpde_adjoint_grad_floats] out: GRAND-nl  d[Wq;Wk] [2A, d], d[bq;bk] [2A], d alpha_train, d beta_train;
+ *                                        GRAND-l   d alpha_train, d beta_train.
+ * dts[n_steps]: the step sizes of the reversed-time grid (torchdiffeq's fixed grid over [-t1, -t0]). */
+typedef struct gnpde_adjoint gnpde_adjoint_t;
+int    gnpde_adjoint_grad_floats(const gnpde_rhs_t* rhs);
+size_t gnpde_adjoint_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, int32_t method);
+int    gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, const int32_t* t_from_csr,
+                            const float* proj_wt, const float* w_t_csr, int32_t method, const float* dts, int32_t n_steps,
+                            void* workspace, size_t workspace_bytes);
+int    gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* grads, int32_t use_graph, void* stream);
+int    gnpde_adjoint_num_rhs_evals(const gnpde_adjoint_t* s);
+int    gnpde_adjoint_destroy(gnpde_adjoint_t* s);
+
 /* f(u) of a descriptor with an arbitrary epilogue / stage (building block of host-controlled adaptive
  * solvers); the epilogue's alpha / beta / x0 / alpha_sigmoid fields are taken from the descriptor. */
 int gnpde_rhs_stage(const gnpde_rhs_t* rhs, const float* u, const gnpde_epilogue_t* epi, void* workspace,

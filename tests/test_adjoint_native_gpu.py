@@ -1,0 +1,185 @@
+"""The native adjoint solve (csrc/adjoint.hip: the whole backward interval as one hipGraph) against the stage-by-stage loop of
+odeint._adjoint_fixed_grid, which the reference-gradient fixtures of test_adjoint_gpu.py pin to torchdiffeq's odeint_adjoint
+(reference src/base_classes.py:44-47, src/block_constant.py:45-55).  Same blocks, same inputs, both paths; and the native path
+itself against float64 autograd through the oracle's right-hand side for one small case."""
+import pytest
+import torch
+
+import gnpde_amd as G
+from helpers import Data, assert_parity, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(**over):
+  opt = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False,
+             reweight_attention=False, beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9,
+             add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=32, augment=False, adjoint=True,
+             adjoint_method='rk4', adjoint_step_size=1.0, tol_scale=1.0, tol_scale_adjoint=1.0, data_norm='rw',
+             method='rk4', step_size=1.0, max_iters=100, block='constant', function='transformer', time=3.0,
+             att_samp_pct=1.0, use_flux=False)
+  opt.update(over)
+  return opt
+
+
+def _run(dev, opt, ei, x, seed, host):
+  o = dict(opt, gnpde_host_adjoint=bool(host))
+  fcls = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc}[o['function']]
+  bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}[o['block']]
+  block = bcls(fcls, [], o, Data(x, ei), dev, t=torch.tensor([0, o['time']])).to(dev)
+  g = torch.Generator().manual_seed(seed)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if p.dim() >= 2 and 'multihead_att_layer' in name:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      elif name.endswith('.bias') and 'multihead_att_layer' in name:
+        p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
+    for f in (block.odefunc, block.reg_odefunc.odefunc):
+      f.alpha_train.fill_(0.3)
+      f.beta_train.fill_(0.2)
+  block.train()
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  c = torch.randn(z.shape, generator=torch.Generator().manual_seed(seed + 7)).to(dev)
+  (z * c).sum().backward()
+  grads = {k: p.grad.detach().clone() for k, p in block.named_parameters() if p.grad is not None}
+  used_native = bool(block.odefunc.__dict__.get('_adjoint_state'))
+  return z.detach(), xin.grad.detach().clone(), grads, used_native, block.odefunc.nfe
+
+
+CASES = {
+  'nl_rk4': dict(),
+  'nl_euler': dict(adjoint_method='euler', adjoint_step_size=0.5, method='euler', step_size=0.5, time=2.0),
+  'nl_short_last_step': dict(time=2.3),
+  'nl_no_source': dict(add_source=False),
+  'nl_squareplus_cols': dict(square_plus=True, attention_norm_idx=1, attention_dim=32, heads=2),
+  'nl_softmax_cols': dict(attention_norm_idx=1),
+  'nl_heads8_dk16': dict(attention_dim=128, heads=8, hidden_dim=80),
+  'nl_d162_padded': dict(hidden_dim=162, attention_dim=32, heads=2),
+  'nl_d256': dict(hidden_dim=256, attention_dim=64, heads=4, time=2.0),
+  'l_rk4': dict(function='laplacian'),
+  'l_euler': dict(function='laplacian', adjoint_method='euler', adjoint_step_size=1.0),
+  'l_attention_block': dict(function='laplacian', block='attention'),
+}
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_native_adjoint_matches_stage_loop(dev, case):
+  opt = _opt(**CASES[case])
+  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded') else 0
+  n = 700
+  ei = random_graph(n, 6, seed=11, hubs=hubs, hub_deg=700, isolated=3, dup=20).to(dev)
+  x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(3))).to(dev)
+  z_h, gx_h, gp_h, native_h, nfe_h = _run(dev, opt, ei, x, 5, host=True)
+  z_n, gx_n, gp_n, native_n, nfe_n = _run(dev, opt, ei, x, 5, host=False)
+  assert not native_h and native_n, 'path selection: host %s native %s' % (native_h, native_n)
+  assert nfe_h == nfe_n
+  assert torch.equal(z_h, z_n)
+  tol = 2e-4     # long reductions in a different order (same bound as test_adjoint_gpu.py)
+  assert_parity(gx_n, gx_h, tol, case + ' grad_x')
+  assert set(gp_n) == set(gp_h)
+  checked = 0
+  scale = max(float(v.abs().max()) for v in gp_h.values())
+  for k in sorted(gp_h):
+    ref = gp_h[k]
+    if float(ref.abs().max()) < 1e-5 * max(scale, 1.0):      # mathematically zero (a row softmax does not see the key bias): rounding noise on both sides
+      assert float(gp_n[k].abs().max()) < 1e-4 * max(scale, 1.0), k
+    else:
+      assert_parity(gp_n[k], ref, tol, case + ' ' + k)
+      checked += 1
+  assert checked >= (2 if opt['function'] == 'laplacian' and opt['add_source'] else 1)
+
+
+def test_native_adjoint_replays_and_follows_parameter_updates(dev):
+  """A second backward replays the captured graph; after an optimiser-like in-place update of the parameters and a new x0 the
+  same solver object must produce the gradients of the NEW parameters (weights are read through stable pointers)."""
+  opt = _opt()
+  n = 500
+  ei = random_graph(n, 5, seed=2).to(dev)
+  x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(1))).to(dev)
+
+  def grads_of(block, xin):
+    for p in block.parameters():
+      p.grad = None
+    block.set_x0(xin)
+    z = block(xin)
+    z.pow(2).sum().backward()
+    return xin.grad.detach().clone(), {k: p.grad.detach().clone() for k, p in block.named_parameters() if p.grad is not None}
+
+  blocks = {}
+  for host in (True, False):
+    block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], dict(opt, gnpde_host_adjoint=host), Data(x, ei), dev,
+                               t=torch.tensor([0, opt['time']])).to(dev)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+      for name, p in block.named_parameters():
+        if p.dim() >= 2 and 'multihead_att_layer' in name:
+          p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+        elif name.endswith('.bias') and 'multihead_att_layer' in name:     # (nn.Linear draws its default bias from the global RNG)
+          p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
+    block.train()
+    blocks[host] = block
+  for it in range(3):
+    res = {}
+    for host in (True, False):
+      xin = (x * (1.0 + 0.1 * it)).clone().requires_grad_(True)
+      res[host] = grads_of(blocks[host], xin)
+      with torch.no_grad():          # the same in-place "optimiser step" on both
+        for name, p in blocks[host].named_parameters():
+          if 'multihead_att_layer.Q' in name or 'multihead_att_layer.K' in name or name.endswith('alpha_train'):
+            p.add_(0.01 * (it + 1))
+    assert_parity(res[False][0], res[True][0], 2e-4, 'iteration %d grad_x' % it)
+    for k in res[True][1]:
+      if float(res[True][1][k].abs().max()) > 1e-4:
+        assert_parity(res[False][1][k], res[True][1][k], 2e-4, 'iteration %d %s' % (it, k))
+  sol = blocks[False].odefunc.__dict__['_adjoint_state']
+  assert len(sol) == 1, 'one live adjoint solver per function object'
+
+
+def test_native_adjoint_against_float64_autograd(dev):
+  """Independent of the stage loop: d/dx0 and d/dtheta of sum(c * z(T)) by float64 autograd through the oracle's f and a
+  plain rk4 (3/8) loop -- the discretise-then-optimise gradient, which the adjoint solve approaches as O(h^4); at this step
+  size and smooth dynamics the two agree to ~1e-3, the bound used for the adaptive fixtures."""
+  from oracle import restate as R
+  opt = _opt(time=2.0, step_size=0.25, adjoint_step_size=0.25, hidden_dim=16, attention_dim=8, heads=2)
+  n = 120
+  ei = random_graph(n, 4, seed=4).to(dev)
+  x = (0.3 * torch.randn(n, 16, generator=torch.Generator().manual_seed(8))).to(dev)
+  z, gx, gp, native, _ = _run(dev, opt, ei, x, 5, host=False)
+  assert native
+  # float64 reference on the CPU
+  block = G.ConstantODEblock(G.ODEFuncTransformerAtt, [], dict(opt), Data(x, ei), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(5)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if p.dim() >= 2 and 'multihead_att_layer' in name:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      elif name.endswith('.bias') and 'multihead_att_layer' in name:
+        p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
+  f = block.odefunc
+  lay = f.multihead_att_layer
+  dd = lambda t: t.detach().double().cpu()
+  wq, bq, wk, bk = (dd(t).requires_grad_(True) for t in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias))
+  al = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+  be = torch.tensor(0.2, dtype=torch.float64, requires_grad=True)
+  x64 = dd(x).requires_grad_(True)
+  x0_64 = dd(x)                      # the source term is a detached copy (ODEblock.set_x0): no gradient through it
+  edge = f.edge_index.cpu()
+  rhs = lambda y: R.rhs_transformer(y, edge, wq, bq, wk, bk, lay.h, al, be, x0_64, False, True)
+  y = x64
+  h = 0.25
+  for _ in range(8):
+    k1 = rhs(y)
+    k2 = rhs(y + h * k1 / 3)
+    k3 = rhs(y + h * (k2 - k1 / 3))
+    k4 = rhs(y + h * (k1 - k2 + k3))
+    y = y + h * (k1 + 3 * (k2 + k3) + k4) / 8
+  c = torch.randn(z.shape, generator=torch.Generator().manual_seed(5 + 7)).double()
+  (y * c).sum().backward()
+  assert_parity(z, y.detach().float(), 1e-5, 'z vs float64 oracle')
+  assert_parity(gx, x64.grad.float(), 2e-3, 'grad_x vs float64 autograd')
+  assert_parity(gp['odefunc.multihead_att_layer.Q.weight'], wq.grad.float(), 2e-3, 'dWq')
+  assert_parity(gp['odefunc.multihead_att_layer.K.weight'], wk.grad.float(), 2e-3, 'dWk')
+  assert_parity(gp['odefunc.alpha_train'].reshape(()), al.grad.float(), 2e-3, 'dalpha')
+  assert_parity(gp['odefunc.beta_train'].reshape(()), be.grad.float(), 2e-3, 'dbeta')
