@@ -66,6 +66,9 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
+  ap.add_argument('--train', action='store_true',
+                  help='training iteration instead of the inference solve: forward (tape-free native solver) + backward (native adjoint '
+                       'solve, opt[adjoint] with adjoint_method rk4 / adjoint_step_size 1) of K steps each; prints its own JSON line')
   ap.add_argument('--replays', type=int, default=5, help='timed launches of the K-step solve (median reported)')
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
@@ -532,6 +535,83 @@ def cpu_baseline(block, x_cpu, evals):
   return dt, out, {str(c): round(v * 1e3, 1) for c, v in trials.items()}
 
 
+def train_main(G, args, opt, cfg, ei, n, x, dev):
+  """`--train`: one training iteration of the ODE block at the benchmark shape -- forward = the tape-free native solver (K rk4
+  steps, as inference), backward = the native adjoint solve (csrc/adjoint.hip: K rk4 steps of the augmented system, 4 K stages of
+  f + VJP + parameter gradients, one hipGraph), as the reference trains ogbn-arxiv (best_params adjoint=True; src/base_classes.py:44-47,
+  run_GNN.py:62-96).  The loss is sum(z * c) with a fixed random c; K steps forward AND backward are inside the timed region."""
+  d, K, W = cfg['d'], args.steps, args.warmup
+  A, h = opt['attention_dim'], opt['heads']
+  topt = dict(opt, adjoint=True, adjoint_method='rk4', adjoint_step_size=1.0, tol_scale_adjoint=1.0, time=float(K))
+  block = make_block(G, topt, ei, n, x, dev, float(K), args.seed)
+  block.train()
+  c = torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed + 3)).to(dev)
+
+  def iteration():
+    for p in block.parameters():
+      p.grad = None
+    xin = x.clone().requires_grad_(True)
+    block.set_x0(xin)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z = block(xin)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    (z * c).sum().backward()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, xin.grad
+
+  for _ in range(max(W, 2)):          # (graph capture, relabelling probe and allocator warm-up happen here)
+    iteration()
+  runs = [iteration() for _ in range(max(args.replays, 1))]
+  fw = sorted(r[0] for r in runs)[len(runs) // 2]
+  bw = sorted(r[1] for r in runs)[len(runs) // 2]
+  gx = runs[-1][2]
+  assert torch.isfinite(gx).all()
+  f = block.odefunc
+  E = int(f.edge_index.shape[1])
+  native = bool(f.__dict__.get('_adjoint_state'))
+  # algorithmic bytes of ONE adjoint stage (f + VJP + parameter gradients), gather model as SURVEY 8d (DESIGN.md section 5):
+  agg = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n                       # an aggregation with a source term (B_l + source)
+  b_rows = agg + 4 * E + 4 * d * n                                           # F + r_e written + g_i read
+  b_vt = agg                                                                 # V on the transposed CSR (P as the source term)
+  b_proj = n * (4 * d + 8 * A)                                               # q||k projection
+  b_att = E * (4 + 4 * A + 4) + n * (16 + 4 * A)                             # row attention -> w
+  b_attb = E * (4 + 4 + 4 * A + 4 * h) + n * (16 + 4 * A)                    # normaliser backward: colidx, r, k rows in; ds out
+  b_dqk = 2 * (E * (4 + 4 * h + 4 * A) + n * (16 + 4 * A)) + E * 4           # d q and d k (+ the position map of the transposed graph)
+  b_pg = n * (8 * A + 4 * d)                                                 # P = [dq dk] [Wq;Wk]
+  b_perm = E * 12                                                            # weights into the transposed order
+  b_gram = n * (8 * A + 4 * d)                                               # [dq dk]^T u_y
+  stage_bytes = b_rows + b_vt + b_proj + b_att + b_attb + b_dqk + b_pg + b_perm + b_gram
+  t_stage = bw / (4 * K)
+  out = {
+    'metric': 'training ODE steps/sec (forward solve + adjoint backward solve), %s d=%d rk4' % (GRAPH_NAMES.get(args.graph, args.graph), d),
+    'value': round(K / (fw + bw), 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
+    'ms_per_step': round(1e3 * (fw + bw) / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+    'dtype': 'f32', 'data': 'synthetic',
+    'config': {'workload': workload_name(args.graph, args.function, K) + '; TRAINING iteration: forward + adjoint (rk4, step 1) backward',
+               'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
+               'native_adjoint_solver': native, 'rhs_evals_forward': 4 * K, 'f_plus_vjp_stages_backward': 4 * K},
+    'forward_ms': round(fw * 1e3, 3), 'backward_ms': round(bw * 1e3, 3),
+    'f_plus_vjp_ms': round(t_stage * 1e3, 4),
+    'roofline': {'kernel': 'one stage of the adjoint solve = f + VJP + parameter gradients (projection, row attention, adjoint_rows_kernel '
+                           '[aggregation + SDDMM + dots], normaliser backward, d q / d k row sums, P GEMM, permute, aggregation on the '
+                           'transposed CSR, Gram + folds), timed as backward wall time / stages',
+                 'bound': 'mall' if n * d * 4 < 2 ** 28 else 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                 'unit': 'GB/s', 'frac': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'frac_is': 'frac_algorithmic: gather-model bytes of one stage / its time / 8 TB/s (no counter traffic in this mode; the '
+                            'state tables of this shape are Infinity-Cache resident)',
+                 'algorithmic_bytes_per_stage': stage_bytes,
+                 'bytes_by_kernel': {'adjoint_rows': b_rows, 'aggregation_transposed': b_vt, 'projection': b_proj, 'row_attention': b_att,
+                                     'normaliser_backward': b_attb, 'dq_dk_row_sums': b_dqk, 'p_gemm': b_pg, 'permute': b_perm, 'gram': b_gram},
+                 'traffic': None},
+    'cpu_baseline': None,
+    'note': 'rocprofv3 --kernel-trace --stats of this command: profiles/r04_train_*_kernel_stats.csv',
+  }
+  print(json.dumps(out))
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -575,6 +655,9 @@ def main():
     with torch.no_grad():
       pmc_child(G, main_block, x)
     return
+  if args.train:
+    del main_block
+    return train_main(G, args, opt, cfg, ei, n, x, dev)
   early = None
   if args.early_stop:
     gen = torch.Generator().manual_seed(args.seed + 1)

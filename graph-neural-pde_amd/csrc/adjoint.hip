@@ -31,7 +31,7 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 
 namespace {
 
-constexpr int kParamBlocks = 1024;      // row slabs of the parameter-gradient pass
+constexpr int kParamBlocks = 512;      // row slabs of the parameter-gradient pass
 constexpr int kGramTile = 32;          // rows of the Gram block (m) one workgroup accumulates
 
 struct ParamArgs {
@@ -74,31 +74,34 @@ __global__ __launch_bounds__(kBlock) void adjoint_gram_kernel(const ParamArgs p)
 #pragma unroll
   for (int c = 0; c < VC; ++c) cm[c] = col + c < p.d ? 1.0f : 0.0f;   // padded rows: columns [d, ld) are not data
   const bool col_ok = col < p.d;
-  // two rows per iteration: both rows' loads (vector and scalar) are issued before the first FMA
-  for (int i = r0 + wave; i < r1; i += 2 * kWavesPerBlock) {
-    const int i2 = i + kWavesPerBlock;
-    const bool two = i2 < r1;                                                        // wave-uniform
-    const float* __restrict__ qa = p.dqk + static_cast<size_t>(i) * p.M + m0;       // wave-uniform addresses
-    const float* __restrict__ qb = p.dqk + static_cast<size_t>(two ? i2 : i) * p.M + m0;
-    float xa[VC], xb[VC];
+  // R rows per iteration, every load (the rows of u_y, and the rows of dqk one value per lane) issued before the first FMA; the
+  // wave-uniform dqk[i, m] is handed to the FMAs by v_readlane (an SGPR operand): no scalar-memory round trip per row
+  constexpr int R = 8;
+  for (int i0 = r0 + wave; i0 < r1; i0 += R * kWavesPerBlock) {
+    float x[R][VC], ql[R];
 #pragma unroll
-    for (int c = 0; c < VC; ++c) xa[c] = xb[c] = 0.f;
-    if (col_ok) {
-      load_vec<VC>(p.uy + static_cast<size_t>(i) * p.ld + col, xa);
-      if (two) load_vec<VC>(p.uy + static_cast<size_t>(i2) * p.ld + col, xb);
+    for (int j = 0; j < R; ++j) {
+      const int i = i0 + j * kWavesPerBlock;
+      const bool live = i < r1;                    // wave-uniform
+#pragma unroll
+      for (int c = 0; c < VC; ++c) x[j][c] = 0.f;
+      ql[j] = 0.f;
+      if (live) {
+        if (col_ok) load_vec<VC>(p.uy + static_cast<size_t>(i) * p.ld + col, x[j]);
+        if (lane < mt) ql[j] = p.dqk[static_cast<size_t>(i) * p.M + m0 + lane];
+      }
     }
-    float ql = lane < mt ? qa[lane] : 0.f;
-    if (two && lane < mt) ql += qb[lane];
-    const float sb = two ? 1.0f : 0.0f;
 #pragma unroll
-    for (int c = 0; c < VC; ++c) { xa[c] *= cm[c]; xb[c] *= cm[c] * sb; }
-    bsum += ql;
+    for (int j = 0; j < R; ++j) {
 #pragma unroll
-    for (int m = 0; m < kGramTile; ++m) {
-      const float q1 = m < mt ? qa[m] : 0.f;
-      const float q2 = m < mt ? qb[m] : 0.f;
+      for (int c = 0; c < VC; ++c) x[j][c] *= cm[c];
+      bsum += ql[j];
 #pragma unroll
-      for (int c = 0; c < VC; ++c) acc[m][c] = fmaf(q2, xb[c], fmaf(q1, xa[c], acc[m][c]));
+      for (int m = 0; m < kGramTile; ++m) {
+        const float q = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql[j]), m));
+#pragma unroll
+        for (int c = 0; c < VC; ++c) acc[m][c] = fmaf(q, x[j][c], acc[m][c]);
+      }
     }
   }
   // fold the four waves in slices of 8 m's
@@ -130,26 +133,15 @@ __global__ __launch_bounds__(kBlock) void adjoint_gram_kernel(const ParamArgs p)
   if (wave == 0 && lane < mt) out[static_cast<size_t>(p.M) * p.d + m0 + lane] = ((bsum + bfold[0][lane]) + bfold[1][lane]) + bfold[2][lane];
 }
 
-// partial[b][M d + M + {0, 1}] = sum over slab b of u_a . F and u_a . x0  (d alpha_train, d beta_train come from them in the fold)
-__global__ __launch_bounds__(kBlock) void adjoint_dots_kernel(const ParamArgs p) {
+// partial[b][M d + M + {0, 1}] = sum of the per-wave dots w = b, b + nb, b + 2 nb, ... written by the row kernel of the stage
+// (launch_adjoint_rows): first level of the fold of sum u_a . F and sum u_a . x0, fixed order
+__global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* __restrict__ dots, int n_dots, int nb, float* __restrict__ partial,
+                                                                  int stride, int slot) {
   __shared__ float red[kWavesPerBlock][2];
-  const int r0 = static_cast<int>(blockIdx.x) * p.rows_per_block;
-  int r1 = r0 + p.rows_per_block;
-  if (r1 > p.n) r1 = p.n;
-  const int d4 = (p.d + 3) / 4;                  // 16-byte lanes per row
-  const long long items = static_cast<long long>(r1 > r0 ? r1 - r0 : 0) * d4;
   float d1 = 0.f, d2 = 0.f;
-  for (long long it = threadIdx.x; it < items; it += kBlock) {
-    const int i = r0 + static_cast<int>(it / d4), col = static_cast<int>(it % d4) * 4;
-    const size_t off = static_cast<size_t>(i) * p.ld + col;
-    const float4 g = *reinterpret_cast<const float4*>(p.ua + off);
-    const float4 f = *reinterpret_cast<const float4*>(p.F + off);
-    const float gg[4] = {g.x, col + 1 < p.d ? g.y : 0.f, col + 2 < p.d ? g.z : 0.f, col + 3 < p.d ? g.w : 0.f};
-    d1 = fmaf(gg[0], f.x, d1); d1 = fmaf(gg[1], f.y, d1); d1 = fmaf(gg[2], f.z, d1); d1 = fmaf(gg[3], f.w, d1);
-    if (p.x0 != nullptr) {
-      const float4 s = *reinterpret_cast<const float4*>(p.x0 + off);
-      d2 = fmaf(gg[0], s.x, d2); d2 = fmaf(gg[1], s.y, d2); d2 = fmaf(gg[2], s.z, d2); d2 = fmaf(gg[3], s.w, d2);
-    }
+  for (long long w = static_cast<long long>(blockIdx.x) + static_cast<long long>(threadIdx.x) * nb; w < n_dots; w += static_cast<long long>(kBlock) * nb) {
+    d1 += dots[2 * w];
+    d2 += dots[2 * w + 1];
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -159,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void adjoint_dots_kernel(const ParamArgs p)
   if ((threadIdx.x & (kWave - 1)) == 0) { red[threadIdx.x >> 6][0] = d1; red[threadIdx.x >> 6][1] = d2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float* out = p.partial + static_cast<size_t>(blockIdx.x) * p.stride + static_cast<size_t>(p.M) * p.d + p.M;
+    float* out = partial + static_cast<size_t>(blockIdx.x) * stride + slot;
     out[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
     out[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
   }
@@ -172,14 +164,15 @@ __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float*
                                                                    float coef, const float* __restrict__ alpha,
                                                                    const float* __restrict__ beta, int has_source,
                                                                    float* __restrict__ grads) {
-  __shared__ float part[4][64][2];
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int idx = static_cast<int>(blockIdx.x) * 64 + o;
+  constexpr int OUTS = 32, SL = kBlock / OUTS;
+  __shared__ float part[SL][OUTS][2];
+  const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
+  const int idx = static_cast<int>(blockIdx.x) * OUTS + o;
   const bool dot_slot = idx == n_plain;                       // this thread folds BOTH dot sums
   const bool live = idx < n_plain || dot_slot;
   float s1 = 0.f, s2 = 0.f;
   if (live) {
-    const int per = (nb + 3) / 4;
+    const int per = (nb + SL - 1) / SL;
     int b0 = sl * per, b1 = b0 + per;
     if (b1 > nb) b1 = nb;
     const float* p = partial + static_cast<size_t>(b0) * stride + idx;
@@ -203,8 +196,9 @@ __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float*
   part[sl][o][1] = s2;
   __syncthreads();
   if (sl != 0 || !live) return;
-  s1 = ((part[0][o][0] + part[1][o][0]) + part[2][o][0]) + part[3][o][0];
-  s2 = ((part[0][o][1] + part[1][o][1]) + part[2][o][1]) + part[3][o][1];
+  s1 = 0.f; s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < SL; ++t) { s1 += part[t][o][0]; s2 += part[t][o][1]; }
   if (!dot_slot) {
     grads[idx] = fmaf(coef, s1, grads[idx]);
     return;
@@ -239,7 +233,8 @@ struct gnpde_adjoint {
   size_t ws_bytes;
   // workspace regions
   size_t state_bytes;
-  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one;
+  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots;
+  int n_dots;
   char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
   size_t att_bytes, attbwd_bytes, spmm_bytes, spmm_t_bytes;
   int M, stride;
@@ -298,11 +293,14 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   const size_t o_one = take(256);
   const size_t e4 = static_cast<size_t>(g.e > 0 ? g.e : 1) * 4;
   size_t att_b = 0, attbwd_b = 0;
+  o_r = take(e4);
+  const int n_dots = adjoint_rows_dot_slots(&g);
+  const size_t o_dots = take(static_cast<size_t>(n_dots) * 8);
   if (nl) {
     o_P = take(state);
     o_qk = take(static_cast<size_t>(g.n) * M * 4);
     o_dqk = take(static_cast<size_t>(g.n) * M * 4);
-    o_w = take(e4); o_wt = take(e4); o_r = take(e4);
+    o_w = take(e4); o_wt = take(e4);
     o_ds = take(e4 * r.att.heads);
     att_b = attention_workspace_bytes(&g, r.att.heads, false);
     attbwd_b = gnpde_attention_bwd_workspace_bytes(&g, &r.att);
@@ -320,7 +318,8 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     for (int i = 0; i < 3; ++i) s->V[i] = i < nV ? f(o_V[i]) : nullptr;
     s->one = f(o_one);
     s->P = nl ? f(o_P) : nullptr; s->qk = nl ? f(o_qk) : nullptr; s->dqk = nl ? f(o_dqk) : nullptr;
-    s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = nl ? f(o_r) : nullptr; s->ds = nl ? f(o_ds) : nullptr;
+    s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = f(o_r); s->ds = nl ? f(o_ds) : nullptr;
+    s->dots = f(o_dots); s->n_dots = n_dots;
     s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
     s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
     s->partial = f(o_part);
@@ -352,24 +351,32 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     if (rc) return rc;
     w = s->w;
   }
+  // F with the next stage input in its epilogue + r_e = ua[row] . uy[col] + the per-wave dots, one kernel over the gathered rows
   eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
   eF.stage = GNPDE_STAGE_LINCOMB; eF.out_k = Fout;
-  rc = launch_spmm_rhs(g, w, uy, d, ld, &eF, nullptr, s->ws_spmm, s->spmm_bytes, st, nullptr, padded);
+  rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
   if (rc) return rc;
   const float* source = nullptr;
   const float* source_scale = nullptr;
   if (nl) {
-    rc = gnpde_sddmm(g, ua, ld, uy, ld, d, nullptr, 0, s->r, st);
-    if (rc) return rc;
     if (s->rows_bwd) rc = gnpde_attention_rows_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, st);
     else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
     if (rc) return rc;
     const int h = at.heads, dk = A / h;
     const float inv = 1.0f / sqrtf(static_cast<float>(dk));
-    rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
-    if (rc) return rc;
-    rc = gnpde_head_spmm(g, 1, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
-    if (rc) return rc;
+    if (head_rowsum_supported(h, dk)) {
+      // d q over the rows, d k over the rows of the transposed graph (a lane per entry; rows without entries stay zero)
+      GNPDE_HIP(hipMemsetAsync(s->dqk, 0, static_cast<size_t>(n) * M * 4, st));
+      rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+      if (rc) return rc;
+      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+      if (rc) return rc;
+    } else {
+      rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+      if (rc) return rc;
+      rc = gnpde_head_spmm(g, 1, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+      if (rc) return rc;
+    }
     rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
     if (rc) return rc;
     if (g->e > 0) {
@@ -400,10 +407,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     else hipLaunchKernelGGL(adjoint_gram_kernel<4>, dim3(nb, gy), dim3(kBlock), 0, st, p);
     GNPDE_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(adjoint_dots_kernel, dim3(nb), dim3(kBlock), 0, st, p);
+  hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, s->n_dots, nb, s->partial, s->stride, M * d + M);
   GNPDE_LAUNCH_CHECK();
   const int n_plain = M * d + M;
-  hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 63) / 64), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
+  hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 31) / 32), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
                      pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, grads);
   GNPDE_LAUNCH_CHECK();
   return 0;
@@ -420,7 +427,7 @@ int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStrea
       gnpde_epilogue_t eF{}, eV{};
       eF.y = cy; eF.out_y = s->uy[flip]; eF.n_prev = 0; eF.coef[0] = -dt;
       eV.y = ca; eV.out_y = s->ua[flip]; eV.n_prev = 0; eV.coef[0] = dt;
-      int rc = enqueue_stage(s, cy, ca, s->F[0], eF, nullptr, eV, dt, grads, st);
+      int rc = enqueue_stage(s, cy, ca, nullptr, eF, nullptr, eV, dt, grads, st);
       if (rc) return rc;
       cy = s->uy[flip]; ca = s->ua[flip];
       flip ^= 1;
@@ -461,7 +468,7 @@ int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStrea
     eF.coef[0] = -c8; eF.coef[1] = -c38; eF.coef[2] = -c38; eF.coef[3] = -c8;
     eV.y = a; eV.out_y = a; eV.n_prev = 3; eV.prev[0] = V[0]; eV.prev[1] = V[1]; eV.prev[2] = V[2];
     eV.coef[0] = c8; eV.coef[1] = c38; eV.coef[2] = c38; eV.coef[3] = c8;
-    rc = enqueue_stage(s, s->uy[0], s->ua[0], F[3], eF, nullptr, eV, c8, grads, st);
+    rc = enqueue_stage(s, s->uy[0], s->ua[0], nullptr, eF, nullptr, eV, c8, grads, st);
     if (rc) return rc;
   }
   return 0;

@@ -382,6 +382,168 @@ int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Head-wise weighted segment sum with one LANE PER ENTRY (the adjoint stage's d q and d k; csrc/adjoint.hip):
+//   out[seg, c] = scale * sum_{t in seg} ds[pos(t), head(c)] * feat[other(t), c]        c < A = H * DK4 * 4
+// head_spmm_kernel above gives a wavefront to every segment and A / 4 lanes to every entry -- at A = 16 and a median of 8 entries
+// per row one iteration of 16 entry slots, most of them empty, behind a chain of four dependent loads: 139 us per launch at the
+// ogbn-arxiv shape for 220 MB of traffic.  Here the segments come from the degree-binned records (as in
+// attention_rows_bwd_kernel): rows of <= 16 entries take 16 lanes (four rows per wavefront), a lane fetches its entry's ds vector
+// and whole feature row (A floats in registers) with all loads of the wavefront in flight at once, and the A partial columns are
+// summed over the lanes of the row by a transposing butterfly (A - 1 + log2(GL / A) shuffles instead of A log2 GL), after which
+// lane gl holds column gl / (GL / A) and the row is written by one coalesced store.  Hub segments: one block each.
+// pos == nullptr: ds is indexed by the segment's own positions (d q, rows of the graph); else through pos (d k: the segments
+// are rows of the transposed graph and pos maps its positions to the CSR positions ds is stored at).
+// ------------------------------------------------------------------------------------------------
+template <int N, int MASK>
+struct LaneTranspose {   // N values per lane -> 1 over the lane pairs (l ^ MASK), then MASK / 2, ...; lane l ends with value index given by its top bits
+  static __device__ __forceinline__ void run(float* p, int l) {
+    constexpr int Hh = N / 2;
+    const bool upper = (l & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < Hh; ++j) {
+      const float send = upper ? p[j] : p[j + Hh];
+      const float keep = upper ? p[j + Hh] : p[j];
+      p[j] = keep + __shfl_xor(send, MASK, kWave);
+    }
+    if constexpr (Hh > 1) LaneTranspose<Hh, MASK / 2>::run(p, l);
+  }
+};
+
+template <int H, int DK4>
+__device__ __forceinline__ void entry_fma(const float* __restrict__ ds, const float* __restrict__ feat, int ldf, int h_rt, long long pp, int o,
+                                          float (&acc)[H * DK4 * 4]) {
+  float dsv[H];
+  if constexpr (H == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(ds + pp * 4);
+    dsv[0] = t.x; dsv[1] = t.y; dsv[2] = t.z; dsv[3] = t.w;
+  } else if constexpr (H == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(ds + pp * 2);
+    dsv[0] = t.x; dsv[1] = t.y;
+  } else {
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) dsv[hh] = ds[pp * H + hh];
+  }
+  const float* fr = feat + static_cast<size_t>(o) * ldf;
+  float4 f[H * DK4];
+#pragma unroll
+  for (int c4 = 0; c4 < H * DK4; ++c4) f[c4] = *reinterpret_cast<const float4*>(fr + 4 * c4);
+#pragma unroll
+  for (int c4 = 0; c4 < H * DK4; ++c4) {
+    const float w = dsv[c4 / DK4];
+    acc[4 * c4 + 0] = fmaf(w, f[c4].x, acc[4 * c4 + 0]);
+    acc[4 * c4 + 1] = fmaf(w, f[c4].y, acc[4 * c4 + 1]);
+    acc[4 * c4 + 2] = fmaf(w, f[c4].z, acc[4 * c4 + 2]);
+    acc[4 * c4 + 3] = fmaf(w, f[c4].w, acc[4 * c4 + 3]);
+  }
+}
+
+template <int H, int DK4, int GL, int PER, bool HUBS>
+__global__ __launch_bounds__(kBlock) void head_rowsum_kernel(const int* __restrict__ rowptr, const int* __restrict__ other,
+                                                            const int* __restrict__ pos, const int* __restrict__ bin_rows, int first_rec,
+                                                            int n_rec, const float* __restrict__ ds, const float* __restrict__ feat, int ldf,
+                                                            float scale, const int* __restrict__ long_rows, int n_long,
+                                                            float* __restrict__ out, int ldo) {
+  constexpr int A = H * DK4 * 4;
+  constexpr int RPW = kWave / GL;
+  __shared__ float part[kWavesPerBlock][A];
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool hub = HUBS && static_cast<int>(blockIdx.x) < n_long;
+  float acc[A];
+#pragma unroll
+  for (int c = 0; c < A; ++c) acc[c] = 0.f;
+  if (!hub) {
+    const int gl = lane % GL;
+    const long long rec = (static_cast<long long>(blockIdx.x) - (HUBS ? n_long : 0)) * (kWavesPerBlock * RPW) +
+                          (threadIdx.x >> 6) * RPW + lane / GL;
+    int4 info = make_int4(0, 0, 0, 0);
+    if (rec < n_rec) info = reinterpret_cast<const int4*>(bin_rows)[first_rec + rec];
+    const int b = info.y, e = info.y + info.z;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = b + gl + i * GL;
+      if (t < e) entry_fma<H, DK4>(ds, feat, ldf, H, pos != nullptr ? pos[t] : t, other[t], acc);
+    }
+    // sum over the GL lanes of the row, C columns at a time
+    constexpr int C = A < GL ? A : GL;
+    constexpr int LPE = GL / C;
+#pragma unroll
+    for (int ch = 0; ch < A / C; ++ch) {
+      if constexpr (C > 1) LaneTranspose<C, GL / 2>::run(acc + ch * C, gl);
+      float v = acc[ch * C];
+#pragma unroll
+      for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+      if (rec < n_rec && (gl % LPE) == 0) out[static_cast<size_t>(info.x) * ldo + ch * C + gl / LPE] = scale * v;
+    }
+    return;
+  }
+  // hub segment: the block's 256 threads stride over its entries, then wave butterflies and a fold through the LDS
+  const int seg = long_rows[blockIdx.x];
+  const int b = rowptr[seg], e = rowptr[seg + 1];
+  for (int t = b + static_cast<int>(threadIdx.x); t < e; t += kBlock)
+    entry_fma<H, DK4>(ds, feat, ldf, H, pos != nullptr ? pos[t] : t, other[t], acc);
+  constexpr int C = A < kWave ? A : kWave;
+  constexpr int LPE = kWave / C;
+#pragma unroll
+  for (int ch = 0; ch < A / C; ++ch) {
+    if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(acc + ch * C, lane);
+    float v = acc[ch * C];
+#pragma unroll
+    for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    if ((lane % LPE) == 0) part[threadIdx.x >> 6][ch * C + lane / LPE] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < A)
+    out[static_cast<size_t>(seg) * ldo + threadIdx.x] =
+        scale * ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+template <int H, int DK4>
+int launch_head_rowsum_hd(const gnpde_graph_t* g, const int* pos, const float* ds, const float* feat, int ldf, float scale, float* out,
+                          int ldo, hipStream_t s) {
+  const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
+  if (n16 > 0) {
+    constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
+    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((head_rowsum_kernel<H, DK4, 16, 1, false>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx, pos, g->bin_rows, 0,
+                       n16, ds, feat, ldf, scale, g->long_rows, 0, out, ldo);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n64 > 0 || nl > 0) {
+    const unsigned grid = static_cast<unsigned>(nl + (n64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((head_rowsum_kernel<H, DK4, kWave, GNPDE_LONG_ROW / kWave, true>), dim3(grid), dim3(kBlock), 0, s, g->rowptr,
+                       g->colidx, pos, g->bin_rows, n16, n64, ds, feat, ldf, scale, g->long_rows, nl, out, ldo);
+    GNPDE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace
+
+// out[seg, 0:A] = scale * sum over the rows of `g` (entry t: ds[pos ? pos[t] : t, head], feat[colidx[t], :]); rows without entries are
+// NOT written (the caller zeroes `out`).  Returns GNPDE_ESHAPE for head shapes without a kernel (the caller falls back to
+// gnpde_head_spmm).
+bool head_rowsum_supported(int heads, int dk) {
+  if (dk % 4 != 0) return false;
+  const int dk4 = dk / 4, a4 = heads * dk4;
+  return (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (dk4 == 1 || dk4 == 2 || dk4 == 4) && a4 <= 8;
+}
+
+int launch_head_rowsum(const gnpde_graph_t* g, const int* pos, const float* ds, int heads, int dk, const float* feat, int ldf,
+                       float scale, float* out, int ldo, hipStream_t s) {
+  GNPDE_CHECK_ARG(g && ds && feat && out && head_rowsum_supported(heads, dk), GNPDE_ESHAPE, "head_rowsum: heads=%d d_k=%d has no kernel", heads, dk);
+  GNPDE_CHECK_ARG(ldf % 4 == 0 && reinterpret_cast<uintptr_t>(feat) % 16 == 0 && reinterpret_cast<uintptr_t>(ds) % 16 == 0, GNPDE_EINVAL,
+                  "head_rowsum: operands must be 16-byte aligned");
+  GNPDE_CHECK_ARG(g->bin_rows != nullptr && (g->n_long_rows == 0 || g->long_rows), GNPDE_EINVAL, "head_rowsum: graph without degree bins");
+  if (g->n == 0 || g->e == 0) return 0;
+  const int dk4 = dk / 4;
+#define GNPDE_HR(HH, DD) if (heads == HH && dk4 == DD) return launch_head_rowsum_hd<HH, DD>(g, pos, ds, feat, ldf, scale, out, ldo, s);
+  GNPDE_HR(1, 1) GNPDE_HR(1, 2) GNPDE_HR(1, 4) GNPDE_HR(2, 1) GNPDE_HR(2, 2) GNPDE_HR(2, 4) GNPDE_HR(4, 1) GNPDE_HR(4, 2) GNPDE_HR(8, 1)
+#undef GNPDE_HR
+  return GNPDE_ESHAPE;
+}
+
+namespace {
 }  // namespace
 }  // namespace gnpde
 

@@ -1277,6 +1277,276 @@ int dispatch_sddmm(const gnpde_graph_t* g, const float* a, const float* b, int d
 
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// ------------------------------------------------------------------------------------------------
+// One stage of the native adjoint solve, row side (csrc/adjoint.hip): the aggregation F = alpha (A u - u) + beta x0 with its
+// LINCOMB stage epilogue, the SDDMM r_e = g[row] . u[col] of the SAME gathered rows, and the two dot products the scalar
+// gradients need (sum g . F, sum g . x0) -- what ran as three kernels, two of which gathered every neighbour row
+// (spmm_pair_kernel 187 us + sddmm_kernel 181 us + a 53-us streaming pass at the ogbn-arxiv shape).  Work items and summation
+// order of the aggregation as in spmm_wide_kernel (L lanes of 16 bytes per neighbour row, G = 64 / L neighbour slots, U gathers
+// in flight, slots combined by the xor butterfly).  The dot of a gathered row with g_i needs a sum over the L lanes of its slot;
+// the U partial dots of a batch are reduced TOGETHER by a transposing butterfly -- at every step a lane keeps half of its values
+// and hands the other half to its partner, so U values cost U - 1 + log2(L / U) shuffles instead of U log2(L), and lane
+// cl ends up with the dot of entry cl / (L / U) of the batch.  r is complete per entry, so hub chunks need no second pass for it.
+// ------------------------------------------------------------------------------------------------
+struct AdjRowsArgs {
+  SpmmArgs s;                      // graph, w, u (the state-side stage input), LINCOMB epilogue, hub-chunk partials
+  const float* __restrict__ g;     // [n, ld] adjoint-side stage input
+  float* __restrict__ r;           // [e] out
+  float* __restrict__ dots;        // [gridDim.x + n_long_rows][2] out: per-wave sums of g . F and g . x0
+};
+
+template <int N, int MASK>
+struct TransposeReduce {   // N values per lane -> 1, over the lane pairs (cl ^ MASK), then recursively MASK / 2
+  static __device__ __forceinline__ void run(float* p, int cl) {
+    constexpr int H = N / 2;
+    const bool upper = (cl & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float send = upper ? p[j] : p[j + H];
+      const float keep = upper ? p[j + H] : p[j];
+      p[j] = keep + __shfl_xor(send, MASK, kWave);
+    }
+    if constexpr (H > 1) TransposeReduce<H, MASK / 2>::run(p, cl);
+  }
+};
+
+// k = alpha (ax - u_i) + beta x0_i, the LINCOMB stage outputs, and this lane's share of g_i . k and g_i . x0_i
+template <int VEC>
+__device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off, const float (&ax)[VEC],
+                                                 const float (&ui)[VEC], const float (&gi)[VEC], const float (&cmask)[VEC],
+                                                 float& d1, float& d2) {
+  float k[VEC], s[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { k[v] = alpha * (ax[v] - ui[v]); s[v] = 0.f; }
+  if (ep.x0 != nullptr) {
+    load_vec_nt<VEC>(ep.x0 + off, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    d1 = fmaf(gi[v] * cmask[v], k[v], d1);
+    d2 = fmaf(gi[v] * cmask[v], s[v], d2);
+  }
+  if (ep.out_k != nullptr) store_vec_nt<VEC>(ep.out_k + off, k);
+  if (ep.out_y != nullptr) {
+    float y[VEC], a[VEC], o[VEC];
+    load_vec_nt<VEC>(ep.y + off, y);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = 0.0f;
+    for (int j = 0; j < ep.n_prev; ++j) {
+      load_vec_nt<VEC>(ep.prev[j] + off, a);
+      const float cj = ep.coef[j];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = fmaf(a[v], cj, o[v]);
+    }
+    const float ck = ep.coef[ep.n_prev];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = y[v] + fmaf(k[v], ck, o[v]);
+    store_vec_nt<VEC>(ep.out_y + off, o);
+  }
+}
+
+template <int L, int U>
+__global__ __launch_bounds__(kWave) void adjoint_rows_kernel(const AdjRowsArgs fa) {
+  constexpr int VEC = 4;
+  constexpr int G = kWave / L;
+  constexpr int EPB = G * U;          // entries per batch
+  constexpr int LPE = L / U;          // lanes that end up with the same entry's dot
+  static_assert(U <= L && (L % U) == 0, "transposing butterfly needs U <= L");
+  const SpmmArgs& a = fa.s;
+  const int lane = threadIdx.x;
+  const int sub = lane / L, cl = lane % L;
+  const int col = cl * VEC;
+  const bool col_ok = col < a.d;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = static_cast<int>(blockIdx.x / kXcds);
+  const Item it = item_of(a, xcd, lw);
+  float d1 = 0.f, d2 = 0.f;
+  if (it.valid) {
+    const int row = it.row, e0 = it.e0, e1 = it.e1, chunk = it.chunk;
+    const size_t off = static_cast<size_t>(row) * a.ld + col;
+    float gi[VEC], ui[VEC], cmask[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { gi[v] = 0.f; ui[v] = 0.f; cmask[v] = col + v < a.d ? 1.0f : 0.0f; }   // padded rows: columns [d, ld) are not data
+    if (col_ok) {
+      load_vec<VEC>(fa.g + off, gi);
+      if (chunk < 0 && sub == 0) load_vec<VEC>(a.u + off, ui);
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) gi[v] *= cmask[v];
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+    for (int base = e0; base < e1; base += kWave) {
+      const int me = base + lane;
+      const bool in = me < e1;
+      const int cv = in ? a.colidx[me] : 0;          // one coalesced load of 64 column ids and weights per wave
+      const float wv = in ? a.w[me] : 0.0f;
+      const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
+      for (int t0 = 0; t0 < cnt; t0 += EPB) {
+        float vals[U][VEC], ww[U], p[U];
+        int cs[U];
+        bool oks[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          const int idx = t0 + t * G + sub;
+          cs[t] = __shfl(cv, idx & (kWave - 1), kWave);
+          const float w = __shfl(wv, idx & (kWave - 1), kWave);
+          oks[t] = col_ok && idx < cnt;
+          ww[t] = oks[t] ? w : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
+          if (oks[t]) load_vec<VEC>(a.u + static_cast<size_t>(cs[t]) * a.ld + col, vals[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          float q = 0.f;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            acc[v] = fmaf(ww[t], vals[t][v], acc[v]);
+            q = fmaf(gi[v], vals[t][v], q);
+          }
+          p[t] = q;
+        }
+        TransposeReduce<U, L / 2>::run(p, cl);
+#pragma unroll
+        for (int m = LPE / 2; m >= 1; m >>= 1) p[0] += __shfl_xor(p[0], m, kWave);
+        const int idx = t0 + (cl / LPE) * G + sub;
+        if ((cl % LPE) == 0 && idx < cnt) fa.r[base + idx] = p[0];
+      }
+    }
+#pragma unroll
+    for (int o = L; o < kWave; o <<= 1)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], o, kWave);
+    if (sub == 0 && col_ok) {
+      if (chunk >= 0) {
+        store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);   // adjoint_long_reduce4_kernel folds the chunks of a row
+      } else {
+        const float alpha = alpha_of(a.ep);
+        const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
+        adjoint_epilogue<VEC>(a.ep, alpha, beta, off, acc, ui, gi, cmask, d1, d2);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    d1 += __shfl_xor(d1, o, kWave);
+    d2 += __shfl_xor(d2, o, kWave);
+  }
+  if (lane == 0) {
+    fa.dots[2 * static_cast<size_t>(blockIdx.x)] = d1;
+    fa.dots[2 * static_cast<size_t>(blockIdx.x) + 1] = d2;
+  }
+}
+
+// hub rows of the adjoint stage: chunk partials in chunk order (as spmm_long_reduce4_kernel), then the same epilogue and dots
+__global__ __launch_bounds__(kWave) void adjoint_long_reduce4_kernel(const AdjRowsArgs fa, const int* __restrict__ long_rows,
+                                                                    const int* __restrict__ long_chunk_ptr, int dots_base) {
+  constexpr int VEC = 4;
+  const SpmmArgs& a = fa.s;
+  const int lr = blockIdx.x;
+  const int row = long_rows[lr];
+  const int c0 = long_chunk_ptr[lr], c1 = long_chunk_ptr[lr + 1];
+  const float alpha = alpha_of(a.ep);
+  const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
+  float d1 = 0.f, d2 = 0.f;
+  for (int col = static_cast<int>(threadIdx.x) * VEC; col < a.d; col += kWave * VEC) {
+    const size_t off = static_cast<size_t>(row) * a.ld + col;
+    float gi[VEC], ui[VEC], cmask[VEC];
+    load_vec<VEC>(fa.g + off, gi);
+    load_vec<VEC>(a.u + off, ui);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmask[v] = col + v < a.d ? 1.0f : 0.0f;
+    float acc[VEC] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* p = a.partial + static_cast<size_t>(c0) * a.ldp + col;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8, p += 8 * static_cast<size_t>(a.ldp)) {
+      float v[8][VEC];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) load_vec<VEC>(p + t * static_cast<size_t>(a.ldp), v[t]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += v[t][q];
+    }
+    for (; c < c1; ++c, p += a.ldp) {
+      float v[VEC];
+      load_vec<VEC>(p, v);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+    }
+    adjoint_epilogue<VEC>(a.ep, alpha, beta, off, acc, ui, gi, cmask, d1, d2);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    d1 += __shfl_xor(d1, o, kWave);
+    d2 += __shfl_xor(d2, o, kWave);
+  }
+  if (threadIdx.x == 0) {
+    fa.dots[2 * (static_cast<size_t>(dots_base) + lr)] = d1;
+    fa.dots[2 * (static_cast<size_t>(dots_base) + lr) + 1] = d2;
+  }
+}
+
+}  // namespace
+
+// number of per-wave dot slots launch_adjoint_rows writes (its grid + one per long row)
+int adjoint_rows_dot_slots(const gnpde_graph_t* g) {
+  SpmmArgs a{};
+  a.chunk_begin = 0; a.chunk_end = g->n_long_chunks; a.row_begin = 0; a.row_end = g->n;
+  a.row_shift = choose_row_shift(g->n, g->xcd_deal);
+  return static_cast<int>(balanced_grid(a, 1)) + g->n_long_rows;
+}
+
+int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
+                        const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
+                        bool padded_rows) {
+  GNPDE_CHECK_ARG(g && u && gvec && epi && r_out && dots && (w_csr || g->e == 0), GNPDE_EINVAL, "adjoint_rows: null pointer");
+  GNPDE_CHECK_ARG(epi->stage == GNPDE_STAGE_LINCOMB && epi->alpha != nullptr && (epi->x0 == nullptr || epi->beta != nullptr) &&
+                  epi->n_prev >= 0 && epi->n_prev <= GNPDE_MAX_PREV && (epi->out_y == nullptr || epi->y != nullptr), GNPDE_EINVAL,
+                  "adjoint_rows: needs a LINCOMB epilogue");
+  GNPDE_CHECK_ARG(epi->out_k != u && epi->out_y != u, GNPDE_EINVAL, "adjoint_rows: output aliases the gathered operand");
+  GNPDE_CHECK_ARG(g->row_begin == 0 && d >= 1 && d <= 256 && ld >= d && ld % 4 == 0 && (d % 4 == 0 || padded_rows), GNPDE_ESHAPE,
+                  "adjoint_rows: whole graphs, rows of up to 256 floats in 16-byte lanes");
+  if (g->n == 0) return 0;
+  AdjRowsArgs fa{};
+  SpmmArgs& a = fa.s;
+  a.n = g->n; a.n_long_chunks = g->n_long_chunks;
+  a.rowptr = g->rowptr; a.colidx = g->colidx;
+  a.lc_row = g->long_chunk_row; a.lc_begin = g->long_chunk_begin; a.lc_end = g->long_chunk_end;
+  a.w = w_csr; a.u = u; a.d = d; a.ld = ld; a.plain_out = nullptr;
+  a.ldp = static_cast<int>(align_up(static_cast<size_t>(d), 4));
+  a.partial = static_cast<float*>(ws);
+  a.ep = *epi;
+  a.chunk_begin = 0; a.chunk_end = g->n_long_chunks; a.row_begin = 0; a.row_end = g->n;
+  a.row_shift = choose_row_shift(g->n, g->xcd_deal);
+  if (g->n_long_chunks > 0) {
+    const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
+    GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need, GNPDE_EWS, "adjoint_rows: workspace %zu < %zu bytes", ws_bytes, need);
+  }
+  const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->out_k, epi->out_y, epi->prev[0], epi->prev[1], epi->prev[2], epi->prev[3]};
+  for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
+  fa.g = gvec; fa.r = r_out; fa.dots = dots;
+  const unsigned grid = balanced_grid(a, 1);
+  const int slots = (d + 3) / 4;
+  if (slots <= 16) hipLaunchKernelGGL((adjoint_rows_kernel<16, 8>), dim3(grid), dim3(kWave), 0, stream, fa);
+  else if (slots <= 32) hipLaunchKernelGGL((adjoint_rows_kernel<32, 8>), dim3(grid), dim3(kWave), 0, stream, fa);
+  else hipLaunchKernelGGL((adjoint_rows_kernel<64, 8>), dim3(grid), dim3(kWave), 0, stream, fa);
+  GNPDE_LAUNCH_CHECK();
+  if (g->n_long_rows > 0) {
+    hipLaunchKernelGGL(adjoint_long_reduce4_kernel, dim3(g->n_long_rows), dim3(kWave), 0, stream, fa, g->long_rows, g->long_chunk_ptr,
+                       static_cast<int>(grid));
+    GNPDE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, int d, int ld,
