@@ -294,7 +294,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   const size_t e4 = static_cast<size_t>(g.e > 0 ? g.e : 1) * 4;
   size_t att_b = 0, attbwd_b = 0;
   o_r = take(e4);
-  const int n_dots = adjoint_rows_dot_slots(&g);
+  const int n_dots = adjoint_rows_dot_slots(&g, r.d);
   const size_t o_dots = take(static_cast<size_t>(n_dots) * 8);
   if (nl) {
     o_P = take(state);
@@ -359,16 +359,20 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   const float* source = nullptr;
   const float* source_scale = nullptr;
   if (nl) {
-    if (s->rows_bwd) rc = gnpde_attention_rows_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, st);
-    else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
-    if (rc) return rc;
     const int h = at.heads, dk = A / h;
     const float inv = 1.0f / sqrtf(static_cast<float>(dk));
-    if (head_rowsum_supported(h, dk)) {
-      // d q over the rows, d k over the rows of the transposed graph (a lane per entry; rows without entries stay zero)
-      GNPDE_HIP(hipMemsetAsync(s->dqk, 0, static_cast<size_t>(n) * M * 4, st));
-      rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
-      if (rc) return rc;
+    const bool lanes = head_rowsum_supported(h, dk);            // lane-per-entry row sums (rows without entries stay zero)
+    const bool dq_fused = s->rows_bwd && lanes && attention_rows_bwd_dq_supported(h, dk);
+    if (lanes) GNPDE_HIP(hipMemsetAsync(s->dqk, 0, static_cast<size_t>(n) * M * 4, st));
+    if (s->rows_bwd) rc = launch_attention_rows_bwd_dq(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, dq_fused ? s->dqk : nullptr, M, st);
+    else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
+    if (rc) return rc;
+    if (lanes) {
+      // d q over the rows (unless the backward kernel formed it), d k over the rows of the transposed graph
+      if (!dq_fused) {
+        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+        if (rc) return rc;
+      }
       rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
       if (rc) return rc;
     } else {

@@ -226,19 +226,54 @@ __device__ __forceinline__ float gmax(float v) {
   return v;
 }
 
+template <int N, int MASK>
+struct LaneTranspose {   // N values per lane -> 1 over the lane pairs (l ^ MASK), then MASK / 2, ...; lane l ends with value index given by its top bits
+  static __device__ __forceinline__ void run(float* p, int l) {
+    constexpr int Hh = N / 2;
+    const bool upper = (l & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < Hh; ++j) {
+      const float send = upper ? p[j] : p[j + Hh];
+      const float keep = upper ? p[j + Hh] : p[j];
+      p[j] = keep + __shfl_xor(send, MASK, kWave);
+    }
+    if constexpr (Hh > 1) LaneTranspose<Hh, MASK / 2>::run(p, l);
+  }
+};
+
 // Ordinary rows come from the degree-binned records {row, begin, len, 0} (graph_prep): rows with <= 16 entries
 // take GL = 16 lanes (four rows per wavefront, one entry per lane), rows with 17..512 entries a whole wavefront
 // (GL = 64, up to PER = 8 entries per lane, scores kept in registers).  With HUBS the first n_long blocks of the
 // grid take one hub row each.
-template <int H, int DK, int GL, int PER, bool HUBS>
+// DQ: the kernel also forms d q[row, :] = (1 / sqrt d_k) sum_{p in row} ds[p, head] k[col_p, :] -- the row-side head sum of the adjoint
+// stage (csrc/adjoint.hip), from the ds values it has just computed and the k rows it has just read, instead of a second launch that
+// re-reads both (A = H DK <= 32 columns: A accumulators per lane, summed over the row's lanes by the transposing butterfly).
+template <int H, int DK, int GL, int PER, bool HUBS, bool DQ>
 __global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                                    const int* __restrict__ bin_rows, int first_rec, int n_rec,
                                                                    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
                                                                    const float* __restrict__ r, const float* __restrict__ edge_w,
                                                                    const float* __restrict__ scale_ptr, int scale_sigmoid,
                                                                    const int* __restrict__ long_rows, int n_long,
-                                                                   float* __restrict__ ds) {
+                                                                   float* __restrict__ ds, float* __restrict__ dq, int lddq) {
   __shared__ float red[kWavesPerBlock];
+  constexpr int A = H * DK;
+  constexpr int AQ = DQ ? A : 1;
+  __shared__ float qpart[DQ ? kWavesPerBlock : 1][AQ];
+  float accq[AQ];
+#pragma unroll
+  for (int c = 0; c < AQ; ++c) accq[c] = 0.f;
+  auto add_dq = [&](const float (&dsv)[H], const float* __restrict__ krow) {
+    if constexpr (DQ) {
+#pragma unroll
+      for (int c = 0; c < A; c += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(krow + c);
+        const float wv = dsv[c / DK];
+        accq[c + 0] = fmaf(wv, kv.x, accq[c + 0]); accq[c + 1] = fmaf(wv, kv.y, accq[c + 1]);
+        accq[c + 2] = fmaf(wv, kv.z, accq[c + 2]); accq[c + 3] = fmaf(wv, kv.w, accq[c + 3]);
+      }
+    }
+  };
   constexpr int RPW = kWave / GL;               // rows per wavefront
   const int lane = threadIdx.x & (kWave - 1);
   const bool hub = HUBS && static_cast<int>(blockIdx.x) < n_long;
@@ -313,6 +348,19 @@ __global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* _
 #pragma unroll
           for (int hh = 0; hh < H; ++hh) ds[static_cast<size_t>(p) * H + hh] = out[hh];
         }
+        add_dq(out, k + static_cast<size_t>(colidx[p]) * ldqk);
+      }
+    }
+    if constexpr (DQ) {
+      constexpr int C = A < GL ? A : GL;
+      constexpr int LPE = GL / C;
+#pragma unroll
+      for (int ch = 0; ch < A / C; ++ch) {
+        if constexpr (C > 1) LaneTranspose<C, GL / 2>::run(accq + ch * C, gl);
+        float v = accq[ch * C];
+#pragma unroll
+        for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+        if (live_row && (gl % LPE) == 0) dq[static_cast<size_t>(info.x) * lddq + ch * C + gl / LPE] = inv * v;
       }
     }
     return;
@@ -354,32 +402,62 @@ __global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* _
     const float ewp = edge_w != nullptr ? edge_w[p] : 1.f;
     row_scores<H, DK>(qrow, k + static_cast<size_t>(colidx[p]) * ldqk, inv, ewp, sc);
     const float rp = r[p];
+    float out[H];
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh)
-      ds[static_cast<size_t>(p) * H + hh] = (expf(sc[hh] - mx[hh]) / den[hh]) * scale * (rp - c[hh]) * ewp;
+    for (int hh = 0; hh < H; ++hh) {
+      out[hh] = (expf(sc[hh] - mx[hh]) / den[hh]) * scale * (rp - c[hh]) * ewp;
+      ds[static_cast<size_t>(p) * H + hh] = out[hh];
+    }
+    add_dq(out, k + static_cast<size_t>(colidx[p]) * ldqk);
+  }
+  if constexpr (DQ) {
+    const int lane_ = threadIdx.x & (kWave - 1);
+    constexpr int C = A < kWave ? A : kWave;
+    constexpr int LPE = kWave / C;
+#pragma unroll
+    for (int ch = 0; ch < A / C; ++ch) {
+      if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(accq + ch * C, lane_);
+      float v = accq[ch * C];
+#pragma unroll
+      for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+      if ((lane_ % LPE) == 0) qpart[threadIdx.x >> 6][ch * C + lane_ / LPE] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < A)
+      dq[static_cast<size_t>(row) * lddq + threadIdx.x] =
+          inv * ((qpart[0][threadIdx.x] + qpart[1][threadIdx.x]) + (qpart[2][threadIdx.x] + qpart[3][threadIdx.x]));
   }
 }
 
-template <int H, int DK>
-int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                              int scale_sigmoid, float* ds_csr, hipStream_t s) {
+template <int H, int DK, bool DQ>
+int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                int scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
   const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
   if (n16 > 0) {
     constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
                        g->bin_rows, 0, n16, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
-                       ds_csr);
+                       ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
   if (n64 > 0 || nl > 0) {
     const unsigned grid = static_cast<unsigned>(nl + (n64 + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, true>), dim3(grid), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, true, DQ>), dim3(grid), dim3(kBlock), 0, s,
                        g->rowptr, g->colidx, g->bin_rows, n16, n64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
-                       scale_sigmoid, g->long_rows, nl, ds_csr);
+                       scale_sigmoid, g->long_rows, nl, ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
   return 0;
+}
+
+template <int H, int DK>
+int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                              int scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
+  if constexpr (H * DK <= 32) {
+    if (dq != nullptr) return launch_attention_rows_bwd_v<H, DK, true>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, s);
+  }
+  return launch_attention_rows_bwd_v<H, DK, false>(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,21 +473,6 @@ int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a
 // pos == nullptr: ds is indexed by the segment's own positions (d q, rows of the graph); else through pos (d k: the segments
 // are rows of the transposed graph and pos maps its positions to the CSR positions ds is stored at).
 // ------------------------------------------------------------------------------------------------
-template <int N, int MASK>
-struct LaneTranspose {   // N values per lane -> 1 over the lane pairs (l ^ MASK), then MASK / 2, ...; lane l ends with value index given by its top bits
-  static __device__ __forceinline__ void run(float* p, int l) {
-    constexpr int Hh = N / 2;
-    const bool upper = (l & MASK) != 0;
-#pragma unroll
-    for (int j = 0; j < Hh; ++j) {
-      const float send = upper ? p[j] : p[j + Hh];
-      const float keep = upper ? p[j + Hh] : p[j];
-      p[j] = keep + __shfl_xor(send, MASK, kWave);
-    }
-    if constexpr (Hh > 1) LaneTranspose<Hh, MASK / 2>::run(p, l);
-  }
-};
-
 template <int H, int DK4>
 __device__ __forceinline__ void entry_fma(const float* __restrict__ ds, const float* __restrict__ feat, int ldf, int h_rt, long long pp, int o,
                                           float (&acc)[H * DK4 * 4]) {
@@ -611,9 +674,15 @@ extern "C" int gnpde_head_spmm(const gnpde_graph_t* g, int32_t by_column, const 
   return 0;
 }
 
-extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                        int32_t scale_sigmoid, float* ds_csr, void* stream) {
-  using namespace gnpde;
+namespace gnpde {
+// dq != nullptr (head shapes with heads * d_k <= 32 only, see attention_rows_bwd_dq_supported): also d q[row, 0:A] into dq (rows
+// without entries are not written)
+bool attention_rows_bwd_dq_supported(int heads, int dk) {
+  return (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (dk == 4 || dk == 8 || dk == 16) && heads * dk <= 32;
+}
+
+int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
   GNPDE_CHECK_ARG(g && att && r_csr && ds_csr && att->q && att->k, GNPDE_EINVAL, "attention_rows_bwd: null argument");
   GNPDE_CHECK_ARG(att->type == GNPDE_ATT_SCALED_DOT && att->norm_idx == 0 && !att->square_plus, GNPDE_ESHAPE,
                   "attention_rows_bwd: only scaled-dot attention with a softmax over the row");
@@ -623,13 +692,19 @@ extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_atte
   GNPDE_CHECK_ARG(g->n_long_rows == 0 || g->long_rows, GNPDE_EINVAL, "attention_rows_bwd: graph has long rows but no list of them");
   if (g->n == 0 || g->e == 0) return 0;
   GNPDE_CHECK_ARG(g->bin_rows != nullptr, GNPDE_EINVAL, "attention_rows_bwd: graph has no degree-binned row records");
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int h = att->heads, dk = att->att_dim / att->heads;
+  GNPDE_CHECK_ARG(dq == nullptr || attention_rows_bwd_dq_supported(h, dk), GNPDE_ESHAPE, "attention_rows_bwd: d q fusion needs heads * d_k <= 32");
 #define GNPDE_AB(HH, DD) \
-  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, s);
+  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, s);
   GNPDE_AB(1, 4) GNPDE_AB(1, 8) GNPDE_AB(1, 16) GNPDE_AB(2, 4) GNPDE_AB(2, 8) GNPDE_AB(2, 16) GNPDE_AB(4, 4) GNPDE_AB(4, 8)
   GNPDE_AB(4, 16) GNPDE_AB(8, 4) GNPDE_AB(8, 8) GNPDE_AB(8, 16)
 #undef GNPDE_AB
   set_error("attention_rows_bwd: no kernel for heads=%d, d_k=%d (heads in {1,2,4,8}, d_k in {4,8,16})", h, dk);
   return GNPDE_ESHAPE;
+}
+}  // namespace gnpde
+
+extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                        int32_t scale_sigmoid, float* ds_csr, void* stream) {
+  return gnpde::launch_attention_rows_bwd_dq(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, static_cast<hipStream_t>(stream));
 }

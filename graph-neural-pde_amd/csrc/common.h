@@ -140,7 +140,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
                     hipStream_t stream, const Fork* fork = nullptr, bool padded_rows = false);
 
 // adjoint stage, row side (spmm.hip): F with its LINCOMB epilogue + r_e = g[row] . u[col] + per-wave dots of g . F and g . x0
-int adjoint_rows_dot_slots(const gnpde_graph_t* g);
+int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d);
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
                         bool padded_rows);
@@ -150,6 +150,11 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
 bool head_rowsum_supported(int heads, int dk);
 int launch_head_rowsum(const gnpde_graph_t* g, const int* pos, const float* ds, int heads, int dk, const float* feat, int ldf,
                        float scale, float* out, int ldo, hipStream_t s);
+
+// row softmax backward (ds) with the row-side head sum d q formed in the same kernel (backward.hip; heads * d_k <= 32)
+bool attention_rows_bwd_dq_supported(int heads, int dk);
+int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s);
 
 // attention + aggregation of the short rows in one kernel (spmm.hip) and the hub-row weights it needs (attention.hip)
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,

@@ -1347,92 +1347,88 @@ __device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, flo
   }
 }
 
+// one work item (a row, or a 512-entry chunk of a hub row) by a whole wavefront: G = 64 / L neighbour slots share the row
 template <int L, int U>
-__global__ __launch_bounds__(kWave) void adjoint_rows_kernel(const AdjRowsArgs fa) {
+__device__ __forceinline__ void adjoint_item(const AdjRowsArgs& fa, int row, int e0, int e1, int chunk, int lane, float& d1, float& d2) {
   constexpr int VEC = 4;
   constexpr int G = kWave / L;
   constexpr int EPB = G * U;          // entries per batch
   constexpr int LPE = L / U;          // lanes that end up with the same entry's dot
   static_assert(U <= L && (L % U) == 0, "transposing butterfly needs U <= L");
   const SpmmArgs& a = fa.s;
-  const int lane = threadIdx.x;
   const int sub = lane / L, cl = lane % L;
   const int col = cl * VEC;
   const bool col_ok = col < a.d;
-  const int xcd = static_cast<int>(blockIdx.x % kXcds);
-  const int lw = static_cast<int>(blockIdx.x / kXcds);
-  const Item it = item_of(a, xcd, lw);
-  float d1 = 0.f, d2 = 0.f;
-  if (it.valid) {
-    const int row = it.row, e0 = it.e0, e1 = it.e1, chunk = it.chunk;
-    const size_t off = static_cast<size_t>(row) * a.ld + col;
-    float gi[VEC], ui[VEC], cmask[VEC];
+  const size_t off = static_cast<size_t>(row) * a.ld + col;
+  float gi[VEC], ui[VEC], cmask[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { gi[v] = 0.f; ui[v] = 0.f; cmask[v] = col + v < a.d ? 1.0f : 0.0f; }   // padded rows: columns [d, ld) are not data
-    if (col_ok) {
-      load_vec<VEC>(fa.g + off, gi);
-      if (chunk < 0 && sub == 0) load_vec<VEC>(a.u + off, ui);
-    }
+  for (int v = 0; v < VEC; ++v) { gi[v] = 0.f; ui[v] = 0.f; cmask[v] = col + v < a.d ? 1.0f : 0.0f; }   // padded rows: columns [d, ld) are not data
+  if (col_ok) {
+    load_vec<VEC>(fa.g + off, gi);
+    if (chunk < 0 && sub == 0) load_vec<VEC>(a.u + off, ui);
+  }
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) gi[v] *= cmask[v];
-    float acc[VEC];
+  for (int v = 0; v < VEC; ++v) gi[v] *= cmask[v];
+  float acc[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
-    for (int base = e0; base < e1; base += kWave) {
-      const int me = base + lane;
-      const bool in = me < e1;
-      const int cv = in ? a.colidx[me] : 0;          // one coalesced load of 64 column ids and weights per wave
-      const float wv = in ? a.w[me] : 0.0f;
-      const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
-      for (int t0 = 0; t0 < cnt; t0 += EPB) {
-        float vals[U][VEC], ww[U], p[U];
-        int cs[U];
-        bool oks[U];
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+  for (int base = e0; base < e1; base += kWave) {
+    const int me = base + lane;
+    const bool in = me < e1;
+    const int cv = in ? a.colidx[me] : 0;          // one coalesced load of 64 column ids and weights per wave
+    const float wv = in ? a.w[me] : 0.0f;
+    const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
+    for (int t0 = 0; t0 < cnt; t0 += EPB) {
+      float vals[U][VEC], ww[U], p[U];
+      int cs[U];
+      bool oks[U];
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
-          const int idx = t0 + t * G + sub;
-          cs[t] = __shfl(cv, idx & (kWave - 1), kWave);
-          const float w = __shfl(wv, idx & (kWave - 1), kWave);
-          oks[t] = col_ok && idx < cnt;
-          ww[t] = oks[t] ? w : 0.0f;
-        }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
-          if (oks[t]) load_vec<VEC>(a.u + static_cast<size_t>(cs[t]) * a.ld + col, vals[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-          float q = 0.f;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            acc[v] = fmaf(ww[t], vals[t][v], acc[v]);
-            q = fmaf(gi[v], vals[t][v], q);
-          }
-          p[t] = q;
-        }
-        TransposeReduce<U, L / 2>::run(p, cl);
-#pragma unroll
-        for (int m = LPE / 2; m >= 1; m >>= 1) p[0] += __shfl_xor(p[0], m, kWave);
-        const int idx = t0 + (cl / LPE) * G + sub;
-        if ((cl % LPE) == 0 && idx < cnt) fa.r[base + idx] = p[0];
+      for (int t = 0; t < U; ++t) {
+        const int idx = t0 + t * G + sub;
+        cs[t] = __shfl(cv, idx & (kWave - 1), kWave);
+        const float w = __shfl(wv, idx & (kWave - 1), kWave);
+        oks[t] = col_ok && idx < cnt;
+        ww[t] = oks[t] ? w : 0.0f;
       }
-    }
 #pragma unroll
-    for (int o = L; o < kWave; o <<= 1)
+      for (int t = 0; t < U; ++t) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], o, kWave);
-    if (sub == 0 && col_ok) {
-      if (chunk >= 0) {
-        store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);   // adjoint_long_reduce4_kernel folds the chunks of a row
-      } else {
-        const float alpha = alpha_of(a.ep);
-        const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
-        adjoint_epilogue<VEC>(a.ep, alpha, beta, off, acc, ui, gi, cmask, d1, d2);
+        for (int v = 0; v < VEC; ++v) vals[t][v] = 0.0f;
+        if (oks[t]) load_vec<VEC>(a.u + static_cast<size_t>(cs[t]) * a.ld + col, vals[t]);
       }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          acc[v] = fmaf(ww[t], vals[t][v], acc[v]);
+          q = fmaf(gi[v], vals[t][v], q);
+        }
+        p[t] = q;
+      }
+      TransposeReduce<U, L / 2>::run(p, cl);
+#pragma unroll
+      for (int m = LPE / 2; m >= 1; m >>= 1) p[0] += __shfl_xor(p[0], m, kWave);
+      const int idx = t0 + (cl / LPE) * G + sub;
+      if ((cl % LPE) == 0 && idx < cnt) fa.r[base + idx] = p[0];
     }
   }
+#pragma unroll
+  for (int o = L; o < kWave; o <<= 1)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], o, kWave);
+  if (sub == 0 && col_ok) {
+    if (chunk >= 0) {
+      store_vec<VEC>(a.partial + static_cast<size_t>(chunk) * a.ldp + col, acc);   // adjoint_long_reduce4_kernel folds the chunks of a row
+    } else {
+      const float alpha = alpha_of(a.ep);
+      const float beta = a.ep.x0 != nullptr ? *a.ep.beta : 0.0f;
+      adjoint_epilogue<VEC>(a.ep, alpha, beta, off, acc, ui, gi, cmask, d1, d2);
+    }
+  }
+}
+
+__device__ __forceinline__ void write_wave_dots(const AdjRowsArgs& fa, int lane, float d1, float d2) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     d1 += __shfl_xor(d1, o, kWave);
@@ -1442,6 +1438,18 @@ __global__ __launch_bounds__(kWave) void adjoint_rows_kernel(const AdjRowsArgs f
     fa.dots[2 * static_cast<size_t>(blockIdx.x)] = d1;
     fa.dots[2 * static_cast<size_t>(blockIdx.x) + 1] = d2;
   }
+}
+
+template <int L, int U>
+__global__ __launch_bounds__(kWave) void adjoint_rows_kernel(const AdjRowsArgs fa) {
+  const SpmmArgs& a = fa.s;
+  const int lane = threadIdx.x;
+  const int xcd = static_cast<int>(blockIdx.x % kXcds);
+  const int lw = static_cast<int>(blockIdx.x / kXcds);
+  const Item it = item_of(a, xcd, lw);
+  float d1 = 0.f, d2 = 0.f;
+  if (it.valid) adjoint_item<L, U>(fa, it.row, it.e0, it.e1, it.chunk, lane, d1, d2);
+  write_wave_dots(fa, lane, d1, d2);
 }
 
 // hub rows of the adjoint stage: chunk partials in chunk order (as spmm_long_reduce4_kernel), then the same epilogue and dots
@@ -1495,12 +1503,22 @@ __global__ __launch_bounds__(kWave) void adjoint_long_reduce4_kernel(const AdjRo
 
 }  // namespace
 
-// number of per-wave dot slots launch_adjoint_rows writes (its grid + one per long row)
-int adjoint_rows_dot_slots(const gnpde_graph_t* g) {
+namespace {
+// grid of the adjoint row kernel: one wavefront per work item.  (A row-PAIR form as spmm_pair_kernel -- two rows of <= 32 entries per
+// wave, 16 gathers in flight per half -- was built and measured SLOWER at the ogbn-arxiv shape, 263 vs 248 us: with the 16 partial
+// dots and g_i next to the 16 gathered float4s it needs 140 VGPRs, three waves per SIMD against five here; profiles/r04_train_*.)
+inline unsigned adjoint_rows_grid(const gnpde_graph_t* g) {
   SpmmArgs a{};
   a.chunk_begin = 0; a.chunk_end = g->n_long_chunks; a.row_begin = 0; a.row_end = g->n;
   a.row_shift = choose_row_shift(g->n, g->xcd_deal);
-  return static_cast<int>(balanced_grid(a, 1)) + g->n_long_rows;
+  return balanced_grid(a, 1);
+}
+}  // namespace
+
+// number of per-wave dot slots launch_adjoint_rows writes (its grid + one per long row)
+int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d) {
+  (void)d;
+  return static_cast<int>(adjoint_rows_grid(g)) + g->n_long_rows;
 }
 
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
@@ -1532,7 +1550,7 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
   const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->out_k, epi->out_y, epi->prev[0], epi->prev[1], epi->prev[2], epi->prev[3]};
   for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
   fa.g = gvec; fa.r = r_out; fa.dots = dots;
-  const unsigned grid = balanced_grid(a, 1);
+  const unsigned grid = adjoint_rows_grid(g);
   const int slots = (d + 3) / 4;
   if (slots <= 16) hipLaunchKernelGGL((adjoint_rows_kernel<16, 8>), dim3(grid), dim3(kWave), 0, stream, fa);
   else if (slots <= 32) hipLaunchKernelGGL((adjoint_rows_kernel<32, 8>), dim3(grid), dim3(kWave), 0, stream, fa);

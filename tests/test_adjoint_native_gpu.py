@@ -67,7 +67,7 @@ CASES = {
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_native_adjoint_matches_stage_loop(dev, case):
   opt = _opt(**CASES[case])
-  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded') else 0
+  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
   n = 700
   ei = random_graph(n, 6, seed=11, hubs=hubs, hub_deg=700, isolated=3, dup=20).to(dev)
   x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(3))).to(dev)
