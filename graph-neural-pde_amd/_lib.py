@@ -52,7 +52,8 @@ class AttentionStruct(ctypes.Structure):
   _fields_ = [('type', ctypes.c_int32), ('heads', ctypes.c_int32), ('att_dim', ctypes.c_int32),
               ('norm_idx', ctypes.c_int32), ('square_plus', ctypes.c_int32), ('leaky_slope', ctypes.c_float),
               ('q', c_vp), ('k', c_vp), ('ldqk', ctypes.c_int32),
-              ('gat_a', c_vp), ('output_var', c_vp), ('lengthscale', c_vp), ('edge_w_csr', c_vp)]
+              ('gat_a', c_vp), ('output_var', c_vp), ('lengthscale', c_vp), ('edge_w_csr', c_vp),
+              ('graph_t', ctypes.POINTER(GraphStruct)), ('t_from_csr', c_vp)]
 
 
 class RhsStruct(ctypes.Structure):
@@ -228,7 +229,7 @@ def lib():
       fn = getattr(handle, name)
       fn.restype = res
       fn.argtypes = args
-    if handle.gnpde_abi_version() != 2:
+    if handle.gnpde_abi_version() != 3:
       raise RuntimeError('libgnpde_hip.so ABI version mismatch')
     _lib = handle
   return _lib

@@ -515,6 +515,7 @@ extern "C" int gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rh
   s->graph = *rhs->graph;
   s->rhs.graph = &s->graph;
   s->graph_t = *graph_t;
+  if (s->rhs.att.graph_t != nullptr) s->rhs.att.graph_t = &s->graph_t;     // the same transposed graph, owned here
   s->t_from_csr = t_from_csr;
   s->proj_wt = proj_wt;
   s->w_t_fixed = w_t_csr;

@@ -57,6 +57,10 @@ struct AttArgs {
   const int* __restrict__ rowptr;
   const int* __restrict__ bin_rows;
   int hub_fold_lds;   // default on; gnpde_tune(11, 2) folds straight from memory: see hub_normalise_body
+  // fused scaled-dot segment kernels beyond the plain row softmax (row_attention_sd_kernel and its hub phases):
+  const int* __restrict__ out_pos;   // nullptr, or position e of the walked graph -> position of the weight in w_mean (the walked graph
+                                     // is the TRANSPOSED one when the normalisation runs over columns)
+  int sp_mode;                       // 0 softmax; 1 squareplus with the global maximum in *gmax; 2 only form that maximum
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -434,9 +438,22 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
   __syncthreads();
   const float m = fmaxf(fmaxf(red[0][head], red[1][head]), fmaxf(red[2][head], red[3][head]));
   __syncthreads();
+  if (a.sp_mode == 2) {          // squareplus, first sweep: only the global maximum of the scores (utils.py:196 `src.max()`)
+    if (threadIdx.x < H && m > -INFINITY) {
+      const unsigned mine = f2ord(m);
+      if (mine > __hip_atomic_load(a.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.gmax, mine);
+    }
+    return;
+  }
   float sum = 0.f;
+  if (a.sp_mode == 1) {          // squareplus: the chunk's share of the segment sum of u = (z + sqrt(z^2 + 4)) / 2, z = s - max
+    const float gm = ord2f(*a.gmax);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) sum += __builtin_amdgcn_exp2f((sv[i] - m) * 1.44269504088896341f);   // v_exp_f32; exp(-inf) = 0 for the absent entries
+    for (int i = 0; i < PER; ++i) sum += cols[i] >= 0 ? squareplus_num(sv[i], gm) : 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) sum += __builtin_amdgcn_exp2f((sv[i] - m) * 1.44269504088896341f);   // v_exp_f32; exp(-inf) = 0 for the absent entries
+  }
 #pragma unroll
   for (int off = H; off < kWave; off <<= 1) sum += __shfl_xor(sum, off, kWave);
   if (lane < H) red[wave][lane] = sum;
@@ -457,7 +474,7 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
   // long_chunk_row_first[c] = index of the first chunk of the row chunk c belongs to
   __shared__ float st[2 * 64];  // [2h]: row maximum and denominator per head
   constexpr int kStage = 2048;  // floats of chunk partials staged through LDS (a row of up to 2048 / 2h chunks)
-  __shared__ float sp[kStage];
+  __shared__ float sp_[kStage];
   const int b = a.chunk_begin[c], e = a.chunk_end[c];
   const int row = a.rowidx[b];
   const int c0 = long_chunk_row_first[c];
@@ -472,17 +489,24 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
   const bool staged = a.hub_fold_lds != 0 && nval <= kStage;
   if (staged) {
     const float* src = part + static_cast<size_t>(c0) * 2 * a.h;
-    for (int t = threadIdx.x; t < nval; t += kBlock) sp[t] = src[t];
+    for (int t = threadIdx.x; t < nval; t += kBlock) sp_[t] = src[t];
     __syncthreads();
   }
-  if (threadIdx.x < a.h) {
+  const bool sp = a.sp_mode == 1;
+  if (threadIdx.x < a.h && sp) {       // squareplus: the statistics are plain sums of the chunks' shares
+    const int head = threadIdx.x;
+    float l = 0.f;
+    for (int i = 0; i < nch; ++i) l += staged ? sp_[i * 2 * a.h + a.h + head] : part[static_cast<size_t>(c0 + i) * 2 * a.h + a.h + head];
+    st[head] = ord2f(*a.gmax);
+    st[a.h + head] = __builtin_amdgcn_rcpf(l + 1e-16f);
+  } else if (threadIdx.x < a.h) {
     const int head = threadIdx.x;
     float m = -INFINITY;
     float l = 0.f;
     if (staged) {
-      for (int i = 0; i < nch; ++i) m = fmaxf(m, sp[i * 2 * a.h + head]);
+      for (int i = 0; i < nch; ++i) m = fmaxf(m, sp_[i * 2 * a.h + head]);
       for (int i = 0; i < nch; ++i) {
-        const float* q = sp + i * 2 * a.h;
+        const float* q = sp_ + i * 2 * a.h;
         l += q[a.h + head] * expf(q[head] - m);
       }
     } else {
@@ -498,9 +522,13 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
   __syncthreads();
   for (int p = b + threadIdx.x; p < e; p += kBlock) {
     float acc = 0.f;
-    for (int head = 0; head < a.h; ++head)
-      acc += __builtin_amdgcn_exp2f((a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) * 1.44269504088896341f) * st[a.h + head];
-    a.w_mean[p] = acc / static_cast<float>(a.h);
+    if (sp) {
+      for (int head = 0; head < a.h; ++head) acc += squareplus_num(a.scores[static_cast<size_t>(p) * a.h + head], st[head]) * st[a.h + head];
+    } else {
+      for (int head = 0; head < a.h; ++head)
+        acc += __builtin_amdgcn_exp2f((a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) * 1.44269504088896341f) * st[a.h + head];
+    }
+    a.w_mean[a.out_pos != nullptr ? a.out_pos[p] : p] = acc / static_cast<float>(a.h);
   }
 }
 
@@ -580,7 +608,12 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
 // The first `n_hub` blocks of the launch do the hub-row work instead (phase 0: chunk scores + partial
 // statistics, phase 1: fold partials + normalise), so the long rows ride along with the row kernels rather
 // than costing two extra serialised launches.
-template <int H, int DK4, int GL, int RI, int PB, int NB>
+// MODE 0: softmax over the segment.  MODE 1: squareplus with the global maximum already in *a.gmax (utils.py:179-208: u = (z +
+// sqrt(z^2 + 4)) / 2 with z = s - max over ALL scores, normalised by the segment sum).  MODE 2: the sweep that forms that maximum
+// (scores recomputed, nothing stored).  The segments are the rows of whatever graph a.bin_rows / a.colidx describe -- the
+// transposed graph, with a.q / a.k exchanged and a.out_pos mapping its positions to the CSR positions of the weights, when the
+// reference normalises over edge[1] (attention_norm_idx = 1, function_transformer_attention.py:210-213).
+template <int H, int DK4, int GL, int RI, int PB, int NB, int MODE>
 __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
                                                                  int hub_phase, float* __restrict__ part,
                                                                  const int* __restrict__ chunk_first) {
@@ -692,23 +725,54 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
   // The reductions run LEVEL by level over all RI rows of the wave, not row by row: every xor step is a dependent LDS round
   // trip (ds_bpermute + wait), and written row by row the 10 steps of a row x RI rows formed one chain of 40 (round 3, from the
   // ISA); level-synchronous there are RI independent exchanges in flight per step.  Same operations per row, same order.
+  if constexpr (MODE == 2) {     // only the maximum over every score (slots past the end hold -inf, rows past the end repeat a listed row)
+    float mw = m[0];
 #pragma unroll
-  for (int off = H; off < GL; off <<= 1)
-#pragma unroll
-    for (int r = 0; r < RI; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, kWave));
+    for (int r = 1; r < RI; ++r) mw = fmaxf(mw, m[r]);
+    mw = wave_max(mw);
+    // one atomic per wave at most, and only while the wave's maximum beats the value it can see (a stale read only costs an atomic:
+    // tens of thousands of waves hammering ONE address serialise -- 0.7 ms per sweep at the ogbn-arxiv shape when every wave did)
+    if (lane == 0 && mw > -INFINITY) {
+      const unsigned mine = f2ord(mw);
+      if (mine > __hip_atomic_load(a.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.gmax, mine);
+    }
+    return;
+  }
   float l[RI];
+  if constexpr (MODE == 1) {
+    const float gm = ord2f(*a.gmax);
 #pragma unroll
-  for (int r = 0; r < RI; ++r) {
-    l[r] = 0.f;
+    for (int r = 0; r < RI; ++r) {
+      l[r] = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (nb < nbatch) {
+      for (int nb = 0; nb < NB; ++nb)
+        if (nb < nbatch) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-          s[r][nb * PB + i] = __builtin_amdgcn_exp2f((s[r][nb * PB + i] - m[r]) * 1.44269504088896341f);   // v_exp_f32: arguments are <= 0, -inf -> 0
-          l[r] += s[r][nb * PB + i];
+          for (int i = 0; i < PB; ++i) {
+            const float sv = s[r][nb * PB + i];
+            s[r][nb * PB + i] = sv > -INFINITY ? squareplus_num(sv, gm) : 0.f;
+            l[r] += s[r][nb * PB + i];
+          }
         }
-      }
+    }
+  } else {
+#pragma unroll
+    for (int off = H; off < GL; off <<= 1)
+#pragma unroll
+      for (int r = 0; r < RI; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, kWave));
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+      l[r] = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (nb < nbatch) {
+#pragma unroll
+          for (int i = 0; i < PB; ++i) {
+            s[r][nb * PB + i] = __builtin_amdgcn_exp2f((s[r][nb * PB + i] - m[r]) * 1.44269504088896341f);   // v_exp_f32: arguments are <= 0, -inf -> 0
+            l[r] += s[r][nb * PB + i];
+          }
+        }
+    }
   }
 #pragma unroll
   for (int off = H; off < GL; off <<= 1)
@@ -736,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int e = e0[r] + (nb * PB + i) * GE + slot;
-          if (head == 0 && live[r] && e < e1[r]) a.w_mean[e] = v[r][i] / static_cast<float>(H);
+          if (head == 0 && live[r] && e < e1[r]) a.w_mean[a.out_pos != nullptr ? a.out_pos[e] : e] = v[r][i] / static_cast<float>(H);
         }
     }
 }
@@ -805,27 +869,36 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
   }
 }
 
-template <int H, int DK4>
-void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
-                    const int* chunk_first = nullptr) {
+template <int H, int DK4, int MODE>
+void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub, float* part, const int* chunk_first) {
   constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
   constexpr int RPW16 = kWave / GL16;
   constexpr int RI16 = (DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1);  // rows interleaved per group
   constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);         // passes to cover GNPDE_LONG_ROW entries
   constexpr int PB64 = (DK4 == 1) ? 4 : 2;
-  // launch 1: hub phase 0 + rows with <= 16 entries; launch 2: hub phase 1 + rows with 17..512 entries
+  // launch 1: hub phase 0 + rows with <= 16 entries; launch 2: hub phase 1 + rows with 17..512 entries (the maximum sweep of
+  // squareplus, MODE 2, has no hub phase 1)
   if (n16 > 0 || n_hub > 0) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block) + n_hub;
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1, MODE>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
                        0, part, chunk_first);
   }
-  if (n64 > 0 || n_hub > 0) {
-    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub;
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64>), dim3(grid), dim3(kBlock), 0, s, a, n16,
-                       n64, n_hub, 1, part, chunk_first);
+  const int n_hub2 = MODE == 2 ? 0 : n_hub;
+  if (n64 > 0 || n_hub2 > 0) {
+    const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub2;
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64, MODE>), dim3(grid), dim3(kBlock), 0, s, a, n16,
+                       n64, n_hub2, 1, part, chunk_first);
   }
+}
+
+template <int H, int DK4>
+void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
+                    const int* chunk_first = nullptr) {
+  if (a.sp_mode == 1) launch_rows_sd_mode<H, DK4, 1>(a, n16, n64, s, n_hub, part, chunk_first);
+  else if (a.sp_mode == 2) launch_rows_sd_mode<H, DK4, 2>(a, n16, n64, s, n_hub, part, chunk_first);
+  else launch_rows_sd_mode<H, DK4, 0>(a, n16, n64, s, n_hub, part, chunk_first);
 }
 
 // scaled-dot rows + hub chunks in two launches; false if this (heads, d_k) has no specialised kernel
@@ -1030,6 +1103,39 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
     return 0;
   }
 
+  // scaled-dot scores with the OTHER normalisers in fused segment passes (the three passes below round-trip an [E,h] score array
+  // and walk the segments twice: 2 - 2.5 x the time of the row softmax at the ogbn-arxiv shape).  squareplus: one sweep for the
+  // global maximum, then the fused kernel with it; normalisation over the columns: the same kernels over the rows of the
+  // transposed graph with q and k exchanged, the weights scattered to their CSR positions.
+  {
+    const gnpde_graph_t* sg = a.norm_idx == 0 ? g : at->graph_t;
+    const bool sd_fast = !stats_only && pass_only == 0 && !hubs_only && a.type == GNPDE_ATT_SCALED_DOT && vec4 && att_edge == nullptr &&
+                         prods_edge == nullptr && w_mean_csr != nullptr && (fork == nullptr || fork->aux == nullptr) &&
+                         (a.h == 1 || a.h == 2 || a.h == 4 || a.h == 8) && (a.dk == 4 || a.dk == 8 || a.dk == 16) &&
+                         g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] == 0 && g->row_begin == 0 && sg != nullptr && sg->bin_rows != nullptr &&
+                         sg->rowidx != nullptr && sg->n == g->n && sg->e == g->e && sg->row_begin == 0 &&
+                         (sg->n_long_rows == 0 || (sg->long_chunk_first != nullptr && sg->long_chunk_begin != nullptr)) &&
+                         (a.norm_idx == 0 || (at->t_from_csr != nullptr && a.edge_w == nullptr));
+    if (sd_fast) {
+      AttArgs c = a;
+      c.rowidx = sg->rowidx; c.colidx = sg->colidx; c.rowptr = sg->rowptr; c.bin_rows = sg->bin_rows;
+      c.chunk_begin = sg->long_chunk_begin; c.chunk_end = sg->long_chunk_end; c.long_segs = sg->long_rows;
+      if (a.norm_idx == 1) {
+        c.q = a.k; c.k = a.q;            // the segment's own vector is k_j, the gathered one q_i
+        c.out_pos = at->t_from_csr;
+      }
+      const int n_hub = sg->n_long_rows > 0 ? sg->n_long_chunks : 0;
+      if (a.square_plus) {
+        c.sp_mode = 2;
+        if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
+        GNPDE_LAUNCH_CHECK();
+        c.sp_mode = 1;
+      }
+      if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
+      GNPDE_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (pass_only == 0 || pass_only == 1) {
     launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
     GNPDE_LAUNCH_CHECK();

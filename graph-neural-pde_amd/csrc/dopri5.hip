@@ -247,6 +247,7 @@ using namespace gnpde;
 struct gnpde_dopri5 {
   gnpde_rhs_t rhs;
   gnpde_graph_t graph;
+  gnpde_graph_t graph_t;
   RhsLayout L;
   float rtol, atol;
   char* ws;
@@ -372,6 +373,10 @@ extern "C" int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs,
   s->rhs = *rhs;
   s->graph = *rhs->graph;
   s->rhs.graph = &s->graph;
+  if (s->rhs.att.graph_t != nullptr) {   // (the descriptor's transposed graph is copied as well: the caller's structs may go away)
+    s->graph_t = *s->rhs.att.graph_t;
+    s->rhs.att.graph_t = &s->graph_t;
+  }
   s->rtol = rtol;
   s->atol = atol;
   s->L = rhs_layout(s->rhs);

@@ -506,6 +506,9 @@ int create_common(gnpde_sharded_solver** out, gnpde_comm* comm, gnpde_p2p* p2p, 
   s->exchanges = p2p ? halo->world > 1 : (n_send > 0 || n_recv > 0);
   s->rhs_int = *rhs_interior;
   s->rhs_bnd = *rhs_boundary;
+  // (row-range views: the column normaliser keeps its three exchangeable passes, never the transposed-graph form)
+  s->rhs_int.att.graph_t = nullptr; s->rhs_int.att.t_from_csr = nullptr;
+  s->rhs_bnd.att.graph_t = nullptr; s->rhs_bnd.att.t_from_csr = nullptr;
   s->g_int = *rhs_interior->graph;
   s->g_bnd = *rhs_boundary->graph;
   s->rhs_int.graph = &s->g_int;

@@ -129,6 +129,7 @@ using namespace gnpde;
 struct gnpde_solver {
   gnpde_rhs_t rhs;
   gnpde_graph_t graph;
+  gnpde_graph_t graph_t;
   int method;
   std::vector<float> dts;
   char* ws;
@@ -319,6 +320,10 @@ extern "C" int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs,
   s->rhs = *rhs;
   s->graph = *rhs->graph;
   s->rhs.graph = &s->graph;
+  if (s->rhs.att.graph_t != nullptr) {   // (the descriptor's transposed graph is copied as well: the caller's structs may go away)
+    s->graph_t = *s->rhs.att.graph_t;
+    s->rhs.att.graph_t = &s->graph_t;
+  }
   s->method = method;
   s->dts.assign(dts, dts + n_steps);
   s->L = rhs_layout(s->rhs);

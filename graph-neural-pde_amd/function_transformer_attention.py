@@ -152,9 +152,13 @@ class SpGraphTransAttentionLayer(nn.Module):
     elif self.opt['attention_type'] == 'exp_kernel':
       kw = dict(output_var=ops._scalar_dev(self.output_var, graph.rowptr),
                 lengthscale=ops._scalar_dev(self.lengthscale, graph.rowptr))
+    transposed = None
+    if self.opt['attention_norm_idx'] == 1 and self.opt['attention_type'] == 'scaled_dot' and graph.device.type == 'cuda' \
+        and graph.struct.row_begin == 0 and graph.n == graph.t['rowptr'].numel() - 1:
+      transposed = graph.transposed_positions()     # the column normaliser as a fused row pass over the transposed graph
     st = ops.attention_struct(_lib.ATT_TYPES[self.opt['attention_type']], self.h, self.kernel_att_dim,
                               self.opt['attention_norm_idx'], self.opt['square_plus'], q=q, k=k, ldqk=ldqk,
-                              edge_w_csr=self._reweight_csr(graph), **kw)
+                              edge_w_csr=self._reweight_csr(graph), transposed=transposed, **kw)
     keep = [q, k] + list(kw.values())
     return st, keep
 
@@ -231,7 +235,7 @@ class ODEFuncTransformerAtt(ODEFunc):
     s = desc.struct
     a = s.att
     return (id(desc.graph), s.alpha, s.beta, s.x0, s.alpha_sigmoid, s.proj_w, s.proj_b, s.proj_m, s.d, s.ld,
-            a.type, a.heads, a.att_dim, a.norm_idx, a.square_plus, a.output_var, a.lengthscale, a.edge_w_csr)
+            a.type, a.heads, a.att_dim, a.norm_idx, a.square_plus, a.output_var, a.lengthscale, a.edge_w_csr, a.t_from_csr)
 
   def __repr__(self):
     return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

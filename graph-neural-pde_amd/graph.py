@@ -222,6 +222,21 @@ class CSRGraph(object):
       self._transposed = CSRGraph(self._edge_index.flip(0), self.n, self.device)
     return self._transposed
 
+  def transposed_positions(self):
+    """(graph_t, t_from_csr): CSR of the transposed operator over the same edge list, and for every position of graph_t the CSR
+    position of the same entry in this graph (both are stable sorts of one edge list: composed through the edge ids)."""
+    hit = self.__dict__.get('_t_from_csr')
+    if hit is None:
+      gt = self.transposed()
+      if self.e > 0:
+        inv = torch.empty(self.e, dtype=torch.int64, device=self.device)
+        inv[self.perm_long] = torch.arange(self.e, dtype=torch.int64, device=self.device)
+        t_from_csr = inv[gt.perm_long].to(torch.int32).contiguous()
+      else:
+        t_from_csr = torch.zeros(1, dtype=torch.int32, device=self.device)
+      hit = self.__dict__['_t_from_csr'] = (gt, t_from_csr)
+    return hit
+
   def locality_view(self, row_bytes, mode='auto'):
     """LocalityView of this graph (the same operator with its nodes relabelled), or None when it does not apply / does not
     pay.  row_bytes: bytes of one row of the table the aggregation gathers from.  Two orders are candidates:

@@ -592,19 +592,6 @@ def _adjoint_native_ok(func, y, method):
   return False
 
 
-def _transposed_positions(graph):
-  """(graph_t, t_from_csr): CSR of the transposed operator over the same edge list, and for every position of graph_t the CSR
-  position of the same entry in `graph` (both stable sorts of one edge list: composed through the edge ids)."""
-  hit = graph.__dict__.get('_t_from_csr')
-  if hit is None:
-    gt = graph.transposed()
-    inv = torch.empty(graph.e, dtype=torch.int64, device=graph.device)
-    inv[graph.perm_long] = torch.arange(graph.e, dtype=torch.int64, device=graph.device)
-    t_from_csr = inv[gt.perm_long].to(torch.int32).contiguous() if graph.e > 0 else torch.zeros(1, dtype=torch.int32, device=graph.device)
-    hit = graph.__dict__['_t_from_csr'] = (gt, t_from_csr)
-  return hit
-
-
 def _adjoint_native(func, params, y, a, span, method, step_size):
   """(a at the earlier time, [gradient contribution per entry of `params`]) of one backward interval, by the native solver."""
   from . import ops
@@ -645,7 +632,7 @@ def _adjoint_native(func, params, y, a, span, method, step_size):
       view.enter(func.x0.detach(), out=ent['x0'])
   graph = func._graph(y) if view is None else view.graph
   desc = func._descriptor(yb, x0_override=ent['x0'], graph=graph)
-  gt, t_from_csr = _transposed_positions(graph)
+  gt, t_from_csr = graph.transposed_positions()
   nl = func.__class__.__name__ == 'ODEFuncTransformerAtt'
   ex = ent['extra']
   proj_wt = w_t = None

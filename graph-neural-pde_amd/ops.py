@@ -268,7 +268,7 @@ def head_spmm(graph, ds_csr, feat, heads, dk, scale, by_column, out=None):
 
 
 def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=None, ldqk=0, leaky_slope=0.2,
-                     gat_a=None, output_var=None, lengthscale=None, edge_w_csr=None):
+                     gat_a=None, output_var=None, lengthscale=None, edge_w_csr=None, transposed=None):
   a = _lib.AttentionStruct()
   a.type, a.heads, a.att_dim = int(att_type), int(heads), int(att_dim)
   a.norm_idx, a.square_plus, a.leaky_slope = int(norm_idx), int(bool(square_plus)), float(leaky_slope)
@@ -280,7 +280,11 @@ def attention_struct(att_type, heads, att_dim, norm_idx, square_plus, q=None, k=
     setattr(a, name, t.data_ptr() if t is not None else None)
   # the struct only holds raw addresses: keep the tensors alive as long as the struct (a temporary passed by
   # the caller would otherwise be freed, and its memory reused, before the kernels read it)
-  a._keepalive = (q, k, gat_a, output_var, lengthscale, edge_w_csr)
+  a._keepalive = (q, k, gat_a, output_var, lengthscale, edge_w_csr, transposed)
+  if transposed is not None:      # (graph_t, t_from_csr) of graph.CSRGraph.transposed_positions(): the column normaliser as a fused row pass
+    gt, t_from_csr = transposed
+    a.graph_t = ctypes.pointer(gt.struct)
+    a.t_from_csr = t_from_csr.data_ptr()
   return a
 
 

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 2   /* 2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map */
+#define GNPDE_ABI_VERSION 3   /* 2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+                                 gnpde_adjoint_*, gnpde_stream_read */
 
 #define GNPDE_EINVAL   (-1)  /* bad argument                                  */
 #define GNPDE_ESHAPE   (-2)  /* shape not supported by any kernel variant     */
@@ -286,6 +287,12 @@ typedef struct gnpde_attention {
   const float* output_var;   /* device scalar (exp_kernel)                                     */
   const float* lengthscale;  /* device scalar (exp_kernel)                                     */
   const float* edge_w_csr;   /* [e] CSR order or NULL: opt['reweight_attention'] (:208-209)    */
+  /* optional (norm_idx == 1, scaled-dot scores): the transposed graph over the SAME edge list and, for every position of it, the
+   * CSR position of that entry in the graph the call is made on.  With them the normalisation over the COLUMNS runs as the fused
+   * row kernel over the rows of graph_t (scores, statistics and weights in one pass, weights scattered to their CSR positions)
+   * instead of three passes with an [E,h] score round trip; NULL: the three passes. */
+  const struct gnpde_graph* graph_t;
+  const int32_t* t_from_csr;
 } gnpde_attention_t;
 
 /* Scratch: scores [e,h] + segment statistics [n,2h] + global max + GAT node terms [n,2h]. */

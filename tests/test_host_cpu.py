@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), 'libgnpde_hip.so does not export %s' % name
   assert declared == set(_lib.PROTOTYPES), 'ctypes prototypes out of sync with gnpde.h'
-  assert G.lib().gnpde_abi_version() == 2
+  assert G.lib().gnpde_abi_version() == 3
 
 
 def test_every_entry_point_is_documented():
@@ -42,7 +42,7 @@ def test_structs_match_header_layout():
   assert ctypes.sizeof(_lib.GraphStruct) == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 3 * 8 + 8   # (+ xcd_deal and its padding)
   assert _lib.GraphStruct.xcd_deal.offset == 8 + 6 * 8 + 8 + 5 * 8 + 24 + 3 * 8
   assert ctypes.sizeof(_lib.EpilogueStruct) == 3 * 8 + 4 + 4 + 4 + 4 + 6 * 8 + 8 + 7 * 8 + 8 * 4 + 8
-  assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8
+  assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8 + 2 * 8     # (+ graph_t, t_from_csr: ABI 3)
   assert ctypes.sizeof(_lib.DecoderStruct) == 4 * 8 + 2 * 4
 
 
