@@ -191,6 +191,12 @@ __device__ __forceinline__ float squareplus_num(float s, float gmax) {
   const float z = s - gmax;
   return (z + sqrtf(z * z + 4.0f)) / 2.0f;
 }
+// the same with v_sqrt_f32 (1 ulp) and an exact halving: the fused row kernel is bound by VALU issue, and the IEEE square root is a
+// dozen instructions per (entry, head)
+__device__ __forceinline__ float squareplus_num_fast(float s, float gmax) {
+  const float z = s - gmax;
+  return (z + __builtin_amdgcn_sqrtf(fmaf(z, z, 4.0f))) * 0.5f;
+}
 
 // ---- pass 2: one wavefront per segment (heads in an outer loop); segments longer than GNPDE_LONG_ROW
 // are left to seg_stats_long_kernel so that a hub does not serialise on one wave
@@ -650,19 +656,31 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
       e1[r] = __builtin_amdgcn_readfirstlane(e1[r]);
     }
   }
-  float4 qv[RI][DK4];
-#pragma unroll
-  for (int r = 0; r < RI; ++r)
-#pragma unroll
-    for (int j = 0; j < DK4; ++j)
-      qv[r][j] = *reinterpret_cast<const float4*>(a.q + static_cast<size_t>(row[r]) * a.ldqk + head * a.dk + 4 * j);
-
   float s[RI][NB * PB];
   float m[RI];
 #pragma unroll
   for (int r = 0; r < RI; ++r) m[r] = -INFINITY;
   int nbatch = NB;
   if constexpr (GL == kWave && RI == 1) nbatch = (e1[0] - e0[0] + PB * GE - 1) / (PB * GE);  // wave-uniform
+  if constexpr (MODE == 1) {
+    // squareplus, second sweep: the scores were stored by the maximum sweep (MODE 2) -- one coalesced 4 H-byte read per entry
+    // instead of the k-row gather
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int e = e0[r] + (nb * PB + i) * GE + slot;
+          s[r][nb * PB + i] = (nb < nbatch && e < e1[r]) ? a.scores[static_cast<size_t>(e) * H + head] : -INFINITY;
+        }
+  } else {
+  float4 qv[RI][DK4];
+#pragma unroll
+  for (int r = 0; r < RI; ++r)
+#pragma unroll
+    for (int j = 0; j < DK4; ++j)
+      qv[r][j] = *reinterpret_cast<const float4*>(a.q + static_cast<size_t>(row[r]) * a.ldqk + head * a.dk + 4 * j);
 
   // column ids of the batch AFTER the current one are requested before the current batch's k rows are used, so that a row of
   // several batches pays one dependent round trip per batch (k rows), not two (ids -> k rows)
@@ -711,6 +729,9 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
           //  division sequences and the full-range expf -- round 3: exact power-of-two scale, one reciprocal per row, v_exp)
           float sv = dot * a.scale_mul;
           if (a.edge_w != nullptr) sv = sv * a.edge_w[e < e1[r] ? e : e1[r] - 1];
+          if constexpr (MODE == 2) {
+            if (live[r] && e < e1[r]) a.scores[static_cast<size_t>(e) * H + head] = sv;     // kept for the second sweep
+          }
           sv = e < e1[r] ? sv : -INFINITY;
           s[r][nb * PB + i] = sv;
           m[r] = fmaxf(m[r], sv);
@@ -722,6 +743,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
         for (int i = 0; i < PB; ++i) s[r][nb * PB + i] = -INFINITY;
     }
   }
+  }   // MODE != 1
   // The reductions run LEVEL by level over all RI rows of the wave, not row by row: every xor step is a dependent LDS round
   // trip (ds_bpermute + wait), and written row by row the 10 steps of a row x RI rows formed one chain of 40 (round 3, from the
   // ISA); level-synchronous there are RI independent exchanges in flight per step.  Same operations per row, same order.
@@ -750,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 #pragma unroll
           for (int i = 0; i < PB; ++i) {
             const float sv = s[r][nb * PB + i];
-            s[r][nb * PB + i] = sv > -INFINITY ? squareplus_num(sv, gm) : 0.f;
+            s[r][nb * PB + i] = sv > -INFINITY ? squareplus_num_fast(sv, gm) : 0.f;
             l[r] += s[r][nb * PB + i];
           }
         }

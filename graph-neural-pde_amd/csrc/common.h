@@ -96,7 +96,8 @@ enum {
   GNPDE_TUNE_FORK = 3,                 // 1: hub-row work on a second stream (fork / join)
   GNPDE_TUNE_ATT_GENERIC_ROWS = 4,     // 1: generic row-attention kernel instead of the scaled-dot specialisation
   GNPDE_TUNE_RK4_CLASSIC = 5,          // 1: torchdiffeq-order rk4 stages (k1..k3 stored) instead of the compact form
-  GNPDE_TUNE_ROW_FUSION = 6,           // 1: row attention + aggregation in one kernel (attn_spmm_kernel; slower, kept for A/B)
+  GNPDE_TUNE_ROW_FUSION = 6,           // row attention + aggregation in one kernel (attn_spmm_kernel): 0 = only for graphs whose state fits an XCD's L2
+                                       // (launch-bound evaluations), 1 = always (slower at scale, A/B), 2 = never
   GNPDE_TUNE_ONE_PASS_VARIANT = 7,     // register / unroll variants of the one-pass kernel (tools/onepass_ab.py)
   GNPDE_TUNE_LINEAR_STREAMING = 8,     // 1: one-tile-per-wave projection kernel instead of the persistent one
   GNPDE_TUNE_SPMM_PART = 9,            // measurement only: 1 = hub chunks only, 2 = rows only (results are then incomplete)

@@ -50,7 +50,7 @@ __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ base, int
 // FULL: every column tile is complete and d % 16 == 0 -> no guards on the operand loads (rows past the end
 // are clamped to the last row and only their stores are masked), so the loads of a K batch are
 // straight-line code the scheduler can issue back to back, and one launch covers the ragged last tile.
-template <int MT, bool ALIGNED, bool FULL>
+template <int MT, bool ALIGNED, bool FULL, int KUV = (MT <= 2 ? 4 : 2)>
 __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int n, int d, int ldx,
                                                         const float* __restrict__ W, int m, int ldw,
                                                         const float* __restrict__ b, float* __restrict__ out,
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
   const long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
   const int row0 = row_base + static_cast<int>(tile * 16);
   if (row0 >= n) return;
+  col_base += static_cast<int>(blockIdx.y) * (MT * 16);     // 2-D launches: grid.y walks the column groups (small n, below)
   const int r = lane & 15;       // row within the tile (A operand) / column within a 16-col tile (B)
   const int kq = lane >> 4;      // which 4-wide K quarter of the 16-wide K block
   const int arow = row0 + r;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict_
   // KU 16-wide K blocks per iteration: all operand loads of an iteration are issued before the first
   // MFMA so that several HBM round trips overlap (a wave has only d/16 dependent-free blocks to hide
   // ~2 us of latency behind)
-  constexpr int KU = MT <= 2 ? 4 : 2;
+  constexpr int KU = KUV;
   for (int kb = 0; kb < d; kb += 16 * KU) {
     f32x4 av[KU];
     f32x4 bv[KU][MT];
@@ -430,9 +431,29 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
                        ldo, col, 0, relu);
 }
 
+// Small n (Cora: 2 708 rows, [n,80] x [80,256]): the persistent / LDS-staged kernels above are built to stream a tall x -- at 170 row
+// tiles they put 22 workgroups on the chip, each staging 40 KB of W first, and need one launch per 128 output columns: 2 x 9.8 us
+// per evaluation, two thirds of a launch-bound GRAND-nl evaluation on such a graph.  Here ONE launch covers all of [n, m]: a
+// wavefront per (16-row tile, 32-column group), operands straight from L2, EIGHT 16-wide K blocks in flight per batch (d <= 128:
+// every operand load of the wave is issued before its first MFMA -- the launch is a few dependent round trips long, nothing
+// else).  Same MFMA sequence and k order per output element as
+// every other variant (bit-identical results).
+constexpr long long kSmallLinearTiles = 2048;      // n <= 32 768 rows
+
 template <bool ALIGNED>
 void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                    int ldo, hipStream_t s, int relu) {
+  if constexpr (ALIGNED) {
+    const long long tiles = (static_cast<long long>(n) + 15) / 16;
+    if (tiles <= kSmallLinearTiles && d % 16 == 0 && m % 16 == 0 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] == 0) {
+      const unsigned gx = static_cast<unsigned>((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+      if (m % 32 == 0)
+        hipLaunchKernelGGL((linear_kernel<2, true, true, 8>), dim3(gx, m / 32), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, 0, 0, relu);
+      else
+        hipLaunchKernelGGL((linear_kernel<1, true, true, 8>), dim3(gx, m / 16), dim3(kBlock), 0, s, x, n, d, ldx, W, m, ldw, b, out, ldo, 0, 0, relu);
+      return;
+    }
+  }
   int col = 0;
   while (col < m) {
     const int rem = (m - col + 15) / 16;

@@ -1685,7 +1685,12 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
 
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
                          const gnpde_epilogue_t& e) {
-  if (g_tune[GNPDE_TUNE_ROW_FUSION] != 1) return false;   // opt-in: measured SLOWER than the separate kernels
+  // Row attention inside the aggregation kernel: measured SLOWER than the separate kernels where the kernels are bound by memory
+  // (ogbn-arxiv and up: DESIGN.md section 4) -- opt-in there (gnpde_tune(6, 1)); where an evaluation is bound by its LAUNCHES (a
+  // state that fits one XCD's L2: Cora, 0.87 MB) one launch instead of three is the point: 7.8 us vs 5.2 + 5.2 (+ boundaries),
+  // profiles/r04_cora_*.  gnpde_tune(6, 2) keeps the separate kernels there too (A/B).
+  const bool small = static_cast<long long>(g->n) * ld * 4 <= (4LL << 20) && g->n_long_rows == 0;
+  if (!(g_tune[GNPDE_TUNE_ROW_FUSION] == 1 || (small && g_tune[GNPDE_TUNE_ROW_FUSION] != 2))) return false;
   if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
   const int dk = at.att_dim / at.heads;
   if (!((at.heads == 4 && dk == 4) || (at.heads == 8 && dk == 16) || (at.heads == 4 && dk == 16) || (at.heads == 2 && dk == 16)))
