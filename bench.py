@@ -66,6 +66,9 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
+  ap.add_argument('--config', default=None, choices=['c4'],
+                  help='c4: BASELINE configs[3] -- ogbn-arxiv BLEND (beltrami split kernel, d = 64 + 98 = 162), block_transformer_rewiring in '
+                       'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward)')
   ap.add_argument('--train', action='store_true',
                   help='training iteration instead of the inference solve: forward (tape-free native solver) + backward (native adjoint '
                        'solve, opt[adjoint] with adjoint_method rk4 / adjoint_step_size 1) of K steps each; prints its own JSON line')
@@ -535,6 +538,137 @@ def cpu_baseline(block, x_cpu, evals):
   return dt, out, {str(c): round(v * 1e3, 1) for c, v in trials.items()}
 
 
+def c4_main(G, args, dev):
+  """`--config c4`: BASELINE configs[3] as named -- ogbn-arxiv shape, BLEND (beltrami: 64 feature + 98 positional channels = d 162,
+  the split exp kernel of reference src/function_transformer_attention.py:133-171), `block_transformer_rewiring` in evaluation mode
+  (head-mean attention recomputed once per forward on the rw-normalised edge set, src/block_transformer_rewiring.py:185-241),
+  Laplacian function, dopri5 with tol_scale 11353, T = 3.676 (best_params ogbn-arxiv).  One "step" of the metric is one FORWARD
+  (the adaptive solver chooses its own steps): ms per forward, evaluations of f, and the aggregation's roofline at d = 162 (rows
+  padded to 164 floats).  cpu_baseline: the restated torchdiffeq dopri5 (oracle/shims) over the oracle's right-hand side."""
+  ei_cpu, n = G.synthetic.make_graph('arxiv', seed=args.seed, scale=args.scale)
+  f0, p0 = 64, 98
+  d = f0 + p0
+  x_cpu = torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed + 41)) * 0.5
+  x, ei = x_cpu.to(dev), ei_cpu.to(dev)
+  opt = dict(heads=2, attention_dim=32, attention_type='exp_kernel', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+             beltrami=True, feat_hidden_dim=f0, pos_enc_hidden_dim=p0, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9,
+             add_source=False, no_alpha_sigmoid=False, mix_features=False, hidden_dim=d, augment=False, adjoint=False,
+             tol_scale=11353.558848254957, data_norm='rw', method='dopri5', step_size=1.0, max_iters=100, block='rewire_attention',
+             function='laplacian', time=3.6760155951687636, att_samp_pct=0.81, use_flux=False, new_edges='k_hop_att', sparsify='S_hat',
+             rw_addD=0.02, threshold_type='addD_rvR', rw_rmvR=0.02)
+  data = _Data()
+  data.x, data.edge_index, data.edge_attr, data.num_nodes = x, ei, None, n
+  block = G.RewireAttODEblock(G.LaplacianODEFunc, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(args.seed + 5)
+  with torch.no_grad():
+    for name, p in block.named_parameters():
+      if 'multihead_att_layer' in name and p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      elif 'lengthscale' in name or 'output_var' in name:
+        p.copy_((1.0 + 0.3 * torch.rand(p.shape, generator=g)).to(dev))
+    block.odefunc.alpha_train.fill_(0.4)
+  block.eval()
+  block.set_x0(x)
+  f = block.odefunc
+  times = []
+  with torch.no_grad():
+    for _ in range(max(args.warmup, 1)):
+      block(x)
+    for _ in range(max(args.replays, 3)):
+      f.nfe = 0
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      z = block(x)
+      torch.cuda.synchronize()
+      times.append(time.perf_counter() - t0)
+  assert torch.isfinite(z).all()
+  elapsed = sorted(times)[len(times) // 2]
+  nfe = int(f.nfe)
+  stats = dict(getattr(f, '_dopri5_stats', {}) or {})
+  E = int(f.edge_index.shape[1])
+  # the solve alone (the attention pass of the block outside): time of odeint on the function the block prepared
+  with torch.no_grad():
+    tt = torch.tensor([0.0, opt['time']], device=dev)
+    kw = dict(method='dopri5', atol=block.atol, rtol=block.rtol)
+    G.odeint(f, x, tt, **kw)
+    solve = []
+    for _ in range(3):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      G.odeint(f, x, tt, **kw)
+      torch.cuda.synchronize()
+      solve.append(time.perf_counter() - t0)
+  t_solve = sorted(solve)[1]
+  # roofline of the dominant kernel: the aggregation at d = 162 on padded rows, with the stage epilogue of the middle of a trial step
+  # (LINCOMB with three earlier stage derivatives), HIP events around a captured graph of launches
+  from gnpde_amd import ops, _lib
+  view = f._locality_view(x) if hasattr(f, '_locality_view') else None
+  bufs = [_lib.alloc_state(n, d, dev) for _ in range(3)]
+  for b_ in bufs:
+    b_.copy_(torch.randn(n, d, device=dev))
+  u, y, out = bufs
+  ld = u.stride(0)
+  # through the descriptor the solver itself builds (padded rows -> 16-byte lanes), on the graph the solve runs on
+  desc = f._descriptor(u, graph=None if view is None else view.graph)
+
+  def launch():
+    ops.rhs_stage(desc, u, _lib.STAGE_LINCOMB, y=y, out_k=out)
+  try:
+    t_agg = timed_replay(launch, 8)
+  except Exception:   # noqa: BLE001
+    t_agg = None
+  bytes_agg = E * (8 + 4 * d) + n * (4 + 8 * d)          # SURVEY 8d B_l (no source term in this configuration)
+  out_line = {
+    'metric': 'forward passes/sec (adaptive solve), ogbn-arxiv BLEND d=162 dopri5',
+    'value': round(1.0 / elapsed, 3), 'unit': 'forwards/s', 'n_gpus': 1, 'steps': 1, 'warmup': args.warmup,
+    'ms_per_step': round(elapsed * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+    'data': 'synthetic',
+    'config': {'workload': 'BASELINE configs[3]: synthetic ogbn-arxiv-shaped graph, BLEND (beltrami split exp kernel, 64 feature + 98 positional '
+                           'channels), block_transformer_rewiring (evaluation mode), Laplacian function, dopri5 tol_scale 11353, T = 3.676; '
+                           'one step = one forward of the block (attention once + adaptive solve)',
+               'nodes': n, 'edges_with_self_loops': E, 'd': d, 'row_stride': ld, 'attention_dim': 32, 'heads': 2, 'scale': args.scale},
+    'ms_per_forward': round(elapsed * 1e3, 3), 'ms_solve_only': round(t_solve * 1e3, 3),
+    'rhs_evals_per_forward': nfe, 'dopri5': stats,
+    'ms_per_rhs_eval_incl_controller': round(t_solve * 1e3 / max(nfe, 1), 4),
+    'aggregation_share_of_solve': None if t_agg is None else round(nfe * t_agg / t_solve, 4),
+    'roofline': None if t_agg is None else {
+      'kernel': 'CSR aggregation + explicit-RK stage epilogue at d = 162 (rows padded to 164 floats: spmm_wide_kernel, 41 of 64 16-byte lanes live), on the graph the solve runs on (relabelled: %s)' % (view is not None),
+      'bound': 'mall', 'achieved': round(bytes_agg / t_agg / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+      'frac': round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4),
+      'frac_is': 'frac_algorithmic: gather-model bytes E (8 + 4 d) + N (4 + 8 d) / launch time / 8 TB/s (the 105-MiB state is Infinity-Cache resident)',
+      'algorithmic_bytes_per_launch': bytes_agg, 'avg_launch_us': round(t_agg * 1e6, 2), 'traffic': None},
+    'cpu_baseline': None,
+  }
+  if not args.no_cpu_baseline:
+    # the restated torchdiffeq dopri5 over the oracle's right-hand side: ONE forward on the host (same accept / reject sequence)
+    from oracle import restate as R
+    from oracle.shims import install as SH
+    cpu = lambda t: t.detach().cpu()   # noqa: E731
+    w_edge = cpu(f.edge_weight)
+    e_n = cpu(f.edge_index)
+    calls = [0]
+
+    def rhs(t, yv):
+      calls[0] += 1
+      return R.rhs_laplacian(yv, e_n, w_edge, cpu(f.alpha_train), cpu(f.beta_train), None, False, False)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    TD = SH          # oracle/shims/install.py: the restated torchdiffeq 0.2.1 (odeint with euler / rk4 / dopri5)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+      ref = TD.odeint(rhs, x_cpu, torch.tensor([0, opt['time']], dtype=torch.float32), method='dopri5', options={},
+                      atol=opt['tol_scale'] * 1e-7, rtol=opt['tol_scale'] * 1e-9)[1]
+    t_cpu = time.perf_counter() - t0
+    from oracle.restate import parity_error
+    e_inf, e_2 = parity_error(z, ref)
+    out_line['cpu_baseline'] = dict(host_info(), value=round(1.0 / t_cpu, 5), unit='forwards/s', cores=torch.get_num_threads(), kind='port',
+                                    sample='ONE forward solve: restated torchdiffeq 0.2.1 dopri5 (oracle/shims) over the oracle right-hand side '
+                                           '(index_select -> mul -> scatter_add), %d evaluations, attention weights taken from the device' % calls[0],
+                                    seconds=round(t_cpu, 2), rhs_evals=calls[0])
+    out_line['parity_vs_restated_torchdiffeq'] = {'rel_max': e_inf, 'rel_l2': e_2, 'same_number_of_evaluations': bool(calls[0] == nfe)}
+    out_line['speedup_vs_cpu'] = round(t_cpu / t_solve, 1)
+  print(json.dumps(out_line))
+
+
 def train_main(G, args, opt, cfg, ei, n, x, dev):
   """`--train`: one training iteration of the ODE block at the benchmark shape -- forward = the tape-free native solver (K rk4
   steps, as inference), backward = the native adjoint solve (csrc/adjoint.hip: K rk4 steps of the augmented system, 4 K stages of
@@ -637,6 +771,8 @@ def main():
     from gnpde_amd import distributed as D
     return D.bench_main(args, rank, world, dev)
 
+  if args.config == 'c4':
+    return c4_main(G, args, dev)
   cfg = G.synthetic.CONFIGS[args.graph]
   ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
   opt = build_opt(cfg, args)

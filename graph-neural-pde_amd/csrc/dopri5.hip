@@ -61,11 +61,11 @@ static_assert(sizeof(Ctl) == 96, "controller record");
 
 // fold of the error partial sums (as rk_error_final_kernel of misc.hip) + torchdiffeq rk_common.py _adaptive_step /
 // _optimal_step_size: safety 0.9, ifactor 10, dfactor 0.2, order 5
-__global__ __launch_bounds__(kBlock) void control_kernel(const float* __restrict__ ws, int nblocks, double count, Ctl* c,
+__global__ __launch_bounds__(kBlock) void control_kernel(const double* __restrict__ ws, int nblocks, double count, Ctl* c,
                                                         int parity, double* __restrict__ times, int times_capacity) {
   __shared__ double red[kBlock];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += static_cast<double>(ws[i]);
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += ws[i];      // block partials in double (misc.hip, rk_error_partial_kernel)
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = kBlock / 2; s > 0; s >>= 1) {
@@ -322,7 +322,7 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   int nblocks = 0;
   if (int rc = launch_rk_error_ratio(y, y1, k, ce, 7, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
     return rc;
-  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, s->err_ws, nblocks, static_cast<double>(n) * r.d, s->ctl, parity,
+  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, reinterpret_cast<const double*>(s->err_ws), nblocks, static_cast<double>(n) * r.d, s->ctl, parity,
                      s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
   GNPDE_LAUNCH_CHECK();
   FinishArgs fa{};

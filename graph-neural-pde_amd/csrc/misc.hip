@@ -76,10 +76,13 @@ struct ErrArgs {
 // block partial sums of (err / tol)^2 in a fixed order -> ws[blockIdx].  VEC4: rows with a stride that is a multiple of 4
 // floats and 16-byte aligned operands are read as float4 (the padding columns [d, ld) are masked out).
 template <bool VEC4>
-__global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, float* __restrict__ ws) {
-  __shared__ float red[kWavesPerBlock];
+// The squares are summed in DOUBLE (per lane, per wave, per block): the norm is then independent of the order of the rows to ~1e-16,
+// far below the float32 the ratio is rounded to -- a solve on a relabelled graph (graph.LocalityView: same rows, permuted) takes the
+// same accept / reject decisions and step sizes as on the graph as given.
+__global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, double* __restrict__ ws) {
+  __shared__ double red[kWavesPerBlock];
   const float s = a.scale != nullptr ? *a.scale : 1.f;   // (applied at the use: the argument struct stays read-only, see lincomb_kernel)
-  float acc = 0.f;
+  double acc = 0.0;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   if constexpr (VEC4) {
     const int q = a.ld / 4;                       // float4 slots per row
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, flo
       for (int t = 0; t < 4; ++t) {
         if (c + t < a.d) {
           const float qv = e[t] / (a.atol + a.rtol * m[t]);
-          acc = fmaf(qv, qv, acc);
+          acc += static_cast<double>(qv * qv);
         }
       }
     }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, flo
       for (int j = 0; j < a.n_k; ++j) err = fmaf(a.k[j][off], a.coef[j] * s, err);
       const float tol = a.atol + a.rtol * fmaxf(fabsf(a.y0[off]), fabsf(a.y1[off]));
       const float qv = err / tol;
-      acc = fmaf(qv, qv, acc);
+      acc += static_cast<double>(qv * qv);
     }
   }
 #pragma unroll
@@ -127,11 +130,11 @@ __global__ __launch_bounds__(kBlock) void rk_error_partial_kernel(ErrArgs a, flo
   if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(kBlock) void rk_error_final_kernel(const float* __restrict__ ws, int nblocks, double count,
+__global__ __launch_bounds__(kBlock) void rk_error_final_kernel(const double* __restrict__ ws, int nblocks, double count,
                                                                float* __restrict__ ratio) {
   __shared__ double red[kBlock];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += static_cast<double>(ws[i]);
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += ws[i];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = kBlock / 2; s > 0; s >>= 1) {
@@ -203,6 +206,7 @@ int launch_dopri5_interp(const float* y0, const float* y1, const float* const* k
 int launch_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k, float atol,
                           float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace, hipStream_t s,
                           const float* scale, int* partial_blocks) {
+  GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 8 == 0, GNPDE_EINVAL, "rk_error_ratio: workspace must be 8-byte aligned");
   GNPDE_CHECK_ARG(y0 && y1 && k && coef && (ratio || partial_blocks) && workspace && n_k >= 1 && n_k <= GNPDE_MAX_PREV && n >= 1 && d >= 1 && ld >= d,
                   GNPDE_EINVAL, "rk_error_ratio: bad arguments");
   ErrArgs a{};
@@ -219,14 +223,14 @@ int launch_rk_error_ratio(const float* y0, const float* y1, const float* const* 
   const long long items = vec ? n * (ld / 4) : n * d;
   long long blocks = (items + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
-  if (vec) hipLaunchKernelGGL((rk_error_partial_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
-  else hipLaunchKernelGGL((rk_error_partial_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, workspace);
+  if (vec) hipLaunchKernelGGL((rk_error_partial_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, reinterpret_cast<double*>(workspace));
+  else hipLaunchKernelGGL((rk_error_partial_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a, reinterpret_cast<double*>(workspace));
   GNPDE_LAUNCH_CHECK();
   if (partial_blocks != nullptr) {   // the caller folds workspace[0 .. blocks) itself (sqrt(sum / (n d)))
     *partial_blocks = static_cast<int>(blocks);
     return 0;
   }
-  hipLaunchKernelGGL(rk_error_final_kernel, dim3(1), dim3(kBlock), 0, s, workspace, static_cast<int>(blocks),
+  hipLaunchKernelGGL(rk_error_final_kernel, dim3(1), dim3(kBlock), 0, s, reinterpret_cast<const double*>(workspace), static_cast<int>(blocks),
                      static_cast<double>(n) * d, ratio);
   GNPDE_LAUNCH_CHECK();
   return 0;

@@ -333,6 +333,7 @@ class CSRGraph(object):
     without it would train differently -- and are freed before this returns."""
     from . import ops
     gen = torch.Generator(device=self.device).manual_seed(20240521)
+    d = (int(d) + 3) // 4 * 4       # the solvers pad such rows to 16-byte lanes (alloc_state): time the kernel they will run
     u = torch.empty(self.n, d, device=self.device).normal_(generator=gen)
     out = torch.empty_like(u)
     w = torch.empty(max(self.e, 1), device=self.device).uniform_(generator=gen)

@@ -371,12 +371,11 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
   if room <= 0:
     raise MaxNFEException
   st = func.__dict__.setdefault('_dopri5_device', {})
-  # Relabelled graph (graph.LocalityView) only on request -- opt['gnpde_reorder'] / GNPDE_REORDER = '1', 'parts' or 'degree', not
-  # 'auto': the error norm of a trial step is a sum over the rows, so on the relabelled graph it is rounded differently, the step
-  # sizes differ in their last bits and the result is equal to the unrelabelled solve to rounding, not bit for bit
-  import os
-  mode = str(func.opt.get('gnpde_reorder', os.environ.get('GNPDE_REORDER', 'auto'))).lower()
-  view = func._locality_view(y0) if mode in ('1', 'true', 'on', 'force', 'parts', 'degree') and hasattr(func, '_locality_view') else None
+  # Relabelled graph (graph.LocalityView) under the same rule as the fixed-step solves (opt['gnpde_reorder'] / GNPDE_REORDER, 'auto' by
+  # default).  The error norm of a trial step is a sum over the rows; its squares are accumulated in double (csrc/misc.hip), so the
+  # float32 ratio -- and with it every accept / reject decision and step size -- is the same on the relabelled graph as on the graph as
+  # given (the states themselves are bit-identical row by row: the entries of a row keep their order)
+  view = func._locality_view(y0) if hasattr(func, '_locality_view') else None
   if evaluator is not None and view is not None:
     evaluator = evaluator.relabelled(view)
   key = (tuple(y0.shape), str(y0.device), float(rtol), float(atol), id(view))

@@ -28,6 +28,16 @@ def linear(x, weight, bias=None, out=None, relu_input=False):
     out = torch.empty(n, m, dtype=torch.float32, device=x.device)
   b = None if bias is None else f32c(bias, 'bias')
   fn = _lib.lib().gnpde_relu_linear if relu_input else _lib.lib().gnpde_linear
+  if n >= 4096 and (d % 16 != 0 or x.stride(0) % 4 != 0 or weight.stride(0) % 4 != 0):
+    # a width the 16-byte operand loads / complete 16-wide K blocks of the MFMA kernels do not cover (BLEND: d = 162) takes their
+    # guarded scalar-load variant -- 383 us against ~60 at the ogbn-arxiv shape.  Zero-padded copies of both operands (K up to the
+    # next multiple of 16) add exact zeros to every dot product and put the product on the fast kernels.
+    d16 = (d + 15) // 16 * 16
+    xp = torch.zeros(n, d16, dtype=torch.float32, device=x.device)
+    xp[:, :d].copy_(x)
+    wp = torch.zeros(m, d16, dtype=torch.float32, device=x.device)
+    wp[:, :d].copy_(weight)
+    x, weight, d = xp, wp, d16
   check(fn(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out), out.stride(0), stream_of(x)))
   return out
 

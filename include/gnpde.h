@@ -457,7 +457,8 @@ int gnpde_rhs_stage(const gnpde_rhs_t* rhs, const float* u, const gnpde_epilogue
 
 /* Error ratio of an embedded Runge-Kutta step, on device (torchdiffeq _compute_error_ratio with the rms norm):
  *   err = sum_j coef[j] * k[j],  tol = atol + rtol * max(|y0|, |y1|),  *ratio = sqrt(mean((err / tol)^2)).
- * Deterministic two-level reduction; workspace: 4096 floats. */
+ * Deterministic two-level reduction with the squares summed in double (the norm does not depend on the order of the rows beyond
+ * ~1e-16, so a solve on a relabelled graph takes the same decisions); workspace: 4096 floats (16 KB), 8-byte aligned. */
 int gnpde_rk_error_ratio(const float* y0, const float* y1, const float* const* k, const float* coef, int32_t n_k,
                          float atol, float rtol, int64_t n, int32_t d, int32_t ld, float* ratio, float* workspace,
                          void* stream);
