@@ -259,7 +259,15 @@ class NativeBackend(object):
       self.norm_idx = int(params.get('norm_idx', 0))
       self.square_plus = bool(params.get('square_plus', False))
       self.general = self.norm_idx != 0 or self.square_plus      # needs exchanges BETWEEN the attention passes (rhs_stage_general)
-      att = ops.attention_struct(_lib.ATT_SCALED_DOT, self.heads, self.A, 0, False)
+      # score function (reference src/function_transformer_attention.py:193-206): scaled_dot, cosine_sim, pearson or exp_kernel --
+      # all are functions of (q_i, k_j) alone, so the partitioned evaluation is the same (keys of the halo rows recomputed locally)
+      self.att_type = str(params.get('att_type', 'scaled_dot'))
+      self.att_code = _lib.ATT_TYPES[self.att_type]
+      self.output_var = self.lengthscale = None
+      if self.att_type == 'exp_kernel':
+        self.output_var = params['output_var'].detach().to(self.dev, torch.float32).reshape(-1).clone()
+        self.lengthscale = params['lengthscale'].detach().to(self.dev, torch.float32).reshape(-1).clone()
+      att = ops.attention_struct(self.att_code, self.heads, self.A, 0, False, output_var=self.output_var, lengthscale=self.lengthscale)
       self._kw = dict(kind=_lib.RHS_TRANSFORMER, proj_w=self.wqk, proj_b=self.bqk, att=att)
       if self.general:
         # the attention passes see ALL local nodes as segments (a halo column is a segment of attention_norm_idx = 1)
@@ -312,6 +320,9 @@ class NativeBackend(object):
     else:
       self.wqk.copy_(torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32))
       self.bqk.copy_(torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32))
+      if self.output_var is not None:
+        self.output_var.copy_(params['output_var'].detach().reshape(-1))
+        self.lengthscale.copy_(params['lengthscale'].detach().reshape(-1))
 
   def _descriptor(self, with_source, part=None):
     """gnpde_rhs_t over the local shard: aggregation on the n_own rows (or the interior / boundary rows),
@@ -385,7 +396,8 @@ class NativeBackend(object):
       self._src, self._src_version = x0, x0._version
     h, A, n_own, n_loc = self.heads, self.A, sh.n_own, sh.n_local
     qk = ops.linear(u, self.wqk, self.bqk)                               # own AND halo rows (keys of halo rows recomputed locally)
-    st = ops.attention_struct(_lib.ATT_SCALED_DOT, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A)
+    st = ops.attention_struct(self.att_code, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A,
+                              output_var=self.output_var, lengthscale=self.lengthscale)
     g = self.g_att
     ws = g.workspace('att', L.gnpde_attention_workspace_bytes(g.ref(), ctypes.byref(st)))
     offs = (ctypes.c_size_t * 4)()
@@ -818,13 +830,15 @@ def _sharded_problem(func):
     return 'laplacian', dict(edge_weight=w.detach())
   if isinstance(func, ODEFuncTransformerAtt):
     o, lay = func.opt, func.multihead_att_layer
-    if (o['attention_type'] != 'scaled_dot' or o['reweight_attention'] or getattr(lay, 'split_kernel', False) or o['mix_features']):
-      raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with scaled-dot scores (softmax or squareplus, '
-                            'over rows or columns; no reweighting / beltrami split kernel / other score functions); this '
+    if (o['attention_type'] not in _lib.ATT_TYPES or o['reweight_attention'] or getattr(lay, 'split_kernel', False) or o['mix_features']):
+      raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with the scaled_dot / cosine_sim / pearson / exp_kernel '
+                            'scores (softmax or squareplus, over rows or columns; no reweighting / beltrami split kernel); this '
                             'configuration runs on one GPU only -- unset gnpde_shard')
-    return 'transformer', dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(),
-                               bk=lay.K.bias.detach(), heads=lay.h, norm_idx=int(o['attention_norm_idx']),
-                               square_plus=bool(o['square_plus']))
+    p = dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(), bk=lay.K.bias.detach(), heads=lay.h,
+             norm_idx=int(o['attention_norm_idx']), square_plus=bool(o['square_plus']), att_type=o['attention_type'])
+    if o['attention_type'] == 'exp_kernel':
+      p.update(output_var=lay.output_var.detach(), lengthscale=lay.lengthscale.detach())
+    return 'transformer', p
   raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc and ODEFuncTransformerAtt, not %s' % type(func).__name__)
 
 
@@ -852,7 +866,8 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
   kind, params = _sharded_problem(func)
   ei = func.edge_index
   st = func.__dict__.setdefault('_shard_state', {})
-  key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev), params.get('norm_idx', 0), params.get('square_plus', False))
+  key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev), params.get('norm_idx', 0), params.get('square_plus', False),
+         params.get('att_type', ''))
   ent = st.get(key)
   if ent is None:
     for old in st.values():
@@ -964,6 +979,34 @@ def gather_rows_all(y_own, plan, shard, group=None):
     ok = id_parts[p] >= 0
     out[id_parts[p][ok]] = parts[p][ok]
   return out
+
+
+def negotiate_transport(ladder, phases, agree, notes, on_reject=None):
+  """The first rung of `ladder` that EVERY rank gets through: for each candidate the ranks run the phases in lockstep --
+  phase(cand) -> (ok, why), exceptions count as a failure -- and vote after each one (`agree(ok)` is True iff all ranks said ok).
+  A candidate one rank cannot use is dropped by all of them (its reason goes to `notes[cand]`, `on_reject(cand)` releases what the
+  attempt set up) and the next rung is tried; returns the chosen candidate or None.  Host logic only: bench_main hands in the
+  device work (one evaluation / a two-step solve against the unpartitioned graph), tests/test_distributed_cpu.py scripted
+  failures."""
+  for cand in ladder:
+    all_ok = True
+    for k, phase in enumerate(phases):
+      try:
+        ok, why = phase(cand)
+      except Exception as exc:   # noqa: BLE001 -- any failure of a transport means: try the next one
+        ok, why = False, '%s%s: %s' % ('' if k == 0 else 'phase %d: ' % (k + 1), type(exc).__name__, str(exc)[:300])
+      if why:
+        notes[cand] = why
+      all_ok = agree(ok)
+      if not all_ok:
+        if ok:
+          notes[cand] = 'unavailable on another rank' if k == 0 else 'phase %d failed on another rank' % (k + 1)
+        break
+    if all_ok:
+      return cand
+    if on_reject is not None:
+      on_reject(cand)
+  return None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1098,69 +1141,68 @@ def bench_main(args, rank, world, dev):
     except Exception:   # noqa: BLE001
       pass
 
-  with torch.no_grad():
-    for cand in ladder:
-      ok, why = True, None
-      chk = None
-      try:
-        if cand == 'torch':
-          chk = ShardedSolver(shard, be)
-          chk.y[:shard.n_own].copy_(x_own)
-          chk.exchange(chk.y)
-          f_own = be.empty(shard.n_own)
-          be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
-          torch.cuda.synchronize(dev)
-          err_local = one_eval_error(f_own)
-        else:
-          if cand == 'p2p' and ctx is None:
-            ctx = P2PContext(shard, d, 4)
-          chk = NativeShardedSolver(shard, be, 1.0, 1.0, 'euler', transport=cand, ctx=ctx if cand == 'p2p' else None)
-          f_own = chk.integrate(x_own, x_own, use_graph=False).clone() - x_own
-          torch.cuda.synchronize(dev)
-          timed_out = chk.status()[0]
-          err_local = one_eval_error(f_own)
-          if timed_out:
-            ok, why = False, 'a peer never published its boundary rows (exchange timed out)'
-        if ok and not (err_local <= 1e-4):
-          ok, why = False, 'one evaluation differs from the unpartitioned graph by %.3e' % err_local
-      except Exception as exc:   # noqa: BLE001 -- any failure of a transport means: try the next one
-        ok, why = False, '%s: %s' % (type(exc).__name__, str(exc)[:300])
-      if why:
-        notes[cand] = why
-      all_ok = agree(ok)
+  state = {'ctx': None, 'err_local': float('inf'), 'err_check': None}
+
+  def one_eval_phase(cand):
+    """ONE evaluation of f through the candidate's exchange (an euler step of size 1) against the unpartitioned graph."""
+    chk = None
+    try:
+      if cand == 'torch':
+        chk = ShardedSolver(shard, be)
+        chk.y[:shard.n_own].copy_(x_own)
+        chk.exchange(chk.y)
+        f_own = be.empty(shard.n_own)
+        be.rhs_stage(chk.y, x_own, _lib.STAGE_RHS, out_k=f_own)
+        torch.cuda.synchronize(dev)
+        state['err_local'] = one_eval_error(f_own)
+      else:
+        if cand == 'p2p' and state['ctx'] is None:
+          state['ctx'] = P2PContext(shard, d, 4)
+        chk = NativeShardedSolver(shard, be, 1.0, 1.0, 'euler', transport=cand, ctx=state['ctx'] if cand == 'p2p' else None)
+        f_own = chk.integrate(x_own, x_own, use_graph=False).clone() - x_own
+        torch.cuda.synchronize(dev)
+        timed_out = chk.status()[0]
+        state['err_local'] = one_eval_error(f_own)
+        if timed_out:
+          return False, 'a peer never published its boundary rows (exchange timed out)'
+      if not (state['err_local'] <= 1e-4):
+        return False, 'one evaluation differs from the unpartitioned graph by %.3e' % state['err_local']
+      return True, None
+    finally:
       close_quietly(chk)
-      if not all_ok and ok:
-        notes[cand] = 'unavailable on another rank'
-      if all_ok and have_ref_check:
-        ok, why, chk = True, None, None
-        try:
-          if cand == 'torch':
-            chk = ShardedSolver(shard, be)
-            y2 = chk.integrate(x_own, x_own, T_CHECK, 1.0, 'rk4').clone()
-            torch.cuda.synchronize(dev)
-          else:
-            chk = NativeShardedSolver(shard, be, T_CHECK, 1.0, 'rk4', transport=cand, ctx=ctx if cand == 'p2p' else None)
-            y2 = chk.integrate(x_own, x_own, use_graph=bool(use_graph and cand == 'p2p')).clone()
-            torch.cuda.synchronize(dev)
-            if chk.status()[0]:
-              ok, why = False, 'two-step solve: a peer never published its boundary rows (exchange timed out)'
-          err_check = solve_error(y2, ref_check)
-          if ok and not (err_check <= 1e-4):
-            ok, why = False, 'two-step rk4 solve differs from the unpartitioned graph by %.3e' % err_check
-        except Exception as exc:   # noqa: BLE001
-          ok, why = False, 'two-step solve: %s: %s' % (type(exc).__name__, str(exc)[:300])
-        if why:
-          notes[cand] = why
-        all_ok = agree(ok)
-        close_quietly(chk)
-        if not all_ok and ok:
-          notes[cand] = 'two-step solve failed on another rank'
-      if all_ok:
-        chosen = cand
-        break
-      if cand == 'p2p' and ctx is not None:
-        close_quietly(ctx)
-        ctx = None
+
+  def two_step_phase(cand):
+    """Ranks still in lockstep: a two-step rk4 solve in the launch mode the timed run will use (8 evaluations: every stage buffer
+    exchanged twice)."""
+    chk = None
+    try:
+      ok, why = True, None
+      if cand == 'torch':
+        chk = ShardedSolver(shard, be)
+        y2 = chk.integrate(x_own, x_own, T_CHECK, 1.0, 'rk4').clone()
+        torch.cuda.synchronize(dev)
+      else:
+        chk = NativeShardedSolver(shard, be, T_CHECK, 1.0, 'rk4', transport=cand, ctx=state['ctx'] if cand == 'p2p' else None)
+        y2 = chk.integrate(x_own, x_own, use_graph=bool(use_graph and cand == 'p2p')).clone()
+        torch.cuda.synchronize(dev)
+        if chk.status()[0]:
+          ok, why = False, 'two-step solve: a peer never published its boundary rows (exchange timed out)'
+      state['err_check'] = solve_error(y2, ref_check)
+      if ok and not (state['err_check'] <= 1e-4):
+        ok, why = False, 'two-step rk4 solve differs from the unpartitioned graph by %.3e' % state['err_check']
+      return ok, why
+    finally:
+      close_quietly(chk)
+
+  def reject(cand):
+    if cand == 'p2p' and state['ctx'] is not None:
+      close_quietly(state['ctx'])
+      state['ctx'] = None
+
+  with torch.no_grad():
+    phases = [one_eval_phase] + ([two_step_phase] if have_ref_check else [])
+    chosen = negotiate_transport(ladder, phases, agree, notes, on_reject=reject)
+    ctx, err_local, err_check = state['ctx'], state['err_local'], state['err_check']
     if chosen is None:
       raise _lib.GnpdeError('no halo transport works on this system: %r' % (notes,))
     python_loop = chosen == 'torch'
@@ -1378,13 +1420,18 @@ def bench_main(args, rank, world, dev):
     if shard_roof is not None and 'error' not in shard_roof:
       resident = shard_roof['local_table_mib'] < 256
       out['roofline'] = dict(shard_roof, kernel='CSR aggregation + fused epilogue on rank 0\'s shard (all local rows in one launch)',
-                             bound='l2-miss/MALL' if resident else 'hbm', achieved=shard_roof['gather_model_gbs'], peak=8000.0,
-                             unit='GB/s', frac=None if resident else round(shard_roof['gather_model_gbs'] / 8000.0, 4),
+                             bound='mall' if resident else 'hbm', achieved=shard_roof['gather_model_gbs'], peak=8000.0,
+                             unit='GB/s', frac=round(shard_roof['gather_model_gbs'] / 8000.0, 4),
+                             frac_is='frac_algorithmic: gather-model bytes of the launch / its time / the 8 TB/s HBM peak (no counter '
+                                     'traffic in the multi-rank line; exceeds 1 when the shard\'s table is cache-resident)', traffic=None,
                              note='per-GPU figure of rank 0; the gathered table of a shard (own + halo rows) '
                                   + ('fits the Infinity Cache, so HBM\'s peak is not its ceiling (see the 1-GPU line\'s measured '
                                      'ceiling)' if resident else 'exceeds the Infinity Cache: fraction of the HBM peak'))
     else:
       out['roofline'] = shard_roof
+    out['north_star_multi_gpu'] = ('BASELINE configs[4] (R-MAT 2M / 40M, d = 256: `--graph rmat`) is the configuration the north star names for 8 GPUs '
+                                   '-- DESIGN.md section 6 predicts ~5x there and 2.3 - 3.0x for the ogbn-arxiv shape, whose 87-MB state leaves '
+                                   'every rank launch- and link-latency bound; this line is `--graph %s`, its own prediction is `model`' % args.graph)
     out['cpu_baseline'] = None     # (timed on rank 0 at N = 1 only, by contract)
     print(json.dumps(out))
   dist.destroy_process_group()

@@ -40,12 +40,20 @@ def main():
   sh = plan.shard(rank)
   general = kind.startswith('transformer_')          # transformer_n1 / transformer_sqp / transformer_sqp_n1
   norm_idx, square_plus = int('n1' in kind), 'sqp' in kind
+  # score functions other than the scaled dot product (reference src/function_transformer_attention.py:193-206), row softmax
+  att_type = kind if kind in ('cosine_sim', 'pearson', 'exp_kernel') else 'scaled_dot'
+  att_kw = dict(attention_type=att_type)
+  if att_type == 'exp_kernel':
+    params.update(output_var=torch.tensor([1.3]), lengthscale=torch.tensor([2.1]))
+    att_kw.update(output_var=params['output_var'], lengthscale=params['lengthscale'])
+  if att_type != 'scaled_dot':
+    params['att_type'] = att_type
   if kind == 'laplacian':
     _, w = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
     p = dict(edge_weight=w[sh.edge_ids])
   else:
     p = dict(params, norm_idx=norm_idx, square_plus=square_plus)
-  be = D.NativeBackend(sh, d, dev, 'transformer' if general else kind, p, alpha, beta, True)
+  be = D.NativeBackend(sh, d, dev, 'transformer' if (general or att_type != 'scaled_dot') else kind, p, alpha, beta, True)
   x_own = D.scatter_rows(x, sh).to(dev)
   res = {}
   if general:
@@ -119,7 +127,7 @@ def main():
       rhs = lambda t, y: R.rhs_laplacian(y, ei, w, alpha, beta, x, False, True)   # noqa: E731
     else:
       rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
-                                           x, False, True)
+                                           x, False, True, **att_kw)
     ref = R.odeint_fixed(rhs, x, T, 1.0, method)
     e_inf, e_2 = parity(full, ref)
     json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,

@@ -32,6 +32,36 @@ def test_sharded_solve_gloo(world):
   assert res.returncode == 0 and 'DIST_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_transport_ladder_falls_down_every_rung(world, tmp_path):
+  """bench.py --gpus N picks its halo transport by distributed.negotiate_transport (p2p -> rccl -> torch, each rung checked in two
+  phases by every rank).  Scripted failures on single ranks, in either phase, by exception or by a wrong result: every rank drops
+  the rung (and releases it), every rank ends on the same next rung, the reasons are recorded, nothing is attempted after the
+  choice; no rung left -> None on every rank."""
+  import json
+  out = str(tmp_path / 'ladder.json')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_ladder_worker.py'), out]
+  res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS='2'))
+  assert res.returncode == 0 and 'LADDER_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+  per_rank = json.load(open(out))
+  assert len(per_rank) == world
+  for rank, scen in enumerate(per_rank):
+    for name, r in scen.items():
+      assert r['chosen'] == r['expected'], (rank, name, r)
+      assert r['same_on_all_ranks'], (rank, name, r)
+      ladder = ['torch'] if name == 'only_torch_offered' else ['p2p', 'rccl', 'torch']
+      tried = ladder if r['chosen'] is None else ladder[:ladder.index(r['chosen']) + 1]
+      assert r['rejected'] == [c for c in tried if c != r['chosen']], (rank, name, r)          # every dropped rung is released, in order
+      assert [c for c, _ in r['calls'] if c not in tried] == [], (rank, name, r)               # nothing past the choice is attempted
+      for c in r['rejected']:
+        assert c in r['notes'] and r['notes'][c], (rank, name, r)                              # ... with a reason on every rank
+  # the rank that failed names its own reason, the others are told it was another rank
+  a = per_rank[0]['p2p_fails_on_rank1_phase1']['notes']['p2p']
+  b = per_rank[1]['p2p_fails_on_rank1_phase1']['notes']['p2p']
+  assert 'another rank' in a and 'scripted failure' in b, (a, b)
+
+
 def test_plan_is_a_permutation_and_local_graphs_cover_all_edges():
   n = 500
   ei = random_graph(n, 6, seed=9, hubs=1, hub_deg=300)

@@ -129,7 +129,7 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
 
 
 def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
-  """gnpde_shard on a configuration the partitioned solver does not cover (a score function other than the scaled dot product)
+  """gnpde_shard on a configuration the partitioned solver does not cover (re-weighted attention)
   raises instead of silently running on one GPU; without a process group the request is ignored (single-GPU solve)."""
   import torch.distributed as dist
   from helpers import Fixture, Data
@@ -149,7 +149,7 @@ def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
   os.environ.setdefault('MASTER_PORT', '29677')
   dist.init_process_group('gloo', rank=0, world_size=1)
   try:
-    block.odefunc.opt = dict(block.odefunc.opt, attention_type='cosine_sim')      # not covered by the partitioned solver
+    block.odefunc.opt = dict(block.odefunc.opt, reweight_attention=True)         # not covered by the partitioned solver
     block.set_x0(x)
     with torch.no_grad(), pytest.raises(_lib.GnpdeError):
       block(x)
@@ -172,6 +172,23 @@ def test_normalisers_that_are_not_row_local(dev, tmp_path, world, kind):
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
   r = json.load(open(out))
   assert r['world'] == world and r['halo_rows'] > 0
+  assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
+
+
+@pytest.mark.parametrize('kind', ['cosine_sim', 'pearson', 'exp_kernel'])
+def test_other_score_functions_run_partitioned(dev, tmp_path, kind):
+  """The row-local score functions besides the scaled dot product (reference src/function_transformer_attention.py:193-206): the
+  partitioned evaluation only differs in the per-edge formula -- 2 processes on this one GPU, P2P transport inside each rank's
+  hipGraph, against the unpartitioned CPU oracle."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / 'result.json')
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29691', os.path.join(root, 'tests', 'dist_gpu_worker.py'), out, kind, 'rk4', '3.0']
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  r = json.load(open(out))
+  assert r['world'] == 2 and r['halo_rows'] > 0 and 0 < r['interior_rows'] < r['own_rows']
   assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
 
 
