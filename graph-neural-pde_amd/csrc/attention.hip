@@ -1215,7 +1215,8 @@ __global__ __launch_bounds__(kBlock) void stats_merge_kernel(float* __restrict__
   }
   const float ma = m[o], mb = m_in[idx];
   const float mm = fmaxf(ma, mb);
-  den[o] = den[o] * expf(ma - mm) + den_in[idx] * expf(mb - mm);
+  // (both maxima -inf = a segment without entries on either side: exp(-inf - -inf) would be NaN; its statistics stay (-inf, sum))
+  den[o] = mm == -INFINITY ? den[o] + den_in[idx] : den[o] * expf(ma - mm) + den_in[idx] * expf(mb - mm);
   m[o] = mm;
 }
 

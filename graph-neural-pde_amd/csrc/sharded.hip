@@ -829,20 +829,41 @@ extern "C" int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* t
   return 0;
 }
 
+namespace {
+// the proportional whole-list walk of the send slots (what create() installs): restored whenever the chunked order goes away
+int restore_default_push_order(gnpde_sharded_solver* s) {
+  if (s->p2p == nullptr || s->n_send == 0 || s->d_order == nullptr) return 0;
+  std::vector<int32_t> order(static_cast<size_t>(s->n_send));
+  const int rc = gnpde_push_order(s->send_counts.data(), static_cast<int32_t>(s->send_counts.size()), order.data());
+  if (rc) return rc;
+  GNPDE_HIP(hipMemcpy(s->d_order, order.data(), static_cast<size_t>(s->n_send) * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+}  // namespace
+
 extern "C" int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* s, const gnpde_rhs_t* const* rhs_chunks,
                                                         int32_t n_chunks, const int32_t* push_order,
                                                         const int32_t* push_chunk_ptr) {
   GNPDE_CHECK_ARG(s != nullptr && n_chunks >= 0, GNPDE_EINVAL, "sharded_solver_set_boundary_chunks: bad arguments");
   drop_sharded_graph(s);
+  // Whatever happens below, the solver is first put back into the one-pass state (no chunk descriptors, the default push
+  // order): a call that fails validation leaves THAT state, never a half-filled chunk list the next run would index past.
+  const bool had_chunks = !s->rhs_chunk.empty();
   s->rhs_chunk.clear(); s->g_chunk.clear(); s->L_chunk.clear(); s->push_chunk_ptr.clear();
+  if (had_chunks)
+    if (int rc = restore_default_push_order(s)) return rc;
   if (n_chunks == 0) return 0;                     // back to one boundary pass + one push per evaluation
   GNPDE_CHECK_ARG(s->p2p != nullptr, GNPDE_ESTATE, "sharded_solver_set_boundary_chunks: P2P transport only");
   GNPDE_CHECK_ARG(rhs_chunks && push_chunk_ptr && (push_order || s->n_send == 0), GNPDE_EINVAL,
                   "sharded_solver_set_boundary_chunks: null argument");
   GNPDE_CHECK_ARG(push_chunk_ptr[0] == 0 && push_chunk_ptr[n_chunks] == s->n_send, GNPDE_EINVAL,
                   "sharded_solver_set_boundary_chunks: the chunks must tile the %d send slots", s->n_send);
+  // everything is validated and built in locals; the solver takes it over only when every check has passed
+  std::vector<gnpde_rhs_t> rhs_new;
+  std::vector<gnpde_graph_t> g_new(static_cast<size_t>(n_chunks));   // (sized first: the descriptors point into it)
+  std::vector<RhsLayout> L_new;
+  std::vector<int> ptr_new;
   int row = s->g_bnd.row_begin;
-  s->g_chunk.resize(n_chunks);                     // (sized first: the descriptors point into it)
   for (int c = 0; c < n_chunks; ++c) {
     GNPDE_CHECK_ARG(rhs_chunks[c] != nullptr && push_chunk_ptr[c] <= push_chunk_ptr[c + 1], GNPDE_EINVAL,
                     "sharded_solver_set_boundary_chunks: bad chunk %d", c);
@@ -852,16 +873,16 @@ extern "C" int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* 
                     r.graph->n >= row && r.graph->n <= s->n_own, GNPDE_EINVAL,
                     "sharded_solver_set_boundary_chunks: chunk %d must continue the boundary rows at row %d", c, row);
     row = r.graph->n;
-    s->g_chunk[c] = *r.graph;
-    s->rhs_chunk.push_back(r);
-    s->rhs_chunk.back().graph = &s->g_chunk[c];
-    s->L_chunk.push_back(rhs_layout(s->rhs_chunk.back()));
-    GNPDE_CHECK_ARG(s->off_rhs + s->L_chunk.back().total <= s->ws_bytes, GNPDE_EWS,
+    g_new[c] = *r.graph;
+    rhs_new.push_back(r);
+    rhs_new.back().att.graph_t = nullptr; rhs_new.back().att.t_from_csr = nullptr;
+    L_new.push_back(rhs_layout(rhs_new.back()));
+    GNPDE_CHECK_ARG(s->off_rhs + L_new.back().total <= s->ws_bytes, GNPDE_EWS,
                     "sharded_solver_set_boundary_chunks: chunk %d needs %zu bytes of scratch, the workspace has %zu", c,
-                    s->L_chunk.back().total, s->ws_bytes - s->off_rhs);
-    s->push_chunk_ptr.push_back(push_chunk_ptr[c]);
+                    L_new.back().total, s->ws_bytes - s->off_rhs);
+    ptr_new.push_back(push_chunk_ptr[c]);
   }
-  s->push_chunk_ptr.push_back(push_chunk_ptr[n_chunks]);
+  ptr_new.push_back(push_chunk_ptr[n_chunks]);
   GNPDE_CHECK_ARG(row == s->n_own, GNPDE_EINVAL, "sharded_solver_set_boundary_chunks: the chunks end at row %d of %d", row, s->n_own);
   if (s->n_send > 0) {
     std::vector<char> seen(static_cast<size_t>(s->n_send), 0);
@@ -872,6 +893,11 @@ extern "C" int gnpde_sharded_solver_set_boundary_chunks(gnpde_sharded_solver_t* 
     }
     GNPDE_HIP(hipMemcpy(s->d_order, push_order, static_cast<size_t>(s->n_send) * 4, hipMemcpyHostToDevice));
   }
+  s->g_chunk.swap(g_new);
+  s->rhs_chunk.swap(rhs_new);
+  for (int c = 0; c < n_chunks; ++c) s->rhs_chunk[c].graph = &s->g_chunk[c];
+  s->L_chunk.swap(L_new);
+  s->push_chunk_ptr.swap(ptr_new);
   return 0;
 }
 

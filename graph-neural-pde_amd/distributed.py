@@ -913,7 +913,14 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
       if func.x0 is None:
         raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
       x0_own = func.x0.detach()[ent['own_ids']].contiguous()
-    z_own = sol.integrate(y_own, x0_own, float(sum(dts)), step_size, method).clone()
+    # the Python-driven loop builds its own grid from (T, step_size) starting at 0: it must be the grid the caller asked for
+    T_loop = float(sum(dts))
+    grid_loop = time_grid(torch.tensor([0.0, T_loop]), step_size)
+    dts_loop = tuple((grid_loop[1:] - grid_loop[:-1]).tolist())
+    if float(t[0]) != 0.0 or len(dts_loop) != len(dts) or any(abs(a - b) > 1e-6 * max(abs(b), 1.0) for a, b in zip(dts_loop, dts)):
+      raise _lib.GnpdeError('sharded solve (normaliser with exchanges between the attention passes): the time grid %r from t[0] = %g '
+                            'cannot be reproduced by the loop\'s grid %r' % (dts, float(t[0]), dts_loop))
+    z_own = sol.integrate(y_own, x0_own, T_loop, step_size, method).clone()
     return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, n_evals)
   if sol is None:
     for old in ent['solvers'].values():     # one live solver per function: its stage buffers are the shared P2P block

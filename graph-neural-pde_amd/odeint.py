@@ -78,12 +78,18 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
     # the solver's copy of the source term is refreshed only when the caller's tensor is another one or was written to (keyed on
     # the tensor OBJECT, kept alive here so that its address cannot be handed to another tensor, and its version counter)
     src = func.x0
-    if ent.get('x0_src') is not src or ent.get('x0_version') != src._version:
+    # (inference tensors have no version counter -- reading it raises -- and writes through .data / set_() do not bump it: the
+    #  key also holds the storage address, and anything that cannot be keyed is copied every solve)
+    try:
+      stamp = (src._version, src.data_ptr())
+    except RuntimeError:
+      stamp = None
+    if stamp is None or ent.get('x0_src') is not src or ent.get('x0_version') != stamp:
       if view is None:
         ent['x0'].copy_(src)
       else:
         view.enter(src.detach(), out=ent['x0'])
-      ent['x0_src'], ent['x0_version'] = src, src._version
+      ent['x0_src'], ent['x0_version'] = src, stamp
   desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=None if view is None else view.graph)
   sig = func._descriptor_signature(desc)
   if ent['solver'] is None or ent['sig'] != sig:
@@ -487,6 +493,12 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
         return D.solve_sharded(func, y0, t, method, step_size, use_graph=use_graph)
       return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
     return _solve_fixed_host(func, y0, t, method, step_size)
+  if method in ('dopri5', 'adaptive_heun') and hasattr(func, '_descriptor'):
+    from . import distributed as D
+    if D.shard_requested(func):
+      # (a replicated single-GPU solve on every rank would be a silent waste of N - 1 GPUs)
+      raise _lib.GnpdeError('gnpde_shard is set but the row-partitioned solver covers the fixed-step methods (euler, rk4) only; '
+                            'method=%r runs on one GPU -- unset gnpde_shard for it' % method)
   if method == 'dopri5':
     if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
       if options.get('eager_stages', False):      # controller on the host, one scalar read per trial step
