@@ -69,9 +69,13 @@ def main():
     k = max(agg, key=lambda n: detail[n]['bytes_per_launch'] * detail[n]['launches'])
     rec = dict(detail[k])
     import hashlib
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'graph-neural-pde_amd', 'csrc', 'spmm.hip')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for rel in ('graph-neural-pde_amd/csrc/spmm.hip', 'graph-neural-pde_amd/csrc/attention.hip', 'graph-neural-pde_amd/csrc/linear.hip',
+                'graph-neural-pde_amd/csrc/epilogue.h'):     # = bench.KERNEL_SOURCES: the record is stale when ANY of them changes
+      h.update(open(os.path.join(root, rel), 'rb').read())
     rec.update(kernel=k, commit=commit, command=cmd, method='rocprofv3 --pmc, mean over the launches of the command',
-               source_sha16=hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16])   # bench.py marks the record stale when spmm.hip changes
+               kernel_sources_sha16=h.hexdigest()[:16])
     data[key] = rec
   data.setdefault('detail', {})[key] = {'commit': commit, 'command': cmd, 'kernels': detail}
   json.dump(data, open(out_path, 'w'), indent=1)
