@@ -410,7 +410,7 @@ __device__ __forceinline__ void hub_scores_partial_body(const AttArgs& a, float*
 // read ONE contiguous A-float row of k (round 1 looped over the heads and gathered every k row H times, 64 B at a time: 6.9 ms
 // for the 99.5 k hub chunks of the R-MAT graph); the scores of the PER passes stay in registers, the per-head maximum / sum
 // are xor butterflies over the lanes with equal head and a fold over the four waves in LDS.
-template <int TYPE, bool VEC4, int H>
+template <int TYPE, bool VEC4, int H, int MODE = 0>
 __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float* __restrict__ part, int chunk) {
   constexpr int EPB = kBlock / H;                 // entries per block pass
   constexpr int PER = GNPDE_LONG_ROW / EPB;       // passes
@@ -444,7 +444,7 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
   __syncthreads();
   const float m = fmaxf(fmaxf(red[0][head], red[1][head]), fmaxf(red[2][head], red[3][head]));
   __syncthreads();
-  if (a.sp_mode == 2) {          // squareplus, first sweep: only the global maximum of the scores (utils.py:196 `src.max()`)
+  if constexpr (MODE == 2) {     // squareplus, first sweep: only the global maximum of the scores (utils.py:196 `src.max()`)
     if (threadIdx.x < H && m > -INFINITY) {
       const unsigned mine = f2ord(m);
       if (mine > __hip_atomic_load(a.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.gmax, mine);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
     return;
   }
   float sum = 0.f;
-  if (a.sp_mode == 1) {          // squareplus: the chunk's share of the segment sum of u = (z + sqrt(z^2 + 4)) / 2, z = s - max
+  if constexpr (MODE == 1) {     // squareplus: the chunk's share of the segment sum of u = (z + sqrt(z^2 + 4)) / 2, z = s - max
     const float gm = ord2f(*a.gmax);
 #pragma unroll
     for (int i = 0; i < PER; ++i) sum += cols[i] >= 0 ? squareplus_num(sv[i], gm) : 0.f;
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kBlock) void hub_scores_partial_kernel(const AttArg
   hub_scores_partial_body<TYPE, VEC4>(a, part, blockIdx.x);
 }
 
+template <int MODE = 0, bool SCATTER = false>
 __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float* __restrict__ part,
                                                    const int* __restrict__ long_chunk_row_first, int c) {
   // long_chunk_row_first[c] = index of the first chunk of the row chunk c belongs to
@@ -498,7 +499,7 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
     for (int t = threadIdx.x; t < nval; t += kBlock) sp_[t] = src[t];
     __syncthreads();
   }
-  const bool sp = a.sp_mode == 1;
+  constexpr bool sp = MODE == 1;
   if (threadIdx.x < a.h && sp) {       // squareplus: the statistics are plain sums of the chunks' shares
     const int head = threadIdx.x;
     float l = 0.f;
@@ -534,13 +535,14 @@ __device__ __forceinline__ void hub_normalise_body(const AttArgs& a, const float
       for (int head = 0; head < a.h; ++head)
         acc += __builtin_amdgcn_exp2f((a.scores[static_cast<size_t>(p) * a.h + head] - st[head]) * 1.44269504088896341f) * st[a.h + head];
     }
-    a.w_mean[a.out_pos != nullptr ? a.out_pos[p] : p] = acc / static_cast<float>(a.h);
+    if constexpr (SCATTER) a.w_mean[a.out_pos[p]] = acc / static_cast<float>(a.h);
+    else a.w_mean[p] = acc / static_cast<float>(a.h);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void hub_normalise_kernel(const AttArgs a, const float* __restrict__ part,
                                                               const int* __restrict__ long_chunk_row_first) {
-  hub_normalise_body(a, part, long_chunk_row_first, blockIdx.x);
+  hub_normalise_body<0, false>(a, part, long_chunk_row_first, blockIdx.x);
 }
 
 // ---- fused path: softmax over the row, head-mean weights only.
@@ -619,13 +621,13 @@ __global__ __launch_bounds__(kBlock) void row_attention_kernel(const AttArgs a, 
 // (scores recomputed, nothing stored).  The segments are the rows of whatever graph a.bin_rows / a.colidx describe -- the
 // transposed graph, with a.q / a.k exchanged and a.out_pos mapping its positions to the CSR positions of the weights, when the
 // reference normalises over edge[1] (attention_norm_idx = 1, function_transformer_attention.py:210-213).
-template <int H, int DK4, int GL, int RI, int PB, int NB, int MODE>
+template <int H, int DK4, int GL, int RI, int PB, int NB, int MODE, bool SCATTER>
 __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs a, int first_row, int n_rows, int n_hub,
                                                                  int hub_phase, float* __restrict__ part,
                                                                  const int* __restrict__ chunk_first) {
   if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H>(a, part, blockIdx.x);
-    else hub_normalise_body(a, part, chunk_first, blockIdx.x);
+    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H, MODE>(a, part, blockIdx.x);
+    else hub_normalise_body<MODE, SCATTER>(a, part, chunk_first, blockIdx.x);
     return;
   }
   constexpr int RPW = kWave / GL;
@@ -822,7 +824,10 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int e = e0[r] + (nb * PB + i) * GE + slot;
-          if (head == 0 && live[r] && e < e1[r]) a.w_mean[a.out_pos != nullptr ? a.out_pos[e] : e] = v[r][i] / static_cast<float>(H);
+          if (head == 0 && live[r] && e < e1[r]) {
+            if constexpr (SCATTER) a.w_mean[a.out_pos[e]] = v[r][i] / static_cast<float>(H);     // (a template switch: the plain row softmax keeps its store as it was)
+            else a.w_mean[e] = v[r][i] / static_cast<float>(H);
+          }
         }
     }
 }
@@ -891,7 +896,7 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
   }
 }
 
-template <int H, int DK4, int MODE>
+template <int H, int DK4, int MODE, bool SCATTER>
 void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub, float* part, const int* chunk_first) {
   constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
@@ -904,13 +909,13 @@ void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int 
   if (n16 > 0 || n_hub > 0) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block) + n_hub;
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1, MODE>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
                        0, part, chunk_first);
   }
   const int n_hub2 = MODE == 2 ? 0 : n_hub;
   if (n64 > 0 || n_hub2 > 0) {
     const unsigned grid = static_cast<unsigned>((n64 + kWavesPerBlock - 1) / kWavesPerBlock) + n_hub2;
-    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64, MODE>), dim3(grid), dim3(kBlock), 0, s, a, n16,
+    hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, 1, PB64, P64 / PB64, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, n16,
                        n64, n_hub2, 1, part, chunk_first);
   }
 }
@@ -918,9 +923,15 @@ void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int 
 template <int H, int DK4>
 void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
                     const int* chunk_first = nullptr) {
-  if (a.sp_mode == 1) launch_rows_sd_mode<H, DK4, 1>(a, n16, n64, s, n_hub, part, chunk_first);
-  else if (a.sp_mode == 2) launch_rows_sd_mode<H, DK4, 2>(a, n16, n64, s, n_hub, part, chunk_first);
-  else launch_rows_sd_mode<H, DK4, 0>(a, n16, n64, s, n_hub, part, chunk_first);
+  const bool sc = a.out_pos != nullptr;
+  if (a.sp_mode == 2) launch_rows_sd_mode<H, DK4, 2, false>(a, n16, n64, s, n_hub, part, chunk_first);      // (writes no weights)
+  else if (a.sp_mode == 1) {
+    if (sc) launch_rows_sd_mode<H, DK4, 1, true>(a, n16, n64, s, n_hub, part, chunk_first);
+    else launch_rows_sd_mode<H, DK4, 1, false>(a, n16, n64, s, n_hub, part, chunk_first);
+  } else {
+    if (sc) launch_rows_sd_mode<H, DK4, 0, true>(a, n16, n64, s, n_hub, part, chunk_first);
+    else launch_rows_sd_mode<H, DK4, 0, false>(a, n16, n64, s, n_hub, part, chunk_first);
+  }
 }
 
 // scaled-dot rows + hub chunks in two launches; false if this (heads, d_k) has no specialised kernel
