@@ -287,7 +287,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
   size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0;
   for (int i = 0; i < 2; ++i) { o_uy[i] = take(state); o_ua[i] = take(state); }
-  const int nF = method == GNPDE_METHOD_RK4 ? 4 : 1, nV = method == GNPDE_METHOD_RK4 ? 3 : 0;
+  const int nF = method == GNPDE_METHOD_RK4 ? 1 : 0, nV = method == GNPDE_METHOD_RK4 ? 1 : 0;     // (u4 of the state / of the adjoint)
   for (int i = 0; i < 4; ++i) o_F[i] = i < nF ? take(state) : 0;
   for (int i = 0; i < 3; ++i) o_V[i] = i < nV ? take(state) : 0;
   const size_t o_one = take(256);
@@ -353,7 +353,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   }
   // F with the next stage input in its epilogue + r_e = ua[row] . uy[col] + the per-wave dots, one kernel over the gathered rows
   eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
-  eF.stage = GNPDE_STAGE_LINCOMB; eF.out_k = Fout;
+  eF.out_k = Fout;
   rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
   if (rc) return rc;
   const float* source = nullptr;
@@ -393,7 +393,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   }
   // V = alpha (A^T ua - ua) [+ 1 * P]
   eV.alpha = r.alpha; eV.beta = source_scale; eV.x0 = source; eV.alpha_sigmoid = r.alpha_sigmoid;
-  eV.stage = GNPDE_STAGE_LINCOMB; eV.out_k = Vout;
+  eV.out_k = Vout;
   rc = launch_spmm_rhs(gt, wt, ua, d, ld, &eV, nullptr, s->ws_spmm_t, s->spmm_t_bytes, st, nullptr, padded);
   if (rc) return rc;
   // parameter gradients
@@ -429,8 +429,8 @@ int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStrea
     int flip = 0;
     for (float dt : s->dts) {
       gnpde_epilogue_t eF{}, eV{};
-      eF.y = cy; eF.out_y = s->uy[flip]; eF.n_prev = 0; eF.coef[0] = -dt;
-      eV.y = ca; eV.out_y = s->ua[flip]; eV.n_prev = 0; eV.coef[0] = dt;
+      eF.stage = GNPDE_STAGE_EULER; eF.dt = -dt; eF.y = cy; eF.out_y = s->uy[flip];       // y' = -F in s = -t
+      eV.stage = GNPDE_STAGE_EULER; eV.dt = dt; eV.y = ca; eV.out_y = s->ua[flip];        // a' = +V
       int rc = enqueue_stage(s, cy, ca, nullptr, eF, nullptr, eV, dt, grads, st);
       if (rc) return rc;
       cy = s->uy[flip]; ca = s->ua[flip];
@@ -442,37 +442,33 @@ int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStrea
     }
     return 0;
   }
-  float** F = s->F; float** V = s->V;
+  // rk4 (3/8 rule) in the COMPACT form of the forward solver (gnpde.h: stage states expressed through the previous stage inputs, so no
+  // stage derivative F_j / V_j is ever stored or re-read -- the identities hold for any sequence of derivatives, here -F for the state
+  // and +V for the adjoint): per stage each kernel reads one or two state-sized operands besides its own row instead of up to five.
+  // u2 = uy[0] / ua[0], u3 = uy[1] / ua[1], u4 = F[0] / V[0] (free buffers).
+  float* y4 = s->F[0]; float* a4 = s->V[0];
   for (float dtf : s->dts) {
     const double dt = dtf;
-    const float c3 = static_cast<float>(dt / 3.0), c8 = static_cast<float>(dt * 0.125), c38 = static_cast<float>(3.0 * (dt * 0.125));
+    const float c8 = static_cast<float>(dt * 0.125), c38 = static_cast<float>(3.0 * (dt * 0.125));
     gnpde_epilogue_t eF{}, eV{};
-    // stage 1: (y, a)
-    eF.y = y; eF.out_y = s->uy[0]; eF.n_prev = 0; eF.coef[0] = -c3;
-    eV.y = a; eV.out_y = s->ua[0]; eV.n_prev = 0; eV.coef[0] = c3;
-    int rc = enqueue_stage(s, y, a, F[0], eF, V[0], eV, c8, grads, st);
+    eF.stage = GNPDE_STAGE_RK1C; eF.dt = -dtf; eF.out_y = s->uy[0];
+    eV.stage = GNPDE_STAGE_RK1C; eV.dt = dtf; eV.out_y = s->ua[0];
+    int rc = enqueue_stage(s, y, a, nullptr, eF, nullptr, eV, c8, grads, st);
     if (rc) return rc;
-    // stage 2: u = y - dt/3 F1, a + dt/3 V1  ->  next: y - dt F2 + dt/3 F1
     eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
-    eF.y = y; eF.out_y = s->uy[1]; eF.n_prev = 1; eF.prev[0] = F[0]; eF.coef[0] = c3; eF.coef[1] = -dtf;
-    eV.y = a; eV.out_y = s->ua[1]; eV.n_prev = 1; eV.prev[0] = V[0]; eV.coef[0] = -c3; eV.coef[1] = dtf;
-    rc = enqueue_stage(s, s->uy[0], s->ua[0], F[1], eF, V[1], eV, c38, grads, st);
+    eF.stage = GNPDE_STAGE_RK2C; eF.dt = -dtf; eF.y = y; eF.out_y = s->uy[1];
+    eV.stage = GNPDE_STAGE_RK2C; eV.dt = dtf; eV.y = a; eV.out_y = s->ua[1];
+    rc = enqueue_stage(s, s->uy[0], s->ua[0], nullptr, eF, nullptr, eV, c38, grads, st);
     if (rc) return rc;
-    // stage 3  ->  next: y - dt F1 + dt F2 - dt F3
     eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
-    eF.y = y; eF.out_y = s->uy[0]; eF.n_prev = 2; eF.prev[0] = F[0]; eF.prev[1] = F[1];
-    eF.coef[0] = -dtf; eF.coef[1] = dtf; eF.coef[2] = -dtf;
-    eV.y = a; eV.out_y = s->ua[0]; eV.n_prev = 2; eV.prev[0] = V[0]; eV.prev[1] = V[1];
-    eV.coef[0] = dtf; eV.coef[1] = -dtf; eV.coef[2] = dtf;
-    rc = enqueue_stage(s, s->uy[1], s->ua[1], F[2], eF, V[2], eV, c38, grads, st);
+    eF.stage = GNPDE_STAGE_RK3C; eF.dt = -dtf; eF.k1 = s->uy[0]; eF.out_y = y4;
+    eV.stage = GNPDE_STAGE_RK3C; eV.dt = dtf; eV.k1 = s->ua[0]; eV.out_y = a4;
+    rc = enqueue_stage(s, s->uy[1], s->ua[1], nullptr, eF, nullptr, eV, c38, grads, st);
     if (rc) return rc;
-    // stage 4  ->  y += -dt/8 (F1 + 3 F2 + 3 F3 + F4),  a += dt/8 (V1 + 3 V2 + 3 V3 + V4)   (in place: y and a are not gathered here)
     eF = gnpde_epilogue_t{}; eV = gnpde_epilogue_t{};
-    eF.y = y; eF.out_y = y; eF.n_prev = 3; eF.prev[0] = F[0]; eF.prev[1] = F[1]; eF.prev[2] = F[2];
-    eF.coef[0] = -c8; eF.coef[1] = -c38; eF.coef[2] = -c38; eF.coef[3] = -c8;
-    eV.y = a; eV.out_y = a; eV.n_prev = 3; eV.prev[0] = V[0]; eV.prev[1] = V[1]; eV.prev[2] = V[2];
-    eV.coef[0] = c8; eV.coef[1] = c38; eV.coef[2] = c38; eV.coef[3] = c8;
-    rc = enqueue_stage(s, s->uy[0], s->ua[0], nullptr, eF, nullptr, eV, c8, grads, st);
+    eF.stage = GNPDE_STAGE_RK4C; eF.dt = -dtf; eF.y = y; eF.k1 = s->uy[1]; eF.out_y = y;     // in place: y is not gathered in this stage
+    eV.stage = GNPDE_STAGE_RK4C; eV.dt = dtf; eV.y = a; eV.k1 = s->ua[1]; eV.out_y = a;
+    rc = enqueue_stage(s, y4, a4, nullptr, eF, nullptr, eV, c8, grads, st);
     if (rc) return rc;
   }
   return 0;

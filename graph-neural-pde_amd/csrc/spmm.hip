@@ -1310,7 +1310,8 @@ struct TransposeReduce {   // N values per lane -> 1, over the lane pairs (cl ^ 
   }
 };
 
-// k = alpha (ax - u_i) + beta x0_i, the LINCOMB stage outputs, and this lane's share of g_i . k and g_i . x0_i
+// k = alpha (ax - u_i) + beta x0_i: this lane's share of g_i . k and g_i . x0_i, then the stage algebra of the shared epilogue
+// (compact rk4 / euler / LINCOMB: epilogue.h; it forms k by the same expression, the source row comes from L1 the second time)
 template <int VEC>
 __device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off, const float (&ax)[VEC],
                                                  const float (&ui)[VEC], const float (&gi)[VEC], const float (&cmask)[VEC],
@@ -1319,7 +1320,7 @@ __device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, flo
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { k[v] = alpha * (ax[v] - ui[v]); s[v] = 0.f; }
   if (ep.x0 != nullptr) {
-    load_vec_nt<VEC>(ep.x0 + off, s);
+    load_vec<VEC>(ep.x0 + off, s);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
   }
@@ -1328,23 +1329,7 @@ __device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, flo
     d1 = fmaf(gi[v] * cmask[v], k[v], d1);
     d2 = fmaf(gi[v] * cmask[v], s[v], d2);
   }
-  if (ep.out_k != nullptr) store_vec_nt<VEC>(ep.out_k + off, k);
-  if (ep.out_y != nullptr) {
-    float y[VEC], a[VEC], o[VEC];
-    load_vec_nt<VEC>(ep.y + off, y);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) o[v] = 0.0f;
-    for (int j = 0; j < ep.n_prev; ++j) {
-      load_vec_nt<VEC>(ep.prev[j] + off, a);
-      const float cj = ep.coef[j];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) o[v] = fmaf(a[v], cj, o[v]);
-    }
-    const float ck = ep.coef[ep.n_prev];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) o[v] = y[v] + fmaf(k[v], ck, o[v]);
-    store_vec_nt<VEC>(ep.out_y + off, o);
-  }
+  epilogue<VEC, true>(ep, alpha, beta, off, ax, ui);
 }
 
 // one work item (a row, or a 512-entry chunk of a hub row) by a whole wavefront: G = 64 / L neighbour slots share the row
@@ -1525,9 +1510,15 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
                         bool padded_rows) {
   GNPDE_CHECK_ARG(g && u && gvec && epi && r_out && dots && (w_csr || g->e == 0), GNPDE_EINVAL, "adjoint_rows: null pointer");
-  GNPDE_CHECK_ARG(epi->stage == GNPDE_STAGE_LINCOMB && epi->alpha != nullptr && (epi->x0 == nullptr || epi->beta != nullptr) &&
-                  epi->n_prev >= 0 && epi->n_prev <= GNPDE_MAX_PREV && (epi->out_y == nullptr || epi->y != nullptr), GNPDE_EINVAL,
-                  "adjoint_rows: needs a LINCOMB epilogue");
+  const int stg = epi->stage;
+  GNPDE_CHECK_ARG((stg == GNPDE_STAGE_LINCOMB || stg == GNPDE_STAGE_EULER || (stg >= GNPDE_STAGE_RK1C && stg <= GNPDE_STAGE_RK4C)) &&
+                  epi->alpha != nullptr && (epi->x0 == nullptr || epi->beta != nullptr), GNPDE_EINVAL,
+                  "adjoint_rows: needs a LINCOMB, euler or compact rk4 epilogue");
+  GNPDE_CHECK_ARG(stg != GNPDE_STAGE_LINCOMB || (epi->n_prev >= 0 && epi->n_prev <= GNPDE_MAX_PREV && (epi->out_y == nullptr || epi->y != nullptr)),
+                  GNPDE_EINVAL, "adjoint_rows: bad LINCOMB epilogue");
+  GNPDE_CHECK_ARG(stg == GNPDE_STAGE_LINCOMB || epi->out_y != nullptr, GNPDE_EINVAL, "adjoint_rows: out_y is null");
+  GNPDE_CHECK_ARG(!(stg == GNPDE_STAGE_EULER || stg == GNPDE_STAGE_RK2C || stg == GNPDE_STAGE_RK4C) || epi->y != nullptr, GNPDE_EINVAL, "adjoint_rows: y is null");
+  GNPDE_CHECK_ARG(!(stg == GNPDE_STAGE_RK3C || stg == GNPDE_STAGE_RK4C) || epi->k1 != nullptr, GNPDE_EINVAL, "adjoint_rows: k1 is null");
   GNPDE_CHECK_ARG(epi->out_k != u && epi->out_y != u, GNPDE_EINVAL, "adjoint_rows: output aliases the gathered operand");
   GNPDE_CHECK_ARG(g->row_begin == 0 && d >= 1 && d <= 256 && ld >= d && ld % 4 == 0 && (d % 4 == 0 || padded_rows), GNPDE_ESHAPE,
                   "adjoint_rows: whole graphs, rows of up to 256 floats in 16-byte lanes");
@@ -1547,7 +1538,8 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
     const size_t need = static_cast<size_t>(g->n_long_chunks) * a.ldp * sizeof(float);
     GNPDE_CHECK_ARG(ws != nullptr && ws_bytes >= need, GNPDE_EWS, "adjoint_rows: workspace %zu < %zu bytes", ws_bytes, need);
   }
-  const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->out_k, epi->out_y, epi->prev[0], epi->prev[1], epi->prev[2], epi->prev[3]};
+  const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->k1, epi->out_k, epi->out_y, stg == GNPDE_STAGE_LINCOMB ? epi->prev[0] : nullptr,
+                        stg == GNPDE_STAGE_LINCOMB ? epi->prev[1] : nullptr, stg == GNPDE_STAGE_LINCOMB ? epi->prev[2] : nullptr};
   for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
   fa.g = gvec; fa.r = r_out; fa.dots = dots;
   const unsigned grid = adjoint_rows_grid(g);
