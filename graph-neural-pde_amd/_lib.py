@@ -37,7 +37,7 @@ class GraphStruct(ctypes.Structure):
               ('long_chunk_begin', c_vp), ('long_chunk_end', c_vp),
               ('n_long_cols', ctypes.c_int32), ('n_bin16', ctypes.c_int32), ('n_bin64', ctypes.c_int32),
               ('max_row_len', ctypes.c_int32), ('max_col_len', ctypes.c_int32), ('row_begin', ctypes.c_int32), ('long_cols', c_vp), ('bin_rows', c_vp), ('long_chunk_first', c_vp),
-              ('xcd_deal', ctypes.c_int32)]
+              ('xcd_deal', ctypes.c_int32), ('n_bin_le64', ctypes.c_int32)]
 
 
 class EpilogueStruct(ctypes.Structure):

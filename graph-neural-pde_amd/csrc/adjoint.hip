@@ -233,7 +233,7 @@ struct gnpde_adjoint {
   size_t ws_bytes;
   // workspace regions
   size_t state_bytes;
-  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots;
+  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots, *hub_ws;
   int n_dots;
   char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
   size_t att_bytes, attbwd_bytes, spmm_bytes, spmm_t_bytes;
@@ -285,7 +285,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   const int M = nl ? r.proj_m : 0;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
-  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0;
+  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0, o_hub = 0;
   for (int i = 0; i < 2; ++i) { o_uy[i] = take(state); o_ua[i] = take(state); }
   const int nF = method == GNPDE_METHOD_RK4 ? 1 : 0, nV = method == GNPDE_METHOD_RK4 ? 1 : 0;     // (u4 of the state / of the adjoint)
   for (int i = 0; i < 4; ++i) o_F[i] = i < nF ? take(state) : 0;
@@ -302,6 +302,8 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     o_dqk = take(static_cast<size_t>(g.n) * M * 4);
     o_w = take(e4); o_wt = take(e4);
     o_ds = take(e4 * r.att.heads);
+    const size_t hub_f = hub_bwd_workspace_floats(&g, r.att.heads, r.att.att_dim), hub_ft = hub_bwd_workspace_floats(&gt, r.att.heads, r.att.att_dim);
+    o_hub = take((hub_f > hub_ft ? hub_f : hub_ft) * 4 + 256);
     att_b = attention_workspace_bytes(&g, r.att.heads, false);
     attbwd_b = gnpde_attention_bwd_workspace_bytes(&g, &r.att);
   }
@@ -320,6 +322,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     s->P = nl ? f(o_P) : nullptr; s->qk = nl ? f(o_qk) : nullptr; s->dqk = nl ? f(o_dqk) : nullptr;
     s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = f(o_r); s->ds = nl ? f(o_ds) : nullptr;
     s->dots = f(o_dots); s->n_dots = n_dots;
+    s->hub_ws = nl ? f(o_hub) : nullptr;
     s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
     s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
     s->partial = f(o_part);
@@ -364,16 +367,16 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     const bool lanes = head_rowsum_supported(h, dk);            // lane-per-entry row sums (rows without entries stay zero)
     const bool dq_fused = s->rows_bwd && lanes && attention_rows_bwd_dq_supported(h, dk);
     if (lanes) GNPDE_HIP(hipMemsetAsync(s->dqk, 0, static_cast<size_t>(n) * M * 4, st));
-    if (s->rows_bwd) rc = launch_attention_rows_bwd_dq(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, dq_fused ? s->dqk : nullptr, M, st);
+    if (s->rows_bwd) rc = launch_attention_rows_bwd_dq(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, dq_fused ? s->dqk : nullptr, M, s->hub_ws, st);
     else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
     if (rc) return rc;
     if (lanes) {
       // d q over the rows (unless the backward kernel formed it), d k over the rows of the transposed graph
       if (!dq_fused) {
-        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, s->hub_ws, st);
         if (rc) return rc;
       }
-      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, s->hub_ws, st);
       if (rc) return rc;
     } else {
       rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);

@@ -429,50 +429,7 @@ __global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* _
   }
 }
 
-template <int H, int DK, bool DQ>
-int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                int scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
-  const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
-  if (n16 > 0) {
-    constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
-    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
-                       g->bin_rows, 0, n16, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
-                       ds_csr, dq, lddq);
-    GNPDE_LAUNCH_CHECK();
-  }
-  if (n64 > 0 || nl > 0) {
-    const unsigned grid = static_cast<unsigned>(nl + (n64 + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, true, DQ>), dim3(grid), dim3(kBlock), 0, s,
-                       g->rowptr, g->colidx, g->bin_rows, n16, n64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
-                       scale_sigmoid, g->long_rows, nl, ds_csr, dq, lddq);
-    GNPDE_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-template <int H, int DK>
-int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                              int scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
-  if constexpr (H * DK <= 32) {
-    if (dq != nullptr) return launch_attention_rows_bwd_v<H, DK, true>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, s);
-  }
-  return launch_attention_rows_bwd_v<H, DK, false>(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Head-wise weighted segment sum with one LANE PER ENTRY (the adjoint stage's d q and d k; csrc/adjoint.hip):
-//   out[seg, c] = scale * sum_{t in seg} ds[pos(t), head(c)] * feat[other(t), c]        c < A = H * DK4 * 4
-// head_spmm_kernel above gives a wavefront to every segment and A / 4 lanes to every entry -- at A = 16 and a median of 8 entries
-// per row one iteration of 16 entry slots, most of them empty, behind a chain of four dependent loads: 139 us per launch at the
-// ogbn-arxiv shape for 220 MB of traffic.  Here the segments come from the degree-binned records (as in
-// attention_rows_bwd_kernel): rows of <= 16 entries take 16 lanes (four rows per wavefront), a lane fetches its entry's ds vector
-// and whole feature row (A floats in registers) with all loads of the wavefront in flight at once, and the A partial columns are
-// summed over the lanes of the row by a transposing butterfly (A - 1 + log2(GL / A) shuffles instead of A log2 GL), after which
-// lane gl holds column gl / (GL / A) and the row is written by one coalesced store.  Hub segments: one block each.
-// pos == nullptr: ds is indexed by the segment's own positions (d q, rows of the graph); else through pos (d k: the segments
-// are rows of the transposed graph and pos maps its positions to the CSR positions ds is stored at).
-// ------------------------------------------------------------------------------------------------
+// one entry of a head-wise row sum: acc[c] += ds[pp, head(c)] * feat[o, c] (head_rowsum_kernel / head_rowsum_hub_kernel below)
 template <int H, int DK4>
 __device__ __forceinline__ void entry_fma(const float* __restrict__ ds, const float* __restrict__ feat, int ldf, int h_rt, long long pp, int o,
                                           float (&acc)[H * DK4 * 4]) {
@@ -501,6 +458,482 @@ __device__ __forceinline__ void entry_fma(const float* __restrict__ ds, const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hub rows (> GNPDE_LONG_ROW entries) of the two backward row kernels, 1024 threads per row.  Inside attention_rows_bwd_kernel /
+// head_rowsum_kernel a hub is ONE 256-thread block walking the row three times (once) with one dependent gather per step: the 13 k-entry
+// hub of the ogbn-arxiv shape alone is 150 serialised round trips and sets the duration of the whole launch (127 us for 3.6 k rows + 204
+// hubs, against 28 us for the 23.6 k rows of 17..64 entries).  Here a hub gets 16 wavefronts and every lane keeps UH entries in flight;
+// same arithmetic per entry, block-wide reductions in a fixed order (wave butterflies, then the 16 wave results in wave order).
+// ------------------------------------------------------------------------------------------------
+constexpr int kHubThreads = 1024;
+constexpr int kHubWaves = kHubThreads / kWave;
+
+__device__ __forceinline__ float hub_block_sum(float v, float* red) {   // all 1024 threads take part
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < kHubWaves; ++w) t += red[w];
+  return t;
+}
+__device__ __forceinline__ float hub_block_max(float v, float* red) {
+  v = wmax(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < kHubWaves; ++w) t = fmaxf(t, red[w]);
+  return t;
+}
+
+template <int H, int DK, bool DQ>
+__global__ __launch_bounds__(kHubThreads) void attention_hub_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                                       const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+                                                                       const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                       const float* __restrict__ scale_ptr, int scale_sigmoid,
+                                                                       const int* __restrict__ long_rows, float* __restrict__ ds,
+                                                                       float* __restrict__ dq, int lddq) {
+  constexpr int A = H * DK;
+  constexpr int AQ = DQ ? A : 1;
+  constexpr int UH = 4;
+  __shared__ float red[kHubWaves];
+  __shared__ float qpart[DQ ? kHubWaves : 1][AQ];
+  float scale = 1.0f / static_cast<float>(H);
+  if (scale_ptr != nullptr) {
+    float sc = *scale_ptr;
+    if (scale_sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+    scale *= sc;
+  }
+  const float inv = 1.0f / sqrtf(static_cast<float>(DK));
+  const int row = long_rows[blockIdx.x];
+  const int b = rowptr[row], e = rowptr[row + 1];
+  const float* qrow = q + static_cast<size_t>(row) * ldqk;
+  float mx[H], den[H], c[H];
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) { mx[hh] = -INFINITY; den[hh] = 0.f; c[hh] = 0.f; }
+  // pass 1: maxima (UH entries per lane per step: their column ids, then their key rows, are all in flight together)
+  for (int p0 = b + static_cast<int>(threadIdx.x); p0 < e; p0 += UH * kHubThreads) {
+    int cols[UH];
+#pragma unroll
+    for (int u = 0; u < UH; ++u) { const int p = p0 + u * kHubThreads; cols[u] = p < e ? colidx[p] : -1; }
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      if (cols[u] < 0) continue;
+      const int p = p0 + u * kHubThreads;
+      float sc[H];
+      row_scores<H, DK>(qrow, k + static_cast<size_t>(cols[u]) * ldqk, inv, edge_w != nullptr ? edge_w[p] : 1.f, sc);
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) mx[hh] = fmaxf(mx[hh], sc[hh]);
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) mx[hh] = hub_block_max(mx[hh], red);
+  // pass 2: denominators and c = sum a r
+  for (int p0 = b + static_cast<int>(threadIdx.x); p0 < e; p0 += UH * kHubThreads) {
+    int cols[UH];
+#pragma unroll
+    for (int u = 0; u < UH; ++u) { const int p = p0 + u * kHubThreads; cols[u] = p < e ? colidx[p] : -1; }
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      if (cols[u] < 0) continue;
+      const int p = p0 + u * kHubThreads;
+      float sc[H];
+      row_scores<H, DK>(qrow, k + static_cast<size_t>(cols[u]) * ldqk, inv, edge_w != nullptr ? edge_w[p] : 1.f, sc);
+      const float rp = r[p];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        const float ex = expf(sc[hh] - mx[hh]);
+        den[hh] += ex;
+        c[hh] = fmaf(ex, rp, c[hh]);
+      }
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) {
+    den[hh] = hub_block_sum(den[hh], red) + 1e-16f;
+    c[hh] = hub_block_sum(c[hh], red) / den[hh];
+  }
+  // pass 3: ds (and d q)
+  float accq[AQ];
+#pragma unroll
+  for (int cc = 0; cc < AQ; ++cc) accq[cc] = 0.f;
+  for (int p0 = b + static_cast<int>(threadIdx.x); p0 < e; p0 += UH * kHubThreads) {
+    int cols[UH];
+#pragma unroll
+    for (int u = 0; u < UH; ++u) { const int p = p0 + u * kHubThreads; cols[u] = p < e ? colidx[p] : -1; }
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      if (cols[u] < 0) continue;
+      const int p = p0 + u * kHubThreads;
+      const float ewp = edge_w != nullptr ? edge_w[p] : 1.f;
+      const float* krow = k + static_cast<size_t>(cols[u]) * ldqk;
+      float sc[H], out[H];
+      row_scores<H, DK>(qrow, krow, inv, ewp, sc);
+      const float rp = r[p];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        out[hh] = (expf(sc[hh] - mx[hh]) / den[hh]) * scale * (rp - c[hh]) * ewp;
+        ds[static_cast<size_t>(p) * H + hh] = out[hh];
+      }
+      if constexpr (DQ) {
+#pragma unroll
+        for (int cc = 0; cc < A; cc += 4) {
+          const float4 kv = *reinterpret_cast<const float4*>(krow + cc);
+          const float wv = out[cc / DK];
+          accq[cc + 0] = fmaf(wv, kv.x, accq[cc + 0]); accq[cc + 1] = fmaf(wv, kv.y, accq[cc + 1]);
+          accq[cc + 2] = fmaf(wv, kv.z, accq[cc + 2]); accq[cc + 3] = fmaf(wv, kv.w, accq[cc + 3]);
+        }
+      }
+    }
+  }
+  if constexpr (DQ) {
+    const int lane_ = threadIdx.x & (kWave - 1);
+    constexpr int C = A < kWave ? A : kWave;
+    constexpr int LPE = kWave / C;
+#pragma unroll
+    for (int ch = 0; ch < A / C; ++ch) {
+      if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(accq + ch * C, lane_);
+      float v = accq[ch * C];
+#pragma unroll
+      for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+      if ((lane_ % LPE) == 0) qpart[threadIdx.x >> 6][ch * C + lane_ / LPE] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < A) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kHubWaves; ++w) t += qpart[w][threadIdx.x];
+      dq[static_cast<size_t>(row) * lddq + threadIdx.x] = inv * t;
+    }
+  }
+}
+
+template <int H, int DK4>
+__global__ __launch_bounds__(kHubThreads) void head_rowsum_hub_kernel(const int* __restrict__ rowptr, const int* __restrict__ other,
+                                                                     const int* __restrict__ pos, const float* __restrict__ ds,
+                                                                     const float* __restrict__ feat, int ldf, float scale,
+                                                                     const int* __restrict__ long_rows, float* __restrict__ out, int ldo) {
+  constexpr int A = H * DK4 * 4;
+  constexpr int UH = 4;
+  __shared__ float part[kHubWaves][A];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int seg = long_rows[blockIdx.x];
+  const int b = rowptr[seg], e = rowptr[seg + 1];
+  float acc[A];
+#pragma unroll
+  for (int c = 0; c < A; ++c) acc[c] = 0.f;
+  for (int t0 = b + static_cast<int>(threadIdx.x); t0 < e; t0 += UH * kHubThreads) {
+    int pp[UH], oo[UH];
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      const int t = t0 + u * kHubThreads;
+      pp[u] = -1; oo[u] = 0;
+      if (t < e) { pp[u] = pos != nullptr ? pos[t] : t; oo[u] = other[t]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UH; ++u)
+      if (pp[u] >= 0) entry_fma<H, DK4>(ds, feat, ldf, H, pp[u], oo[u], acc);
+  }
+  constexpr int C = A < kWave ? A : kWave;
+  constexpr int LPE = kWave / C;
+#pragma unroll
+  for (int ch = 0; ch < A / C; ++ch) {
+    if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(acc + ch * C, lane);
+    float v = acc[ch * C];
+#pragma unroll
+    for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    if ((lane % LPE) == 0) part[threadIdx.x >> 6][ch * C + lane / LPE] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < A) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kHubWaves; ++w) t += part[w][threadIdx.x];
+    out[static_cast<size_t>(seg) * ldo + threadIdx.x] = scale * t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hub rows as 512-entry CHUNKS spread over the chip (the graph's long_chunk_* lists, as the forward's hub phases).  One workgroup
+// per hub -- even with 1024 threads -- is bound by what ONE CU's memory pipeline delivers: the 10.8 k-entry hub of the ogbn-arxiv
+// shape pulls 3 MB of key rows / ds vectors through one CU, 127 us for the softmax backward and 45 us for a head sum while 250 CUs
+// idle.  Chunked: (a) per chunk, scores + online-softmax partials (m_c, l_c = sum e^{s-m_c}, t_c = sum e^{s-m_c} r); (b) per chunk,
+// fold the row's partials (<= 22 of them, every chunk block redoes the fold), then ds for its entries and its partial d q; (c) per
+// hub row, the chunks' d q partials in chunk order.  The head sums (d k, or d q when it is not fused) are (b')/(c) alone.
+// Needs scratch: [n_long_chunks] x (3 H + A) floats (hub_bwd_workspace_floats).
+// ------------------------------------------------------------------------------------------------
+template <int H, int DK>
+__global__ __launch_bounds__(kBlock) void attention_hub_stats_kernel(const int* __restrict__ colidx, const int* __restrict__ lc_row,
+                                                                    const int* __restrict__ lc_begin, const int* __restrict__ lc_end,
+                                                                    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+                                                                    const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                    float* __restrict__ part) {
+  constexpr int PER = GNPDE_LONG_ROW / kBlock;      // entries per thread
+  __shared__ float red[kWavesPerBlock];
+  const int c = blockIdx.x;
+  const int row = lc_row[c], b = lc_begin[c], e = lc_end[c];
+  const float inv = 1.0f / sqrtf(static_cast<float>(DK));
+  const float* qrow = q + static_cast<size_t>(row) * ldqk;
+  int cols[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const int p = b + i * kBlock + static_cast<int>(threadIdx.x); cols[i] = p < e ? colidx[p] : -1; }
+  float sc[PER][H], rr[PER];
+  float mx[H];
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) mx[hh] = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = b + i * kBlock + static_cast<int>(threadIdx.x);
+    rr[i] = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) sc[i][hh] = -INFINITY;
+    if (cols[i] >= 0) {
+      rr[i] = r[p];
+      row_scores<H, DK>(qrow, k + static_cast<size_t>(cols[i]) * ldqk, inv, edge_w != nullptr ? edge_w[p] : 1.f, sc[i]);
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) mx[hh] = fmaxf(mx[hh], sc[i][hh]);
+    }
+  }
+  float* out = part + static_cast<size_t>(c) * 3 * H;
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) {
+    const float m = block_max(mx[hh], red);
+    float l = 0.f, t = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const float ex = cols[i] >= 0 ? expf(sc[i][hh] - m) : 0.f;
+      l += ex;
+      t = fmaf(ex, rr[i], t);
+    }
+    l = block_sum(l, red);
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) { out[hh] = m; out[H + hh] = l; out[2 * H + hh] = t; }
+  }
+}
+
+template <int H, int DK, bool DQ>
+__global__ __launch_bounds__(kBlock) void attention_hub_ds_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                                 const int* __restrict__ lc_row, const int* __restrict__ lc_begin,
+                                                                 const int* __restrict__ lc_end, const int* __restrict__ lc_first,
+                                                                 const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+                                                                 const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                 const float* __restrict__ scale_ptr, int scale_sigmoid,
+                                                                 const float* __restrict__ part, float* __restrict__ ds,
+                                                                 float* __restrict__ dqpart) {
+  constexpr int A = H * DK;
+  constexpr int AQ = DQ ? A : 1;
+  constexpr int PER = GNPDE_LONG_ROW / kBlock;
+  __shared__ float st[3 * H];                       // row maximum, 1 / denominator, c per head
+  __shared__ float qpart[DQ ? kWavesPerBlock : 1][AQ];
+  const int c = blockIdx.x;
+  const int row = lc_row[c], b = lc_begin[c], e = lc_end[c];
+  const int c0 = lc_first[c];
+  const int nch = (rowptr[row + 1] - rowptr[row] + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
+  if (threadIdx.x < H) {                            // the row's statistics from its chunks' partials, chunk order
+    const int hh = threadIdx.x;
+    float m = -INFINITY;
+    for (int i = 0; i < nch; ++i) m = fmaxf(m, part[static_cast<size_t>(c0 + i) * 3 * H + hh]);
+    float l = 0.f, t = 0.f;
+    for (int i = 0; i < nch; ++i) {
+      const float* pc = part + static_cast<size_t>(c0 + i) * 3 * H;
+      const float w = expf(pc[hh] - m);
+      l = fmaf(pc[H + hh], w, l);
+      t = fmaf(pc[2 * H + hh], w, t);
+    }
+    const float den = l + 1e-16f;
+    st[hh] = m; st[H + hh] = den; st[2 * H + hh] = t / den;
+  }
+  __syncthreads();
+  float scale = 1.0f / static_cast<float>(H);
+  if (scale_ptr != nullptr) {
+    float sv = *scale_ptr;
+    if (scale_sigmoid) sv = 1.0f / (1.0f + expf(-sv));
+    scale *= sv;
+  }
+  const float inv = 1.0f / sqrtf(static_cast<float>(DK));
+  const float* qrow = q + static_cast<size_t>(row) * ldqk;
+  float accq[AQ];
+#pragma unroll
+  for (int cc = 0; cc < AQ; ++cc) accq[cc] = 0.f;
+  int cols[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const int p = b + i * kBlock + static_cast<int>(threadIdx.x); cols[i] = p < e ? colidx[p] : -1; }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (cols[i] < 0) continue;
+    const int p = b + i * kBlock + static_cast<int>(threadIdx.x);
+    const float ewp = edge_w != nullptr ? edge_w[p] : 1.f;
+    const float* krow = k + static_cast<size_t>(cols[i]) * ldqk;
+    float sc[H], out[H];
+    row_scores<H, DK>(qrow, krow, inv, ewp, sc);
+    const float rp = r[p];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      out[hh] = (expf(sc[hh] - st[hh]) / st[H + hh]) * scale * (rp - st[2 * H + hh]) * ewp;
+      ds[static_cast<size_t>(p) * H + hh] = out[hh];
+    }
+    if constexpr (DQ) {
+#pragma unroll
+      for (int cc = 0; cc < A; cc += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(krow + cc);
+        const float wv = out[cc / DK];
+        accq[cc + 0] = fmaf(wv, kv.x, accq[cc + 0]); accq[cc + 1] = fmaf(wv, kv.y, accq[cc + 1]);
+        accq[cc + 2] = fmaf(wv, kv.z, accq[cc + 2]); accq[cc + 3] = fmaf(wv, kv.w, accq[cc + 3]);
+      }
+    }
+  }
+  if constexpr (DQ) {
+    const int lane_ = threadIdx.x & (kWave - 1);
+    constexpr int C = A < kWave ? A : kWave;
+    constexpr int LPE = kWave / C;
+#pragma unroll
+    for (int ch = 0; ch < A / C; ++ch) {
+      if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(accq + ch * C, lane_);
+      float v = accq[ch * C];
+#pragma unroll
+      for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+      if ((lane_ % LPE) == 0) qpart[threadIdx.x >> 6][ch * C + lane_ / LPE] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < A)
+      dqpart[static_cast<size_t>(c) * A + threadIdx.x] = (qpart[0][threadIdx.x] + qpart[1][threadIdx.x]) + (qpart[2][threadIdx.x] + qpart[3][threadIdx.x]);
+  }
+}
+
+// partial head sums of one 512-entry chunk of a hub segment: rowpart[c][0:A]
+template <int H, int DK4>
+__global__ __launch_bounds__(kBlock) void head_rowsum_chunk_kernel(const int* __restrict__ other, const int* __restrict__ pos,
+                                                                  const int* __restrict__ lc_begin, const int* __restrict__ lc_end,
+                                                                  const float* __restrict__ ds, const float* __restrict__ feat, int ldf,
+                                                                  float* __restrict__ rowpart) {
+  constexpr int A = H * DK4 * 4;
+  constexpr int PER = GNPDE_LONG_ROW / kBlock;
+  __shared__ float part[kWavesPerBlock][A];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int c = blockIdx.x;
+  const int b = lc_begin[c], e = lc_end[c];
+  float acc[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) acc[a] = 0.f;
+  int pp[PER], oo[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int t = b + i * kBlock + static_cast<int>(threadIdx.x);
+    pp[i] = -1; oo[i] = 0;
+    if (t < e) { pp[i] = pos != nullptr ? pos[t] : t; oo[i] = other[t]; }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+    if (pp[i] >= 0) entry_fma<H, DK4>(ds, feat, ldf, H, pp[i], oo[i], acc);
+  constexpr int C = A < kWave ? A : kWave;
+  constexpr int LPE = kWave / C;
+#pragma unroll
+  for (int ch = 0; ch < A / C; ++ch) {
+    if constexpr (C > 1) LaneTranspose<C, kWave / 2>::run(acc + ch * C, lane);
+    float v = acc[ch * C];
+#pragma unroll
+    for (int m = LPE / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    if ((lane % LPE) == 0) part[threadIdx.x >> 6][ch * C + lane / LPE] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < A)
+    rowpart[static_cast<size_t>(c) * A + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// out[hub row, a] = scale * sum of its chunks' partials, chunk order (one wavefront per hub row, lanes = columns)
+__global__ __launch_bounds__(kWave) void hub_rowpart_fold_kernel(const int* __restrict__ long_rows, const int* __restrict__ long_chunk_ptr,
+                                                                const float* __restrict__ rowpart, int A, float scale,
+                                                                float* __restrict__ out, int ldo) {
+  const int lr = blockIdx.x;
+  const int row = long_rows[lr];
+  const int c0 = long_chunk_ptr[lr], c1 = long_chunk_ptr[lr + 1];
+  for (int a = threadIdx.x; a < A; a += kWave) {
+    float t = 0.f;
+    for (int c = c0; c < c1; ++c) t += rowpart[static_cast<size_t>(c) * A + a];
+    out[static_cast<size_t>(row) * ldo + a] = scale * t;
+  }
+}
+
+template <int H, int DK, bool DQ>
+int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                                int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
+  const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
+  // second class (17..512 entries, longest first): its trailing n_bin_le64 records (17..64 entries) take a ONE-pass launch (an entry per
+  // lane, 1/8 of the score registers: twice the waves per SIMD and no predicated dead passes), the leading ones the 8-pass launch
+  const int n_le64 = (g->n_bin_le64 > 0 && g->n_bin_le64 <= n64) ? g->n_bin_le64 : 0;
+  const int n_gt64 = n64 - n_le64;
+  if (n16 > 0) {
+    constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
+    const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
+                       g->bin_rows, 0, n16, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
+                       ds_csr, dq, lddq);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (nl > 0 && hub_ws != nullptr && g->long_chunk_first != nullptr && g->n_long_chunks > 0) {
+    // hubs as 512-entry chunks over the whole chip (scratch: [chunks][3 H] statistics, then [chunks][A] d q partials)
+    const int nc = g->n_long_chunks;
+    float* stats = hub_ws;
+    float* dqpart = hub_ws + static_cast<size_t>(nc) * 3 * H;
+    hipLaunchKernelGGL((attention_hub_stats_kernel<H, DK>), dim3(nc), dim3(kBlock), 0, s, g->colidx, g->long_chunk_row, g->long_chunk_begin,
+                       g->long_chunk_end, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, stats);
+    GNPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attention_hub_ds_kernel<H, DK, DQ>), dim3(nc), dim3(kBlock), 0, s, g->rowptr, g->colidx, g->long_chunk_row,
+                       g->long_chunk_begin, g->long_chunk_end, g->long_chunk_first, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
+                       scale_sigmoid, stats, ds_csr, dqpart);
+    GNPDE_LAUNCH_CHECK();
+    if constexpr (DQ) {
+      hipLaunchKernelGGL(hub_rowpart_fold_kernel, dim3(nl), dim3(kWave), 0, s, g->long_rows, g->long_chunk_ptr, dqpart, H * DK,
+                         1.0f / sqrtf(static_cast<float>(DK)), dq, lddq);
+      GNPDE_LAUNCH_CHECK();
+    }
+  } else if (nl > 0) {       // no scratch: one 1024-thread workgroup per hub
+    hipLaunchKernelGGL((attention_hub_bwd_kernel<H, DK, DQ>), dim3(nl), dim3(kHubThreads), 0, s, g->rowptr, g->colidx, att->q, att->k,
+                       att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, ds_csr, dq, lddq);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n_gt64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n_gt64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, false, DQ>), dim3(grid), dim3(kBlock), 0, s,
+                       g->rowptr, g->colidx, g->bin_rows, n16, n_gt64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
+                       scale_sigmoid, g->long_rows, 0, ds_csr, dq, lddq);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n_le64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n_le64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
+                       g->bin_rows, n16 + n_gt64, n_le64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid,
+                       g->long_rows, 0, ds_csr, dq, lddq);
+    GNPDE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <int H, int DK>
+int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
+                              int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
+  if constexpr (H * DK <= 32) {
+    if (dq != nullptr) return launch_attention_rows_bwd_v<H, DK, true>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s);
+  }
+  return launch_attention_rows_bwd_v<H, DK, false>(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, hub_ws, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head-wise weighted segment sum with one LANE PER ENTRY (the adjoint stage's d q and d k; csrc/adjoint.hip):
+//   out[seg, c] = scale * sum_{t in seg} ds[pos(t), head(c)] * feat[other(t), c]        c < A = H * DK4 * 4
+// head_spmm_kernel above gives a wavefront to every segment and A / 4 lanes to every entry -- at A = 16 and a median of 8 entries
+// per row one iteration of 16 entry slots, most of them empty, behind a chain of four dependent loads: 139 us per launch at the
+// ogbn-arxiv shape for 220 MB of traffic.  Here the segments come from the degree-binned records (as in
+// attention_rows_bwd_kernel): rows of <= 16 entries take 16 lanes (four rows per wavefront), a lane fetches its entry's ds vector
+// and whole feature row (A floats in registers) with all loads of the wavefront in flight at once, and the A partial columns are
+// summed over the lanes of the row by a transposing butterfly (A - 1 + log2(GL / A) shuffles instead of A log2 GL), after which
+// lane gl holds column gl / (GL / A) and the row is written by one coalesced store.  Hub segments: one block each.
+// pos == nullptr: ds is indexed by the segment's own positions (d q, rows of the graph); else through pos (d k: the segments
+// are rows of the transposed graph and pos maps its positions to the CSR positions ds is stored at).
+// ------------------------------------------------------------------------------------------------
 template <int H, int DK4, int GL, int PER, bool HUBS>
 __global__ __launch_bounds__(kBlock) void head_rowsum_kernel(const int* __restrict__ rowptr, const int* __restrict__ other,
                                                             const int* __restrict__ pos, const int* __restrict__ bin_rows, int first_rec,
@@ -563,8 +996,10 @@ __global__ __launch_bounds__(kBlock) void head_rowsum_kernel(const int* __restri
 
 template <int H, int DK4>
 int launch_head_rowsum_hd(const gnpde_graph_t* g, const int* pos, const float* ds, const float* feat, int ldf, float scale, float* out,
-                          int ldo, hipStream_t s) {
+                          int ldo, float* hub_ws, hipStream_t s) {
   const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
+  const int n_le64 = (g->n_bin_le64 > 0 && g->n_bin_le64 <= n64) ? g->n_bin_le64 : 0;     // as launch_attention_rows_bwd_v
+  const int n_gt64 = n64 - n_le64;
   if (n16 > 0) {
     constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
@@ -572,10 +1007,27 @@ int launch_head_rowsum_hd(const gnpde_graph_t* g, const int* pos, const float* d
                        n16, ds, feat, ldf, scale, g->long_rows, 0, out, ldo);
     GNPDE_LAUNCH_CHECK();
   }
-  if (n64 > 0 || nl > 0) {
-    const unsigned grid = static_cast<unsigned>(nl + (n64 + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((head_rowsum_kernel<H, DK4, kWave, GNPDE_LONG_ROW / kWave, true>), dim3(grid), dim3(kBlock), 0, s, g->rowptr,
-                       g->colidx, pos, g->bin_rows, n16, n64, ds, feat, ldf, scale, g->long_rows, nl, out, ldo);
+  if (nl > 0 && hub_ws != nullptr && g->n_long_chunks > 0) {      // hub segments as 512-entry chunks over the whole chip
+    hipLaunchKernelGGL((head_rowsum_chunk_kernel<H, DK4>), dim3(g->n_long_chunks), dim3(kBlock), 0, s, g->colidx, pos, g->long_chunk_begin,
+                       g->long_chunk_end, ds, feat, ldf, hub_ws);
+    GNPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hub_rowpart_fold_kernel, dim3(nl), dim3(kWave), 0, s, g->long_rows, g->long_chunk_ptr, hub_ws, H * DK4 * 4, scale, out, ldo);
+    GNPDE_LAUNCH_CHECK();
+  } else if (nl > 0) {
+    hipLaunchKernelGGL((head_rowsum_hub_kernel<H, DK4>), dim3(nl), dim3(kHubThreads), 0, s, g->rowptr, g->colidx, pos, ds, feat, ldf, scale,
+                       g->long_rows, out, ldo);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n_gt64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n_gt64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((head_rowsum_kernel<H, DK4, kWave, GNPDE_LONG_ROW / kWave, false>), dim3(grid), dim3(kBlock), 0, s, g->rowptr,
+                       g->colidx, pos, g->bin_rows, n16, n_gt64, ds, feat, ldf, scale, g->long_rows, 0, out, ldo);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (n_le64 > 0) {
+    const unsigned grid = static_cast<unsigned>((n_le64 + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((head_rowsum_kernel<H, DK4, kWave, 1, false>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx, pos, g->bin_rows,
+                       n16 + n_gt64, n_le64, ds, feat, ldf, scale, g->long_rows, 0, out, ldo);
     GNPDE_LAUNCH_CHECK();
   }
   return 0;
@@ -592,15 +1044,19 @@ bool head_rowsum_supported(int heads, int dk) {
   return (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (dk4 == 1 || dk4 == 2 || dk4 == 4) && a4 <= 8;
 }
 
+size_t hub_bwd_workspace_floats(const gnpde_graph_t* g, int heads, int att_dim) {
+  return static_cast<size_t>(g->n_long_chunks) * (3 * static_cast<size_t>(heads) + static_cast<size_t>(att_dim));
+}
+
 int launch_head_rowsum(const gnpde_graph_t* g, const int* pos, const float* ds, int heads, int dk, const float* feat, int ldf,
-                       float scale, float* out, int ldo, hipStream_t s) {
+                       float scale, float* out, int ldo, float* hub_ws, hipStream_t s) {
   GNPDE_CHECK_ARG(g && ds && feat && out && head_rowsum_supported(heads, dk), GNPDE_ESHAPE, "head_rowsum: heads=%d d_k=%d has no kernel", heads, dk);
   GNPDE_CHECK_ARG(ldf % 4 == 0 && reinterpret_cast<uintptr_t>(feat) % 16 == 0 && reinterpret_cast<uintptr_t>(ds) % 16 == 0, GNPDE_EINVAL,
                   "head_rowsum: operands must be 16-byte aligned");
   GNPDE_CHECK_ARG(g->bin_rows != nullptr && (g->n_long_rows == 0 || g->long_rows), GNPDE_EINVAL, "head_rowsum: graph without degree bins");
   if (g->n == 0 || g->e == 0) return 0;
   const int dk4 = dk / 4;
-#define GNPDE_HR(HH, DD) if (heads == HH && dk4 == DD) return launch_head_rowsum_hd<HH, DD>(g, pos, ds, feat, ldf, scale, out, ldo, s);
+#define GNPDE_HR(HH, DD) if (heads == HH && dk4 == DD) return launch_head_rowsum_hd<HH, DD>(g, pos, ds, feat, ldf, scale, out, ldo, hub_ws, s);
   GNPDE_HR(1, 1) GNPDE_HR(1, 2) GNPDE_HR(1, 4) GNPDE_HR(2, 1) GNPDE_HR(2, 2) GNPDE_HR(2, 4) GNPDE_HR(4, 1) GNPDE_HR(4, 2) GNPDE_HR(8, 1)
 #undef GNPDE_HR
   return GNPDE_ESHAPE;
@@ -682,7 +1138,7 @@ bool attention_rows_bwd_dq_supported(int heads, int dk) {
 }
 
 int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s) {
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
   GNPDE_CHECK_ARG(g && att && r_csr && ds_csr && att->q && att->k, GNPDE_EINVAL, "attention_rows_bwd: null argument");
   GNPDE_CHECK_ARG(att->type == GNPDE_ATT_SCALED_DOT && att->norm_idx == 0 && !att->square_plus, GNPDE_ESHAPE,
                   "attention_rows_bwd: only scaled-dot attention with a softmax over the row");
@@ -695,7 +1151,7 @@ int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t
   const int h = att->heads, dk = att->att_dim / att->heads;
   GNPDE_CHECK_ARG(dq == nullptr || attention_rows_bwd_dq_supported(h, dk), GNPDE_ESHAPE, "attention_rows_bwd: d q fusion needs heads * d_k <= 32");
 #define GNPDE_AB(HH, DD) \
-  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, s);
+  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s);
   GNPDE_AB(1, 4) GNPDE_AB(1, 8) GNPDE_AB(1, 16) GNPDE_AB(2, 4) GNPDE_AB(2, 8) GNPDE_AB(2, 16) GNPDE_AB(4, 4) GNPDE_AB(4, 8)
   GNPDE_AB(4, 16) GNPDE_AB(8, 4) GNPDE_AB(8, 8) GNPDE_AB(8, 16)
 #undef GNPDE_AB
@@ -706,5 +1162,5 @@ int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t
 
 extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
                                         int32_t scale_sigmoid, float* ds_csr, void* stream) {
-  return gnpde::launch_attention_rows_bwd_dq(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, static_cast<hipStream_t>(stream));
+  return gnpde::launch_attention_rows_bwd_dq(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
 }

@@ -150,12 +150,15 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
 // transposed graph, pos = its positions -> CSR positions of ds); rows without entries are not written
 bool head_rowsum_supported(int heads, int dk);
 int launch_head_rowsum(const gnpde_graph_t* g, const int* pos, const float* ds, int heads, int dk, const float* feat, int ldf,
-                       float scale, float* out, int ldo, hipStream_t s);
+                       float scale, float* out, int ldo, float* hub_ws, hipStream_t s);
+// scratch (floats) that lets the backward row passes spread the hub rows of `g` over the chip as 512-entry chunks (hub_ws; nullptr: one
+// workgroup per hub)
+size_t hub_bwd_workspace_floats(const gnpde_graph_t* g, int heads, int att_dim);
 
 // row softmax backward (ds) with the row-side head sum d q formed in the same kernel (backward.hip; heads * d_k <= 32)
 bool attention_rows_bwd_dq_supported(int heads, int dk);
 int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, hipStream_t s);
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s);
 
 // attention + aggregation of the short rows in one kernel (spmm.hip) and the hub-row weights it needs (attention.hip)
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,

@@ -100,7 +100,7 @@ def build_arrays_on_device(edge_index, n):
   out['bin_rows'] = fit(bins, 4 * max(n, 1))
   out['long_chunk_first'] = fit(chunk_ptr[which], nlc)
   counts = dict(n_long_rows=nlr, n_long_chunks=nlc, n_long_cols=int(long_cols.numel()), n_bin16=int(rows16.numel()),
-                n_bin64=int(rows64.numel()), max_row_len=int(deg.max()) if n > 0 and e > 0 else 0,
+                n_bin64=int(rows64.numel()), n_bin_le64=int((deg[rows64] <= 64).sum()) if rows64.numel() else 0, max_row_len=int(deg.max()) if n > 0 and e > 0 else 0,
                 max_col_len=int(cdeg.max()) if n > 0 and e > 0 else 0)
   return out, counts
 
@@ -160,6 +160,9 @@ class CSRGraph(object):
     s.n_long_cols, s.n_bin16, s.n_bin64 = self.n_long_cols, self.n_bin16, self.n_bin64
     rp, cp = host['rowptr'], host['cscptr']
     self.max_row_len = int((rp[1:] - rp[:-1]).max()) if self.n > 0 else 0
+    _lens = rp[1:] - rp[:-1]
+    self.n_bin_le64 = int(((_lens > 16) & (_lens <= 64)).sum()) if self.n > 0 else 0
+    s.n_bin_le64 = self.n_bin_le64
     self.max_col_len = int((cp[1:] - cp[:-1]).max()) if self.n > 0 else 0
     s.max_row_len, s.max_col_len = self.max_row_len, self.max_col_len
     for k in order + ['long_chunk_first']:
@@ -172,6 +175,7 @@ class CSRGraph(object):
     self.t, c = build_arrays_on_device(edge_index, self.n)
     self.n_long_rows, self.n_long_chunks, self.n_long_cols = c['n_long_rows'], c['n_long_chunks'], c['n_long_cols']
     self.n_bin16, self.n_bin64 = c['n_bin16'], c['n_bin64']
+    self.n_bin_le64 = c['n_bin_le64']
     self.max_row_len, self.max_col_len = c['max_row_len'], c['max_col_len']
     self.perm_long = self.t['perm'][:self.e].long()
     s = _lib.GraphStruct()
@@ -179,6 +183,7 @@ class CSRGraph(object):
     s.n_long_rows, s.n_long_chunks = self.n_long_rows, self.n_long_chunks
     s.n_long_cols, s.n_bin16, s.n_bin64 = self.n_long_cols, self.n_bin16, self.n_bin64
     s.max_row_len, s.max_col_len = self.max_row_len, self.max_col_len
+    s.n_bin_le64 = self.n_bin_le64
     for k, v in self.t.items():
       setattr(s, k, v.data_ptr())
     self.struct = s

@@ -128,6 +128,9 @@ typedef struct gnpde_graph {
   const int32_t* long_chunk_first;   /* [n_long_chunks] index of the first chunk of the same row */
   int32_t xcd_deal;                  /* how the aggregation launches deal the rows to the 8 XCDs (gnpde_xcd_row_map):
                                         GNPDE_XCD_CONTIGUOUS or GNPDE_XCD_HASHED; chosen per graph by whoever builds it */
+  int32_t n_bin_le64;                /* (ABI 3) how many records of the second degree class (17..GNPDE_LONG_ROW entries, longest
+                                        first) have at most 64 entries: they TRAIL that class, and the backward kernels give them a
+                                        one-pass launch of their own (one entry per lane); 0: the whole class in one launch */
 } gnpde_graph_t;
 
 /* gnpde_graph_t.xcd_deal.  CONTIGUOUS: XCD x takes the x-th eighth of the rows -- neighbouring rows share an XCD's L2, and the
