@@ -490,7 +490,9 @@ class ShardedSolver(object):
     if getattr(self.be, 'general', False):
       self.exchange(u)
       self.be.rhs_stage_general(u, x0, stage, group=self.group, **kw)
-    elif getattr(self.be, 'supports_split', False) and self.overlap:
+    elif getattr(self.be, 'supports_split', False) and self.overlap and (not u.is_cuda or dist.get_backend(self.group) == 'nccl'):
+      # (an asynchronous all-to-all of device tensors over gloo completes on gloo's own stream: wait() does not order it before
+      #  the boundary pass on the launch stream -- such groups take the blocking, host-staged exchange below)
       work = self.exchange(u, async_op=True)
       self.be.rhs_stage(u, x0, stage, part='interior', **kw)
       if work is not None:
@@ -522,6 +524,46 @@ class ShardedSolver(object):
         raise ValueError(method)
     self.y, self.ua = y, ua
     return y[:n]
+
+  def all_rows_rms(self, n_rows_total):
+    """rms over ALL rows of the partitioned state (torchdiffeq's default norm, misc.py _rms_norm), for tensors that hold this
+    rank's rows: the squares are summed in double per rank and added over the ranks -- every rank gets the same bits back from
+    the all-reduce, so every rank takes the same accept / reject decisions and step sizes."""
+    total = float(n_rows_total) * float(self.be.d)
+    group = self.group
+
+    def norm(v):
+      sq = v.double().pow(2).sum().reshape(1)
+      if self.shard.world > 1 or os.environ.get('GNPDE_FORCE_SHARDED', '0') == '1':
+        if sq.is_cuda and dist.get_backend(group) != 'nccl':
+          host = sq.cpu()
+          dist.all_reduce(host, group=group)
+          sq = host.to(v.device)
+        else:
+          dist.all_reduce(sq, group=group)
+      return (sq / total).sqrt().to(v.dtype)[0]
+    return norm
+
+  def integrate_adaptive(self, y_own, x0_own, t, rtol, atol, n_rows_total, method='dopri5', on_eval=None):
+    """torchdiffeq's adaptive embedded pairs (dopri5 / adaptive_heun, reference src/block_constant.py:57-62 with
+    opt['method'] = 'dopri5', the default of run_GNN.py) on the partitioned graph: the controller of odeint._solve_dopri5
+    (0.2.1's rule, float64 time) on every rank, one halo exchange + one fused evaluation per stage, and the error norm as the
+    one extra exchange step the adaptive method has -- an all-reduce of one double per trial step (all_rows_rms).
+    Returns the owned rows of y(t[-1])."""
+    from .odeint import _solve_dopri5
+    n = self.shard.n_own
+    u, kbuf = self.ua, self.ub
+    self.n_evals = 0
+
+    def f(tq, yo):
+      if on_eval is not None:
+        on_eval()
+      u[:n].copy_(yo)
+      self.evaluate(u, x0_own, _lib.STAGE_LINCOMB, out_k=kbuf)
+      self.n_evals += 1
+      return kbuf[:n].clone()
+    out = _solve_dopri5(f, y_own, t, rtol, atol, tableau=method, norm=self.all_rows_rms(n_rows_total))
+    return out[-1]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -787,8 +829,8 @@ class NativeShardedSolver(object):
 # the operator surface: ODEblock -> odeint -> here, when torch.distributed is initialised and sharding is requested
 # --------------------------------------------------------------------------------------------------
 def shard_requested(func):
-  """opt['gnpde_shard'] (or GNPDE_SHARD=1) with an initialised process group: the fixed-step solves of this function run
-  row-partitioned over the ranks of the default group (one process per GPU)."""
+  """opt['gnpde_shard'] (or GNPDE_SHARD=1) with an initialised process group: the solves of this function run row-partitioned
+  over the ranks of the default group (one process per GPU)."""
   if not (dist.is_available() and dist.is_initialized()):
     return False
   v = func.opt.get('gnpde_shard', os.environ.get('GNPDE_SHARD', '0'))
@@ -842,7 +884,7 @@ def _sharded_problem(func):
   raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc and ODEFuncTransformerAtt, not %s' % type(func).__name__)
 
 
-def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
+def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rtol=None, atol=None):
   """torchdiffeq.odeint(func, y0, t, method='euler'|'rk4') of a block of this package on a row-partitioned graph, one
   process per GPU: every rank calls with the SAME replicated y0 / func (as the reference's model is replicated by
   nn.DataParallel, src/ray_tune.py:65-66, which cannot split a full-graph model); the graph is partitioned once per
@@ -855,14 +897,18 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
   if func._needs_grad(y0):
     raise _lib.GnpdeError('sharded solve: inference only (no autograd through the partitioned solver); call under torch.no_grad()')
   dev, (n, d) = y0.device, y0.shape
-  grid = time_grid(t.detach().to('cpu'), step_size)
-  dts = tuple((grid[1:] - grid[:-1]).tolist())
-  n_evals = len(dts) * (4 if method == 'rk4' else 1)
-  room = func.opt['max_nfe'] + 1 - func.nfe
-  if n_evals > room:
-    func.nfe += max(room, 0)
-    from .utils import MaxNFEException
-    raise MaxNFEException
+  adaptive = method in ('dopri5', 'adaptive_heun')
+  if adaptive:
+    dts, n_evals = (), 0          # (evaluations are counted one by one, func._check_nfe, as on one GPU)
+  else:
+    grid = time_grid(t.detach().to('cpu'), step_size)
+    dts = tuple((grid[1:] - grid[:-1]).tolist())
+    n_evals = len(dts) * (4 if method == 'rk4' else 1)
+    room = func.opt['max_nfe'] + 1 - func.nfe
+    if n_evals > room:
+      func.nfe += max(room, 0)
+      from .utils import MaxNFEException
+      raise MaxNFEException
   kind, params = _sharded_problem(func)
   ei = func.edge_index
   st = func.__dict__.setdefault('_shard_state', {})
@@ -902,6 +948,24 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None):
   with_source = bool(func.opt['add_source'])
   skey = (method, dts, with_source)
   sol = ent['solvers'].get(skey)
+  if adaptive:
+    # dopri5 / adaptive_heun: the host controller over sharded evaluations (ShardedSolver.integrate_adaptive); the in-graph P2P
+    # solver is fixed-step
+    if sol is None:
+      for old in ent['solvers'].values():
+        if hasattr(old, 'close'):
+          old.close()
+      ent['solvers'].clear()
+      sol = ShardedSolver(shard, be, group)
+      ent['solvers'][skey] = sol
+    y_own = y0.detach()[ent['own_ids']]
+    x0_own = None
+    if with_source:
+      if func.x0 is None:
+        raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+      x0_own = func.x0.detach()[ent['own_ids']].contiguous()
+    z_own = sol.integrate_adaptive(y_own, x0_own, t, rtol, atol, n, method=method, on_eval=func._check_nfe).clone()
+    return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, 0)
   if getattr(be, 'general', False):
     if sol is None:
       ent['solvers'].clear()

@@ -496,9 +496,12 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
   if method in ('dopri5', 'adaptive_heun') and hasattr(func, '_descriptor'):
     from . import distributed as D
     if D.shard_requested(func):
+      # rows partitioned over the ranks; the controller runs on every rank over an all-reduced error norm
+      if _native_ok(func, y0, t):
+        return D.solve_sharded(func, y0, t, method, None, rtol=rtol, atol=atol)
       # (a replicated single-GPU solve on every rank would be a silent waste of N - 1 GPUs)
-      raise _lib.GnpdeError('gnpde_shard is set but the row-partitioned solver covers the fixed-step methods (euler, rk4) only; '
-                            'method=%r runs on one GPU -- unset gnpde_shard for it' % method)
+      raise _lib.GnpdeError('gnpde_shard is set but this %s solve cannot run row-partitioned (float32 [n, d] state on a HIP device, two '
+                            'output times, no autograd) -- unset gnpde_shard for it' % method)
   if method == 'dopri5':
     if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
       if options.get('eager_stages', False):      # controller on the host, one scalar read per trial step

@@ -79,6 +79,34 @@ def main():
     dist.destroy_process_group()
     assert same, 'rank %d: repeated solve differs' % rank
     return
+  if method in ('dopri5', 'adaptive_heun'):
+    # adaptive pair on the partitioned graph: host controller over the sharded HIP evaluations, error norm all-reduced; against
+    # the restated torchdiffeq 0.2.1 of oracle/shims over the CPU oracle on the whole graph (same evaluations, same state)
+    from oracle.shims import install as REF_TORCHDIFFEQ
+    rtol, atol = 1e-4, 1e-6
+    tt = torch.tensor([0.0, T])
+    with torch.no_grad():
+      solver = D.ShardedSolver(sh, be)
+      z1 = solver.integrate_adaptive(x_own, x_own, tt.to(dev), rtol, atol, n, method=method).clone()
+      evals = solver.n_evals
+      z2 = solver.integrate_adaptive(x_own, x_own, tt.to(dev), rtol, atol, n, method=method).clone()
+    assert torch.equal(z1, z2), 'rank %d: repeated adaptive solve differs' % rank
+    full = D.gather_rows_all(z1.cpu(), plan, sh)
+    if rank == 0:
+      calls = [0]
+
+      def rhs(t, y):
+        calls[0] += 1
+        if kind == 'laplacian':
+          return R.rhs_laplacian(y, ei, w, alpha, beta, x, False, True)
+        return R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta, x, False, True, **att_kw)
+      ref = REF_TORCHDIFFEQ.odeint(rhs, x, tt, method=method, options={}, rtol=rtol, atol=atol)[1]
+      e_inf, e_2 = parity(full, ref)
+      json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
+                 'interior_rows': sh.n_interior, 'own_rows': sh.n_own, 'evals': evals, 'ref_evals': calls[0]}, open(out_path, 'w'))
+    dist.barrier()
+    dist.destroy_process_group()
+    return
   ctx = D.P2PContext(sh, d, 4)
   with torch.no_grad():
     for use_graph in (False, True):

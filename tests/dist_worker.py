@@ -70,6 +70,8 @@ class OracleBackend(object):
       out_y[rows] = (2 * k1[rows] - un) + dt * k
     elif stage == _lib.STAGE_RK4C:
       out_y[rows] = ((6 * k1[rows] + 3 * un - y[rows]) + dt * k) * 0.125
+    elif stage == _lib.STAGE_LINCOMB:          # plain evaluation: k = f(u) (the adaptive solvers' stage call)
+      out_k[rows] = k
     else:
       raise ValueError(stage)
 
@@ -126,6 +128,38 @@ def main():
     if not (e_inf < 1e-5 and e_2 < 1e-5):
       ok = False
       print('rank %d %s %s: mismatch %g %g' % (rank, kind, method, e_inf, e_2))
+  # adaptive methods (dopri5 / adaptive_heun) on the partitioned graph: the product's host controller over the sharded
+  # evaluations with the all-reduced error norm, against the restated torchdiffeq 0.2.1 (oracle/shims) on the whole graph --
+  # same number of evaluations (= same accept / reject sequence) and the same state
+  from oracle.shims import install as REF_TORCHDIFFEQ
+  _, wfull = G.get_rw_adj(ei, None, norm_dim=0, fill_value=0.0, num_nodes=n, dtype=torch.float32)
+  for kind, method, T, rtol, atol in (('laplacian', 'dopri5', 2.5, 1e-4, 1e-6), ('transformer', 'dopri5', 1.5, 1e-5, 1e-7),
+                                      ('laplacian', 'adaptive_heun', 1.0, 1e-3, 1e-5)):
+    calls = [0]
+    if kind == 'laplacian':
+      p = dict(edge_weight=wfull[shard.edge_ids])
+
+      def rhs(t, y):
+        calls[0] += 1
+        return R.rhs_laplacian(y, ei, wfull, alpha, beta, x, False, True)
+    else:
+      p = params
+
+      def rhs(t, y):
+        calls[0] += 1
+        return R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta, x, False, True)
+    be = OracleBackend(shard, d, kind, p, alpha, beta)
+    solver = D.ShardedSolver(shard, be)
+    x_own = D.scatter_rows(x, shard)
+    tt = torch.tensor([0.0, T])
+    y_own = solver.integrate_adaptive(x_own, x_own, tt, rtol, atol, n, method=method)
+    y = D.gather_rows_all(y_own.clone(), plan, shard)
+    ref = REF_TORCHDIFFEQ.odeint(rhs, x, tt, method=method, options={}, rtol=rtol, atol=atol)[1]
+    e_inf, e_2 = R.parity_error(y, ref)
+    if not (e_inf < 1e-5 and e_2 < 1e-5 and solver.n_evals == calls[0] and solver.n_exchanges == calls[0]):
+      ok = False
+      print('rank %d %s %s: mismatch %g %g, evaluations %d vs %d, exchanges %d' % (rank, kind, method, e_inf, e_2, solver.n_evals,
+                                                                                   calls[0], solver.n_exchanges))
   if rank == 0 and ok:
     print('DIST_OK world=%d cut=%.3f halo=%d' % (world, plan.edge_cut(), shard.n_halo))
   dist.destroy_process_group()

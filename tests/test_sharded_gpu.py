@@ -114,7 +114,8 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
   reference-recorded fixtures, with the reference's NFE, every rank holding the whole result (tests/dist_block_worker.py)."""
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   out = str(tmp_path / 'blocks.json')
-  names = 'block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4'
+  names = ('block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4,'
+           'block_attention_laplacian_dopri5,block_constant_transformer_dopri5')
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
@@ -126,6 +127,23 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
     assert e['world'] == world and e['halo_rows'] > 0, e
     assert e['rel_max'] < 1e-5 and e['rel_l2'] < 1e-5, (name, e)
     assert e['nfe'] == e['ref_nfe'] and e['replay_equal'] and e['ranks_agree'], (name, e)
+
+
+@pytest.mark.parametrize('kind,method,T', [('laplacian', 'dopri5', 2.5), ('transformer', 'dopri5', 1.5), ('laplacian', 'adaptive_heun', 1.0)])
+def test_adaptive_methods_run_partitioned(dev, tmp_path, kind, method, T):
+  """dopri5 / adaptive_heun over the row partition (3 ranks sharing the GPU): every stage one halo exchange + one fused HIP
+  evaluation, the error norm all-reduced, torchdiffeq 0.2.1's controller on every rank -- the same number of evaluations (= the
+  same accept / reject sequence) and the same state as the restated torchdiffeq over the CPU oracle on the whole graph."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / 'result.json')
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+         '--master-port', '29670', os.path.join(root, 'tests', 'dist_gpu_worker.py'), out, kind, method, str(T)]
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  r = json.load(open(out))
+  assert r['world'] == 3 and r['halo_rows'] > 0 and r['evals'] == r['ref_evals'], r
+  assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
 
 
 def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
