@@ -51,7 +51,7 @@ class EpilogueStruct(ctypes.Structure):
 class AttentionStruct(ctypes.Structure):
   _fields_ = [('type', ctypes.c_int32), ('heads', ctypes.c_int32), ('att_dim', ctypes.c_int32),
               ('norm_idx', ctypes.c_int32), ('square_plus', ctypes.c_int32), ('leaky_slope', ctypes.c_float),
-              ('q', c_vp), ('k', c_vp), ('ldqk', ctypes.c_int32),
+              ('q', c_vp), ('k', c_vp), ('ldqk', ctypes.c_int32), ('n_key_rows', ctypes.c_int32),
               ('gat_a', c_vp), ('output_var', c_vp), ('lengthscale', c_vp), ('edge_w_csr', c_vp),
               ('graph_t', ctypes.POINTER(GraphStruct)), ('t_from_csr', c_vp)]
 

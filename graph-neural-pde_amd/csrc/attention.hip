@@ -867,14 +867,14 @@ struct AttLayout {
   size_t scores, seg_m, seg_den, gmax, gat, part, total;
 };
 // `long_slots` = (number of long segments) x (max chunks of one segment), an upper bound is fine
-AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots) {
+AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots, int key_rows = 0) {
   AttLayout L{};
   size_t off = 0;
   L.scores = off; off += align_up(static_cast<size_t>(e) * h * 4, 256);
   L.seg_m = off;  off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.gmax = off; off += 256;
-  L.gat = off; if (gat) off += align_up(static_cast<size_t>(n) * 2 * h * 4, 256);
+  L.gat = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 2 * h * 4, 256);   // (halo rows of a partitioned graph)
   L.part = off; off += align_up(long_slots * 2 * h * 4, 256);
   L.total = off;
   return L;
@@ -1062,7 +1062,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   const int* long_list = at->norm_idx == 0 ? g->long_rows : g->long_cols;
   const int max_len = at->norm_idx == 0 ? g->max_row_len : g->max_col_len;
   const int max_chunks = (max_len + GNPDE_LONG_ROW - 1) / GNPDE_LONG_ROW;
-  const AttLayout L = att_layout(g->n, g->e, at->heads, gat, long_slots_of(g));
+  const AttLayout L = att_layout(g->n, g->e, at->heads, gat, long_slots_of(g), at->n_key_rows);
   GNPDE_CHECK_ARG(ws && ws_bytes >= L.total, GNPDE_EWS, "edge_attention: workspace %zu < %zu bytes", ws_bytes, L.total);
   GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0, GNPDE_EINVAL, "edge_attention: workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
@@ -1090,9 +1090,10 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
 
   if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
   if (gat) {
-    const long long items = static_cast<long long>(g->n) * a.h;
+    const int term_rows = at->n_key_rows > g->n ? at->n_key_rows : g->n;      // every row a column may address
+    const long long items = static_cast<long long>(term_rows) * a.h;
     hipLaunchKernelGGL(gat_terms_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       at->q, at->ldqk, at->gat_a, g->n, a.h, a.dk, reinterpret_cast<float*>(base + L.gat));
+                       at->q, at->ldqk, at->gat_a, term_rows, a.h, a.dk, reinterpret_cast<float*>(base + L.gat));
     GNPDE_LAUNCH_CHECK();
   }
   const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
@@ -1439,6 +1440,10 @@ int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* a
   return 0;
 }
 
+size_t attention_workspace_bytes_rows(const gnpde_graph_t* g, int h, bool gat, int key_rows) {
+  return att_layout(g->n, g->e, h, gat, long_slots_of(g), key_rows).total;
+}
+
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
   return att_layout(g->n, g->e, h, gat, long_slots_of(g)).total;
 }
@@ -1447,7 +1452,7 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat) {
 
 extern "C" size_t gnpde_attention_workspace_bytes(const gnpde_graph_t* g, const gnpde_attention_t* a) {
   if (!g || !a || a->heads < 1) return 0;
-  return gnpde::attention_workspace_bytes(g, a->heads, a->type == GNPDE_ATT_GAT);
+  return gnpde::attention_workspace_bytes_rows(g, a->heads, a->type == GNPDE_ATT_GAT, a->n_key_rows);
 }
 
 extern "C" int gnpde_edge_attention_pass(const gnpde_graph_t* g, const gnpde_attention_t* a, int32_t pass, float* w_mean_csr,
@@ -1457,7 +1462,7 @@ extern "C" int gnpde_edge_attention_pass(const gnpde_graph_t* g, const gnpde_att
 
 extern "C" int gnpde_attention_workspace_regions(const gnpde_graph_t* g, const gnpde_attention_t* a, size_t* offsets) {
   GNPDE_CHECK_ARG(g && a && offsets && a->heads >= 1, GNPDE_EINVAL, "attention_workspace_regions: bad arguments");
-  const gnpde::AttLayout L = gnpde::att_layout(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT, gnpde::long_slots_of(g));
+  const gnpde::AttLayout L = gnpde::att_layout(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT, gnpde::long_slots_of(g), a->n_key_rows);
   offsets[0] = L.scores; offsets[1] = L.seg_m; offsets[2] = L.seg_den; offsets[3] = L.gmax;
   return 0;
 }

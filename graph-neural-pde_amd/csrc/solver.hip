@@ -18,6 +18,7 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
+size_t attention_workspace_bytes_rows(const gnpde_graph_t* g, int h, bool gat, int key_rows);
 size_t fused_attn_workspace_bytes(const gnpde_graph_t* g, int d, int heads);
 bool fused_attn_supported(const gnpde_attention_t& at, int d, int ld, const void* u, const gnpde_epilogue_t* epi);
 int launch_attn_rhs_fused(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* proj_w, const float* proj_b,
@@ -42,7 +43,7 @@ RhsLayout rhs_layout(const gnpde_rhs_t& r) {
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
     L.wmean = off; off += align_up(static_cast<size_t>(g.e) * 4, 256);
     L.att = off;
-    L.att_bytes = attention_workspace_bytes(&g, r.att.heads, r.kind == GNPDE_RHS_GAT);
+    L.att_bytes = attention_workspace_bytes_rows(&g, r.att.heads, r.kind == GNPDE_RHS_GAT, r.n_state_rows);
     off += align_up(L.att_bytes, 256);
     if (r.kind == GNPDE_RHS_TRANSFORMER) {
       L.fused = off;
@@ -96,6 +97,7 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     at.ldqk = r.proj_m;
     at.q = proj;
     at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
+    at.n_key_rows = r.n_state_rows > g->n ? r.n_state_rows : 0;     // halo rows: the GAT node terms cover them
     const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0;
     if (r.kind == GNPDE_RHS_TRANSFORMER && fork == nullptr && r.proj_row_end == 0 && r.n_state_rows <= g->n &&
         (r.d % 4 == 0 || padded) && attn_spmm_supported(g, at, r.d, r.ld, u, epi)) {

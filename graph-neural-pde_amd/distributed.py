@@ -218,7 +218,8 @@ def boundary_cuts(rows, n_interior, n_own, n_chunks):
 
 class NativeBackend(object):
   """f(u) with fused solver stage on the local shard.  kind = 'laplacian' (params: edge_weight over
-  the LOCAL edges) or 'transformer' (params: Wq, bq, Wk, bk, heads; scaled-dot, softmax over rows)."""
+  the LOCAL edges), 'transformer' (params: Wq, bq, Wk, bk, heads, att_type, norm_idx, square_plus) or 'gat' (params: W [A, d], a,
+  heads, leaky_slope, norm_idx)."""
 
   def __init__(self, shard, d, device, kind, params, alpha, beta, alpha_sigmoid=True):
     from . import ops
@@ -273,6 +274,25 @@ class NativeBackend(object):
         # the attention passes see ALL local nodes as segments (a halo column is a segment of attention_norm_idx = 1)
         self.g_att = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
         self.supports_split = False
+    elif kind == 'gat':
+      # GAT scores (reference src/function_GAT_attention.py:105-115): leaky_relu(a_src . Wx_i + a_dst . Wx_j) -- functions of the
+      # projected rows of the two end points, so the halo rows' projections are recomputed locally like the transformer's keys
+      self.wqk = params['W'].detach().to(self.dev, torch.float32).contiguous().clone()     # [A, d] (SpGraphAttentionLayer.proj_weight)
+      self.bqk = None
+      self.heads = int(params['heads'])
+      self.A = self.wqk.shape[0]
+      self.norm_idx = int(params.get('norm_idx', 0))
+      self.square_plus = False
+      self.general = self.norm_idx != 0
+      self.att_type, self.att_code = 'GAT', _lib.ATT_GAT
+      self.output_var = self.lengthscale = None
+      self.gat_a = params['a'].detach().to(self.dev, torch.float32).reshape(-1).clone()
+      self.leaky_slope = float(params.get('leaky_slope', 0.2))
+      att = ops.attention_struct(_lib.ATT_GAT, self.heads, self.A, 0, False, leaky_slope=self.leaky_slope, gat_a=self.gat_a)
+      self._kw = dict(kind=_lib.RHS_GAT, proj_w=self.wqk, proj_b=None, att=att)
+      if self.general:
+        self.g_att = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
+        self.supports_split = False
     else:
       raise ValueError(kind)
     self._desc = {}
@@ -317,6 +337,9 @@ class NativeBackend(object):
       for chunks in self.chunk_sets.values():
         for (_, _, g, eid, w) in chunks:
           self.ops.edge_to_csr_mean(g, ew[eid.to(self.dev)], out=w)
+    elif self.kind == 'gat':
+      self.wqk.copy_(params['W'].detach().to(self.dev, torch.float32))
+      self.gat_a.copy_(params['a'].detach().reshape(-1))
     else:
       self.wqk.copy_(torch.cat([params['Wq'], params['Wk']]).to(self.dev, torch.float32))
       self.bqk.copy_(torch.cat([params['bq'], params['bk']]).to(self.dev, torch.float32))
@@ -396,8 +419,12 @@ class NativeBackend(object):
       self._src, self._src_version = x0, x0._version
     h, A, n_own, n_loc = self.heads, self.A, sh.n_own, sh.n_local
     qk = ops.linear(u, self.wqk, self.bqk)                               # own AND halo rows (keys of halo rows recomputed locally)
-    st = ops.attention_struct(self.att_code, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A,
-                              output_var=self.output_var, lengthscale=self.lengthscale)
+    if self.kind == 'gat':
+      st = ops.attention_struct(_lib.ATT_GAT, h, A, self.norm_idx, False, q=qk, k=qk, ldqk=A, leaky_slope=self.leaky_slope,
+                                gat_a=self.gat_a)
+    else:
+      st = ops.attention_struct(self.att_code, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A,
+                                output_var=self.output_var, lengthscale=self.lengthscale)
     g = self.g_att
     ws = g.workspace('att', L.gnpde_attention_workspace_bytes(g.ref(), ctypes.byref(st)))
     offs = (ctypes.c_size_t * 4)()
@@ -881,7 +908,15 @@ def _sharded_problem(func):
     if o['attention_type'] == 'exp_kernel':
       p.update(output_var=lay.output_var.detach(), lengthscale=lay.lengthscale.detach())
     return 'transformer', p
-  raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc and ODEFuncTransformerAtt, not %s' % type(func).__name__)
+  from .function_GAT_attention import ODEFuncAtt
+  if isinstance(func, ODEFuncAtt):
+    if func.opt['mix_features']:
+      raise _lib.GnpdeError('the row-partitioned solver does not cover mix_features -- unset gnpde_shard')
+    lay = func.multihead_att_layer
+    return 'gat', dict(W=lay.proj_weight().detach(), a=lay.a.detach().reshape(-1), heads=lay.h, leaky_slope=float(lay.alpha),
+                       norm_idx=int(func.opt['attention_norm_idx']), square_plus=False, att_type='GAT')
+  raise _lib.GnpdeError('the row-partitioned solver covers LaplacianODEFunc, ODEFuncTransformerAtt and ODEFuncAtt, not %s'
+                        % type(func).__name__)
 
 
 def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rtol=None, atol=None):

@@ -286,6 +286,9 @@ typedef struct gnpde_attention {
   const float* q;            /* [n, ldqk] device: row-side projection (GAT: h = x W)           */
   const float* k;            /* [n, ldqk] device: column-side projection (GAT: same as q)      */
   int32_t ldqk;
+  int32_t n_key_rows;        /* rows of q / k the COLUMNS may address when that is more than the graph's n (a row-partitioned
+                              * graph's halo rows lie behind its row range); 0: n.  ABI 3, in what was padding.  The GAT node
+                              * terms (:111-114) are formed for all of them                    */
   const float* gat_a;        /* [2*d_k] device (GAT only)                                      */
   const float* output_var;   /* device scalar (exp_kernel)                                     */
   const float* lengthscale;  /* device scalar (exp_kernel)                                     */

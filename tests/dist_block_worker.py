@@ -16,7 +16,7 @@ import gnpde_amd as G  # noqa: E402
 from helpers import Fixture, Data, parity  # noqa: E402
 
 BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
-FUNCS = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc}
+FUNCS = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc, 'GAT': G.ODEFuncAtt}
 
 
 def main():

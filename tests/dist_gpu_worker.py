@@ -53,7 +53,14 @@ def main():
     p = dict(edge_weight=w[sh.edge_ids])
   else:
     p = dict(params, norm_idx=norm_idx, square_plus=square_plus)
-  be = D.NativeBackend(sh, d, dev, 'transformer' if (general or att_type != 'scaled_dot') else kind, p, alpha, beta, True)
+  gat = kind.startswith('gat')                        # gat (softmax over rows, in-graph P2P solver) / gat_n1 (over columns: general path)
+  if gat:
+    # reference src/function_GAT_attention.py: W [d, A], a [2 d_k, 1, 1]; the backend takes the row-major [A, d] copy the layer keeps
+    Wg = torch.randn(d, A, generator=g) / d ** 0.5
+    ag = torch.randn(2 * (A // h), 1, 1, generator=g) * 0.5
+    p = dict(W=Wg.t().contiguous(), a=ag.reshape(-1), heads=h, leaky_slope=0.2, norm_idx=norm_idx)
+    general = norm_idx != 0
+  be = D.NativeBackend(sh, d, dev, 'gat' if gat else ('transformer' if (general or att_type != 'scaled_dot') else kind), p, alpha, beta, True)
   x_own = D.scatter_rows(x, sh).to(dev)
   res = {}
   if general:
@@ -70,6 +77,8 @@ def main():
     if rank == 0:
       rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
                                            x, False, True, norm_idx=norm_idx, square_plus=square_plus)
+      if gat:
+        rhs = lambda t, y: R.rhs_gat(y, ei, Wg, ag, h, alpha, beta, x, False, True, 0.2, norm_idx)   # noqa: E731
       ref = R.odeint_fixed(rhs, x, T, 1.0, method)
       e_inf, e_2 = parity(full, ref)
       print('general %s: rel_max %g rel_l2 %g' % (kind, e_inf, e_2), flush=True)
@@ -99,6 +108,8 @@ def main():
         calls[0] += 1
         if kind == 'laplacian':
           return R.rhs_laplacian(y, ei, w, alpha, beta, x, False, True)
+        if gat:
+          return R.rhs_gat(y, ei, Wg, ag, h, alpha, beta, x, False, True, 0.2, norm_idx)
         return R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta, x, False, True, **att_kw)
       ref = REF_TORCHDIFFEQ.odeint(rhs, x, tt, method=method, options={}, rtol=rtol, atol=atol)[1]
       e_inf, e_2 = parity(full, ref)
@@ -153,6 +164,8 @@ def main():
   if rank == 0:
     if kind == 'laplacian':
       rhs = lambda t, y: R.rhs_laplacian(y, ei, w, alpha, beta, x, False, True)   # noqa: E731
+    elif gat:
+      rhs = lambda t, y: R.rhs_gat(y, ei, Wg, ag, h, alpha, beta, x, False, True, 0.2, norm_idx)   # noqa: E731
     else:
       rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
                                            x, False, True, **att_kw)

@@ -44,6 +44,7 @@ def test_structs_match_header_layout():
   assert _lib.GraphStruct.n_bin_le64.offset == _lib.GraphStruct.xcd_deal.offset + 4     # (ABI 3: in what was padding)
   assert ctypes.sizeof(_lib.EpilogueStruct) == 3 * 8 + 4 + 4 + 4 + 4 + 6 * 8 + 8 + 7 * 8 + 8 * 4 + 8
   assert ctypes.sizeof(_lib.AttentionStruct) == 24 + 8 + 8 + 8 + 4 * 8 + 2 * 8     # (+ graph_t, t_from_csr: ABI 3)
+  assert _lib.AttentionStruct.n_key_rows.offset == _lib.AttentionStruct.ldqk.offset + 4   # (ABI 3: in what was padding)
   assert ctypes.sizeof(_lib.DecoderStruct) == 4 * 8 + 2 * 4
 
 

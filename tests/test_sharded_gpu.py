@@ -115,7 +115,7 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   out = str(tmp_path / 'blocks.json')
   names = ('block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4,'
-           'block_attention_laplacian_dopri5,block_constant_transformer_dopri5')
+           'block_attention_laplacian_dopri5,block_constant_transformer_dopri5,block_constant_gat_rk4')
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
@@ -144,6 +144,26 @@ def test_adaptive_methods_run_partitioned(dev, tmp_path, kind, method, T):
   r = json.load(open(out))
   assert r['world'] == 3 and r['halo_rows'] > 0 and r['evals'] == r['ref_evals'], r
   assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
+
+
+@pytest.mark.parametrize('kind,method', [('gat', 'rk4'), ('gat_n1', 'rk4'), ('gat', 'dopri5')])
+def test_gat_function_runs_partitioned(dev, tmp_path, kind, method):
+  """ODEFuncAtt's right-hand side (reference src/function_GAT_attention.py:45-65, :105-115) over the row partition, 2 ranks sharing
+  the GPU: the projections of the halo rows are recomputed locally like the transformer's keys.  Softmax over rows: P2P transport
+  inside each rank's hipGraph; over columns (attention_norm_idx = 1): the loop with exchanges between the attention passes;
+  dopri5: the all-reduced error norm.  Against the unpartitioned CPU oracle."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / 'result.json')
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29693', os.path.join(root, 'tests', 'dist_gpu_worker.py'), out, kind, method, '2.0']
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  r = json.load(open(out))
+  assert r['world'] == 2 and r['halo_rows'] > 0
+  assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
+  if method == 'dopri5':
+    assert r['evals'] == r['ref_evals'], r
 
 
 def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
