@@ -133,6 +133,104 @@ __global__ __launch_bounds__(kBlock) void adjoint_gram_kernel(const ParamArgs p)
   if (wave == 0 && lane < mt) out[static_cast<size_t>(p.M) * p.d + m0 + lane] = ((bsum + bfold[0][lane]) + bfold[1][lane]) + bfold[2][lane];
 }
 
+// The same Gram block on the fp32 matrix cores (exact fp32 products and sums, as the projection of csrc/linear.hip).  The product
+// [M, n] x [n, d] has its K index along the ROWS of both operands, so the v_mfma_f32_16x16x4_f32 operand shapes are row-major memory
+// as it lies: lane (j = l & 15, kq = l >> 4) of a K step over rows i0..i0+3 reads row i0 + kq -- MV consecutive floats of dqk at
+// m = MV j (A operand of M tile jm: its component jm, i.e. m = MV j + jm) and one float4 of u_y per 64 columns at c = 64 g + 4 j
+// (B operand of N tile (g, jn): component jn, i.e. c = 64 g + 4 j + jn).  The tiles are therefore strided sets of m's / columns --
+// a permutation of the output, undone by the store.  Three loads feed 16 MFMAs (M = 32, d = 128); the VALU kernel above spends
+// 4096 FMAs per row on operands it reads once (42.7 us at the ogbn-arxiv shape; this one 28 us, profiles/r04_train_v8_*).
+// A wavefront owns every fourth K step of its slab; the four waves fold through the LDS in wave order.
+typedef float gram_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MV, int NG>
+__global__ __launch_bounds__(kBlock) void adjoint_gram_mfma_kernel(const ParamArgs p) {
+  constexpr int NT = NG * 4;                       // N tiles (16 columns each)
+  constexpr int KU = 4;                            // K steps (of 4 rows) in flight per wave
+  __shared__ gram_f32x4 fold[kWavesPerBlock][MV * NT][kWave];
+  __shared__ float bfold[kWavesPerBlock][MV][16];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int j = lane & 15, kq = lane >> 4;
+  const int r0 = static_cast<int>(blockIdx.x) * p.rows_per_block;
+  int r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  gram_f32x4 acc[MV][NT];
+#pragma unroll
+  for (int t = 0; t < MV; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[t][u] = gram_f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[MV];
+#pragma unroll
+  for (int t = 0; t < MV; ++t) bsum[t] = 0.f;
+  for (int i0 = r0 + 4 * wave; i0 < r1; i0 += 4 * KU * kWavesPerBlock) {
+    float av[KU][MV];
+    gram_f32x4 bv[KU][NG];
+#pragma unroll
+    for (int s = 0; s < KU; ++s) {
+      const int i = i0 + 4 * kWavesPerBlock * s + kq;
+      const bool live = i < r1;
+#pragma unroll
+      for (int t = 0; t < MV; ++t) av[s][t] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bv[s][g] = gram_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const float* qa = p.dqk + static_cast<size_t>(i) * p.M + MV * j;
+        if constexpr (MV == 1) av[s][0] = qa[0];
+        else if constexpr (MV == 2) { const float2 v = *reinterpret_cast<const float2*>(qa); av[s][0] = v.x; av[s][1] = v.y; }
+        else { const float4 v = *reinterpret_cast<const float4*>(qa); av[s][0] = v.x; av[s][1] = v.y; av[s][2] = v.z; av[s][3] = v.w; }
+        const float* xa = p.uy + static_cast<size_t>(i) * p.ld + 4 * j;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(xa + 64 * g);
+          bv[s][g] = gram_f32x4{v.x, v.y, v.z, v.w};
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KU; ++s) {
+#pragma unroll
+      for (int t = 0; t < MV; ++t) {
+        bsum[t] += av[s][t];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int jn = 0; jn < 4; ++jn)
+            acc[t][g * 4 + jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[s][g][jn], acc[t][g * 4 + jn], 0, 0, 0);
+      }
+    }
+  }
+  // column sums of dqk: the four row groups of a wave, then the waves
+#pragma unroll
+  for (int t = 0; t < MV; ++t) {
+    bsum[t] += __shfl_xor(bsum[t], 16, kWave);
+    bsum[t] += __shfl_xor(bsum[t], 32, kWave);
+    if (lane < 16) bfold[wave][t][lane] = bsum[t];
+  }
+#pragma unroll
+  for (int t = 0; t < MV; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) fold[wave][t * NT + u][lane] = acc[t][u];
+  __syncthreads();
+  float* out = p.partial + static_cast<size_t>(blockIdx.x) * p.stride;
+  // wave w folds the tiles q = w, w + 4, ...: C layout of a tile = (row 4 kq + i, column j)
+  for (int q = wave; q < MV * NT; q += kWavesPerBlock) {
+    const gram_f32x4 v = ((fold[0][q][lane] + fold[1][q][lane]) + fold[2][q][lane]) + fold[3][q][lane];
+    const int t = q / NT, u = q % NT;
+    const int c = 64 * (u / 4) + 4 * j + (u % 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = MV * (4 * kq + i) + t;
+      out[static_cast<size_t>(m) * p.d + c] = v[i];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+#pragma unroll
+    for (int t = 0; t < MV; ++t)
+      out[static_cast<size_t>(p.M) * p.d + MV * lane + t] = ((bfold[0][t][lane] + bfold[1][t][lane]) + bfold[2][t][lane]) + bfold[3][t][lane];
+  }
+}
+
 // partial[b][M d + M + {0, 1}] = sum of the per-wave dots w = b, b + nb, b + 2 nb, ... written by the row kernel of the stage
 // (launch_adjoint_rows): first level of the fold of sum u_a . F and sum u_a . x0, fixed order
 __global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* __restrict__ dots, int n_dots, int nb, float* __restrict__ partial,
@@ -386,6 +484,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     }
     rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
     if (rc) return rc;
+    // (measured and not adopted, profiles/r04_train_v7_* / v9_*: scattering w_t from the row kernel and ds in the transposed order from the
+    //  softmax backward -- 4- / 16-byte scattered stores cost more than these gathers, adjoint_rows +50 us, softmax backward +35 us against
+    //  -25 / -30 us; and running this permutation + the NEXT stage's attention as a parallel hipGraph branch beside the backward chain --
+    //  the overlapped kernels slow each other down by what the overlap hides, 0.82 ms per f + VJP either way)
     if (g->e > 0) {
       hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->w, s->t_from_csr, g->e, s->w_t);
       GNPDE_LAUNCH_CHECK();
@@ -407,7 +509,18 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   if (p.rows_per_block < 4) p.rows_per_block = 4;
   const int nb = (n + p.rows_per_block - 1) / p.rows_per_block;
   p.stride = s->stride; p.partial = s->partial;
-  if (nl) {
+  const bool gram_mfma = nl && (M == 16 || M == 32 || M == 64) && d % 64 == 0 && d <= 256 && d * (M / 16) <= 512 && ld % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(uy) % 16 == 0 && g_tune[GNPDE_TUNE_ADJOINT_GRAM] != 1;
+  if (gram_mfma) {
+#define GNPDE_GM(MVV, NGV) hipLaunchKernelGGL((adjoint_gram_mfma_kernel<MVV, NGV>), dim3(nb), dim3(kBlock), 0, st, p)
+    const int mv = M / 16, ng = d / 64;
+    if (mv == 1 && ng == 1) GNPDE_GM(1, 1); else if (mv == 1 && ng == 2) GNPDE_GM(1, 2); else if (mv == 1 && ng == 3) GNPDE_GM(1, 3);
+    else if (mv == 1 && ng == 4) GNPDE_GM(1, 4); else if (mv == 2 && ng == 1) GNPDE_GM(2, 1); else if (mv == 2 && ng == 2) GNPDE_GM(2, 2);
+    else if (mv == 2 && ng == 3) GNPDE_GM(2, 3); else if (mv == 2 && ng == 4) GNPDE_GM(2, 4); else if (mv == 4 && ng == 1) GNPDE_GM(4, 1);
+    else GNPDE_GM(4, 2);
+#undef GNPDE_GM
+    GNPDE_LAUNCH_CHECK();
+  } else if (nl) {
     const unsigned gy = static_cast<unsigned>((M + kGramTile - 1) / kGramTile);
     if (d <= 64) hipLaunchKernelGGL(adjoint_gram_kernel<1>, dim3(nb, gy), dim3(kBlock), 0, st, p);
     else if (d <= 128) hipLaunchKernelGGL(adjoint_gram_kernel<2>, dim3(nb, gy), dim3(kBlock), 0, st, p);

@@ -58,6 +58,12 @@ CASES = {
   'nl_heads8_dk16': dict(attention_dim=128, heads=8, hidden_dim=80),
   'nl_d162_padded': dict(hidden_dim=162, attention_dim=32, heads=2),
   'nl_d256': dict(hidden_dim=256, attention_dim=64, heads=4, time=2.0),
+  # weight gradients on the matrix cores (adjoint_gram_mfma_kernel: 2 A in {16, 32, 64}, d a multiple of 64)
+  'nl_d128_mfma': dict(hidden_dim=128, attention_dim=16, heads=4),                      # the ogbn-arxiv shape: <2, 2>
+  'nl_d64_m16_mfma': dict(hidden_dim=64, attention_dim=8, heads=2, time=2.3),           # <1, 1>, short last step
+  'nl_d128_m64_mfma': dict(hidden_dim=128, attention_dim=32, heads=2),                  # <4, 2>
+  'nl_d192_mfma': dict(hidden_dim=192, attention_dim=16, heads=4, add_source=False),    # <2, 3>
+  'nl_d256_m16_mfma': dict(hidden_dim=256, attention_dim=8, heads=1, time=2.0),         # <1, 4>
   'l_rk4': dict(function='laplacian'),
   'l_euler': dict(function='laplacian', adjoint_method='euler', adjoint_step_size=1.0),
   'l_attention_block': dict(function='laplacian', block='attention'),
@@ -67,8 +73,8 @@ CASES = {
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_native_adjoint_matches_stage_loop(dev, case):
   opt = _opt(**CASES[case])
-  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
-  n = 700
+  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16', 'nl_d128_mfma') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
+  n = 21000 if case == 'nl_d128_mfma' else 700       # (21000 rows: 42-row slabs -- several K steps per wave, ragged last steps)
   ei = random_graph(n, 6, seed=11, hubs=hubs, hub_deg=700, isolated=3, dup=20).to(dev)
   x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(3))).to(dev)
   z_h, gx_h, gp_h, native_h, nfe_h = _run(dev, opt, ei, x, 5, host=True)
