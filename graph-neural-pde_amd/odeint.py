@@ -7,6 +7,8 @@ package's ODEFunc objects run as ONE native solver object whose whole time loop 
 hipGraph (csrc/solver.hip).  Everything else (dopri5, foreign callables, several output times) runs
 the host loops below, which still evaluate f through the native kernels."""
 import math
+import os
+
 import torch
 
 from . import _lib
@@ -427,6 +429,8 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
     # launch-bound sizes: keep the queue full between reads; large states: a read per trial step costs nothing next to six
     # evaluations and nothing is replayed past the end point
     trials_per_sync = 8 if y0c.numel() < (1 << 22) else 1
+    if os.environ.get('GNPDE_DOPRI5_TRIALS_PER_SYNC'):          # A/B runs
+      trials_per_sync = max(1, int(os.environ['GNPDE_DOPRI5_TRIALS_PER_SYNC']))
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
   out[0].copy_(y0c)
   if view is None:
