@@ -44,7 +44,7 @@ for v in "--norm-idx 1" "--square-plus" "--norm-idx 1 --square-plus"; do
 done
 timeout 500 $B --graph rmat --steps 8 --warmup 1 --no-live-pmc --no-hbm-probe > "$OUT/bench_rmat_steps8.json" 2> "$OUT/bench_rmat.err"
 prof rmat_steps2 $B --graph rmat --steps 2 --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1
-timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc $?" >> "$OUT/pytest_gpu.log"
 tail -3 "$OUT/pytest_gpu.log"
 for f in bench_default_steps20 bench_steps100 bench_train bench_c4 bench_cora_laplacian bench_cora_transformer bench_cora_transformer_as_run bench_rmat_steps8 "bench_arxiv--norm-idx_1" "bench_arxiv--square-plus" "bench_arxiv--norm-idx_1_--square-plus"; do
