@@ -899,10 +899,21 @@ def _sharded_problem(func):
     return 'laplacian', dict(edge_weight=w.detach())
   if isinstance(func, ODEFuncTransformerAtt):
     o, lay = func.opt, func.multihead_att_layer
-    if (o['attention_type'] not in _lib.ATT_TYPES or o['reweight_attention'] or getattr(lay, 'split_kernel', False) or o['mix_features']):
+    if (o['attention_type'] not in _lib.ATT_TYPES or o['reweight_attention'] or o['mix_features']):
       raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with the scaled_dot / cosine_sim / pearson / exp_kernel '
-                            'scores (softmax or squareplus, over rows or columns; no reweighting / beltrami split kernel); this '
+                            'scores incl. the beltrami split kernel (softmax or squareplus, over rows or columns; no reweighting); this '
                             'configuration runs on one GPU only -- unset gnpde_shard')
+    if getattr(lay, 'split_kernel', False):
+      # BLEND's feature x positional kernel (reference src/function_transformer_attention.py:133-171) runs as ONE exp_kernel over the
+      # concatenated, length-scaled projections (SpGraphTransAttentionLayer._split_qk_weights): heads of width 2 d_k, output_var =
+      # ov_x ov_p, lengthscale 1 -- for the partitioned evaluation just another (W, b) pair
+      wqk, bqk = lay.qk_weights()
+      A2 = lay.kernel_att_dim
+      ent = lay._bufs['qk']
+      p = dict(Wq=wqk[:A2].detach(), bq=bqk[:A2].detach(), Wk=wqk[A2:].detach(), bk=bqk[A2:].detach(), heads=lay.h,
+               norm_idx=int(o['attention_norm_idx']), square_plus=bool(o['square_plus']), att_type='exp_kernel',
+               output_var=ent[3].detach(), lengthscale=ent[4].detach())
+      return 'transformer', p
     p = dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(), bk=lay.K.bias.detach(), heads=lay.h,
              norm_idx=int(o['attention_norm_idx']), square_plus=bool(o['square_plus']), att_type=o['attention_type'])
     if o['attention_type'] == 'exp_kernel':

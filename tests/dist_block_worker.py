@@ -27,6 +27,42 @@ def main():
   torch.cuda.set_device(dev)
   res = {}
   for name in names:
+    if name.startswith('selfcheck:'):
+      # a FUNCTION fixture (reference parameters, state and graph) integrated by the constant block: the partitioned solve against the
+      # unpartitioned solve of this package (which the reference-recorded fixtures pin) -- for functions without a recorded block solve
+      fx = Fixture(name[len('selfcheck:'):])
+      x = fx.t('x', dev)
+      opt = dict(fx.opt, block='constant', method='rk4', time=2.3, step_size=1.0)
+      block = G.ConstantODEblock(FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev)), dev,
+                                 t=torch.tensor([0, opt['time']])).to(dev)
+      missing, unexpected = block.load_state_dict({'odefunc.' + k: v for k, v in fx.params.items()}, strict=False)
+      assert not unexpected and all(k.startswith('reg_odefunc.') for k in missing), (missing, unexpected)
+      block.eval()
+      with torch.no_grad():
+        block.set_x0(x)
+        z_one = block(x)                                     # no request: one GPU
+        nfe_one = block.odefunc.nfe
+        block.odefunc.opt = dict(block.odefunc.opt, gnpde_shard=1)
+        block.odefunc.nfe = 0
+        block.set_x0(x)
+        z = block(x)
+        nfe = block.odefunc.nfe
+        block.set_x0(x)
+        z2 = block(x)
+      e_inf, e_2 = parity(z, z_one)
+      ent = next(iter(block.odefunc._shard_state.values()))
+      sh = ent['shard']
+      mine = z.cpu()
+      allz = [torch.empty_like(mine) for _ in range(world)]
+      dist.all_gather(allz, mine)
+      res[name] = dict(rel_max=e_inf, rel_l2=e_2, nfe=nfe, ref_nfe=nfe_one, replay_equal=bool(torch.equal(z, z2)),
+                       ranks_agree=all(torch.equal(a, mine) for a in allz), own_rows=sh.n_own, halo_rows=sh.n_halo, world=world,
+                       moved=float((z_one - x).abs().max()))
+      dist.barrier()
+      for e in block.odefunc._shard_state.values():
+        e['close']()
+      block.odefunc._shard_state.clear()
+      continue
     fx = Fixture(name)
     x = fx.t('x', dev)
     opt = dict(fx.opt, gnpde_shard=1)

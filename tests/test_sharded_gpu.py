@@ -115,7 +115,9 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   out = str(tmp_path / 'blocks.json')
   names = ('block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4,'
-           'block_attention_laplacian_dopri5,block_constant_transformer_dopri5,block_constant_gat_rk4')
+           'block_attention_laplacian_dopri5,block_constant_transformer_dopri5,block_constant_gat_rk4,block_attention_laplacian_beltrami_rk4,'
+           # BLEND's split feature x positional kernel as a per-evaluation attention (no recorded block solve: against the one-GPU solve)
+           'selfcheck:func_transformer_beltrami_expkernel,selfcheck:func_transformer_beltrami_expkernel_sqp')
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
@@ -127,6 +129,7 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
     assert e['world'] == world and e['halo_rows'] > 0, e
     assert e['rel_max'] < 1e-5 and e['rel_l2'] < 1e-5, (name, e)
     assert e['nfe'] == e['ref_nfe'] and e['replay_equal'] and e['ranks_agree'], (name, e)
+    assert e.get('moved', 1.0) > 1e-3, (name, e)       # (self-checks: the solve did something)
 
 
 @pytest.mark.parametrize('kind,method,T', [('laplacian', 'dopri5', 2.5), ('transformer', 'dopri5', 1.5), ('laplacian', 'adaptive_heun', 1.0)])
