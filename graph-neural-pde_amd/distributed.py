@@ -270,10 +270,21 @@ class NativeBackend(object):
         self.lengthscale = params['lengthscale'].detach().to(self.dev, torch.float32).reshape(-1).clone()
       att = ops.attention_struct(self.att_code, self.heads, self.A, 0, False, output_var=self.output_var, lengthscale=self.lengthscale)
       self._kw = dict(kind=_lib.RHS_TRANSFORMER, proj_w=self.wqk, proj_b=self.bqk, att=att)
+      # opt['reweight_attention'] (reference src/function_transformer_attention.py:208-209): the scores of an entry times the weight of
+      # its edge -- row-local data, every view of the local graph gets the weights of ITS entries in ITS CSR order
+      self.reweight = None
+      if params.get('edge_weight') is not None:
+        ew = params['edge_weight'].detach().to(self.dev, torch.float32)
+        self._edge_weight = ew
+        self.reweight = {None: ops.edge_to_csr_mean(self.graph, ew),
+                         'interior': ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)]),
+                         'boundary': ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)])}
       if self.general:
         # the attention passes see ALL local nodes as segments (a halo column is a segment of attention_norm_idx = 1)
         self.g_att = CSRGraph(shard.edge_index, shard.n_local, device=self.dev)
         self.supports_split = False
+        if self.reweight is not None:
+          self.reweight['att'] = ops.edge_to_csr_mean(self.g_att, self._edge_weight)
     elif kind == 'gat':
       # GAT scores (reference src/function_GAT_attention.py:105-115): leaky_relu(a_src . Wx_i + a_dst . Wx_j) -- functions of the
       # projected rows of the two end points, so the halo rows' projections are recomputed locally like the transformer's keys
@@ -317,7 +328,7 @@ class NativeBackend(object):
       g.set_row_range(lo, hi)
       eid = torch.nonzero(m).flatten()
       w = None
-      if self.kind == 'laplacian':
+      if self.kind == 'laplacian' or getattr(self, 'reweight', None) is not None:
         w = self.ops.edge_to_csr_mean(g, self._edge_weight[eid.to(self.dev)])
       chunks.append((lo, hi, g, eid, w))
     self.chunk_sets[int(n_chunks)] = chunks
@@ -359,6 +370,10 @@ class NativeBackend(object):
       # ('chunk', k, c): the c-th of the k row ranges of the boundary rows (split_boundary)
       chunk, chunks = (part[2], self.chunk_sets[part[1]]) if isinstance(part, tuple) else (None, None)
       graph = chunks[chunk][2] if chunk is not None else {None: self.graph, 'interior': self.g_int, 'boundary': self.g_bnd}[part]
+      if kind != _lib.RHS_LAPLACIAN and getattr(self, 'reweight', None) is not None:
+        rw = chunks[chunk][4] if chunk is not None else self.reweight[part]
+        kw['att'] = self.ops.attention_struct(self.att_code, self.heads, self.A, 0, False, output_var=self.output_var,
+                                              lengthscale=self.lengthscale, edge_w_csr=rw)
       if kind == _lib.RHS_LAPLACIAN:
         kw['w_csr'] = chunks[chunk][4] if chunk is not None else {None: self.w_csr, 'interior': self.w_int, 'boundary': self.w_bnd}[part]
       elif chunk is not None:
@@ -424,7 +439,8 @@ class NativeBackend(object):
                                 gat_a=self.gat_a)
     else:
       st = ops.attention_struct(self.att_code, h, A, self.norm_idx, self.square_plus, q=qk, k=qk[:, A:], ldqk=2 * A,
-                                output_var=self.output_var, lengthscale=self.lengthscale)
+                                output_var=self.output_var, lengthscale=self.lengthscale,
+                                edge_w_csr=self.reweight['att'] if self.reweight is not None else None)
     g = self.g_att
     ws = g.workspace('att', L.gnpde_attention_workspace_bytes(g.ref(), ctypes.byref(st)))
     offs = (ctypes.c_size_t * 4)()
@@ -899,10 +915,11 @@ def _sharded_problem(func):
     return 'laplacian', dict(edge_weight=w.detach())
   if isinstance(func, ODEFuncTransformerAtt):
     o, lay = func.opt, func.multihead_att_layer
-    if (o['attention_type'] not in _lib.ATT_TYPES or o['reweight_attention'] or o['mix_features']):
+    if (o['attention_type'] not in _lib.ATT_TYPES or o['mix_features']):
       raise _lib.GnpdeError('the row-partitioned solver covers GRAND-l and GRAND-nl with the scaled_dot / cosine_sim / pearson / exp_kernel '
-                            'scores incl. the beltrami split kernel (softmax or squareplus, over rows or columns; no reweighting); this '
-                            'configuration runs on one GPU only -- unset gnpde_shard')
+                            'scores incl. the beltrami split kernel (softmax or squareplus, over rows or columns, re-weighted or not), '
+                            'not mix_features; this configuration runs on one GPU only -- unset gnpde_shard')
+    rw = lay.edge_weights.detach() if (o['reweight_attention'] and lay.edge_weights is not None) else None
     if getattr(lay, 'split_kernel', False):
       # BLEND's feature x positional kernel (reference src/function_transformer_attention.py:133-171) runs as ONE exp_kernel over the
       # concatenated, length-scaled projections (SpGraphTransAttentionLayer._split_qk_weights): heads of width 2 d_k, output_var =
@@ -912,12 +929,13 @@ def _sharded_problem(func):
       ent = lay._bufs['qk']
       p = dict(Wq=wqk[:A2].detach(), bq=bqk[:A2].detach(), Wk=wqk[A2:].detach(), bk=bqk[A2:].detach(), heads=lay.h,
                norm_idx=int(o['attention_norm_idx']), square_plus=bool(o['square_plus']), att_type='exp_kernel',
-               output_var=ent[3].detach(), lengthscale=ent[4].detach())
+               output_var=ent[3].detach(), lengthscale=ent[4].detach(), edge_weight=rw)
       return 'transformer', p
     p = dict(Wq=lay.Q.weight.detach(), bq=lay.Q.bias.detach(), Wk=lay.K.weight.detach(), bk=lay.K.bias.detach(), heads=lay.h,
              norm_idx=int(o['attention_norm_idx']), square_plus=bool(o['square_plus']), att_type=o['attention_type'])
     if o['attention_type'] == 'exp_kernel':
       p.update(output_var=lay.output_var.detach(), lengthscale=lay.lengthscale.detach())
+    p['edge_weight'] = rw
     return 'transformer', p
   from .function_GAT_attention import ODEFuncAtt
   if isinstance(func, ODEFuncAtt):
@@ -959,7 +977,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
   ei = func.edge_index
   st = func.__dict__.setdefault('_shard_state', {})
   key = (id(ei), ei._version, tuple(ei.shape), world, rank, d, kind, str(dev), params.get('norm_idx', 0), params.get('square_plus', False),
-         params.get('att_type', ''))
+         params.get('att_type', ''), params.get('edge_weight') is not None)
   ent = st.get(key)
   if ent is None:
     for old in st.values():
@@ -969,7 +987,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
     plan = PartitionPlan.search(ei, n, world, rank=rank, group_size=world, per_rank=per_rank, group=group)
     shard = plan.shard(rank)
     local = dict(params)
-    if kind == 'laplacian':
+    if params.get('edge_weight') is not None:
       local['edge_weight'] = params['edge_weight'][shard.edge_ids.to(params['edge_weight'].device)]
     be = NativeBackend(shard, d, dev, kind, local, func.alpha_train, func.beta_train, not func.opt['no_alpha_sigmoid'])
     # normalisers that are not row-local (attention_norm_idx 1, squareplus) exchange BETWEEN the attention passes: they run the
@@ -988,7 +1006,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
     st[key] = ent
   plan, shard, be = ent['plan'], ent['shard'], ent['be']
   local = dict(params)
-  if kind == 'laplacian':
+  if params.get('edge_weight') is not None:
     local['edge_weight'] = params['edge_weight'][shard.edge_ids.to(params['edge_weight'].device)]
   be.refresh(func.alpha_train, func.beta_train, local)
   with_source = bool(func.opt['add_source'])

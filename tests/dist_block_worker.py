@@ -27,13 +27,20 @@ def main():
   torch.cuda.set_device(dev)
   res = {}
   for name in names:
-    if name.startswith('selfcheck:'):
+    if name.startswith('selfcheck:') or name.startswith('selfcheck_rw:'):
       # a FUNCTION fixture (reference parameters, state and graph) integrated by the constant block: the partitioned solve against the
       # unpartitioned solve of this package (which the reference-recorded fixtures pin) -- for functions without a recorded block solve
-      fx = Fixture(name[len('selfcheck:'):])
+      fx = Fixture(name.split(':', 1)[1])
       x = fx.t('x', dev)
       opt = dict(fx.opt, block='constant', method='rk4', time=2.3, step_size=1.0)
-      block = G.ConstantODEblock(FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev)), dev,
+      edge_attr = None
+      if name.startswith('selfcheck_rw:'):
+        # opt['reweight_attention'] with a weighted edge list (reference src/function_transformer_attention.py:208-209: the scores
+        # times the edge weights; the one-GPU path is pinned by the reference-recorded `layer_reweight` fixture)
+        opt['reweight_attention'] = True
+        E = fx.t('edge_index').shape[1]
+        edge_attr = (0.5 + torch.rand(E, generator=torch.Generator().manual_seed(17))).to(dev)
+      block = G.ConstantODEblock(FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev), edge_attr), dev,
                                  t=torch.tensor([0, opt['time']])).to(dev)
       missing, unexpected = block.load_state_dict({'odefunc.' + k: v for k, v in fx.params.items()}, strict=False)
       assert not unexpected and all(k.startswith('reg_odefunc.') for k in missing), (missing, unexpected)

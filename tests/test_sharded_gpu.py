@@ -117,7 +117,9 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
   names = ('block_constant_transformer_rk4,block_constant_laplacian_euler,block_attention_laplacian_euler,block_constant_transformer_sqp_n1_rk4,'
            'block_attention_laplacian_dopri5,block_constant_transformer_dopri5,block_constant_gat_rk4,block_attention_laplacian_beltrami_rk4,'
            # BLEND's split feature x positional kernel as a per-evaluation attention (no recorded block solve: against the one-GPU solve)
-           'selfcheck:func_transformer_beltrami_expkernel,selfcheck:func_transformer_beltrami_expkernel_sqp')
+           'selfcheck:func_transformer_beltrami_expkernel,selfcheck:func_transformer_beltrami_expkernel_sqp,'
+           # re-weighted attention (edge_attr data): row softmax in the in-graph solver, column softmax in the exchange loop
+           'selfcheck_rw:func_transformer_sd_softmax_n0,selfcheck_rw:func_transformer_sd_softmax_n1')
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
