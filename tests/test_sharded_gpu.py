@@ -172,7 +172,7 @@ def test_gat_function_runs_partitioned(dev, tmp_path, kind, method):
 
 
 def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
-  """gnpde_shard on a configuration the partitioned solver does not cover (re-weighted attention)
+  """gnpde_shard on a configuration the partitioned solver does not cover (mix_features)
   raises instead of silently running on one GPU; without a process group the request is ignored (single-GPU solve)."""
   import torch.distributed as dist
   from helpers import Fixture, Data
@@ -192,7 +192,7 @@ def test_sharding_request_without_a_supported_configuration_fails_loudly(dev):
   os.environ.setdefault('MASTER_PORT', '29677')
   dist.init_process_group('gloo', rank=0, world_size=1)
   try:
-    block.odefunc.opt = dict(block.odefunc.opt, reweight_attention=True)         # not covered by the partitioned solver
+    block.odefunc.opt = dict(block.odefunc.opt, mix_features=True)               # not covered by the partitioned solver
     block.set_x0(x)
     with torch.no_grad(), pytest.raises(_lib.GnpdeError):
       block(x)
