@@ -18,6 +18,7 @@ LONG_ROW = 512
 STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 STAGE_RK1C, STAGE_RK2C, STAGE_RK3C, STAGE_RK4C = range(6, 10)
 STAGE_LINCOMB = 10
+ABI_VERSION = 3      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4 = range(2)
@@ -229,8 +230,9 @@ def lib():
       fn = getattr(handle, name)
       fn.restype = res
       fn.argtypes = args
-    if handle.gnpde_abi_version() != 3:
-      raise RuntimeError('libgnpde_hip.so ABI version mismatch')
+    if handle.gnpde_abi_version() != ABI_VERSION:
+      raise RuntimeError('libgnpde_hip.so ABI version mismatch: the library says %d, this package was written for %d -- rebuild '
+                         '(python -c "import __graft_entry__ as g; g.build()")' % (handle.gnpde_abi_version(), ABI_VERSION))
     _lib = handle
   return _lib
 

@@ -26,7 +26,18 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), 'libgnpde_hip.so does not export %s' % name
   assert declared == set(_lib.PROTOTYPES), 'ctypes prototypes out of sync with gnpde.h'
-  assert G.lib().gnpde_abi_version() == 3
+  # one ABI number in three places: the header, the library built from it, the Python side's struct layouts
+  in_header = int(re.search(r'#define\s+GNPDE_ABI_VERSION\s+(\d+)', header).group(1))
+  assert G.lib().gnpde_abi_version() == in_header == _lib.ABI_VERSION
+
+
+def test_driver_build_hook_passes():
+  """__graft_entry__.build() -- the driver's "does it build" check -- compiles what changed, loads the library and agrees with it
+  on the ABI version (a hard-coded number there went stale once)."""
+  import __graft_entry__ as entry
+  entry.build()
+  src = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+  assert not re.search(r'gnpde_abi_version\(\)\s*==\s*\d', src), 'compare with _lib.ABI_VERSION, not a literal'
 
 
 def test_every_entry_point_is_documented():
