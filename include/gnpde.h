@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 #define GNPDE_ABI_VERSION 3   /* 2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
-                                 gnpde_adjoint_*, gnpde_stream_read */
+                                 gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
+                                 padding (struct sizes unchanged) */
 
 #define GNPDE_EINVAL   (-1)  /* bad argument                                  */
 #define GNPDE_ESHAPE   (-2)  /* shape not supported by any kernel variant     */
