@@ -84,8 +84,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- pass 0 (GAT): per-node terms  src[i,h] = sum_c a[c] h_i[c,head],  dst[i,h] = sum_c a[d_k+c] h_i[c,head]
+// `table` (optional, [n, 8h]): the same terms as 4-wide query / key vectors for the scaled-dot row kernels --
+//   q_i[head] = (2 src, 2, 0, 0),  k_j[head] = (1, dst, 0, 0):  q . k / sqrt(4) = src_i + dst_j  (bit for bit: 2 src and 2 dst are
+//   exact, their sum is rounded once, halving is exact), so GAT's row softmax rides row_attention_sd_kernel (MODE 3: leaky ReLU on the
+//   score) instead of the generic row kernel + separate hub launches: 103 -> 47 us of attention per evaluation at the ogbn-arxiv shape
 __global__ __launch_bounds__(kBlock) void gat_terms_kernel(const float* __restrict__ wx, int ld, const float* __restrict__ a,
-                                                          int n, int h, int dk, float* __restrict__ terms) {
+                                                          int n, int h, int dk, float* __restrict__ terms, float* __restrict__ table) {
   const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (idx >= static_cast<long long>(n) * h) return;
   const int i = static_cast<int>(idx / h), head = static_cast<int>(idx % h);
@@ -98,6 +102,11 @@ __global__ __launch_bounds__(kBlock) void gat_terms_kernel(const float* __restri
   }
   terms[static_cast<size_t>(i) * 2 * h + head] = s;
   terms[static_cast<size_t>(i) * 2 * h + h + head] = t;
+  if (table != nullptr) {
+    float* row = table + static_cast<size_t>(i) * 8 * h;
+    *reinterpret_cast<float4*>(row + 4 * head) = make_float4(2.0f * s, 2.0f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(row + 4 * h + 4 * head) = make_float4(1.0f, t, 0.f, 0.f);
+  }
 }
 
 // score of one (edge, head): q-slice of the row node against k-slice of the column node
@@ -434,6 +443,7 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
     sv[i] = -INFINITY;
     if (cols[i] >= 0) {
       sv[i] = edge_score<TYPE, VEC4>(a, p, row, cols[i], head);
+      if constexpr (MODE == 3) sv[i] = sv[i] > 0.f ? sv[i] : sv[i] * a.leaky_slope;
       a.scores[static_cast<size_t>(p) * H + head] = sv[i];
       mx = fmaxf(mx, sv[i]);
     }
@@ -730,6 +740,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
           // (this kernel is bound by VALU issue, not by memory: ~580 wave instructions per 4 rows, a fifth of them the IEEE
           //  division sequences and the full-range expf -- round 3: exact power-of-two scale, one reciprocal per row, v_exp)
           float sv = dot * a.scale_mul;
+          if constexpr (MODE == 3) sv = sv > 0.f ? sv : sv * a.leaky_slope;      // GAT: the vectors are gat_terms_kernel's table
           if (a.edge_w != nullptr) sv = sv * a.edge_w[e < e1[r] ? e : e1[r] - 1];
           if constexpr (MODE == 2) {
             if (live[r] && e < e1[r]) a.scores[static_cast<size_t>(e) * H + head] = sv;     // kept for the second sweep
@@ -864,7 +875,7 @@ inline size_t long_slots_of(const gnpde_graph_t* g) {
 }
 
 struct AttLayout {
-  size_t scores, seg_m, seg_den, gmax, gat, part, total;
+  size_t scores, seg_m, seg_den, gmax, gat, gat_table, part, total;
 };
 // `long_slots` = (number of long segments) x (max chunks of one segment), an upper bound is fine
 AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots, int key_rows = 0) {
@@ -875,6 +886,7 @@ AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots, int key_r
   L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.gmax = off; off += 256;
   L.gat = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 2 * h * 4, 256);   // (halo rows of a partitioned graph)
+  L.gat_table = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 8 * h * 4, 256);
   L.part = off; off += align_up(long_slots * 2 * h * 4, 256);
   L.total = off;
   return L;
@@ -924,6 +936,10 @@ template <int H, int DK4>
 void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
                     const int* chunk_first = nullptr) {
   const bool sc = a.out_pos != nullptr;
+  if (a.sp_mode == 3) {              // GAT scores through the scaled-dot kernels (4-wide vectors only)
+    if constexpr (DK4 == 1) launch_rows_sd_mode<H, DK4, 3, false>(a, n16, n64, s, n_hub, part, chunk_first);
+    return;
+  }
   if (a.sp_mode == 2) launch_rows_sd_mode<H, DK4, 2, false>(a, n16, n64, s, n_hub, part, chunk_first);      // (writes no weights)
   else if (a.sp_mode == 1) {
     if (sc) launch_rows_sd_mode<H, DK4, 1, true>(a, n16, n64, s, n_hub, part, chunk_first);
@@ -1089,11 +1105,17 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   float* part = reinterpret_cast<float*>(base + L.part);
 
   if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
+  // GAT's row softmax on the scaled-dot row kernels (gat_terms_kernel's table): the fused row path without edge weights
+  const bool gat_sd = gat && !stats_only && pass_only == 0 && !hubs_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr &&
+                      prods_edge == nullptr && w_mean_csr != nullptr && g->bin_rows != nullptr && a.edge_w == nullptr &&
+                      (a.h == 1 || a.h == 2 || a.h == 4 || a.h == 8) && (fork == nullptr || fork->aux == nullptr) &&
+                      (g->n_long_rows == 0 || g->long_chunk_first != nullptr) && g_tune[GNPDE_TUNE_ATT_GENERIC_ROWS] == 0;
   if (gat) {
     const int term_rows = at->n_key_rows > g->n ? at->n_key_rows : g->n;      // every row a column may address
     const long long items = static_cast<long long>(term_rows) * a.h;
     hipLaunchKernelGGL(gat_terms_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       at->q, at->ldqk, at->gat_a, term_rows, a.h, a.dk, reinterpret_cast<float*>(base + L.gat));
+                       at->q, at->ldqk, at->gat_a, term_rows, a.h, a.dk, reinterpret_cast<float*>(base + L.gat),
+                       gat_sd ? reinterpret_cast<float*>(base + L.gat_table) : nullptr);
     GNPDE_LAUNCH_CHECK();
   }
   const bool vec4 = (a.dk % 4 == 0) && (a.ldqk % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
@@ -1115,6 +1137,21 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
         GNPDE_LAUNCH_CHECK();
       }
       return 0;
+    }
+    if (gat_sd) {
+      AttArgs c2 = c;
+      c2.type = GNPDE_ATT_SCALED_DOT;
+      c2.q = reinterpret_cast<const float*>(base + L.gat_table);
+      c2.k = c2.q + 4 * a.h;
+      c2.ldqk = 8 * a.h;
+      c2.dk = 4;
+      c2.scale_mul = 0.5f;
+      c2.inv_sqrt_dk_den = 2.0f;
+      c2.sp_mode = 3;
+      if (launch_sd_with_hubs(c2, g->n_bin16, g->n_bin64, g->n_long_rows > 0 ? g->n_long_chunks : 0, part, g->long_chunk_first, stream)) {
+        GNPDE_LAUNCH_CHECK();
+        return 0;
+      }
     }
     if (a.type == GNPDE_ATT_SCALED_DOT && vec4 && (fork == nullptr || fork->aux == nullptr) &&
         (g->n_long_rows == 0 || g->long_chunk_first != nullptr) &&
