@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
                                                                  int hub_phase, float* __restrict__ part,
                                                                  const int* __restrict__ chunk_first) {
   if (static_cast<int>(blockIdx.x) < n_hub) {
-    if (hub_phase == 0) hub_scores_partial_heads<GNPDE_ATT_SCALED_DOT, true, H, MODE>(a, part, blockIdx.x);
+    if (hub_phase == 0) hub_scores_partial_heads<(MODE == 4 ? GNPDE_ATT_EXP_KERNEL : GNPDE_ATT_SCALED_DOT), true, H, MODE>(a, part, blockIdx.x);
     else hub_normalise_body<MODE, SCATTER>(a, part, chunk_first, blockIdx.x);
     return;
   }
@@ -693,6 +693,12 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
 #pragma unroll
     for (int j = 0; j < DK4; ++j)
       qv[r][j] = *reinterpret_cast<const float4*>(a.q + static_cast<size_t>(row[r]) * a.ldqk + head * a.dk + 4 * j);
+  float exp_ov2 = 0.f, exp_den = 1.f;
+  if constexpr (MODE == 4) {
+    const float ov = *a.output_var, ls = *a.lengthscale;
+    exp_ov2 = ov * ov;
+    exp_den = 2.0f * (ls * ls);
+  }
 
   // column ids of the batch AFTER the current one are requested before the current batch's k rows are used, so that a row of
   // several batches pays one dependent round trip per batch (k rows), not two (ids -> k rows)
@@ -731,16 +737,25 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
           float dot = 0.f;
 #pragma unroll
           for (int j = 0; j < DK4; ++j) {
-            dot = fmaf(qv[r][j].x, kv[r][i][j].x, dot);
-            dot = fmaf(qv[r][j].y, kv[r][i][j].y, dot);
-            dot = fmaf(qv[r][j].z, kv[r][i][j].z, dot);
-            dot = fmaf(qv[r][j].w, kv[r][i][j].w, dot);
+            if constexpr (MODE == 4) {   // exp kernel: |q - k|^2, the same chain as edge_score<GNPDE_ATT_EXP_KERNEL>
+              float t;
+              t = qv[r][j].x - kv[r][i][j].x; dot = fmaf(t, t, dot);
+              t = qv[r][j].y - kv[r][i][j].y; dot = fmaf(t, t, dot);
+              t = qv[r][j].z - kv[r][i][j].z; dot = fmaf(t, t, dot);
+              t = qv[r][j].w - kv[r][i][j].w; dot = fmaf(t, t, dot);
+            } else {
+              dot = fmaf(qv[r][j].x, kv[r][i][j].x, dot);
+              dot = fmaf(qv[r][j].y, kv[r][i][j].y, dot);
+              dot = fmaf(qv[r][j].z, kv[r][i][j].z, dot);
+              dot = fmaf(qv[r][j].w, kv[r][i][j].w, dot);
+            }
           }
           const int e = e0[r] + (nb * PB + i) * GE + slot;
           // (this kernel is bound by VALU issue, not by memory: ~580 wave instructions per 4 rows, a fifth of them the IEEE
           //  division sequences and the full-range expf -- round 3: exact power-of-two scale, one reciprocal per row, v_exp)
           float sv = dot * a.scale_mul;
           if constexpr (MODE == 3) sv = sv > 0.f ? sv : sv * a.leaky_slope;      // GAT: the vectors are gat_terms_kernel's table
+          if constexpr (MODE == 4) sv = exp_ov2 * expf(-(dot / exp_den));        // ov^2 exp(-|q - k|^2 / 2 l^2) (reference :193-196)
           if (a.edge_w != nullptr) sv = sv * a.edge_w[e < e1[r] ? e : e1[r] - 1];
           if constexpr (MODE == 2) {
             if (live[r] && e < e1[r]) a.scores[static_cast<size_t>(e) * H + head] = sv;     // kept for the second sweep
@@ -936,6 +951,7 @@ template <int H, int DK4>
 void launch_rows_sd(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub = 0, float* part = nullptr,
                     const int* chunk_first = nullptr) {
   const bool sc = a.out_pos != nullptr;
+  if (a.sp_mode == 4) { launch_rows_sd_mode<H, DK4, 4, false>(a, n16, n64, s, n_hub, part, chunk_first); return; }   // exp kernel scores
   if (a.sp_mode == 3) {              // GAT scores through the scaled-dot kernels (4-wide vectors only)
     if constexpr (DK4 == 1) launch_rows_sd_mode<H, DK4, 3, false>(a, n16, n64, s, n_hub, part, chunk_first);
     return;
@@ -1159,6 +1175,17 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
                             stream)) {
       GNPDE_LAUNCH_CHECK();
       return 0;
+    }
+    if (a.type == GNPDE_ATT_EXP_KERNEL && vec4 && (fork == nullptr || fork->aux == nullptr) &&
+        (g->n_long_rows == 0 || g->long_chunk_first != nullptr)) {
+      // the exp kernel through the same row kernels (MODE 4: squared distance instead of the dot product, per-entry formula as
+      // edge_score<GNPDE_ATT_EXP_KERNEL>): 815 -> ~1000 steps/s at the ogbn-arxiv shape
+      AttArgs c4 = c;
+      c4.sp_mode = 4;
+      if (launch_sd_with_hubs(c4, g->n_bin16, g->n_bin64, g->n_long_rows > 0 ? g->n_long_chunks : 0, part, g->long_chunk_first, stream)) {
+        GNPDE_LAUNCH_CHECK();
+        return 0;
+      }
     }
     hipStream_t br = stream;
     if (g->n_long_rows > 0) {  // hubs: chunk passes, as a parallel branch when a fork stream is given

@@ -390,6 +390,90 @@ __global__ __launch_bounds__(kBlock) void stream_read_kernel(const float4* __res
 }
 }  // namespace gnpde
 
+namespace gnpde {
+namespace {
+// q||k rows -> unit (optionally mean-centred) head vectors, in place; the query side also takes the factor sqrt(d_k) the scaled-dot
+// kernels divide by.  One thread per (row, side, head).
+__global__ __launch_bounds__(kBlock) void normalise_heads_kernel(float* __restrict__ qk, long long n, int ld, int att_dim, int heads,
+                                                                int centre, float q_scale) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n * 2 * heads) return;
+  const int head = static_cast<int>(idx % heads);
+  const int side = static_cast<int>((idx / heads) % 2);
+  const long long row = idx / (2 * heads);
+  const int dk = att_dim / heads;
+  float* v = qk + row * ld + side * att_dim + head * dk;
+  float mean = 0.f;
+  if (centre) {
+    for (int j = 0; j < dk; ++j) mean += v[j];
+    mean = mean / static_cast<float>(dk);
+  }
+  float nn = 0.f;
+  for (int j = 0; j < dk; ++j) {
+    const float c = v[j] - mean;
+    nn = fmaf(c, c, nn);
+  }
+  // the reference divides by sqrt(max(|q|^2 |k|^2, eps^2)), eps = 1e-5: per vector max(|.|, sqrt(eps)) gives the same quotient whenever
+  // both norms lie on the same side of sqrt(eps) (in particular for every pair of non-degenerate vectors, and for two zero vectors)
+  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 3.16227766e-3f);
+  for (int j = 0; j < dk; ++j) v[j] = (v[j] - mean) * inv;
+}
+}  // namespace
+
+namespace {
+// the same with the head vector in registers (d_k = 4 DK4, 16-byte aligned rows): one 16-byte load and store per 4 columns
+template <int DK4>
+__global__ __launch_bounds__(kBlock) void normalise_heads_vec_kernel(float* __restrict__ qk, long long n, int ld, int att_dim, int heads,
+                                                                    int centre, float q_scale) {
+  constexpr int DK = 4 * DK4;
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n * 2 * heads) return;
+  const int head = static_cast<int>(idx % heads);
+  const int side = static_cast<int>((idx / heads) % 2);
+  const long long row = idx / (2 * heads);
+  float4* v = reinterpret_cast<float4*>(qk + row * ld + side * att_dim + head * DK);
+  float4 x[DK4];
+#pragma unroll
+  for (int j = 0; j < DK4; ++j) x[j] = v[j];
+  float mean = 0.f;
+  if (centre) {
+#pragma unroll
+    for (int j = 0; j < DK4; ++j) { mean += x[j].x; mean += x[j].y; mean += x[j].z; mean += x[j].w; }
+    mean = mean / static_cast<float>(DK);
+  }
+  float nn = 0.f;
+#pragma unroll
+  for (int j = 0; j < DK4; ++j) {
+    x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+    nn = fmaf(x[j].x, x[j].x, nn); nn = fmaf(x[j].y, x[j].y, nn); nn = fmaf(x[j].z, x[j].z, nn); nn = fmaf(x[j].w, x[j].w, nn);
+  }
+  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 3.16227766e-3f);
+#pragma unroll
+  for (int j = 0; j < DK4; ++j) v[j] = make_float4(x[j].x * inv, x[j].y * inv, x[j].z * inv, x[j].w * inv);
+}
+}  // namespace
+
+// cosine_sim / pearson scores as scaled-dot scores of normalised vectors (csrc/solver.hip enqueue_rhs): rows [0, n) of the q||k table
+int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s) {
+  if (n <= 0) return 0;
+  const int dk = att_dim / heads;
+  const long long items = n * 2 * heads;
+  if (ld % 4 == 0 && reinterpret_cast<uintptr_t>(qk) % 16 == 0 && (dk == 4 || dk == 8 || dk == 16)) {
+    const dim3 grid(static_cast<unsigned>((items + kBlock - 1) / kBlock));
+    const float qs = sqrtf(static_cast<float>(dk));
+    if (dk == 4) hipLaunchKernelGGL(normalise_heads_vec_kernel<1>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
+    else if (dk == 8) hipLaunchKernelGGL(normalise_heads_vec_kernel<2>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
+    else hipLaunchKernelGGL(normalise_heads_vec_kernel<4>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
+    GNPDE_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(normalise_heads_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, qk, n, ld, att_dim,
+                     heads, centre ? 1 : 0, sqrtf(static_cast<float>(dk)));
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace gnpde
+
 extern "C" int gnpde_stream_read(const float* table, int64_t n_floats, int32_t passes, float* sink, int32_t n_sink, void* stream) {
   GNPDE_CHECK_ARG(table && sink && passes >= 1 && n_floats >= 4 && n_floats % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0, GNPDE_EINVAL,
                   "stream_read: a 16-byte aligned table of a multiple of 4 floats");

@@ -17,6 +17,7 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
                       int ldo, hipStream_t s, int relu = 0);
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
+int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 size_t attention_workspace_bytes_rows(const gnpde_graph_t* g, int h, bool gat, int key_rows);
 size_t fused_attn_workspace_bytes(const gnpde_graph_t* g, int d, int heads);
@@ -97,6 +98,17 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     at.ldqk = r.proj_m;
     at.q = proj;
     at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
+    if (r.kind == GNPDE_RHS_TRANSFORMER && (at.type == GNPDE_ATT_COSINE || at.type == GNPDE_ATT_PEARSON) &&
+        at.heads >= 1 && at.att_dim % at.heads == 0) {
+      // cosine_sim / pearson (reference src/function_transformer_attention.py:198-206) = the scaled dot product of unit (mean-centred)
+      // head vectors: the rows just projected are normalised in place (the query side times sqrt(d_k)) and everything behind --
+      // fused row kernels with their hub phases, the fused normalisers over columns / squareplus, attention inside the aggregation
+      // kernel on small graphs -- is the scaled-dot path
+      rc = launch_normalise_heads(proj + static_cast<size_t>(p0) * r.proj_m, p1 > p0 ? p1 - p0 : 0, r.proj_m, at.att_dim, at.heads,
+                                  at.type == GNPDE_ATT_PEARSON, s);
+      if (rc) return rc;
+      at.type = GNPDE_ATT_SCALED_DOT;
+    }
     at.n_key_rows = r.n_state_rows > g->n ? r.n_state_rows : 0;     // halo rows: the GAT node terms cover them
     const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0;
     if (r.kind == GNPDE_RHS_TRANSFORMER && fork == nullptr && r.proj_row_end == 0 && r.n_state_rows <= g->n &&

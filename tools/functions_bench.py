@@ -1,5 +1,6 @@
-"""GAT function (ODEFuncAtt) at the benchmark shape: rk4 steps/s of ConstantODEblock.forward next to the transformer function, and
-the kernel profile when run under rocprofv3 (not a BASELINE configuration: a look at row a10 of SURVEY section 8)."""
+"""Functions / score types outside the BASELINE configurations at the benchmark shape: rk4 steps/s of ConstantODEblock.forward for the
+transformer function with each score type and for the GAT function (ODEFuncAtt), and the kernel profile when run under rocprofv3
+(a look at rows a4 / a10 of SURVEY section 8)."""
 import os
 import sys
 import time
@@ -21,8 +22,10 @@ def main():
   ei, n = G.synthetic.make_graph('arxiv', seed=0)
   d = 128
   x = torch.randn(n, d, generator=torch.Generator().manual_seed(1)).to(dev)
-  for function, fcls in (('transformer', G.ODEFuncTransformerAtt), ('GAT', G.ODEFuncAtt)):
-    opt = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+  for function, att_type, fcls in (('transformer', 'scaled_dot', G.ODEFuncTransformerAtt), ('transformer', 'cosine_sim', G.ODEFuncTransformerAtt),
+                                   ('transformer', 'pearson', G.ODEFuncTransformerAtt), ('transformer', 'exp_kernel', G.ODEFuncTransformerAtt),
+                                   ('GAT', 'scaled_dot', G.ODEFuncAtt)):
+    opt = dict(heads=4, attention_dim=16, attention_type=att_type, attention_norm_idx=0, square_plus=False, reweight_attention=False,
                beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=100000, add_source=True, no_alpha_sigmoid=False,
                mix_features=False, hidden_dim=d, augment=False, adjoint=False, tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0,
                max_iters=100, block='constant', function=function, time=float(K))
@@ -46,7 +49,7 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = sorted(times[1:])[len(times[1:]) // 2]
-    print('%-12s %d rk4 steps: %.3f ms per forward, %.1f steps/s (finite %s)' % (function, K, 1e3 * best, K / best, bool(torch.isfinite(z).all())))
+    print('%-12s %-11s %d rk4 steps: %.3f ms per forward, %.1f steps/s (finite %s)' % (function, att_type, K, 1e3 * best, K / best, bool(torch.isfinite(z).all())))
 
 
 if __name__ == '__main__':
