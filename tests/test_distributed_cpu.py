@@ -239,3 +239,34 @@ def test_partition_plan_takes_the_candidate_with_the_cheapest_busiest_link():
   fixed = D.PartitionPlan(ei, n, 4, part=plan.part)
   assert fixed.candidates is None and torch.equal(fixed.part, plan.part)
   assert len(D.PartitionPlan(ei, n, 1).candidates or []) == 0
+
+
+@pytest.mark.parametrize('name', ['func_transformer_beltrami_expkernel', 'func_transformer_beltrami_expkernel_sqp',
+                                  'func_transformer_beltrami_expkernel_labels_n1', 'func_transformer_expkernel_n0',
+                                  'func_transformer_cosine_n0', 'func_transformer_pearson_n1', 'func_gat_n0', 'func_gat_slope'])
+def test_partitioned_problem_parameters_reproduce_the_reference_attention(name):
+  """What `distributed._sharded_problem` hands the partitioned backend -- (W, b) pairs, score type, kernel scalars -- evaluated by the
+  CPU oracle must give the attention the REFERENCE recorded for that function: in particular BLEND's split feature x positional
+  kernel as ONE exp kernel over the concatenated, length-scaled projections (heads of width 2 d_k, output_var = ov_x ov_p,
+  lengthscale 1), and the GAT layer's transposed weight + flattened `a`.  No GPU involved."""
+  from helpers import Fixture, Data
+  from oracle import restate as R
+  fx = Fixture(name)
+  x = fx.t('x')
+  fcls = {'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}[fx.opt['function']]
+  func = fcls(x.shape[1], x.shape[1], fx.opt, Data(x, fx.t('edge_index')), torch.device('cpu'))
+  func.load_state_dict(fx.params, strict=True)
+  kind, p = D._sharded_problem(func)
+  edge = func.edge_index
+  want = fx.t('attention')
+  if kind == 'gat':
+    dk = p['W'].shape[0] // p['heads']
+    got, _ = R.gat_attention(x, edge, p['W'].t(), p['a'].view(2 * dk, 1, 1), p['heads'], p['leaky_slope'], p['norm_idx'])
+  else:
+    assert kind == 'transformer'
+    got, _ = R.transformer_attention(x, edge, p['Wq'], p['bq'], p['Wk'], p['bk'], p['heads'], attention_type=p['att_type'],
+                                     norm_idx=p['norm_idx'], square_plus=p['square_plus'], output_var=p.get('output_var'),
+                                     lengthscale=p.get('lengthscale'))
+  assert got.shape == want.shape
+  err = float((got - want).abs().max() / want.abs().max())
+  assert err < 2e-6, (name, kind, err)
