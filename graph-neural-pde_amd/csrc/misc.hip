@@ -413,9 +413,10 @@ __global__ __launch_bounds__(kBlock) void normalise_heads_kernel(float* __restri
     const float c = v[j] - mean;
     nn = fmaf(c, c, nn);
   }
-  // the reference divides by sqrt(max(|q|^2 |k|^2, eps^2)), eps = 1e-5: per vector max(|.|, sqrt(eps)) gives the same quotient whenever
-  // both norms lie on the same side of sqrt(eps) (in particular for every pair of non-degenerate vectors, and for two zero vectors)
-  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 3.16227766e-3f);
+  // torch.nn.functional.cosine_similarity(eps = 1e-5) (reference src/function_transformer_attention.py:197-206) divides by
+  // max(|x1|, eps) max(|x2|, eps) (torch >= 1.12; the fixtures were recorded with this image's torch): a clamp per vector, which is
+  // exactly what a normalisation per vector can express
+  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 1e-5f);
   for (int j = 0; j < dk; ++j) v[j] = (v[j] - mean) * inv;
 }
 }  // namespace
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void normalise_heads_vec_kernel(float* __re
     x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
     nn = fmaf(x[j].x, x[j].x, nn); nn = fmaf(x[j].y, x[j].y, nn); nn = fmaf(x[j].z, x[j].z, nn); nn = fmaf(x[j].w, x[j].w, nn);
   }
-  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 3.16227766e-3f);
+  const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 1e-5f);      // (as the scalar kernel above)
 #pragma unroll
   for (int j = 0; j < DK4; ++j) v[j] = make_float4(x[j].x * inv, x[j].y * inv, x[j].z * inv, x[j].w * inv);
 }

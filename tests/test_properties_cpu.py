@@ -221,3 +221,41 @@ def test_relabelled_graph_keeps_every_rows_edges_in_the_callers_order(g, rnd):
   assert torch.equal(view.leave(view.enter(x)), x)
   buf = torch.empty(n, 4)[:, :3]                               # a padded (non-contiguous) destination
   assert torch.equal(view.enter(x, out=buf), x[order]) and torch.equal(view.leave(buf, out=torch.empty(n, 3)), x)
+
+
+@pytest.mark.parametrize('centre', [False, True])
+@pytest.mark.parametrize('dk', [4, 8, 24])
+def test_cosine_scores_are_scaled_dot_scores_of_normalised_rows(centre, dk):
+  """The identity behind csrc/misc.hip normalise_heads_kernel (cosine_sim / pearson run on the scaled-dot kernels): with
+  q^ = sqrt(d_k) (q - mean) / max(|q - mean|, eps) and k^ = (k - mean) / max(|k - mean|, eps), eps = 1e-5,
+  q^ . k^ / sqrt(d_k) is torch.nn.functional.cosine_similarity(eps = 1e-5) of the (mean-centred) head vectors -- the reference's score
+  (src/function_transformer_attention.py:197-206, restated in oracle/restate.py) -- for ordinary, tiny, zero and mixed pairs alike."""
+  from oracle import restate as R
+  g = torch.Generator().manual_seed(dk + int(centre))
+  n, h = 400, 3
+  A = h * dk
+  q = torch.randn(n, A, generator=g)
+  k = torch.randn(n, A, generator=g)
+  q[:40] *= 1e-4                      # tiny on both sides
+  k[:40] *= 1e-4
+  q[40:50] = 0.0                      # zero on both sides
+  k[40:50] = 0.0
+  q[50:60] *= 1e-7                    # below eps on one side only
+  k[60:70] = 0.0
+  edge = torch.stack([torch.arange(n), torch.arange(n)])
+  eye = torch.eye(A)
+  zero = torch.zeros(A)
+  _, want = R.transformer_attention(torch.cat([q, k], dim=1), edge, torch.cat([eye, torch.zeros(A, A)], dim=1), zero,
+                                    torch.cat([torch.zeros(A, A), eye], dim=1), zero, h,
+                                    attention_type='pearson' if centre else 'cosine_sim')
+
+  def normalise(v, scale):
+    v = v.view(n, h, dk)
+    if centre:
+      v = v - v.mean(dim=2, keepdim=True)
+    nrm = v.pow(2).sum(dim=2, keepdim=True).sqrt().clamp_min(1e-5)
+    return (v * (scale / nrm)).reshape(n, A)
+  qn, kn = normalise(q, dk ** 0.5), normalise(k, 1.0)
+  got = (qn.view(n, h, dk) * kn.view(n, h, dk)).sum(dim=2) / dk ** 0.5
+  assert got.shape == want.shape
+  assert float((got - want).abs().max()) < 5e-6
