@@ -47,7 +47,10 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=100)
   ap.add_argument('--warmup', type=int, default=10)
-  ap.add_argument('--graph', default='arxiv', choices=['arxiv', 'cora', 'rmat'])
+  ap.add_argument('--graph', default='arxiv', choices=['arxiv', 'arxiv_flat', 'cora', 'rmat'],
+                  help='arxiv: ogbn-arxiv shape with 40 planted communities (the headline); arxiv_flat: same degree skew, NO community '
+                       'structure (what the node relabelling gains without planted locality)')
+  ap.add_argument('--method', default='rk4', choices=['rk4', 'euler'], help='fixed-step method of the timed solve (BASELINE configs[0] is euler)')
   ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the metric)')
   ap.add_argument('--att-dim', type=int, default=None)
   ap.add_argument('--heads', type=int, default=None)
@@ -66,9 +69,15 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
-  ap.add_argument('--config', default=None, choices=['c4'],
+  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch'],
                   help='c4: BASELINE configs[3] -- ogbn-arxiv BLEND (beltrami split kernel, d = 64 + 98 = 162), block_transformer_rewiring in '
-                       'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward)')
+                       'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward).  '
+                       'cora-epoch: the reference\'s flagship run -- best_params Cora (attention block, Laplacian function, dopri5, adjoint=False, '
+                       '8 heads, A = 128, squareplus over columns) on a Cora-LCC-shaped graph: one epoch = run_GNN.py train() + test()')
+  ap.add_argument('--no-configs', action='store_true',
+                  help='default line only: skip the `configs` block (the other BASELINE configurations, each measured by a child process of this script)')
+  ap.add_argument('--configs-budget', type=float, default=1100.0, help='seconds the `configs` block may take in total (children past it are skipped, and say so)')
+  ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter_collection.csv files of the live PMC passes')
   ap.add_argument('--train', action='store_true',
                   help='training iteration instead of the inference solve: forward (tape-free native solver) + backward (native adjoint '
                        'solve, opt[adjoint] with adjoint_method rk4 / adjoint_step_size 1) of K steps each; prints its own JSON line')
@@ -88,7 +97,7 @@ def build_opt(cfg, args):
               reweight_attention=False,
               beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True,
               no_alpha_sigmoid=False, mix_features=False, hidden_dim=cfg['d'], augment=False, adjoint=False,
-              tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100, block='constant',
+              tol_scale=1.0, data_norm='rw', method=args.method, step_size=1.0, max_iters=100, block='constant',
               function=args.function, time=float(args.steps))
 
 
@@ -96,20 +105,22 @@ class _Data(object):
   pass
 
 
-GRAPH_NAMES = {'arxiv': 'ogbn-arxiv', 'cora': 'Cora', 'rmat': 'RMAT-2M'}
+GRAPH_NAMES = {'arxiv': 'ogbn-arxiv', 'arxiv_flat': 'ogbn-arxiv (no communities)', 'cora': 'Cora', 'rmat': 'RMAT-2M'}
 
 
-def metric_name(graph, d, world=1):
+def metric_name(graph, d, world=1, method='rk4'):
   """BASELINE.json's metric with the graph that was ACTUALLY run."""
-  return 'ODE steps/sec (full-graph diffusion), %s d=%d rk4' % (GRAPH_NAMES.get(graph, graph), d)
+  return 'ODE steps/sec (full-graph diffusion), %s d=%d %s' % (GRAPH_NAMES.get(graph, graph), d, method)
 
 
-def workload_name(graph, function, K):
+def workload_name(graph, function, K, method='rk4'):
   shape = {'arxiv': 'synthetic ogbn-arxiv-shaped graph (power-law degrees, 40 communities, shuffled ids)',
+           'arxiv_flat': 'synthetic ogbn-arxiv-shaped graph WITHOUT community structure (power-law degrees, shuffled ids)',
            'cora': 'synthetic Cora-shaped graph (uniform random)',
            'rmat': 'synthetic R-MAT graph (Graph500 parameters, 2^21 nodes, 40 M generated edges, symmetrised)'}[graph]
-  return '%s, GRAND-%s add_source, rk4 3/8-rule, step_size 1, T=%d, hipGraph-captured solver' % (
-    shape, 'nl scaled_dot softmax attention' if function == 'transformer' else 'l', K)
+  return '%s, GRAND-%s add_source, %s, step_size 1, T=%d, hipGraph-captured solver' % (
+    shape, 'nl scaled_dot softmax attention' if function == 'transformer' else 'l',
+    'rk4 3/8-rule' if method == 'rk4' else 'euler', K)
 
 
 def host_info():
@@ -168,6 +179,8 @@ def dominant_kernel_time(G, block, x, reps=10):
             dict(stage=_lib.STAGE_RK2C, y=y, out_y=ub, u=ua),
             dict(stage=_lib.STAGE_RK3C, k1=ua, out_y=k1, u=ub),
             dict(stage=_lib.STAGE_RK4C, y=y, k1=ub, out_y=y, u=k1)]
+  if f.opt.get('method') == 'euler':      # the one stage the euler solver runs (ping-pong between two buffers)
+    stages = [dict(stage=_lib.STAGE_EULER, y=y, out_y=ua, u=y), dict(stage=_lib.STAGE_EULER, y=ua, out_y=y, u=ua)] * 2
   fused = False
   if hasattr(f, 'multihead_att_layer') and os.environ.get('GNPDE_ONE_PASS', '0') == '1':
     desc = f._descriptor(x)
@@ -392,13 +405,15 @@ def pmc_child(G, block, x, reps=3):
   alpha, beta = ops._scalar_dev(f.alpha_train, x), ops._scalar_dev(f.beta_train, x)
   stages = [dict(stage=_lib.STAGE_RK1C, out_y=ua, u=y), dict(stage=_lib.STAGE_RK2C, y=y, out_y=ub, u=ua),
             dict(stage=_lib.STAGE_RK3C, k1=ua, out_y=k1, u=ub), dict(stage=_lib.STAGE_RK4C, y=y, k1=ub, out_y=y, u=k1)]
+  if f.opt.get('method') == 'euler':
+    stages = [dict(stage=_lib.STAGE_EULER, y=y, out_y=ua, u=y), dict(stage=_lib.STAGE_EULER, y=ua, out_y=y, u=ua)] * 2
   w = torch.rand(max(graph.e, 1), device=dev) / 16
   att = None
   if hasattr(f, 'multihead_att_layer'):
     lay = f.multihead_att_layer
     wqk, bqk = lay.qk_weights()
     A, h = lay.attention_dim, lay.h
-    qk = ops.linear(x, wqk, bqk)
+    qk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=dev)     # (filled by the loop: exactly `reps` projection launches)
     att = ops.attention_struct(_lib.ATT_TYPES[f.opt['attention_type']], h, A, f.opt['attention_norm_idx'], f.opt['square_plus'],
                                q=qk, k=qk[:, A:], ldqk=2 * A)
   for _ in range(reps):
@@ -413,13 +428,12 @@ def pmc_child(G, block, x, reps=3):
   print(json.dumps({'pmc_child': 'done', 'aggregation_calls': 4 * reps, 'evaluations': reps}))
 
 
-def live_pmc_traffic(args, reorder_mode, timeout_s=150):
-  """L2 -> fabric bytes of the evaluation's kernels, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE
+def pmc_passes(child, env, tag, keep_dir=None, timeout_s=150, marker='{"pmc_child"'):
+  """L2 -> fabric bytes per kernel of the command `child`, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE
   TCC_HIT_sum TCC_MISS_sum -- separate passes, with --kernel-trace only, as MI355X_MICROARCH.md section "rocprofv3 PMC slots"
-  prescribes) over a child process of this script (--pmc-child) that launches the projection, the row attention and the four
-  stage variants of the aggregation three times on the same graph.  bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is in
-  KiB and tallies the 128-B requests of wide coalesced reads at 64 B on gfx950 (same guide, section HBM).  Returns
-  {kernel name: {...}} + '_calls', or {'error': ...}."""
+  prescribes).  bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is in KiB and tallies the 128-B requests of wide coalesced
+  reads at 64 B on gfx950 (same guide, section HBM).  Returns {kernel name: {...}} + '_calls' (the JSON line of the child that starts
+  with `marker`) + '_seconds', or {'error': ...}.  keep_dir: the raw counter_collection.csv files are copied there."""
   import csv
   import glob
   import re
@@ -430,15 +444,6 @@ def live_pmc_traffic(args, reorder_mode, timeout_s=150):
   if not os.path.exists(exe):
     return {'error': 'rocprofv3 not found'}
   base = tempfile.mkdtemp(prefix='gnpde_pmc_', dir='/tmp')
-  child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--graph', args.graph, '--scale', str(args.scale), '--seed', str(args.seed),
-           '--function', args.function, '--norm-idx', str(args.norm_idx), '--steps', '1', '--warmup', '0']
-  if args.att_dim:
-    child += ['--att-dim', str(args.att_dim)]
-  if args.heads:
-    child += ['--heads', str(args.heads)]
-  if args.square_plus:
-    child += ['--square-plus']
-  env = dict(os.environ, TMPDIR='/tmp', GNPDE_BENCH_REORDER=reorder_mode)
   acc, calls = {}, None
   t0 = time.perf_counter()
   try:
@@ -449,12 +454,18 @@ def live_pmc_traffic(args, reorder_mode, timeout_s=150):
       if res.returncode != 0:
         return {'error': 'rocprofv3 pass %d exited with %d: %s' % (i, res.returncode, (res.stderr or res.stdout)[-300:])}
       for line in res.stdout.splitlines():
-        if line.startswith('{"pmc_child"'):
+        if line.startswith(marker):
           calls = json.loads(line)
       found = glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True)
       if not found:
         return {'error': 'rocprofv3 pass %d wrote no counter_collection.csv' % i}
       for path in found:
+        if keep_dir:     # the raw counter records of this run, next to the line they produced
+          try:
+            os.makedirs(keep_dir, exist_ok=True)
+            shutil.copy(path, os.path.join(keep_dir, 'live_pmc_%s_pass%d_%s.csv' % (tag, i, '_'.join(counters))))
+          except OSError:
+            pass
         for r in csv.DictReader(open(path)):
           name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
           name = re.sub(r'^void ', '', name).split('(')[0]
@@ -486,6 +497,29 @@ def live_pmc_traffic(args, reorder_mode, timeout_s=150):
   return out
 
 
+def live_pmc_traffic(args, reorder_mode, timeout_s=150):
+  """The PMC passes over a child process of this script (--pmc-child) that launches the projection, the row attention and the four
+  stage variants of the aggregation three times on the same graph, in the node order the parent's solver chose."""
+  child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--graph', args.graph, '--scale', str(args.scale), '--seed', str(args.seed),
+           '--function', args.function, '--norm-idx', str(args.norm_idx), '--steps', '1', '--warmup', '0', '--method', args.method]
+  if args.att_dim:
+    child += ['--att-dim', str(args.att_dim)]
+  if args.heads:
+    child += ['--heads', str(args.heads)]
+  if args.square_plus:
+    child += ['--square-plus']
+  env = dict(os.environ, TMPDIR='/tmp', GNPDE_BENCH_REORDER=reorder_mode)
+  return pmc_passes(child, env, '%s_%s' % (args.graph, args.function), getattr(args, 'keep_pmc', None), timeout_s)
+
+
+def mode_pmc_traffic(args, mode_flags, tag, timeout_s=240):
+  """The same two passes over a short run of this script in another mode (`--train`, `--config c4`): the child prints its own
+  bench line, whose counts (evaluations, stages) turn the per-kernel totals into bytes per stage / per launch."""
+  child = [sys.executable, os.path.abspath(__file__), '--scale', str(args.scale), '--seed', str(args.seed), '--no-live-pmc', '--no-cpu-baseline',
+           '--no-configs', '--replays', '1'] + list(mode_flags)
+  return pmc_passes(child, dict(os.environ, TMPDIR='/tmp'), tag, getattr(args, 'keep_pmc', None), timeout_s, marker='{"metric"')
+
+
 def traffic_of(pmc, pattern, calls):
   """Bytes per call of the kernels whose name holds `pattern` (a call of the aggregation = its row kernel + the hub-row fold)."""
   recs = [(k, v) for k, v in pmc.items() if not k.startswith('_') and pattern in k and 'bytes_per_launch' in v]
@@ -498,6 +532,41 @@ def traffic_of(pmc, pattern, calls):
           'kernels': {k: {'launches': v['launches'], 'bytes_per_launch': round(v['bytes_per_launch']), 'l2_hit_rate': v.get('l2_hit_rate')}
                       for k, v in recs},
           'l2_hit_rate': big[1].get('l2_hit_rate')}
+
+
+def subset_parity(block, x, x_cpu, n_random=3000):
+  """f is row-local once the neighbours are known: the rows of a SUBSET (the six largest hubs, 2-3-chunk rows, mid-degree rows,
+  random rows) of one full-size evaluation against the oracle on the sub-graph those rows and all their neighbours induce
+  (tests/test_rmat_gpu.py does the same) -- the parity check of a shape whose whole-graph oracle evaluation needs ~100 GB."""
+  from oracle import restate as R
+  f = block.odefunc
+  lay = f.multihead_att_layer
+  cpu = lambda t: t.detach().cpu()   # noqa: E731
+  edge = cpu(f.edge_index)
+  n = x.shape[0]
+  deg = torch.bincount(edge[0], minlength=n)
+  g = torch.Generator().manual_seed(9)
+  hubs = torch.topk(deg, 6).indices
+  long_small = torch.nonzero((deg > 512) & (deg <= 1100)).flatten()[:40]
+  mid = torch.nonzero((deg > 16) & (deg <= 512)).flatten()
+  mid = mid[torch.randperm(mid.numel(), generator=g)[:400]]
+  rows = torch.unique(torch.cat([hubs, long_small, mid, torch.randperm(n, generator=g)[:n_random]]))
+  pick = torch.zeros(n, dtype=torch.bool)
+  pick[rows] = True
+  keep = pick[edge[0]]
+  r, c = edge[0][keep], edge[1][keep]
+  nodes = torch.unique(torch.cat([rows, c]))
+  sub_edge = torch.stack([torch.searchsorted(nodes, r), torch.searchsorted(nodes, c)])
+  xs = x_cpu[nodes]
+  with torch.no_grad():
+    f.x0 = x
+    got = f(0.0, x)
+    ref = R.rhs_transformer(xs, sub_edge, cpu(lay.Q.weight), cpu(lay.Q.bias), cpu(lay.K.weight), cpu(lay.K.bias), lay.h,
+                            cpu(f.alpha_train), cpu(f.beta_train), xs, False, True)[torch.searchsorted(nodes, rows)]
+  e_inf, e_2 = R.parity_error(got[rows.to(got.device)], ref)
+  return {'rel_max': e_inf, 'rel_l2': e_2, 'rows': int(rows.numel()), 'entries': int(keep.sum()), 'largest_row_entries': int(deg.max()),
+          'what': 'one full-size evaluation, rows of a subset (6 largest hubs, 2-3-chunk rows, 400 mid-degree rows, %d random rows) vs the oracle on '
+                  'the sub-graph they induce with all their neighbours' % n_random}
 
 
 def cpu_baseline(block, x_cpu, evals):
@@ -618,6 +687,26 @@ def c4_main(G, args, dev):
   except Exception:   # noqa: BLE001
     t_agg = None
   bytes_agg = E * (8 + 4 * d) + n * (4 + 8 * d)          # SURVEY 8d B_l (no source term in this configuration)
+  traffic, traffic_src = None, None
+  if not args.no_live_pmc and t_agg is not None:
+    # counter traffic of the aggregation launches of a short run of this same configuration (two rocprofv3 --pmc passes over a child)
+    pmc = mode_pmc_traffic(args, ['--config', 'c4', '--warmup', '1'], 'c4')
+    if isinstance(pmc, dict) and 'error' not in pmc:
+      wide = [(k, v) for k, v in pmc.items() if not k.startswith('_') and 'bytes_per_launch' in v and
+              any(t in k for t in ('spmm_wide', 'spmm_rows', 'spmm_pair'))]
+      if wide:
+        launches = sum(v['launches'] for _, v in wide)
+        tot = sum(v['fetch_bytes_total'] + v['write_bytes_total'] for k, v in pmc.items()
+                  if not k.startswith('_') and 'bytes_per_launch' in v and 'spmm_' in k)
+        traffic = tot / launches
+        traffic_src = {'how': 'measured in this run: rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes, --kernel-trace only) '
+                              'over a child process running this configuration (1 warm-up + 3 forwards); bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024, mean '
+                              'over the %d aggregation launches of that run (row kernel + its share of the hub-row fold)' % launches,
+                       'live': True, 'seconds': pmc.get('_seconds'),
+                       'kernels': {k: {'launches': v['launches'], 'bytes_per_launch': round(v['bytes_per_launch']), 'l2_hit_rate': v.get('l2_hit_rate')}
+                                   for k, v in pmc.items() if not k.startswith('_') and 'spmm_' in k and 'bytes_per_launch' in v}}
+    elif isinstance(pmc, dict):
+      traffic_src = {'live_pmc_error': pmc.get('error')}
   out_line = {
     'metric': 'forward passes/sec (adaptive solve), ogbn-arxiv BLEND d=162 dopri5',
     'value': round(1.0 / elapsed, 3), 'unit': 'forwards/s', 'n_gpus': 1, 'steps': 1, 'warmup': args.warmup,
@@ -634,9 +723,14 @@ def c4_main(G, args, dev):
     'roofline': None if t_agg is None else {
       'kernel': 'CSR aggregation + explicit-RK stage epilogue at d = 162 (rows padded to 164 floats: spmm_wide_kernel, 41 of 64 16-byte lanes live), on the graph the solve runs on (relabelled: %s)' % (view is not None),
       'bound': 'mall', 'achieved': round(bytes_agg / t_agg / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-      'frac': round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4),
-      'frac_is': 'frac_algorithmic: gather-model bytes E (8 + 4 d) + N (4 + 8 d) / launch time / 8 TB/s (the 105-MiB state is Infinity-Cache resident)',
-      'algorithmic_bytes_per_launch': bytes_agg, 'avg_launch_us': round(t_agg * 1e6, 2), 'traffic': None},
+      'frac': None if traffic is None else round(traffic / t_agg / 1e9 / HBM_PEAK_GBS, 4),
+      'frac_is': ('frac_traffic: L2 -> fabric counter bytes per aggregation launch / launch time / 8 TB/s (the 105-MiB state is Infinity-Cache resident)'
+                  if traffic is not None else 'null: cache-resident table and no live counter traffic in this run; see frac_algorithmic'),
+      'frac_algorithmic': round(bytes_agg / t_agg / 1e9 / HBM_PEAK_GBS, 4),
+      'frac_algorithmic_is': 'gather-model bytes E (8 + 4 d) + N (4 + 8 d) / launch time / 8 TB/s; exceeds what is physical when rows are served from cache',
+      'frac_traffic': None if traffic is None else round(traffic / t_agg / 1e9 / HBM_PEAK_GBS, 4),
+      'algorithmic_bytes_per_launch': bytes_agg, 'avg_launch_us': round(t_agg * 1e6, 2),
+      'traffic': None if traffic is None else round(traffic), 'traffic_source': traffic_src},
     'cpu_baseline': None,
   }
   if not args.no_cpu_baseline:
@@ -667,6 +761,216 @@ def c4_main(G, args, dev):
     out_line['parity_vs_restated_torchdiffeq'] = {'rel_max': e_inf, 'rel_l2': e_2, 'same_number_of_evaluations': bool(calls[0] == nfe)}
     out_line['speedup_vs_cpu'] = round(t_cpu / t_solve, 1)
   print(json.dumps(out_line))
+
+
+CORA_BEST = dict(   # reference src/best_params.py 'Cora' (the entries the model reads), + run_GNN.py's defaults for the rest
+  block='attention', function='laplacian', method='dopri5', adjoint=False, adjoint_method='adaptive_heun', adjoint_step_size=1,
+  add_source=True, alpha_dim='sc', beta_dim='sc', attention_dim=128, attention_norm_idx=1, attention_type='scaled_dot', heads=8,
+  hidden_dim=80, input_dropout=0.5, dropout=0.046878964627763316, square_plus=True, reweight_attention=False, mix_features=False,
+  no_alpha_sigmoid=False, self_loop_weight=1, data_norm='rw', step_size=1, max_iters=100, max_nfe=2000, time=18.294754260552843,
+  tol_scale=821.9773048827274, tol_scale_adjoint=1.0, beltrami=False, use_mlp=False, use_labels=False, fc_out=False, batch_norm=False,
+  augment=False, leaky_relu_slope=0.2, optimizer='adamax', lr=0.022924849756740397, decay=0.00507685443154266, dataset='Cora',
+  earlystopxT=3.0, max_test_steps=100, no_early=False, feat_hidden_dim=64, pos_enc_hidden_dim=16)
+
+
+def cora_lcc_dataset(seed, dev):
+  """A graph of the shape run_GNN.py trains Cora on (use_lcc: largest connected component, 2 485 nodes, 5 069 undirected edges =
+  12 623 entries with self-loops), 1 433 bag-of-words features (row-normalised, ~18 words per paper), 7 classes, the planetoid-style
+  split of the reference's set_train_val_test_split (20 per class train, rest of 1 500 development nodes validation, the others test)."""
+  import numpy as np
+  import gnpde_amd as G
+  n, pairs, nfeat, ncls = 2485, 5069, 1433, 7
+  rng = np.random.default_rng(seed)
+  a, b = rng.integers(0, n, 2 * pairs), rng.integers(0, n, 2 * pairs)
+  keep = a != b
+  key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+  key = np.sort(rng.permutation(key)[:pairs])          # exactly `pairs` distinct non-loop pairs
+  lo, hi = key // n, key % n
+  row, col = np.concatenate([lo, hi]), np.concatenate([hi, lo])
+  order = np.lexsort((col, row))
+  ei = torch.from_numpy(np.stack([row[order], col[order]])).long()
+  gen = torch.Generator().manual_seed(seed)
+  x = (torch.rand(n, nfeat, generator=gen) < 18.0 / nfeat).float()
+  x = x / x.sum(dim=1, keepdim=True).clamp_min(1.0)
+  y = torch.randint(0, ncls, (n,), generator=gen)
+  perm = torch.randperm(n, generator=gen)
+  train = torch.zeros(n, dtype=torch.bool)
+  for c in range(ncls):
+    idx = perm[(y[perm] == c)][:20]
+    train[idx] = True
+  rest = perm[~train[perm]]
+  val = torch.zeros(n, dtype=torch.bool)
+  val[rest[:1500 - int(train.sum())]] = True
+  test = ~(train | val)
+
+  class _D(object):
+    def __call__(self, *keys):
+      for k in keys:
+        yield k, getattr(self, k)
+  data = _D()
+  data.x, data.edge_index, data.edge_attr, data.y = x.to(dev), ei.to(dev), None, y.to(dev)
+  data.train_mask, data.val_mask, data.test_mask = train.to(dev), val.to(dev), test.to(dev)
+  data.num_nodes, data.num_features = n, nfeat
+  return G.DummyDataset(data, ncls), x, ei
+
+
+def cora_epoch_main(G, args, dev):
+  """`--config cora-epoch`: the reference's flagship run, the one with a published number (notebooks/visualise_attention.ipynb:
+  1.72-2.04 s per epoch, ~124 forward evaluations).  best_params Cora through gnpde_amd.GNN: encoder Linear 1433 -> 80, attention
+  block (scaled-dot attention, 8 heads, A = 128, squareplus normalised over COLUMNS, computed once per forward with autograd history),
+  Laplacian function, dopri5 (tol_scale 822, T = 18.29, adjoint = False), decoder; one EPOCH = run_GNN.py's train() (forward in train
+  mode, cross-entropy on the train mask, backward, Adamax step; src/run_GNN.py:62-96) + test() (eval forward through the early-stopping
+  test integrator to 3 T, three masked accuracies; :137-148, GNN_early.py:28-36).  Reports s/epoch, the NFE meters run_GNN.py prints,
+  the split of an epoch into its phases (synchronised between phases in a separate pass), and which solve path ran."""
+  import copy
+  import gnpde_amd.odeint as O
+  opt = dict(CORA_BEST)
+  dataset, x_cpu, ei_cpu = cora_lcc_dataset(args.seed, dev)
+  data = dataset.data
+  torch.manual_seed(args.seed)
+  model = G.GNN(opt, dataset, dev).to(dev)
+  # GNNEarly (reference src/GNN_early.py:28-36, 70-75): the early-stopping test integrator, handed the decoder before every forward
+  model.odeblock.test_integrator = G.EarlyStopInt(model.T, opt, dev)
+  model.odeblock.test_integrator.data = data
+  params = [p for p in model.parameters() if p.requires_grad]
+  optim = torch.optim.Adamax(params, lr=opt['lr'], weight_decay=opt['decay'])
+  lf = torch.nn.CrossEntropyLoss()
+  sync = torch.cuda.synchronize
+
+  def train_step(timers=None):
+    tick = (lambda k: None) if timers is None else (lambda k: (sync(), timers.__setitem__(k, time.perf_counter())))
+    model.train()
+    optim.zero_grad()
+    tick('t0')
+    out = model(data.x)
+    loss = lf(out[data.train_mask], data.y.squeeze()[data.train_mask])
+    tick('fwd')
+    model.fm.update(model.getNFE())
+    model.resetNFE()
+    loss.backward()
+    tick('bwd')
+    optim.step()
+    tick('opt')
+    model.bm.update(model.getNFE())
+    model.resetNFE()
+    return loss
+
+  @torch.no_grad()
+  def test_step():
+    model.eval()
+    ti = model.odeblock.test_integrator
+    ti.m2_weight = model.m2.weight.data.detach().clone()
+    ti.m2_bias = model.m2.bias.data.detach().clone()
+    logits, accs = model(data.x), []
+    for _, mask in data('train_mask', 'val_mask', 'test_mask'):
+      pred = logits[mask].max(1)[1]
+      accs.append(pred.eq(data.y[mask]).sum().item() / mask.sum().item())
+    nfe = model.getNFE()
+    model.resetNFE()
+    return accs, nfe
+
+  W, K = max(args.warmup, 3), max(args.steps if args.steps != 100 else 20, 1)
+  for _ in range(W):
+    train_step()
+    test_step()
+  sync()
+  model.fm.reset()
+  model.bm.reset()
+  ep, tr_t, te_t, eval_nfe = [], [], [], []
+  for _ in range(K):
+    sync()
+    t0 = time.perf_counter()
+    loss = train_step()
+    lv = loss.item()                       # run_GNN.py: `return loss.item()`
+    t1 = time.perf_counter()
+    accs, nfe_eval = test_step()
+    sync()
+    t2 = time.perf_counter()
+    ep.append(t2 - t0)
+    tr_t.append(t1 - t0)
+    te_t.append(t2 - t1)
+    eval_nfe.append(nfe_eval)
+  assert lv == lv, 'loss is NaN'
+  med = lambda v: sorted(v)[len(v) // 2]     # noqa: E731
+  fwd_nfe = model.fm.sum / max(model.fm.cnt, 1)
+  bwd_nfe = model.bm.sum / max(model.bm.cnt, 1)
+  # phases, synchronised in between (a separate pass: the syncs themselves cost a little)
+  ph = {'fwd': [], 'bwd': [], 'opt': []}
+  for _ in range(5):
+    tm = {}
+    train_step(tm)
+    ph['fwd'].append(tm['fwd'] - tm['t0'])
+    ph['bwd'].append(tm['bwd'] - tm['fwd'])
+    ph['opt'].append(tm['opt'] - tm['bwd'])
+  # device-busy share: HIP events around the solve region only cannot see idle gaps, so measure the same training forward+backward once
+  # with the kernel launches counted by the library (gnpde_launch_count, if exported) -- otherwise report wall times only
+  f = model.odeblock.odefunc
+  path = getattr(f, '_last_train_solve', None) or ('native recorded-tape dopri5' if f.__dict__.get('_tape_state') else
+                                                   'host controller loop (odeint._solve_dopri5) over kernel-backed autograd Functions')
+  stats_eval = dict(getattr(f, '_dopri5_stats', {}) or {})
+  E = int(f.edge_index.shape[1])
+  out = {
+    'metric': 'seconds per epoch (train + test), Cora best_params (attention block, Laplacian, dopri5, adjoint=False)',
+    'value': round(med(ep), 6), 'unit': 's/epoch', 'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': round(med(ep) * 1e3, 4),
+    'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+    'config': {'workload': 'reference best_params Cora on a Cora-LCC-shaped synthetic graph: GNN (encoder 1433 -> 80, attention block: scaled-dot, 8 heads, '
+                           'A = 128, squareplus over columns; Laplacian function; dopri5 tol_scale 822, T = 18.29, adjoint=False; decoder 80 -> 7); one step = '
+                           'one EPOCH = run_GNN.py train() + test() (early-stopping test integrator to 3 T)',
+               'nodes': data.num_nodes, 'edges_with_self_loops': E, 'features': data.num_features, 'classes': dataset.num_classes,
+               'hidden_dim': opt['hidden_dim'], 'heads': opt['heads'], 'attention_dim': opt['attention_dim'], 'optimizer': 'adamax'},
+    'ms_train_step': round(med(tr_t) * 1e3, 3), 'ms_test_step': round(med(te_t) * 1e3, 3),
+    'ms_train_phases_synchronised': {k: round(med(v) * 1e3, 3) for k, v in ph.items()},
+    'nfe_forward_per_epoch': fwd_nfe, 'nfe_backward_per_epoch': bwd_nfe, 'nfe_test_per_epoch': med(eval_nfe),
+    'train_solve_path': path, 'test_solve': stats_eval,
+    'final_loss': round(lv, 5), 'accuracies_last_epoch': [round(a, 4) for a in accs],
+    'reference_published': {'s_per_epoch': [1.72, 2.04], 'nfe_forward': 124, 'where': 'notebooks/visualise_attention.ipynb:132-138 (real Cora, the authors\' GPU)',
+                            'note': 'another graph (real Cora) on other hardware: context, not a baseline for vs_baseline'},
+    'roofline': None, 'roofline_note': 'launch-latency bound: the 0.8-MB state lives in one L2; there is no bandwidth roofline to quote (DESIGN.md section 4, small graphs)',
+    'cpu_baseline': None,
+  }
+  if not args.no_cpu_baseline:
+    # the oracle's right-hand side under the restated torchdiffeq controller on the host cores: ONE training forward + backward of the
+    # block in eval-mode arithmetic (no dropout), and the device block's forward against it (values + number of evaluations)
+    from oracle import restate as R
+    cpu = lambda t: t.detach().cpu()   # noqa: E731
+    blk = model.odeblock
+    lay = blk.multihead_att_layer
+    model.eval()
+    with torch.no_grad():
+      h0 = model.encode(data.x)
+      blk.set_x0(h0)
+      f.nfe = 0
+      saved = blk.test_integrator
+      blk.test_integrator = G.odeint
+      z_dev = blk(h0)
+      blk.test_integrator = saved
+      nfe_dev = int(f.nfe)
+      f.nfe = 0
+    hc = cpu(h0)
+    e_n, _ = R.get_rw_adj(ei_cpu, None, 1, 1, data.num_nodes)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ps = [cpu(p).clone().requires_grad_(True) for p in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias)]
+    hx = hc.clone().requires_grad_(True)
+    calls = [0]
+    t0 = time.perf_counter()
+    att, _ = R.transformer_attention(hx, e_n, ps[0], ps[1], ps[2], ps[3], opt['heads'], norm_idx=1, square_plus=True)
+
+    def rhs(t, yv):
+      calls[0] += 1
+      return R.rhs_laplacian(yv, e_n, att, cpu(f.alpha_train), cpu(f.beta_train), hc, False, True)
+    zr = O._solve_dopri5(rhs, hx, torch.tensor([0, opt['time']]), opt['tol_scale'] * 1e-9, opt['tol_scale'] * 1e-7)[1]
+    t_f = time.perf_counter() - t0
+    (zr ** 2).sum().backward()
+    t_cpu = time.perf_counter() - t0
+    e_inf, e_2 = R.parity_error(z_dev, zr.detach())
+    out['cpu_baseline'] = dict(host_info(), value=round(t_cpu, 4), unit='s per block forward+backward', cores=torch.get_num_threads(), kind='port',
+                               sample='ONE forward + backward of the ODE block alone (attention once + dopri5 solve, %d evaluations; no encoder / decoder / '
+                                      'optimiser / test pass): the oracle right-hand side under the restated torchdiffeq 0.2.1 controller, torch CPU autograd' % calls[0],
+                               forward_seconds=round(t_f, 4), rhs_evals=calls[0])
+    out['parity_vs_restated_torchdiffeq'] = {'rel_max': e_inf, 'rel_l2': e_2, 'rhs_evals_device': nfe_dev, 'rhs_evals_oracle': calls[0],
+                                             'same_number_of_evaluations': bool(nfe_dev == calls[0]),
+                                             'what': 'eval-mode forward of the block (plain dopri5 to T) on the device vs the CPU oracle'}
+  print(json.dumps(out))
 
 
 def train_main(G, args, opt, cfg, ei, n, x, dev):
@@ -719,6 +1023,63 @@ def train_main(G, args, opt, cfg, ei, n, x, dev):
   b_gram = n * (8 * A + 4 * d)                                               # [dq dk]^T u_y
   stage_bytes = b_rows + b_vt + b_proj + b_att + b_attb + b_dqk + b_pg + b_perm + b_gram
   t_stage = bw / (4 * K)
+  traffic, traffic_src = None, None
+  if not args.no_live_pmc and native:
+    # counter traffic of ONE adjoint stage: the per-kernel totals of a short run of this mode (two rocprofv3 --pmc passes over a child).
+    # Kernels that also run in the forward solve (projection, row attention, aggregation, folds) are charged to the backward by
+    # their share of the launches: S stages against F forward evaluations, one launch of each per evaluation / stage.
+    kc, wc = 2, 2
+    flags = ['--train', '--steps', str(kc), '--warmup', str(wc), '--graph', args.graph]
+    pmc = mode_pmc_traffic(args, flags, 'train')
+    if isinstance(pmc, dict) and 'error' not in pmc:
+      iters = max(wc, 2) + 1
+      F = S = float(iters * 4 * kc)
+      shared = ('linear_staged', 'linear_persistent', 'row_attention', 'spmm_pair', 'spmm_wide', 'spmm_rows', 'spmm_long_reduce',
+                'hub_rowpart_fold', 'normalise_heads')
+      tot, by = 0.0, {}
+      for k, v in pmc.items():
+        if k.startswith('_') or 'bytes_per_launch' not in v:
+          continue
+        b = v['fetch_bytes_total'] + v['write_bytes_total']
+        share = S / (S + F) if any(t in k for t in shared) else 1.0
+        by[k] = {'launches': v['launches'], 'bytes_per_launch': round(v['bytes_per_launch']), 'l2_hit_rate': v.get('l2_hit_rate'),
+                 'charged_to_backward': round(share, 3)}
+        tot += b * share
+      traffic = tot / S
+      traffic_src = {'how': 'measured in this run: rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes, --kernel-trace only) over '
+                            'a child process running `bench.py --train --steps %d` (%d iterations = %d forward evaluations + %d adjoint stages); bytes = '
+                            '(2 FETCH_SIZE + WRITE_SIZE) * 1024 summed over every gnpde kernel, kernels shared with the forward solve charged S / (S + F), '
+                            'per stage' % (kc, iters, int(F), int(S)),
+                     'live': True, 'seconds': pmc.get('_seconds'), 'kernels': by}
+    elif isinstance(pmc, dict):
+      traffic_src = {'live_pmc_error': pmc.get('error')}
+  resident = n * d * 4 < 2 ** 28
+  vjp_parity = None
+  if not args.no_cpu_baseline:
+    # parity of the training arithmetic at FULL size: f and its vector-Jacobian product (d/dx, d/dWq, d/dWk, d/dalpha) of one evaluation
+    # through the native backward kernels against CPU autograd through the oracle's right-hand side (float32, 32 threads)
+    from oracle import restate as R
+    lay = f.multihead_att_layer
+    cpu = lambda t: t.detach().cpu()   # noqa: E731
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    xg = x.clone().requires_grad_(True)
+    f.x0 = x
+    for p_ in block.parameters():
+      p_.grad = None
+    fv = f(0.0, xg)
+    fv.backward(c)
+    torch.cuda.synchronize()
+    xc = cpu(x).requires_grad_(True)
+    ps = [cpu(t).clone().requires_grad_(True) for t in (lay.Q.weight, lay.Q.bias, lay.K.weight, lay.K.bias, f.alpha_train, f.beta_train)]
+    t0 = time.perf_counter()
+    fr = R.rhs_transformer(xc, cpu(f.edge_index), ps[0], ps[1], ps[2], ps[3], lay.h, ps[4], ps[5], cpu(x), False, True)
+    fr.backward(cpu(c))
+    t_cpu = time.perf_counter() - t0
+    pe = R.parity_error
+    vjp_parity = {'f': pe(fv, fr.detach())[0], 'dx': pe(xg.grad, xc.grad)[0], 'dWq': pe(lay.Q.weight.grad, ps[0].grad)[0],
+                  'dWk': pe(lay.K.weight.grad, ps[2].grad)[0], 'dalpha': pe(f.alpha_train.grad.reshape(1), ps[4].grad.reshape(1))[0],
+                  'what': 'rel max error of one full-size evaluation and its VJP (native kernels) vs CPU autograd through the oracle; '
+                          'gradient bar 2e-4 (tests/test_autograd_gpu.py)', 'cpu_seconds_f_plus_vjp': round(t_cpu, 2)}
   out = {
     'metric': 'training ODE steps/sec (forward solve + adjoint backward solve), %s d=%d rk4' % (GRAPH_NAMES.get(args.graph, args.graph), d),
     'value': round(K / (fw + bw), 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
@@ -732,18 +1093,123 @@ def train_main(G, args, opt, cfg, ei, n, x, dev):
     'roofline': {'kernel': 'one stage of the adjoint solve = f + VJP + parameter gradients (projection, row attention, adjoint_rows_kernel '
                            '[aggregation + SDDMM + dots], normaliser backward, d q / d k row sums, P GEMM, permute, aggregation on the '
                            'transposed CSR, Gram + folds), timed as backward wall time / stages',
-                 'bound': 'mall' if n * d * 4 < 2 ** 28 else 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS,
-                 'unit': 'GB/s', 'frac': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
-                 'frac_is': 'frac_algorithmic: gather-model bytes of one stage / its time / 8 TB/s (no counter traffic in this mode; the '
-                            'state tables of this shape are Infinity-Cache resident)',
+                 'bound': 'mall' if resident else 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                 'unit': 'GB/s',
+                 'frac': (round(traffic / t_stage / 1e9 / HBM_PEAK_GBS, 4) if traffic is not None else
+                          (None if resident else round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4))),
+                 'frac_is': ('frac_traffic: L2 -> fabric counter bytes of one stage / its time / 8 TB/s' if traffic is not None else
+                             'null: cache-resident tables and no live counter traffic in this run; see frac_algorithmic' if resident else
+                             'frac_algorithmic'),
+                 'frac_algorithmic': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'frac_traffic': None if traffic is None else round(traffic / t_stage / 1e9 / HBM_PEAK_GBS, 4),
                  'algorithmic_bytes_per_stage': stage_bytes,
                  'bytes_by_kernel': {'adjoint_rows': b_rows, 'aggregation_transposed': b_vt, 'projection': b_proj, 'row_attention': b_att,
                                      'normaliser_backward': b_attb, 'dq_dk_row_sums': b_dqk, 'p_gemm': b_pg, 'permute': b_perm, 'gram': b_gram},
-                 'traffic': None},
-    'cpu_baseline': None,
-    'note': 'rocprofv3 --kernel-trace --stats of this command: profiles/r04_train_*_kernel_stats.csv',
+                 'traffic': None if traffic is None else round(traffic), 'traffic_source': traffic_src},
+    'cpu_baseline': None if vjp_parity is None else dict(host_info(), value=round(1.0 / (4 * vjp_parity['cpu_seconds_f_plus_vjp']), 4), unit='steps/s',
+                                                         cores=torch.get_num_threads(), kind='port',
+                                                         sample='ONE full-size evaluation of f + its VJP by torch CPU autograd through the oracle right-hand '
+                                                                'side; steps/s = 1 / (4 x that), the backward half of a training step only'),
+    'parity_vjp_one_eval_vs_oracle': vjp_parity,
+    'note': 'rocprofv3 --kernel-trace --stats of this command: profiles/r05_train_kernel_stats.csv',
   }
   print(json.dumps(out))
+
+
+CONFIG_CHILDREN = (
+  # (key, BASELINE.json reference, flags, timeout s).  Every child is this script in another mode and prints its own full JSON line;
+  # the parent keeps a summary.  Ordered so that the cheap ones are never starved by the expensive ones.
+  ('c1_cora_grand_l_euler_T4', 'configs[0] as named: Cora GRAND-l, euler, step_size 1, T = 4',
+   ['--graph', 'cora', '--function', 'laplacian', '--method', 'euler', '--steps', '4', '--warmup', '4', '--no-live-pmc', '--no-hbm-probe', '--replays', '21'], 120),
+  ('c1_cora_grand_l_rk4', 'configs[0] shape with rk4 (per-step time over 100 steps)',
+   ['--graph', 'cora', '--function', 'laplacian', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120),
+  ('c2_cora_grand_nl_rk4_row_softmax', 'configs[1]: Cora GRAND-nl scaled_dot, rk4 (A = 128, 8 heads), softmax over rows',
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120),
+  ('c2_cora_grand_nl_rk4_as_run_GNN_runs_it', 'configs[1] with best_params Cora normaliser: squareplus over columns',
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120),
+  ('cora_best_params_epoch', 'the reference\'s flagship run (best_params Cora: attention block, Laplacian, dopri5, adjoint=False): s per epoch',
+   ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240),
+  ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
+   ['--train', '--steps', '10', '--warmup', '2'], 400),
+  ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
+   ['--config', 'c4', '--warmup', '2'], 400),
+  ('c3_normalised_over_columns_squareplus', 'configs[2] shape with attention_norm_idx 1 + squareplus (the reference\'s Cora / Citeseer normaliser at scale)',
+   ['--steps', '20', '--warmup', '5', '--norm-idx', '1', '--square-plus', '--no-live-pmc', '--no-hbm-probe', '--cpu-evals', '2'], 300),
+  ('c3_arxiv_flat_no_planted_communities', 'configs[2] shape on a graph WITHOUT community structure (what relabelling gains without planted locality)',
+   ['--graph', 'arxiv_flat', '--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--cpu-evals', '2'], 300),
+  ('c3_arxiv_relabelling_off', 'configs[2] with the node relabelling switched off (GNPDE_REORDER=0)',
+   ['--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--no-cpu-baseline'], 200),
+  ('c5_rmat_one_gpu', 'configs[4] shape on ONE GPU: R-MAT 2^21 nodes, d = 256 (the 8-GPU run is the driver\'s)',
+   ['--graph', 'rmat', '--steps', '4', '--warmup', '1', '--no-live-pmc', '--no-hbm-probe'], 900),
+)
+
+
+def summarise_child(line):
+  """What the parent keeps of a child's bench line."""
+  r = line.get('roofline') or {}
+  keep = {k: line.get(k) for k in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'higher_is_better') if k in line}
+  cfg = line.get('config') or {}
+  keep['workload'] = cfg.get('workload')
+  for k in ('nodes', 'edges_with_self_loops', 'd', 'attention_dim', 'heads', 'attention_norm_idx', 'square_plus', 'native_adjoint_solver'):
+    if k in cfg:
+      keep[k] = cfg[k]
+  rel = cfg.get('node_relabelling')
+  if isinstance(rel, dict):
+    keep['node_relabelling'] = {k: rel.get(k) for k in ('order', 'entries_inside_a_part', 'gain', 'solve_equal_to_unrelabelled_bitwise') if k in rel}
+  elif 'node_relabelling' in cfg:
+    keep['node_relabelling'] = None
+  for k in ('parity_vs_oracle_one_eval', 'parity_vs_restated_torchdiffeq', 'parity_vs_oracle_row_subset', 'parity_vjp_one_eval_vs_oracle', 'speedup_vs_cpu',
+            'ms_per_forward', 'ms_solve_only', 'rhs_evals_per_forward', 'dopri5', 'forward_ms', 'backward_ms', 'f_plus_vjp_ms', 'ms_train_step', 'ms_test_step',
+            'ms_train_phases_synchronised', 'nfe_forward_per_epoch', 'nfe_backward_per_epoch', 'nfe_test_per_epoch', 'train_solve_path', 'timing'):
+    if k in line:
+      v = line[k]
+      if isinstance(v, dict) and 'what' in v:
+        v = {a: b for a, b in v.items() if a != 'what'}
+      keep[k] = v
+  if r:
+    keep['roofline'] = {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_algorithmic', 'frac_traffic', 'traffic', 'avg_launch_us',
+                                              'algorithmic_bytes_per_launch', 'algorithmic_bytes_per_stage') if k in r}
+    keep['roofline']['kernel'] = str(r.get('kernel', ''))[:90]
+  else:
+    keep['roofline'] = None
+  cb = line.get('cpu_baseline')
+  keep['cpu_baseline'] = None if not cb else {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind') if k in cb}
+  return keep
+
+
+def run_configs(args, budget_s):
+  """The other BASELINE configurations (and the variants DESIGN.md quotes), each measured NOW by a child process of this script
+  on the same GPU, so that the one line the driver records witnesses them all."""
+  import subprocess
+  t_start = time.perf_counter()
+  out = {}
+  for key, what, flags, limit in CONFIG_CHILDREN:
+    left = budget_s - (time.perf_counter() - t_start)
+    if left < 30:
+      out[key] = {'skipped': 'the configs block had used its %.0f s budget' % budget_s, 'what': what}
+      continue
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-configs', '--seed', str(args.seed)] + flags
+    env = dict(os.environ)
+    if key == 'c3_arxiv_relabelling_off':
+      env['GNPDE_REORDER'] = '0'
+    t0 = time.perf_counter()
+    try:
+      res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(limit, left))
+      line = None
+      for ln in reversed(res.stdout.splitlines()):
+        if ln.startswith('{"metric"'):
+          line = json.loads(ln)
+          break
+      if line is None:
+        out[key] = {'error': 'rc %d, no bench line; stderr tail: %s' % (res.returncode, (res.stderr or '')[-300:]), 'what': what}
+      else:
+        out[key] = dict(summarise_child(line), what=what, command='python bench.py ' + ' '.join(flags), seconds=round(time.perf_counter() - t0, 1))
+    except subprocess.TimeoutExpired:
+      out[key] = {'error': 'timed out after %.0f s' % min(limit, left), 'what': what}
+    except Exception as exc:   # noqa: BLE001
+      out[key] = {'error': repr(exc)[:300], 'what': what}
+  out['_seconds'] = round(time.perf_counter() - t_start, 1)
+  return out
 
 
 def main():
@@ -773,6 +1239,8 @@ def main():
 
   if args.config == 'c4':
     return c4_main(G, args, dev)
+  if args.config == 'cora-epoch':
+    return cora_epoch_main(G, args, dev)
   cfg = G.synthetic.CONFIGS[args.graph]
   ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
   opt = build_opt(cfg, args)
@@ -832,16 +1300,17 @@ def main():
   assert torch.isfinite(z).all()
   elapsed = sorted(times)[len(times) // 2]  # median replay
   steps_per_s = K / elapsed
+  evals_per_step = 4 if args.method == 'rk4' else 1
   f = main_block.odefunc
   E = int(f.edge_index.shape[1])
   A, h = opt['attention_dim'], opt['heads']
 
   # roofline of the dominant kernel (B_spmm = E (4 + 4 + 4d) + N (4 + 8d) + 4dN with add_source)
   if args.no_roofline_probe:
-    print(json.dumps({'metric': metric_name(args.graph, d), 'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1,
+    print(json.dumps({'metric': metric_name(args.graph, d, method=args.method), 'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1,
                       'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
                       'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                      'config': {'workload': workload_name(args.graph, args.function, K), 'graph': args.graph, 'nodes': n,
+                      'config': {'workload': workload_name(args.graph, args.function, K, args.method), 'graph': args.graph, 'nodes': n,
                                  'edges_with_self_loops': E, 'd': d, 'hipgraph': use_graph},
                       'roofline': None, 'cpu_baseline': None, 'note': 'profiling run: --no-roofline-probe'}))
     return
@@ -927,15 +1396,15 @@ def main():
   except Exception as exc:   # noqa: BLE001
     hbm_probe = {'error': repr(exc)[:200]}
   out = {
-    'metric': metric_name(args.graph, d),
+    'metric': metric_name(args.graph, d, method=args.method),
     'value': round(steps_per_s, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
     'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
     'dtype': 'f32', 'data': 'synthetic',
     'timing': {'replays': len(times), 'statistic': 'median', 'ms_per_step_min': round(1e3 * min(times) / K, 4),
                'ms_per_step_max': round(1e3 * max(times) / K, 4)},
-    'config': {'workload': workload_name(args.graph, args.function, K),
+    'config': {'workload': workload_name(args.graph, args.function, K, args.method),
                'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h,
-               'rhs_evals_per_step': 4, 'hipgraph': use_graph, 'scale': args.scale,
+               'rhs_evals_per_step': evals_per_step, 'hipgraph': use_graph, 'scale': args.scale,
                'attention_norm_idx': args.norm_idx, 'square_plus': args.square_plus,
                'early_stop_evaluator': bool(args.early_stop),
                'long_rows': graph.n_long_rows,
@@ -945,14 +1414,18 @@ def main():
                                 1: 'contiguous_eighths (forced)', 2: 'hashed_blocks (forced)'}.get(xcd_knob, '?'),
                'xcd_contiguous_imbalance': round(graph.xcd_imbalance_contiguous, 4),
                'algorithmic_bytes_per_rhs_eval': bytes_eval,
-               'eval_gbs_vs_gather_model': round(bytes_eval * 4 * steps_per_s / 1e9, 1)},
+               'eval_gbs_vs_gather_model': round(bytes_eval * evals_per_step * steps_per_s / 1e9, 1)},
     'roofline': {'kernel': kname, 'bound': 'mall' if resident else 'hbm',
                  'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                 'frac': round(frac_traffic if use_traffic else frac_alg, 4),
+                 # cache-resident table: `frac` is the counter figure or nothing -- the gather model exceeds the peak there and must not
+                 # pass for a roofline fraction (`frac_algorithmic` stays next to it); DRAM-resident table: the algorithmic fraction
+                 'frac': round(frac_traffic, 4) if use_traffic else (None if resident else round(frac_alg, 4)),
                  'frac_is': ('frac_traffic: L2 -> fabric bytes of one aggregation call (counter record, `traffic`; includes Infinity-Cache hits) / '
                              'its duration / the 8 TB/s HBM peak -- the gathered table (%.0f MiB) is resident in the 256-MiB Infinity Cache, so '
                              'the gather model (`achieved`, `frac_algorithmic`) charges cache-served rows to HBM and exceeds the peak' % state_mb)
-                 if use_traffic else 'frac_algorithmic: algorithmic bytes / duration / the 8 TB/s HBM peak (SURVEY 8d)',
+                 if use_traffic else ('null: the gathered table is cache-resident and this run has no live counter traffic (see frac_algorithmic, '
+                                      'which exceeds 1 by construction there)' if resident else
+                                      'frac_algorithmic: algorithmic bytes / duration / the 8 TB/s HBM peak (SURVEY 8d)'),
                  'frac_algorithmic': round(frac_alg, 4),
                  'frac_algorithmic_is': 'gather model (every non-zero fetches its neighbour row, no cache reuse credited) / duration / 8 TB/s'
                                         + ('; table cache-resident: not a fraction of anything physical' if resident else ''),
@@ -1008,6 +1481,10 @@ def main():
                                sample='skipped: one evaluation of the reference op sequence at this shape materialises '
                                       '[E,d] temporaries of %.0f GB each (SURVEY 8d: "reference path OOM"); pass '
                                       '--cpu-evals N to time it on a host that has the memory' % (E * d * 4 / 1e9))
+    try:
+      out['parity_vs_oracle_row_subset'] = subset_parity(main_block, x, x_cpu)
+    except Exception as exc:   # noqa: BLE001
+      out['parity_vs_oracle_row_subset'] = {'error': repr(exc)[:200]}
   elif not args.no_cpu_baseline:
     t_eval, ref, thread_trials = cpu_baseline(main_block, x_cpu, cpu_evals)
     with torch.no_grad():
@@ -1016,17 +1493,26 @@ def main():
     from oracle import restate as R
     e_inf, e_2 = R.parity_error(got, ref)
     out['cpu_baseline'] = dict(host_info(), **{
-      'value': round(1.0 / (4 * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+      'value': round(1.0 / (evals_per_step * t_eval), 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
       'threads_used': torch.get_num_threads(), 'kind': 'port',
       'kind_note': 'oracle/restate.py = the reference op sequence (index_select -> mul -> scatter_add, PyG softmax) in '
                    'torch CPU; the reference src/ itself needs /root/reference and third-party wheels that do not exist '
                    'on the GPU box',
-      'sample': '%d full-size evaluations of f (= %.1f rk4 steps) of the same workload at the torch thread count with the best median '
-                'of three evaluations (`thread_trials_ms`: median ms per evaluation by thread count); steps/s = 1 / (4 t_eval)' % (cpu_evals, cpu_evals / 4.0),
+      'sample': '%d full-size evaluations of f (= %.1f solver steps) of the same workload at the torch thread count with the best median '
+                'of three evaluations (`thread_trials_ms`: median ms per evaluation by thread count); steps/s = 1 / (%d t_eval)' % (cpu_evals, cpu_evals / float(evals_per_step), evals_per_step),
       'thread_trials_ms': thread_trials,
       'ms_per_rhs_eval': round(t_eval * 1e3, 2)})
     out['parity_vs_oracle_one_eval'] = {'rel_max': e_inf, 'rel_l2': e_2}
     out['speedup_vs_cpu'] = round(steps_per_s / out['cpu_baseline']['value'], 1)
+  default_run = (args.graph == 'arxiv' and args.function == 'transformer' and args.method == 'rk4' and args.norm_idx == 0 and not args.square_plus
+                 and not args.early_stop and args.scale == 1.0 and use_graph)
+  if default_run and not args.no_configs:
+    # free this process's device memory first: the children run on the same GPU, one at a time
+    del main_block, z, x, ei
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    out['configs'] = run_configs(args, args.configs_budget)
   print(json.dumps(out))
 
 

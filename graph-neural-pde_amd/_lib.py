@@ -21,7 +21,7 @@ STAGE_LINCOMB = 10
 ABI_VERSION = 3      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
-METHOD_EULER, METHOD_RK4 = range(2)
+METHOD_EULER, METHOD_RK4, METHOD_MIDPOINT = range(3)
 TUNE_SPMM_VARIANT, TUNE_FUSED_BLOCKS_PER_CU, TUNE_ONE_PASS, TUNE_FORK, TUNE_ATT_GENERIC_ROWS, TUNE_RK4_CLASSIC = range(6)
 TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING, TUNE_SPMM_PART, TUNE_XCD_ROWS, TUNE_HUB_FOLD = 6, 7, 8, 9, 10, 11
 

@@ -137,23 +137,32 @@ class ODEFunc(nn.Module):
       raise _lib.GnpdeError('edge_index is on %s but the state is on %s' % (ei.device, x.device))
     return graph_of(ei, x.shape[0], x.device)
 
-  def _locality_view(self, x):
+  def _locality_view(self, x, forward_solve=True):
     """graph.LocalityView the fused solves of this function run on (nodes relabelled part by part or by descending row
     length, whichever a timed aggregation prefers; results bit-identical up to the row permutation, which the solver undoes), or
     None.  opt['gnpde_reorder'] / GNPDE_REORDER: 'auto' (default: in evaluation mode, when the state does not fit the L2s and a
-    candidate is at least 2 % faster), '1' (the faster candidate, always), 'parts' / 'degree' (that order), '0' (never)."""
+    candidate is at least 2 % faster), '1' (the faster candidate, always), 'parts' / 'degree' (that order), '0' (never).
+    forward_solve=False: the caller is the BACKWARD (adjoint) solve of a training step -- it takes the decision its forward took
+    and never counts as a repeat of the edge set."""
     import os
     mode = str(self.opt.get('gnpde_reorder', os.environ.get('GNPDE_REORDER', 'auto'))).lower()
     if mode == 'auto' and self.training:
       # training forwards may hand over a NEW edge set every step (hard attention, rewiring: reference
       # src/block_transformer_hard_attention.py:55-61) -- a clustering and a timing run per step would cost more than any order
-      # can return.  So the automatic rule applies in training only from the SECOND solve on the same edge_index tensor
-      # (identity and version unchanged since the previous solve: constant / attention blocks, every epoch after the first)
+      # can return.  So the automatic rule applies in training only from the SECOND FORWARD solve on the same edge_index tensor
+      # (identity and version unchanged: constant / attention blocks, every epoch after the first).  The adjoint solve of a step
+      # is not a repeat: with a fresh edge set per step it would otherwise run the probe on every step's backward.
       ei = self.edge_index
-      key = (ei, ei._version) if ei is not None else None
-      last = self.__dict__.get('_reorder_seen')
-      self.__dict__['_reorder_seen'] = key          # (holds the tensor itself: its id cannot be reused while it is remembered)
-      if key is None or last is None or last[0] is not key[0] or last[1] != key[1]:
+      if ei is None:
+        return None
+      last = self.__dict__.get('_reorder_seen')     # (tensor, version, forward solves seen): holds the tensor, so its id stays unique
+      same = last is not None and last[0] is ei and last[1] == ei._version
+      if forward_solve:
+        count = last[2] + 1 if same else 1
+        self.__dict__['_reorder_seen'] = (ei, ei._version, count)
+      else:
+        count = last[2] if same else 0
+      if count < 2:
         return None
     return self._graph(x).locality_view(4 * int(x.shape[1]), mode)
 

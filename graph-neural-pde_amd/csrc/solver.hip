@@ -225,6 +225,22 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
       GNPDE_HIP(hipMemcpyAsync(y, cur, static_cast<size_t>(r.graph->n) * r.ld * 4, hipMemcpyDeviceToDevice, st));
     return 0;
   }
+  if (s->method == GNPDE_METHOD_MIDPOINT) {
+    // torchdiffeq Midpoint._step_func: y_mid = y + f(y) * (dt / 2);  y += dt * f(y_mid)  (second stage row-local in place on y)
+    for (float dt : s->dts) {
+      gnpde_epilogue_t e = base_epilogue(r);
+      e.stage = GNPDE_STAGE_LINCOMB; e.y = y; e.n_prev = 0; e.out_k = nullptr;
+      e.coef[0] = 0.5f * dt; e.out_y = ua;
+      int rc = enqueue_rhs(r, y, e, rws, s->L, st, fk);
+      if (rc) return rc;
+      e.coef[0] = dt; e.out_y = y;
+      rc = enqueue_rhs(r, ua, e, rws, s->L, st, fk);
+      if (rc) return rc;
+      rc = evaluate(y);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   float* ub = reinterpret_cast<float*>(s->ws + s->off_ub);
   float* k1 = reinterpret_cast<float*>(s->ws + s->off_k1);
   float* k2 = reinterpret_cast<float*>(s->ws + s->off_k2);
@@ -318,7 +334,7 @@ extern "C" int gnpde_rhs_stage(const gnpde_rhs_t* rhs, const float* u, const gnp
 
 extern "C" size_t gnpde_solver_workspace_bytes(const gnpde_rhs_t* rhs, int32_t method) {
   if (check_rhs(rhs)) return 0;
-  if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4) return 0;
+  if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4 && method != GNPDE_METHOD_MIDPOINT) return 0;
   return solver_layout(*rhs, method, nullptr);
 }
 
@@ -328,7 +344,8 @@ extern "C" int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs,
   *out = nullptr;
   int rc = check_rhs(rhs);
   if (rc) return rc;
-  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "solver_create: bad method %d", method);
+  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4 || method == GNPDE_METHOD_MIDPOINT, GNPDE_EINVAL,
+                  "solver_create: bad method %d", method);
   GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "solver_create: bad time grid");
   gnpde_solver* s = new gnpde_solver();
   s->rhs = *rhs;
@@ -349,7 +366,7 @@ extern "C" int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs,
   }
   s->ws = static_cast<char*>(workspace);
   s->ws_bytes = workspace_bytes;
-  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
+  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : method == GNPDE_METHOD_MIDPOINT ? 2 : 1);
   *out = s;
   return 0;
 }

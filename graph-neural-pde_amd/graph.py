@@ -14,7 +14,8 @@ L2_BYTES_TOTAL = 32 << 20          # 8 XCDs x 4 MiB
 LOCALITY_PART_BYTES = 5.5 * 2 ** 20   # table bytes per part of the locality relabelling (two parts per XCD at the ogbn-arxiv size)
 LOCALITY_MIN_GAIN = 1.02           # auto mode: keep the relabelled graph when a timed aggregation on it is at least this much faster
 XCD_IMBALANCE_LIMIT = 1.03   # contiguous eighths are kept while the slowest XCD has at most 3 % more than the mean
-_LOCALITY_DECISIONS = {}      # (nodes, entries, width, device) -> (best order, measured gains): one timing probe per shape and process
+_LOCALITY_DECISIONS = {}      # (nodes, entries, width, device, edge-set fingerprint) -> (best order, measured gains): one timing probe per graph and process
+_LOCALITY_DECISIONS_MAX = 64  # bounded: a block that builds a new edge set every training step must not grow it without end
 
 
 def contiguous_deal_imbalance(rowptr, row_begin, row_end):
@@ -272,11 +273,12 @@ class CSRGraph(object):
     if d not in dec:
       # one decision per (nodes, entries, width): a graph object rebuilt for the same edge set (cache eviction, a block that
       # swaps the same edges back in) reuses it instead of timing again; GNPDE_REORDER / opt['gnpde_reorder'] override it
-      memo = _LOCALITY_DECISIONS.get((self.n, self.e, d, self.device.index))
+      memo = _LOCALITY_DECISIONS.get(self._locality_memo_key(d))
       if memo is not None:
         dec[d] = memo
     if d not in dec:
       gains = {}
+      measured = True
       try:
         t_base = self._aggregation_time(d)
         for kind in ('parts', 'degree'):
@@ -289,18 +291,34 @@ class CSRGraph(object):
         self._locality.get('views', {}).clear()
         torch.cuda.empty_cache()
         gains = {'parts': 0.0, 'degree': 0.0}
+        measured = False          # a transient shortage: decided for THIS graph object only, never memoised for the shape
       best = max(gains, key=lambda k: gains[k])
       for kind in gains:                                   # the loser's CSR is state-sized at R-MAT scale: drop it
         if kind != best:
           self._locality.get('views', {}).pop(self._locality_key(kind, row_bytes), None)
       dec[d] = (best, gains)
-      _LOCALITY_DECISIONS[(self.n, self.e, d, self.device.index)] = dec[d]
+      if measured:
+        while len(_LOCALITY_DECISIONS) >= _LOCALITY_DECISIONS_MAX:      # bounded: oldest decision out (dicts keep insertion order)
+          _LOCALITY_DECISIONS.pop(next(iter(_LOCALITY_DECISIONS)))
+        _LOCALITY_DECISIONS[self._locality_memo_key(d)] = dec[d]
     best, gains = dec[d]
     if not force and gains[best] < LOCALITY_MIN_GAIN:
       return None
     view = self._locality_candidate(best, row_bytes)
     view.stats.setdefault('aggregation_speedup_measured', {})[str(d)] = {k: round(v, 4) for k, v in gains.items()}
     return view
+
+  def _locality_memo_key(self, d):
+    """Key of the process-wide decision memo: shape AND a fingerprint of the edge set (a weighted checksum of the row pointer and
+    of the column ids: another graph with the same counts does not inherit this one's decision)."""
+    fp = self._locality.get('fingerprint')
+    if fp is None:
+      rp = self.t['rowptr'].to(torch.int64)
+      ci = self.t['colidx'][:self.e].to(torch.int64)
+      wr = torch.arange(1, rp.numel() + 1, device=rp.device, dtype=torch.int64)
+      wc = torch.arange(1, ci.numel() + 1, device=ci.device, dtype=torch.int64)
+      fp = self._locality['fingerprint'] = (int((rp * wr).sum().item()) & 0xFFFFFFFFFFFF, int((ci * wc).sum().item()) & 0xFFFFFFFFFFFF)
+    return (self.n, self.e, d, self.device.index, fp)
 
   def _locality_key(self, kind, row_bytes):
     if kind == 'degree':

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 _THIRD = 1 / 3
+_EVALS_PER_STEP = {'euler': 1, 'midpoint': 2, 'rk4': 4}
 
 
 def time_grid(t, step_size):
@@ -38,7 +39,7 @@ def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None
   from . import ops
   grid = time_grid(t.detach().to('cpu'), step_size)
   dts = (grid[1:] - grid[:-1]).tolist()
-  n_evals = len(dts) * (4 if method == 'rk4' else 1)
+  n_evals = len(dts) * _EVALS_PER_STEP[method]
   # NFE guard with the reference's semantics (raise at the first evaluation that finds nfe > max_nfe)
   room = func.opt['max_nfe'] + 1 - func.nfe
   if n_evals > room:
@@ -132,7 +133,13 @@ def _solve_fixed_host(func, y0, t, method, step_size, on_step=None):
   for i in range(len(grid) - 1):
     ta, tb = grid[i], grid[i + 1]
     dt = tb - ta
-    dy = dt * func(ta, y) if method == 'euler' else _rk4_38_step(func, ta, dt, tb, y)
+    if method == 'euler':
+      dy = dt * func(ta, y)
+    elif method == 'midpoint':      # torchdiffeq fixed_grid.py Midpoint._step_func
+      half = 0.5 * dt
+      dy = dt * func(ta + half, y + func(ta, y) * half)
+    else:
+      dy = _rk4_38_step(func, ta, dt, tb, y)
     y_next = y + dy
     while j < len(t) and tb >= t[j]:
       if t[j] == tb:
@@ -253,14 +260,16 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
           on_accept(y, float(t_cur))
       elif on_reject is not None:
         on_reject(y, float(t_cur))
-      # step-size controller
-      if ratio == 0:
-        dt = dt * ifactor
-      else:
-        lo = 1.0 if ratio < 1 else dfactor
-        r = ratio.to(torch.float64)
-        factor = torch.clamp(safety / r ** (1.0 / order), min=lo, max=ifactor)
-        dt = dt * factor
+      # step-size controller: torchdiffeq 0.2.1 computes the next step size under torch.no_grad (misc.py _optimal_step_size), so a
+      # differentiated solve (opt['adjoint'] = False) treats every step size after the first as a constant of the backward pass
+      with torch.no_grad():
+        if ratio == 0:
+          dt = dt * ifactor
+        else:
+          lo = 1.0 if ratio < 1 else dfactor
+          r = ratio.to(torch.float64)
+          factor = torch.clamp(safety / r ** (1.0 / order), min=lo, max=ifactor)
+          dt = dt * factor
       n_steps += 1
     if stop_after is not None and n_steps >= stop_after:   # EarlyStopDopri5.advance: the state where it stopped
       out[i] = y
@@ -487,13 +496,15 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
     return _solve_tuple(odeint, func, y0, t, dict(rtol=rtol, atol=atol, method=method, options=options, use_graph=use_graph))
   options = dict(options or {})
   method = 'dopri5' if method is None else method
-  if method in ('euler', 'rk4'):
+  if method in ('euler', 'rk4', 'midpoint'):
     step_size = options.get('step_size', None)
     if step_size is None:
       raise ValueError('fixed-grid methods need options["step_size"]')
     if _native_ok(func, y0, t):
       from . import distributed as D
       if D.shard_requested(func):     # one process per GPU, rows partitioned over the ranks (distributed.solve_sharded)
+        if method == 'midpoint':
+          raise _lib.GnpdeError('gnpde_shard: the row-partitioned solver runs euler, rk4, dopri5 and adaptive_heun; unset gnpde_shard for midpoint')
         return D.solve_sharded(func, y0, t, method, step_size, use_graph=use_graph)
       return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
     return _solve_fixed_host(func, y0, t, method, step_size)
@@ -514,7 +525,7 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
     return _solve_dopri5(func, y0, t, rtol, atol, norm=options.get('norm'))
   if method == 'adaptive_heun':
     return _solve_dopri5(func, y0, t, rtol, atol, tableau='adaptive_heun', norm=options.get('norm'))
-  raise ValueError('unsupported method %r (euler, rk4, dopri5, adaptive_heun)' % (method,))
+  raise ValueError('unsupported method %r (euler, midpoint, rk4, dopri5, adaptive_heun)' % (method,))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -622,7 +633,7 @@ def _adjoint_native(func, params, y, a, span, method, step_size):
     func.nfe += max(room, 0)
     raise MaxNFEException
   st = func.__dict__.setdefault('_adjoint_state', {})
-  view = func._locality_view(y) if hasattr(func, '_locality_view') else None
+  view = func._locality_view(y, forward_solve=False) if hasattr(func, '_locality_view') else None
   key = (method, tuple(dts), tuple(y.shape), str(y.device), id(view))
   ent = st.get(key)
   if ent is None:

@@ -15,6 +15,9 @@ def _scalar_dev(t, like):
   return t.reshape(-1)
 
 
+_PAD_X, _PAD_W = {}, {}
+
+
 def linear(x, weight, bias=None, out=None, relu_input=False):
   """out = x @ weight.T + bias on the fp32 matrix cores (gnpde_linear); relu_input: out = relu(x) @ weight.T + bias
   (gnpde_relu_linear, the decoder of GNN.forward).  x may have padded rows (unit column stride)."""
@@ -33,11 +36,26 @@ def linear(x, weight, bias=None, out=None, relu_input=False):
     # guarded scalar-load variant -- 383 us against ~60 at the ogbn-arxiv shape.  Zero-padded copies of both operands (K up to the
     # next multiple of 16) add exact zeros to every dot product and put the product on the fast kernels.
     d16 = (d + 15) // 16 * 16
-    xp = torch.zeros(n, d16, dtype=torch.float32, device=x.device)
+    # the padded operand buffers are kept (one per shape and device; the padding columns are zeroed once and never written again):
+    # this sits on the training path, once per evaluation -- ~119 MB of allocation + memset per call at the ogbn-arxiv BLEND shape
+    key = (n, d, d16, str(x.device))
+    xp = _PAD_X.get(key)
+    if xp is None:
+      if len(_PAD_X) >= 4:
+        _PAD_X.clear()
+      xp = _PAD_X[key] = torch.zeros(n, d16, dtype=torch.float32, device=x.device)
     xp[:, :d].copy_(x)
-    wp = torch.zeros(m, d16, dtype=torch.float32, device=x.device)
-    wp[:, :d].copy_(weight)
-    x, weight, d = xp, wp, d16
+    try:
+      ver = weight._version
+    except RuntimeError:        # inference tensors have no version counter: never reuse
+      ver = object()
+    wkey = (weight.data_ptr(), ver, tuple(weight.shape), str(weight.device))
+    hit = _PAD_W.get('w')
+    if hit is None or hit[0] != wkey or hit[1] is not weight:
+      wp = torch.zeros(m, d16, dtype=torch.float32, device=x.device)
+      wp[:, :d].copy_(weight)
+      _PAD_W['w'] = hit = (wkey, weight, wp)     # (holds `weight`: its address cannot be reused while it is the key)
+    x, weight, d = xp, hit[2], d16
   check(fn(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out), out.stride(0), stream_of(x)))
   return out
 
@@ -567,11 +585,11 @@ class EarlyStopEvaluator(object):
 
 
 class FixedStepSolver(object):
-  """gnpde_solver_t: euler / rk4 over a fixed grid, the whole loop captured in one hipGraph."""
+  """gnpde_solver_t: euler / midpoint / rk4 over a fixed grid, the whole loop captured in one hipGraph."""
 
   def __init__(self, desc, method, dts, device):
     self.desc = desc
-    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
+    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4, 'midpoint': _lib.METHOD_MIDPOINT}[method]
     self.dts = [float(v) for v in dts]
     L = _lib.lib()
     nbytes = L.gnpde_solver_workspace_bytes(desc.ref(), self.method)

@@ -388,7 +388,9 @@ enum { GNPDE_RHS_LAPLACIAN = 0, GNPDE_RHS_TRANSFORMER = 1, GNPDE_RHS_GAT = 2 };
  * input, x0, y, k*, outputs) are padding that may be read and overwritten -- lets a state width that is not a multiple of
  * 4 (BLEND ogbn-arxiv: d = 162, reference best_params feat_hidden_dim 64 + pos_enc_hidden_dim 98) use 16-byte lanes. */
 #define GNPDE_RHS_PADDED_ROWS 1
-enum { GNPDE_METHOD_EULER = 0, GNPDE_METHOD_RK4 = 1 };
+/* MIDPOINT (torchdiffeq fixed_grid.py Midpoint, advertised by the reference at src/run_GNN.py:330): y + dt f(y + (dt / 2) f(y)),
+ * two evaluations per step, both as GNPDE_STAGE_LINCOMB stages; gnpde_solver_* only. */
+enum { GNPDE_METHOD_EULER = 0, GNPDE_METHOD_RK4 = 1, GNPDE_METHOD_MIDPOINT = 2 };
 
 typedef struct gnpde_rhs {
   int32_t kind;               /* GNPDE_RHS_*                                                   */

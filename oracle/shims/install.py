@@ -357,6 +357,15 @@ class Euler(FixedGridODESolver):
     return dt * func(t0, y0)
 
 
+class Midpoint(FixedGridODESolver):
+  order = 2
+
+  def _step_func(self, func, t0, dt, t1, y0):
+    half_dt = 0.5 * dt
+    y_mid = y0 + func(t0, y0) * half_dt
+    return dt * func(t0 + half_dt, y_mid)
+
+
 class RK4(FixedGridODESolver):
   order = 4
 
@@ -425,6 +434,7 @@ def _compute_error_ratio(error_estimate, rtol, atol, y0, y1, norm):
   return norm(error_estimate / error_tol)
 
 
+@torch.no_grad()          # torchdiffeq 0.2.1 misc.py: the controller is not differentiated
 def _optimal_step_size(last_step, error_ratio, safety, ifactor, dfactor, order):
   if error_ratio == 0:
     return last_step * ifactor
@@ -436,15 +446,30 @@ def _optimal_step_size(last_step, error_ratio, safety, ifactor, dfactor, order):
   return last_step * factor
 
 
+class _UncheckedAssign(torch.autograd.Function):
+  """torchdiffeq 0.2.1 rk_common.py: writes a stage derivative into the scratch tensor `k` without bumping its version counter, so
+  that a differentiated solve (no adjoint) can save slices of `k` for the backward pass while later stages are still written."""
+
+  @staticmethod
+  def forward(ctx, scratch, value, index):
+    ctx.index = index
+    scratch.data[index] = value
+    return scratch
+
+  @staticmethod
+  def backward(ctx, grad_scratch):
+    return grad_scratch, grad_scratch[ctx.index], None
+
+
 def _runge_kutta_step(func, y0, f0, t0, dt, t1, tableau):
   t0, dt, t1 = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
   k = torch.empty(*f0.shape, len(tableau.alpha) + 1, dtype=y0.dtype, device=y0.device)
-  k[..., 0] = f0
+  k = _UncheckedAssign.apply(k, f0, (..., 0))
   for i, (alpha_i, beta_i) in enumerate(zip(tableau.alpha, tableau.beta)):
     ti = t1 if alpha_i == 1. else t0 + alpha_i.to(y0.dtype) * dt
     yi = y0 + k[..., :i + 1].matmul(beta_i.to(y0.dtype) * dt).view_as(f0)
     f = func(ti, yi)
-    k[..., i + 1] = f
+    k = _UncheckedAssign.apply(k, f, (..., i + 1))
   if not (tableau.c_sol[-1] == 0 and (tableau.c_sol[:-1] == tableau.beta[-1]).all()):
     yi = y0 + k.matmul(dt * tableau.c_sol.to(y0.dtype)).view_as(f0)
   y1 = yi
@@ -566,7 +591,7 @@ class AdaptiveHeunSolver(RKAdaptiveStepsizeODESolver):
   mid = torch.tensor([0.5, 0.], dtype=torch.float64)
 
 
-SOLVERS = {'euler': Euler, 'rk4': RK4, 'dopri5': Dopri5Solver, 'adaptive_heun': AdaptiveHeunSolver}
+SOLVERS = {'euler': Euler, 'midpoint': Midpoint, 'rk4': RK4, 'dopri5': Dopri5Solver, 'adaptive_heun': AdaptiveHeunSolver}
 
 
 class _TupleFunc(torch.nn.Module):
