@@ -18,7 +18,7 @@ LONG_ROW = 512
 STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 STAGE_RK1C, STAGE_RK2C, STAGE_RK3C, STAGE_RK4C = range(6, 10)
 STAGE_LINCOMB = 10
-ABI_VERSION = 3      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
+ABI_VERSION = 4      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4, METHOD_MIDPOINT = range(3)
@@ -171,6 +171,13 @@ PROTOTYPES = {
                                                  ctypes.c_int32]),
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_dopri5_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
+  'gnpde_dopri5_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, ctypes.c_int32]),
+  'gnpde_dopri5_tape_steps': (ctypes.c_int, [c_vp]),
+  'gnpde_dopri5_tape_record': (ctypes.c_int, [c_vp, c_float_p, ctypes.c_int32, c_float_p]),
+  'gnpde_dopri5_tape_backward_workspace_bytes': (ctypes.c_size_t, [c_vp, ctypes.POINTER(GraphStruct)]),
+  'gnpde_dopri5_tape_backward': (ctypes.c_int, [c_vp, ctypes.POINTER(GraphStruct), c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp, c_vp, c_vp, c_vp,
+                                                ctypes.c_size_t, c_vp]),
   'gnpde_two_hop_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32]),
   'gnpde_two_hop_count': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_two_hop_fill': (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp,

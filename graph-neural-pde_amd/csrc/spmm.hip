@@ -1293,6 +1293,8 @@ struct AdjRowsArgs {
   const float* __restrict__ g;     // [n, ld] adjoint-side stage input
   float* __restrict__ r;           // [e] out
   float* __restrict__ dots;        // [gridDim.x + n_long_rows][2] out: per-wave sums of g . F and g . x0
+  int r_accumulate;                // != 0: r[e] += (every entry belongs to exactly one lane of one launch: no race); the recorded
+                                   // dopri5 backward sums the edge products of all its evaluations this way
 };
 
 template <int N, int MASK>
@@ -1395,7 +1397,10 @@ __device__ __forceinline__ void adjoint_item(const AdjRowsArgs& fa, int row, int
 #pragma unroll
       for (int m = LPE / 2; m >= 1; m >>= 1) p[0] += __shfl_xor(p[0], m, kWave);
       const int idx = t0 + (cl / LPE) * G + sub;
-      if ((cl % LPE) == 0 && idx < cnt) fa.r[base + idx] = p[0];
+      if ((cl % LPE) == 0 && idx < cnt) {
+        if (fa.r_accumulate) fa.r[base + idx] += p[0];
+        else fa.r[base + idx] = p[0];
+      }
     }
   }
 #pragma unroll
@@ -1508,7 +1513,7 @@ int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d) {
 
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
-                        bool padded_rows) {
+                        bool padded_rows, bool accumulate_r) {
   GNPDE_CHECK_ARG(g && u && gvec && epi && r_out && dots && (w_csr || g->e == 0), GNPDE_EINVAL, "adjoint_rows: null pointer");
   const int stg = epi->stage;
   GNPDE_CHECK_ARG((stg == GNPDE_STAGE_LINCOMB || stg == GNPDE_STAGE_EULER || (stg >= GNPDE_STAGE_RK1C && stg <= GNPDE_STAGE_RK4C)) &&
@@ -1541,7 +1546,7 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
   const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->k1, epi->out_k, epi->out_y, stg == GNPDE_STAGE_LINCOMB ? epi->prev[0] : nullptr,
                         stg == GNPDE_STAGE_LINCOMB ? epi->prev[1] : nullptr, stg == GNPDE_STAGE_LINCOMB ? epi->prev[2] : nullptr};
   for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
-  fa.g = gvec; fa.r = r_out; fa.dots = dots;
+  fa.g = gvec; fa.r = r_out; fa.dots = dots; fa.r_accumulate = accumulate_r ? 1 : 0;
   const unsigned grid = adjoint_rows_grid(g);
   const int slots = (d + 3) / 4;
   if (slots <= 16) hipLaunchKernelGGL((adjoint_rows_kernel<16, 8>), dim3(grid), dim3(kWave), 0, stream, fa);

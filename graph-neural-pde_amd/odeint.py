@@ -460,6 +460,134 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
   return out
 
 
+# --------------------------------------------------------------------------------------------------
+# recorded dopri5: training WITHOUT the adjoint method (reference default opt['adjoint'] = False; best_params Cora / Citeseer)
+# --------------------------------------------------------------------------------------------------
+_TAPE_BUDGET_BYTES = 8 << 30     # first tape allocation (it grows when a solve accepts more steps than it holds)
+
+
+def _recorded_ok(func, y0, t, options):
+  """The differentiated dopri5 solve runs as ONE recorded device solve + ONE native reverse sweep (csrc/dopri5.hip,
+  gnpde_dopri5_set_tape / _tape_backward) for the Laplacian function -- f is linear in the state, its weights are constants of
+  the solve that may carry gradients (attention block) -- with alpha' = sigmoid(alpha_train).  Everything else keeps the host
+  loop `_solve_dopri5` over the kernel-backed autograd Functions of autograd.py."""
+  if func.__class__.__name__ != 'LaplacianODEFunc' or not hasattr(func, '_descriptor'):
+    return False
+  if not (y0.is_cuda and y0.dim() == 2 and y0.dtype == torch.float32 and y0.shape[1] <= 256 and len(t) == 2 and t.dtype == torch.float32):
+    return False
+  opt = func.opt
+  if opt.get('no_alpha_sigmoid') or opt.get('gnpde_host_dopri5_training') or opt.get('gnpde_composite_backward'):
+    return False
+  if os.environ.get('GNPDE_HOST_DOPRI5_TRAINING', '0') == '1':      # A/B runs (bench.py --config cora-epoch)
+    return False
+  if options.get('norm') is not None or options.get('host_controller') or options.get('eager_stages'):
+    return False
+  return torch.is_grad_enabled() and func._needs_grad(y0)
+
+
+class _RecordedDopri5(torch.autograd.Function):
+  """Forward: the device-controlled dopri5 solve (one hipGraph per trial step) that leaves the stage inputs of every ACCEPTED step
+  on a tape.  Backward: what autograd does through torchdiffeq's accepted steps (step sizes constants: misc.py _optimal_step_size
+  is decorated with torch.no_grad), as one native reverse sweep -- one fused row-kernel launch per evaluation, no PyTorch op and no
+  host synchronisation inside (oracle/tape_reverse.py states the algebra; tests/test_tape_gpu.py)."""
+
+  @staticmethod
+  def forward(ctx, y0, edge_values, alpha_train, beta_train, func, t0, t1, rtol, atol):
+    from . import ops
+    from .utils import MaxNFEException
+    room = func.opt['max_nfe'] + 1 - func.nfe
+    if room <= 0:
+      raise MaxNFEException
+    y0c = _lib.f32c(y0.detach())
+    n, d = y0c.shape
+    st = func.__dict__.setdefault('_tape_state', {})
+    key = (n, d, str(y0c.device), float(rtol), float(atol))
+    ent = st.get(key)
+    if ent is None:
+      for old in st.values():
+        if old.get('solver') is not None:
+          old['solver'].close()
+      st.clear()
+      ent = st[key] = {'y': _lib.alloc_state(n, d, y0c.device),
+                       'x0': _lib.alloc_state(n, d, y0c.device) if func.opt['add_source'] else None, 'solver': None, 'sig': None}
+    if ent['x0'] is not None:
+      if func.x0 is None:
+        raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+      ent['x0'].copy_(func.x0.detach())
+    graph = func._graph(y0c)
+    desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=graph)      # (refreshes the CSR-ordered weights in place)
+    sig = func._descriptor_signature(desc)
+    if ent['solver'] is None or ent['sig'] != sig:
+      if ent['solver'] is not None:
+        ent['solver'].close()
+      ent['solver'] = ops.Dopri5Solver(desc, rtol, atol, y0c.device)
+      ent['sig'] = sig
+      state_bytes = max(n * desc.struct.ld * 4, 1)
+      ent['solver'].set_tape(int(max(8, min(64, _TAPE_BUDGET_BYTES // (6 * state_bytes)))))
+    sol = ent['solver']
+    out = torch.empty((2, n, d), dtype=torch.float32, device=y0c.device)
+    out[0].copy_(y0c)
+    tps = 8 if y0c.numel() < (1 << 22) else 1
+    while True:
+      try:
+        finished = sol.run(y0c, t0, t1, out[1], trials_per_sync=tps, max_evals=room)
+        break
+      except _lib.GnpdeError as exc:
+        if 'do not fit the tape' not in str(exc):
+          raise
+        torch.cuda.synchronize(y0c.device)
+        sol.set_tape(2 * sol.tape_capacity)           # more accepted steps than slots: a longer tape, and the solve again
+    stats = sol.stats()
+    func._dopri5_stats = dict(stats, recorded=True)
+    spent = stats['evals']
+    if not finished or spent > room:
+      func.nfe += min(spent, room)
+      raise MaxNFEException
+    func.nfe += spent
+    sol.tape_generation += 1
+    gt, t_from_csr = graph.transposed_positions()
+    w_csr = func._weights_csr(graph)
+    w_t = torch.index_select(w_csr[:graph.e], 0, t_from_csr[:graph.e].long()) if graph.e > 0 else w_csr
+    ctx.func, ctx.sol, ctx.gen, ctx.gt, ctx.e = func, sol, sol.tape_generation, gt, graph.e
+    ctx.x0 = ent['x0']
+    ctx.x0_version = None if ent['x0'] is None else ent['x0']._version
+    ctx.heads = edge_values.shape[1] if edge_values.dim() == 2 else 0
+    ctx.save_for_backward(w_t, alpha_train, beta_train)
+    func._last_train_solve = 'native recorded-tape dopri5'
+    return out
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    w_t, alpha_train, beta_train = ctx.saved_tensors
+    sol, gt, E = ctx.sol, ctx.gt, ctx.e
+    if sol.handle is None or sol.tape_generation != ctx.gen:
+      raise _lib.GnpdeError('recorded dopri5: the tape of this forward pass was overwritten by a later solve of the same function '
+                            '(backward must run before the next training forward; opt["gnpde_host_dopri5_training"] = True keeps a tape per forward)')
+    need = ctx.needs_input_grad
+    with torch.no_grad():
+      g1 = grad_out[1].contiguous()
+      gy0, r_t, sum_g, dot = sol.tape_backward(gt, w_t, g1)
+      a = torch.sigmoid(alpha_train.detach().reshape(()))
+      dy0 = gy0 + grad_out[0] if need[0] else None
+      dw = None
+      if need[1] and E > 0:
+        dw_e = torch.empty(E, dtype=torch.float32, device=g1.device)
+        dw_e[gt.perm_long] = a * r_t[:E]
+        dw = (dw_e / ctx.heads).unsqueeze(1).expand(E, ctx.heads).contiguous() if ctx.heads else dw_e
+      dalpha = (dot.reshape(()) * (1 - a)).reshape(alpha_train.shape) if need[2] else None
+      dbeta = None
+      if need[3] and ctx.x0 is not None:
+        if ctx.x0._version != ctx.x0_version:
+          raise _lib.GnpdeError('recorded dopri5: the source term of this forward pass was overwritten before its backward')
+        dbeta = (sum_g * ctx.x0).sum().reshape(beta_train.shape)
+    return dy0, dw, dalpha, dbeta, None, None, None, None, None
+
+
+def _solve_dopri5_recorded(func, y0, t, rtol, atol):
+  return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, float(t[0]), float(t[-1]), float(rtol),
+                               float(atol))
+
+
 class _TupleFunc(object):
   """A function of a tuple state seen as a function of the flattened concatenation (torchdiffeq misc.py _TupleFunc):
   the regularised training state (x, r_1, ..., r_k) of reference src/block_constant.py:40-43."""
@@ -518,6 +646,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
       raise _lib.GnpdeError('gnpde_shard is set but this %s solve cannot run row-partitioned (float32 [n, d] state on a HIP device, two '
                             'output times, no autograd) -- unset gnpde_shard for it' % method)
   if method == 'dopri5':
+    if _recorded_ok(func, y0, t, options):      # training without the adjoint method: recorded solve + native reverse sweep
+      return _solve_dopri5_recorded(func, y0, t, rtol, atol)
     if _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False):
       if options.get('eager_stages', False):      # controller on the host, one scalar read per trial step
         return _solve_dopri5_native(func, y0, t, rtol, atol)

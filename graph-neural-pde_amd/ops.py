@@ -445,6 +445,55 @@ class Dopri5Solver(object):
                                         ptr(self.times), cap, int(max_trial_steps)))
     self.evaluator, self.max_trial_steps = evaluator, int(max_trial_steps)
 
+  # ---- recorded solve (training without the adjoint method): gnpde_dopri5_set_tape / _tape_backward ---------------------------
+  def set_tape(self, capacity_steps):
+    """Record the accepted steps of the following runs (None / 0 detaches).  The tape is zero-filled device memory owned here."""
+    L = _lib.lib()
+    if not capacity_steps:
+      check(L.gnpde_dopri5_set_tape(self.handle, None, 0, 0))
+      self.tape, self.tape_capacity = None, 0
+      return
+    nbytes = int(L.gnpde_dopri5_tape_bytes(self.desc.ref(), int(capacity_steps)))
+    if nbytes == 0:
+      raise _lib.GnpdeError('recorded dopri5: %s' % L.gnpde_last_error().decode(errors='replace'))
+    self.tape = None          # (the old tape is released before the new one is allocated)
+    self.tape = torch.zeros(nbytes, dtype=torch.uint8, device=self.ws.device)
+    check(L.gnpde_dopri5_set_tape(self.handle, ptr(self.tape), self.tape.numel(), int(capacity_steps)))
+    self.tape_capacity = int(capacity_steps)
+    self.tape_generation = 0
+
+  def tape_steps(self):
+    return int(_lib.lib().gnpde_dopri5_tape_steps(self.handle))
+
+  def tape_record(self):
+    """([h of every accepted step of the last recorded run], x = fraction of the last step at which the end time lies)."""
+    n = self.tape_steps()
+    hs = (ctypes.c_float * max(n, 1))()
+    x = ctypes.c_float(0.0)
+    check(_lib.lib().gnpde_dopri5_tape_record(self.handle, hs, n, ctypes.byref(x)))
+    return [float(hs[i]) for i in range(n)], float(x.value)
+
+  def tape_backward(self, graph_t, w_t, grad_out):
+    """(dL/dy0 [n, d], r_t [e] in graph_t's CSR order, sum_g [n, ld], dot [1]) of the last recorded run; no host synchronisation."""
+    require_hip(grad_out, w_t)
+    L = _lib.lib()
+    g = _lib.f32rows(grad_out, 'grad_out')
+    n, d = g.shape
+    ld = self.desc.struct.ld
+    dev = g.device
+    nbytes = int(L.gnpde_dopri5_tape_backward_workspace_bytes(self.handle, graph_t.ref()))
+    ws = getattr(self, '_sweep_ws', None)
+    if ws is None or ws.numel() < nbytes:
+      self._sweep_ws = None
+      ws = self._sweep_ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    gy0 = torch.empty(n, d, dtype=torch.float32, device=dev)
+    r_t = torch.empty(max(graph_t.e, 1), dtype=torch.float32, device=dev)
+    sum_g = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    dot = torch.empty(1, dtype=torch.float32, device=dev)
+    check(L.gnpde_dopri5_tape_backward(self.handle, graph_t.ref(), ptr(w_t), ptr(g), g.stride(0), ptr(gy0), gy0.stride(0), ptr(r_t),
+                                       ptr(sum_g), ptr(dot), ptr(ws), ws.numel(), stream_of(g)))
+    return gy0, r_t, sum_g[:, :d], dot
+
   def stats(self):
     v = [ctypes.c_int32(0) for _ in range(5)]
     check(_lib.lib().gnpde_dopri5_stats(self.handle, *[ctypes.byref(x) for x in v]))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 3   /* 2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 4   /* 4: gnpde_dopri5_set_tape / _tape_backward, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -560,6 +560,33 @@ int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decoder_t* dec, i
 int gnpde_dopri5_stats(const gnpde_dopri5_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected, int32_t* n_launches,
                        int32_t* n_syncs);
 int gnpde_dopri5_destroy(gnpde_dopri5_t* s);
+/* Recorded solve + reverse sweep  [replaces what torch autograd does when the reference trains with opt['adjoint'] = False -- its
+ * default, and its Cora / Citeseer best_params (src/base_classes.py:44-47, src/best_params.py) -- i.e. `loss.backward()` through
+ * every accepted step of torchdiffeq's dopri5 (rk_common.py _runge_kutta_step, interp.py), with the step sizes constants of the
+ * backward pass (misc.py _optimal_step_size runs under torch.no_grad)].  GRAND-l descriptors only (f linear in the state; the
+ * edge weights are constants of the solve that carry gradients: src/block_transformer_attention.py:36-72).
+ *   gnpde_dopri5_set_tape       ZERO-FILLED device memory of gnpde_dopri5_tape_bytes(rhs, capacity_steps) bytes, 256-byte aligned;
+ *                               every ACCEPTED trial step of the following runs leaves its stage inputs u_0..u_5 (and y1 as u_0 of
+ *                               the next slot) and its step size there (one copy kernel inside the captured trial step, gated by the
+ *                               controller record).  A run that accepts more than capacity_steps steps returns GNPDE_EWS.  NULL
+ *                               detaches.  Call between runs (drops the captured trial steps).
+ *   gnpde_dopri5_tape_steps     accepted steps of the last recorded run that reached t1 (0: nothing to differentiate)
+ *   gnpde_dopri5_tape_backward  given dL/d(y_out) of the LAST run (grad_out [n, ld_go]): dL/dy0 -> grad_y0 [n, ld_gy0];
+ *                               r_t [e] = sum over all 6 S + 1 evaluations k = f(u) of  u[row'] . G[col']  in the CSR order of
+ *                               graph_t (G = gradient reaching k): dL/dw_e = alpha' r; sum_g [n, ld] = sum of the G (dL/dbeta =
+ *                               <sum_g, x0>); dot_out[0] = sum <G, k - beta x0> (dL/dalpha_train = that * (1 - alpha') under the
+ *                               sigmoid).  graph_t / w_t: the transposed graph (gnpde_graph_t of the flipped edge list) and the weights
+ *                               of the descriptor in ITS CSR order.  One launch of the fused row kernel per evaluation + two small
+ *                               combinations per step, no host synchronisation; the algebra is written out in oracle/tape_reverse.py. */
+size_t gnpde_dopri5_tape_bytes(const gnpde_rhs_t* rhs, int32_t capacity_steps);
+int gnpde_dopri5_set_tape(gnpde_dopri5_t* s, void* tape, size_t tape_bytes, int32_t capacity_steps);
+int gnpde_dopri5_tape_steps(const gnpde_dopri5_t* s);
+/* host arrays: the float32 step sizes of the accepted steps of the last recorded run and the fraction of the last step at which t1 lies */
+int gnpde_dopri5_tape_record(const gnpde_dopri5_t* s, float* h_out, int32_t capacity, float* x_out);
+size_t gnpde_dopri5_tape_backward_workspace_bytes(const gnpde_dopri5_t* s, const gnpde_graph_t* graph_t);
+int gnpde_dopri5_tape_backward(gnpde_dopri5_t* s, const gnpde_graph_t* graph_t, const float* w_t, const float* grad_out,
+                               int32_t ld_go, float* grad_y0, int32_t ld_gy0, float* r_t, float* sum_g, float* dot_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU halo exchange helpers (row-partitioned graph, one process per GPU, RCCL between).

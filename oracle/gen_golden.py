@@ -526,6 +526,52 @@ def gen_regularised():
     print('    regs %s nfe %d' % ([float(r.mean()) for r in regs], block.reg_odefunc.odefunc.nfe))
 
 
+def gen_training():
+  """Training-mode block forward + `loss.backward()` WITHOUT the adjoint method (opt['adjoint'] = False, the reference's default and
+  its Cora / Citeseer best_params): torch autograd runs back through every accepted step of the restated torchdiffeq dopri5
+  (oracle/shims: rk_common's _UncheckedAssign, the controller under no_grad) or through the fixed grid.  Records the output, the
+  gradient of <z, c> with respect to the input and to every parameter that receives one, and the evaluation count."""
+  n, d = 140, 24
+  ei = make_graph(n, 6, 71)
+  g = torch.Generator().manual_seed(72)
+  x = torch.randn(n, d, generator=g)
+  c = torch.randn(n, d, generator=g)
+  cases = {
+    # best_params Cora in miniature: attention block, squareplus over columns, 8 heads
+    'attention_laplacian_dopri5_cora': dict(block='attention', function='laplacian', method='dopri5', time=4.0, tol_scale=800.0,
+                                            square_plus=True, attention_norm_idx=1, heads=8, attention_dim=32),
+    'attention_laplacian_dopri5_softmax_rows': dict(block='attention', function='laplacian', method='dopri5', time=2.5, tol_scale=50.0,
+                                                    add_source=False),
+    'constant_laplacian_dopri5': dict(block='constant', function='laplacian', method='dopri5', time=3.0, tol_scale=200.0),
+    'constant_laplacian_midpoint': dict(block='constant', function='laplacian', method='midpoint', time=2.3, step_size=0.5),
+    'constant_transformer_midpoint': dict(block='constant', function='transformer', method='midpoint', time=2.0),
+  }
+  for i, (name, over) in enumerate(cases.items()):
+    opt = {**BASE, **over}
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt}[opt['function']]
+    bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
+    block = bcls(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
+    randomise(block, 900 + i)
+    block.eval()
+    block.set_x0(x)
+    with torch.no_grad():
+      z_eval = block(x)
+    block.odefunc.nfe = 0
+    block.train()
+    xin = x.clone().requires_grad_(True)
+    block.set_x0(xin)
+    z = block(xin)
+    nfe = block.odefunc.nfe
+    (z * c).sum().backward()
+    rec = {'edge_index': ei, 'x': x, 'c': c, 'z': z, 'z_eval': z_eval, 'grad_x': xin.grad, 'nfe': np.int64(nfe),
+           'nfe_after_backward': np.int64(block.odefunc.nfe)}
+    for k, p in block.named_parameters():
+      if p.grad is not None:
+        rec['grad/' + k] = p.grad
+    save('train_' + name, opt, rec, block)
+    print('    nfe forward %d (after backward %d); grads: %s' % (nfe, block.odefunc.nfe, ', '.join(k[5:] for k in rec if k.startswith('grad/'))))
+
+
 if __name__ == '__main__':
   if len(sys.argv) > 1:          # regenerate selected groups only: python oracle/gen_golden.py regularised
     for name in sys.argv[1:]:
@@ -543,3 +589,4 @@ if __name__ == '__main__':
   gen_early()
   gen_adjoint()
   gen_regularised()
+  gen_training()

@@ -271,7 +271,7 @@ def time_grid(T, step_size, dtype=torch.float32):
 
 
 def odeint_fixed(func, y0, T, step_size=1.0, method='rk4'):
-  """y(T) of dy/dt = func(t, y) with torchdiffeq's `euler` or `rk4` (= 3/8-rule
+  """y(T) of dy/dt = func(t, y) with torchdiffeq's `euler`, `midpoint` or `rk4` (= 3/8-rule
   `rk4_alt_step_func`, confirmed by early_stop_solver.py:10,150-155)."""
   grid = time_grid(T, step_size, y0.dtype)
   y = y0
@@ -280,6 +280,9 @@ def odeint_fixed(func, y0, T, step_size=1.0, method='rk4'):
     dt = t1 - t0
     if method == 'euler':
       dy = dt * func(t0, y)
+    elif method == 'midpoint':     # torchdiffeq fixed_grid.py Midpoint._step_func [3P]
+      half = 0.5 * dt
+      dy = dt * func(t0 + half, y + func(t0, y) * half)
     elif method == 'rk4':
       k1 = func(t0, y)
       k2 = func(t0 + dt * third, y + dt * k1 * third)

@@ -112,6 +112,44 @@ def dopri5_record(f, y0, T, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2):
   return out, {'steps': steps, 'x': x, 'nfe': nfe[0]}
 
 
+@torch.no_grad()
+def dopri5_replay(f, y0, hs, x):
+  """The accepted steps of a dopri5 solve replayed with GIVEN step sizes hs (no controller) and end-point fraction x of the last step:
+  (out, tape) as dopri5_record returns them.  Lets a float64 check follow the accept / reject decisions a float32 solve took."""
+  dt_ = y0.dtype
+  y, k0 = y0, f(y0)
+  steps = []
+  ks = None
+  for h in hs:
+    h = torch.as_tensor(h, dtype=dt_)
+    ks, us = [k0], [y]
+    for row in A:
+      acc = None
+      for kj, c in zip(ks, row):
+        if c != 0.0:
+          term = kj * (torch.tensor(c, dtype=dt_) * h)
+          acc = term if acc is None else acc + term
+      us.append(y + acc)
+      ks.append(f(us[-1]))
+    steps.append({'u': us, 'h': h})
+    ya, y, k0 = y, us[6], ks[6]
+  yb, h = y, torch.as_tensor(hs[-1], dtype=dt_)
+  acc = None
+  for kj, c in zip(ks, MID):
+    if c != 0.0:
+      term = kj * (torch.tensor(c, dtype=dt_) * h)
+      acc = term if acc is None else acc + term
+  ym = ya + acc
+  x = torch.as_tensor(x, dtype=dt_)
+  fa, fb = ks[0], ks[6]
+  ca = 2 * h * (fb - fa) - 8 * (yb + ya) + 16 * ym
+  cb = h * (5 * fa - 3 * fb) + 18 * ya + 14 * yb - 32 * ym
+  cc = h * (fb - 4 * fa) - 11 * ya - 5 * yb + 16 * ym
+  cd = h * fa
+  out = ya + x * cd + x ** 2 * cc + x ** 3 * cb + x ** 4 * ca
+  return out, {'steps': steps, 'x': x, 'nfe': 1 + 6 * len(steps)}
+
+
 def interp_weights(x, h):
   """Partial derivatives of the quartic end-point interpolation (torchdiffeq interp.py) with respect to what it is built from:
   out = p_y y + p_y1 y1 + p_ym y_mid + p_k0 k_0 + p_k6 k_6  (every operand enters linearly)."""

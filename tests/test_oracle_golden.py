@@ -160,7 +160,8 @@ def _block_rhs(fx):
                                 opt['add_source'], opt['leaky_relu_slope'], opt['attention_norm_idx'])
 
 
-@pytest.mark.parametrize('name', [n for n in fixtures('block_') if 'dopri5' not in n] + fixtures('rewire_'))
+@pytest.mark.parametrize('name', [n for n in fixtures('block_') if 'dopri5' not in n] + fixtures('rewire_') +
+                         [n for n in fixtures('train_') if 'dopri5' not in n])
 def test_block_fixed_step(name):
   fx = Fixture(name)
   z = R.odeint_fixed(_block_rhs(fx), fx.t('x'), fx.opt['time'], fx.opt['step_size'], fx.opt['method'])
@@ -202,3 +203,61 @@ def test_head_aggregation_linearity():
   att = torch.rand(4, 4, generator=g)
   a1 = torch.mean(torch.stack([R.spmm(edge, att[:, i], 3, x) for i in range(4)]), dim=0)
   assert torch.allclose(a1, R.spmm(edge, att.mean(dim=1), 3, x))
+
+
+@pytest.mark.parametrize('name', fixtures('train_'))
+def test_training_without_the_adjoint_method(name):
+  """opt['adjoint'] = False (reference default; best_params Cora / Citeseer): the reference's block in training mode, loss.backward()
+  through the solver -- recorded from the reference's own code over oracle/shims (torchdiffeq's rk_common with _UncheckedAssign, its
+  controller under no_grad).  The oracle's right-hand side under this package's differentiable host loops with torch CPU autograd
+  reproduces output, evaluation count and every gradient."""
+  import importlib
+  O = importlib.import_module('gnpde_amd.odeint')
+  fx = Fixture(name)
+  opt = fx.opt
+  p = {k: v.clone().requires_grad_(True) for k, v in fx.params.items()}
+  x = fx.t('x').clone().requires_grad_(True)
+  x0 = fx.t('x')
+  n = x.shape[0]
+  ei = fx.t('edge_index')
+  e_n, w_n = R.get_rw_adj(ei, None, 1, opt['self_loop_weight'], n)
+  calls = [0]
+  if opt['function'] == 'laplacian':
+    w = w_n
+    if opt['block'] == 'attention':
+      w, _ = R.transformer_attention(x, e_n, p['multihead_att_layer.Q.weight'], p['multihead_att_layer.Q.bias'], p['multihead_att_layer.K.weight'],
+                                     p['multihead_att_layer.K.bias'], opt['heads'], edge_weights=w_n, reweight=opt['reweight_attention'], **_att_kwargs(opt))
+
+    def rhs(t, y):
+      calls[0] += 1
+      return R.rhs_laplacian(y, e_n, w, p['odefunc.alpha_train'], p['odefunc.beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'])
+  else:
+    edge, _ = R.add_remaining_self_loops(ei, None, opt['self_loop_weight'], int(ei.max()) + 1)
+    pre = 'odefunc.multihead_att_layer.'
+
+    def rhs(t, y):
+      calls[0] += 1
+      return R.rhs_transformer(y, edge, p[pre + 'Q.weight'], p[pre + 'Q.bias'], p[pre + 'K.weight'], p[pre + 'K.bias'], opt['heads'],
+                               p['odefunc.alpha_train'], p['odefunc.beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'])
+  t = torch.tensor([0, opt['time']])
+  if opt['method'] == 'dopri5':
+    z = O._solve_dopri5(rhs, x, t, opt['tol_scale'] * 1e-9, opt['tol_scale'] * 1e-7)[1]
+  else:
+    z = O._solve_fixed_host(rhs, x, t, opt['method'], opt['step_size'])[1]
+  assert calls[0] == int(fx.arr['nfe']) == int(fx.arr['nfe_after_backward'])       # the backward evaluates nothing
+  assert_parity(z, fx.t('z'), 1e-5, name + ' z')
+  (z * fx.t('c')).sum().backward()
+  assert_parity(x.grad, fx.t('grad_x'), 1e-4, name + ' grad_x')
+  # (a gradient that is zero in exact arithmetic -- K.bias under a softmax over rows: the scores of a row all move by q_i . b -- is
+  #  rounding noise on both sides: errors are measured against the largest gradient of the same module)
+  keys = [k for k in fx.arr if k.startswith('grad/')]
+  scale = {}
+  for k in keys:
+    mod = k[5:].rsplit('.', 2)[0] if 'multihead' in k else k
+    scale[mod] = max(scale.get(mod, 0.0), float(fx.t(k).abs().max()))
+  for k in keys:
+    got = p[k[5:]].grad
+    assert got is not None, k
+    mod = k[5:].rsplit('.', 2)[0] if 'multihead' in k else k
+    err = float((got.reshape(fx.arr[k].shape) - fx.t(k)).abs().max())
+    assert err <= 1e-4 * scale[mod], '%s %s: abs err %.3e against module scale %.3e' % (name, k, err, scale[mod])

@@ -1,0 +1,237 @@
+"""Training WITHOUT the adjoint method (opt['adjoint'] = False: the reference's default and its Cora / Citeseer best_params) on the
+native recorded dopri5 -- forward = the device-controlled solve leaving the accepted steps' stage inputs on a tape, backward = one
+native reverse sweep (csrc/dopri5.hip: gnpde_dopri5_set_tape / gnpde_dopri5_tape_backward) -- against
+  * the reference's own gradients (tests/golden/train_*.npz: reference src/ over oracle/shims, torch autograd through torchdiffeq),
+  * this package's differentiable host loop over the kernel-backed autograd Functions (opt['gnpde_host_dopri5_training']),
+  * the explicit reverse sweep of oracle/tape_reverse.py in float64 on the CPU oracle.
+Also: the midpoint method (run_GNN.py --method midpoint) on the native fixed-step solver."""
+import importlib
+
+import pytest
+import torch
+
+import gnpde_amd as G
+from oracle import restate as R
+from helpers import Fixture, fixtures, Data, assert_parity, random_graph
+
+pytestmark = pytest.mark.gpu
+
+O = importlib.import_module('gnpde_amd.odeint')
+FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt}
+BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
+OPT = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
+           beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True, no_alpha_sigmoid=False,
+           mix_features=False, hidden_dim=20, augment=False, adjoint=False, tol_scale=1.0, data_norm='rw', method='dopri5', step_size=1.0,
+           max_iters=100, block='attention', function='laplacian', time=2.0)
+
+
+def _module_scaled(grads, refs, tol, what):
+  """Every gradient within tol of the largest reference gradient of its module (a gradient that is zero in exact arithmetic --
+  K.bias under a softmax over rows -- is rounding noise on both sides)."""
+  scale = {}
+  for k, ref in refs.items():
+    mod = k.rsplit('.', 2)[0] if 'multihead' in k else k
+    scale[mod] = max(scale.get(mod, 0.0), float(ref.abs().max()))
+  for k, ref in refs.items():
+    mod = k.rsplit('.', 2)[0] if 'multihead' in k else k
+    got = grads[k]
+    assert got is not None, '%s: %s received no gradient' % (what, k)
+    err = float((got.detach().cpu().reshape(ref.shape) - ref.cpu()).abs().max())
+    assert err <= tol * scale[mod], '%s %s: abs err %.3e against module scale %.3e (tol %.1e)' % (what, k, err, scale[mod], tol)
+
+
+def _fixture_block(fx, dev, **over):
+  opt = dict(fx.opt, **over)
+  x = fx.t('x', dev)
+  block = BLOCKS[opt['block']](FUNCS[opt['function']], [], opt, Data(x, fx.t('edge_index', dev)), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  block.load_state_dict(fx.params, strict=True)
+  return block, x
+
+
+@pytest.mark.parametrize('name', [n for n in fixtures('train_') if 'dopri5' in n])
+@pytest.mark.parametrize('host_loop', [False, True])
+def test_training_without_adjoint_against_the_reference(dev, name, host_loop):
+  fx = Fixture(name)
+  block, x = _fixture_block(fx, dev, gnpde_host_dopri5_training=host_loop)
+  block.train()
+  assert block.train_integrator is G.odeint
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  assert z.requires_grad
+  f = block.odefunc
+  recorded = bool(f.__dict__.get('_tape_state'))
+  assert recorded == (not host_loop), 'solve path: %s' % getattr(f, '_last_train_solve', None)
+  assert f.nfe == int(fx.arr['nfe']), 'nfe %d vs reference %d' % (f.nfe, int(fx.arr['nfe']))
+  assert_parity(z, fx.t('z'), max(1e-5, 2 * fx.opt['tol_scale'] * 1e-7), name + ' z')
+  (z * fx.t('c', dev)).sum().backward()
+  assert f.nfe == int(fx.arr['nfe_after_backward'])        # the reference's backward evaluates nothing either
+  gtol = 2e-4
+  assert_parity(xin.grad, fx.t('grad_x'), gtol, name + ' grad_x')
+  refs = {k[5:]: fx.t(k) for k in fx.arr if k.startswith('grad/')}
+  grads = dict((k, p.grad) for k, p in block.named_parameters())
+  _module_scaled(grads, refs, gtol, name)
+  for k, p in block.named_parameters():
+    if k not in refs:
+      assert p.grad is None or float(p.grad.abs().max()) == 0.0, '%s received a gradient the reference does not produce' % k
+
+
+def _cora_like(dev, n, d, heads, A, seed, hubs=0, hub_deg=0, **over):
+  ei = random_graph(n, 5, seed=seed, hubs=hubs, hub_deg=hub_deg)
+  x = torch.randn(n, d, generator=torch.Generator().manual_seed(seed + 1)) * 0.5
+  opt = dict(OPT, hidden_dim=d, heads=heads, attention_dim=A, **over)
+  block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(seed + 2)
+  with torch.no_grad():
+    for p in block.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      else:
+        p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(dev))
+  return block, x, ei, opt
+
+
+def _train_once(block, x, dev, c):
+  for p in block.parameters():
+    p.grad = None
+  block.train()
+  xin = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xin)
+  block.odefunc.nfe = 0
+  z = block(xin)
+  (z * c).sum().backward()
+  return z.detach(), xin.grad, {k: (None if p.grad is None else p.grad.clone()) for k, p in block.named_parameters()}, block.odefunc.nfe
+
+
+@pytest.mark.parametrize('case', ['cora', 'hubs', 'd22', 'no_source'])
+def test_recorded_solve_equals_the_host_loop(dev, case):
+  """Same block, same weights: the recorded solve + reverse sweep against the differentiable host loop (same accept / reject
+  sequence, so the same evaluation count) -- at the Cora best_params shape, with hub rows (512-entry chunks in the row kernel),
+  with a width that is not a multiple of 4 (padded rows) and without the source term."""
+  kw = dict(cora=dict(n=2485, d=80, heads=8, A=128, time=18.294754, tol_scale=821.977, square_plus=True, attention_norm_idx=1),
+            hubs=dict(n=1500, d=32, heads=4, A=16, time=3.0, tol_scale=300.0, hubs=2, hub_deg=700),
+            d22=dict(n=600, d=22, heads=2, A=8, time=2.5, tol_scale=100.0),
+            no_source=dict(n=500, d=16, heads=4, A=16, time=3.0, tol_scale=500.0, add_source=False))[case]
+  block, x, ei, opt = _cora_like(dev, seed=31, **kw)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+  z1, gx1, g1, nfe1 = _train_once(block, x, dev, c)
+  assert block.odefunc.__dict__.get('_tape_state'), 'the recorded solve did not run'
+  assert block.odefunc._dopri5_stats['accepted'] >= 2
+  block.odefunc.opt['gnpde_host_dopri5_training'] = True
+  block.reg_odefunc.odefunc.opt['gnpde_host_dopri5_training'] = True
+  z2, gx2, g2, nfe2 = _train_once(block, x, dev, c)
+  assert nfe1 == nfe2, (nfe1, nfe2)
+  assert_parity(z1, z2, 1e-5, case + ' z')
+  assert_parity(gx1, gx2, 2e-4, case + ' grad_x')
+  refs = {k: v for k, v in g2.items() if v is not None}
+  _module_scaled(g1, refs, 2e-4, case)
+  # a second recorded iteration replays the captured trial steps and gives the same numbers bit for bit
+  block.odefunc.opt['gnpde_host_dopri5_training'] = False
+  z3, gx3, g3, _ = _train_once(block, x, dev, c)
+  assert torch.equal(z1, z3) and torch.equal(gx1, gx3)
+
+
+def test_tape_grows_when_a_solve_accepts_more_steps_than_it_holds(dev, monkeypatch):
+  monkeypatch.setattr(O, '_TAPE_BUDGET_BYTES', 1)          # -> the smallest tape (8 slots)
+  block, x, ei, opt = _cora_like(dev, n=400, d=16, heads=4, A=16, seed=41, time=30.0, tol_scale=1.0)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+  z1, gx1, g1, nfe1 = _train_once(block, x, dev, c)
+  sol = next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver']
+  assert block.odefunc._dopri5_stats['accepted'] > 8 and sol.tape_capacity >= block.odefunc._dopri5_stats['accepted']
+  block.odefunc.opt['gnpde_host_dopri5_training'] = True
+  z2, gx2, g2, nfe2 = _train_once(block, x, dev, c)
+  assert nfe1 == nfe2
+  assert_parity(gx1, gx2, 2e-4, 'grad_x after the tape grew')
+
+
+def test_backward_after_a_later_forward_fails_loudly(dev):
+  block, x, ei, opt = _cora_like(dev, n=300, d=16, heads=4, A=16, seed=51, time=2.0, tol_scale=100.0)
+  block.train()
+  xa = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xa)
+  za = block(xa)
+  xb = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xb)
+  zb = block(xb)
+  zb.sum().backward()
+  with pytest.raises(G.GnpdeError):
+    za.sum().backward()
+
+
+def test_recorded_gradients_against_the_float64_reverse_sweep(dev):
+  """The device gradients against oracle/tape_reverse.py (float64, CPU oracle right-hand side) replaying the DEVICE's own accepted
+  step sizes: independent of the float32 accept / reject decisions, so the bar is plain float32 rounding."""
+  from oracle import tape_reverse as TR
+  block, x, ei, opt = _cora_like(dev, n=700, d=24, heads=4, A=16, seed=61, time=4.0, tol_scale=400.0, square_plus=True, attention_norm_idx=1)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(7))
+  block.train()
+  xin = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  f = block.odefunc
+  att = f.attention_weights
+  att.retain_grad()
+  (z * c.to(dev)).sum().backward()
+  sol = next(iter(f.__dict__['_tape_state'].values()))['solver']
+  S = sol.tape_steps()
+  assert S == f._dopri5_stats['accepted'] >= 2
+  f64 = torch.float64
+  n, d = x.shape
+  e_n = f.edge_index.cpu()
+  w = att.detach().cpu().to(f64).mean(dim=1)
+  a = torch.sigmoid(f.alpha_train.detach().cpu().to(f64))
+  b = f.beta_train.detach().cpu().to(f64)
+  row, col = e_n[0], e_n[1]
+  x64 = x.to(f64)
+
+  def fn(u):
+    return a * (R.spmm(e_n, w, n, u) - u) + b * x64
+
+  def vjp_u(g):
+    return a * (torch.zeros_like(g).index_add_(0, col, g[row] * w.unsqueeze(1)) - g)
+  # the device's accepted steps replayed in float64 (its step sizes, its end-point fraction: no second controller to disagree with)
+  hs, xfrac = sol.tape_record()
+  assert len(hs) == S and abs(sum(hs[:-1]) + xfrac * hs[-1] - opt['time']) <= 1e-4 * opt['time']
+  out, tape = TR.dopri5_replay(fn, x64, hs, xfrac)
+  acc = {'r': torch.zeros(e_n.shape[1], dtype=f64), 's_a': 0.0, 's_b': 0.0}
+
+  def on_eval(g, u, wv):
+    acc['r'] += (g[row] * u[col]).sum(dim=1)
+    acc['s_a'] += float((u * wv).sum())
+    acc['s_b'] += float((g * x64).sum())
+  gy0 = TR.dopri5_tape_reverse(tape, c.to(f64), vjp_u, on_eval)
+  assert_parity(z, out, 2e-5, 'z vs float64')
+  # d/dx through the initial state alone = total - the part through the attention; compare the pieces the sweep produces
+  h = att.shape[1]
+  assert_parity(att.grad, ((a * acc['r']) / h).unsqueeze(1).expand(-1, h), 2e-4, 'd attention')
+  assert abs(float(f.alpha_train.grad) - acc['s_a'] * float(1 - a)) <= 2e-4 * abs(acc['s_a'] * float(1 - a)) + 1e-7
+  assert abs(float(f.beta_train.grad) - acc['s_b']) <= 2e-4 * abs(acc['s_b']) + 1e-7
+
+
+@pytest.mark.parametrize('name', [n for n in fixtures('train_') if 'midpoint' in n])
+def test_midpoint_method(dev, name):
+  """run_GNN.py --method midpoint: evaluation on the native fixed-step solver (one hipGraph, two LINCOMB stages per step), training
+  through the host loop; both against the reference's block."""
+  fx = Fixture(name)
+  block, x = _fixture_block(fx, dev)
+  block.eval()
+  block.set_x0(x)
+  with torch.no_grad():
+    z = block(x)
+  assert block.odefunc.__dict__.get('_solver_state'), 'native solver was not used'
+  assert_parity(z, fx.t('z_eval'), 1e-5, name + ' eval')
+  assert block.odefunc.nfe == int(fx.arr['nfe'])
+  with torch.no_grad():
+    z_eager = G.odeint(block.odefunc, x, torch.tensor([0, fx.opt['time']], device=dev), method='midpoint', options={'step_size': fx.opt['step_size']},
+                       use_graph=False)[1]
+  assert torch.equal(z, z_eager)
+  block.train()
+  block.odefunc.nfe = 0
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  zt = block(xin)
+  assert_parity(zt, fx.t('z'), 1e-5, name + ' z')
+  (zt * fx.t('c', dev)).sum().backward()
+  assert_parity(xin.grad, fx.t('grad_x'), 2e-4, name + ' grad_x')
+  refs = {k[5:]: fx.t(k) for k in fx.arr if k.startswith('grad/')}
+  _module_scaled(dict((k, p.grad) for k, p in block.named_parameters()), refs, 2e-4, name)
