@@ -886,6 +886,7 @@ def cora_epoch_main(G, args, dev):
     accs, nfe_eval = test_step()
     sync()
     t2 = time.perf_counter()
+    stats_eval = dict(getattr(model.odeblock.odefunc, '_dopri5_stats', {}) or {})
     ep.append(t2 - t0)
     tr_t.append(t1 - t0)
     te_t.append(t2 - t1)
@@ -907,7 +908,6 @@ def cora_epoch_main(G, args, dev):
   f = model.odeblock.odefunc
   path = getattr(f, '_last_train_solve', None) or ('native recorded-tape dopri5' if f.__dict__.get('_tape_state') else
                                                    'host controller loop (odeint._solve_dopri5) over kernel-backed autograd Functions')
-  stats_eval = dict(getattr(f, '_dopri5_stats', {}) or {})
   E = int(f.edge_index.shape[1])
   out = {
     'metric': 'seconds per epoch (train + test), Cora best_params (attention block, Laplacian, dopri5, adjoint=False)',
@@ -921,7 +921,7 @@ def cora_epoch_main(G, args, dev):
     'ms_train_step': round(med(tr_t) * 1e3, 3), 'ms_test_step': round(med(te_t) * 1e3, 3),
     'ms_train_phases_synchronised': {k: round(med(v) * 1e3, 3) for k, v in ph.items()},
     'nfe_forward_per_epoch': fwd_nfe, 'nfe_backward_per_epoch': bwd_nfe, 'nfe_test_per_epoch': med(eval_nfe),
-    'train_solve_path': path, 'test_solve': stats_eval,
+    'train_solve_path': path, 'train_solve': dict(getattr(f, '_dopri5_stats', {}) or {}), 'test_solve': stats_eval,
     'final_loss': round(lv, 5), 'accuracies_last_epoch': [round(a, 4) for a in accs],
     'reference_published': {'s_per_epoch': [1.72, 2.04], 'nfe_forward': 124, 'where': 'notebooks/visualise_attention.ipynb:132-138 (real Cora, the authors\' GPU)',
                             'note': 'another graph (real Cora) on other hardware: context, not a baseline for vs_baseline'},
@@ -940,10 +940,9 @@ def cora_epoch_main(G, args, dev):
       h0 = model.encode(data.x)
       blk.set_x0(h0)
       f.nfe = 0
-      saved = blk.test_integrator
-      blk.test_integrator = G.odeint
-      z_dev = blk(h0)
-      blk.test_integrator = saved
+      # the block's forward with the plain integrator (AttODEblock.forward: attention once, then odeint) instead of the early-stopping one
+      f.attention_weights = blk.get_attention_weights(h0)
+      z_dev = G.odeint(f, h0, blk.t.type_as(h0), method='dopri5', options={'step_size': opt['step_size']}, atol=blk.atol, rtol=blk.rtol)[1]
       nfe_dev = int(f.nfe)
       f.nfe = 0
     hc = cpu(h0)

@@ -77,7 +77,10 @@ class GNN(BaseGNN):
     return (not self.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
   def _lin(self, layer, x, relu_input=False):
-    if self._native(x):
+    # the projection kernel is built for the hot path's shapes (K a multiple of 16, >= 16 outputs); a bag-of-words encoder (Cora: K = 1433)
+    # or a 7-class decoder would take its guarded scalar-load variant -- 158 / 64 us against ~20 for the vendor GEMM, measured on Cora
+    # (profiles/r05_cora_epoch_kernel_stats.csv) -- so those plain GEMMs outside the ODE go to the library
+    if self._native(x) and x.shape[1] % 16 == 0 and layer.weight.shape[0] >= 16:
       return ops.linear(x, layer.weight.detach(), None if layer.bias is None else layer.bias.detach(), relu_input=relu_input)
     return layer(F.relu(x) if relu_input else x)
 

@@ -271,15 +271,33 @@ __global__ __launch_bounds__(kBlock) void tape_store_kernel(const TapeArgs a) {
   }
 }
 
-// sum over the per-wave dots of every launch of the reverse sweep: out[0] = sum d1 - sum d2 (fixed order, double)
-__global__ __launch_bounds__(kBlock) void tape_dots_fold_kernel(const float* __restrict__ dots, long long n_pairs, float* __restrict__ out) {
+// sum over the per-wave dots of every launch of the reverse sweep: sum d1 - sum d2 in double, fixed order -- kTapeFoldBlocks blocks over
+// contiguous ranges, then one wave over their partial sums
+constexpr int kTapeFoldBlocks = 128;
+
+__global__ __launch_bounds__(kBlock) void tape_dots_partial_kernel(const float* __restrict__ dots, long long n_pairs, double* __restrict__ part) {
   __shared__ double red[kBlock];
+  const long long per = (n_pairs + gridDim.x - 1) / gridDim.x;
+  const long long b0 = per * blockIdx.x, b1 = b0 + per < n_pairs ? b0 + per : n_pairs;
   double acc = 0.0;
-  for (long long i = threadIdx.x; i < n_pairs; i += kBlock)
-    acc += static_cast<double>(dots[2 * i]) - static_cast<double>(dots[2 * i + 1]);
+  for (long long i = b0 + threadIdx.x; i < b1; i += kBlock) {
+    const float2 v = reinterpret_cast<const float2*>(dots)[i];
+    acc += static_cast<double>(v.x) - static_cast<double>(v.y);
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(kTapeFoldBlocks) void tape_dots_fold_kernel(const double* __restrict__ part, float* __restrict__ out) {
+  __shared__ double red[kTapeFoldBlocks];
+  red[threadIdx.x] = part[threadIdx.x];
+  __syncthreads();
+  for (int s = kTapeFoldBlocks / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -719,7 +737,7 @@ SweepLayout sweep_layout(const gnpde_dopri5* s, const gnpde_graph_t* gt, int ste
   L.dots_floats = 2 * static_cast<size_t>(L.slots) * (6 * static_cast<size_t>(steps) + 1);
   L.part_bytes = static_cast<size_t>(gt->n_long_chunks) * align_up(static_cast<size_t>(r.d), 4) * sizeof(float);
   size_t off = 0;
-  L.off_one = off;   off += 256;
+  L.off_one = off;   off += 2048;                              // 1.0f, then the fold's 128 partial sums (double)
   L.off_dots = off;  off += align_up(L.dots_floats * sizeof(float), 256);
   L.off_part = off;  off += align_up(L.part_bytes, 256);
   L.off_state = off; off += 18 * s->state_bytes;
@@ -850,7 +868,10 @@ extern "C" int gnpde_dopri5_tape_backward(gnpde_dopri5_t* s, const gnpde_graph_t
   }
   hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, GY0, r.ld, grad_y0, ld_gy0, n, r.d);
   GNPDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tape_dots_fold_kernel, dim3(1), dim3(kBlock), 0, st, dots, static_cast<long long>(L.slots) * launch, dot_out);
+  double* fold_part = reinterpret_cast<double*>(ws + L.off_one + 64);       // (behind the 1.0f of the source weight)
+  hipLaunchKernelGGL(tape_dots_partial_kernel, dim3(kTapeFoldBlocks), dim3(kBlock), 0, st, dots, static_cast<long long>(L.slots) * launch, fold_part);
+  GNPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tape_dots_fold_kernel, dim3(1), dim3(kTapeFoldBlocks), 0, st, fold_part, dot_out);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
