@@ -170,6 +170,7 @@ PROTOTYPES = {
   'gnpde_dopri5_set_early_stop': (ctypes.c_int, [c_vp, ctypes.POINTER(DecoderStruct), c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32,
                                                  ctypes.c_int32]),
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  'gnpde_dopri5_set_row_order': (ctypes.c_int, [c_vp, c_vp]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_dopri5_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
   'gnpde_dopri5_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, ctypes.c_int32]),

@@ -181,6 +181,22 @@ __global__ __launch_bounds__(kBlock) void copy_rows_kernel(const float* __restri
   }
 }
 
+// the same copy through a row map: gather != 0: dst[r] = src[map[r]] (state in: solver row r holds the caller's row map[r]);
+// gather == 0: dst[map[r]] = src[r] (result out).  Folds the node relabelling of graph.LocalityView into the two copies a solve makes
+// anyway (two index_select launches, a state-sized temporary and their host gaps per forward otherwise).
+__global__ __launch_bounds__(kBlock) void copy_rows_map_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                                              long long n, int d, const int* __restrict__ map, int gather) {
+  const long long total = n * d;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long r = i / d;
+    const int c = static_cast<int>(i - r * d);
+    const long long m = map[r];
+    const long long rs = gather ? m : r, rd = gather ? r : m;
+    dst[static_cast<size_t>(rd) * ld_dst + c] = src[static_cast<size_t>(rs) * ld_src + c];
+  }
+}
+
 struct FinishArgs {
   const float* y; float* y1;      // the next trial step reads its y from the y1 buffer and its k0 from the k6 buffer:
   float* k[7];                    // written here only when this step was rejected
@@ -346,6 +362,7 @@ struct gnpde_dopri5 {
   int* tape_overflow = nullptr;
   float* host_h = nullptr;      // pinned copy of the accepted steps' sizes, read once behind a recorded solve
   int host_h_capacity = 0;
+  const int* row_order = nullptr;   // gnpde_dopri5_set_row_order: solver row r <-> caller's row row_order[r]
   float last_x = 0.f;           // interpolation fraction of the last accepted step of the last run
   int tape_steps = 0;           // accepted steps of the last recorded run (0: nothing to differentiate)
 };
@@ -518,8 +535,12 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
   }
   long long copy_blocks = (static_cast<long long>(n) * r.d + kBlock - 1) / kBlock;
   if (copy_blocks > 8192) copy_blocks = 8192;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, y0, ld_y0, s->Y[0], r.ld,
-                     static_cast<long long>(n), r.d);
+  if (s->row_order != nullptr)
+    hipLaunchKernelGGL(copy_rows_map_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, y0, ld_y0, s->Y[0], r.ld,
+                       static_cast<long long>(n), r.d, s->row_order, 1);
+  else
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, y0, ld_y0, s->Y[0], r.ld,
+                       static_cast<long long>(n), r.d);
   GNPDE_LAUNCH_CHECK();
   char* rws = s->ws + s->off_rhs;
   auto feval = [&](const float* src, float* dst) -> int {
@@ -598,8 +619,12 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     GNPDE_CHECK_ARG(hc.t + hc.dt > hc.t, GNPDE_EINVAL, "dopri5_run: underflow in dt %g at t %g", hc.dt, hc.t);
     if (max_evals > 0 && s->n_evals > max_evals) return 0;   // *finished stays 0
   }
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, s->yout, r.ld, y_out, ld_out,
-                     static_cast<long long>(n), r.d);
+  if (s->row_order != nullptr)
+    hipLaunchKernelGGL(copy_rows_map_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, s->yout, r.ld, y_out, ld_out,
+                       static_cast<long long>(n), r.d, s->row_order, 0);
+  else
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, s->yout, r.ld, y_out, ld_out,
+                       static_cast<long long>(n), r.d);
   GNPDE_LAUNCH_CHECK();
   if (s->tape != nullptr) {
     GNPDE_CHECK_ARG(s->n_accepted <= s->tape_capacity, GNPDE_EWS, "dopri5_run: %d accepted steps do not fit the tape (%d slots)",
@@ -639,6 +664,12 @@ extern "C" int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decode
   s->times_capacity = times_capacity;
   s->max_trials = max_trial_steps;
   s->early = true;
+  return 0;
+}
+
+extern "C" int gnpde_dopri5_set_row_order(gnpde_dopri5_t* s, const int32_t* order) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "dopri5_set_row_order: solver is null");
+  s->row_order = order;      // (read by the copy kernels of gnpde_dopri5_run only: the captured trial steps are untouched)
   return 0;
 }
 

@@ -442,12 +442,16 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
       trials_per_sync = max(1, int(os.environ['GNPDE_DOPRI5_TRIALS_PER_SYNC']))
   out = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
   out[0].copy_(y0c)
-  if view is None:
-    finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
-  else:
-    y1 = torch.empty_like(y0c)
-    finished = ent['solver'].run(view.enter(y0c), float(t[0]), float(t[-1]), y1, trials_per_sync=trials_per_sync, max_evals=room)
-    view.leave(y1, out=out[1])
+  # relabelled graph: the permutation rides in the solver's own first and last copy (gnpde_dopri5_set_row_order) instead of two
+  # index_select launches around it
+  order32 = None
+  if view is not None:
+    order32 = view.__dict__.get('order32')
+    if order32 is None:
+      order32 = view.__dict__['order32'] = view.order.to(torch.int32).contiguous()
+  if getattr(sol, '_row_order', None) is not order32:
+    sol.set_row_order(order32)
+  finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
   spent = ent['solver'].stats()['evals']
   func._dopri5_stats = ent['solver'].stats()
   if not finished or spent > room:

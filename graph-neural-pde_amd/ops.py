@@ -445,6 +445,11 @@ class Dopri5Solver(object):
                                         ptr(self.times), cap, int(max_trial_steps)))
     self.evaluator, self.max_trial_steps = evaluator, int(max_trial_steps)
 
+  def set_row_order(self, order32):
+    """Fold a node relabelling into the solve's copies: solver row r <-> caller's row order32[r] (int32 device tensor or None)."""
+    check(_lib.lib().gnpde_dopri5_set_row_order(self.handle, ptr(order32)))
+    self._row_order = order32          # (kept alive: the solver holds the address)
+
   # ---- recorded solve (training without the adjoint method): gnpde_dopri5_set_tape / _tape_backward ---------------------------
   def set_tape(self, capacity_steps):
     """Record the accepted steps of the following runs (None / 0 detaches).  The tape is zero-filled device memory owned here."""

@@ -556,6 +556,11 @@ int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y0, double t
  * runs (drops the captured trial steps). */
 int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decoder_t* dec, int32_t* state, int32_t* trace,
                                 int32_t trace_capacity, double* times, int32_t times_capacity, int32_t max_trial_steps);
+/* Node relabelling folded into the solve's own copies (graph.LocalityView of the Python layer: the fused solves run on the graph with
+ * its nodes relabelled; no reference equivalent): order[r] = the caller's row that solver row r holds (device, int32 [n], must outlive the
+ * runs).  gnpde_dopri5_run then reads y0[order[r]] into its row r and writes its row r to y_out[order[r]] (y_out must not alias y0
+ * then).  NULL restores the plain copies. */
+int gnpde_dopri5_set_row_order(gnpde_dopri5_t* s, const int32_t* order);
 /* of the last run: evaluations of f, accepted and rejected steps, graph launches, host synchronisations */
 int gnpde_dopri5_stats(const gnpde_dopri5_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected, int32_t* n_launches,
                        int32_t* n_syncs);
