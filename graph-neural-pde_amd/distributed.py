@@ -357,6 +357,20 @@ class NativeBackend(object):
       if self.output_var is not None:
         self.output_var.copy_(params['output_var'].detach().reshape(-1))
         self.lengthscale.copy_(params['lengthscale'].detach().reshape(-1))
+      if getattr(self, 'reweight', None) is not None and params.get('edge_weight') is not None:
+        # opt['reweight_attention']: the edge weights may have changed while the edge_index tensor (the cache key) stayed the same --
+        # every view's CSR-ordered copy is rebuilt in place, like the laplacian branch above (round-4 advisor item)
+        ew = params['edge_weight'].detach().to(self.dev, torch.float32)
+        self._edge_weight = ew
+        self.ops.edge_to_csr_mean(self.graph, ew, out=self.reweight[None])
+        self.ops.edge_to_csr_mean(self.g_int, ew[self.eid_int.to(self.dev)], out=self.reweight['interior'])
+        self.ops.edge_to_csr_mean(self.g_bnd, ew[self.eid_bnd.to(self.dev)], out=self.reweight['boundary'])
+        if 'att' in self.reweight:
+          self.ops.edge_to_csr_mean(self.g_att, ew, out=self.reweight['att'])
+        for chunks in self.chunk_sets.values():
+          for (_, _, g, eid, w) in chunks:
+            if w is not None:
+              self.ops.edge_to_csr_mean(g, ew[eid.to(self.dev)], out=w)
 
   def _descriptor(self, with_source, part=None):
     """gnpde_rhs_t over the local shard: aggregation on the n_own rows (or the interior / boundary rows),

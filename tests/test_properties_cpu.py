@@ -259,3 +259,37 @@ def test_cosine_scores_are_scaled_dot_scores_of_normalised_rows(centre, dk):
   got = (qn.view(n, h, dk) * kn.view(n, h, dk)).sum(dim=2) / dk ** 0.5
   assert got.shape == want.shape
   assert float((got - want).abs().max()) < 5e-6
+
+
+def test_cosine_clamp_against_torch_1_8_product_clamp():
+  """The reference pins torch 1.8, whose cosine_similarity divides by max(|x| |y|, eps) -- ONE clamp on the product (ATen
+  Distance.cpp: w12 / sqrt(clamp_min(w1 w2, eps^2))); torch >= 1.12 -- the torch the fixtures were recorded with, and what the
+  per-vector normalisation of csrc/misc.hip expresses -- divides by max(|x|, eps) max(|y|, eps).  Both give the true cosine, and so
+  agree, wherever NEITHER clamps: |x| >= eps, |y| >= eps and |x| |y| >= eps.  They differ (a) when |x| |y| < eps = 1e-5 with both norms
+  still above eps -- head vectors of norm ~3e-3 and below on both sides: torch 1.8 shrinks the score by |x| |y| / eps, the per-norm form
+  returns the true cosine -- and (b) when exactly one norm is below eps with the product above it: torch 1.8 returns the true cosine, the
+  per-norm form shrinks it by |x| / eps.  Pinned here; stated in INTEGRATION.md (torch-version dependence of cosine_sim / pearson)."""
+  g = torch.Generator().manual_seed(7)
+  n, dk, eps = 4000, 8, 1e-5
+  x = torch.randn(n, dk, generator=g, dtype=torch.float64)
+  y = torch.randn(n, dk, generator=g, dtype=torch.float64)
+  x = x * 10.0 ** torch.empty(n, 1, dtype=torch.float64).uniform_(-8, 2, generator=g)
+  y = y * 10.0 ** torch.empty(n, 1, dtype=torch.float64).uniform_(-8, 2, generator=g)
+  nx, ny = x.norm(dim=1), y.norm(dim=1)
+  dot = (x * y).sum(dim=1)
+  true = dot / (nx * ny)
+  old = dot / (nx * ny).clamp_min(eps)                          # torch 1.8
+  new = dot / (nx.clamp_min(eps) * ny.clamp_min(eps))           # torch >= 1.12 (= torch.nn.functional.cosine_similarity here)
+  ref = torch.nn.functional.cosine_similarity(x, y, dim=1, eps=eps)
+  assert float((new - ref).abs().max()) < 1e-12
+  neither = (nx >= eps) & (ny >= eps) & (nx * ny >= eps)
+  assert int(neither.sum()) > 500
+  assert float((old[neither] - new[neither]).abs().max()) < 1e-12 and float((new[neither] - true[neither]).abs().max()) < 1e-12
+  a = (nx >= eps) & (ny >= eps) & (nx * ny < eps)                # (a): only the product clamp is active
+  assert int(a.sum()) > 50
+  assert float((new[a] - true[a]).abs().max()) < 1e-12
+  assert float((old[a] - true[a] * (nx * ny)[a] / eps).abs().max()) < 1e-12
+  b = ((nx < eps) ^ (ny < eps)) & (nx * ny >= eps)               # (b): only a per-norm clamp is active
+  assert int(b.sum()) > 20
+  assert float((old[b] - true[b]).abs().max()) < 1e-12
+  assert float((new[b] - true[b] * torch.minimum(nx, ny)[b] / eps).abs().max()) < 1e-12
