@@ -1166,7 +1166,7 @@ def summarise_child(line):
       keep[k] = cfg[k]
   rel = cfg.get('node_relabelling')
   if isinstance(rel, dict):
-    keep['node_relabelling'] = {k: rel.get(k) for k in ('order', 'entries_inside_a_part', 'gain', 'solve_equal_to_unrelabelled_bitwise') if k in rel}
+    keep['node_relabelling'] = {k: rel.get(k) for k in ('order', 'n_parts', 'entries_inside_a_part', 'aggregation_speedup_measured', 'solve_equal_to_unrelabelled_bitwise') if k in rel}
   elif 'node_relabelling' in cfg:
     keep['node_relabelling'] = None
   for k in ('parity_vs_oracle_one_eval', 'parity_vs_restated_torchdiffeq', 'parity_vs_oracle_row_subset', 'parity_vjp_one_eval_vs_oracle', 'speedup_vs_cpu',

@@ -25,6 +25,8 @@
 namespace gnpde {
 namespace {
 
+constexpr int kGmaxSlots = 64;
+
 struct AttArgs {
   int n, e, h, dk, type, norm_idx, square_plus;
   float inv_sqrt_dk_den;  // sqrt(d_k), divisor of the scaled dot product
@@ -46,6 +48,10 @@ struct AttArgs {
   float* seg_m;       // [n,h]
   float* seg_den;     // [n,h]
   unsigned* gmax;     // ordered-uint encoding of the global max score
+  unsigned* gmax_slots;   // squareplus maximum sweep of the fused path: kGmaxSlots partial maxima, 128 bytes apart (a block updates slot
+                          // blockIdx % kGmaxSlots; gmax_fold_kernel folds them into *gmax).  A small graph's whole grid is resident at once,
+                          // so every wave sees the initial value and issues its atomic: on ONE address they serialise at ~10 ns each --
+                          // 24-36 us of a 48-us Cora evaluation (profiles/r05_c2_as_run_sequence_before.txt).  nullptr: straight into *gmax.
   float* w_mean;      // [e] or null
   float* att_edge;    // [E,h] or null
   float* prods_edge;  // [E,h] or null
@@ -70,6 +76,17 @@ __device__ __forceinline__ unsigned f2ord(float f) {
 __device__ __forceinline__ float ord2f(unsigned o) {
   const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   return __uint_as_float(u);
+}
+
+// the partial maxima of the squareplus sweep (AttArgs::gmax_slots) -> *gmax; one wavefront
+__global__ __launch_bounds__(kWave) void gmax_fold_kernel(const unsigned* __restrict__ slots, unsigned* __restrict__ gmax) {
+  unsigned v = slots[32 * static_cast<int>(threadIdx.x)];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned w = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), o, kWave));
+    v = w > v ? w : v;
+  }
+  if (threadIdx.x == 0 && v > *gmax) *gmax = v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -457,7 +474,8 @@ __device__ __forceinline__ void hub_scores_partial_heads(const AttArgs& a, float
   if constexpr (MODE == 2) {     // squareplus, first sweep: only the global maximum of the scores (utils.py:196 `src.max()`)
     if (threadIdx.x < H && m > -INFINITY) {
       const unsigned mine = f2ord(m);
-      if (mine > __hip_atomic_load(a.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.gmax, mine);
+      unsigned* tgt = a.gmax_slots != nullptr ? a.gmax_slots + 32 * (blockIdx.x % kGmaxSlots) : a.gmax;
+      if (mine > __hip_atomic_load(tgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tgt, mine);
     }
     return;
   }
@@ -784,7 +802,8 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
     // tens of thousands of waves hammering ONE address serialise -- 0.7 ms per sweep at the ogbn-arxiv shape when every wave did)
     if (lane == 0 && mw > -INFINITY) {
       const unsigned mine = f2ord(mw);
-      if (mine > __hip_atomic_load(a.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.gmax, mine);
+      unsigned* tgt = a.gmax_slots != nullptr ? a.gmax_slots + 32 * (blockIdx.x % kGmaxSlots) : a.gmax;
+      if (mine > __hip_atomic_load(tgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tgt, mine);
     }
     return;
   }
@@ -899,7 +918,7 @@ AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots, int key_r
   L.scores = off; off += align_up(static_cast<size_t>(e) * h * 4, 256);
   L.seg_m = off;  off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
-  L.gmax = off; off += 256;
+  L.gmax = off; off += 256 + kGmaxSlots * 128;      // the maximum, then its partial slots (AttArgs::gmax_slots)
   L.gat = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 2 * h * 4, 256);   // (halo rows of a partitioned graph)
   L.gat_table = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 8 * h * 4, 256);
   L.part = off; off += align_up(long_slots * 2 * h * 4, 256);
@@ -1120,7 +1139,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 2 ? 0 : 1;   // default since round 3 (bit-identical; -3.4 % on the R-MAT launch)
   float* part = reinterpret_cast<float*>(base + L.part);
 
-  if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, sizeof(unsigned), stream));
+  if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, 256 + kGmaxSlots * 128, stream));
   // GAT's row softmax on the scaled-dot row kernels (gat_terms_kernel's table): the fused row path without edge weights
   const bool gat_sd = gat && !stats_only && pass_only == 0 && !hubs_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr &&
                       prods_edge == nullptr && w_mean_csr != nullptr && g->bin_rows != nullptr && a.edge_w == nullptr &&
@@ -1225,8 +1244,12 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
       const int n_hub = sg->n_long_rows > 0 ? sg->n_long_chunks : 0;
       if (a.square_plus) {
         c.sp_mode = 2;
+        c.gmax_slots = a.gmax + 64;          // (256 bytes behind the maximum itself)
         if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
         GNPDE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gmax_fold_kernel, dim3(1), dim3(kWave), 0, stream, c.gmax_slots, a.gmax);
+        GNPDE_LAUNCH_CHECK();
+        c.gmax_slots = nullptr;
         c.sp_mode = 1;
       }
       if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
