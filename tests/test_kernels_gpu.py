@@ -7,7 +7,7 @@ import torch
 import gnpde_amd as G
 from gnpde_amd import ops, _lib
 from oracle import restate as R
-from helpers import assert_parity, random_graph
+from helpers import assert_parity, random_graph, Data
 
 pytestmark = pytest.mark.gpu
 
@@ -318,3 +318,45 @@ def test_spmm_row_deal_over_the_xcds(dev, d):
   ref = R.rhs_laplacian(x, ei, w, alpha, beta, x0, no_alpha_sigmoid=False, add_source=True)
   assert_parity(hashed[0], ref, what='spmm_rhs, hashed row deal, d=%d' % d)
   assert_parity(hashed[1], (2 * y - x) + 0.7 * ref, what='RK2C stage, hashed row deal, d=%d' % d)
+
+
+@pytest.mark.parametrize('att_type', ['cosine_sim', 'pearson'])
+@pytest.mark.parametrize('norm_idx,square_plus', [(0, False), (1, True)])
+def test_cosine_fused_path_agrees_with_the_generic_score_kernels_near_zero_norms(dev, att_type, norm_idx, square_plus):
+  """cosine_sim / pearson in ODEFunc.forward run as scaled-dot scores of rows normalised after the projection (per-vector clamp of
+  each norm at 1e-5: torch >= 1.12's cosine_similarity); the layer's [E,h] attention comes from the generic score kernels
+  (scores_kernel<COSINE / PEARSON>).  Same evaluation assembled both ways -- with nodes whose head vectors are tiny (1e-7), exactly
+  zero, or tiny on a few heads only -- within float32 rounding of each other (round-4 advisor item; the torch-version dependence of
+  the clamp itself is pinned in tests/test_properties_cpu.py and stated in INTEGRATION.md)."""
+  from gnpde_amd import ops
+  n, d, h, A = 900, 24, 4, 16
+  ei = random_graph(n, 5, seed=77, hubs=1, hub_deg=600)
+  g = torch.Generator().manual_seed(78)
+  x = torch.randn(n, d, generator=g) * 0.5
+  x[:60] *= 1e-7              # tiny rows: every head vector of q and k below the clamp
+  x[60:90] = 0.0              # zero rows
+  opt = dict(heads=h, attention_dim=A, attention_type=att_type, attention_norm_idx=norm_idx, square_plus=square_plus, reweight_attention=False,
+             beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=1000, add_source=True, no_alpha_sigmoid=False, mix_features=False,
+             hidden_dim=d, augment=False, adjoint=False, tol_scale=1.0, data_norm='rw', method='rk4', step_size=1.0, max_iters=100,
+             block='constant', function='transformer', time=1.0)
+  func = G.ODEFuncTransformerAtt(d, d, opt, Data(x.to(dev), ei.to(dev)), dev).to(dev)
+  with torch.no_grad():
+    for p in func.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+    lay = func.multihead_att_layer
+    lay.Q.bias.zero_()
+    lay.K.bias.zero_()
+    lay.Q.weight[:4] *= 1e-7      # head 0 of every query below the clamp, the other heads ordinary
+    func.alpha_train.fill_(0.2)
+    func.beta_train.fill_(0.3)
+  xd = x.to(dev)
+  func.x0 = xd
+  with torch.no_grad():
+    f_fused = func(0.0, xd)                                       # projection -> normalise rows -> scaled-dot kernels
+    att, _ = lay(xd, func.edge_index)                             # generic score kernels, [E,h] in edge order
+    graph = func._graph(xd)
+    w = ops.edge_to_csr_mean(graph, att)
+    f_generic = ops.spmm_rhs(graph, w, xd, func.alpha_train, func.beta_train, xd, True)
+  assert torch.isfinite(f_fused).all() and torch.isfinite(att).all()
+  assert_parity(f_fused, f_generic, 1e-5, '%s norm_idx %d squareplus %s' % (att_type, norm_idx, square_plus))

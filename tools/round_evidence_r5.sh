@@ -1,0 +1,75 @@
+#!/bin/bash
+# Round-5 evidence of the SHIPPED code in one GPU call (GPU box only; run from the repo root), most valuable first:
+#   tools/round_evidence_r5.sh TAG COMMIT
+# Writes gpurun_out/$TAG/*: the driver's command (default bench line incl. the configs block, raw live-PMC CSVs kept), kernel stats of
+# the headline / training / C4 / Cora-epoch runs, the PMC record of the aggregation (hbm_traffic.json), launch sequences, the GPU suite.
+set -u
+TAG=$1; COMMIT=$2
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+prof() {  # name, command...
+  local name=$1; shift
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/st_$name" -o p -- "$@" > "$OUT/$name.stats.log" 2>&1
+  python tools/prof_summary.py "$(find $OUT/st_$name -name '*kernel_stats.csv' | head -1)" "$OUT/${name}_kernel_stats.csv" \
+    "rocprofv3 --kernel-trace --stats -- $*   (commit $COMMIT)" > /dev/null 2>> "$OUT/$name.stats.log"
+}
+B="python bench.py"
+T0=$(date +%s)
+timeout 1700 $B --gpus 1 --steps 20 --warmup 5 --keep-pmc "$OUT/live_pmc" > "$OUT/bench_default_steps20.json" 2> "$OUT/bench_default.err"
+echo "default bench rc $? seconds $(( $(date +%s) - T0 ))" | tee "$OUT/bench_default.time"
+prof arxiv_steps20 $B --graph arxiv --steps 20 --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1
+find "$OUT/st_arxiv_steps20" -name '*kernel_trace.csv' -delete
+timeout 400 $B --steps 100 --warmup 10 --no-cpu-baseline --no-configs > "$OUT/bench_steps100.json" 2>> "$OUT/bench_default.err"
+cp profiles/hbm_traffic.json "$OUT/hbm_traffic.json"
+DIRS=""
+i=0
+PB="$B --graph arxiv --steps 20 --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1 --no-graph"
+for CNT in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$i" -o p -- $PB > "$OUT/pmc_$i.log" 2>&1
+  DIRS="$DIRS $OUT/pmc_$i"
+done
+python tools/pmc_traffic.py "$OUT/hbm_traffic.json" "arxiv_d128_spmm" "$COMMIT" "$PB" $DIRS > "$OUT/pmc_summary.log" 2>&1
+find "$OUT" -name '*kernel_trace.csv' -path '*pmc_*' -delete; find "$OUT" -name '*counter_collection.csv' -path '*pmc_[12]*' -delete
+prof train $B --train --steps 10 --warmup 2 --replays 3 --no-live-pmc --no-cpu-baseline
+find "$OUT/st_train" -name '*kernel_trace.csv' -delete
+prof c4 $B --config c4 --warmup 1 --replays 3 --no-cpu-baseline --no-live-pmc
+find "$OUT/st_c4" -name '*kernel_trace.csv' -delete
+prof cora_epoch $B --config cora-epoch --steps 10 --warmup 3 --no-cpu-baseline
+python tools/trace_sequence.py "$(find $OUT/st_cora_epoch -name '*kernel_trace.csv' | head -1)" tape_store -1 90 > "$OUT/cora_epoch_sequence_train_step.txt" 2>&1
+find "$OUT/st_cora_epoch" -name '*kernel_trace.csv' -delete
+timeout 300 $B --config cora-epoch --steps 20 --warmup 3 > "$OUT/bench_cora_epoch.json" 2> "$OUT/bench_cora_epoch.err"
+GNPDE_HOST_DOPRI5_TRAINING=1 timeout 300 $B --config cora-epoch --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_cora_epoch_host_loop.json" 2>> "$OUT/bench_cora_epoch.err"
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_c2" -o p -- $B --graph cora --steps 20 --warmup 0 --square-plus --norm-idx 1 --no-cpu-baseline --no-roofline-probe --replays 1 > "$OUT/tr_c2.log" 2>&1
+python tools/trace_sequence.py "$(find $OUT/tr_c2 -name '*kernel_trace.csv' | head -1)" linear_kernel -1 21 > "$OUT/c2_as_run_sequence.txt" 2>&1
+find "$OUT/tr_c2" -name '*kernel_trace.csv' -delete
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
+echo "pytest rc $?" >> "$OUT/pytest_gpu.log"
+tail -3 "$OUT/pytest_gpu.log"
+python - "$OUT" <<'PY'
+import json, sys, os
+out = sys.argv[1]
+def last(path):
+  return json.loads(open(path).read().strip().splitlines()[-1])
+try:
+  d = last(os.path.join(out, 'bench_default_steps20.json'))
+  r = d['roofline']
+  print('C3', d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'frac', r['frac'], 'alg', r['frac_algorithmic'], 'hbm_probe', (r.get('hbm_bound_probe') or {}).get('frac'))
+  for s_ in r.get('secondary', []):
+    print('  secondary', s_.get('kernel', '')[:40], s_.get('avg_us'), s_.get('traffic'), s_.get('frac_traffic'))
+  for k, v in (d.get('configs') or {}).items():
+    if isinstance(v, dict):
+      rr = v.get('roofline') or {}
+      par = {a: v[a] for a in v if a.startswith('parity')}
+      print(k, '|', v.get('value'), v.get('unit'), '| ms/step', v.get('ms_per_step'), '| frac', rr.get('frac'), 'alg', rr.get('frac_algorithmic'), '|', json.dumps(par)[:260], '|', v.get('error') or v.get('skipped') or '')
+except Exception as exc:
+  print('default line unreadable', exc)
+for f in ('bench_steps100', 'bench_cora_epoch', 'bench_cora_epoch_host_loop'):
+  try:
+    d = last(os.path.join(out, f + '.json'))
+    print(f, d.get('value'), d.get('unit'), 'ms/step', d.get('ms_per_step'), {k: d[k] for k in d if k.startswith('ms_train') or k.startswith('ms_test') or k.startswith('nfe')})
+  except Exception as exc:
+    print(f, 'unreadable', exc)
+PY
+cat "$OUT/c2_as_run_sequence.txt" | tail -12
