@@ -393,9 +393,9 @@ def hbm_bound_probe(G, dev, log_n=21, d=256, k=16, reps=3):
 
 
 def pmc_child(G, block, x, reps=3):
-  """--pmc-child: the launches of one evaluation of f, eagerly, `reps` times -- the projection, the row attention and the four
-  rk4-stage variants of the aggregation on the solver's own graph -- and nothing else on the device afterwards (the parent folds
-  the counters of the gnpde:: kernels by name)."""
+  """--pmc-child: the launches of the four evaluations of one rk4 step, eagerly, `reps` times -- per stage the projection, the row
+  attention and that stage's variant of the aggregation, in the solver's order, on the solver's own graph -- and nothing else on the
+  device afterwards (the parent folds the counters of the gnpde:: kernels by name)."""
   from gnpde_amd import ops, _lib
   f = block.odefunc
   graph, _ = solver_graph(f, x)
@@ -416,16 +416,20 @@ def pmc_child(G, block, x, reps=3):
     qk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=dev)     # (filled by the loop: exactly `reps` projection launches)
     att = ops.attention_struct(_lib.ATT_TYPES[f.opt['attention_type']], h, A, f.opt['attention_norm_idx'], f.opt['square_plus'],
                                q=qk, k=qk[:, A:], ldqk=2 * A)
+  # as the solver issues them: EVERY aggregation is preceded by the projection and the row attention of its own stage input (they
+  # sweep ~300 MB through the L2s in between: four aggregations back to back would find more of the state still cached than the
+  # solve does -- 1.16 instead of 1.24 GB of L2 -> fabric traffic per launch, the difference the round-4 review found between the
+  # live figure and the record of the solver's own launches)
   for _ in range(reps):
-    if att is not None:
-      ops.linear(x, wqk, bqk, out=qk)
-      ops.edge_attention(graph, att, True, False, False, like=x)
     for st in stages:
       kw = dict(st)
       u = kw.pop('u')
+      if att is not None:
+        ops.linear(u, wqk, bqk, out=qk)
+        ops.edge_attention(graph, att, True, False, False, like=x)
       ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
   torch.cuda.synchronize()
-  print(json.dumps({'pmc_child': 'done', 'aggregation_calls': 4 * reps, 'evaluations': reps}))
+  print(json.dumps({'pmc_child': 'done', 'aggregation_calls': len(stages) * reps, 'evaluations': len(stages) * reps}))
 
 
 def pmc_passes(child, env, tag, keep_dir=None, timeout_s=150, marker='{"pmc_child"'):
@@ -1357,7 +1361,7 @@ def main():
     if agg is not None:
       traffic = agg['bytes_per_call']
       traffic_src = {'how': 'measured in this run: rocprofv3 --pmc (two passes: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, --kernel-trace '
-                            'only) over a child process of bench.py that launches one evaluation\'s kernels %d times on the same graph; '
+                            'only) over a child process of bench.py that launches the kernels of %d evaluations in the solver\'s order (projection, row attention, aggregation per stage) on the same graph; '
                             'bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024 per call of the aggregation (row kernel + hub-row fold)'
                             % pmc['_calls']['evaluations'],
                      'live': True, 'stale': False, 'seconds': pmc.get('_seconds'), 'fetch_bytes': round(agg['fetch_bytes_per_call']),
