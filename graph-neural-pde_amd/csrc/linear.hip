@@ -285,7 +285,9 @@ template <int MT, int KB>
 __global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __restrict__ x, int n, int ldx,
                                                                const float* __restrict__ W, int ldw,
                                                                const float* __restrict__ b, float* __restrict__ out,
-                                                               int ldo, int col_base, int relu) {
+                                                               int ldo, int col_base, int relu, int variant) {
+  // variant (A/B knob gnpde_tune(8, 3 | 4 | 5), bit 0: nontemporal loads of x, bit 1: every wave walks a CONTIGUOUS range of tiles
+  // instead of striding over the table by the grid; results are bit-identical in every variant)
   constexpr int CPR = KB * 4;                 // 16-byte chunks per row (d = 16 KB floats)
   constexpr int CHUNKS = 16 * CPR;            // per tile
   constexpr int PER_LANE = CHUNKS / kWave;    // = KB
@@ -294,9 +296,15 @@ __global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __re
   const int wave = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
-  const long long stride = static_cast<long long>(gridDim.x) * kWavesPerBlock;
-  long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
-  if (tile >= n_tiles) return;
+  const long long n_waves = static_cast<long long>(gridDim.x) * kWavesPerBlock;
+  const bool contiguous = (variant & 2) != 0;
+  const bool nt = (variant & 1) != 0;
+  const long long per_wave = (n_tiles + n_waves - 1) / n_waves;
+  const long long wid = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
+  const long long stride = contiguous ? 1 : n_waves;
+  long long tile = contiguous ? wid * per_wave : wid;
+  const long long tile_end = contiguous ? ((wid + 1) * per_wave < n_tiles ? (wid + 1) * per_wave : n_tiles) : n_tiles;
+  if (tile >= tile_end) return;
 
   f32x4 bv[KB][MT];
 #pragma unroll
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __re
       const int c = it * kWave + lane;
       long long row = tl * 16 + c / CPR;
       if (row >= n) row = n - 1;               // ragged last tile: clamp reads, mask writes
-      const float4 ta = *reinterpret_cast<const float4*>(x + static_cast<size_t>(row) * ldx + 4 * (c % CPR));
-      g[it] = f32x4{ta.x, ta.y, ta.z, ta.w};
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + static_cast<size_t>(row) * ldx + 4 * (c % CPR));
+      g[it] = nt ? __builtin_nontemporal_load(src) : *src;
     }
   };
   f32x4* my = slab[wave];
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __re
       my[rr * CPR + (j ^ (rr & 7))] = g[it];
     }
     const long long next = tile + stride;
-    const bool more = next < n_tiles;
+    const bool more = next < tile_end;
     if (more) load_tile(next, g);              // in flight during the MFMAs of this tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -373,7 +381,7 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
   const bool full_cols = ALIGNED && (d % 16 == 0) && (col + 16 * MT <= m);
   const long long tiles = (static_cast<long long>(n) + 15) / 16;
   if constexpr (MT <= 2) {
-    if (full_cols && d <= 128 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 1) {
+    if (full_cols && d <= 128 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 1) {     // (values >= 3: variants of the staged kernel)
       // persistent grid: enough wavefronts to fill the chip (8 per SIMD at these register counts would be
       // ideal; W fragments + double-buffered A cost ~150 VGPRs -> 3 per SIMD), each striding over tiles
       long long blocks = 256LL * 3;
@@ -383,10 +391,11 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
       // d = 64 / 128 (4 or 8 chunks per lane and tile): full-line loads transposed through LDS (linear_staged_kernel);
       // gnpde_tune(8, 2) keeps the fragment-shaped loads for A/B runs
       if ((d == 128 || d == 64) && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 2) {
+        const int variant = g_tune[GNPDE_TUNE_LINEAR_STREAMING] >= 3 ? g_tune[GNPDE_TUNE_LINEAR_STREAMING] - 2 : 0;     // 3 / 4 / 5 -> 1 / 2 / 3
         if (d == 128)
-          hipLaunchKernelGGL((linear_staged_kernel<MT, 8>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+          hipLaunchKernelGGL((linear_staged_kernel<MT, 8>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu, variant);
         else
-          hipLaunchKernelGGL((linear_staged_kernel<MT, 4>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+          hipLaunchKernelGGL((linear_staged_kernel<MT, 4>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu, variant);
         return;
       }
 #define GNPDE_LP(KBV) \
