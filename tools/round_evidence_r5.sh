@@ -27,7 +27,9 @@ i=0
 PB="$B --graph arxiv --steps 20 --warmup 0 --no-cpu-baseline --no-roofline-probe --replays 1 --no-graph"
 for CNT in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$i" -o p -- $PB > "$OUT/pmc_$i.log" 2>&1
+  # (GNPDE_REORDER=parts: the order the automatic rule picks for this graph, without its timing probe -- whose launches on OTHER graphs
+  #  entered the mean of round 4's record: 1.245 against 1.16 GB per launch)
+  GNPDE_REORDER=parts timeout 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$i" -o p -- $PB > "$OUT/pmc_$i.log" 2>&1
   DIRS="$DIRS $OUT/pmc_$i"
 done
 python tools/pmc_traffic.py "$OUT/hbm_traffic.json" "arxiv_d128_spmm" "$COMMIT" "$PB" $DIRS > "$OUT/pmc_summary.log" 2>&1
