@@ -844,6 +844,205 @@ def _adjoint_native(func, params, y, a, span, method, step_size):
   return a_out, [by_param.get(id(p)) for p in params]
 
 
+def _adjoint_adaptive_ok(func, y, method):
+  """The ADAPTIVE adjoint methods (`adjoint_method` adaptive_heun -- the reference's default, run_GNN.py:334; best_params Pubmed -- and
+  dopri5 -- CoauthorCS, Computers) on the Laplacian function run with native stages: no autograd graph, no flat vector, two aggregation
+  launches per stage (see _adjoint_adaptive_native).  Everything else keeps the flat host loop."""
+  if method not in ('dopri5', 'adaptive_heun') or func.__class__.__name__ != 'LaplacianODEFunc' or not hasattr(func, '_descriptor'):
+    return False
+  if not (y.is_cuda and y.dim() == 2 and y.dtype == torch.float32):
+    return False
+  opt = func.opt
+  return not (opt.get('no_alpha_sigmoid') or opt.get('gnpde_composite_backward') or opt.get('gnpde_host_adjoint'))
+
+
+def _adjoint_adaptive_native(func, params, y, a, gparams, span, method, rtol, atol, safety=0.9, ifactor=10.0, dfactor=0.2):
+  """One backward interval of torchdiffeq's adjoint with an ADAPTIVE adjoint method, for f(u) = alpha' (A u - u) + beta x0: the augmented
+  system (vjp_t, y, a, g_theta) in reversed time s = -t is
+
+      y' = -f(y),   a' = alpha' (A^T a - a),   g_alpha' = (1 - alpha') <a, f(y) - beta x0>,   g_beta' = <a, x0>,   everything else 0,
+
+  integrated by the embedded pair with torchdiffeq 0.2.1's controller (host, float64; mixed norm = the largest component rms, the
+  scalars being components of their own) exactly as `_solve_dopri5` does on the flat vector -- but on the components: per stage ONE
+  launch of the aggregation on the graph (f, its epilogue forming the next stage input of y) and ONE on the transposed graph (the
+  same for a), two dot products, no autograd graph; per trial step two error-norm launches and one host read.  Returns (a at the earlier
+  time, new accumulated gradients of alpha_train / beta_train as a dict by parameter id)."""
+  import numpy as np
+  from . import ops
+  f32 = np.float32
+  tab = _TABLEAUS[method]
+  order, stages = tab['order'], len(tab['alpha'])
+  dev = y.device
+  n, d = y.shape
+  graph = func._graph(y)
+  gt, t_from_csr = graph.transposed_positions()
+  cache = func.__dict__.setdefault('_adjoint_adaptive', {})
+  key = (n, d, str(dev), method)
+  if cache.get('key') != key:
+    cache.clear()
+    cache['key'] = key
+    cache['bufs'] = [_lib.alloc_state(n, d, dev) for _ in range(2 * (stages + 1) + 9)]
+  bufs = cache['bufs']
+  KF, KV = bufs[:stages + 1], bufs[stages + 1:2 * (stages + 1)]
+  Y, Y1, A_, A1, UY0, UY1, UA0, UA1, X0 = bufs[2 * (stages + 1):]
+  Y.copy_(y.detach())
+  A_.copy_(a.detach())
+  has_src = bool(func.opt['add_source'])
+  if has_src:
+    if func.x0 is None:
+      raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+    X0.copy_(func.x0.detach())
+  desc_f = func._descriptor(Y, x0_override=X0 if has_src else None, graph=graph)
+  w_csr = func._weights_csr(graph)
+  w_t = torch.index_select(w_csr[:graph.e], 0, t_from_csr[:graph.e].long()) if graph.e > 0 else w_csr
+  alpha_d = ops._scalar_dev(func.alpha_train, Y)
+  desc_b = ops.RhsDescriptor(_lib.RHS_LAPLACIAN, gt, d, Y.stride(0), alpha_d, None, None, True, w_csr=w_t, padded_rows=_lib.is_padded(Y))
+  one_minus_a = 1 - torch.sigmoid(func.alpha_train.detach().reshape(()))
+  beta = func.beta_train.detach().reshape(()) if has_src else None
+  ids = [id(p) for p in params]
+  ia = ids.index(id(func.alpha_train)) if id(func.alpha_train) in ids else None
+  ib = ids.index(id(func.beta_train)) if (has_src and id(func.beta_train) in ids) else None
+  g = torch.zeros(2, dtype=torch.float32, device=dev)          # (g_alpha, g_beta) accumulated so far: they scale the tolerance of their components
+  if ia is not None:
+    g[0] = gparams[ia].reshape(())
+  if ib is not None:
+    g[1] = gparams[ib].reshape(())
+  ratio_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+  err_ws = torch.empty(4096, dtype=torch.float32, device=dev)
+  rt, at = float(rtol), float(atol)
+
+  def dot(u, v):
+    return (u * v).sum()
+
+  def feval(uy, ua, j, nxt=None):
+    """K_j of every component at the stage inputs (uy, ua); nxt = (out_uy, out_ua, coefficient row) forms the next stage inputs in the
+    epilogues: u + sum_m (row_m dt) K_m with K_y = -F."""
+    func._check_nfe()
+    if nxt is None:
+      ops.rhs_stage(desc_f, uy, _lib.STAGE_LINCOMB, out_k=KF[j])
+      ops.rhs_stage(desc_b, ua, _lib.STAGE_LINCOMB, out_k=KV[j])
+    else:
+      out_uy, out_ua, row = nxt
+      ops.rhs_stage(desc_f, uy, _lib.STAGE_LINCOMB, y=Y, out_k=KF[j], out_y=out_uy, prev=KF[:j], coef=[-c for c in row])
+      ops.rhs_stage(desc_b, ua, _lib.STAGE_LINCOMB, y=A_, out_k=KV[j], out_y=out_ua, prev=KV[:j], coef=list(row))
+    dx0 = dot(ua, X0) if has_src else torch.zeros((), device=dev)
+    dF = dot(ua, KF[j])
+    ka = one_minus_a * (dF - beta * dx0) if has_src else one_minus_a * dF
+    return torch.stack([ka, dx0])
+
+  def comp_rms(base0, base1, ks, coefs):
+    ops.rk_error_ratio(base0, base1, ks, coefs, at, rt, ratio_dev, err_ws)
+    return ratio_dev.clone()
+
+  def scal_ratio(v, g0, g1):
+    tol = at + rt * torch.max(g0.abs(), g1.abs())
+    r = (v / tol).abs()
+    if ia is None:
+      r = r * torch.tensor([0.0, 1.0], device=dev)
+    if ib is None:
+      r = r * torch.tensor([1.0, 0.0], device=dev)
+    return r.max().reshape(1)
+
+  def mixed(parts):
+    return float(torch.cat(parts).max().item())
+
+  T0, T1 = float(span[0]), float(span[-1])
+  Ks = [None] * (stages + 1)
+  Ks[0] = feval(Y, A_, 0)
+  # initial step (Hairer, Norsett & Wanner), as misc.py _select_initial_step over the mixed norm
+  d0 = mixed([comp_rms(Y, Y, [Y], [1.0]), comp_rms(A_, A_, [A_], [1.0]), scal_ratio(g, g, g)])
+  d1 = mixed([comp_rms(Y, Y, [KF[0]], [1.0]), comp_rms(A_, A_, [KV[0]], [1.0]), scal_ratio(Ks[0], g, g)])
+  h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else float(f32(0.01) * f32(d0) / f32(d1))
+  torch.add(Y, KF[0], alpha=-h0, out=UY0)
+  torch.add(A_, KV[0], alpha=h0, out=UA0)
+  Ks[1] = feval(UY0, UA0, 1)
+  d2 = mixed([comp_rms(Y, Y, [KF[1], KF[0]], [1.0, -1.0]), comp_rms(A_, A_, [KV[1], KV[0]], [1.0, -1.0]), scal_ratio(Ks[1] - Ks[0], g, g)]) / h0
+  h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else float(f32(f32(0.01) / f32(max(d1, d2))) ** f32(1.0 / order))
+  dt = float(min(100 * h0, h1))
+  t_cur = T0
+  a_out = None
+  g_out = g
+  while T1 > t_cur:
+    assert t_cur + dt > t_cur, 'underflow in dt {}'.format(dt)
+    dty = f32(dt)
+    rows = [[float(f32(b) * dty) for b in row] for row in tab['beta']]
+    # first stage input from the derivative carried over (rk_common: f1 = k[..., -1], also for the non-FSAL Heun pair)
+    torch.add(Y, KF[0], alpha=-rows[0][0], out=UY0)
+    torch.add(A_, KV[0], alpha=rows[0][0], out=UA0)
+    uy, ua = [UY0, UY1], [UA0, UA1]
+    src_y, src_a = UY0, UA0
+    for r in range(1, stages + 1):               # K_r at stage input u_r; its epilogue forms u_{r+1}
+      if r < stages:
+        last = r == stages - 1 and tab['fsal']    # (first-same-as-last: the last stage input IS the solution)
+        dst_y = Y1 if last else uy[r % 2]
+        dst_a = A1 if last else ua[r % 2]
+        Ks[r] = feval(src_y, src_a, r, (dst_y, dst_a, rows[r]))
+        src_y, src_a = dst_y, dst_a
+      else:
+        Ks[r] = feval(src_y, src_a, r)
+
+    def axpys(base, ks, cs, sign, out):
+      """out = base + sign * sum_j cs_j ks_j (views of padded rows are fine: plain torch ops)"""
+      first = True
+      for kj, c in zip(ks, cs):
+        if c == 0.0:
+          continue
+        if first:
+          torch.add(base, kj, alpha=sign * c, out=out)
+          first = False
+        else:
+          out.add_(kj, alpha=sign * c)
+      if first:
+        out.copy_(base)
+      return out
+    if tab['fsal']:
+      sol = rows[stages - 1]
+    else:
+      sol = [float(f32(c) * dty) for c in tab['c_sol']]
+      axpys(Y, KF, sol, -1.0, Y1)
+      axpys(A_, KV, sol, 1.0, A1)
+    g1 = g + sum(Ks[j] * sol[j] for j in range(len(sol)) if sol[j] != 0.0)
+    cerr = [float(f32(e) * dty) for e in tab['c_err']]
+    err_s = sum(Ks[j] * cerr[j] for j in range(stages + 1) if cerr[j] != 0.0)
+    ratio = mixed([comp_rms(Y, Y1, KF, cerr), comp_rms(A_, A1, KV, cerr), scal_ratio(err_s, g, g1)])
+    if ratio <= 1:
+      t_next = t_cur + dt
+      if t_next >= T1:     # the end time lies in this step: torchdiffeq's quartic interpolation (only a and the scalars are returned)
+        xf = float(f32((T1 - t_cur) / (t_next - t_cur)))
+        cmid = [float(f32(c) * dty) for c in tab['c_mid']]
+        h = float(dty)
+
+        def interp(v0, v1, k0, k1, mid):
+          ca = 2 * h * (k1 - k0) - 8 * (v1 + v0) + 16 * mid
+          cb = h * (5 * k0 - 3 * k1) + 18 * v0 + 14 * v1 - 32 * mid
+          cc = h * (k1 - 4 * k0) - 11 * v0 - 5 * v1 + 16 * mid
+          cd = h * k0
+          return v0 + xf * cd + xf ** 2 * cc + xf ** 3 * cb + xf ** 4 * ca
+        a_mid = axpys(A_, KV, cmid, 1.0, torch.empty_like(A_))
+        a_out = interp(A_, A1, KV[0], KV[stages], a_mid)[:, :d].contiguous()
+        g_mid = g + sum(Ks[j] * cmid[j] for j in range(stages + 1) if cmid[j] != 0.0)
+        g_out = interp(g, g1, Ks[0], Ks[stages], g_mid)
+      Y, Y1 = Y1, Y
+      A_, A1 = A1, A_
+      KF[0], KF[stages] = KF[stages], KF[0]
+      KV[0], KV[stages] = KV[stages], KV[0]
+      Ks[0] = Ks[stages]
+      g = g1
+      t_cur = t_next
+      # (the descriptor of f reads y-independent operands only: alpha, beta, x0, the weights -- its `ld` is every buffer's)
+    if ratio == 0:
+      dt = dt * ifactor
+    else:
+      lo = 1.0 if ratio < 1 else dfactor
+      dt = dt * min(ifactor, max(safety / ratio ** (1.0 / order), lo))
+  new = {}
+  if ia is not None:
+    new[ia] = g_out[0].reshape(gparams[ia].shape)
+  if ib is not None:
+    new[ib] = g_out[1].reshape(gparams[ib].shape)
+  return a_out, new
+
+
 class _AdjointSolve(torch.autograd.Function):
   """Forward: the plain solve WITHOUT a tape -- on this package's functions that is the native hipGraph solver, so
   the training forward runs at inference speed and stores two states, not the trajectory.  Backward: the augmented
@@ -902,6 +1101,11 @@ class _AdjointSolve(torch.autograd.Function):
           state[2], gp = _adjoint_fixed_grid(func, params, state[1], state[2], state[3:], span, adj['method'],
                                              options['step_size'])
           state = state[:3] + list(gp)
+        elif _adjoint_adaptive_ok(func, state[1], adj['method']) and not options.get('host_flat', False):
+          # adaptive adjoint method on the Laplacian function: native stages on the components (no autograd graph, no flat vector)
+          state[2], new = _adjoint_adaptive_native(func, params, state[1], state[2], state[3:], span, adj['method'], adj['rtol'], adj['atol'])
+          for idx, val in new.items():
+            state[3 + idx] = val
         else:
           flat = odeint(reversed_flat_dynamics, _flatten(state), span, rtol=adj['rtol'], atol=adj['atol'],
                         method=adj['method'], options=options)[1]

@@ -189,3 +189,43 @@ def test_native_adjoint_against_float64_autograd(dev):
   assert_parity(gp['odefunc.multihead_att_layer.K.weight'], wk.grad.float(), 2e-3, 'dWk')
   assert_parity(gp['odefunc.alpha_train'].reshape(()), al.grad.float(), 2e-3, 'dalpha')
   assert_parity(gp['odefunc.beta_train'].reshape(()), be.grad.float(), 2e-3, 'dbeta')
+
+
+ADAPTIVE = {
+  'pubmed_like_heun': dict(block='attention', function='laplacian', method='dopri5', tol_scale=500.0, adjoint_method='adaptive_heun',
+                           tol_scale_adjoint=3000.0, time=4.0, attention_type='cosine_sim', heads=1, attention_dim=16),
+  'coauthor_like_dopri5': dict(block='attention', function='laplacian', method='dopri5', tol_scale=2000.0, adjoint_method='dopri5',
+                               tol_scale_adjoint=1500.0, time=3.0, add_source=False, attention_norm_idx=1, square_plus=True),
+  'constant_dopri5_tight': dict(block='constant', function='laplacian', method='dopri5', tol_scale=10.0, adjoint_method='dopri5',
+                                tol_scale_adjoint=10.0, time=2.0),
+  'constant_heun_d22': dict(block='constant', function='laplacian', method='rk4', adjoint_method='adaptive_heun', tol_scale_adjoint=200.0,
+                            time=2.0, hidden_dim=22),
+}
+
+
+@pytest.mark.parametrize('name', sorted(ADAPTIVE))
+def test_adaptive_adjoint_native_stages_match_the_flat_host_loop(dev, name):
+  """adjoint_method adaptive_heun (the reference's default; best_params Pubmed) / dopri5 (CoauthorCS, Computers) on the Laplacian
+  function: the component-wise solve with native stages (odeint._adjoint_adaptive_native: no autograd graph, no flat vector) against
+  torchdiffeq's flat-vector formulation through the kernel-backed autograd Functions (opt['gnpde_host_adjoint']), same blocks, same
+  inputs: same number of evaluations (the controllers see the same numbers to rounding) and gradients to the solver's tolerance."""
+  opt = _opt(**ADAPTIVE[name])
+  n, d = 1200, opt['hidden_dim']
+  ei = random_graph(n, 5, seed=91, hubs=1, hub_deg=600).to(dev)
+  x = (torch.randn(n, d, generator=torch.Generator().manual_seed(92)) * 0.5).to(dev)
+  z1, gx1, g1, _, nfe1 = _run(dev, opt, ei, x, 93, host=False)
+  z2, gx2, g2, _, nfe2 = _run(dev, opt, ei, x, 93, host=True)
+  assert torch.equal(z1, z2)
+  # same accept / reject sequence -> agreement to float32 rounding; a ratio within rounding of 1 may flip one decision, then the two
+  # solves agree to their tolerance like any two adaptive solves
+  tol = 1e-4 if nfe1 == nfe2 else 2e-3
+  assert abs(nfe1 - nfe2) <= 12, (nfe1, nfe2)
+  assert_parity(gx1, gx2, tol, name + ' grad_x')
+  checked = 0
+  for k, ref in g2.items():
+    if float(ref.abs().max()) < 1e-7:
+      continue
+    assert k in g1, k
+    assert_parity(g1[k], ref, tol, name + ' ' + k)
+    checked += 1
+  assert checked >= 1
