@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 _THIRD = 1 / 3
+_TRIAL_TRACE = None       # tests / diagnostics: a list that receives (t, dt, error ratio) of every trial step of the host-controlled adaptive solves
 _EVALS_PER_STEP = {'euler': 1, 'midpoint': 2, 'rk4': 4}
 
 
@@ -251,6 +252,8 @@ def _solve_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, safety=0.9
       tol = atol_t + rtol_t * torch.max(y.abs(), y1.abs())
       ratio = nrm(err / tol)
       accept = bool(ratio <= 1)
+      if _TRIAL_TRACE is not None:
+        _TRIAL_TRACE.append((float(t_cur), float(dt), float(ratio)))
       if accept:
         y_mid = _combine(y, ks, tab['c_mid'], dty)
         interp = (y, y1, y_mid, ks[0], ks[-1], dty, t_cur, t_cur + dt)
@@ -1005,6 +1008,8 @@ def _adjoint_adaptive_native(func, params, y, a, gparams, span, method, rtol, at
     cerr = [float(f32(e) * dty) for e in tab['c_err']]
     err_s = sum(Ks[j] * cerr[j] for j in range(stages + 1) if cerr[j] != 0.0)
     ratio = mixed([comp_rms(Y, Y1, KF, cerr), comp_rms(A_, A1, KV, cerr), scal_ratio(err_s, g, g1)])
+    if _TRIAL_TRACE is not None:
+      _TRIAL_TRACE.append((t_cur, dt, ratio))
     if ratio <= 1:
       t_next = t_cur + dt
       if t_next >= T1:     # the end time lies in this step: torchdiffeq's quartic interpolation (only a and the scalars are returned)

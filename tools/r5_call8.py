@@ -1,0 +1,39 @@
+# diagnostic: trial-step traces of the adaptive adjoint backward, native stages vs flat host loop (Pubmed-shaped block)
+import importlib, sys, time, torch
+sys.path.insert(0, '.')
+import gnpde_amd as G
+from tests.helpers import Data, random_graph
+O = importlib.import_module('gnpde_amd.odeint')
+dev = torch.device('cuda:0')
+n, d = 19717, 128
+ei = random_graph(n, 4, seed=5).to(dev)
+x = (torch.randn(n, d, generator=torch.Generator().manual_seed(6)) * 0.5).to(dev)
+base = dict(heads=1, attention_dim=16, attention_type='cosine_sim', attention_norm_idx=0, square_plus=True, reweight_attention=False, beltrami=False,
+            leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=5000, add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=d,
+            augment=False, adjoint=True, adjoint_method='adaptive_heun', adjoint_step_size=1, tol_scale=1991.07, tol_scale_adjoint=16324.37,
+            data_norm='rw', method='dopri5', step_size=1, max_iters=100, block='attention', function='laplacian', time=12.94)
+traces = {}
+for host in (False, True):
+  opt = dict(base, gnpde_host_adjoint=host)
+  block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x, ei), dev, t=torch.tensor([0, opt['time']])).to(dev)
+  g = torch.Generator().manual_seed(1)
+  with torch.no_grad():
+    for p in block.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+  block.train()
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  O._TRIAL_TRACE = []
+  z.sum().backward()
+  traces[host] = O._TRIAL_TRACE
+  O._TRIAL_TRACE = None
+  print('host' if host else 'native', 'trials', len(traces[host]), 'grad alpha', float(block.odefunc.alpha_train.grad), 'beta', float(block.odefunc.beta_train.grad), 'gx norm', float(xin.grad.norm()))
+for i in range(min(len(traces[False]), len(traces[True]), 400)):
+  a, b = traces[False][i], traces[True][i]
+  flag = '' if abs(a[2] - b[2]) <= 1e-3 * max(abs(b[2]), 1e-9) and (a[2] <= 1) == (b[2] <= 1) else '   <---'
+  if i < 12 or flag:
+    print(i, 'native t %.5f dt %.6f ratio %.6f | host t %.5f dt %.6f ratio %.6f%s' % (a + b + (flag,)))
+  if flag and i > 12:
+    break
