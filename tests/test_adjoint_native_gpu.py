@@ -229,3 +229,17 @@ def test_adaptive_adjoint_native_stages_match_the_flat_host_loop(dev, name):
     assert_parity(g1[k], ref, tol, name + ' ' + k)
     checked += 1
   assert checked >= 1
+
+
+def test_adaptive_adjoint_native_stages_are_reproducible(dev):
+  """Two runs of the same training step through the native adaptive adjoint give the same bits (no atomics, fixed-order reductions)."""
+  opt = _opt(**ADAPTIVE['pubmed_like_heun'])
+  n, d = 3000, opt['hidden_dim']
+  ei = random_graph(n, 5, seed=94).to(dev)
+  x = (torch.randn(n, d, generator=torch.Generator().manual_seed(95)) * 0.5).to(dev)
+  z1, gx1, g1, _, nfe1 = _run(dev, opt, ei, x, 96, host=False)
+  z2, gx2, g2, _, nfe2 = _run(dev, opt, ei, x, 96, host=False)
+  assert torch.equal(z1, z2) and nfe1 == nfe2
+  assert torch.equal(gx1, gx2)
+  for k in g1:
+    assert torch.equal(g1[k], g2[k]), k
