@@ -69,11 +69,13 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
-  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch'],
+  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch', 'pubmed-adjoint'],
                   help='c4: BASELINE configs[3] -- ogbn-arxiv BLEND (beltrami split kernel, d = 64 + 98 = 162), block_transformer_rewiring in '
                        'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward).  '
                        'cora-epoch: the reference\'s flagship run -- best_params Cora (attention block, Laplacian function, dopri5, adjoint=False, '
-                       '8 heads, A = 128, squareplus over columns) on a Cora-LCC-shaped graph: one epoch = run_GNN.py train() + test()')
+                       '8 heads, A = 128, squareplus over columns) on a Cora-LCC-shaped graph: one epoch = run_GNN.py train() + test().  pubmed-adjoint: best_params '
+                       'Pubmed\'s ODE block (attention block, Laplacian, dopri5, adjoint=True with adjoint_method adaptive_heun -- the reference\'s default '
+                       'adjoint method) on a Pubmed-shaped graph: ms per training iteration of the block, native stages vs the flat host loop')
   ap.add_argument('--no-configs', action='store_true',
                   help='default line only: skip the `configs` block (the other BASELINE configurations, each measured by a child process of this script)')
   ap.add_argument('--configs-budget', type=float, default=1100.0, help='seconds the `configs` block may take in total (children past it are skipped, and say so)')
@@ -988,6 +990,87 @@ def cora_epoch_main(G, args, dev):
   print(json.dumps(out))
 
 
+def pubmed_adjoint_main(G, args, dev):
+  """`--config pubmed-adjoint`: the ODE block of best_params Pubmed -- attention block (cosine_sim, 1 head, A = 16, squareplus), Laplacian
+  function, d = 128, dopri5 `tol_scale` 1991, T = 12.94, `adjoint = True` with `adjoint_method = adaptive_heun` (run_GNN.py's default
+  adjoint method) and `tol_scale_adjoint` 16 324 -- on a Pubmed-shaped graph (19 717 nodes, 44 324 undirected edges): one training
+  iteration of the block (forward: the device-controlled dopri5; backward: torchdiffeq's augmented system integrated component-wise with
+  native stages, odeint._adjoint_adaptive_native) next to the same iteration through torchdiffeq's flat-vector loop
+  (opt['gnpde_host_adjoint'])."""
+  import numpy as np
+  n, pairs, d = 19717, 44324, 128
+  rng = np.random.default_rng(args.seed + 11)
+  a, b = rng.integers(0, n, 2 * pairs), rng.integers(0, n, 2 * pairs)
+  keep = a != b
+  key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+  key = np.sort(rng.permutation(key)[:pairs])
+  lo, hi = key // n, key % n
+  row, col = np.concatenate([lo, hi]), np.concatenate([hi, lo])
+  order = np.lexsort((col, row))
+  ei = torch.from_numpy(np.stack([row[order], col[order]])).long().to(dev)
+  x = (torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed + 12)) * 0.5).to(dev)
+  base = dict(heads=1, attention_dim=16, attention_type='cosine_sim', attention_norm_idx=0, square_plus=True, reweight_attention=False, beltrami=False,
+              leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=5000, add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=d,
+              augment=False, adjoint=True, adjoint_method='adaptive_heun', adjoint_step_size=1, tol_scale=1991.0688305523001,
+              tol_scale_adjoint=16324.368093998313, data_norm='rw', method='dopri5', step_size=1, max_iters=100, block='attention',
+              function='laplacian', time=12.942327880200853)
+  data = _Data()
+  data.x, data.edge_index, data.edge_attr, data.num_nodes = x, ei, None, n
+  res = {}
+  for host in (False, True):
+    opt = dict(base, gnpde_host_adjoint=host)
+    block = G.AttODEblock(G.LaplacianODEFunc, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
+    g = torch.Generator().manual_seed(args.seed + 13)
+    with torch.no_grad():
+      for p in block.parameters():
+        if p.dim() >= 2:
+          p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+    block.train()
+    runs = []
+    for it in range(2 + (max(args.replays, 3) if not host else 2)):
+      xin = x.clone().requires_grad_(True)
+      block.set_x0(xin)
+      block.odefunc.nfe = 0
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      z = block(xin)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      nf = block.odefunc.nfe
+      z.sum().backward()
+      torch.cuda.synchronize()
+      t2 = time.perf_counter()
+      runs.append((t1 - t0, t2 - t1, nf, block.odefunc.nfe - nf))
+    runs = runs[2:]
+    fw = sorted(r[0] for r in runs)[len(runs) // 2]
+    bw = sorted(r[1] for r in runs)[len(runs) // 2]
+    res[host] = dict(forward_ms=round(fw * 1e3, 3), backward_ms=round(bw * 1e3, 3), evals_forward=runs[-1][2], augmented_evals_backward=runs[-1][3],
+                     grad_x=xin.grad.detach().clone(), z=z.detach())
+  from oracle import restate as R
+  e_inf, e_2 = R.parity_error(res[False]['grad_x'], res[True]['grad_x'])
+  nat, hst = res[False], res[True]
+  out = {
+    'metric': 'ms per training iteration of the ODE block (forward + adaptive_heun adjoint backward), Pubmed shape d=128',
+    'value': round(nat['forward_ms'] + nat['backward_ms'], 3), 'unit': 'ms', 'n_gpus': 1, 'steps': 1, 'warmup': 2,
+    'ms_per_step': round(nat['forward_ms'] + nat['backward_ms'], 3), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+    'data': 'synthetic',
+    'config': {'workload': 'ODE block of best_params Pubmed (attention block: cosine_sim, 1 head, A = 16, squareplus; Laplacian function; dopri5 tol_scale 1991, '
+                           'T = 12.94; adjoint=True, adjoint_method adaptive_heun, tol_scale_adjoint 16324) on a Pubmed-shaped synthetic graph; one step = one '
+                           'training iteration of the block (loss = sum of the output)', 'nodes': n, 'edges_with_self_loops': int(ei.shape[1]) + n, 'd': d},
+    'forward_ms': nat['forward_ms'], 'backward_ms': nat['backward_ms'], 'evals_forward': nat['evals_forward'],
+    'augmented_evals_backward': nat['augmented_evals_backward'],
+    'flat_host_loop': {k: hst[k] for k in ('forward_ms', 'backward_ms', 'evals_forward', 'augmented_evals_backward')},
+    'backward_speedup_vs_flat_host_loop': round(hst['backward_ms'] / nat['backward_ms'], 2),
+    'parity_vs_flat_host_loop': {'grad_x_rel_max': e_inf, 'grad_x_rel_l2': e_2, 'z_bitwise_equal': bool(torch.equal(nat['z'], hst['z'])),
+                                 'what': 'dL/dx of the same iteration through torchdiffeq\'s flat-vector loop: two adaptive solves at tol_scale_adjoint 16324 '
+                                         '(atol 1.6e-3) whose controllers are driven by a float32 scalar component -- agreement to the solver tolerance, not to rounding '
+                                         '(profiles/r05_adaptive_adjoint_pubmed_shape.txt)'},
+    'roofline': None, 'roofline_note': 'launch-bound (10-MB state, ~250 us of host work per augmented evaluation): no bandwidth roofline to quote',
+    'cpu_baseline': None,
+  }
+  print(json.dumps(out))
+
+
 def train_main(G, args, opt, cfg, ei, n, x, dev):
   """`--train`: one training iteration of the ODE block at the benchmark shape -- forward = the tape-free native solver (K rk4
   steps, as inference), backward = the native adjoint solve (csrc/adjoint.hip: K rk4 steps of the augmented system, 4 K stages of
@@ -1144,6 +1227,8 @@ CONFIG_CHILDREN = (
    ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120),
   ('cora_best_params_epoch', 'the reference\'s flagship run (best_params Cora: attention block, Laplacian, dopri5, adjoint=False): s per epoch',
    ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240),
+  ('pubmed_block_adaptive_heun_adjoint', 'best_params Pubmed\'s ODE block in training: dopri5 forward, adjoint_method adaptive_heun (the reference\'s default)',
+   ['--config', 'pubmed-adjoint'], 200),
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
    ['--train', '--steps', '10', '--warmup', '2'], 400),
   ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
@@ -1174,7 +1259,8 @@ def summarise_child(line):
   elif 'node_relabelling' in cfg:
     keep['node_relabelling'] = None
   for k in ('parity_vs_oracle_one_eval', 'parity_vs_restated_torchdiffeq', 'parity_vs_oracle_row_subset', 'parity_vjp_one_eval_vs_oracle', 'speedup_vs_cpu',
-            'ms_per_forward', 'ms_solve_only', 'rhs_evals_per_forward', 'dopri5', 'forward_ms', 'backward_ms', 'f_plus_vjp_ms', 'ms_train_step', 'ms_test_step',
+            'ms_per_forward', 'ms_solve_only', 'rhs_evals_per_forward', 'dopri5', 'forward_ms', 'backward_ms', 'f_plus_vjp_ms', 'flat_host_loop',
+            'backward_speedup_vs_flat_host_loop', 'parity_vs_flat_host_loop', 'evals_forward', 'augmented_evals_backward', 'ms_train_step', 'ms_test_step',
             'ms_train_phases_synchronised', 'nfe_forward_per_epoch', 'nfe_backward_per_epoch', 'nfe_test_per_epoch', 'train_solve_path', 'timing'):
     if k in line:
       v = line[k]
@@ -1256,6 +1342,8 @@ def main():
     return c4_main(G, args, dev)
   if args.config == 'cora-epoch':
     return cora_epoch_main(G, args, dev)
+  if args.config == 'pubmed-adjoint':
+    return pubmed_adjoint_main(G, args, dev)
   cfg = G.synthetic.CONFIGS[args.graph]
   ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
   opt = build_opt(cfg, args)
