@@ -1021,10 +1021,12 @@ def pubmed_adjoint_main(G, args, dev):
     opt = dict(base, gnpde_host_adjoint=host)
     block = G.AttODEblock(G.LaplacianODEFunc, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
     g = torch.Generator().manual_seed(args.seed + 13)
-    with torch.no_grad():
-      for p in block.parameters():
+    with torch.no_grad():         # EVERY parameter from the seeded generator (nn.Linear's own bias init draws from the global RNG: two blocks would differ)
+      for name, p in block.named_parameters():
         if p.dim() >= 2:
           p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+        elif name.endswith('.bias'):
+          p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
     block.train()
     runs = []
     for it in range(2 + (max(args.replays, 3) if not host else 2)):
