@@ -1064,9 +1064,8 @@ def pubmed_adjoint_main(G, args, dev):
     'flat_host_loop': {k: hst[k] for k in ('forward_ms', 'backward_ms', 'evals_forward', 'augmented_evals_backward')},
     'backward_speedup_vs_flat_host_loop': round(hst['backward_ms'] / nat['backward_ms'], 2),
     'parity_vs_flat_host_loop': {'grad_x_rel_max': e_inf, 'grad_x_rel_l2': e_2, 'z_bitwise_equal': bool(torch.equal(nat['z'], hst['z'])),
-                                 'what': 'dL/dx of the same iteration through torchdiffeq\'s flat-vector loop: two adaptive solves at tol_scale_adjoint 16324 '
-                                         '(atol 1.6e-3) whose controllers are driven by a float32 scalar component -- agreement to the solver tolerance, not to rounding '
-                                         '(profiles/r05_adaptive_adjoint_pubmed_shape.txt)'},
+                                 'what': 'dL/dx of the same iteration (identical parameters) through torchdiffeq\'s flat-vector loop; the two take the same '
+                                         'steps when `augmented_evals_backward` agree'},
     'roofline': None, 'roofline_note': 'launch-bound (10-MB state, ~250 us of host work per augmented evaluation): no bandwidth roofline to quote',
     'cpu_baseline': None,
   }
