@@ -24,9 +24,11 @@ for host in (False, True):
   block = G.AttODEblock(G.LaplacianODEFunc, [], opt, Data(x, ei), dev, t=torch.tensor([0, opt['time']])).to(dev)
   g = torch.Generator().manual_seed(1)
   with torch.no_grad():
-    for p in block.parameters():
+    for name, p in block.named_parameters():        # (every parameter seeded: nn.Linear's default bias init would make the two blocks differ)
       if p.dim() >= 2:
         p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      elif name.endswith('.bias'):
+        p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
   block.train()
   ts = []
   for it in range(4):
