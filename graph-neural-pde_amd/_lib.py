@@ -172,6 +172,13 @@ PROTOTYPES = {
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   'gnpde_dopri5_set_row_order': (ctypes.c_int, [c_vp, c_vp]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_adjoint_heun_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct)]),
+  'gnpde_adjoint_heun_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, ctypes.c_float,
+                                               ctypes.c_float, c_vp, ctypes.c_size_t]),
+  'gnpde_adjoint_heun_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_adjoint_heun_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  'gnpde_adjoint_heun_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_dopri5_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
   'gnpde_dopri5_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, ctypes.c_int32]),
   'gnpde_dopri5_tape_steps': (ctypes.c_int, [c_vp]),

@@ -243,3 +243,26 @@ def test_adaptive_adjoint_native_stages_are_reproducible(dev):
   assert torch.equal(gx1, gx2)
   for k in g1:
     assert torch.equal(g1[k], g2[k]), k
+
+
+@pytest.mark.parametrize('name', ['pubmed_like_heun', 'constant_heun_d22'])
+def test_adaptive_heun_adjoint_device_controller(dev, name):
+  """adjoint_method = adaptive_heun (the reference's default): the controller on the device (csrc/adjoint_heun.hip, one hipGraph replay per
+  trial step) against the same component-wise solve with the controller on the host (opt['gnpde_host_controller_adjoint']) -- same
+  evaluations, gradients to float32 rounding -- with hub rows and (d = 22) padded rows; and a second iteration replays the captured
+  trial steps bit for bit."""
+  opt = _opt(**ADAPTIVE[name])
+  n, d = 1500, opt['hidden_dim']
+  ei = random_graph(n, 5, seed=97, hubs=2, hub_deg=700).to(dev)
+  x = (torch.randn(n, d, generator=torch.Generator().manual_seed(98)) * 0.5).to(dev)
+  z1, gx1, g1, _, nfe1 = _run(dev, opt, ei, x, 99, host=False)
+  z2, gx2, g2, _, nfe2 = _run(dev, dict(opt, gnpde_host_controller_adjoint=True), ei, x, 99, host=False)
+  assert torch.equal(z1, z2)
+  assert nfe1 == nfe2, (nfe1, nfe2)
+  assert_parity(gx1, gx2, 2e-5, name + ' grad_x')
+  for k, ref in g2.items():
+    if float(ref.abs().max()) < 1e-7:
+      continue
+    assert_parity(g1[k], ref, 2e-5, name + ' ' + k)
+  z3, gx3, g3, _, nfe3 = _run(dev, opt, ei, x, 99, host=False)
+  assert torch.equal(gx1, gx3) and nfe1 == nfe3
