@@ -22,6 +22,7 @@ ABI_VERSION = 4      # GNPDE_ABI_VERSION of include/gnpde.h this package's struc
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4, METHOD_MIDPOINT = range(3)
+ADAPTIVE_HEUN, ADAPTIVE_DOPRI5 = range(2)
 TUNE_SPMM_VARIANT, TUNE_FUSED_BLOCKS_PER_CU, TUNE_ONE_PASS, TUNE_FORK, TUNE_ATT_GENERIC_ROWS, TUNE_RK4_CLASSIC = range(6)
 TUNE_ROW_FUSION, TUNE_ONE_PASS_VARIANT, TUNE_LINEAR_STREAMING, TUNE_SPMM_PART, TUNE_XCD_ROWS, TUNE_HUB_FOLD = 6, 7, 8, 9, 10, 11
 
@@ -172,13 +173,13 @@ PROTOTYPES = {
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   'gnpde_dopri5_set_row_order': (ctypes.c_int, [c_vp, c_vp]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
-  'gnpde_adjoint_heun_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct)]),
-  'gnpde_adjoint_heun_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, ctypes.c_float,
-                                               ctypes.c_float, c_vp, ctypes.c_size_t]),
-  'gnpde_adjoint_heun_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                            ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
-  'gnpde_adjoint_heun_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-  'gnpde_adjoint_heun_destroy': (ctypes.c_int, [c_vp]),
+  'gnpde_adjoint_adaptive_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), ctypes.c_int32]),
+  'gnpde_adjoint_adaptive_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32,
+                                                   ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t]),
+  'gnpde_adjoint_adaptive_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp, ctypes.c_double, ctypes.c_double,
+                                                ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
+  'gnpde_adjoint_adaptive_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  'gnpde_adjoint_adaptive_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_dopri5_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32]),
   'gnpde_dopri5_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, ctypes.c_int32]),
   'gnpde_dopri5_tape_steps': (ctypes.c_int, [c_vp]),

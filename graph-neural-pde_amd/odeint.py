@@ -962,10 +962,10 @@ def _adjoint_adaptive_native(func, params, y, a, gparams, span, method, rtol, at
   d2 = mixed([comp_rms(Y, Y, [KF[1], KF[0]], [1.0, -1.0]), comp_rms(A_, A_, [KV[1], KV[0]], [1.0, -1.0]), scal_ratio(Ks[1] - Ks[0], g, g)]) / h0
   h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else float(f32(f32(0.01) / f32(max(d1, d2))) ** f32(1.0 / order))
   dt = float(min(100 * h0, h1))
-  if (method == 'adaptive_heun' and ia is not None and (ib is not None or not has_src) and not func.opt.get('gnpde_host_controller_adjoint')
+  if (ia is not None and (ib is not None or not has_src) and not func.opt.get('gnpde_host_controller_adjoint')
       and Y.stride(0) % 4 == 0 and d <= 256):
-    # the reference's default adjoint method: the rest of the interval with the controller on the device (csrc/adjoint_heun.hip: one
-    # hipGraph replay per trial step; the host reads a record once per batch)
+    # the rest of the interval with the controller on the device (csrc/adjoint_adaptive.hip: one hipGraph replay per trial step of the
+    # embedded pair; the host reads a record once per batch)
     from .utils import MaxNFEException
     if cache.get('w_t') is None or cache['w_t'].numel() != max(graph.e, 1):
       cache['w_t'] = torch.empty(max(graph.e, 1), dtype=torch.float32, device=dev)
@@ -975,7 +975,7 @@ def _adjoint_adaptive_native(func, params, y, a, gparams, span, method, rtol, at
     if cache.get('heun') is None or cache.get('heun_sig') != sig:
       if cache.get('heun') is not None:
         cache['heun'].close()
-      cache['heun'] = ops.AdjointHeunSolver(desc_f, gt, cache['w_t'], rt, at, dev)
+      cache['heun'] = ops.AdjointAdaptiveSolver(desc_f, gt, cache['w_t'], method, rt, at, dev)
       cache['heun_sig'] = sig
     sol = cache['heun']
     room = func.opt['max_nfe'] + 1 - func.nfe

@@ -516,20 +516,21 @@ class Dopri5Solver(object):
     self.close()
 
 
-class AdjointHeunSolver(object):
-  """gnpde_adjoint_heun_t: one backward interval of the adjoint with adjoint_method = 'adaptive_heun' on the Laplacian function, the
-  controller on the device (one hipGraph replay per trial step)."""
+class AdjointAdaptiveSolver(object):
+  """gnpde_adjoint_adaptive_t: one backward interval of the adjoint with an adaptive adjoint method ('adaptive_heun' / 'dopri5') on the
+  Laplacian function, the controller on the device (one hipGraph replay per trial step)."""
 
-  def __init__(self, desc, graph_t, w_t, rtol, atol, device):
+  def __init__(self, desc, graph_t, w_t, method, rtol, atol, device):
     self.desc, self.graph_t, self.w_t = desc, graph_t, w_t
+    self.method = {'adaptive_heun': _lib.ADAPTIVE_HEUN, 'dopri5': _lib.ADAPTIVE_DOPRI5}[method]
     L = _lib.lib()
-    nbytes = int(L.gnpde_adjoint_heun_workspace_bytes(desc.ref(), graph_t.ref()))
+    nbytes = int(L.gnpde_adjoint_adaptive_workspace_bytes(desc.ref(), graph_t.ref(), self.method))
     if nbytes == 0:
-      raise _lib.GnpdeError('adaptive_heun adjoint: %s' % L.gnpde_last_error().decode(errors='replace'))
+      raise _lib.GnpdeError('adaptive adjoint: %s' % L.gnpde_last_error().decode(errors='replace'))
     self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     handle = ctypes.c_void_p()
-    check(L.gnpde_adjoint_heun_create(ctypes.byref(handle), desc.ref(), graph_t.ref(), ptr(w_t), float(rtol), float(atol), ptr(self.ws),
-                                      self.ws.numel()))
+    check(L.gnpde_adjoint_adaptive_create(ctypes.byref(handle), desc.ref(), graph_t.ref(), ptr(w_t), self.method, float(rtol), float(atol),
+                                          ptr(self.ws), self.ws.numel()))
     self.handle = handle
 
   def run(self, y, a, g, s0, s1, dt0, trials_per_sync=8, max_evals=0):
@@ -538,19 +539,19 @@ class AdjointHeunSolver(object):
     require_hip(y, a, g)
     y, a = _lib.f32rows(y, 'y'), _lib.f32rows(a, 'a')
     fin = ctypes.c_int32(0)
-    check(_lib.lib().gnpde_adjoint_heun_run(self.handle, ptr(y), y.stride(0), ptr(a), a.stride(0), ptr(g), float(s0), float(s1), float(dt0),
-                                            int(trials_per_sync), int(max_evals), ctypes.byref(fin), stream_of(y)))
+    check(_lib.lib().gnpde_adjoint_adaptive_run(self.handle, ptr(y), y.stride(0), ptr(a), a.stride(0), ptr(g), float(s0), float(s1), float(dt0),
+                                                int(trials_per_sync), int(max_evals), ctypes.byref(fin), stream_of(y)))
     return bool(fin.value)
 
   def stats(self):
     v = [ctypes.c_int32(0) for _ in range(5)]
-    check(_lib.lib().gnpde_adjoint_heun_stats(self.handle, *[ctypes.byref(x) for x in v]))
+    check(_lib.lib().gnpde_adjoint_adaptive_stats(self.handle, *[ctypes.byref(x) for x in v]))
     return dict(zip(('evals', 'accepted', 'rejected', 'launches', 'syncs'), [x.value for x in v]))
 
   def close(self):
     if getattr(self, 'handle', None) is not None and self.handle.value:
       try:
-        _lib.lib().gnpde_adjoint_heun_destroy(self.handle)
+        _lib.lib().gnpde_adjoint_adaptive_destroy(self.handle)
       except Exception:
         pass
       self.handle = None

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 4   /* 4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_heun_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 4   /* 4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -594,33 +594,35 @@ int gnpde_dopri5_tape_backward(gnpde_dopri5_t* s, const gnpde_graph_t* graph_t, 
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Adjoint with adjoint_method = 'adaptive_heun', the controller ON THE DEVICE  [replaces torchdiffeq 0.2.1's odeint_adjoint backward
- * pass with its DEFAULT adjoint method in the reference (src/run_GNN.py:334 `--adjoint_method adaptive_heun`; best_params Pubmed) as
- * reached from src/base_classes.py:44-47: the augmented state (vjp_t, y, a, g_theta) integrated backwards as one flat vector through
- * autograd (adjoint.py augmented_dynamics), AdaptiveHeunSolver / RKAdaptiveStepsizeODESolver with the mixed norm of misc.py]
+ * Adjoint with an ADAPTIVE adjoint method, the controller ON THE DEVICE  [replaces torchdiffeq 0.2.1's odeint_adjoint backward pass
+ * with `adjoint_method` 'adaptive_heun' -- the reference's DEFAULT (src/run_GNN.py:334; best_params Pubmed) -- or 'dopri5' (best_params
+ * CoauthorCS, Computers) as reached from src/base_classes.py:44-47: the augmented state (vjp_t, y, a, g_theta) integrated backwards as one
+ * flat vector through autograd (adjoint.py augmented_dynamics), AdaptiveHeunSolver / Dopri5Solver with the mixed norm of misc.py]
  *
  * GRAND-l descriptors only: for f(u) = alpha' (A u - u) + beta x0 the system decouples (reversed time s = -t) into
  *   y' = -f(y),  a' = alpha' (A^T a - a),  g_alpha' = (1 - alpha') <a, f(y) - beta x0>,  g_beta' = <a, x0>.
- * One TRIAL step of the Heun-Euler pair = one hipGraph of six launches (fused row kernel on the graph incl. the dots, aggregation on the
- * transposed graph, two error norms, control, finish: csrc/adjoint_heun.hip); accept / reject, step size (float64), mixed norm (largest
- * of rms(y), rms(a), |g_alpha|, |g_beta| errors over their tolerances), end-point interpolation decided by kernels from a 112-byte record
- * the host reads once per batch of trial steps.  torchdiffeq's rule throughout (safety 0.9, factors 0.2 / 10, order 2, the last stage
- * derivative carried over as the next step's first).
+ * One TRIAL step of the embedded pair = one hipGraph: per stage the fused row kernel on the graph (f at the stage input, the next stage
+ * input in its epilogue, the dots) and the aggregation on the transposed graph, then two error norms, control, finish
+ * (csrc/adjoint_adaptive.hip); accept / reject, step size (float64), mixed norm (largest of rms(y), rms(a), |g_alpha|, |g_beta| errors
+ * over their tolerances), end-point interpolation decided by kernels from a 112-byte record the host reads once per batch of trial steps.
+ * torchdiffeq's rule throughout (safety 0.9, factors 0.2 / 10, the pair's order, the last stage derivative carried over as the next
+ * step's first).
  *   rhs: f on the graph (kind GNPDE_RHS_LAPLACIAN; x0 / beta optional); graph_t / w_t: the transposed graph and the weights in ITS CSR
- *   order; rtol / atol: the adjoint tolerances.
- *   gnpde_adjoint_heun_run: y [n, ld_y] = the state at the LATER time (read), a [n, ld_a] in: dL/dy there, out: at the earlier time;
+ *   order; method: GNPDE_ADAPTIVE_*; rtol / atol: the adjoint tolerances.
+ *   gnpde_adjoint_adaptive_run: y [n, ld_y] = the state at the LATER time (read), a [n, ld_a] in: dL/dy there, out: at the earlier time;
  *   g (device float[2]) in / out: accumulated (g_alpha, g_beta); integrates s from s0 to s1 > s0 (= -t) starting with step dt0 (the
  *   caller selects it: misc.py _select_initial_step, two evaluations).  max_evals / *finished as gnpde_dopri5_run.  Synchronises the stream
  *   while it runs (one read per batch); the final copies are queued behind. */
-typedef struct gnpde_adjoint_heun gnpde_adjoint_heun_t;
-size_t gnpde_adjoint_heun_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t);
-int gnpde_adjoint_heun_create(gnpde_adjoint_heun_t** out, const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, const float* w_t,
-                              float rtol, float atol, void* workspace, size_t workspace_bytes);
-int gnpde_adjoint_heun_run(gnpde_adjoint_heun_t* s, const float* y, int32_t ld_y, float* a, int32_t ld_a, float* g, double s0, double s1,
-                           double dt0, int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream);
-int gnpde_adjoint_heun_stats(const gnpde_adjoint_heun_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected, int32_t* n_launches,
-                             int32_t* n_syncs);
-int gnpde_adjoint_heun_destroy(gnpde_adjoint_heun_t* s);
+enum { GNPDE_ADAPTIVE_HEUN = 0, GNPDE_ADAPTIVE_DOPRI5 = 1 };
+typedef struct gnpde_adjoint_adaptive gnpde_adjoint_adaptive_t;
+size_t gnpde_adjoint_adaptive_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, int32_t method);
+int gnpde_adjoint_adaptive_create(gnpde_adjoint_adaptive_t** out, const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, const float* w_t,
+                                  int32_t method, float rtol, float atol, void* workspace, size_t workspace_bytes);
+int gnpde_adjoint_adaptive_run(gnpde_adjoint_adaptive_t* s, const float* y, int32_t ld_y, float* a, int32_t ld_a, float* g, double s0,
+                               double s1, double dt0, int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream);
+int gnpde_adjoint_adaptive_stats(const gnpde_adjoint_adaptive_t* s, int32_t* n_evals, int32_t* n_accepted, int32_t* n_rejected,
+                                 int32_t* n_launches, int32_t* n_syncs);
+int gnpde_adjoint_adaptive_destroy(gnpde_adjoint_adaptive_t* s);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU halo exchange helpers (row-partitioned graph, one process per GPU, RCCL between).

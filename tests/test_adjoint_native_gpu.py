@@ -245,11 +245,11 @@ def test_adaptive_adjoint_native_stages_are_reproducible(dev):
     assert torch.equal(g1[k], g2[k]), k
 
 
-@pytest.mark.parametrize('name', ['pubmed_like_heun', 'constant_heun_d22'])
-def test_adaptive_heun_adjoint_device_controller(dev, name):
-  """adjoint_method = adaptive_heun (the reference's default): the controller on the device (csrc/adjoint_heun.hip, one hipGraph replay per
-  trial step) against the same component-wise solve with the controller on the host (opt['gnpde_host_controller_adjoint']) -- same
-  evaluations, gradients to float32 rounding -- with hub rows and (d = 22) padded rows; and a second iteration replays the captured
+@pytest.mark.parametrize('name', sorted(ADAPTIVE))
+def test_adaptive_adjoint_device_controller(dev, name):
+  """adjoint_method = adaptive_heun (the reference's default) / dopri5: the controller on the device (csrc/adjoint_adaptive.hip, one hipGraph
+  replay per trial step) against the same component-wise solve with the controller on the host (opt['gnpde_host_controller_adjoint']) --
+  same evaluations, gradients to float32 rounding -- with hub rows and (d = 22) padded rows; and a second iteration replays the captured
   trial steps bit for bit."""
   opt = _opt(**ADAPTIVE[name])
   n, d = 1500, opt['hidden_dim']
