@@ -972,18 +972,18 @@ def _adjoint_adaptive_native(func, params, y, a, gparams, span, method, rtol, at
     if graph.e > 0:
       cache['w_t'][:graph.e].copy_(w_t)          # persistent address: the captured trial steps keep the pointer
     sig = (func._descriptor_signature(desc_f), id(gt), float(rt), float(at))
-    if cache.get('heun') is None or cache.get('heun_sig') != sig:
-      if cache.get('heun') is not None:
-        cache['heun'].close()
-      cache['heun'] = ops.AdjointAdaptiveSolver(desc_f, gt, cache['w_t'], method, rt, at, dev)
-      cache['heun_sig'] = sig
-    sol = cache['heun']
+    if cache.get('solver') is None or cache.get('solver_sig') != sig:
+      if cache.get('solver') is not None:
+        cache['solver'].close()
+      cache['solver'] = ops.AdjointAdaptiveSolver(desc_f, gt, cache['w_t'], method, rt, at, dev)
+      cache['solver_sig'] = sig
+    sol = cache['solver']
     room = func.opt['max_nfe'] + 1 - func.nfe
     if room <= 0:
       raise MaxNFEException
     finished = sol.run(Y, A_, g, T0, T1, dt, trials_per_sync=8 if Y.numel() < (1 << 22) else 1, max_evals=room)
     spent = sol.stats()['evals']
-    func._adjoint_heun_stats = sol.stats()
+    func._adjoint_adaptive_stats = sol.stats()
     if not finished or spent > room:
       func.nfe += min(spent, room)
       raise MaxNFEException
