@@ -1471,7 +1471,8 @@ def main():
       stored = json.load(open(tpath)).get('%s_d%d_%s' % (args.graph, d, 'fused' if fused else 'spmm'))
     except Exception:   # noqa: BLE001
       stored = None
-    if isinstance(stored, dict) and stored.get('bytes_per_launch'):
+    # (the record belongs to ONE node order: a run on another order -- relabelling off, or decided differently -- has no stored traffic)
+    if isinstance(stored, dict) and stored.get('bytes_per_launch') and stored.get('node_order', 'parts') == reorder_mode:
       traffic = stored['bytes_per_launch']
       traffic_src = {k: stored.get(k) for k in ('kernel', 'commit', 'fetch_bytes', 'write_bytes', 'l2_hit_rate', 'method')}
       rec_hash = stored.get('kernel_sources_sha16')

@@ -363,12 +363,15 @@ class CSRGraph(object):
     for _ in range(2):
       ops.spmm(self, w, u, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-      ops.spmm(self, w, u, out=out)
-    e1.record()
-    torch.cuda.synchronize(self.device)
-    t = e0.elapsed_time(e1) * 1e-3 / reps
+    t = None
+    for _ in range(3):        # the BEST of three timings: one disturbed measurement must not decide the node order of every later solve
+      e0.record()             # (seen once in round 5: a run of the headline bench without relabelling, 1000 instead of 1060 steps/s)
+      for _ in range(reps):
+        ops.spmm(self, w, u, out=out)
+      e1.record()
+      torch.cuda.synchronize(self.device)
+      ti = e0.elapsed_time(e1) * 1e-3 / reps
+      t = ti if t is None or ti < t else t
     del u, out, w
     return t
 

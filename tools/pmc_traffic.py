@@ -75,7 +75,7 @@ def main():
                 'graph-neural-pde_amd/csrc/epilogue.h'):     # = bench.KERNEL_SOURCES: the record is stale when ANY of them changes
       h.update(open(os.path.join(root, rel), 'rb').read())
     rec.update(kernel=k, commit=commit, command=cmd, method='rocprofv3 --pmc, mean over the launches of the command',
-               kernel_sources_sha16=h.hexdigest()[:16])
+               kernel_sources_sha16=h.hexdigest()[:16], node_order=os.environ.get('GNPDE_REORDER', 'auto'))
     data[key] = rec
   data.setdefault('detail', {})[key] = {'commit': commit, 'command': cmd, 'kernels': detail}
   json.dump(data, open(out_path, 'w'), indent=1)
