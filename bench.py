@@ -69,7 +69,7 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
-  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch', 'pubmed-adjoint'],
+  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch', 'pubmed-adjoint', 'coauthor-adjoint'],
                   help='c4: BASELINE configs[3] -- ogbn-arxiv BLEND (beltrami split kernel, d = 64 + 98 = 162), block_transformer_rewiring in '
                        'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward).  '
                        'cora-epoch: the reference\'s flagship run -- best_params Cora (attention block, Laplacian function, dopri5, adjoint=False, '
@@ -998,7 +998,8 @@ def pubmed_adjoint_main(G, args, dev):
   native stages, odeint._adjoint_adaptive_native) next to the same iteration through torchdiffeq's flat-vector loop
   (opt['gnpde_host_adjoint'])."""
   import numpy as np
-  n, pairs, d = 19717, 44324, 128
+  preset = getattr(args, 'config', 'pubmed-adjoint')
+  n, pairs, d = (19717, 44324, 128) if preset == 'pubmed-adjoint' else (18333, 81894, 16)
   rng = np.random.default_rng(args.seed + 11)
   a, b = rng.integers(0, n, 2 * pairs), rng.integers(0, n, 2 * pairs)
   keep = a != b
@@ -1014,6 +1015,13 @@ def pubmed_adjoint_main(G, args, dev):
               augment=False, adjoint=True, adjoint_method='adaptive_heun', adjoint_step_size=1, tol_scale=1991.0688305523001,
               tol_scale_adjoint=16324.368093998313, data_norm='rw', method='dopri5', step_size=1, max_iters=100, block='attention',
               function='laplacian', time=12.942327880200853)
+  label = 'Pubmed'
+  if preset == 'coauthor-adjoint':
+    # best_params CoauthorCS: hidden_dim 16, 4 heads, A = 8, scaled_dot normalised over columns with squareplus, no source term, no self-loops,
+    # dopri5 tol_scale 9349, T = 3.126, adjoint_method dopri5 with tol_scale_adjoint 6599
+    label = 'CoauthorCS'
+    base.update(heads=4, attention_dim=8, attention_type='scaled_dot', attention_norm_idx=1, square_plus=True, add_source=False, self_loop_weight=0,
+                adjoint_method='dopri5', tol_scale=9348.983916372074, tol_scale_adjoint=6599.1250595331385, time=3.126400580172773, max_nfe=3000)
   data = _Data()
   data.x, data.edge_index, data.edge_attr, data.num_nodes = x, ei, None, n
   res = {}
@@ -1052,13 +1060,16 @@ def pubmed_adjoint_main(G, args, dev):
   e_inf, e_2 = R.parity_error(res[False]['grad_x'], res[True]['grad_x'])
   nat, hst = res[False], res[True]
   out = {
-    'metric': 'ms per training iteration of the ODE block (forward + adaptive_heun adjoint backward), Pubmed shape d=128',
+    'metric': 'ms per training iteration of the ODE block (forward + %s adjoint backward), %s shape d=%d' % (base['adjoint_method'], label, d),
     'value': round(nat['forward_ms'] + nat['backward_ms'], 3), 'unit': 'ms', 'n_gpus': 1, 'steps': 1, 'warmup': 2,
     'ms_per_step': round(nat['forward_ms'] + nat['backward_ms'], 3), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
     'data': 'synthetic',
-    'config': {'workload': 'ODE block of best_params Pubmed (attention block: cosine_sim, 1 head, A = 16, squareplus; Laplacian function; dopri5 tol_scale 1991, '
-                           'T = 12.94; adjoint=True, adjoint_method adaptive_heun, tol_scale_adjoint 16324) on a Pubmed-shaped synthetic graph; one step = one '
-                           'training iteration of the block (loss = sum of the output)', 'nodes': n, 'edges_with_self_loops': int(ei.shape[1]) + n, 'd': d},
+    'config': {'workload': ('ODE block of best_params %s (attention block: %s, %d head(s), A = %d, squareplus; Laplacian function; dopri5 tol_scale %.0f, '
+                            'T = %.2f; adjoint=True, adjoint_method %s, tol_scale_adjoint %.0f) on a %s-shaped synthetic graph; one step = one training '
+                            'iteration of the block (loss = sum of the output)') % (label, base['attention_type'], base['heads'], base['attention_dim'],
+                                                                                     base['tol_scale'], base['time'], base['adjoint_method'],
+                                                                                     base['tol_scale_adjoint'], label),
+               'nodes': n, 'edges_with_self_loops': int(ei.shape[1]) + (n if base['self_loop_weight'] else 0), 'd': d},
     'forward_ms': nat['forward_ms'], 'backward_ms': nat['backward_ms'], 'evals_forward': nat['evals_forward'],
     'augmented_evals_backward': nat['augmented_evals_backward'],
     'flat_host_loop': {k: hst[k] for k in ('forward_ms', 'backward_ms', 'evals_forward', 'augmented_evals_backward')},
@@ -1230,6 +1241,8 @@ CONFIG_CHILDREN = (
    ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240),
   ('pubmed_block_adaptive_heun_adjoint', 'best_params Pubmed\'s ODE block in training: dopri5 forward, adjoint_method adaptive_heun (the reference\'s default)',
    ['--config', 'pubmed-adjoint'], 200),
+  ('coauthorcs_block_dopri5_adjoint', 'best_params CoauthorCS\'s ODE block in training: dopri5 forward, adjoint_method dopri5',
+   ['--config', 'coauthor-adjoint'], 200),
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
    ['--train', '--steps', '10', '--warmup', '2'], 400),
   ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
@@ -1343,7 +1356,7 @@ def main():
     return c4_main(G, args, dev)
   if args.config == 'cora-epoch':
     return cora_epoch_main(G, args, dev)
-  if args.config == 'pubmed-adjoint':
+  if args.config in ('pubmed-adjoint', 'coauthor-adjoint'):
     return pubmed_adjoint_main(G, args, dev)
   cfg = G.synthetic.CONFIGS[args.graph]
   ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
