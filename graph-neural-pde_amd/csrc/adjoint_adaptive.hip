@@ -129,21 +129,75 @@ __global__ __launch_bounds__(kBlock) void adaptive_init_kernel(const float* __re
   for (int j = 0; j < 2; ++j) { c->g[0][j] = g_in[j]; c->g[1][j] = g_in[j]; c->ks[0][j] = ks[j]; c->ks[1][j] = ks[j]; c->g_out[j] = g_in[j]; }
 }
 
-__global__ __launch_bounds__(kBlock) void adaptive_control_kernel(const HCtlArgs a) {
-  __shared__ double red[kBlock];
+// One block of kCtlBlock threads per trial step.  Everything it folds (the two error-norm partial arrays, S regions of dot pairs) is read with
+// independent loads in one pass -- as separate strided loops behind a 256-thread tree each, the fold was 32 us of load latency per trial at
+// Pubmed's size (profiles/r05_pubmed_adjoint_trial_sequence_before.txt), the longest launch of the trial -- and reduced with wave shuffles and one
+// LDS exchange.  The order of the additions is fixed, so a solve is reproducible run to run.
+constexpr int kCtlBlock = 1024;
+constexpr int kCtlVals = 2 + 2 * kMaxStages;
+
+__global__ __launch_bounds__(kCtlBlock) void adaptive_control_kernel(const HCtlArgs a) {
+  __shared__ double part[kCtlBlock / 64][kCtlVals];
   __shared__ double dsum[kMaxStages][2];
-  double sy = 0.0, sa = 0.0;
-  for (int i = threadIdx.x; i < a.nb_y; i += kBlock) sy += a.err_y[i];
-  for (int i = threadIdx.x; i < a.nb_a; i += kBlock) sa += a.err_a[i];
-  sy = block_sum(sy, red);
-  sa = block_sum(sa, red);
-  for (int r = 0; r < a.S; ++r) {
-    const float* dr = a.dots + 2 * a.n_pairs * r;
-    double a1 = 0.0, a2 = 0.0;
-    for (long long i = threadIdx.x; i < a.n_pairs; i += kBlock) { a1 += dr[2 * i]; a2 += dr[2 * i + 1]; }
-    const double d1 = block_sum(a1, red), d2 = block_sum(a2, red);
-    if (threadIdx.x == 0) { dsum[r][0] = d1; dsum[r][1] = d2; }
+  __shared__ double esum[2];
+  double v[kCtlVals];
+#pragma unroll
+  for (int j = 0; j < kCtlVals; ++j) v[j] = 0.0;
+  const int tid = threadIdx.x;
+  const float2* __restrict__ pairs = reinterpret_cast<const float2*>(a.dots);
+  if (a.nb_y > 0 && a.nb_a > 0 && a.n_pairs > 0) {
+    // one loop over the longest array, every load unconditional (clamped index, masked add) so that the 2 + kMaxStages loads of an iteration --
+    // and of the next, unrolled -- are in flight together; a branch per stage costs a round trip to memory each
+    const long long last_y = a.nb_y - 1, last_a = a.nb_a - 1, last_p = a.n_pairs - 1;
+    const long long lim = (last_y > last_a ? (last_y > last_p ? last_y : last_p) : (last_a > last_p ? last_a : last_p)) + 1;
+#pragma unroll 2
+    for (long long i = tid; i < lim; i += kCtlBlock) {
+      const double ey = a.err_y[i < last_y ? i : last_y], ea = a.err_a[i < last_a ? i : last_a];
+      const long long ip = i < last_p ? i : last_p;
+      float2 d[kMaxStages];
+#pragma unroll
+      for (int r = 0; r < kMaxStages; ++r) d[r] = pairs[a.n_pairs * (r < a.S ? r : 0) + ip];
+      v[0] += i <= last_y ? ey : 0.0;
+      v[1] += i <= last_a ? ea : 0.0;
+#pragma unroll
+      for (int r = 0; r < kMaxStages; ++r) {
+        const bool on = r < a.S && i <= last_p;
+        v[2 + 2 * r] += on ? d[r].x : 0.f;
+        v[3 + 2 * r] += on ? d[r].y : 0.f;
+      }
+    }
+  } else {
+    for (int i = tid; i < a.nb_y; i += kCtlBlock) v[0] += a.err_y[i];
+    for (int i = tid; i < a.nb_a; i += kCtlBlock) v[1] += a.err_a[i];
+    for (long long i = tid; i < a.n_pairs; i += kCtlBlock) {
+      for (int r = 0; r < a.S; ++r) {
+        const float2 d = pairs[a.n_pairs * r + i];
+        if (r == 0) { v[2] += d.x; v[3] += d.y; }
+        else if (r == 1) { v[4] += d.x; v[5] += d.y; }
+        else if (r == 2) { v[6] += d.x; v[7] += d.y; }
+        else if (r == 3) { v[8] += d.x; v[9] += d.y; }
+        else if (r == 4) { v[10] += d.x; v[11] += d.y; }
+        else { v[12] += d.x; v[13] += d.y; }
+      }
+    }
   }
+#pragma unroll
+  for (int j = 0; j < kCtlVals; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_down(v[j], off, 64);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < kCtlVals; ++j) part[tid >> 6][j] = v[j];
+  }
+  __syncthreads();
+  if (tid < kCtlVals) {
+    double t = 0.0;
+    for (int w = 0; w < kCtlBlock / 64; ++w) t += part[w][tid];
+    if (tid < 2) esum[tid] = t; else dsum[(tid - 2) >> 1][(tid - 2) & 1] = t;
+  }
+  __syncthreads();
+  const double sy = esum[0], sa = esum[1];
   if (threadIdx.x != 0) return;
   HCtl* c = a.c;
   const int p = a.parity, q = 1 - a.parity;
@@ -419,7 +473,7 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
     ca.c_sol[j] = static_cast<float>(tab.c_sol[j]); ca.c_err[j] = static_cast<float>(tab.c_err[j]); ca.c_mid[j] = static_cast<float>(tab.c_mid[j]);
   }
   ca.c = s->ctl; ca.parity = p;
-  hipLaunchKernelGGL(adaptive_control_kernel, dim3(1), dim3(kBlock), 0, st, ca);
+  hipLaunchKernelGGL(adaptive_control_kernel, dim3(1), dim3(kCtlBlock), 0, st, ca);
   GNPDE_LAUNCH_CHECK();
   HFinishArgs fa{};
   fa.y = s->Y[p]; fa.y1 = s->Y[q]; fa.f = kf[0]; fa.f1 = kf[S];
