@@ -129,139 +129,147 @@ __global__ __launch_bounds__(kBlock) void adaptive_init_kernel(const float* __re
   for (int j = 0; j < 2; ++j) { c->g[0][j] = g_in[j]; c->g[1][j] = g_in[j]; c->ks[0][j] = ks[j]; c->ks[1][j] = ks[j]; c->g_out[j] = g_in[j]; }
 }
 
-// One block of kCtlBlock threads per trial step.  Everything it folds (the two error-norm partial arrays, S regions of dot pairs) is read with
-// independent loads in one pass -- as separate strided loops behind a 256-thread tree each, the fold was 32 us of load latency per trial at
-// Pubmed's size (profiles/r05_pubmed_adjoint_trial_sequence_before.txt), the longest launch of the trial -- and reduced with wave shuffles and one
-// LDS exchange.  The order of the additions is fixed, so a solve is reproducible run to run.
+// One block of kCtlBlock threads per trial step, S (the number of new stages of the pair) a compile-time constant.  Two things made the first
+// version of this kernel the longest launch of a trial (32 us at Pubmed's size, profiles/r05_pubmed_adjoint_trial_sequence_before.txt):
+//  * the partial arrays were folded by separate strided loops behind a 256-thread tree each -- now every load of an iteration is issued
+//    together by 1024 threads and the fold is wave shuffles plus one LDS exchange;
+//  * the scalar tail read and wrote the controller record field by field through its pointer (some thirty dependent round trips to memory)
+//    and indexed its small arrays dynamically (scratch) -- now the record, alpha and beta are read once BEFORE the fold, the tail works on
+//    registers with compile-time indices, and the record is written back once.
+// The order of the additions is fixed, so a solve is reproducible run to run; the float arithmetic of the tail is unchanged.
 constexpr int kCtlBlock = 1024;
-constexpr int kCtlVals = 2 + 2 * kMaxStages;
 
+template <int S>
 __global__ __launch_bounds__(kCtlBlock) void adaptive_control_kernel(const HCtlArgs a) {
-  __shared__ double part[kCtlBlock / 64][kCtlVals];
-  __shared__ double dsum[kMaxStages][2];
-  __shared__ double esum[2];
-  double v[kCtlVals];
-#pragma unroll
-  for (int j = 0; j < kCtlVals; ++j) v[j] = 0.0;
+  constexpr int kVals = 2 + 2 * S;
+  __shared__ double part[kCtlBlock / 64][kVals];
+  __shared__ double tot[kVals];
   const int tid = threadIdx.x;
-  const float2* __restrict__ pairs = reinterpret_cast<const float2*>(a.dots);
-  if (a.nb_y > 0 && a.nb_a > 0 && a.n_pairs > 0) {
-    // one loop over the longest array, every load unconditional (clamped index, masked add) so that the 2 + kMaxStages loads of an iteration --
-    // and of the next, unrolled -- are in flight together; a branch per stage costs a round trip to memory each
-    const long long last_y = a.nb_y - 1, last_a = a.nb_a - 1, last_p = a.n_pairs - 1;
-    const long long lim = (last_y > last_a ? (last_y > last_p ? last_y : last_p) : (last_a > last_p ? last_a : last_p)) + 1;
-#pragma unroll 2
-    for (long long i = tid; i < lim; i += kCtlBlock) {
-      const double ey = a.err_y[i < last_y ? i : last_y], ea = a.err_a[i < last_a ? i : last_a];
-      const long long ip = i < last_p ? i : last_p;
-      float2 d[kMaxStages];
+  const HCtl L = *a.c;
+  const float alpha_raw = *a.alpha;
+  const float beta = a.beta != nullptr ? *a.beta : 0.0f;
+  double v[kVals];
 #pragma unroll
-      for (int r = 0; r < kMaxStages; ++r) d[r] = pairs[a.n_pairs * (r < a.S ? r : 0) + ip];
+  for (int j = 0; j < kVals; ++j) v[j] = 0.0;
+  // (issuing several iterations' loads at once -- four per array, clamped and masked -- was measured and is no faster for S = 1 and slower for
+  //  S = 6, 27 us against 21: what is left of this kernel's time is a single wave running ~4-6 KB of cold code, so smaller code wins)
+  if (a.nb_y > 0 && a.nb_a > 0) {
+    const int last_y = a.nb_y - 1, last_a = a.nb_a - 1;
+    const int lim = (last_y > last_a ? last_y : last_a) + 1;
+    for (int i = tid; i < lim; i += kCtlBlock) {
+      const double ey = a.err_y[i < last_y ? i : last_y], ea = a.err_a[i < last_a ? i : last_a];
       v[0] += i <= last_y ? ey : 0.0;
       v[1] += i <= last_a ? ea : 0.0;
-#pragma unroll
-      for (int r = 0; r < kMaxStages; ++r) {
-        const bool on = r < a.S && i <= last_p;
-        v[2 + 2 * r] += on ? d[r].x : 0.f;
-        v[3 + 2 * r] += on ? d[r].y : 0.f;
-      }
-    }
-  } else {
-    for (int i = tid; i < a.nb_y; i += kCtlBlock) v[0] += a.err_y[i];
-    for (int i = tid; i < a.nb_a; i += kCtlBlock) v[1] += a.err_a[i];
-    for (long long i = tid; i < a.n_pairs; i += kCtlBlock) {
-      for (int r = 0; r < a.S; ++r) {
-        const float2 d = pairs[a.n_pairs * r + i];
-        if (r == 0) { v[2] += d.x; v[3] += d.y; }
-        else if (r == 1) { v[4] += d.x; v[5] += d.y; }
-        else if (r == 2) { v[6] += d.x; v[7] += d.y; }
-        else if (r == 3) { v[8] += d.x; v[9] += d.y; }
-        else if (r == 4) { v[10] += d.x; v[11] += d.y; }
-        else { v[12] += d.x; v[13] += d.y; }
-      }
     }
   }
+  const float2* __restrict__ pairs = reinterpret_cast<const float2*>(a.dots);
+  for (long long i = tid; i < a.n_pairs; i += kCtlBlock) {
+    float2 d[S];
 #pragma unroll
-  for (int j = 0; j < kCtlVals; ++j) {
+    for (int r = 0; r < S; ++r) d[r] = pairs[a.n_pairs * r + i];
+#pragma unroll
+    for (int r = 0; r < S; ++r) { v[2 + 2 * r] += d[r].x; v[3 + 2 * r] += d[r].y; }
+  }
+#pragma unroll
+  for (int j = 0; j < kVals; ++j) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_down(v[j], off, 64);
   }
   if ((tid & 63) == 0) {
 #pragma unroll
-    for (int j = 0; j < kCtlVals; ++j) part[tid >> 6][j] = v[j];
+    for (int j = 0; j < kVals; ++j) part[tid >> 6][j] = v[j];
   }
   __syncthreads();
-  if (tid < kCtlVals) {
+  if (tid < kVals) {
     double t = 0.0;
     for (int w = 0; w < kCtlBlock / 64; ++w) t += part[w][tid];
-    if (tid < 2) esum[tid] = t; else dsum[(tid - 2) >> 1][(tid - 2) & 1] = t;
+    tot[tid] = t;
   }
   __syncthreads();
-  const double sy = esum[0], sa = esum[1];
-  if (threadIdx.x != 0) return;
-  HCtl* c = a.c;
-  const int p = a.parity, q = 1 - a.parity;
-  if (c->done) {                      // replayed past the end point (never queued by gnpde_adjoint_adaptive_run): change nothing
-    c->accept = 0;
-    c->interp = 0;
-    c->h[q] = c->h[p];
-    for (int j = 0; j < 2; ++j) { c->g[q][j] = c->g[p][j]; c->ks[q][j] = c->ks[p][j]; }
-    return;
-  }
-  float ks[kMaxStages + 1][2];
-  ks[0][0] = c->ks[p][0]; ks[0][1] = c->ks[p][1];
-  for (int r = 0; r < a.S; ++r) scalars_of(dsum[r][0], dsum[r][1], a.alpha, a.alpha_sigmoid, a.beta, ks[r + 1]);
-  const float h = c->h[p];
-  float g1[2], gm[2], rs = 0.f;
-  const int use[2] = {a.use_alpha, a.use_beta};
-  for (int j = 0; j < 2; ++j) {
-    float acc = 0.f, err = 0.f, mid = 0.f;
-    for (int m = 0; m <= a.S; ++m) {          // fl32(c) * fl32(dt) per weight, summed in stage order, as on the flat vector
-      if (a.c_sol[m] != 0.f) acc += ks[m][j] * (a.c_sol[m] * h);
-      if (a.c_err[m] != 0.f) err += ks[m][j] * (a.c_err[m] * h);
-      if (a.c_mid[m] != 0.f) mid += ks[m][j] * (a.c_mid[m] * h);
-    }
-    g1[j] = c->g[p][j] + acc;
-    gm[j] = c->g[p][j] + mid;
-    const float tol = a.atol + a.rtol * fmaxf(fabsf(c->g[p][j]), fabsf(g1[j]));
-    if (use[j]) rs = fmaxf(rs, fabsf(err / tol));
-  }
-  const float ry = static_cast<float>(sqrt(sy / a.count)), ra = static_cast<float>(sqrt(sa / a.count));
-  const float ratio32 = fmaxf(fmaxf(ry, ra), rs);
-  c->ratio = ratio32;
-  const double ratio = static_cast<double>(ratio32);
-  const double dt = c->dt;
-  c->trials += 1;
-  int accept = 0, interp = 0;
-  if (ratio <= 1.0) {
-    const double t_next = c->t + dt;
-    if (t_next >= c->t1) {
-      c->x = static_cast<float>((c->t1 - c->t) / (t_next - c->t));
-      interp = 1;
-      c->done = 1;
-      for (int j = 0; j < 2; ++j) c->g_out[j] = quartic(c->g[p][j], g1[j], ks[0][j], ks[a.S][j], gm[j], h, c->x);
-    }
-    c->t = t_next;
-    accept = 1;
-    c->accepted += 1;
+  if (tid != 0) return;
+  const bool p1 = a.parity != 0;         // slot of the trial step in flight; the next one takes the other
+  HCtl N = L;
+  const float h = p1 ? L.h[1] : L.h[0];
+  const float g0[2] = {p1 ? L.g[1][0] : L.g[0][0], p1 ? L.g[1][1] : L.g[0][1]};
+  const float k0[2] = {p1 ? L.ks[1][0] : L.ks[0][0], p1 ? L.ks[1][1] : L.ks[0][1]};
+  float h_next, g_next[2], k_next[2];
+  if (L.done) {                       // replayed past the end point (never queued by gnpde_adjoint_adaptive_run): change nothing
+    N.accept = 0;
+    N.interp = 0;
+    h_next = h;
+    g_next[0] = g0[0]; g_next[1] = g0[1];
+    k_next[0] = k0[0]; k_next[1] = k0[1];
   } else {
-    c->rejected += 1;
+    const float al = a.alpha_sigmoid ? 1.0f / (1.0f + expf(-alpha_raw)) : alpha_raw;
+    float ks[S + 1][2];                // Ks of every evaluation from the folded dots: ((1 - alpha') (<u_a, F> - beta <u_a, x0>), <u_a, x0>)
+    ks[0][0] = k0[0]; ks[0][1] = k0[1];
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const float f1 = static_cast<float>(tot[2 + 2 * r]), f2 = static_cast<float>(tot[3 + 2 * r]);
+      ks[r + 1][0] = (1.0f - al) * (f1 - beta * f2);
+      ks[r + 1][1] = f2;
+    }
+    float g1[2], gm[2], rs = 0.f;
+    const int use[2] = {a.use_alpha, a.use_beta};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float acc = 0.f, err = 0.f, mid = 0.f;
+#pragma unroll
+      for (int m = 0; m <= S; ++m) {          // fl32(c) * fl32(dt) per weight, summed in stage order, as on the flat vector
+        if (a.c_sol[m] != 0.f) acc += ks[m][j] * (a.c_sol[m] * h);
+        if (a.c_err[m] != 0.f) err += ks[m][j] * (a.c_err[m] * h);
+        if (a.c_mid[m] != 0.f) mid += ks[m][j] * (a.c_mid[m] * h);
+      }
+      g1[j] = g0[j] + acc;
+      gm[j] = g0[j] + mid;
+      const float tol = a.atol + a.rtol * fmaxf(fabsf(g0[j]), fabsf(g1[j]));
+      if (use[j]) rs = fmaxf(rs, fabsf(err / tol));
+    }
+    const float ry = static_cast<float>(sqrt(tot[0] / a.count)), ra = static_cast<float>(sqrt(tot[1] / a.count));
+    const float ratio32 = fmaxf(fmaxf(ry, ra), rs);
+    N.ratio = ratio32;
+    const double ratio = static_cast<double>(ratio32);
+    const double dt = L.dt;
+    N.trials = L.trials + 1;
+    int accept = 0, interp = 0;
+    if (ratio <= 1.0) {
+      const double t_next = L.t + dt;
+      if (t_next >= L.t1) {
+        N.x = static_cast<float>((L.t1 - L.t) / (t_next - L.t));
+        interp = 1;
+        N.done = 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) N.g_out[j] = quartic(g0[j], g1[j], ks[0][j], ks[S][j], gm[j], h, N.x);
+      }
+      N.t = t_next;
+      accept = 1;
+      N.accepted = L.accepted + 1;
+    } else {
+      N.rejected = L.rejected + 1;
+    }
+    double factor;
+    if (ratio == 0.0) {
+      factor = 10.0;
+    } else {
+      const double lo = ratio < 1.0 ? 1.0 : 0.2;
+      factor = fmin(10.0, fmax(0.9 / pow(ratio, 1.0 / a.order), lo));
+    }
+    N.dt = dt * factor;
+    h_next = static_cast<float>(N.dt);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      g_next[j] = accept ? g1[j] : g0[j];
+      k_next[j] = accept ? ks[S][j] : k0[j];
+    }
+    N.accept = accept;
+    N.interp = interp;
   }
-  double factor;
-  if (ratio == 0.0) {
-    factor = 10.0;
+  if (p1) {
+    N.h[0] = h_next; N.g[0][0] = g_next[0]; N.g[0][1] = g_next[1]; N.ks[0][0] = k_next[0]; N.ks[0][1] = k_next[1];
   } else {
-    const double lo = ratio < 1.0 ? 1.0 : 0.2;
-    factor = fmin(10.0, fmax(0.9 / pow(ratio, 1.0 / a.order), lo));
+    N.h[1] = h_next; N.g[1][0] = g_next[0]; N.g[1][1] = g_next[1]; N.ks[1][0] = k_next[0]; N.ks[1][1] = k_next[1];
   }
-  c->dt = dt * factor;
-  c->h[q] = static_cast<float>(c->dt);
-  for (int j = 0; j < 2; ++j) {
-    c->g[q][j] = accept ? g1[j] : c->g[p][j];
-    c->ks[q][j] = accept ? ks[a.S][j] : c->ks[p][j];
-  }
-  c->accept = accept;
-  c->interp = interp;
+  *a.c = N;
 }
 
 struct HFinishArgs {
@@ -473,7 +481,14 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
     ca.c_sol[j] = static_cast<float>(tab.c_sol[j]); ca.c_err[j] = static_cast<float>(tab.c_err[j]); ca.c_mid[j] = static_cast<float>(tab.c_mid[j]);
   }
   ca.c = s->ctl; ca.parity = p;
-  hipLaunchKernelGGL(adaptive_control_kernel, dim3(1), dim3(kCtlBlock), 0, st, ca);
+  if (S == 1) {
+    hipLaunchKernelGGL(adaptive_control_kernel<1>, dim3(1), dim3(kCtlBlock), 0, st, ca);
+  } else if (S == 6) {
+    hipLaunchKernelGGL(adaptive_control_kernel<6>, dim3(1), dim3(kCtlBlock), 0, st, ca);
+  } else {
+    set_error("adjoint_adaptive: no controller kernel for a pair of %d stages", S);
+    return GNPDE_EINVAL;
+  }
   GNPDE_LAUNCH_CHECK();
   HFinishArgs fa{};
   fa.y = s->Y[p]; fa.y1 = s->Y[q]; fa.f = kf[0]; fa.f1 = kf[S];
