@@ -1258,6 +1258,113 @@ CONFIG_CHILDREN = (
 )
 
 
+HEADLINE_MAX_BYTES = 4096     # the driver keeps an 8-KB tail of stdout: the LAST line must be the headline object and must fit with room
+
+
+def _strip_prose(obj, depth=0):
+  """Drop the explanatory strings (`*_is`, `what`, `note`, `how`, `sample`) of a bench object: they belong to the detail line."""
+  if isinstance(obj, dict):
+    return {k: _strip_prose(v, depth + 1) for k, v in obj.items()
+            if not (k.endswith('_is') or k.endswith('_note') or k in ('what', 'note', 'how', 'sample', 'command'))}
+  if isinstance(obj, list):
+    return [_strip_prose(v, depth + 1) for v in obj]
+  return obj
+
+
+def configs_summary(configs):
+  """{key: [value, unit, frac | null]} of the `configs` block, small enough for the headline line."""
+  if not isinstance(configs, dict):
+    return None
+  out = {}
+  for key, rec in configs.items():
+    if not isinstance(rec, dict):
+      continue
+    if 'error' in rec or 'skipped' in rec:
+      out[key] = ['error' if 'error' in rec else 'skipped', None, None]
+      continue
+    r = rec.get('roofline') or {}
+    frac = r.get('frac')
+    if frac is None:
+      frac = r.get('frac_traffic')
+    out[key] = [rec.get('value'), rec.get('unit'), frac]
+  return out
+
+
+def headline(out, configs=None):
+  """The compact object of the LAST stdout line: BASELINE.json's metric, `roofline` and `cpu_baseline` by the keys the task's contract
+  names, and a summary of the other configurations.  Everything else this run measured is on the earlier `bench_detail` /
+  `bench_configs` lines."""
+  keep = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                  'vs_baseline', 'dtype', 'data') if k in out}
+  cfg = out.get('config') or {}
+  keep['config'] = {k: cfg.get(k) for k in ('workload', 'graph', 'nodes', 'edges_with_self_loops', 'd', 'attention_dim', 'heads',
+                                            'rhs_evals_per_step', 'hipgraph', 'parallelism', 'transport', 'ranks_seen', 'driver', 'edge_cut',
+                                            'ranks_share_one_device', 'max_bytes_on_one_link_per_evaluation', 'finite',
+                                            'sharded_vs_unpartitioned_timed_solve_rel_max') if k in cfg}
+  r = out.get('roofline')
+  if isinstance(r, dict):
+    rk = {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_algorithmic', 'frac_traffic', 'traffic', 'avg_launch_us',
+                                'algorithmic_bytes_per_launch', 'algorithmic_bytes_per_stage') if k in r}
+    rk['kernel'] = str(r.get('kernel', ''))[:80]
+    src = r.get('traffic_source')
+    if isinstance(src, dict):
+      rk['traffic_live'] = bool(src.get('live')) and not src.get('stale', False)
+      if src.get('l2_hit_rate') is not None:
+        rk['l2_hit_rate'] = src.get('l2_hit_rate')
+    probe = r.get('hbm_bound_probe')
+    if isinstance(probe, dict) and probe.get('frac') is not None:
+      rk['hbm_bound_probe_frac'] = probe.get('frac')
+    sec = []
+    for ent in r.get('secondary') or []:
+      if isinstance(ent, dict) and 'avg_us' in ent:
+        sec.append({'kernel': str(ent.get('kernel', ''))[:40], 'avg_us': ent.get('avg_us'),
+                    'frac_algorithmic': None if ent.get('gbs') is None else round(ent['gbs'] / HBM_PEAK_GBS, 4),
+                    'frac_traffic': ent.get('frac_traffic')})
+    if sec:
+      rk['secondary'] = sec
+    keep['roofline'] = rk
+  else:
+    keep['roofline'] = None
+  cb = out.get('cpu_baseline')
+  keep['cpu_baseline'] = None if not isinstance(cb, dict) else {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'ms_per_rhs_eval') if k in cb}
+  if isinstance(cb, dict) and cb.get('sample'):
+    keep['cpu_baseline']['sample'] = str(cb['sample'])[:160]
+  for k in ('parity_vs_oracle_one_eval', 'parity_vs_oracle_row_subset', 'speedup_vs_cpu', 'timing'):
+    if k in out:
+      keep[k] = _strip_prose(out[k])
+  summ = configs_summary(configs)
+  if summ is not None:
+    keep['configs_summary'] = summ
+    keep['configs_seconds'] = configs.get('_seconds') if isinstance(configs, dict) else None
+  keep['detail'] = 'earlier stdout lines {"bench_detail": ...} and {"bench_configs": ...} of this run'
+  line = json.dumps(keep)
+  # never let the line outgrow the driver's tail: shed the optional parts, largest first
+  for victim in ('configs_summary', 'timing', 'parity_vs_oracle_row_subset'):
+    if len(line) < HEADLINE_MAX_BYTES:
+      break
+    if victim == 'configs_summary' and isinstance(keep.get(victim), dict):
+      keep[victim] = {k: v[0] for k, v in keep[victim].items()}
+    else:
+      keep.pop(victim, None)
+    line = json.dumps(keep)
+  if len(line) >= HEADLINE_MAX_BYTES and isinstance(keep.get('roofline'), dict):
+    keep['roofline'].pop('secondary', None)
+    keep.pop('configs_summary', None)
+    line = json.dumps(keep)
+  return keep
+
+
+def emit(out, configs=None):
+  """Print what the run measured: the full object and the `configs` block each on a line of its own, then -- LAST, so that it is
+  what the driver's tail of stdout ends with -- the compact headline object."""
+  print(json.dumps({'bench_detail': out}))
+  if configs is not None:
+    print(json.dumps({'bench_configs': configs}))
+  sys.stdout.flush()
+  print(json.dumps(headline(out, configs)))
+  sys.stdout.flush()
+
+
 def summarise_child(line):
   """What the parent keeps of a child's bench line."""
   r = line.get('roofline') or {}
@@ -1311,10 +1418,12 @@ def run_configs(args, budget_s):
     try:
       res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(limit, left))
       line = None
-      for ln in reversed(res.stdout.splitlines()):
-        if ln.startswith('{"metric"'):
-          line = json.loads(ln)
+      for ln in reversed(res.stdout.splitlines()):   # the child's full object: its `bench_detail` line, or the one line of the other modes
+        if ln.startswith('{"bench_detail"'):
+          line = json.loads(ln)['bench_detail']
           break
+        if ln.startswith('{"metric"') and line is None:
+          line = json.loads(ln)
       if line is None:
         out[key] = {'error': 'rc %d, no bench line; stderr tail: %s' % (res.returncode, (res.stderr or '')[-300:]), 'what': what}
       else:
@@ -1327,14 +1436,38 @@ def run_configs(args, budget_s):
   return out
 
 
+def launch_ranks(n_ranks):
+  """`python bench.py --gpus N` without a launcher: run this script as N ranks under torch.distributed.run (one process per GPU, RCCL) on
+  a free local port and pass the ranks' stdout through, so that rank 0's headline stays the last line.  With fewer than N devices the
+  ranks can only share one (GNPDE_RANKS_SHARE_DEVICE=1: a functional run, the line says so) -- never silently."""
+  import socket
+  import subprocess
+  have = torch.cuda.device_count()
+  if have < n_ranks and os.environ.get('GNPDE_RANKS_SHARE_DEVICE', '0') != '1':
+    raise SystemExit('--gpus %d but this host shows %d HIP device(s); set GNPDE_RANKS_SHARE_DEVICE=1 for a functional run of the %d-rank '
+                     'path on one device (not a scaling measurement)' % (n_ranks, have, n_ranks))
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  res = subprocess.run(cmd, env=env)
+  if res.returncode != 0:
+    raise SystemExit(res.returncode)
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus > 1 and 'RANK' not in os.environ:
+    return launch_ranks(args.gpus)        # `python bench.py --gpus N` as the driver runs `--gpus 1`: spawn the N ranks ourselves
   if args.gpus != world:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    raise SystemExit('--gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
   import gnpde_amd as G
   if os.environ.get('GNPDE_ONE_PASS', '0') == '1':
     G.ops.tune(G._lib.TUNE_ONE_PASS, 1)
@@ -1350,7 +1483,7 @@ def main():
   torch.cuda.set_device(dev)
   if world > 1 or os.environ.get('GNPDE_FORCE_SHARDED', '0') == '1':   # (the env switch exercises the sharded driver on one GPU)
     from gnpde_amd import distributed as D
-    return D.bench_main(args, rank, world, dev)
+    return D.bench_main(args, rank, world, dev, emit=emit)
 
   if args.config == 'c4':
     return c4_main(G, args, dev)
@@ -1632,8 +1765,10 @@ def main():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    out['configs'] = run_configs(args, args.configs_budget)
-  print(json.dumps(out))
+    configs = run_configs(args, args.configs_budget)
+  else:
+    configs = None
+  emit(out, configs)
 
 
 if __name__ == '__main__':

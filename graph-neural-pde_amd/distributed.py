@@ -1161,7 +1161,7 @@ def negotiate_transport(ladder, phases, agree, notes, on_reject=None):
 # --------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (launched by torch.distributed.run, one rank per GPU)
 # --------------------------------------------------------------------------------------------------
-def bench_main(args, rank, world, dev):
+def bench_main(args, rank, world, dev, emit=None):
   import gnpde_amd as G
   # GNPDE_RANKS_SHARE_DEVICE=1 (set by the caller, together with a device every rank can see): all ranks on ONE GPU, gloo for
   # the host-side collectives -- the P2P transport does not care which device a peer's memory is on.  Functional runs of the
@@ -1582,5 +1582,10 @@ def bench_main(args, rank, world, dev):
                                    '-- DESIGN.md section 6 predicts ~5x there and 2.3 - 3.0x for the ogbn-arxiv shape, whose 87-MB state leaves '
                                    'every rank launch- and link-latency bound; this line is `--graph %s`, its own prediction is `model`' % args.graph)
     out['cpu_baseline'] = None     # (timed on rank 0 at N = 1 only, by contract)
-    print(json.dumps(out))
+    out['config']['parallelism'] = 'rows%d' % world
+    out['config']['ranks_seen'] = dist.get_world_size()
+    if emit is not None:
+      emit(out)                      # bench.py: the full object on its own line, the compact headline LAST
+    else:
+      print(json.dumps(out))
   dist.destroy_process_group()

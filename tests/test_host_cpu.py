@@ -650,3 +650,69 @@ def test_locality_view_relabels_without_touching_the_order_inside_a_row():
   assert torch.equal(view.leave(view.enter(x)), x) and torch.equal(view.enter(x)[inv], x)
   inside = view.stats['entries_inside_a_part']
   assert 0.3 < inside <= 1.0                                   # ten planted communities, 65 % of the edges inside one
+
+
+def test_bench_headline_is_the_last_line_and_fits_the_drivers_tail(capsys):
+  """The driver keeps an 8-KB tail of bench.py's stdout and parses its LAST line (round 5's single 26-KB line left `parsed: null`).  The
+  line builder on a recorded full object + configs block: the last line is the headline, < 4 KB, with `roofline` and `cpu_baseline`."""
+  import json
+  import os
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  full = json.loads(open(os.path.join(root, 'profiles', 'r05_bench_default_steps20.json')).read().strip().splitlines()[-1])
+  configs = full.pop('configs')
+  bench.emit(full, configs)
+  lines = capsys.readouterr().out.splitlines()
+  assert lines[0].startswith('{"bench_detail"') and lines[1].startswith('{"bench_configs"') and len(lines) == 3
+  last = lines[-1]
+  assert len(last) < bench.HEADLINE_MAX_BYTES
+  head = json.loads(last)
+  assert head['metric'] == full['metric'] and head['value'] == full['value'] and head['unit'] == 'steps/s'
+  for key in ('n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+    assert key in head
+  assert 'workload' in head['config'] and 'model' not in head['config']
+  for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'algorithmic_bytes_per_launch'):
+    assert key in head['roofline']
+  assert head['roofline']['frac'] == full['roofline']['frac']
+  for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+    assert key in head['cpu_baseline']
+  assert set(head['configs_summary']) == set(k for k in configs if not k.startswith('_'))
+  # a pathologically large configs block is shed, never the contract keys
+  big = dict(configs, **{'filler_%d' % i: {'value': 1.0, 'unit': 'x' * 40, 'roofline': None} for i in range(200)})
+  head2 = bench.headline(full, big)
+  assert len(json.dumps(head2)) < bench.HEADLINE_MAX_BYTES and 'roofline' in head2 and 'cpu_baseline' in head2
+
+
+def test_bench_gpus_n_without_a_launcher_refuses_only_for_lack_of_devices(monkeypatch):
+  """`python bench.py --gpus 8` the way the driver runs `--gpus 1` spawns its ranks itself (bench.launch_ranks); on a host with fewer
+  devices it says why instead of dying at argument parsing."""
+  import os
+  import sys
+  import pytest
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  monkeypatch.delenv('GNPDE_RANKS_SHARE_DEVICE', raising=False)
+  monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 1)
+  with pytest.raises(SystemExit) as err:
+    bench.launch_ranks(8)
+  assert 'GNPDE_RANKS_SHARE_DEVICE' in str(err.value)
+  seen = {}
+
+  class _Done(object):
+    returncode = 0
+
+  def fake_run(cmd, env=None, **kw):
+    seen['cmd'], seen['env'] = cmd, env
+    return _Done()
+  import subprocess
+  monkeypatch.setattr(subprocess, 'run', fake_run)
+  monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 8)
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '20', '--warmup', '5'])
+  bench.launch_ranks(8)
+  cmd = seen['cmd']
+  assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+  assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+  assert 'RANK' not in seen['env'] and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

@@ -248,3 +248,25 @@ def test_no_exchange_world1_matches_single_gpu_solver(dev):
     z = solver.integrate(x_own, x_own)
   ref = R.odeint_fixed(rhs, x, 2.0, 1.0, 'rk4')
   assert_parity(z, ref[sh.own_old_ids], what='world-1 native sharded solve')
+
+
+@pytest.mark.timeout(600, method='thread')
+def test_bench_gpus_2_launches_its_own_ranks_and_prints_a_parseable_headline():
+  """`python bench.py --gpus 2` without a launcher (how the driver runs `--gpus 1`): the script spawns its ranks itself
+  (bench.launch_ranks); on this one-GPU box the two ranks share the device (a functional run).  The LAST stdout line is the compact
+  headline with n_gpus = 2."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, GNPDE_RANKS_SHARE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--scale', '0.25'],
+                       env=env, capture_output=True, text=True, timeout=540)
+  assert res.returncode == 0, res.stderr[-2000:]
+  lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+  head = json.loads(lines[-1])
+  assert len(lines[-1]) < 4096
+  assert head['n_gpus'] == 2 and head['steps'] == 4 and head['unit'] == 'steps/s' and head['value'] > 0
+  assert head['config']['ranks_seen'] == 2 and head['config']['ranks_share_one_device'] is True
+  assert head['config']['transport'] in ('p2p', 'rccl', 'torch') and head['config']['finite'] is True
+  assert head['config']['sharded_vs_unpartitioned_timed_solve_rel_max'] is None or head['config']['sharded_vs_unpartitioned_timed_solve_rel_max'] < 1e-4
+  assert any(ln.startswith('{"bench_detail"') for ln in lines[:-1])
