@@ -343,6 +343,10 @@ struct gnpde_adjoint {
   hipGraphExec_t exec = nullptr;
   float *cap_y = nullptr, *cap_a = nullptr, *cap_g = nullptr;
   int n_evals = 0;
+  // recorded forward solve (gnpde_adjoint_set_tape): the stage inputs of the FORWARD solve in evaluation order; the run is then the
+  // reverse sweep through those evaluations (what autograd does through torchdiffeq's fixed-grid loop when opt['adjoint'] is off)
+  const float* tape = nullptr;
+  float* r_acc = nullptr;    // [e] or null: sum over the evaluations of (b_j h) u_a[row] . u_y[col] in CSR order (GRAND-l weight gradients)
 };
 
 namespace {
@@ -358,7 +362,8 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
   if (rc) return rc;
   GNPDE_CHECK_ARG(gt != nullptr && gt->n == rhs->graph->n && gt->e == rhs->graph->e, GNPDE_EINVAL,
                   "adjoint: the transposed graph does not match the descriptor's graph");
-  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4, GNPDE_EINVAL, "adjoint: bad method %d", method);
+  GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4 || method == GNPDE_METHOD_MIDPOINT, GNPDE_EINVAL,
+                  "adjoint: bad method %d", method);     // (midpoint: as the reverse sweep of a recorded solve only)
   GNPDE_CHECK_ARG(rhs->kind == GNPDE_RHS_LAPLACIAN || rhs->kind == GNPDE_RHS_TRANSFORMER, GNPDE_ESHAPE,
                   "adjoint: GRAND-l and GRAND-nl (scaled-dot) only");
   GNPDE_CHECK_ARG(rhs->alpha_sigmoid == 1, GNPDE_ESHAPE, "adjoint: the native solve needs alpha' = sigmoid(alpha_train)");
@@ -455,7 +460,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   // F with the next stage input in its epilogue + r_e = ua[row] . uy[col] + the per-wave dots, one kernel over the gathered rows
   eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
   eF.out_k = Fout;
-  rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
+  if (s->tape != nullptr && s->r_acc != nullptr && !nl)
+    rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r_acc, s->dots, s->ws_spmm, s->spmm_bytes, st, padded, true, pcoef);
+  else
+    rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
   if (rc) return rc;
   const float* source = nullptr;
   const float* source_scale = nullptr;
@@ -590,6 +598,80 @@ int enqueue_adjoint(gnpde_adjoint* s, float* y, float* a, float* grads, hipStrea
   return 0;
 }
 
+// Reverse sweep through a RECORDED fixed-grid solve (s->tape: the forward's stage inputs, csrc/solver.hip gnpde_solver_set_tape).
+// With the cotangents of the stage derivatives normalised by their weights, c_j = (b_j h) chat_j, the sweep through one rk4 (3/8 rule)
+// step reads
+//     chat_4 = g,  chat_3 = g + (h/3) J_4^T chat_4,  chat_2 = 2 g - chat_3 + h J_3^T chat_3,  chat_1 = 2 chat_3 - chat_2 + h J_2^T chat_2,
+//     g_new  = (6 chat_2 + 3 chat_1 - g + h J_1^T chat_1) / 8
+// -- the compact stage formulas of the forward solver with (g, chat_3, chat_2, chat_1) in the places of (y, u2, u3, u4): the same V
+// epilogues as the continuous adjoint above, the state-side operand read from the tape (u4, u3, u2, u1) instead of integrated
+// backwards, parameter gradients weighted b_j h.  F is formed for the scalar gradients' dots only (no stage output).
+int enqueue_taped(gnpde_adjoint* s, float* a, float* grads, hipStream_t st) {
+  const gnpde_rhs_t& r = s->rhs;
+  const size_t nbytes = static_cast<size_t>(r.graph->n) * r.ld * 4;
+  const size_t stride = s->state_bytes / 4;
+  auto slot = [&](size_t i) { return s->tape + i * stride; };
+  GNPDE_HIP(hipMemsetAsync(grads, 0, static_cast<size_t>(s->stride) * 4, st));
+  if (s->r_acc != nullptr && r.graph->e > 0) GNPDE_HIP(hipMemsetAsync(s->r_acc, 0, static_cast<size_t>(r.graph->e) * 4, st));
+  const int S = static_cast<int>(s->dts.size());
+  auto no_output = []() { gnpde_epilogue_t e{}; e.stage = GNPDE_STAGE_LINCOMB; return e; };
+  if (s->method == GNPDE_METHOD_EULER) {
+    float* ca = a;
+    int flip = 0;
+    for (int n = S - 1; n >= 0; --n) {
+      const float h = s->dts[n];
+      gnpde_epilogue_t eV{};
+      eV.stage = GNPDE_STAGE_EULER; eV.dt = h; eV.y = ca; eV.out_y = s->ua[flip];
+      int rc = enqueue_stage(s, slot(n), ca, nullptr, no_output(), nullptr, eV, h, grads, st);
+      if (rc) return rc;
+      ca = s->ua[flip];
+      flip ^= 1;
+    }
+    if (ca != a) GNPDE_HIP(hipMemcpyAsync(a, ca, nbytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (s->method == GNPDE_METHOD_MIDPOINT) {
+    // y_mid = y + (h/2) f(y), y' = y + h f(y_mid):  W = J_mid^T g,  g_new = g + h W + (h^2 / 2) J_y^T W
+    for (int n = S - 1; n >= 0; --n) {
+      const float h = s->dts[n];
+      gnpde_epilogue_t eV{};
+      eV.stage = GNPDE_STAGE_LINCOMB; eV.y = a; eV.n_prev = 0; eV.coef[0] = h; eV.out_y = s->ua[1];
+      int rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n) + 1), a, nullptr, no_output(), s->ua[0], eV, h, grads, st);
+      if (rc) return rc;
+      const float hh = 0.5f * h * h;
+      eV = gnpde_epilogue_t{};
+      eV.stage = GNPDE_STAGE_LINCOMB; eV.y = s->ua[1]; eV.n_prev = 0; eV.coef[0] = hh; eV.out_y = a;
+      rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n)), s->ua[0], nullptr, no_output(), nullptr, eV, hh, grads, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  float* a4 = s->V[0];
+  for (int n = S - 1; n >= 0; --n) {
+    const float dtf = s->dts[n];
+    const double dt = dtf;
+    const float c8 = static_cast<float>(dt * 0.125), c38 = static_cast<float>(3.0 * (dt * 0.125));
+    const float *u1 = slot(4 * static_cast<size_t>(n)), *u2 = u1 + stride, *u3 = u2 + stride, *u4 = u3 + stride;
+    gnpde_epilogue_t eV{};
+    eV.stage = GNPDE_STAGE_RK1C; eV.dt = dtf; eV.out_y = s->ua[0];
+    int rc = enqueue_stage(s, u4, a, nullptr, no_output(), nullptr, eV, c8, grads, st);
+    if (rc) return rc;
+    eV = gnpde_epilogue_t{};
+    eV.stage = GNPDE_STAGE_RK2C; eV.dt = dtf; eV.y = a; eV.out_y = s->ua[1];
+    rc = enqueue_stage(s, u3, s->ua[0], nullptr, no_output(), nullptr, eV, c38, grads, st);
+    if (rc) return rc;
+    eV = gnpde_epilogue_t{};
+    eV.stage = GNPDE_STAGE_RK3C; eV.dt = dtf; eV.k1 = s->ua[0]; eV.out_y = a4;
+    rc = enqueue_stage(s, u2, s->ua[1], nullptr, no_output(), nullptr, eV, c38, grads, st);
+    if (rc) return rc;
+    eV = gnpde_epilogue_t{};
+    eV.stage = GNPDE_STAGE_RK4C; eV.dt = dtf; eV.y = a; eV.k1 = s->ua[1]; eV.out_y = a;      // in place: a is not gathered in this stage
+    rc = enqueue_stage(s, u1, a4, nullptr, no_output(), nullptr, eV, c8, grads, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 void drop_adjoint_graph(gnpde_adjoint* s) {
   if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
   if (s->graph_obj) { (void)hipGraphDestroy(s->graph_obj); s->graph_obj = nullptr; }
@@ -643,7 +725,7 @@ extern "C" int gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rh
   s->ws = static_cast<char*>(workspace);
   s->ws_bytes = workspace_bytes;
   adjoint_layout(s->rhs, s->graph_t, method, s);
-  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : 1);
+  s->n_evals = n_steps * (method == GNPDE_METHOD_RK4 ? 4 : method == GNPDE_METHOD_MIDPOINT ? 2 : 1);
   *out = s;
   return 0;
 }
@@ -661,12 +743,14 @@ extern "C" int gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* 
     GNPDE_HIP(hipStreamSynchronize(st));   // (the host scalar above must not go out of scope before the copy ran)
     s->zeroed = true;
   }
-  if (!use_graph) return enqueue_adjoint(s, y, a, grads, st);
+  GNPDE_CHECK_ARG(s->tape != nullptr || s->method != GNPDE_METHOD_MIDPOINT, GNPDE_EINVAL,
+                  "adjoint_run: midpoint runs as the reverse sweep of a recorded solve only (gnpde_adjoint_set_tape)");
+  if (!use_graph) return s->tape ? enqueue_taped(s, a, grads, st) : enqueue_adjoint(s, y, a, grads, st);
   if (s->exec == nullptr || s->cap_y != y || s->cap_a != a || s->cap_g != grads) {
     drop_adjoint_graph(s);
     if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
     GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_adjoint(s, y, a, grads, s->cap_stream);
+    const int rc = s->tape ? enqueue_taped(s, a, grads, s->cap_stream) : enqueue_adjoint(s, y, a, grads, s->cap_stream);
     hipGraph_t gobj = nullptr;
     const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
     if (rc != 0) {
@@ -682,6 +766,24 @@ extern "C" int gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* 
     s->cap_y = y; s->cap_a = a; s->cap_g = grads;
   }
   GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "adjoint_set_tape: solver is null");
+  drop_adjoint_graph(s);
+  s->tape = nullptr;
+  s->r_acc = nullptr;
+  if (tape == nullptr) return 0;
+  const size_t per = s->method == GNPDE_METHOD_RK4 ? 4 : s->method == GNPDE_METHOD_MIDPOINT ? 2 : 1;
+  const size_t need = (per * s->dts.size() + 1) * s->state_bytes;
+  GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(tape) % 256 == 0 && tape_bytes >= need, GNPDE_EWS,
+                  "adjoint_set_tape: %zu bytes (need %zu, 256-byte aligned: the tape of gnpde_solver_set_tape for the same method and grid)",
+                  tape_bytes, need);
+  GNPDE_CHECK_ARG(r_acc == nullptr || s->rhs.kind == GNPDE_RHS_LAPLACIAN, GNPDE_EINVAL,
+                  "adjoint_set_tape: edge-weight gradients are GRAND-l's (GRAND-nl forms its weights from the state)");
+  s->tape = static_cast<const float*>(tape);
+  s->r_acc = r_acc;
   return 0;
 }
 

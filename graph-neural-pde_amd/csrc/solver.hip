@@ -161,6 +161,7 @@ struct gnpde_solver {
   int* early_state = nullptr;
   int* early_trace = nullptr;
   int early_trace_capacity = 0;
+  float* tape = nullptr;     // recorded solve (gnpde_solver_set_tape): n_evals + 1 state-sized slots, the stage inputs in evaluation order
 };
 
 namespace {
@@ -209,6 +210,53 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
                                    s->early_trace, s->early_trace_capacity, st);
   };
   if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, 8 * sizeof(int32_t), st));
+  if (s->tape != nullptr) {
+    // Recorded solve: the same launches, every stage input written to a slot of its own instead of a recycled buffer -- the record
+    // costs no extra pass over the state.  Slot 0 = y0, slot i = the input of evaluation i (rk4: u1..u4 of step n at 4n..4n+3),
+    // the last slot = y(T), copied back into y.
+    const size_t stride = align_up(static_cast<size_t>(r.graph->n) * r.ld * 4, 256) / 4;
+    const size_t nbytes = static_cast<size_t>(r.graph->n) * r.ld * 4;
+    auto slot = [&](size_t i) { return s->tape + i * stride; };
+    GNPDE_HIP(hipMemcpyAsync(slot(0), y, nbytes, hipMemcpyDeviceToDevice, st));
+    size_t at = 0;
+    for (float dt : s->dts) {
+      gnpde_epilogue_t e = base_epilogue(r);
+      e.dt = dt;
+      int rc = 0;
+      if (s->method == GNPDE_METHOD_EULER) {
+        e.stage = GNPDE_STAGE_EULER; e.y = slot(at); e.out_y = slot(at + 1);
+        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk);
+        at += 1;
+      } else if (s->method == GNPDE_METHOD_MIDPOINT) {
+        e.stage = GNPDE_STAGE_LINCOMB; e.y = slot(at); e.n_prev = 0; e.out_k = nullptr;
+        e.coef[0] = 0.5f * dt; e.out_y = slot(at + 1);
+        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk);
+        if (rc) return rc;
+        e.coef[0] = dt; e.out_y = slot(at + 2);
+        rc = enqueue_rhs(r, slot(at + 1), e, rws, s->L, st, fk);
+        at += 2;
+      } else {
+        float *u1 = slot(at), *u2 = slot(at + 1), *u3 = slot(at + 2), *u4 = slot(at + 3);
+        e.stage = GNPDE_STAGE_RK1C; e.out_y = u2;
+        rc = enqueue_rhs(r, u1, e, rws, s->L, st, fk);
+        if (rc) return rc;
+        e.stage = GNPDE_STAGE_RK2C; e.y = u1; e.out_y = u3;
+        rc = enqueue_rhs(r, u2, e, rws, s->L, st, fk);
+        if (rc) return rc;
+        e.stage = GNPDE_STAGE_RK3C; e.k1 = u2; e.out_y = u4;
+        rc = enqueue_rhs(r, u3, e, rws, s->L, st, fk);
+        if (rc) return rc;
+        e.stage = GNPDE_STAGE_RK4C; e.k1 = u3; e.out_y = slot(at + 4);
+        rc = enqueue_rhs(r, u4, e, rws, s->L, st, fk);
+        at += 4;
+      }
+      if (rc) return rc;
+      rc = evaluate(slot(at));
+      if (rc) return rc;
+    }
+    GNPDE_HIP(hipMemcpyAsync(y, slot(at), nbytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
   if (s->method == GNPDE_METHOD_EULER) {
     float* cur = y;
     float* nxt = ua;
@@ -395,6 +443,26 @@ extern "C" int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, 
     s->captured_y = y;
   }
   GNPDE_HIP(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" size_t gnpde_solver_tape_bytes(const gnpde_rhs_t* rhs, int32_t method, int32_t n_steps) {
+  if (check_rhs(rhs) || n_steps < 0) return 0;
+  if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4 && method != GNPDE_METHOD_MIDPOINT) return 0;
+  const size_t state = align_up(static_cast<size_t>(rhs->graph->n) * rhs->ld * 4, 256);
+  const size_t per = method == GNPDE_METHOD_RK4 ? 4 : method == GNPDE_METHOD_MIDPOINT ? 2 : 1;
+  return (per * static_cast<size_t>(n_steps) + 1) * state;
+}
+
+extern "C" int gnpde_solver_set_tape(gnpde_solver_t* s, void* tape, size_t tape_bytes) {
+  GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "solver_set_tape: solver is null");
+  drop_graph(s);
+  s->tape = nullptr;
+  if (tape == nullptr) return 0;
+  const size_t need = gnpde_solver_tape_bytes(&s->rhs, s->method, static_cast<int32_t>(s->dts.size()));
+  GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(tape) % 256 == 0 && tape_bytes >= need, GNPDE_EWS,
+                  "solver_set_tape: %zu bytes (need %zu, 256-byte aligned, zero-filled)", tape_bytes, need);
+  s->tape = static_cast<float*>(tape);
   return 0;
 }
 

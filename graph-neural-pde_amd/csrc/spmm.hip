@@ -1295,6 +1295,7 @@ struct AdjRowsArgs {
   float* __restrict__ dots;        // [gridDim.x + n_long_rows][2] out: per-wave sums of g . F and g . x0
   int r_accumulate;                // != 0: r[e] += (every entry belongs to exactly one lane of one launch: no race); the recorded
                                    // dopri5 backward sums the edge products of all its evaluations this way
+  float r_scale;                   // weight of this launch's products in the sum (the recorded fixed-grid backward: the stage's b_j h)
 };
 
 template <int N, int MASK>
@@ -1398,7 +1399,7 @@ __device__ __forceinline__ void adjoint_item(const AdjRowsArgs& fa, int row, int
       for (int m = LPE / 2; m >= 1; m >>= 1) p[0] += __shfl_xor(p[0], m, kWave);
       const int idx = t0 + (cl / LPE) * G + sub;
       if ((cl % LPE) == 0 && idx < cnt) {
-        if (fa.r_accumulate) fa.r[base + idx] += p[0];
+        if (fa.r_accumulate) fa.r[base + idx] = fmaf(fa.r_scale, p[0], fa.r[base + idx]);
         else fa.r[base + idx] = p[0];
       }
     }
@@ -1513,7 +1514,7 @@ int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d) {
 
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
-                        bool padded_rows, bool accumulate_r) {
+                        bool padded_rows, bool accumulate_r, float r_scale) {
   GNPDE_CHECK_ARG(g && u && gvec && epi && r_out && dots && (w_csr || g->e == 0), GNPDE_EINVAL, "adjoint_rows: null pointer");
   const int stg = epi->stage;
   GNPDE_CHECK_ARG((stg == GNPDE_STAGE_LINCOMB || stg == GNPDE_STAGE_EULER || (stg >= GNPDE_STAGE_RK1C && stg <= GNPDE_STAGE_RK4C)) &&
@@ -1546,7 +1547,7 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
   const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->k1, epi->out_k, epi->out_y, stg == GNPDE_STAGE_LINCOMB ? epi->prev[0] : nullptr,
                         stg == GNPDE_STAGE_LINCOMB ? epi->prev[1] : nullptr, stg == GNPDE_STAGE_LINCOMB ? epi->prev[2] : nullptr};
   for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
-  fa.g = gvec; fa.r = r_out; fa.dots = dots; fa.r_accumulate = accumulate_r ? 1 : 0;
+  fa.g = gvec; fa.r = r_out; fa.dots = dots; fa.r_accumulate = accumulate_r ? 1 : 0; fa.r_scale = r_scale;
   const unsigned grid = adjoint_rows_grid(g);
   const int slots = (d + 3) / 4;
   if (slots <= 16) hipLaunchKernelGGL((adjoint_rows_kernel<16, 8>), dim3(grid), dim3(kWave), 0, stream, fa);

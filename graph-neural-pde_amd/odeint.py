@@ -595,6 +595,204 @@ def _solve_dopri5_recorded(func, y0, t, rtol, atol):
                                float(atol))
 
 
+# --------------------------------------------------------------------------------------------------
+# recorded fixed-grid solve: training WITHOUT the adjoint method through euler / midpoint / rk4 -- `python run_GNN.py --function
+# transformer --block constant --method rk4` (reference run_GNN.py:336 `--adjoint` is store_true, base_classes.py:44-47 then picks
+# torchdiffeq.odeint and loss.backward() runs through its Python loop, run_GNN.py:62-96)
+# --------------------------------------------------------------------------------------------------
+def _recorded_fixed_ok(func, y0, t, method):
+  """The differentiated fixed-grid solve runs as ONE recorded native solve (csrc/solver.hip, gnpde_solver_set_tape: the captured
+  hipGraph of the inference solve with every stage input written to a slot of its own) + ONE native reverse sweep over the record
+  (csrc/adjoint.hip, gnpde_adjoint_set_tape: the VJP stage kernels of the adjoint solve, one hipGraph) for GRAND-l (weights may carry
+  gradients: attention block) and GRAND-nl with scaled-dot scores, alpha' = sigmoid(alpha_train).  Everything else keeps the host
+  loop `_solve_fixed_host` over the kernel-backed autograd Functions of autograd.py."""
+  if method not in ('euler', 'rk4', 'midpoint') or not hasattr(func, '_descriptor'):
+    return False
+  if not (y0.is_cuda and y0.dim() == 2 and y0.dtype == torch.float32 and y0.shape[1] <= 256 and len(t) == 2):
+    return False
+  opt = func.opt
+  if opt.get('no_alpha_sigmoid') or opt.get('gnpde_composite_backward') or opt.get('gnpde_host_fixed_training') or opt.get('gnpde_shard'):
+    return False
+  if os.environ.get('GNPDE_HOST_FIXED_TRAINING', '0') == '1':      # A/B runs (bench.py --train --no-adjoint)
+    return False
+  if not (torch.is_grad_enabled() and func._needs_grad(y0)):
+    return False
+  kind = func.__class__.__name__
+  if kind == 'LaplacianODEFunc':
+    return True
+  if kind == 'ODEFuncTransformerAtt':
+    from .autograd import _native_transformer_vjp_ok
+    lay = func.multihead_att_layer
+    return bool(_native_transformer_vjp_ok(func)) and (2 * lay.attention_dim) % 4 == 0
+  return False
+
+
+def _grad_vector_by_param(func, g, d):
+  """{id(parameter): its slice of the native gradient vector} (gnpde_adjoint_run: d[Wq;Wk], d[bq;bk], d alpha_train, d beta_train)."""
+  by_param = {}
+  tail = 0
+  if func.__class__.__name__ == 'ODEFuncTransformerAtt':
+    lay = func.multihead_att_layer
+    A = lay.attention_dim
+    gram = g[:2 * A * d].view(2 * A, d)
+    gb = g[2 * A * d:2 * A * d + 2 * A]
+    by_param = {id(lay.Q.weight): gram[:A], id(lay.K.weight): gram[A:], id(lay.Q.bias): gb[:A], id(lay.K.bias): gb[A:]}
+    tail = 2 * A * d + 2 * A
+  by_param[id(func.alpha_train)] = g[tail].reshape(func.alpha_train.shape)
+  if func.opt['add_source']:
+    by_param[id(func.beta_train)] = g[tail + 1].reshape(func.beta_train.shape)
+  return by_param
+
+
+class _RecordedFixedGrid(torch.autograd.Function):
+  """Forward: the native fixed-grid solver with a tape (no extra pass: the stage epilogues write their outputs into the tape's slots).
+  Backward: the reverse sweep through the recorded evaluations -- per evaluation the VJP stage of the native adjoint solve (projection,
+  attention, row kernel with the edge products, normaliser backward, d q / d k, aggregation on the transposed graph whose epilogue forms
+  the next cotangent, parameter-gradient pass), all steps in one hipGraph, no PyTorch op and no host synchronisation inside."""
+
+  @staticmethod
+  def forward(ctx, y0, edge_values, func, method, dts, *params):
+    from . import ops
+    from .utils import MaxNFEException
+    n_evals = len(dts) * _EVALS_PER_STEP[method]
+    room = func.opt['max_nfe'] + 1 - func.nfe
+    if n_evals > room:
+      func.nfe += max(room, 0)
+      raise MaxNFEException
+    y0c = _lib.f32c(y0.detach())
+    n, d = y0c.shape
+    view = func._locality_view(y0c) if hasattr(func, '_locality_view') else None
+    st = func.__dict__.setdefault('_fixed_tape_state', {})
+    key = (method, tuple(dts), n, d, str(y0c.device), id(view))
+    ent = st.get(key)
+    if ent is None:
+      for old in st.values():
+        for name in ('solver', 'sweep'):
+          if old.get(name) is not None:
+            old[name].close()
+      st.clear()
+      ent = st[key] = {'y': _lib.alloc_state(n, d, y0c.device), 'a': _lib.alloc_state(n, d, y0c.device),
+                       'x0': _lib.alloc_state(n, d, y0c.device) if func.opt['add_source'] else None,
+                       'solver': None, 'sweep': None, 'sig': None, 'sweep_sig': None, 'view': view, 'extra': {}}
+    if view is None:
+      ent['y'].copy_(y0c)
+    else:
+      view.enter(y0c, out=ent['y'])
+    if ent['x0'] is not None:
+      if func.x0 is None:
+        raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+      if view is None:
+        ent['x0'].copy_(func.x0.detach())
+      else:
+        view.enter(func.x0.detach(), out=ent['x0'])
+    graph = func._graph(y0c) if view is None else view.graph
+    desc = func._descriptor(ent['y'], x0_override=ent['x0'], graph=graph)      # (refreshes the CSR-ordered weights in place)
+    sig = func._descriptor_signature(desc)
+    if ent['solver'] is None or ent['sig'] != sig:
+      for name in ('solver', 'sweep'):
+        if ent[name] is not None:
+          ent[name].close()
+      ent['sweep'] = None
+      ent['solver'] = ops.FixedStepSolver(desc, method, dts, y0c.device)
+      ent['solver'].set_tape(True)
+      ent['sig'] = sig
+    sol = ent['solver']
+    sol.run(ent['y'])
+    func.nfe += n_evals
+    sol.tape_generation += 1
+    out = torch.empty((2, n, d), dtype=torch.float32, device=y0c.device)
+    out[0].copy_(y0c)
+    if view is None:
+      out[1].copy_(ent['y'])
+    else:
+      view.leave(ent['y'], out=out[1])
+    ctx.func, ctx.ent, ctx.gen, ctx.desc, ctx.graph, ctx.view = func, ent, sol.tape_generation, desc, graph, view
+    ctx.method, ctx.dts, ctx.params = method, dts, params
+    ctx.heads = 0 if edge_values is None else (edge_values.shape[1] if edge_values.dim() == 2 else 0)
+    ctx.has_edge_values = edge_values is not None
+    func._last_train_solve = 'native recorded fixed-grid %s' % method
+    return out
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    from . import ops
+    func, ent, graph, view, desc = ctx.func, ctx.ent, ctx.graph, ctx.view, ctx.desc
+    sol = ent['solver']
+    if sol is None or sol.handle is None or sol.tape_generation != ctx.gen:
+      raise _lib.GnpdeError('recorded fixed-grid solve: the tape of this forward pass was overwritten by a later solve of the same function '
+                            '(backward must run before the next training forward; opt["gnpde_host_fixed_training"] = True keeps a graph per forward)')
+    need = ctx.needs_input_grad
+    nl = func.__class__.__name__ == 'ODEFuncTransformerAtt'
+    with torch.no_grad():
+      n, d = grad_out.shape[1], grad_out.shape[2]
+      dev = grad_out.device
+      gt, t_from_csr = graph.transposed_positions()
+      ex = ent['extra']
+      proj_wt = w_t = None
+      if nl:
+        wqk, _ = func.multihead_att_layer.qk_weights()
+        if ex.get('proj_wt') is None or ex['proj_wt'].shape != (wqk.shape[1], wqk.shape[0]):
+          ex['proj_wt'] = torch.empty(wqk.shape[1], wqk.shape[0], dtype=torch.float32, device=dev)
+        ex['proj_wt'].copy_(wqk.t())                 # refreshed in place: the captured graph keeps the pointer
+        proj_wt = ex['proj_wt']
+      else:
+        w_csr = func._weights_csr(graph)
+        if ex.get('w_t') is None or ex['w_t'].numel() != max(graph.e, 1):
+          ex['w_t'] = torch.empty(max(graph.e, 1), dtype=torch.float32, device=dev)
+          ex['r_acc'] = torch.zeros(max(graph.e, 1), dtype=torch.float32, device=dev)
+        if graph.e > 0:
+          torch.index_select(w_csr[:graph.e], 0, t_from_csr.long(), out=ex['w_t'][:graph.e])
+        w_t = ex['w_t']
+      want_dw = (not nl) and ctx.has_edge_values and need[1] and graph.e > 0
+      sweep_sig = (ent['sig'], id(gt), bool(want_dw), id(sol))
+      if ent['sweep'] is None or ent['sweep_sig'] != sweep_sig:
+        if ent['sweep'] is not None:
+          ent['sweep'].close()
+        ent['sweep'] = ops.AdjointSolver(desc, gt, t_from_csr if nl else None, proj_wt, w_t, ctx.method, ctx.dts, dev)
+        ent['sweep'].set_tape(sol.tape, ex['r_acc'] if want_dw else None)
+        ent['grads'] = torch.zeros(ent['sweep'].n_grad, dtype=torch.float32, device=dev)
+        ent['sweep_sig'] = sweep_sig
+      ab = ent['a']
+      g1 = grad_out[1]
+      if view is None:
+        ab.copy_(g1)
+      else:
+        view.enter(g1.contiguous(), out=ab)
+      ent['sweep'].run(ent['y'], ab, ent['grads'])      # (y is not read in the taped mode: the state comes from the tape)
+      dy0 = None
+      if need[0]:
+        dy0 = torch.empty((n, d), dtype=torch.float32, device=dev)
+        if view is None:
+          dy0.copy_(ab)
+        else:
+          view.leave(ab, out=dy0)
+        dy0 += grad_out[0]
+      dw = None
+      if want_dw:
+        a = torch.sigmoid(func.alpha_train.detach().reshape(()))
+        E = graph.e
+        dw_e = torch.empty(E, dtype=torch.float32, device=dev)
+        dw_e[graph.perm_long] = a * ex['r_acc'][:E]
+        dw = (dw_e / ctx.heads).unsqueeze(1).expand(E, ctx.heads).contiguous() if ctx.heads else dw_e
+      by_param = _grad_vector_by_param(func, ent['grads'], d)
+      gparams = []
+      for i, p in enumerate(ctx.params):
+        g = by_param.get(id(p)) if need[5 + i] else None
+        gparams.append(None if g is None else g.clone())
+    return (dy0, dw, None, None, None) + tuple(gparams)
+
+
+def _solve_fixed_recorded(func, y0, t, method, step_size):
+  grid = time_grid(t.detach().to('cpu'), step_size)
+  dts = tuple((grid[1:] - grid[:-1]).tolist())
+  params = tuple(p for p in func.parameters() if p.requires_grad)
+  edge_values = None
+  if func.__class__.__name__ == 'LaplacianODEFunc':
+    ev = func._edge_values()
+    edge_values = ev if ev.requires_grad else None
+  return _RecordedFixedGrid.apply(y0, edge_values, func, method, dts, *params)
+
+
 class _TupleFunc(object):
   """A function of a tuple state seen as a function of the flattened concatenation (torchdiffeq misc.py _TupleFunc):
   the regularised training state (x, r_1, ..., r_k) of reference src/block_constant.py:40-43."""
@@ -642,6 +840,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
           raise _lib.GnpdeError('gnpde_shard: the row-partitioned solver runs euler, rk4, dopri5 and adaptive_heun; unset gnpde_shard for midpoint')
         return D.solve_sharded(func, y0, t, method, step_size, use_graph=use_graph)
       return _solve_native(func, y0, t, method, step_size, use_graph=use_graph)
+    if _recorded_fixed_ok(func, y0, t, method):      # training without the adjoint method: recorded solve + native reverse sweep
+      return _solve_fixed_recorded(func, y0, t, method, step_size)
     return _solve_fixed_host(func, y0, t, method, step_size)
   if method in ('dopri5', 'adaptive_heun') and hasattr(func, '_descriptor'):
     from . import distributed as D
@@ -1121,6 +1321,9 @@ class _AdjointSolve(torch.autograd.Function):
         return -_flatten(outs)
 
       options = dict(adj['options'])
+      # (a caller's own adjoint norm -- torchdiffeq's adjoint_options['norm'], e.g. 'seminorm' -- is honoured by the flat loop only: the
+      # native controller's norm is the default mixed one)
+      user_norm = options.get('norm') is not None
       if adj['method'] in ('dopri5', 'adaptive_heun') and 'norm' not in options:
         options['norm'] = _mixed_norm(shapes)
       fixed = adj['method'] in ('euler', 'rk4')
@@ -1136,7 +1339,7 @@ class _AdjointSolve(torch.autograd.Function):
           state[2], gp = _adjoint_fixed_grid(func, params, state[1], state[2], state[3:], span, adj['method'],
                                              options['step_size'])
           state = state[:3] + list(gp)
-        elif _adjoint_adaptive_ok(func, state[1], adj['method']) and not options.get('host_flat', False):
+        elif _adjoint_adaptive_ok(func, state[1], adj['method']) and not options.get('host_flat', False) and not user_norm:
           # adaptive adjoint method on the Laplacian function: native stages on the components (no autograd graph, no flat vector)
           state[2], new = _adjoint_adaptive_native(func, params, state[1], state[2], state[3:], span, adj['method'], adj['rtol'], adj['atol'])
           for idx, val in new.items():

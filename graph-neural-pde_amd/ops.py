@@ -465,7 +465,9 @@ class Dopri5Solver(object):
     self.tape = torch.zeros(nbytes, dtype=torch.uint8, device=self.ws.device)
     check(L.gnpde_dopri5_set_tape(self.handle, ptr(self.tape), self.tape.numel(), int(capacity_steps)))
     self.tape_capacity = int(capacity_steps)
-    self.tape_generation = 0
+    # (a new tape invalidates every forward pass recorded on the old one: the counter only ever grows -- odeint._RecordedDopri5.backward
+    # compares the stamp of its forward pass with it)
+    self.tape_generation = getattr(self, 'tape_generation', 0) + 1
 
   def tape_steps(self):
     return int(_lib.lib().gnpde_dopri5_tape_steps(self.handle))
@@ -710,6 +712,20 @@ class FixedStepSolver(object):
                                           evaluator.trace_capacity))
     self.evaluator = evaluator
 
+  def set_tape(self, on=True):
+    """Record the stage inputs of the following runs (gnpde_solver_set_tape): the tape is zero-filled device memory owned here."""
+    L = _lib.lib()
+    if not on:
+      check(L.gnpde_solver_set_tape(self.handle, None, 0))
+      self.tape = None
+      return
+    nbytes = int(L.gnpde_solver_tape_bytes(self.desc.ref(), self.method, len(self.dts)))
+    if nbytes == 0:
+      raise _lib.GnpdeError('recorded fixed-grid solve: %s' % L.gnpde_last_error().decode(errors='replace'))
+    self.tape = torch.zeros(nbytes, dtype=torch.uint8, device=self.ws.device)
+    check(L.gnpde_solver_set_tape(self.handle, ptr(self.tape), self.tape.numel()))
+    self.tape_generation = getattr(self, 'tape_generation', 0) + 1      # (only ever grows: stale-tape stamp of odeint._RecordedFixedGrid)
+
   def run(self, y, use_graph=True):
     """Integrate y in place."""
     require_hip(y)
@@ -736,7 +752,7 @@ class AdjointSolver(object):
   def __init__(self, desc, graph_t, t_from_csr, proj_wt, w_t, method, dts, device):
     self.desc, self.graph_t = desc, graph_t
     self.keep = [t_from_csr, proj_wt, w_t]
-    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4}[method]
+    self.method = {'euler': _lib.METHOD_EULER, 'rk4': _lib.METHOD_RK4, 'midpoint': _lib.METHOD_MIDPOINT}[method]
     self.dts = [float(v) for v in dts]
     L = _lib.lib()
     nbytes = L.gnpde_adjoint_workspace_bytes(desc.ref(), graph_t.ref(), self.method)
@@ -750,6 +766,16 @@ class AdjointSolver(object):
                                  arr, len(self.dts), ptr(self.ws), self.ws.numel()))
     self.handle = handle
     self.n_rhs_evals = L.gnpde_adjoint_num_rhs_evals(handle)
+
+  def set_tape(self, tape, r_acc=None):
+    """Reverse sweep through the recorded forward solve whose stage inputs `tape` holds (FixedStepSolver.set_tape; same method and
+    grid): run() then maps a = dL/dy(T) to dL/dy0.  r_acc [e] (GRAND-l): receives the weighted edge products in CSR order."""
+    if tape is None:
+      check(_lib.lib().gnpde_adjoint_set_tape(self.handle, None, 0, None))
+    else:
+      require_hip(tape)
+      check(_lib.lib().gnpde_adjoint_set_tape(self.handle, ptr(tape), tape.numel(), ptr(r_acc)))
+    self.tape, self.r_acc = tape, r_acc
 
   def run(self, y, a, grads, use_graph=True):
     """y, a [n, ld] integrated backwards in place; grads [n_grad] receives the parameter gradients."""

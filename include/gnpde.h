@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 4   /* 4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 5   /* 5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -427,6 +427,15 @@ int gnpde_solver_create(gnpde_solver_t** out, const gnpde_rhs_t* rhs, int32_t me
  * captured once into a hipGraph (keyed on the y pointer) and replayed. */
 int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* stream);
 
+/* Recorded solve -- training with opt['adjoint'] off through a fixed-grid method (the reference's default: src/base_classes.py:44-47
+ * picks torchdiffeq.odeint, run_GNN.py:62-96 calls loss.backward() through its Python loop; src/block_constant.py:45-62).  With a tape
+ * attached every stage input of the following runs is written to a slot of its own (n_evals + 1 state-sized slots, 256-byte aligned
+ * strides: slot 0 = y0, slot i = the input of evaluation i, the last slot = y(T)) instead of a recycled stage buffer, so the record
+ * costs no extra pass over the state.  The caller hands over ZERO-FILLED memory (padding columns are read by 16-byte lanes).
+ * tape == NULL detaches.  The reverse sweep is gnpde_adjoint_set_tape + gnpde_adjoint_run below. */
+size_t gnpde_solver_tape_bytes(const gnpde_rhs_t* rhs, int32_t method, int32_t n_steps);
+int    gnpde_solver_set_tape(gnpde_solver_t* s, void* tape, size_t tape_bytes);
+
 /* One un-fused evaluation out = f(u) of the same descriptor (what ODEFunc.forward returns). */
 int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);
@@ -456,6 +465,13 @@ int    gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rhs, const
                             const float* proj_wt, const float* w_t_csr, int32_t method, const float* dts, int32_t n_steps,
                             void* workspace, size_t workspace_bytes);
 int    gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* grads, int32_t use_graph, void* stream);
+/* Reverse sweep through a RECORDED forward solve (gnpde_solver_set_tape; what autograd does through torchdiffeq's fixed-grid loop,
+ * fixed_grid.py / rk_common.py rk4_alt_step_func, when opt['adjoint'] is off).  The object is created with the FORWARD method
+ * (euler, midpoint or rk4) and the forward grid's dts; with a tape attached gnpde_adjoint_run ignores y's contents and maps
+ * a = dL/dy(T) to dL/dy0, grads as above.  r_acc (GRAND-l, nullable) [e]: receives sum over the evaluations of
+ * (b_j h) u_a[row] . u_y[col] in the CSR order of rhs->graph -- times alpha' the gradient of the edge weights (attention block).
+ * tape == NULL detaches. */
+int    gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc);
 int    gnpde_adjoint_num_rhs_evals(const gnpde_adjoint_t* s);
 int    gnpde_adjoint_destroy(gnpde_adjoint_t* s);
 

@@ -545,6 +545,15 @@ def gen_training():
     'constant_laplacian_dopri5': dict(block='constant', function='laplacian', method='dopri5', time=3.0, tol_scale=200.0),
     'constant_laplacian_midpoint': dict(block='constant', function='laplacian', method='midpoint', time=2.3, step_size=0.5),
     'constant_transformer_midpoint': dict(block='constant', function='transformer', method='midpoint', time=2.0),
+    # round 6: the fixed-grid methods of run_GNN.py's default mode (adjoint off) -- rk4 with a short last step, euler, the normaliser of
+    # best_params Cora, and the attention block (gradients reach the attention layer through the edge weights of every evaluation)
+    'constant_transformer_rk4': dict(block='constant', function='transformer', method='rk4', time=2.3),
+    'constant_transformer_euler': dict(block='constant', function='transformer', method='euler', time=2.0, step_size=0.5),
+    'constant_transformer_rk4_columns_squareplus': dict(block='constant', function='transformer', method='rk4', time=2.0,
+                                                        square_plus=True, attention_norm_idx=1, heads=8, attention_dim=32),
+    'constant_laplacian_rk4': dict(block='constant', function='laplacian', method='rk4', time=2.3),
+    'attention_laplacian_rk4': dict(block='attention', function='laplacian', method='rk4', time=2.3, step_size=0.5),
+    'attention_laplacian_euler_no_source': dict(block='attention', function='laplacian', method='euler', time=3.0, add_source=False),
   }
   for i, (name, over) in enumerate(cases.items()):
     opt = {**BASE, **over}

@@ -158,6 +158,31 @@ def test_backward_after_a_later_forward_fails_loudly(dev):
     za.sum().backward()
 
 
+def test_backward_after_a_later_forward_that_outgrew_the_tape_fails_loudly(dev, monkeypatch):
+  """The stale-tape stamp only ever grows: forward A (stamp g), then forward B on the same function that accepts more steps than the
+  tape holds (a new, longer tape) -- A's backward must raise instead of differentiating B's record (round-5 advisor item)."""
+  monkeypatch.setattr(O, '_TAPE_BUDGET_BYTES', 1)          # -> the smallest tape (8 slots)
+  block, x, ei, opt = _cora_like(dev, n=400, d=16, heads=4, A=16, seed=41, time=30.0, tol_scale=1.0)
+  block.train()
+  block.odefunc.opt['time'] = 1.0
+  xa = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xa)
+  t_long = block.t.clone()
+  block.t = torch.tensor([0.0, 0.5]).to(dev)              # a short solve: fits the 8 slots
+  za = block(xa)
+  sol = next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver']
+  assert sol.tape_capacity == 8
+  block.t = t_long                                         # the long one outgrows them
+  xb = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xb)
+  zb = block(xb)
+  assert sol.tape_capacity > 8 or next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver'] is not sol
+  with pytest.raises(G.GnpdeError):
+    za.sum().backward()
+  zb.sum().backward()
+  assert torch.isfinite(xb.grad).all()
+
+
 def test_recorded_gradients_against_the_float64_reverse_sweep(dev):
   """The device gradients against oracle/tape_reverse.py (float64, CPU oracle right-hand side) replaying the DEVICE's own accepted
   step sizes: independent of the float32 accept / reject decisions, so the bar is plain float32 rounding."""
@@ -211,7 +236,8 @@ def test_recorded_gradients_against_the_float64_reverse_sweep(dev):
 @pytest.mark.parametrize('name', [n for n in fixtures('train_') if 'midpoint' in n])
 def test_midpoint_method(dev, name):
   """run_GNN.py --method midpoint: evaluation on the native fixed-step solver (one hipGraph, two LINCOMB stages per step), training
-  through the host loop; both against the reference's block."""
+  on the recorded solve + reverse sweep (round 6; the host loop in test_fixed_grid_training_against_the_reference); both against the
+  reference's block."""
   fx = Fixture(name)
   block, x = _fixture_block(fx, dev)
   block.eval()
@@ -235,3 +261,127 @@ def test_midpoint_method(dev, name):
   assert_parity(xin.grad, fx.t('grad_x'), 2e-4, name + ' grad_x')
   refs = {k[5:]: fx.t(k) for k in fx.arr if k.startswith('grad/')}
   _module_scaled(dict((k, p.grad) for k, p in block.named_parameters()), refs, 2e-4, name)
+
+
+# ---- round 6: fixed-grid training without the adjoint method = recorded native solve + native reverse sweep -------------------
+FIXED = [n for n in fixtures('train_') if 'dopri5' not in n]
+
+
+@pytest.mark.parametrize('name', FIXED)
+@pytest.mark.parametrize('host_loop', [False, True])
+def test_fixed_grid_training_against_the_reference(dev, name, host_loop):
+  """`run_GNN.py --method rk4 / euler / midpoint` with the adjoint off (the reference's default): output, evaluation count and every
+  gradient of the reference's own block (torch autograd through the restated torchdiffeq fixed-grid loop), on the recorded native solve
+  + reverse sweep (csrc/solver.hip gnpde_solver_set_tape, csrc/adjoint.hip gnpde_adjoint_set_tape) and on the host loop."""
+  fx = Fixture(name)
+  assert len(FIXED) >= 8
+  block, x = _fixture_block(fx, dev, gnpde_host_fixed_training=host_loop)
+  block.train()
+  assert block.train_integrator is G.odeint
+  xin = x.clone().requires_grad_(True)
+  block.set_x0(xin)
+  z = block(xin)
+  assert z.requires_grad
+  f = block.odefunc
+  recorded = str(getattr(f, '_last_train_solve', '')).startswith('native recorded fixed-grid')
+  assert recorded == (not host_loop), 'solve path: %s' % getattr(f, '_last_train_solve', None)
+  assert f.nfe == int(fx.arr['nfe']), 'nfe %d vs reference %d' % (f.nfe, int(fx.arr['nfe']))
+  assert_parity(z, fx.t('z'), 1e-5, name + ' z')
+  (z * fx.t('c', dev)).sum().backward()
+  assert f.nfe == int(fx.arr['nfe_after_backward'])        # the reference's backward evaluates nothing either
+  gtol = 2e-4
+  assert_parity(xin.grad, fx.t('grad_x'), gtol, name + ' grad_x')
+  refs = {k[5:]: fx.t(k) for k in fx.arr if k.startswith('grad/')}
+  grads = dict((k, p.grad) for k, p in block.named_parameters())
+  _module_scaled(grads, refs, gtol, name)
+  for k, p in block.named_parameters():
+    if k not in refs:
+      assert p.grad is None or float(p.grad.abs().max()) == 0.0, '%s received a gradient the reference does not produce' % k
+
+
+def _fixed_block(dev, kind, block_kind, n, d, heads, A, seed, method, time, step_size=1.0, hubs=0, hub_deg=0, **over):
+  ei = random_graph(n, 5, seed=seed, hubs=hubs, hub_deg=hub_deg)
+  g = torch.Generator().manual_seed(seed)
+  x = torch.randn(n, d, generator=g)
+  opt = dict(OPT, hidden_dim=d, heads=heads, attention_dim=A, function=kind, block=block_kind, method=method, time=time, step_size=step_size, **over)
+  block = BLOCKS[block_kind](FUNCS[kind], [], opt, Data(x.to(dev), ei.to(dev)), dev, t=torch.tensor([0, time])).to(dev)
+  with torch.no_grad():
+    for p in block.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+      else:
+        p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(dev))
+  return block, x
+
+
+FIXED_CASES = {
+  # GRAND-nl at a Cora-like shape (A = 128 / 8 heads, squareplus over columns), rk4 with a short last step
+  'nl_cora_rk4': dict(kind='transformer', block_kind='constant', n=2485, d=80, heads=8, A=128, method='rk4', time=4.3,
+                      square_plus=True, attention_norm_idx=1),
+  # hub rows (512-entry chunks in the row kernel and in the attention backward)
+  'nl_hubs_rk4': dict(kind='transformer', block_kind='constant', n=1500, d=32, heads=4, A=16, method='rk4', time=3.0, hubs=2, hub_deg=700),
+  # a width that is not a multiple of 4 (padded rows), euler, no source term
+  'nl_d22_euler': dict(kind='transformer', block_kind='constant', n=600, d=22, heads=2, A=8, method='euler', time=2.5, step_size=0.5, add_source=False),
+  'nl_midpoint': dict(kind='transformer', block_kind='constant', n=700, d=64, heads=4, A=32, method='midpoint', time=2.2, step_size=0.4),
+  # GRAND-l under the attention block: the edge weights carry gradients into the attention layer
+  'l_attention_rk4_hubs': dict(kind='laplacian', block_kind='attention', n=1500, d=32, heads=4, A=16, method='rk4', time=3.5, hubs=2, hub_deg=700),
+  'l_attention_midpoint_d22': dict(kind='laplacian', block_kind='attention', n=600, d=22, heads=2, A=8, method='midpoint', time=2.0, step_size=0.5),
+  'l_constant_euler': dict(kind='laplacian', block_kind='constant', n=900, d=48, heads=4, A=16, method='euler', time=4.0),
+}
+
+
+@pytest.mark.parametrize('case', sorted(FIXED_CASES))
+def test_recorded_fixed_grid_equals_the_host_loop(dev, case):
+  """Same block, same weights: recorded solve + reverse sweep against the differentiable host loop over the kernel-backed autograd
+  Functions; a second recorded iteration replays both captured graphs and reproduces the first bit for bit."""
+  kw = dict(FIXED_CASES[case])
+  block, x = _fixed_block(dev, seed=61, **kw)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+  z1, gx1, g1, nfe1 = _train_once(block, x, dev, c)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded fixed-grid'), block.odefunc._last_train_solve
+  block.odefunc.opt['gnpde_host_fixed_training'] = True
+  block.reg_odefunc.odefunc.opt['gnpde_host_fixed_training'] = True
+  z2, gx2, g2, nfe2 = _train_once(block, x, dev, c)
+  assert nfe1 == nfe2, (nfe1, nfe2)
+  assert_parity(z1, z2, 1e-5, case + ' z')
+  assert_parity(gx1, gx2, 2e-4, case + ' grad_x')
+  refs = {k: v for k, v in g2.items() if v is not None}
+  assert refs, 'the host loop produced no parameter gradients'
+  _module_scaled(g1, refs, 2e-4, case)
+  block.odefunc.opt['gnpde_host_fixed_training'] = False
+  z3, gx3, g3, _ = _train_once(block, x, dev, c)
+  assert torch.equal(z1, z3) and torch.equal(gx1, gx3)
+  for k, v in g1.items():
+    if v is not None:
+      assert torch.equal(v, g3[k]), k
+
+
+def test_recorded_fixed_grid_on_the_relabelled_graph(dev):
+  """opt['gnpde_reorder'] = 'degree': forward and reverse sweep run on graph.LocalityView (nodes relabelled); output and gradients come
+  back in the caller's order and agree with the run on the graph as given."""
+  kw = dict(FIXED_CASES['nl_hubs_rk4'])
+  block, x = _fixed_block(dev, seed=62, **kw)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+  block.odefunc.opt['gnpde_reorder'] = '0'
+  z1, gx1, g1, _ = _train_once(block, x, dev, c)
+  block.odefunc.opt['gnpde_reorder'] = 'degree'
+  z2, gx2, g2, _ = _train_once(block, x, dev, c)
+  ent = next(iter(block.odefunc.__dict__['_fixed_tape_state'].values()))
+  assert ent['view'] is not None
+  assert_parity(z2, z1, 1e-6, 'z relabelled')
+  assert_parity(gx2, gx1, 2e-5, 'grad_x relabelled')
+  _module_scaled(g2, {k: v for k, v in g1.items() if v is not None}, 2e-5, 'relabelled')
+
+
+def test_fixed_grid_backward_after_a_later_forward_fails_loudly(dev):
+  block, x = _fixed_block(dev, seed=63, **FIXED_CASES['nl_d22_euler'])
+  block.train()
+  xa = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xa)
+  za = block(xa)
+  xb = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xb)
+  zb = block(xb)
+  zb.sum().backward()
+  with pytest.raises(G.GnpdeError):
+    za.sum().backward()
