@@ -83,6 +83,8 @@ def parse():
   ap.add_argument('--train', action='store_true',
                   help='training iteration instead of the inference solve: forward (tape-free native solver) + backward (native adjoint '
                        'solve, opt[adjoint] with adjoint_method rk4 / adjoint_step_size 1) of K steps each; prints its own JSON line')
+  ap.add_argument('--no-adjoint', action='store_true',
+                  help='with --train: opt[adjoint] off (run_GNN.py\'s default) -- recorded native solve + native reverse sweep, A/B against the host loop')
   ap.add_argument('--replays', type=int, default=5, help='timed launches of the K-step solve (median reported)')
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
@@ -1226,6 +1228,102 @@ def train_main(G, args, opt, cfg, ei, n, x, dev):
   print(json.dumps(out))
 
 
+def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
+  """`--train --no-adjoint`: one training iteration of the ODE block at the benchmark shape the way `run_GNN.py --function transformer
+  --block constant --method rk4` runs it by default (opt['adjoint'] off: reference run_GNN.py:336, src/base_classes.py:44-47 ->
+  torchdiffeq.odeint, loss.backward() through the solver loop).  Here: forward = the recorded native solve (the inference hipGraph with
+  every stage input written to a tape slot), backward = the native reverse sweep over the record (4 K VJP stages, one hipGraph);
+  A/B against this package's differentiable host loop over the kernel-backed autograd Functions (GNPDE_HOST_FIXED_TRAINING=1: what
+  ran before round 6).  K steps forward AND backward inside the timed region; loss = sum(z * c)."""
+  d, K, W = cfg['d'], args.steps, args.warmup
+  A, h = opt['attention_dim'], opt['heads']
+  topt = dict(opt, adjoint=False, time=float(K))
+  c = torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed + 3)).to(dev)
+
+  def measure(host_loop, replays):
+    block = make_block(G, dict(topt, gnpde_host_fixed_training=host_loop), ei, n, x, dev, float(K), args.seed)
+    block.train()
+
+    def iteration():
+      for p in block.parameters():
+        p.grad = None
+      xin = x.clone().requires_grad_(True)
+      block.set_x0(xin)
+      block.odefunc.nfe = 0
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      z = block(xin)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      (z * c).sum().backward()
+      torch.cuda.synchronize()
+      t2 = time.perf_counter()
+      return t1 - t0, t2 - t1, xin.grad, z.detach()
+
+    for _ in range(max(W, 2) if not host_loop else 1):
+      iteration()
+    runs = [iteration() for _ in range(max(replays, 1))]
+    fw = sorted(r[0] for r in runs)[len(runs) // 2]
+    bw = sorted(r[1] for r in runs)[len(runs) // 2]
+    f = block.odefunc
+    grads = {k: p.grad.detach().clone() for k, p in block.named_parameters() if p.grad is not None}
+    res = dict(fw=fw, bw=bw, gx=runs[-1][2].clone(), z=runs[-1][3].clone(), grads=grads, nfe=f.nfe, path=getattr(f, '_last_train_solve', None),
+               E=int(f.edge_index.shape[1]))
+    del block, runs
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+  rec = measure(False, args.replays)
+  assert torch.isfinite(rec['gx']).all()
+  try:
+    host = measure(True, 1)
+  except Exception as exc:   # noqa: BLE001
+    host = {'error': repr(exc)[:300]}
+  E = rec['E']
+  agg = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n
+  # one VJP stage of the reverse sweep moves what an adjoint stage moves (train_main) less the state-side stage output
+  stage_bytes = (agg + 4 * E + 4 * d * n - 4 * d * n) + agg + n * (4 * d + 8 * A) + (E * (4 + 4 * A + 4) + n * (16 + 4 * A)) \
+      + (E * (4 + 4 + 4 * A + 4 * h) + n * (16 + 4 * A)) + (2 * (E * (4 + 4 * h + 4 * A) + n * (16 + 4 * A)) + E * 4) + n * (8 * A + 4 * d) + E * 12 + n * (8 * A + 4 * d)
+  t_stage = rec['bw'] / (4 * K)
+  parity = None
+  if 'error' not in host:
+    from oracle import restate as R
+    gi, g2 = R.parity_error(rec['gx'], host['gx'])
+    zi, z2 = R.parity_error(rec['z'], host['z'])
+    worst = 0.0
+    for k, v in host['grads'].items():
+      if k in rec['grads']:
+        scale = float(v.abs().max())
+        if scale > 0:
+          worst = max(worst, float((rec['grads'][k] - v).abs().max()) / scale)
+    parity = {'grad_x_rel_max': gi, 'grad_x_rel_l2': g2, 'z_rel_max': zi, 'parameter_gradients_rel_max': worst, 'nfe_equal': rec['nfe'] == host['nfe']}
+  out = {
+    'metric': 'training steps/sec WITHOUT the adjoint method (forward + loss.backward() through the solver), %s d=%d rk4' % (GRAPH_NAMES.get(args.graph, args.graph), d),
+    'value': round(K / (rec['fw'] + rec['bw']), 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
+    'ms_per_step': round(1e3 * (rec['fw'] + rec['bw']) / K, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+    'dtype': 'f32', 'data': 'synthetic',
+    'config': {'workload': workload_name(args.graph, args.function, K, args.method) + '; TRAINING with opt[adjoint] off: recorded solve + native reverse sweep',
+               'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h, 'adjoint': False,
+               'tape_bytes': (4 * K + 1) * n * d * 4},
+    'train_solve_path': rec['path'],
+    'forward_ms': round(1e3 * rec['fw'], 3), 'backward_ms': round(1e3 * rec['bw'], 3), 'vjp_stage_ms': round(1e3 * t_stage, 4),
+    'rhs_evals_forward': rec['nfe'],
+    'host_loop': host if 'error' in host else {
+      'forward_ms': round(1e3 * host['fw'], 3), 'backward_ms': round(1e3 * host['bw'], 3), 'path': host['path'] or 'differentiable host loop (odeint._solve_fixed_host)',
+      'steps_per_s': round(K / (host['fw'] + host['bw']), 3)},
+    'speedup_vs_host_loop': None if 'error' in host else round((host['fw'] + host['bw']) / (rec['fw'] + rec['bw']), 2),
+    'parity_vs_host_loop': parity,
+    'roofline': {'kernel': 'one VJP stage of the reverse sweep (projection, row attention, adjoint row kernel, normaliser backward, d q / d k, P, transposed aggregation, Gram)',
+                 'bound': 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4), 'frac_algorithmic': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'traffic': None, 'algorithmic_bytes_per_stage': stage_bytes},
+    'cpu_baseline': None,
+  }
+  print(json.dumps(out))
+
+
 CONFIG_CHILDREN = (
   # (key, BASELINE.json reference, flags, timeout s).  Every child is this script in another mode and prints its own full JSON line;
   # the parent keeps a summary.  Ordered so that the cheap ones are never starved by the expensive ones.
@@ -1245,6 +1343,8 @@ CONFIG_CHILDREN = (
    ['--config', 'coauthor-adjoint'], 200),
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
    ['--train', '--steps', '10', '--warmup', '2'], 400),
+  ('c3_training_iteration_adjoint_off', 'configs[2] shape, TRAINING as run_GNN.py runs rk4 by default (adjoint off): recorded solve + native reverse sweep, host-loop A/B',
+   ['--train', '--no-adjoint', '--steps', '10', '--warmup', '2'], 300),
   ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
    ['--config', 'c4', '--warmup', '2'], 400),
   ('c3_normalised_over_columns_squareplus', 'configs[2] shape with attention_norm_idx 1 + squareplus (the reference\'s Cora / Citeseer normaliser at scale)',
@@ -1254,7 +1354,7 @@ CONFIG_CHILDREN = (
   ('c3_arxiv_relabelling_off', 'configs[2] with the node relabelling switched off (GNPDE_REORDER=0)',
    ['--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--no-cpu-baseline'], 200),
   ('c5_rmat_one_gpu', 'configs[4] shape on ONE GPU: R-MAT 2^21 nodes, d = 256 (the 8-GPU run is the driver\'s)',
-   ['--graph', 'rmat', '--steps', '4', '--warmup', '1', '--no-live-pmc', '--no-hbm-probe'], 900),
+   ['--graph', 'rmat', '--steps', '4', '--warmup', '1', '--no-hbm-probe'], 900),
 )
 
 
@@ -1382,7 +1482,8 @@ def summarise_child(line):
   for k in ('parity_vs_oracle_one_eval', 'parity_vs_restated_torchdiffeq', 'parity_vs_oracle_row_subset', 'parity_vjp_one_eval_vs_oracle', 'speedup_vs_cpu',
             'ms_per_forward', 'ms_solve_only', 'rhs_evals_per_forward', 'dopri5', 'forward_ms', 'backward_ms', 'f_plus_vjp_ms', 'flat_host_loop',
             'backward_speedup_vs_flat_host_loop', 'parity_vs_flat_host_loop', 'evals_forward', 'augmented_evals_backward', 'ms_train_step', 'ms_test_step',
-            'ms_train_phases_synchronised', 'nfe_forward_per_epoch', 'nfe_backward_per_epoch', 'nfe_test_per_epoch', 'train_solve_path', 'timing'):
+            'ms_train_phases_synchronised', 'nfe_forward_per_epoch', 'nfe_backward_per_epoch', 'nfe_test_per_epoch', 'train_solve_path', 'timing',
+            'host_loop', 'speedup_vs_host_loop', 'vjp_stage_ms'):
     if k in line:
       v = line[k]
       if isinstance(v, dict) and 'what' in v:
@@ -1511,6 +1612,8 @@ def main():
     return
   if args.train:
     del main_block
+    if args.no_adjoint:
+      return train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev)
     return train_main(G, args, opt, cfg, ei, n, x, dev)
   early = None
   if args.early_stop:
@@ -1590,7 +1693,7 @@ def main():
   # ---- counter traffic: live PMC passes over a child of this script; the stored record only as a marked fallback ----
   now_hash = kernel_sources_sha16()
   traffic, traffic_src = None, None
-  pmc = None if (args.no_live_pmc or fused) else live_pmc_traffic(args, reorder_mode)
+  pmc = None if (args.no_live_pmc or fused) else live_pmc_traffic(args, reorder_mode, timeout_s=150 if args.graph != 'rmat' else 420)
   if isinstance(pmc, dict) and 'error' not in pmc and pmc.get('_calls'):
     agg = traffic_of(pmc, 'spmm_', pmc['_calls']['aggregation_calls'])
     if agg is not None:
@@ -1641,7 +1744,9 @@ def main():
   #                      without any counter record, frac_algorithmic in both cases -- never a ceiling of our own making.
   frac_alg = achieved / HBM_PEAK_GBS
   frac_traffic = None if traffic is None else traffic / t_spmm / 1e9 / HBM_PEAK_GBS
-  use_traffic = resident and frac_traffic is not None and not traffic_src.get('stale', True)
+  # (a live counter record is the physical figure for a DRAM-resident table as well: there the gather model credits no reuse of the hub
+  #  columns, which are L2 hits, and exceeds what crossed the fabric)
+  use_traffic = frac_traffic is not None and not traffic_src.get('stale', True) and (resident or bool(traffic_src.get('live')))
   try:
     hbm_probe = None if args.no_hbm_probe else hbm_bound_probe(G, dev)
   except Exception as exc:   # noqa: BLE001
@@ -1674,6 +1779,8 @@ def main():
                  'frac_is': ('frac_traffic: L2 -> fabric bytes of one aggregation call (counter record, `traffic`; includes Infinity-Cache hits) / '
                              'its duration / the 8 TB/s HBM peak -- the gathered table (%.0f MiB) is resident in the 256-MiB Infinity Cache, so '
                              'the gather model (`achieved`, `frac_algorithmic`) charges cache-served rows to HBM and exceeds the peak' % state_mb)
+                 if use_traffic and resident else ('frac_traffic: L2 -> fabric bytes of one aggregation call (live counter passes of this run) / its duration / '
+                                                   'the 8 TB/s HBM peak; the %.0f-MiB table does not fit the Infinity Cache: DRAM-bound' % state_mb)
                  if use_traffic else ('null: the gathered table is cache-resident and this run has no live counter traffic (see frac_algorithmic, '
                                       'which exceeds 1 by construction there)' if resident else
                                       'null: the gather model (frac_algorithmic) exceeds the peak -- it credits no reuse, and the hub columns of this '

@@ -28,6 +28,9 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
+int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s, float* inv_out = nullptr);
+int launch_normalise_heads_bwd(const float* out, float* g, long long n, int ld, int att_dim, int heads, bool centre, const float* inv, hipStream_t s);
+bool normalise_heads_bwd_supported(int att_dim, int heads);
 
 namespace {
 
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* 
 // Block = 64 outputs x 4 slices of the slabs, slices folded through the LDS in order.
 __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float* __restrict__ partial, int nb, int stride, int n_plain,
                                                                    float coef, const float* __restrict__ alpha,
-                                                                   const float* __restrict__ beta, int has_source,
+                                                                   const float* __restrict__ beta, int has_source, int alpha_sigmoid,
                                                                    float* __restrict__ grads) {
   constexpr int OUTS = 32, SL = kBlock / OUTS;
   __shared__ float part[SL][OUTS][2];
@@ -301,6 +304,11 @@ __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float*
     grads[idx] = fmaf(coef, s1, grads[idx]);
     return;
   }
+  if (!alpha_sigmoid) {        // opt['no_alpha_sigmoid']: alpha' = alpha_train, and the row kernel summed u_a . (A u - u) itself
+    grads[n_plain] = fmaf(coef, s1, grads[n_plain]);
+    grads[n_plain + 1] = fmaf(coef, has_source ? s2 : 0.f, grads[n_plain + 1]);
+    return;
+  }
   const float a = *alpha;
   const float sig = 1.0f / (1.0f + expf(-a));
   const float b = has_source ? *beta : 0.f;
@@ -331,7 +339,8 @@ struct gnpde_adjoint {
   size_t ws_bytes;
   // workspace regions
   size_t state_bytes;
-  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots, *hub_ws;
+  float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots, *hub_ws, *qk_inv;
+  int unit_heads = 0;        // 1: cosine_sim, 2: pearson -- scores are the scaled dot product of normalised (mean-centred) head vectors
   int n_dots;
   char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
   size_t att_bytes, attbwd_bytes, spmm_bytes, spmm_t_bytes;
@@ -352,7 +361,7 @@ struct gnpde_adjoint {
 namespace {
 
 bool rows_bwd_shape(const gnpde_attention_t& at) {
-  if (at.type != GNPDE_ATT_SCALED_DOT || at.norm_idx != 0 || at.square_plus) return false;
+  if ((at.type != GNPDE_ATT_SCALED_DOT && at.type != GNPDE_ATT_COSINE && at.type != GNPDE_ATT_PEARSON) || at.norm_idx != 0 || at.square_plus) return false;
   const int h = at.heads, dk = at.att_dim / at.heads;
   return (h == 1 || h == 2 || h == 4 || h == 8) && (dk == 4 || dk == 8 || dk == 16);
 }
@@ -366,7 +375,6 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
                   "adjoint: bad method %d", method);     // (midpoint: as the reverse sweep of a recorded solve only)
   GNPDE_CHECK_ARG(rhs->kind == GNPDE_RHS_LAPLACIAN || rhs->kind == GNPDE_RHS_TRANSFORMER, GNPDE_ESHAPE,
                   "adjoint: GRAND-l and GRAND-nl (scaled-dot) only");
-  GNPDE_CHECK_ARG(rhs->alpha_sigmoid == 1, GNPDE_ESHAPE, "adjoint: the native solve needs alpha' = sigmoid(alpha_train)");
   GNPDE_CHECK_ARG(rhs->ld % 4 == 0 && rhs->d <= 256 && (rhs->d % 4 == 0 || (rhs->flags & GNPDE_RHS_PADDED_ROWS)), GNPDE_ESHAPE,
                   "adjoint: state rows of up to 256 floats in 16-byte lanes (d %% 4 == 0 or padded rows)");
   GNPDE_CHECK_ARG(rhs->n_state_rows <= rhs->graph->n && rhs->proj_row_end == 0 && rhs->graph->row_begin == 0, GNPDE_ESHAPE,
@@ -374,7 +382,10 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
   if (rhs->kind == GNPDE_RHS_TRANSFORMER) {
     const gnpde_attention_t& at = rhs->att;
     const int a4 = at.att_dim / 4;
-    GNPDE_CHECK_ARG(at.type == GNPDE_ATT_SCALED_DOT, GNPDE_ESHAPE, "adjoint: scaled-dot scores only");
+    const bool unit = at.type == GNPDE_ATT_COSINE || at.type == GNPDE_ATT_PEARSON;
+    GNPDE_CHECK_ARG(at.type == GNPDE_ATT_SCALED_DOT || unit, GNPDE_ESHAPE, "adjoint: scaled-dot, cosine_sim and pearson scores");
+    GNPDE_CHECK_ARG(!unit || (at.heads >= 1 && normalise_heads_bwd_supported(at.att_dim, at.heads)), GNPDE_ESHAPE,
+                    "adjoint: cosine_sim / pearson need d_k in {4, 8, 16}");
     GNPDE_CHECK_ARG(at.att_dim % at.heads == 0 && (at.att_dim / at.heads) % 4 == 0 && a4 <= 64 && (a4 & (a4 - 1)) == 0, GNPDE_ESHAPE,
                     "adjoint: attention_dim / 4 must be a power of two <= 64 and d_k a multiple of 4");
   }
@@ -388,7 +399,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   const int M = nl ? r.proj_m : 0;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
-  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0, o_hub = 0;
+  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0, o_hub = 0, o_inv = 0;
   for (int i = 0; i < 2; ++i) { o_uy[i] = take(state); o_ua[i] = take(state); }
   const int nF = method == GNPDE_METHOD_RK4 ? 1 : 0, nV = method == GNPDE_METHOD_RK4 ? 1 : 0;     // (u4 of the state / of the adjoint)
   for (int i = 0; i < 4; ++i) o_F[i] = i < nF ? take(state) : 0;
@@ -404,6 +415,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     o_qk = take(static_cast<size_t>(g.n) * M * 4);
     o_dqk = take(static_cast<size_t>(g.n) * M * 4);
     o_w = take(e4); o_wt = take(e4);
+    o_inv = take(static_cast<size_t>(g.n) * 2 * r.att.heads * 4);
     o_ds = take(e4 * r.att.heads);
     const size_t hub_f = hub_bwd_workspace_floats(&g, r.att.heads, r.att.att_dim), hub_ft = hub_bwd_workspace_floats(&gt, r.att.heads, r.att.att_dim);
     o_hub = take((hub_f > hub_ft ? hub_f : hub_ft) * 4 + 256);
@@ -426,6 +438,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = f(o_r); s->ds = nl ? f(o_ds) : nullptr;
     s->dots = f(o_dots); s->n_dots = n_dots;
     s->hub_ws = nl ? f(o_hub) : nullptr;
+    s->qk_inv = nl ? f(o_inv) : nullptr;
     s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
     s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
     s->partial = f(o_part);
@@ -453,6 +466,13 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     rc = launch_linear_any(uy, n, d, ld, r.proj_w, M, d, r.proj_b, s->qk, M, st);
     if (rc) return rc;
     at.q = s->qk; at.k = s->qk + A; at.ldqk = M;
+    if (s->unit_heads) {
+      // cosine_sim / pearson (reference src/function_transformer_attention.py:197-206) = the scaled dot product of unit (mean-centred) head
+      // vectors, as in the forward solver (csrc/solver.hip enqueue_rhs): normalised in place, the scale of every vector kept for the backward
+      rc = launch_normalise_heads(s->qk, n, M, A, at.heads, s->unit_heads == 2, st, s->qk_inv);
+      if (rc) return rc;
+      at.type = GNPDE_ATT_SCALED_DOT;
+    }
     rc = launch_edge_attention(g, &at, s->w, nullptr, nullptr, s->ws_att, s->att_bytes, st, nullptr);
     if (rc) return rc;
     w = s->w;
@@ -488,6 +508,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
       rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
       if (rc) return rc;
       rc = gnpde_head_spmm(g, 1, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+      if (rc) return rc;
+    }
+    if (s->unit_heads) {         // through the normalisation: d (q||k) from the gradient of the unit vectors, in place
+      rc = launch_normalise_heads_bwd(s->qk, s->dqk, n, M, A, h, s->unit_heads == 2, s->qk_inv, st);
       if (rc) return rc;
     }
     rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
@@ -539,7 +563,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   GNPDE_LAUNCH_CHECK();
   const int n_plain = M * d + M;
   hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 31) / 32), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
-                     pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, grads);
+                     pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, r.alpha_sigmoid, grads);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -716,6 +740,8 @@ extern "C" int gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rh
   s->method = method;
   s->dts.assign(dts, dts + n_steps);
   s->rows_bwd = rhs->kind == GNPDE_RHS_TRANSFORMER && rows_bwd_shape(rhs->att) && rhs->proj_m % 4 == 0;
+  if (rhs->kind == GNPDE_RHS_TRANSFORMER)
+    s->unit_heads = rhs->att.type == GNPDE_ATT_COSINE ? 1 : rhs->att.type == GNPDE_ATT_PEARSON ? 2 : 0;
   const size_t need = adjoint_layout(s->rhs, s->graph_t, method, nullptr);
   if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
     set_error("adjoint_create: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);

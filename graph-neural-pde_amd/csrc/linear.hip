@@ -374,6 +374,136 @@ __global__ __launch_bounds__(kBlock) void linear_staged_kernel(const float* __re
   }
 }
 
+// Round 6 variants of the staged kernel for the q||k projection shape (MT = 2: m = 32 output columns), selected by
+// gnpde_tune(8, 6 | 7 | 8) for A/B runs and by default where they measured faster:
+//   PAIRC  column tile t of lane r is output column 2 r + t, so a lane's two accumulators of an output row are ADJACENT columns and leave
+//          as one 8-byte store: a store instruction writes four complete 128-byte output rows (the kernel above writes every output
+//          line as two 64-byte halves by two different instructions);
+//   DEPTH2 two row tiles of x in flight per wave (registers) instead of one.
+// Same MFMA sequence and k order per output element: bit-identical results.
+template <int KB, bool PAIRC, bool DEPTH2, int DIAG = 0>
+__global__ __launch_bounds__(kBlock) void linear_staged2_kernel(const float* __restrict__ x, int n, int ldx,
+                                                                const float* __restrict__ W, int ldw,
+                                                                const float* __restrict__ b, float* __restrict__ out,
+                                                                int ldo, int col_base, int relu) {
+  // DIAG (A/B diagnostics, gnpde_tune(13, v)): 1 = no output stores (unless a result is NaN), 2 = no LDS / MFMA work (the loads alone)
+  constexpr int diag = DIAG;
+  constexpr int MT = 2;
+  constexpr int CPR = KB * 4;
+  constexpr int CHUNKS = 16 * CPR;
+  constexpr int PER_LANE = CHUNKS / kWave;
+  __shared__ f32x4 slab[kWavesPerBlock][CHUNKS];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const long long n_tiles = (static_cast<long long>(n) + 15) / 16;
+  const long long stride = static_cast<long long>(gridDim.x) * kWavesPerBlock;
+  long long tile = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
+  if (tile >= n_tiles) return;
+
+  int wcol[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) wcol[t] = col_base + (PAIRC ? 2 * r + t : t * 16 + r);
+  f32x4 bv[KB][MT];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const float4 tb = *reinterpret_cast<const float4*>(W + static_cast<size_t>(wcol[t]) * ldw + 16 * u + 4 * kq);
+      bv[u][t] = f32x4{tb.x, tb.y, tb.z, tb.w};
+    }
+  float bias[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) bias[t] = b != nullptr ? b[wcol[t]] : 0.0f;
+
+  // chunk c = it * 64 + lane of a tile: row c / CPR = it * (64 / CPR) + lane / CPR, column chunk j = lane % CPR (CPR = 16 or 32 divides 64):
+  // one per-lane offset, the rest are compile-time multiples of the row stride
+  constexpr int RPI = kWave / CPR;               // rows per load instruction
+  const int lr = lane / CPR, j = lane % CPR;
+  auto load_tile = [&](long long tl, f32x4 (&g)[PER_LANE]) {
+    const long long row0 = tl * 16;
+    const int rmax = static_cast<int>(n - 1 - row0 < 15 ? n - 1 - row0 : 15);       // (wave-uniform) ragged last tile: clamp reads, mask writes
+    const float* base = x + static_cast<size_t>(row0) * ldx + 4 * j;
+#pragma unroll
+    for (int it = 0; it < PER_LANE; ++it) {
+      const int rr = it * RPI + lr;
+      g[it] = *reinterpret_cast<const f32x4*>(base + static_cast<size_t>(rr < rmax ? rr : rmax) * ldx);
+    }
+  };
+  f32x4* my = slab[wave];
+  auto consume = [&](long long tl, const f32x4 (&g)[PER_LANE]) {
+#pragma unroll
+    for (int it = 0; it < PER_LANE; ++it) {
+      const int rr = it * RPI + lr;
+      if (diag == 2) { if (g[it][0] != g[it][0]) out[lane] = g[it][1]; continue; }
+      my[rr * CPR + (j ^ (rr & 7))] = g[it];
+    }
+  };
+  auto compute = [&](long long tl) {
+    if (diag == 2) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KB; u += 2) {
+      f32x4 cu[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cu[q] = relu_if(my[r * CPR + ((4 * (u + q) + kq) ^ (r & 7))], relu);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[q][i], bv[u + q][t][i], acc[t], 0, 0, 0);
+    }
+    const long long row0 = tl * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long orow = row0 + 4 * kq + i;
+      if (orow < n && (diag != 1 || acc[0][i] != acc[0][i])) {
+        if constexpr (PAIRC) {
+          *reinterpret_cast<float2*>(out + static_cast<size_t>(orow) * ldo + col_base + 2 * r) = make_float2(acc[0][i] + bias[0], acc[1][i] + bias[1]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) out[static_cast<size_t>(orow) * ldo + wcol[t]] = acc[t][i] + bias[t];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();           // the fragment reads above precede the next tile's slab writes
+  };
+  if constexpr (!DEPTH2) {
+    f32x4 g[PER_LANE];
+    load_tile(tile, g);
+    while (true) {
+      consume(tile, g);
+      const long long next = tile + stride;
+      const bool more = next < n_tiles;
+      if (more) load_tile(next, g);
+      compute(tile);
+      if (!more) break;
+      tile = next;
+    }
+  } else {
+    f32x4 ga[PER_LANE], gb[PER_LANE];
+    load_tile(tile, ga);
+    if (tile + stride < n_tiles) load_tile(tile + stride, gb);
+    while (true) {
+      consume(tile, ga);
+      if (tile + 2 * stride < n_tiles) load_tile(tile + 2 * stride, ga);
+      compute(tile);
+      tile += stride;
+      if (tile >= n_tiles) break;
+      consume(tile, gb);
+      if (tile + 2 * stride < n_tiles) load_tile(tile + 2 * stride, gb);
+      compute(tile);
+      tile += stride;
+      if (tile >= n_tiles) break;
+    }
+  }
+}
+
 template <int MT, bool ALIGNED>
 void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                  int ldo, int col, hipStream_t s, int relu) {
@@ -391,7 +521,27 @@ void launch_tile(const float* x, int n, int d, int ldx, const float* W, int m, i
       // d = 64 / 128 (4 or 8 chunks per lane and tile): full-line loads transposed through LDS (linear_staged_kernel);
       // gnpde_tune(8, 2) keeps the fragment-shaped loads for A/B runs
       if ((d == 128 || d == 64) && g_tune[GNPDE_TUNE_LINEAR_STREAMING] != 2) {
-        const int variant = g_tune[GNPDE_TUNE_LINEAR_STREAMING] >= 3 ? g_tune[GNPDE_TUNE_LINEAR_STREAMING] - 2 : 0;     // 3 / 4 / 5 -> 1 / 2 / 3
+        const int knob = g_tune[GNPDE_TUNE_LINEAR_STREAMING];
+        if constexpr (MT == 2) {
+          if ((knob == 0 || (knob >= 6 && knob <= 11)) && ldo % 2 == 0 && col % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0) {
+            // 0 (default since round 6) = 9: paired columns on a grid of 4 workgroups per CU (3 resident: the fourth starts as one ends) --
+            // 24.4 -> 24.0 us in the headline solve, 26.9 -> 25.8 us stand-alone (profiles/r06_linear_ab.txt); 6: paired columns;
+            // 7: two tiles in flight; 8: both; 10 / 11: 7 / 8 on grids of 4 / 2 workgroups per CU; 12: the round-3 kernel
+            long long pg2 = (knob == 0 || knob >= 9) ? 256LL * (knob == 11 ? 2 : 4) : blocks;
+            if (pg2 > need) pg2 = need;
+            const unsigned g2 = static_cast<unsigned>(pg2);
+            const int kv = knob == 0 ? 6 : (knob >= 9 ? knob - 3 : knob);
+#define GNPDE_LS2(KBV, PC, D2) hipLaunchKernelGGL((linear_staged2_kernel<KBV, PC, D2>), dim3(g2), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu)
+            const int diag = g_tune[GNPDE_TUNE_LINEAR_DIAG];
+            if (d == 128 && diag == 1) hipLaunchKernelGGL((linear_staged2_kernel<8, true, false, 1>), dim3(g2), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+            else if (d == 128 && diag == 2) hipLaunchKernelGGL((linear_staged2_kernel<8, true, false, 2>), dim3(g2), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu);
+            else if (d == 128) { if (kv == 6) GNPDE_LS2(8, true, false); else if (kv == 7) GNPDE_LS2(8, false, true); else GNPDE_LS2(8, true, true); }
+            else { if (kv == 6) GNPDE_LS2(4, true, false); else if (kv == 7) GNPDE_LS2(4, false, true); else GNPDE_LS2(4, true, true); }
+#undef GNPDE_LS2
+            return;
+          }
+        }
+        const int variant = knob >= 3 && knob <= 5 ? knob - 2 : 0;     // 3 / 4 / 5 -> 1 / 2 / 3
         if (d == 128)
           hipLaunchKernelGGL((linear_staged_kernel<MT, 8>), dim3(pg), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out, ldo, col, relu, variant);
         else

@@ -425,7 +425,7 @@ namespace {
 // the same with the head vector in registers (d_k = 4 DK4, 16-byte aligned rows): one 16-byte load and store per 4 columns
 template <int DK4>
 __global__ __launch_bounds__(kBlock) void normalise_heads_vec_kernel(float* __restrict__ qk, long long n, int ld, int att_dim, int heads,
-                                                                    int centre, float q_scale) {
+                                                                    int centre, float q_scale, float* __restrict__ inv_out) {
   constexpr int DK = 4 * DK4;
   const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (idx >= n * 2 * heads) return;
@@ -449,25 +449,94 @@ __global__ __launch_bounds__(kBlock) void normalise_heads_vec_kernel(float* __re
     nn = fmaf(x[j].x, x[j].x, nn); nn = fmaf(x[j].y, x[j].y, nn); nn = fmaf(x[j].z, x[j].z, nn); nn = fmaf(x[j].w, x[j].w, nn);
   }
   const float inv = (side == 0 ? q_scale : 1.0f) / fmaxf(sqrtf(nn), 1e-5f);      // (as the scalar kernel above)
+  if (inv_out != nullptr) inv_out[idx] = sqrtf(nn) >= 1e-5f ? inv : -inv;       // (negative: the clamp was active -- no projection term in the backward)
 #pragma unroll
   for (int j = 0; j < DK4; ++j) v[j] = make_float4(x[j].x * inv, x[j].y * inv, x[j].z * inv, x[j].w * inv);
+}
+
+// Backward of the normalisation above, in place on the gradient g = dL/d(out) of the SAME table layout: with out = s c / max(|c|, eps),
+// c = v - mean (centre) or v, s = sqrt(d_k) on the query side:
+//     dL/dc = inv (g - out (out . g) / s^2)      (|c| >= eps;  inv g where the clamp was active),      dL/dv = dL/dc - mean(dL/dc) (centre)
+// (torch autograd through F.cosine_similarity of the mean-centred head vectors, reference src/function_transformer_attention.py:197-206).
+template <int DK4>
+__global__ __launch_bounds__(kBlock) void normalise_heads_bwd_kernel(const float* __restrict__ out, float* __restrict__ g, long long n, int ld,
+                                                                    int att_dim, int heads, int centre, float q_scale,
+                                                                    const float* __restrict__ inv_in) {
+  constexpr int DK = 4 * DK4;
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n * 2 * heads) return;
+  const int head = static_cast<int>(idx % heads);
+  const int side = static_cast<int>((idx / heads) % 2);
+  const long long row = idx / (2 * heads);
+  const size_t off = row * ld + side * att_dim + head * DK;
+  const float4* o4 = reinterpret_cast<const float4*>(out + off);
+  float4* g4 = reinterpret_cast<float4*>(g + off);
+  float o[DK], gg[DK];
+#pragma unroll
+  for (int j = 0; j < DK4; ++j) {
+    const float4 a = o4[j], b = g4[j];
+    o[4 * j] = a.x; o[4 * j + 1] = a.y; o[4 * j + 2] = a.z; o[4 * j + 3] = a.w;
+    gg[4 * j] = b.x; gg[4 * j + 1] = b.y; gg[4 * j + 2] = b.z; gg[4 * j + 3] = b.w;
+  }
+  const float inv_s = inv_in[idx];
+  const float inv = fabsf(inv_s);
+  const float s2 = side == 0 ? q_scale * q_scale : 1.0f;
+  float dot = 0.f;
+  if (inv_s > 0.f) {
+#pragma unroll
+    for (int j = 0; j < DK; ++j) dot = fmaf(o[j], gg[j], dot);
+    dot = dot / s2;
+  }
+  float mean = 0.f;
+#pragma unroll
+  for (int j = 0; j < DK; ++j) {
+    gg[j] = inv * (gg[j] - o[j] * dot);
+    mean += gg[j];
+  }
+  mean = centre ? mean / static_cast<float>(DK) : 0.f;
+#pragma unroll
+  for (int j = 0; j < DK4; ++j) g4[j] = make_float4(gg[4 * j] - mean, gg[4 * j + 1] - mean, gg[4 * j + 2] - mean, gg[4 * j + 3] - mean);
 }
 }  // namespace
 
 // cosine_sim / pearson scores as scaled-dot scores of normalised vectors (csrc/solver.hip enqueue_rhs): rows [0, n) of the q||k table
-int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s) {
+bool normalise_heads_bwd_supported(int att_dim, int heads) {
+  const int dk = heads > 0 ? att_dim / heads : 0;
+  return heads > 0 && att_dim % heads == 0 && (dk == 4 || dk == 8 || dk == 16);
+}
+
+// in place on g [n, ld] (the gradient of the normalised q||k table `out`); inv: what launch_normalise_heads recorded for the same rows
+int launch_normalise_heads_bwd(const float* out, float* g, long long n, int ld, int att_dim, int heads, bool centre, const float* inv,
+                               hipStream_t s) {
+  if (n <= 0) return 0;
+  GNPDE_CHECK_ARG(out && g && inv && normalise_heads_bwd_supported(att_dim, heads) && ld % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(g) % 16 == 0, GNPDE_ESHAPE,
+                  "normalise_heads_bwd: d_k in {4, 8, 16}, 16-byte aligned rows");
+  const int dk = att_dim / heads;
+  const long long items = n * 2 * heads;
+  const dim3 grid(static_cast<unsigned>((items + kBlock - 1) / kBlock));
+  const float qs = sqrtf(static_cast<float>(dk));
+  if (dk == 4) hipLaunchKernelGGL(normalise_heads_bwd_kernel<1>, grid, dim3(kBlock), 0, s, out, g, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv);
+  else if (dk == 8) hipLaunchKernelGGL(normalise_heads_bwd_kernel<2>, grid, dim3(kBlock), 0, s, out, g, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv);
+  else hipLaunchKernelGGL(normalise_heads_bwd_kernel<4>, grid, dim3(kBlock), 0, s, out, g, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s, float* inv_out) {
   if (n <= 0) return 0;
   const int dk = att_dim / heads;
   const long long items = n * 2 * heads;
   if (ld % 4 == 0 && reinterpret_cast<uintptr_t>(qk) % 16 == 0 && (dk == 4 || dk == 8 || dk == 16)) {
     const dim3 grid(static_cast<unsigned>((items + kBlock - 1) / kBlock));
     const float qs = sqrtf(static_cast<float>(dk));
-    if (dk == 4) hipLaunchKernelGGL(normalise_heads_vec_kernel<1>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
-    else if (dk == 8) hipLaunchKernelGGL(normalise_heads_vec_kernel<2>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
-    else hipLaunchKernelGGL(normalise_heads_vec_kernel<4>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs);
+    if (dk == 4) hipLaunchKernelGGL(normalise_heads_vec_kernel<1>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv_out);
+    else if (dk == 8) hipLaunchKernelGGL(normalise_heads_vec_kernel<2>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv_out);
+    else hipLaunchKernelGGL(normalise_heads_vec_kernel<4>, grid, dim3(kBlock), 0, s, qk, n, ld, att_dim, heads, centre ? 1 : 0, qs, inv_out);
     GNPDE_LAUNCH_CHECK();
     return 0;
   }
+  GNPDE_CHECK_ARG(inv_out == nullptr, GNPDE_ESHAPE, "normalise_heads: the recorded scale needs d_k in {4, 8, 16} and 16-byte aligned rows");
   hipLaunchKernelGGL(normalise_heads_kernel, dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, qk, n, ld, att_dim,
                      heads, centre ? 1 : 0, sqrtf(static_cast<float>(dk)));
   GNPDE_LAUNCH_CHECK();

@@ -17,7 +17,7 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
                       int ldo, hipStream_t s, int relu = 0);
 int launch_edge_attention(const gnpde_graph_t* g, const gnpde_attention_t* at, float* w_mean_csr, float* att_edge,
                           float* prods_edge, void* ws, size_t ws_bytes, hipStream_t stream, const Fork* fork);
-int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s);
+int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s, float* inv_out = nullptr);
 size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 size_t attention_workspace_bytes_rows(const gnpde_graph_t* g, int h, bool gat, int key_rows);
 size_t fused_attn_workspace_bytes(const gnpde_graph_t* g, int d, int heads);

@@ -1327,9 +1327,11 @@ __device__ __forceinline__ void adjoint_epilogue(const gnpde_epilogue_t& ep, flo
 #pragma unroll
     for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
   }
+  // d1: with alpha' = sigmoid(alpha_train) the dot with k (d alpha_train = (1 - sigma)(sum g . k - beta sum g . x0)); with the raw
+  // alpha (opt['no_alpha_sigmoid']) the dot with A u - u itself, which IS d k / d alpha_train
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    d1 = fmaf(gi[v] * cmask[v], k[v], d1);
+    d1 = fmaf(gi[v] * cmask[v], ep.alpha_sigmoid ? k[v] : ax[v] - ui[v], d1);
     d2 = fmaf(gi[v] * cmask[v], s[v], d2);
   }
   epilogue<VEC, true>(ep, alpha, beta, off, ax, ui);

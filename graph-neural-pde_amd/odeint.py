@@ -600,6 +600,20 @@ def _solve_dopri5_recorded(func, y0, t, rtol, atol):
 # transformer --block constant --method rk4` (reference run_GNN.py:336 `--adjoint` is store_true, base_classes.py:44-47 then picks
 # torchdiffeq.odeint and loss.backward() runs through its Python loop, run_GNN.py:62-96)
 # --------------------------------------------------------------------------------------------------
+def _transformer_stage_native(func):
+  """GRAND-nl per-evaluation attention the native VJP stage of csrc/adjoint.hip covers: scaled-dot scores, and (round 6) cosine_sim /
+  pearson -- the scaled dot product of unit (mean-centred) head vectors, d_k in {4, 8, 16} -- with any normaliser."""
+  lay, opt = func.multihead_att_layer, func.opt
+  a4 = lay.attention_dim // 4
+  if opt['mix_features'] or getattr(lay, 'split_kernel', False):
+    return False
+  if not (lay.d_k % 4 == 0 and lay.attention_dim % 4 == 0 and a4 <= 64 and (a4 & (a4 - 1)) == 0):
+    return False
+  if opt['attention_type'] == 'scaled_dot':
+    return True
+  return opt['attention_type'] in ('cosine_sim', 'pearson') and lay.d_k in (4, 8, 16)
+
+
 def _recorded_fixed_ok(func, y0, t, method):
   """The differentiated fixed-grid solve runs as ONE recorded native solve (csrc/solver.hip, gnpde_solver_set_tape: the captured
   hipGraph of the inference solve with every stage input written to a slot of its own) + ONE native reverse sweep over the record
@@ -611,7 +625,7 @@ def _recorded_fixed_ok(func, y0, t, method):
   if not (y0.is_cuda and y0.dim() == 2 and y0.dtype == torch.float32 and y0.shape[1] <= 256 and len(t) == 2):
     return False
   opt = func.opt
-  if opt.get('no_alpha_sigmoid') or opt.get('gnpde_composite_backward') or opt.get('gnpde_host_fixed_training') or opt.get('gnpde_shard'):
+  if opt.get('gnpde_composite_backward') or opt.get('gnpde_host_fixed_training') or opt.get('gnpde_shard'):
     return False
   if os.environ.get('GNPDE_HOST_FIXED_TRAINING', '0') == '1':      # A/B runs (bench.py --train --no-adjoint)
     return False
@@ -621,9 +635,7 @@ def _recorded_fixed_ok(func, y0, t, method):
   if kind == 'LaplacianODEFunc':
     return True
   if kind == 'ODEFuncTransformerAtt':
-    from .autograd import _native_transformer_vjp_ok
-    lay = func.multihead_att_layer
-    return bool(_native_transformer_vjp_ok(func)) and (2 * lay.attention_dim) % 4 == 0
+    return _transformer_stage_native(func)
   return False
 
 
@@ -769,7 +781,9 @@ class _RecordedFixedGrid(torch.autograd.Function):
         dy0 += grad_out[0]
       dw = None
       if want_dw:
-        a = torch.sigmoid(func.alpha_train.detach().reshape(()))
+        a = func.alpha_train.detach().reshape(())
+        if not func.opt['no_alpha_sigmoid']:
+          a = torch.sigmoid(a)
         E = graph.e
         dw_e = torch.empty(E, dtype=torch.float32, device=dev)
         dw_e[graph.perm_long] = a * ex['r_acc'][:E]
@@ -939,22 +953,21 @@ def _adjoint_fixed_grid(func, params, y, a, gparams, span, method, step_size):
 
 
 def _adjoint_native_ok(func, y, method):
-  """The fixed-grid adjoint solve runs as ONE native object (csrc/adjoint.hip) for GRAND-l and for GRAND-nl with scaled-dot
-  scores (any normaliser) when alpha' = sigmoid(alpha_train); everything else keeps the stage-by-stage loop above."""
+  """The fixed-grid adjoint solve runs as ONE native object (csrc/adjoint.hip) for GRAND-l and for GRAND-nl with scaled-dot, cosine_sim
+  or pearson scores (any normaliser), alpha' = sigmoid(alpha_train) or the raw alpha_train; everything else (GAT, exp_kernel, the BLEND
+  split kernel) keeps the stage-by-stage loop above."""
   if method not in ('euler', 'rk4') or not hasattr(func, '_descriptor'):
     return False
   if not (y.is_cuda and y.dim() == 2 and y.dtype == torch.float32 and y.shape[1] <= 256):
     return False
   opt = func.opt
-  if opt.get('no_alpha_sigmoid') or opt.get('gnpde_composite_backward') or opt.get('gnpde_host_adjoint'):
+  if opt.get('gnpde_composite_backward') or opt.get('gnpde_host_adjoint'):
     return False
   kind = func.__class__.__name__
   if kind == 'LaplacianODEFunc':
     return True       # the weights are constants of the solve: torchdiffeq's adjoint returns gradients for y0 and func.parameters() only
   if kind == 'ODEFuncTransformerAtt':
-    from .autograd import _native_transformer_vjp_ok
-    lay = func.multihead_att_layer
-    return bool(_native_transformer_vjp_ok(func)) and (2 * lay.attention_dim) % 4 == 0
+    return _transformer_stage_native(func)     # (round 6: cosine_sim / pearson scores and the raw alpha of opt['no_alpha_sigmoid'] as well)
   return False
 
 

@@ -460,6 +460,16 @@ def gen_adjoint():
                                           adjoint_method='adaptive_heun', tol_scale_adjoint=3000.0),
     'constant_gat_dopri5_dopri5': dict(block='constant', function='GAT', method='dopri5', time=1.5, tol_scale=20.0,
                                        adjoint_method='dopri5', tol_scale_adjoint=20.0),
+    # round 6: the ODE blocks of best_params Pubmed (attention block, cosine scores, squareplus over rows, one head; dopri5 forward,
+    # adjoint_method adaptive_heun -- the reference's default) and CoauthorCS (4 heads, squareplus over columns, no source term, no
+    # self-loop weight; dopri5 both ways) in miniature, with their tolerances
+    'attention_laplacian_dopri5_heun_pubmed': dict(block='attention', function='laplacian', method='dopri5', time=4.0, tol_scale=1991.0688305523001,
+                                                   adjoint_method='adaptive_heun', tol_scale_adjoint=16324.368093998313, heads=1, attention_dim=16,
+                                                   attention_type='cosine_sim', square_plus=True, attention_norm_idx=0, add_source=True),
+    'attention_laplacian_dopri5_dopri5_coauthorcs': dict(block='attention', function='laplacian', method='dopri5', time=3.126400580172773,
+                                                         tol_scale=9348.983916372074, adjoint_method='dopri5', tol_scale_adjoint=6599.1250595331385,
+                                                         heads=4, attention_dim=8, attention_type='scaled_dot', square_plus=True, attention_norm_idx=1,
+                                                         add_source=False, self_loop_weight=0),
   }
   for i, (name, over) in enumerate(cases.items()):
     opt = {**BASE, 'adjoint': True, 'adjoint_step_size': 1.0, 'tol_scale_adjoint': 1.0, **over}

@@ -64,6 +64,15 @@ CASES = {
   'nl_d128_m64_mfma': dict(hidden_dim=128, attention_dim=32, heads=2),                  # <4, 2>
   'nl_d192_mfma': dict(hidden_dim=192, attention_dim=16, heads=4, add_source=False),    # <2, 3>
   'nl_d256_m16_mfma': dict(hidden_dim=256, attention_dim=8, heads=1, time=2.0),         # <1, 4>
+  # round 6: cosine_sim / pearson scores (unit head vectors: normalisation + its backward around the scaled-dot kernels) and the raw
+  # alpha of opt['no_alpha_sigmoid']
+  'nl_cosine': dict(attention_type='cosine_sim'),
+  'nl_cosine_squareplus_cols_dk16': dict(attention_type='cosine_sim', square_plus=True, attention_norm_idx=1, attention_dim=32, heads=2),
+  'nl_pearson': dict(attention_type='pearson', attention_dim=32, heads=4, time=2.3),
+  'nl_pearson_d128_mfma': dict(attention_type='pearson', hidden_dim=128, attention_dim=16, heads=4, add_source=False),
+  'nl_raw_alpha': dict(no_alpha_sigmoid=True),
+  'nl_raw_alpha_cols_euler': dict(no_alpha_sigmoid=True, attention_norm_idx=1, adjoint_method='euler', adjoint_step_size=0.5),
+  'l_raw_alpha': dict(function='laplacian', no_alpha_sigmoid=True),
   'l_rk4': dict(function='laplacian'),
   'l_euler': dict(function='laplacian', adjoint_method='euler', adjoint_step_size=1.0),
   'l_attention_block': dict(function='laplacian', block='attention'),

@@ -238,7 +238,7 @@ def test_training_without_the_adjoint_method(name):
     def rhs(t, y):
       calls[0] += 1
       return R.rhs_transformer(y, edge, p[pre + 'Q.weight'], p[pre + 'Q.bias'], p[pre + 'K.weight'], p[pre + 'K.bias'], opt['heads'],
-                               p['odefunc.alpha_train'], p['odefunc.beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'])
+                               p['odefunc.alpha_train'], p['odefunc.beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'], **_att_kwargs(opt))
   t = torch.tensor([0, opt['time']])
   if opt['method'] == 'dopri5':
     z = O._solve_dopri5(rhs, x, t, opt['tol_scale'] * 1e-9, opt['tol_scale'] * 1e-7)[1]

@@ -327,6 +327,12 @@ FIXED_CASES = {
   'l_attention_rk4_hubs': dict(kind='laplacian', block_kind='attention', n=1500, d=32, heads=4, A=16, method='rk4', time=3.5, hubs=2, hub_deg=700),
   'l_attention_midpoint_d22': dict(kind='laplacian', block_kind='attention', n=600, d=22, heads=2, A=8, method='midpoint', time=2.0, step_size=0.5),
   'l_constant_euler': dict(kind='laplacian', block_kind='constant', n=900, d=48, heads=4, A=16, method='euler', time=4.0),
+  # cosine_sim / pearson scores and the raw alpha of opt['no_alpha_sigmoid'] on the native VJP stage
+  'nl_pearson_rk4': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=4, A=32, method='rk4', time=2.3, attention_type='pearson'),
+  'nl_cosine_cols_euler': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=2, A=32, method='euler', time=2.0, step_size=0.5,
+                               attention_type='cosine_sim', attention_norm_idx=1, square_plus=True),
+  'nl_raw_alpha_rk4': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
+  'l_attention_raw_alpha_rk4': dict(kind='laplacian', block_kind='attention', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
 }
 
 
