@@ -45,17 +45,16 @@ def linear(x, weight, bias=None, out=None, relu_input=False):
         _PAD_X.clear()
       xp = _PAD_X[key] = torch.zeros(n, d16, dtype=torch.float32, device=x.device)
     xp[:, :d].copy_(x)
-    try:
-      ver = weight._version
-    except RuntimeError:        # inference tensors have no version counter: never reuse
-      ver = object()
-    wkey = (weight.data_ptr(), ver, tuple(weight.shape), str(weight.device))
-    hit = _PAD_W.get('w')
-    if hit is None or hit[0] != wkey or hit[1] is not weight:
-      wp = torch.zeros(m, d16, dtype=torch.float32, device=x.device)
-      wp[:, :d].copy_(weight)
-      _PAD_W['w'] = hit = (wkey, weight, wp)     # (holds `weight`: its address cannot be reused while it is the key)
-    x, weight, d = xp, hit[2], d16
+    # the padded weight buffer is reused per shape (padding columns zeroed once); the weight itself is copied in on every call -- it is
+    # m x d floats, and no identity / version key can see an in-place update made through .data (round-5 advisor item)
+    wkey = (m, d, d16, str(x.device))
+    wp = _PAD_W.get(wkey)
+    if wp is None:
+      if len(_PAD_W) >= 8:
+        _PAD_W.clear()
+      wp = _PAD_W[wkey] = torch.zeros(m, d16, dtype=torch.float32, device=x.device)
+    wp[:, :d].copy_(weight)
+    x, weight, d = xp, wp, d16
   check(fn(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(b), ptr(out), out.stride(0), stream_of(x)))
   return out
 
