@@ -1292,13 +1292,18 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
     from oracle import restate as R
     gi, g2 = R.parity_error(rec['gx'], host['gx'])
     zi, z2 = R.parity_error(rec['z'], host['z'])
+    # (errors against the largest gradient of the same module: a gradient that is zero in exact arithmetic -- K.bias under a softmax over
+    #  rows -- is rounding noise on both sides, as in tests/test_tape_gpu.py)
     worst = 0.0
+    scale = {}
     for k, v in host['grads'].items():
-      if k in rec['grads']:
-        scale = float(v.abs().max())
-        if scale > 0:
-          worst = max(worst, float((rec['grads'][k] - v).abs().max()) / scale)
-    parity = {'grad_x_rel_max': gi, 'grad_x_rel_l2': g2, 'z_rel_max': zi, 'parameter_gradients_rel_max': worst, 'nfe_equal': rec['nfe'] == host['nfe']}
+      mod = k.rsplit('.', 2)[0] if 'multihead' in k else k
+      scale[mod] = max(scale.get(mod, 0.0), float(v.abs().max()))
+    for k, v in host['grads'].items():
+      mod = k.rsplit('.', 2)[0] if 'multihead' in k else k
+      if k in rec['grads'] and scale[mod] > 0:
+        worst = max(worst, float((rec['grads'][k] - v).abs().max()) / scale[mod])
+    parity = {'grad_x_rel_max': gi, 'grad_x_rel_l2': g2, 'z_rel_max': zi, 'parameter_gradients_rel_max_module_scaled': worst, 'nfe_equal': rec['nfe'] == host['nfe']}
   out = {
     'metric': 'training steps/sec WITHOUT the adjoint method (forward + loss.backward() through the solver), %s d=%d rk4' % (GRAPH_NAMES.get(args.graph, args.graph), d),
     'value': round(K / (rec['fw'] + rec['bw']), 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
@@ -1306,7 +1311,7 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
     'dtype': 'f32', 'data': 'synthetic',
     'config': {'workload': workload_name(args.graph, args.function, K, args.method) + '; TRAINING with opt[adjoint] off: recorded solve + native reverse sweep',
                'graph': args.graph, 'nodes': n, 'edges_with_self_loops': E, 'd': d, 'attention_dim': A, 'heads': h, 'adjoint': False,
-               'tape_bytes': (4 * K + 1) * n * d * 4},
+               'tape_bytes': (4 * K + 1) * n * d * 4 + 4 * K * (n * 2 * A * 4 + E * 4)},
     'train_solve_path': rec['path'],
     'forward_ms': round(1e3 * rec['fw'], 3), 'backward_ms': round(1e3 * rec['bw'], 3), 'vjp_stage_ms': round(1e3 * t_stage, 4),
     'rhs_evals_forward': rec['nfe'],

@@ -316,10 +316,20 @@ __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float*
   grads[n_plain + 1] = fmaf(coef, has_source ? s2 : 0.f, grads[n_plain + 1]);
 }
 
+// dst[i] = src[idx[i]].  Eight elements per thread: two 16-byte loads of the map, all eight gathers issued before the first use, two 16-byte
+// stores -- the one-element-per-thread form of round 4 kept one 4-byte gather in flight per lane and ran at 0.4 TB/s on a table that sits
+// in the L2s (25 us for the 2.48 M weights of the ogbn-arxiv shape).
 __global__ __launch_bounds__(kBlock) void permute_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n,
                                                             float* __restrict__ dst) {
-  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
+  const long long base = (static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x) * 8;
+  if (base + 8 <= n) {
+    const int4 a = *reinterpret_cast<const int4*>(idx + base), b = *reinterpret_cast<const int4*>(idx + base + 4);
+    const float v0 = src[a.x], v1 = src[a.y], v2 = src[a.z], v3 = src[a.w], v4 = src[b.x], v5 = src[b.y], v6 = src[b.z], v7 = src[b.w];
+    *reinterpret_cast<float4*>(dst + base) = make_float4(v0, v1, v2, v3);
+    *reinterpret_cast<float4*>(dst + base + 4) = make_float4(v4, v5, v6, v7);
+  } else {
+    for (long long i = base; i < n; ++i) dst[i] = src[idx[i]];
+  }
 }
 
 }  // namespace
@@ -355,6 +365,7 @@ struct gnpde_adjoint {
   // recorded forward solve (gnpde_adjoint_set_tape): the stage inputs of the FORWARD solve in evaluation order; the run is then the
   // reverse sweep through those evaluations (what autograd does through torchdiffeq's fixed-grid loop when opt['adjoint'] is off)
   const float* tape = nullptr;
+  const float* tape_rec = nullptr;   // one RhsRecord (q||k, head-mean weights) per forward evaluation, behind the stage inputs (rhs.h), or null
   float* r_acc = nullptr;    // [e] or null: sum over the evaluations of (b_j h) u_a[row] . u_y[col] in CSR order (GRAND-l weight gradients)
 };
 
@@ -450,7 +461,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
 
 // One stage: F = f(uy) with epilogue eF, V = (df/dy)^T ua with epilogue eV, parameter gradients accumulated with weight pcoef.
 int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fout, gnpde_epilogue_t eF, float* Vout,
-                  gnpde_epilogue_t eV, float pcoef, float* grads, hipStream_t st) {
+                  gnpde_epilogue_t eV, float pcoef, float* grads, hipStream_t st, const RhsRecord* recorded = nullptr) {
   const gnpde_rhs_t& r = s->rhs;
   const gnpde_graph_t* g = &s->graph;
   const gnpde_graph_t* gt = &s->graph_t;
@@ -462,7 +473,15 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   int rc;
   gnpde_attention_t at = r.att;
   const int A = at.att_dim, M = s->M;
-  if (nl) {
+  const float* qk = s->qk;
+  const float* wfwd = s->w;
+  if (nl && recorded != nullptr) {
+    // the forward solve left this evaluation's q||k and weights on the tape: neither the projection nor the attention runs again
+    qk = recorded->proj;
+    wfwd = recorded->wmean;
+    at.q = qk; at.k = qk + A; at.ldqk = M;
+    w = wfwd;
+  } else if (nl) {
     rc = launch_linear_any(uy, n, d, ld, r.proj_w, M, d, r.proj_b, s->qk, M, st);
     if (rc) return rc;
     at.q = s->qk; at.k = s->qk + A; at.ldqk = M;
@@ -499,15 +518,15 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     if (lanes) {
       // d q over the rows (unless the backward kernel formed it), d k over the rows of the transposed graph
       if (!dq_fused) {
-        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, s->hub_ws, st);
+        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, qk + A, M, inv, s->dqk, M, s->hub_ws, st);
         if (rc) return rc;
       }
-      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, s->hub_ws, st);
+      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, qk, M, inv, s->dqk + A, M, s->hub_ws, st);
       if (rc) return rc;
     } else {
-      rc = gnpde_head_spmm(g, 0, s->ds, h, dk, s->qk + A, M, inv, s->dqk, M, st);
+      rc = gnpde_head_spmm(g, 0, s->ds, h, dk, qk + A, M, inv, s->dqk, M, st);
       if (rc) return rc;
-      rc = gnpde_head_spmm(g, 1, s->ds, h, dk, s->qk, M, inv, s->dqk + A, M, st);
+      rc = gnpde_head_spmm(g, 1, s->ds, h, dk, qk, M, inv, s->dqk + A, M, st);
       if (rc) return rc;
     }
     if (s->unit_heads) {         // through the normalisation: d (q||k) from the gradient of the unit vectors, in place
@@ -521,7 +540,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     //  -25 / -30 us; and running this permutation + the NEXT stage's attention as a parallel hipGraph branch beside the backward chain --
     //  the overlapped kernels slow each other down by what the overlap hides, 0.82 ms per f + VJP either way)
     if (g->e > 0) {
-      hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s->w, s->t_from_csr, g->e, s->w_t);
+      hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
       GNPDE_LAUNCH_CHECK();
     }
     wt = s->w_t;
@@ -639,6 +658,12 @@ int enqueue_taped(gnpde_adjoint* s, float* a, float* grads, hipStream_t st) {
   if (s->r_acc != nullptr && r.graph->e > 0) GNPDE_HIP(hipMemsetAsync(s->r_acc, 0, static_cast<size_t>(r.graph->e) * 4, st));
   const int S = static_cast<int>(s->dts.size());
   auto no_output = []() { gnpde_epilogue_t e{}; e.stage = GNPDE_STAGE_LINCOMB; return e; };
+  RhsRecord rec_store{};
+  auto rec = [&](size_t eval) -> const RhsRecord* {
+    if (s->tape_rec == nullptr) return nullptr;
+    rec_store = rhs_record_at(r, const_cast<float*>(s->tape_rec), eval);
+    return &rec_store;
+  };
   if (s->method == GNPDE_METHOD_EULER) {
     float* ca = a;
     int flip = 0;
@@ -646,7 +671,7 @@ int enqueue_taped(gnpde_adjoint* s, float* a, float* grads, hipStream_t st) {
       const float h = s->dts[n];
       gnpde_epilogue_t eV{};
       eV.stage = GNPDE_STAGE_EULER; eV.dt = h; eV.y = ca; eV.out_y = s->ua[flip];
-      int rc = enqueue_stage(s, slot(n), ca, nullptr, no_output(), nullptr, eV, h, grads, st);
+      int rc = enqueue_stage(s, slot(n), ca, nullptr, no_output(), nullptr, eV, h, grads, st, rec(n));
       if (rc) return rc;
       ca = s->ua[flip];
       flip ^= 1;
@@ -660,12 +685,12 @@ int enqueue_taped(gnpde_adjoint* s, float* a, float* grads, hipStream_t st) {
       const float h = s->dts[n];
       gnpde_epilogue_t eV{};
       eV.stage = GNPDE_STAGE_LINCOMB; eV.y = a; eV.n_prev = 0; eV.coef[0] = h; eV.out_y = s->ua[1];
-      int rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n) + 1), a, nullptr, no_output(), s->ua[0], eV, h, grads, st);
+      int rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n) + 1), a, nullptr, no_output(), s->ua[0], eV, h, grads, st, rec(2 * static_cast<size_t>(n) + 1));
       if (rc) return rc;
       const float hh = 0.5f * h * h;
       eV = gnpde_epilogue_t{};
       eV.stage = GNPDE_STAGE_LINCOMB; eV.y = s->ua[1]; eV.n_prev = 0; eV.coef[0] = hh; eV.out_y = a;
-      rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n)), s->ua[0], nullptr, no_output(), nullptr, eV, hh, grads, st);
+      rc = enqueue_stage(s, slot(2 * static_cast<size_t>(n)), s->ua[0], nullptr, no_output(), nullptr, eV, hh, grads, st, rec(2 * static_cast<size_t>(n)));
       if (rc) return rc;
     }
     return 0;
@@ -678,19 +703,20 @@ int enqueue_taped(gnpde_adjoint* s, float* a, float* grads, hipStream_t st) {
     const float *u1 = slot(4 * static_cast<size_t>(n)), *u2 = u1 + stride, *u3 = u2 + stride, *u4 = u3 + stride;
     gnpde_epilogue_t eV{};
     eV.stage = GNPDE_STAGE_RK1C; eV.dt = dtf; eV.out_y = s->ua[0];
-    int rc = enqueue_stage(s, u4, a, nullptr, no_output(), nullptr, eV, c8, grads, st);
+    const size_t e0 = 4 * static_cast<size_t>(n);
+    int rc = enqueue_stage(s, u4, a, nullptr, no_output(), nullptr, eV, c8, grads, st, rec(e0 + 3));
     if (rc) return rc;
     eV = gnpde_epilogue_t{};
     eV.stage = GNPDE_STAGE_RK2C; eV.dt = dtf; eV.y = a; eV.out_y = s->ua[1];
-    rc = enqueue_stage(s, u3, s->ua[0], nullptr, no_output(), nullptr, eV, c38, grads, st);
+    rc = enqueue_stage(s, u3, s->ua[0], nullptr, no_output(), nullptr, eV, c38, grads, st, rec(e0 + 2));
     if (rc) return rc;
     eV = gnpde_epilogue_t{};
     eV.stage = GNPDE_STAGE_RK3C; eV.dt = dtf; eV.k1 = s->ua[0]; eV.out_y = a4;
-    rc = enqueue_stage(s, u2, s->ua[1], nullptr, no_output(), nullptr, eV, c38, grads, st);
+    rc = enqueue_stage(s, u2, s->ua[1], nullptr, no_output(), nullptr, eV, c38, grads, st, rec(e0 + 1));
     if (rc) return rc;
     eV = gnpde_epilogue_t{};
     eV.stage = GNPDE_STAGE_RK4C; eV.dt = dtf; eV.y = a; eV.k1 = s->ua[1]; eV.out_y = a;      // in place: a is not gathered in this stage
-    rc = enqueue_stage(s, u1, a4, nullptr, no_output(), nullptr, eV, c8, grads, st);
+    rc = enqueue_stage(s, u1, a4, nullptr, no_output(), nullptr, eV, c8, grads, st, rec(e0));
     if (rc) return rc;
   }
   return 0;
@@ -799,16 +825,19 @@ extern "C" int gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size
   GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "adjoint_set_tape: solver is null");
   drop_adjoint_graph(s);
   s->tape = nullptr;
+  s->tape_rec = nullptr;
   s->r_acc = nullptr;
   if (tape == nullptr) return 0;
   const size_t per = s->method == GNPDE_METHOD_RK4 ? 4 : s->method == GNPDE_METHOD_MIDPOINT ? 2 : 1;
-  const size_t need = (per * s->dts.size() + 1) * s->state_bytes;
+  const size_t rec_floats = rhs_record_stride(s->rhs);
+  const size_t need = (per * s->dts.size() + 1) * s->state_bytes + per * s->dts.size() * rec_floats * 4;
   GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(tape) % 256 == 0 && tape_bytes >= need, GNPDE_EWS,
                   "adjoint_set_tape: %zu bytes (need %zu, 256-byte aligned: the tape of gnpde_solver_set_tape for the same method and grid)",
                   tape_bytes, need);
   GNPDE_CHECK_ARG(r_acc == nullptr || s->rhs.kind == GNPDE_RHS_LAPLACIAN, GNPDE_EINVAL,
                   "adjoint_set_tape: edge-weight gradients are GRAND-l's (GRAND-nl forms its weights from the state)");
   s->tape = static_cast<const float*>(tape);
+  s->tape_rec = rec_floats > 0 ? s->tape + (per * s->dts.size() + 1) * (s->state_bytes / 4) : nullptr;
   s->r_acc = r_acc;
   return 0;
 }

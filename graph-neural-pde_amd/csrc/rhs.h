@@ -13,11 +13,28 @@ struct RhsLayout {
   size_t att_bytes, spmm_bytes, fused_bytes;
 };
 
+// Recorded solve (gnpde_solver_set_tape) of GRAND-nl: the evaluation writes its q||k projection and its head-mean weights into buffers
+// of their own (the record of that evaluation) instead of the shared scratch regions, and keeps to the separate kernels (no attention
+// inside the aggregation kernel), so that the reverse sweep finds both and runs neither the projection nor the attention again.
+struct RhsRecord {
+  float* proj;     // [n, proj_m]
+  float* wmean;    // [e]
+};
+// floats of one evaluation's record (0: this descriptor records nothing besides its stage inputs)
+inline size_t rhs_record_stride(const gnpde_rhs_t& r) {
+  if (r.kind != GNPDE_RHS_TRANSFORMER || r.att.type != GNPDE_ATT_SCALED_DOT || r.graph == nullptr) return 0;
+  return (align_up(static_cast<size_t>(r.graph->n) * r.proj_m * 4, 256) + align_up(static_cast<size_t>(r.graph->e > 0 ? r.graph->e : 1) * 4, 256)) / 4;
+}
+inline RhsRecord rhs_record_at(const gnpde_rhs_t& r, float* base, size_t eval) {
+  float* p = base + eval * rhs_record_stride(r);
+  return RhsRecord{p, p + align_up(static_cast<size_t>(r.graph->n) * r.proj_m * 4, 256) / 4};
+}
+
 RhsLayout rhs_layout(const gnpde_rhs_t& r);
 int check_rhs(const gnpde_rhs_t* r);
 // Enqueue f(u) with the given epilogue; `ws` follows rhs_layout(r).
 int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, char* ws, const RhsLayout& L,
-                hipStream_t s, const Fork* fork = nullptr);
+                hipStream_t s, const Fork* fork = nullptr, const RhsRecord* record = nullptr);
 // epilogue with the descriptor's alpha / beta / x0 filled in
 gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r);
 

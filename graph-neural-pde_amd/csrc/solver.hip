@@ -74,17 +74,18 @@ int check_rhs(const gnpde_rhs_t* r) {
 
 // Enqueue f(u) with the given epilogue.  `ws` follows rhs_layout.
 int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& epi, char* ws, const RhsLayout& L,
-                hipStream_t s, const Fork* fork) {
+                hipStream_t s, const Fork* fork, const RhsRecord* record) {
   const gnpde_graph_t* g = r.graph;
   const float* w = r.w_csr;
-  if (r.kind == GNPDE_RHS_TRANSFORMER && fused_attn_supported(r.att, r.d, r.ld, u, &epi) &&
+  if (record != nullptr && rhs_record_stride(r) == 0) record = nullptr;
+  if (record == nullptr && r.kind == GNPDE_RHS_TRANSFORMER && fused_attn_supported(r.att, r.d, r.ld, u, &epi) &&
       reinterpret_cast<uintptr_t>(r.proj_w) % 16 == 0) {
     // scaled-dot attention, softmax over rows: projection + attention + aggregation + epilogue in one pass
     return launch_attn_rhs_fused(g, &r.att, r.proj_w, r.proj_b, u, r.d, r.ld, &epi, ws + L.fused, L.fused_bytes, s);
   }
   if (r.kind != GNPDE_RHS_LAPLACIAN) {
-    float* proj = reinterpret_cast<float*>(ws + L.proj);
-    float* wmean = reinterpret_cast<float*>(ws + L.wmean);
+    float* proj = record ? record->proj : reinterpret_cast<float*>(ws + L.proj);
+    float* wmean = record ? record->wmean : reinterpret_cast<float*>(ws + L.wmean);
     int p0 = 0, p1 = r.n_state_rows > g->n ? r.n_state_rows : g->n;   // keys of halo rows are recomputed locally
     if (r.proj_row_end > 0) {  // this pass projects only a slice of the state rows
       p0 = r.proj_row_begin;
@@ -111,7 +112,7 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
     }
     at.n_key_rows = r.n_state_rows > g->n ? r.n_state_rows : 0;     // halo rows: the GAT node terms cover them
     const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && r.ld % 4 == 0;
-    if (r.kind == GNPDE_RHS_TRANSFORMER && fork == nullptr && r.proj_row_end == 0 && r.n_state_rows <= g->n &&
+    if (record == nullptr && r.kind == GNPDE_RHS_TRANSFORMER && fork == nullptr && r.proj_row_end == 0 && r.n_state_rows <= g->n &&
         (r.d % 4 == 0 || padded) && attn_spmm_supported(g, at, r.d, r.ld, u, epi)) {
       // scaled-dot row softmax: the short rows are attended inside the aggregation kernel; only the hub rows' weights are
       // computed ahead (two small launches)
@@ -162,6 +163,7 @@ struct gnpde_solver {
   int* early_trace = nullptr;
   int early_trace_capacity = 0;
   float* tape = nullptr;     // recorded solve (gnpde_solver_set_tape): n_evals + 1 state-sized slots, the stage inputs in evaluation order
+  float* tape_rec = nullptr; // ... followed by one RhsRecord per evaluation (GRAND-nl with scaled-dot scores: q||k and the weights)
 };
 
 namespace {
@@ -219,35 +221,41 @@ int enqueue_solve(gnpde_solver* s, float* y, hipStream_t st) {
     auto slot = [&](size_t i) { return s->tape + i * stride; };
     GNPDE_HIP(hipMemcpyAsync(slot(0), y, nbytes, hipMemcpyDeviceToDevice, st));
     size_t at = 0;
+    RhsRecord rec_store{};
+    auto rec = [&](size_t eval) -> const RhsRecord* {
+      if (s->tape_rec == nullptr) return nullptr;
+      rec_store = rhs_record_at(r, s->tape_rec, eval);
+      return &rec_store;
+    };
     for (float dt : s->dts) {
       gnpde_epilogue_t e = base_epilogue(r);
       e.dt = dt;
       int rc = 0;
       if (s->method == GNPDE_METHOD_EULER) {
         e.stage = GNPDE_STAGE_EULER; e.y = slot(at); e.out_y = slot(at + 1);
-        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk, rec(at));
         at += 1;
       } else if (s->method == GNPDE_METHOD_MIDPOINT) {
         e.stage = GNPDE_STAGE_LINCOMB; e.y = slot(at); e.n_prev = 0; e.out_k = nullptr;
         e.coef[0] = 0.5f * dt; e.out_y = slot(at + 1);
-        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, slot(at), e, rws, s->L, st, fk, rec(at));
         if (rc) return rc;
         e.coef[0] = dt; e.out_y = slot(at + 2);
-        rc = enqueue_rhs(r, slot(at + 1), e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, slot(at + 1), e, rws, s->L, st, fk, rec(at + 1));
         at += 2;
       } else {
         float *u1 = slot(at), *u2 = slot(at + 1), *u3 = slot(at + 2), *u4 = slot(at + 3);
         e.stage = GNPDE_STAGE_RK1C; e.out_y = u2;
-        rc = enqueue_rhs(r, u1, e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, u1, e, rws, s->L, st, fk, rec(at));
         if (rc) return rc;
         e.stage = GNPDE_STAGE_RK2C; e.y = u1; e.out_y = u3;
-        rc = enqueue_rhs(r, u2, e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, u2, e, rws, s->L, st, fk, rec(at + 1));
         if (rc) return rc;
         e.stage = GNPDE_STAGE_RK3C; e.k1 = u2; e.out_y = u4;
-        rc = enqueue_rhs(r, u3, e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, u3, e, rws, s->L, st, fk, rec(at + 2));
         if (rc) return rc;
         e.stage = GNPDE_STAGE_RK4C; e.k1 = u3; e.out_y = slot(at + 4);
-        rc = enqueue_rhs(r, u4, e, rws, s->L, st, fk);
+        rc = enqueue_rhs(r, u4, e, rws, s->L, st, fk, rec(at + 3));
         at += 4;
       }
       if (rc) return rc;
@@ -451,18 +459,21 @@ extern "C" size_t gnpde_solver_tape_bytes(const gnpde_rhs_t* rhs, int32_t method
   if (method != GNPDE_METHOD_EULER && method != GNPDE_METHOD_RK4 && method != GNPDE_METHOD_MIDPOINT) return 0;
   const size_t state = align_up(static_cast<size_t>(rhs->graph->n) * rhs->ld * 4, 256);
   const size_t per = method == GNPDE_METHOD_RK4 ? 4 : method == GNPDE_METHOD_MIDPOINT ? 2 : 1;
-  return (per * static_cast<size_t>(n_steps) + 1) * state;
+  return (per * static_cast<size_t>(n_steps) + 1) * state + per * static_cast<size_t>(n_steps) * rhs_record_stride(*rhs) * 4;
 }
 
 extern "C" int gnpde_solver_set_tape(gnpde_solver_t* s, void* tape, size_t tape_bytes) {
   GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "solver_set_tape: solver is null");
   drop_graph(s);
   s->tape = nullptr;
+  s->tape_rec = nullptr;
   if (tape == nullptr) return 0;
   const size_t need = gnpde_solver_tape_bytes(&s->rhs, s->method, static_cast<int32_t>(s->dts.size()));
   GNPDE_CHECK_ARG(reinterpret_cast<uintptr_t>(tape) % 256 == 0 && tape_bytes >= need, GNPDE_EWS,
                   "solver_set_tape: %zu bytes (need %zu, 256-byte aligned, zero-filled)", tape_bytes, need);
   s->tape = static_cast<float*>(tape);
+  const size_t state = align_up(static_cast<size_t>(s->rhs.graph->n) * s->rhs.ld * 4, 256);
+  s->tape_rec = rhs_record_stride(s->rhs) > 0 ? s->tape + (static_cast<size_t>(s->n_evals) + 1) * (state / 4) : nullptr;
   return 0;
 }
 

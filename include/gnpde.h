@@ -431,7 +431,10 @@ int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* strea
  * picks torchdiffeq.odeint, run_GNN.py:62-96 calls loss.backward() through its Python loop; src/block_constant.py:45-62).  With a tape
  * attached every stage input of the following runs is written to a slot of its own (n_evals + 1 state-sized slots, 256-byte aligned
  * strides: slot 0 = y0, slot i = the input of evaluation i, the last slot = y(T)) instead of a recycled stage buffer, so the record
- * costs no extra pass over the state.  The caller hands over ZERO-FILLED memory (padding columns are read by 16-byte lanes).
+ * costs no extra pass over the state.  GRAND-nl with scaled-dot scores also records, behind the slots, every evaluation's q||k
+ * projection [n, 2A] and head-mean weights [e] (the evaluation writes them there instead of into its scratch regions), so that the
+ * reverse sweep runs neither the projection nor the attention again.  The caller hands over ZERO-FILLED memory (padding columns are
+ * read by 16-byte lanes).
  * tape == NULL detaches.  The reverse sweep is gnpde_adjoint_set_tape + gnpde_adjoint_run below. */
 size_t gnpde_solver_tape_bytes(const gnpde_rhs_t* rhs, int32_t method, int32_t n_steps);
 int    gnpde_solver_set_tape(gnpde_solver_t* s, void* tape, size_t tape_bytes);
