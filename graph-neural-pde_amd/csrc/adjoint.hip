@@ -31,6 +31,9 @@ size_t attention_workspace_bytes(const gnpde_graph_t* g, int h, bool gat);
 int launch_normalise_heads(float* qk, long long n, int ld, int att_dim, int heads, bool centre, hipStream_t s, float* inv_out = nullptr);
 int launch_normalise_heads_bwd(const float* out, float* g, long long n, int ld, int att_dim, int heads, bool centre, const float* inv, hipStream_t s);
 bool normalise_heads_bwd_supported(int att_dim, int heads);
+int launch_edge_attention_bwd(const gnpde_graph_t* g, const gnpde_attention_t* at, const float* dw_csr, const float* datt_edge,
+                              int post, const float* scale, int scale_sigmoid, float* ds_csr, void* ws, size_t ws_bytes,
+                              hipStream_t stream);
 
 namespace {
 
@@ -332,6 +335,86 @@ __global__ __launch_bounds__(kBlock) void permute_f32_kernel(const float* __rest
   }
 }
 
+// ---- GAT (reference src/function_GAT_attention.py:105-115): score_eh = LeakyReLU(ts_ih + td_jh), ts_ih = sum_c a[c] wx[i, h, c],
+// td_jh = sum_c a[d_k + c] wx[j, h, c], wx = u W.  With c_eh = dL/d(score) LeakyReLU'(score) from the normaliser backward:
+//     d ts_ih = sum over row i of c,   d td_jh = sum over column j of c,
+//     d wx[i, h, c] = d ts_ih a[c] + d td_ih a[d_k + c],   d a[c] = sum_ih d ts_ih wx[i, h, c],   d a[d_k + c] = sum_ih d td_ih wx[i, h, c].
+// out[i, h] = sum over the entries p of row i of c[pos ? pos[p] : p, h]: a wavefront per row, lanes over the entries, fixed fold
+constexpr int kGatMaxHeads = 8;
+__global__ __launch_bounds__(kBlock) void gat_head_sums_kernel(const int* __restrict__ rowptr, const int* __restrict__ pos,
+                                                              const float* __restrict__ c, int n, int h, float* __restrict__ out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int row = static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  float acc[kGatMaxHeads];
+#pragma unroll
+  for (int j = 0; j < kGatMaxHeads; ++j) acc[j] = 0.f;
+  for (int e = e0 + lane; e < e1; e += kWave) {
+    const size_t p = static_cast<size_t>(pos != nullptr ? pos[e] : e) * h;
+#pragma unroll
+    for (int j = 0; j < kGatMaxHeads; ++j)
+      if (j < h) acc[j] += c[p + j];
+  }
+#pragma unroll
+  for (int j = 0; j < kGatMaxHeads; ++j) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc[j] += __shfl_xor(acc[j], off, kWave);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < kGatMaxHeads; ++j)
+      if (j < h) out[static_cast<size_t>(row) * h + j] = acc[j];
+  }
+}
+
+// d wx [n, A] from the head sums
+__global__ __launch_bounds__(kBlock) void gat_dwx_kernel(const float* __restrict__ dts, const float* __restrict__ dtd, const float* __restrict__ a,
+                                                        long long n, int A, int h, float* __restrict__ dwx) {
+  const int dk = A / h;
+  const long long total = n * A;
+  for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * kBlock) {
+    const long long row = i / A;
+    const int col = static_cast<int>(i - row * A);
+    const int hh = col / dk, cc = col - hh * dk;
+    dwx[i] = fmaf(dts[row * h + hh], a[cc], dtd[row * h + hh] * a[dk + cc]);
+  }
+}
+
+// partial[b][slot + {c, d_k + c}] = this slab's share of d a; the rest of the M slots behind `slot` (where the Gram kernels left the
+// column sums of d wx -- GAT's projection has no bias) is zeroed.  One thread per column of wx, rows of the slab in order.
+__global__ __launch_bounds__(kBlock) void gat_da_partial_kernel(const float* __restrict__ dts, const float* __restrict__ dtd, const float* __restrict__ wx,
+                                                               int n, int A, int h, int rows_per_block, float* __restrict__ partial, int stride, int slot) {
+  __shared__ float ps[kBlock], pd[kBlock];
+  const int dk = A / h;
+  const int col = threadIdx.x;
+  const int r0 = static_cast<int>(blockIdx.x) * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  float s1 = 0.f, s2 = 0.f;
+  if (col < A) {
+    const int hh = col / dk;
+    for (int i = r0; i < r1; ++i) {
+      const float v = wx[static_cast<size_t>(i) * A + col];
+      s1 = fmaf(dts[static_cast<size_t>(i) * h + hh], v, s1);
+      s2 = fmaf(dtd[static_cast<size_t>(i) * h + hh], v, s2);
+    }
+  }
+  ps[threadIdx.x] = s1;
+  pd[threadIdx.x] = s2;
+  __syncthreads();
+  float* out = partial + static_cast<size_t>(blockIdx.x) * stride + slot;
+  if (col < A) {
+    float v = 0.f;
+    if (col < dk) {
+      for (int hh = 0; hh < h; ++hh) v += ps[hh * dk + col];
+    } else if (col < 2 * dk) {
+      for (int hh = 0; hh < h; ++hh) v += pd[hh * dk + (col - dk)];
+    }
+    out[col] = v;
+  }
+}
+
 }  // namespace
 }  // namespace gnpde
 
@@ -350,6 +433,7 @@ struct gnpde_adjoint {
   // workspace regions
   size_t state_bytes;
   float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots, *hub_ws, *qk_inv;
+  float *gts = nullptr, *gtd = nullptr;      // GAT: [n, h] head sums of c over the rows / over the columns
   int unit_heads = 0;        // 1: cosine_sim, 2: pearson -- scores are the scaled dot product of normalised (mean-centred) head vectors
   int n_dots;
   char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
@@ -384,8 +468,14 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
                   "adjoint: the transposed graph does not match the descriptor's graph");
   GNPDE_CHECK_ARG(method == GNPDE_METHOD_EULER || method == GNPDE_METHOD_RK4 || method == GNPDE_METHOD_MIDPOINT, GNPDE_EINVAL,
                   "adjoint: bad method %d", method);     // (midpoint: as the reverse sweep of a recorded solve only)
-  GNPDE_CHECK_ARG(rhs->kind == GNPDE_RHS_LAPLACIAN || rhs->kind == GNPDE_RHS_TRANSFORMER, GNPDE_ESHAPE,
-                  "adjoint: GRAND-l and GRAND-nl (scaled-dot) only");
+  GNPDE_CHECK_ARG(rhs->kind == GNPDE_RHS_LAPLACIAN || rhs->kind == GNPDE_RHS_TRANSFORMER || rhs->kind == GNPDE_RHS_GAT, GNPDE_ESHAPE,
+                  "adjoint: GRAND-l, GRAND-nl and the GAT function");
+  if (rhs->kind == GNPDE_RHS_GAT) {
+    const gnpde_attention_t& at = rhs->att;
+    GNPDE_CHECK_ARG(at.heads >= 2 && at.heads <= kGatMaxHeads && at.att_dim % at.heads == 0 && at.att_dim % 4 == 0 && at.att_dim <= kBlock &&
+                    rhs->proj_m == at.att_dim && at.gat_a != nullptr, GNPDE_ESHAPE,
+                    "adjoint (GAT): 2..8 heads, attention_dim a multiple of 4 and <= 256");
+  }
   GNPDE_CHECK_ARG(rhs->ld % 4 == 0 && rhs->d <= 256 && (rhs->d % 4 == 0 || (rhs->flags & GNPDE_RHS_PADDED_ROWS)), GNPDE_ESHAPE,
                   "adjoint: state rows of up to 256 floats in 16-byte lanes (d %% 4 == 0 or padded rows)");
   GNPDE_CHECK_ARG(rhs->n_state_rows <= rhs->graph->n && rhs->proj_row_end == 0 && rhs->graph->row_begin == 0, GNPDE_ESHAPE,
@@ -406,11 +496,12 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
 size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method, gnpde_adjoint* s) {
   const gnpde_graph_t& g = *r.graph;
   const size_t state = align_up(static_cast<size_t>(g.n) * r.ld * 4, 256);
-  const bool nl = r.kind == GNPDE_RHS_TRANSFORMER;
+  const bool nl = r.kind != GNPDE_RHS_LAPLACIAN;        // an attention per evaluation (GRAND-nl, GAT)
+  const bool gat = r.kind == GNPDE_RHS_GAT;
   const int M = nl ? r.proj_m : 0;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
-  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0, o_hub = 0, o_inv = 0;
+  size_t o_uy[2], o_ua[2], o_F[4], o_V[3], o_P = 0, o_qk = 0, o_dqk = 0, o_w = 0, o_wt = 0, o_r = 0, o_ds = 0, o_hub = 0, o_inv = 0, o_dts = 0, o_dtd = 0;
   for (int i = 0; i < 2; ++i) { o_uy[i] = take(state); o_ua[i] = take(state); }
   const int nF = method == GNPDE_METHOD_RK4 ? 1 : 0, nV = method == GNPDE_METHOD_RK4 ? 1 : 0;     // (u4 of the state / of the adjoint)
   for (int i = 0; i < 4; ++i) o_F[i] = i < nF ? take(state) : 0;
@@ -430,8 +521,9 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     o_ds = take(e4 * r.att.heads);
     const size_t hub_f = hub_bwd_workspace_floats(&g, r.att.heads, r.att.att_dim), hub_ft = hub_bwd_workspace_floats(&gt, r.att.heads, r.att.att_dim);
     o_hub = take((hub_f > hub_ft ? hub_f : hub_ft) * 4 + 256);
-    att_b = attention_workspace_bytes(&g, r.att.heads, false);
+    att_b = attention_workspace_bytes(&g, r.att.heads, gat);
     attbwd_b = gnpde_attention_bwd_workspace_bytes(&g, &r.att);
+    if (gat) { o_dts = take(static_cast<size_t>(g.n) * r.att.heads * 4); o_dtd = take(static_cast<size_t>(g.n) * r.att.heads * 4); }
   }
   const size_t o_att = take(att_b), o_attbwd = take(attbwd_b);
   const size_t spmm_b = gnpde_spmm_workspace_bytes(&g, r.d), spmm_t_b = gnpde_spmm_workspace_bytes(&gt, r.d);
@@ -450,6 +542,7 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     s->dots = f(o_dots); s->n_dots = n_dots;
     s->hub_ws = nl ? f(o_hub) : nullptr;
     s->qk_inv = nl ? f(o_inv) : nullptr;
+    s->gts = gat ? f(o_dts) : nullptr; s->gtd = gat ? f(o_dtd) : nullptr;
     s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
     s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
     s->partial = f(o_part);
@@ -467,7 +560,8 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   const gnpde_graph_t* gt = &s->graph_t;
   const int n = g->n, d = r.d, ld = r.ld;
   const bool padded = (r.flags & GNPDE_RHS_PADDED_ROWS) != 0 && ld % 4 == 0;
-  const bool nl = r.kind == GNPDE_RHS_TRANSFORMER;
+  const bool nl = r.kind != GNPDE_RHS_LAPLACIAN;
+  const bool gat = r.kind == GNPDE_RHS_GAT;
   const float* w = r.w_csr;
   const float* wt = s->w_t_fixed;
   int rc;
@@ -484,7 +578,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   } else if (nl) {
     rc = launch_linear_any(uy, n, d, ld, r.proj_w, M, d, r.proj_b, s->qk, M, st);
     if (rc) return rc;
-    at.q = s->qk; at.k = s->qk + A; at.ldqk = M;
+    at.q = s->qk; at.k = gat ? s->qk : s->qk + A; at.ldqk = M;
     if (s->unit_heads) {
       // cosine_sim / pearson (reference src/function_transformer_attention.py:197-206) = the scaled dot product of unit (mean-centred) head
       // vectors, as in the forward solver (csrc/solver.hip enqueue_rhs): normalised in place, the scale of every vector kept for the backward
@@ -506,7 +600,29 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   if (rc) return rc;
   const float* source = nullptr;
   const float* source_scale = nullptr;
-  if (nl) {
+  if (gat) {
+    const int h = at.heads;
+    rc = launch_edge_attention_bwd(g, &at, s->r, nullptr, 2, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
+    if (rc) return rc;
+    const unsigned gr = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(gat_head_sums_kernel, dim3(gr), dim3(kBlock), 0, st, g->rowptr, static_cast<const int*>(nullptr), s->ds, n, h, s->gts);
+    GNPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_head_sums_kernel, dim3(gr), dim3(kBlock), 0, st, gt->rowptr, s->t_from_csr, s->ds, n, h, s->gtd);
+    GNPDE_LAUNCH_CHECK();
+    long long blocks = (static_cast<long long>(n) * M + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gat_dwx_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, s->gts, s->gtd, at.gat_a, static_cast<long long>(n), M, h, s->dqk);
+    GNPDE_LAUNCH_CHECK();
+    rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
+    if (rc) return rc;
+    if (g->e > 0) {
+      hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
+      GNPDE_LAUNCH_CHECK();
+    }
+    wt = s->w_t;
+    source = s->P;
+    source_scale = s->one;
+  } else if (nl) {
     const int h = at.heads, dk = A / h;
     const float inv = 1.0f / sqrtf(static_cast<float>(dk));
     const bool lanes = head_rowsum_supported(h, dk);            // lane-per-entry row sums (rows without entries stay zero)
@@ -576,6 +692,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     if (d <= 64) hipLaunchKernelGGL(adjoint_gram_kernel<1>, dim3(nb, gy), dim3(kBlock), 0, st, p);
     else if (d <= 128) hipLaunchKernelGGL(adjoint_gram_kernel<2>, dim3(nb, gy), dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL(adjoint_gram_kernel<4>, dim3(nb, gy), dim3(kBlock), 0, st, p);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (gat) {       // d a into the (otherwise unused: no bias) M slots behind the Gram block
+    hipLaunchKernelGGL(gat_da_partial_kernel, dim3(nb), dim3(kBlock), 0, st, s->gts, s->gtd, qk, n, M, at.heads, p.rows_per_block, s->partial, s->stride, M * d);
     GNPDE_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, s->n_dots, nb, s->partial, s->stride, M * d + M);
@@ -732,7 +852,7 @@ void drop_adjoint_graph(gnpde_adjoint* s) {
 
 extern "C" int gnpde_adjoint_grad_floats(const gnpde_rhs_t* rhs) {
   if (!rhs) return 0;
-  const int M = rhs->kind == GNPDE_RHS_TRANSFORMER ? rhs->proj_m : 0;
+  const int M = rhs->kind != GNPDE_RHS_LAPLACIAN ? rhs->proj_m : 0;
   return M * rhs->d + M + 2;
 }
 
@@ -749,7 +869,7 @@ extern "C" int gnpde_adjoint_create(gnpde_adjoint_t** out, const gnpde_rhs_t* rh
   int rc = check_adjoint(rhs, graph_t, method);
   if (rc) return rc;
   GNPDE_CHECK_ARG(n_steps >= 0 && (dts || n_steps == 0), GNPDE_EINVAL, "adjoint_create: bad time grid");
-  if (rhs->kind == GNPDE_RHS_TRANSFORMER)
+  if (rhs->kind != GNPDE_RHS_LAPLACIAN)
     GNPDE_CHECK_ARG(t_from_csr != nullptr && proj_wt != nullptr && reinterpret_cast<uintptr_t>(proj_wt) % 16 == 0, GNPDE_EINVAL,
                     "adjoint_create: GRAND-nl needs the position map of the transposed graph and the transposed projection weights");
   else

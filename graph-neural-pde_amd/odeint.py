@@ -614,6 +614,25 @@ def _transformer_stage_native(func):
   return opt['attention_type'] in ('cosine_sim', 'pearson') and lay.d_k in (4, 8, 16)
 
 
+def _gat_stage_native(func):
+  """The GAT function (reference src/function_GAT_attention.py) on the native VJP stage: 2..8 heads, attention_dim a multiple of 4."""
+  lay, opt = func.multihead_att_layer, func.opt
+  return (not opt['mix_features']) and 2 <= lay.h <= 8 and lay.attention_dim % 4 == 0 and lay.attention_dim <= 256
+
+
+def _stage_projection_t(func, ex, dev):
+  """[d, m] projection weights of the per-evaluation attention, transposed for P = d(q||k) W, in a buffer with a persistent address."""
+  if func.__class__.__name__ == 'ODEFuncAtt':
+    src = func.multihead_att_layer.W.detach()                    # [d, A] as the reference stores it
+  else:
+    wqk, _ = func.multihead_att_layer.qk_weights()
+    src = wqk.t()
+  if ex.get('proj_wt') is None or ex['proj_wt'].shape != tuple(src.shape):
+    ex['proj_wt'] = torch.empty(tuple(src.shape), dtype=torch.float32, device=dev)
+  ex['proj_wt'].copy_(src)                 # refreshed in place: the captured graph keeps the pointer
+  return ex['proj_wt']
+
+
 def _recorded_fixed_ok(func, y0, t, method):
   """The differentiated fixed-grid solve runs as ONE recorded native solve (csrc/solver.hip, gnpde_solver_set_tape: the captured
   hipGraph of the inference solve with every stage input written to a slot of its own) + ONE native reverse sweep over the record
@@ -636,6 +655,8 @@ def _recorded_fixed_ok(func, y0, t, method):
     return True
   if kind == 'ODEFuncTransformerAtt':
     return _transformer_stage_native(func)
+  if kind == 'ODEFuncAtt':
+    return _gat_stage_native(func)
   return False
 
 
@@ -650,6 +671,11 @@ def _grad_vector_by_param(func, g, d):
     gb = g[2 * A * d:2 * A * d + 2 * A]
     by_param = {id(lay.Q.weight): gram[:A], id(lay.K.weight): gram[A:], id(lay.Q.bias): gb[:A], id(lay.K.bias): gb[A:]}
     tail = 2 * A * d + 2 * A
+  elif func.__class__.__name__ == 'ODEFuncAtt':      # d W^T [A, d], then d a in the first 2 d_k of the A slots behind it
+    lay = func.multihead_att_layer
+    A = lay.attention_dim
+    by_param = {id(lay.W): g[:A * d].view(A, d).t(), id(lay.a): g[A * d:A * d + 2 * lay.d_k].reshape(lay.a.shape)}
+    tail = A * d + A
   by_param[id(func.alpha_train)] = g[tail].reshape(func.alpha_train.shape)
   if func.opt['add_source']:
     by_param[id(func.beta_train)] = g[tail + 1].reshape(func.beta_train.shape)
@@ -734,7 +760,7 @@ class _RecordedFixedGrid(torch.autograd.Function):
       raise _lib.GnpdeError('recorded fixed-grid solve: the tape of this forward pass was overwritten by a later solve of the same function '
                             '(backward must run before the next training forward; opt["gnpde_host_fixed_training"] = True keeps a graph per forward)')
     need = ctx.needs_input_grad
-    nl = func.__class__.__name__ == 'ODEFuncTransformerAtt'
+    nl = func.__class__.__name__ in ('ODEFuncTransformerAtt', 'ODEFuncAtt')
     with torch.no_grad():
       n, d = grad_out.shape[1], grad_out.shape[2]
       dev = grad_out.device
@@ -742,11 +768,7 @@ class _RecordedFixedGrid(torch.autograd.Function):
       ex = ent['extra']
       proj_wt = w_t = None
       if nl:
-        wqk, _ = func.multihead_att_layer.qk_weights()
-        if ex.get('proj_wt') is None or ex['proj_wt'].shape != (wqk.shape[1], wqk.shape[0]):
-          ex['proj_wt'] = torch.empty(wqk.shape[1], wqk.shape[0], dtype=torch.float32, device=dev)
-        ex['proj_wt'].copy_(wqk.t())                 # refreshed in place: the captured graph keeps the pointer
-        proj_wt = ex['proj_wt']
+        proj_wt = _stage_projection_t(func, ex, dev)
       else:
         w_csr = func._weights_csr(graph)
         if ex.get('w_t') is None or ex['w_t'].numel() != max(graph.e, 1):
@@ -792,7 +814,7 @@ class _RecordedFixedGrid(torch.autograd.Function):
       gparams = []
       for i, p in enumerate(ctx.params):
         g = by_param.get(id(p)) if need[5 + i] else None
-        gparams.append(None if g is None else g.clone())
+        gparams.append(None if g is None else g.clone(memory_format=torch.contiguous_format))
     return (dy0, dw, None, None, None) + tuple(gparams)
 
 
@@ -968,6 +990,8 @@ def _adjoint_native_ok(func, y, method):
     return True       # the weights are constants of the solve: torchdiffeq's adjoint returns gradients for y0 and func.parameters() only
   if kind == 'ODEFuncTransformerAtt':
     return _transformer_stage_native(func)     # (round 6: cosine_sim / pearson scores and the raw alpha of opt['no_alpha_sigmoid'] as well)
+  if kind == 'ODEFuncAtt':
+    return _gat_stage_native(func)             # (round 6)
   return False
 
 
@@ -1012,15 +1036,11 @@ def _adjoint_native(func, params, y, a, span, method, step_size):
   graph = func._graph(y) if view is None else view.graph
   desc = func._descriptor(yb, x0_override=ent['x0'], graph=graph)
   gt, t_from_csr = graph.transposed_positions()
-  nl = func.__class__.__name__ == 'ODEFuncTransformerAtt'
+  nl = func.__class__.__name__ in ('ODEFuncTransformerAtt', 'ODEFuncAtt')
   ex = ent['extra']
   proj_wt = w_t = None
   if nl:
-    wqk, _ = func.multihead_att_layer.qk_weights()
-    if ex.get('proj_wt') is None or ex['proj_wt'].shape != (wqk.shape[1], wqk.shape[0]):
-      ex['proj_wt'] = torch.empty(wqk.shape[1], wqk.shape[0], dtype=torch.float32, device=y.device)
-    ex['proj_wt'].copy_(wqk.t())                 # refreshed in place: the captured graph keeps the pointer
-    proj_wt = ex['proj_wt']
+    proj_wt = _stage_projection_t(func, ex, y.device)
   else:
     w_csr = func._weights_csr(graph)
     if ex.get('w_t') is None or ex['w_t'].numel() != max(graph.e, 1):
@@ -1043,20 +1063,7 @@ def _adjoint_native(func, params, y, a, span, method, step_size):
     a_out.copy_(ab)
   else:
     view.leave(ab, out=a_out)
-  g = ent['grads']
-  by_param = {}
-  if nl:
-    lay = func.multihead_att_layer
-    A, d = lay.attention_dim, y.shape[1]
-    gram = g[:2 * A * d].view(2 * A, d)
-    gb = g[2 * A * d:2 * A * d + 2 * A]
-    by_param = {id(lay.Q.weight): gram[:A], id(lay.K.weight): gram[A:], id(lay.Q.bias): gb[:A], id(lay.K.bias): gb[A:]}
-    tail = 2 * A * d + 2 * A
-  else:
-    tail = 0
-  by_param[id(func.alpha_train)] = g[tail].reshape(func.alpha_train.shape)
-  if func.opt['add_source']:
-    by_param[id(func.beta_train)] = g[tail + 1].reshape(func.beta_train.shape)
+  by_param = _grad_vector_by_param(func, ent['grads'], y.shape[1])
   return a_out, [by_param.get(id(p)) for p in params]
 
 

@@ -470,6 +470,7 @@ def gen_adjoint():
                                                          tol_scale=9348.983916372074, adjoint_method='dopri5', tol_scale_adjoint=6599.1250595331385,
                                                          heads=4, attention_dim=8, attention_type='scaled_dot', square_plus=True, attention_norm_idx=1,
                                                          add_source=False, self_loop_weight=0),
+    'constant_gat_rk4_rk4': dict(block='constant', function='GAT', method='rk4', time=2.3, adjoint_method='rk4', adjoint_step_size=1.0),
   }
   for i, (name, over) in enumerate(cases.items()):
     opt = {**BASE, 'adjoint': True, 'adjoint_step_size': 1.0, 'tol_scale_adjoint': 1.0, **over}
@@ -564,10 +565,11 @@ def gen_training():
     'constant_laplacian_rk4': dict(block='constant', function='laplacian', method='rk4', time=2.3),
     'attention_laplacian_rk4': dict(block='attention', function='laplacian', method='rk4', time=2.3, step_size=0.5),
     'attention_laplacian_euler_no_source': dict(block='attention', function='laplacian', method='euler', time=3.0, add_source=False),
+    'constant_gat_rk4': dict(block='constant', function='GAT', method='rk4', time=2.3),
   }
   for i, (name, over) in enumerate(cases.items()):
     opt = {**BASE, **over}
-    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt}[opt['function']]
+    fcls = {'laplacian': LaplacianODEFunc, 'transformer': ODEFuncTransformerAtt, 'GAT': ODEFuncAtt}[opt['function']]
     bcls = {'constant': ConstantODEblock, 'attention': AttODEblock}[opt['block']]
     block = bcls(fcls, [], opt, data_of(ei, x), torch.device('cpu'), t=torch.tensor([0, opt['time']]))
     randomise(block, 900 + i)

@@ -24,7 +24,7 @@ def _opt(**over):
 
 def _run(dev, opt, ei, x, seed, host):
   o = dict(opt, gnpde_host_adjoint=bool(host))
-  fcls = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc}[o['function']]
+  fcls = {'transformer': G.ODEFuncTransformerAtt, 'laplacian': G.LaplacianODEFunc, 'GAT': G.ODEFuncAtt}[o['function']]
   bcls = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}[o['block']]
   block = bcls(fcls, [], o, Data(x, ei), dev, t=torch.tensor([0, o['time']])).to(dev)
   g = torch.Generator().manual_seed(seed)
@@ -73,6 +73,10 @@ CASES = {
   'nl_raw_alpha': dict(no_alpha_sigmoid=True),
   'nl_raw_alpha_cols_euler': dict(no_alpha_sigmoid=True, attention_norm_idx=1, adjoint_method='euler', adjoint_step_size=0.5),
   'l_raw_alpha': dict(function='laplacian', no_alpha_sigmoid=True),
+  # the GAT function (reference src/function_GAT_attention.py) on the native stage
+  'gat_rk4': dict(function='GAT'),
+  'gat_cols_euler_h8': dict(function='GAT', attention_norm_idx=1, attention_dim=64, heads=8, adjoint_method='euler', adjoint_step_size=0.5),
+  'gat_d128_no_source': dict(function='GAT', hidden_dim=128, attention_dim=32, heads=2, add_source=False, time=2.3),
   'l_rk4': dict(function='laplacian'),
   'l_euler': dict(function='laplacian', adjoint_method='euler', adjoint_step_size=1.0),
   'l_attention_block': dict(function='laplacian', block='attention'),
@@ -82,7 +86,7 @@ CASES = {
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_native_adjoint_matches_stage_loop(dev, case):
   opt = _opt(**CASES[case])
-  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16', 'nl_d128_mfma') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
+  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16', 'nl_d128_mfma', 'gat_rk4') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
   n = 21000 if case == 'nl_d128_mfma' else 700       # (21000 rows: 42-row slabs -- several K steps per wave, ragged last steps)
   ei = random_graph(n, 6, seed=11, hubs=hubs, hub_deg=700, isolated=3, dup=20).to(dev)
   x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(3))).to(dev)

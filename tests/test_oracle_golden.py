@@ -231,6 +231,14 @@ def test_training_without_the_adjoint_method(name):
     def rhs(t, y):
       calls[0] += 1
       return R.rhs_laplacian(y, e_n, w, p['odefunc.alpha_train'], p['odefunc.beta_train'], x0, opt['no_alpha_sigmoid'], opt['add_source'])
+  elif opt['function'] == 'GAT':
+    edge, _ = R.add_remaining_self_loops(ei, None, opt['self_loop_weight'], int(ei.max()) + 1)
+    pre = 'odefunc.multihead_att_layer.'
+
+    def rhs(t, y):
+      calls[0] += 1
+      return R.rhs_gat(y, edge, p[pre + 'W'], p[pre + 'a'], opt['heads'], p['odefunc.alpha_train'], p['odefunc.beta_train'], x0,
+                       opt['no_alpha_sigmoid'], opt['add_source'], opt['leaky_relu_slope'], opt['attention_norm_idx'])
   else:
     edge, _ = R.add_remaining_self_loops(ei, None, opt['self_loop_weight'], int(ei.max()) + 1)
     pre = 'odefunc.multihead_att_layer.'

@@ -17,7 +17,7 @@ from helpers import Fixture, fixtures, Data, assert_parity, random_graph
 pytestmark = pytest.mark.gpu
 
 O = importlib.import_module('gnpde_amd.odeint')
-FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt}
+FUNCS = {'laplacian': G.LaplacianODEFunc, 'transformer': G.ODEFuncTransformerAtt, 'GAT': G.ODEFuncAtt}
 BLOCKS = {'constant': G.ConstantODEblock, 'attention': G.AttODEblock}
 OPT = dict(heads=4, attention_dim=16, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, reweight_attention=False,
            beltrami=False, leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=10 ** 9, add_source=True, no_alpha_sigmoid=False,
@@ -332,6 +332,8 @@ FIXED_CASES = {
   'nl_cosine_cols_euler': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=2, A=32, method='euler', time=2.0, step_size=0.5,
                                attention_type='cosine_sim', attention_norm_idx=1, square_plus=True),
   'nl_raw_alpha_rk4': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
+  'gat_rk4_hubs': dict(kind='GAT', block_kind='constant', n=1500, d=32, heads=4, A=16, method='rk4', time=2.3, hubs=2, hub_deg=700),
+  'gat_midpoint_cols': dict(kind='GAT', block_kind='constant', n=700, d=48, heads=2, A=32, method='midpoint', time=2.0, step_size=0.5, attention_norm_idx=1),
   'l_attention_raw_alpha_rk4': dict(kind='laplacian', block_kind='attention', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
 }
 
