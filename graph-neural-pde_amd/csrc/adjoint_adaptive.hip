@@ -63,15 +63,15 @@ struct HCtl {             // controller record (device; copied to the host once 
 static_assert(sizeof(HCtl) == 112, "controller record");
 
 struct HCtlArgs {
-  const double* err_y; const double* err_a; int nb_y, nb_a;
-  const float* dots; long long n_pairs;      // S regions of n_pairs (d1, d2) pairs, stage by stage
+  const double* part;                        // [kErrBlocks][2 + 2 S]: adaptive_err_kernel's block partial sums
   double count;
   const float* alpha; const float* beta; int alpha_sigmoid;
   float atol, rtol;
   int use_alpha, use_beta;
   int S, order;
   float c_sol[kMaxStages + 1], c_err[kMaxStages + 1], c_mid[kMaxStages + 1];
-  HCtl* c;
+  const HCtl* c;                             // the record this trial step started from ...
+  HCtl* c_next;                              // ... and where the next one's goes (the other of the two records)
   int parity;
 };
 
@@ -129,71 +129,19 @@ __global__ __launch_bounds__(kBlock) void adaptive_init_kernel(const float* __re
   for (int j = 0; j < 2; ++j) { c->g[0][j] = g_in[j]; c->g[1][j] = g_in[j]; c->ks[0][j] = ks[j]; c->ks[1][j] = ks[j]; c->g_out[j] = g_in[j]; }
 }
 
-// One block of kCtlBlock threads per trial step, S (the number of new stages of the pair) a compile-time constant.  Two things made the first
-// version of this kernel the longest launch of a trial (32 us at Pubmed's size, profiles/r05_pubmed_adjoint_trial_sequence_before.txt):
-//  * the partial arrays were folded by separate strided loops behind a 256-thread tree each -- now every load of an iteration is issued
-//    together by 1024 threads and the fold is wave shuffles plus one LDS exchange;
-//  * the scalar tail read and wrote the controller record field by field through its pointer (some thirty dependent round trips to memory)
-//    and indexed its small arrays dynamically (scratch) -- now the record, alpha and beta are read once BEFORE the fold, the tail works on
-//    registers with compile-time indices, and the record is written back once.
-// The order of the additions is fixed, so a solve is reproducible run to run; the float arithmetic of the tail is unchanged.
-constexpr int kCtlBlock = 1024;
-
+// The controller's arithmetic for one trial step (torchdiffeq rk_common.py _adaptive_step / misc.py _optimal_step_size and _mixed_norm over
+// the components y, a and each scalar of its own), from the folded sums `tot` = (sum err_y^2, sum err_a^2, then per new stage the dots
+// <u_a, F>, <u_a, x0>).  L: the record this trial step started from; returns the record of the next one.  Registers and compile-time
+// indices only (round 5: the first version read and wrote the record field by field through its pointer and cost 32 us).
 template <int S>
-__global__ __launch_bounds__(kCtlBlock) void adaptive_control_kernel(const HCtlArgs a) {
-  constexpr int kVals = 2 + 2 * S;
-  __shared__ double part[kCtlBlock / 64][kVals];
-  __shared__ double tot[kVals];
-  const int tid = threadIdx.x;
-  const HCtl L = *a.c;
-  const float alpha_raw = *a.alpha;
-  const float beta = a.beta != nullptr ? *a.beta : 0.0f;
-  double v[kVals];
-#pragma unroll
-  for (int j = 0; j < kVals; ++j) v[j] = 0.0;
-  // (issuing several iterations' loads at once -- four per array, clamped and masked -- was measured and is no faster for S = 1 and slower for
-  //  S = 6, 27 us against 21: what is left of this kernel's time is a single wave running ~4-6 KB of cold code, so smaller code wins)
-  if (a.nb_y > 0 && a.nb_a > 0) {
-    const int last_y = a.nb_y - 1, last_a = a.nb_a - 1;
-    const int lim = (last_y > last_a ? last_y : last_a) + 1;
-    for (int i = tid; i < lim; i += kCtlBlock) {
-      const double ey = a.err_y[i < last_y ? i : last_y], ea = a.err_a[i < last_a ? i : last_a];
-      v[0] += i <= last_y ? ey : 0.0;
-      v[1] += i <= last_a ? ea : 0.0;
-    }
-  }
-  const float2* __restrict__ pairs = reinterpret_cast<const float2*>(a.dots);
-  for (long long i = tid; i < a.n_pairs; i += kCtlBlock) {
-    float2 d[S];
-#pragma unroll
-    for (int r = 0; r < S; ++r) d[r] = pairs[a.n_pairs * r + i];
-#pragma unroll
-    for (int r = 0; r < S; ++r) { v[2 + 2 * r] += d[r].x; v[3 + 2 * r] += d[r].y; }
-  }
-#pragma unroll
-  for (int j = 0; j < kVals; ++j) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_down(v[j], off, 64);
-  }
-  if ((tid & 63) == 0) {
-#pragma unroll
-    for (int j = 0; j < kVals; ++j) part[tid >> 6][j] = v[j];
-  }
-  __syncthreads();
-  if (tid < kVals) {
-    double t = 0.0;
-    for (int w = 0; w < kCtlBlock / 64; ++w) t += part[w][tid];
-    tot[tid] = t;
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  const bool p1 = a.parity != 0;         // slot of the trial step in flight; the next one takes the other
+__device__ __forceinline__ HCtl control_decide(const HCtl& L, const double* tot, const HCtlArgs& a, float alpha_raw, float beta) {
+  const bool p1 = a.parity != 0;         // slot of the trial in flight; the next one takes the other
   HCtl N = L;
   const float h = p1 ? L.h[1] : L.h[0];
   const float g0[2] = {p1 ? L.g[1][0] : L.g[0][0], p1 ? L.g[1][1] : L.g[0][1]};
   const float k0[2] = {p1 ? L.ks[1][0] : L.ks[0][0], p1 ? L.ks[1][1] : L.ks[0][1]};
   float h_next, g_next[2], k_next[2];
-  if (L.done) {                       // replayed past the end point (never queued by gnpde_adjoint_adaptive_run): change nothing
+  if (L.done) {                       // replayed past the end point: change nothing
     N.accept = 0;
     N.interp = 0;
     h_next = h;
@@ -269,7 +217,105 @@ __global__ __launch_bounds__(kCtlBlock) void adaptive_control_kernel(const HCtlA
   } else {
     N.h[1] = h_next; N.g[1][0] = g_next[0]; N.g[1][1] = g_next[1]; N.ks[1][0] = k_next[0]; N.ks[1][1] = k_next[1];
   }
-  *a.c = N;
+  return N;
+}
+
+// ---- round 6: the tail of a trial step in TWO launches instead of four (error norm of y, error norm of a, controller, finish), and no
+// launch whose only work is one wave of scalar code.
+//   adaptive_err_kernel     kErrBlocks blocks: block partial sums (double) of BOTH error norms and of every new stage's dot pairs
+//   adaptive_finish2_kernel every block folds those kErrBlocks partial rows itself (same code, same order: the same doubles in every
+//                           block) and its first thread takes the controller's decision; block 0 writes the record of the NEXT trial step
+//                           -- into the OTHER of two records, so that no block can read a record that has already been advanced --
+//                           and all of them go on to the finish pass with the decision in LDS.
+// Element arithmetic and the controller's float sequence are unchanged (rk_error_partial_kernel, control_decide); the squares and the dots
+// are summed in double, so the grouping of the partial sums does not reach the float32 ratio.
+constexpr int kErrBlocks = 1024;             // (256 blocks read the 8 operands of a Pubmed-size state in 41 us, 1024 in ~13)
+
+struct HErrArgs {
+  const float* y0; const float* y1; const float* kf[kMaxStages + 1];
+  const float* a0; const float* a1; const float* kv[kMaxStages + 1];
+  float ce[kMaxStages + 1];
+  float atol, rtol;
+  long long n;
+  int d, ld;
+  const float* h;                 // fl32(dt) of this trial step (device)
+  const float* dots; long long n_pairs;
+  double* part;                   // [kErrBlocks][2 + 2 S]
+};
+
+// this thread's share of sum ((sum_j ce_j h k_j) / (atol + rtol max(|y0|, |y1|)))^2 for the state (-> ey) and the adjoint (-> ea): the element
+// arithmetic of rk_error_partial_kernel (misc.hip), both components in one loop so that their loads overlap
+template <int S>
+__device__ __forceinline__ void err_both(const HErrArgs& a, float s, double& ey, double& ea) {
+  const int q = a.ld / 4;
+  const long long total = a.n * q;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / q;
+    const int c = static_cast<int>(i - r * q) * 4;
+    if (c >= a.d) continue;
+    float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j <= S; ++j) {
+      if (a.ce[j] == 0.0f) continue;              // (dopri5: the second stage has no weight in the error estimate)
+      const float4 k1 = reinterpret_cast<const float4*>(a.kf[j])[i];
+      const float4 k2 = reinterpret_cast<const float4*>(a.kv[j])[i];
+      const float cj = a.ce[j] * s;
+      e1.x = fmaf(k1.x, cj, e1.x); e1.y = fmaf(k1.y, cj, e1.y); e1.z = fmaf(k1.z, cj, e1.z); e1.w = fmaf(k1.w, cj, e1.w);
+      e2.x = fmaf(k2.x, cj, e2.x); e2.y = fmaf(k2.y, cj, e2.y); e2.z = fmaf(k2.z, cj, e2.z); e2.w = fmaf(k2.w, cj, e2.w);
+    }
+    const float4 u1 = reinterpret_cast<const float4*>(a.y0)[i], v1 = reinterpret_cast<const float4*>(a.y1)[i];
+    const float4 u2 = reinterpret_cast<const float4*>(a.a0)[i], v2 = reinterpret_cast<const float4*>(a.a1)[i];
+    const float ee1[4] = {e1.x, e1.y, e1.z, e1.w}, ee2[4] = {e2.x, e2.y, e2.z, e2.w};
+    const float m1[4] = {fmaxf(fabsf(u1.x), fabsf(v1.x)), fmaxf(fabsf(u1.y), fabsf(v1.y)), fmaxf(fabsf(u1.z), fabsf(v1.z)), fmaxf(fabsf(u1.w), fabsf(v1.w))};
+    const float m2[4] = {fmaxf(fabsf(u2.x), fabsf(v2.x)), fmaxf(fabsf(u2.y), fabsf(v2.y)), fmaxf(fabsf(u2.z), fabsf(v2.z)), fmaxf(fabsf(u2.w), fabsf(v2.w))};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (c + t < a.d) {
+        const float q1 = ee1[t] / (a.atol + a.rtol * m1[t]);
+        const float q2 = ee2[t] / (a.atol + a.rtol * m2[t]);
+        ey += static_cast<double>(q1 * q1);
+        ea += static_cast<double>(q2 * q2);
+      }
+    }
+  }
+}
+
+// sum of one double per thread over the block, fixed order (lanes by xor butterfly, the four waves in order); thread 0 holds it
+__device__ __forceinline__ double block_fold(double v, double* red4) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void adaptive_err_kernel(const HErrArgs a) {
+  __shared__ double red4[kWavesPerBlock];
+  constexpr int kVals = 2 + 2 * S;
+  const float s = *a.h;
+  double* out = a.part + static_cast<size_t>(blockIdx.x) * kVals;
+  double ey = 0.0, ea = 0.0;
+  err_both<S>(a, s, ey, ea);
+  ey = block_fold(ey, red4);
+  ea = block_fold(ea, red4);
+  if (threadIdx.x == 0) { out[0] = ey; out[1] = ea; }
+  const float2* __restrict__ pairs = reinterpret_cast<const float2*>(a.dots);
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    double d1 = 0.0, d2 = 0.0;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n_pairs; i += stride) {
+      const float2 v = pairs[a.n_pairs * r + i];
+      d1 += v.x;
+      d2 += v.y;
+    }
+    d1 = block_fold(d1, red4);
+    d2 = block_fold(d2, red4);
+    if (threadIdx.x == 0) { out[2 + 2 * r] = d1; out[3 + 2 * r] = d2; }
+  }
 }
 
 struct HFinishArgs {
@@ -285,9 +331,44 @@ struct HFinishArgs {
   int parity;
 };
 
-__global__ __launch_bounds__(kBlock) void adaptive_finish_kernel(const HFinishArgs p) {
-  const int accept = p.c->accept, interp = p.c->interp;
-  const float h = p.c->h[p.parity], hn = p.c->h[1 - p.parity], x = p.c->x;
+template <int S>
+__global__ __launch_bounds__(kBlock) void adaptive_finish2_kernel(const HCtlArgs a, const HFinishArgs p) {
+  constexpr int kVals = 2 + 2 * S;
+  __shared__ double red4[kWavesPerBlock];
+  __shared__ double tot[kVals];
+  __shared__ float dec_f[3];       // h, h of the next trial step, interpolation fraction
+  __shared__ int dec_i[2];         // accept, interp
+  // every block: the kErrBlocks partial rows, kErrBlocks / kBlock per thread in row order, folded in the same order everywhere
+  static_assert(kErrBlocks % kBlock == 0, "partial rows per thread");
+  double mine[kVals];
+#pragma unroll
+  for (int j = 0; j < kVals; ++j) mine[j] = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < kErrBlocks / kBlock; ++rr) {
+    const double* row = a.part + (static_cast<size_t>(rr) * kBlock + threadIdx.x) * kVals;
+#pragma unroll
+    for (int j = 0; j < kVals; ++j) mine[j] += row[j];
+  }
+#pragma unroll
+  for (int j = 0; j < kVals; ++j) {
+    const double t = block_fold(mine[j], red4);
+    if (threadIdx.x == 0) tot[j] = t;
+  }
+  if (threadIdx.x == 0) {
+    const HCtl L = *a.c;
+    const float alpha_raw = *a.alpha;
+    const float beta = a.beta != nullptr ? *a.beta : 0.0f;
+    const HCtl N = control_decide<S>(L, tot, a, alpha_raw, beta);
+    dec_f[0] = a.parity ? L.h[1] : L.h[0];
+    dec_f[1] = a.parity ? N.h[0] : N.h[1];
+    dec_f[2] = N.x;
+    dec_i[0] = N.accept;
+    dec_i[1] = N.interp;
+    if (blockIdx.x == 0) *a.c_next = N;
+  }
+  __syncthreads();
+  const int accept = dec_i[0], interp = dec_i[1];
+  const float h = dec_f[0], hn = dec_f[1], x = dec_f[2];
   const float cn = p.a00 * hn;
   typedef float f4 __attribute__((ext_vector_type(4)));
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < p.n4;
@@ -295,10 +376,11 @@ __global__ __launch_bounds__(kBlock) void adaptive_finish_kernel(const HFinishAr
     const f4 ya = reinterpret_cast<const f4*>(p.y)[i], yb = reinterpret_cast<const f4*>(p.y1)[i];
     const f4 fa = reinterpret_cast<const f4*>(p.f)[i], fb = reinterpret_cast<const f4*>(p.f1)[i];
     const f4 aa = reinterpret_cast<const f4*>(p.a)[i], ab = reinterpret_cast<const f4*>(p.a1)[i];
-    const f4 va = reinterpret_cast<const f4*>(p.v[0])[i], vb = reinterpret_cast<const f4*>(p.v[p.S])[i];
+    const f4 va = reinterpret_cast<const f4*>(p.v[0])[i], vb = reinterpret_cast<const f4*>(p.v[S])[i];
     if (interp) {
       f4 am = aa;
-      for (int j = 0; j <= p.S; ++j) {
+#pragma unroll
+      for (int j = 0; j <= S; ++j) {
         const float m = p.c_mid[j] * h;
         if (m != 0.0f) am += reinterpret_cast<const f4*>(p.v[j])[i] * m;
       }
@@ -359,8 +441,8 @@ struct gnpde_adjoint_adaptive {
   int slots, n_state;
   size_t part_bytes;
   hipStream_t cap_stream = nullptr;
-  hipGraph_t graph_obj[2] = {nullptr, nullptr};
-  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  hipGraph_t graph_obj[4] = {nullptr, nullptr, nullptr, nullptr};      // one trial step of parity 0 / 1; TWO trial steps starting with parity 0 / 1
+  hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
   bool cleared = false;
   HCtl* host_ctl = nullptr;
   int n_evals = 0, n_accepted = 0, n_rejected = 0, n_launches = 0, n_syncs = 0;
@@ -380,9 +462,9 @@ size_t adaptive_layout(const gnpde_rhs_t& r, const gnpde_rhs_t& rb, const Tablea
   const size_t part = static_cast<size_t>(r.graph->n_long_chunks) * align_up(static_cast<size_t>(r.d), 4) * sizeof(float);
   const int n_state = 4 + 4 + 2 * (tab.S - 1) + 4 + 1;        // Y, A pairs; carried / last derivatives; middle stages; stage inputs; a_out
   size_t off = 0;
-  const size_t off_ctl = off;   off += 256;
-  const size_t off_err_y = off; off += 4096 * 4;
-  const size_t off_err_a = off; off += 4096 * 4;
+  const size_t off_ctl = off;   off += 512;                  // two controller records (a trial step reads one and writes the other)
+  const size_t off_err_y = off; off += align_up(static_cast<size_t>(kErrBlocks) * (2 + 2 * kMaxStages) * sizeof(double), 256);
+  const size_t off_err_a = off; off += 256;                  // (unused since round 6)
   const size_t off_dots = off;  off += align_up(static_cast<size_t>(slots) * 2 * sizeof(float) * tab.S, 256);
   const size_t off_part = off;  off += align_up(part, 256);
   const RhsLayout Lb = rhs_layout(rb);
@@ -431,7 +513,7 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
   const int S = tab.S;
   const long long n = r.graph->n;
   const int p = parity, q = 1 - parity;
-  const float* h = &s->ctl->h[p];
+  const float* h = &s->ctl[p].h[p];            // (record p is the one the trial step of parity p reads)
   float* kf[kMaxStages + 1];
   float* kv[kMaxStages + 1];
   kf[0] = s->KFp[p]; kv[0] = s->KVp[p];
@@ -459,19 +541,16 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
     if (int rc = enqueue_eval(s, cur_y, cur_a, kf[rr], kv[rr], rr - 1, n_prev, kf, kv, w, s->Y[p], dst_y, s->A[p], dst_a, h, st)) return rc;
     if (dst_y != nullptr) { cur_y = dst_y; cur_a = dst_a; }
   }
-  float ce[kMaxStages + 1];
-  for (int j = 0; j <= S; ++j) ce[j] = static_cast<float>(tab.c_err[j]);
-  int nb_y = 0, nb_a = 0;
-  if (int rc = launch_rk_error_ratio(s->Y[p], s->Y[q], kf, ce, S + 1, s->atol, s->rtol, n, r.d, r.ld, nullptr,
-                                     reinterpret_cast<float*>(s->ws + s->off_err_y), st, h, &nb_y))
-    return rc;
-  if (int rc = launch_rk_error_ratio(s->A[p], s->A[q], kv, ce, S + 1, s->atol, s->rtol, n, r.d, r.ld, nullptr,
-                                     reinterpret_cast<float*>(s->ws + s->off_err_a), st, h, &nb_a))
-    return rc;
+  const HCtl* rec = s->ctl + p;                 // this trial step's record; the next one's goes to the other
+  HErrArgs ea{};
+  ea.y0 = s->Y[p]; ea.y1 = s->Y[q]; ea.a0 = s->A[p]; ea.a1 = s->A[q];
+  for (int j = 0; j <= S; ++j) { ea.kf[j] = kf[j]; ea.kv[j] = kv[j]; ea.ce[j] = static_cast<float>(tab.c_err[j]); }
+  ea.atol = s->atol; ea.rtol = s->rtol; ea.n = n; ea.d = r.d; ea.ld = r.ld;
+  ea.h = &rec->h[p];
+  ea.dots = s->dots; ea.n_pairs = s->slots;
+  ea.part = reinterpret_cast<double*>(s->ws + s->off_err_y);
   HCtlArgs ca{};
-  ca.err_y = reinterpret_cast<const double*>(s->ws + s->off_err_y); ca.err_a = reinterpret_cast<const double*>(s->ws + s->off_err_a);
-  ca.nb_y = nb_y; ca.nb_a = nb_a;
-  ca.dots = s->dots; ca.n_pairs = s->slots;
+  ca.part = ea.part;
   ca.count = static_cast<double>(n) * r.d;
   ca.alpha = r.alpha; ca.beta = r.x0 != nullptr ? r.beta : nullptr; ca.alpha_sigmoid = r.alpha_sigmoid;
   ca.atol = s->atol; ca.rtol = s->rtol;
@@ -480,15 +559,13 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
   for (int j = 0; j <= S; ++j) {
     ca.c_sol[j] = static_cast<float>(tab.c_sol[j]); ca.c_err[j] = static_cast<float>(tab.c_err[j]); ca.c_mid[j] = static_cast<float>(tab.c_mid[j]);
   }
-  ca.c = s->ctl; ca.parity = p;
-  if (S == 1) {
-    hipLaunchKernelGGL(adaptive_control_kernel<1>, dim3(1), dim3(kCtlBlock), 0, st, ca);
-  } else if (S == 6) {
-    hipLaunchKernelGGL(adaptive_control_kernel<6>, dim3(1), dim3(kCtlBlock), 0, st, ca);
-  } else {
+  ca.c = rec; ca.c_next = s->ctl + q; ca.parity = p;
+  if (S != 1 && S != 6) {
     set_error("adjoint_adaptive: no controller kernel for a pair of %d stages", S);
     return GNPDE_EINVAL;
   }
+  if (S == 1) hipLaunchKernelGGL(adaptive_err_kernel<1>, dim3(kErrBlocks), dim3(kBlock), 0, st, ea);
+  else hipLaunchKernelGGL(adaptive_err_kernel<6>, dim3(kErrBlocks), dim3(kBlock), 0, st, ea);
   GNPDE_LAUNCH_CHECK();
   HFinishArgs fa{};
   fa.y = s->Y[p]; fa.y1 = s->Y[q]; fa.f = kf[0]; fa.f1 = kf[S];
@@ -498,11 +575,12 @@ int enqueue_trial(gnpde_adjoint_adaptive* s, int parity, hipStream_t st) {
   fa.uy = s->UY[0]; fa.ua = s->UA[0]; fa.a_out = s->AOUT;
   fa.a00 = static_cast<float>(tab.a[0][0]);
   fa.S = S;
-  fa.n4 = n * r.ld / 4; fa.c = s->ctl; fa.parity = p;
+  fa.n4 = n * r.ld / 4; fa.c = rec; fa.parity = p;
   long long blocks = (fa.n4 + kBlock - 1) / kBlock;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;         // (every block folds the partial rows and takes the decision itself: 32 KB of L2 reads per block)
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adaptive_finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, fa);
+  if (S == 1) hipLaunchKernelGGL(adaptive_finish2_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, ca, fa);
+  else hipLaunchKernelGGL(adaptive_finish2_kernel<6>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, ca, fa);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -617,11 +695,13 @@ extern "C" int gnpde_adjoint_adaptive_run(gnpde_adjoint_adaptive_t* s, const flo
     const float c2[1] = {a00};
     if (int rc = launch_lincomb(s->A[0], w, c2, 1, flat, s->UA[0], st, &s->ctl->h[0])) return rc;
   }
-  for (int parity = 0; parity < 2; ++parity) {
-    if (s->exec[parity] != nullptr) continue;
+  for (int which = 0; which < 4; ++which) {
+    if (s->exec[which] != nullptr) continue;
+    const int parity = which & 1;
     if (s->cap_stream == nullptr) GNPDE_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
     GNPDE_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_trial(s, parity, s->cap_stream);
+    int rc = enqueue_trial(s, parity, s->cap_stream);
+    if (rc == 0 && which >= 2) rc = enqueue_trial(s, 1 - parity, s->cap_stream);      // two trial steps per launch: half the launch gaps
     hipGraph_t gobj = nullptr;
     const hipError_t ec = hipStreamEndCapture(s->cap_stream, &gobj);
     if (rc != 0) {
@@ -632,8 +712,8 @@ extern "C" int gnpde_adjoint_adaptive_run(gnpde_adjoint_adaptive_t* s, const flo
       set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec));
       return static_cast<int>(ec);
     }
-    s->graph_obj[parity] = gobj;
-    GNPDE_HIP(hipGraphInstantiate(&s->exec[parity], gobj, nullptr, nullptr, 0));
+    s->graph_obj[which] = gobj;
+    GNPDE_HIP(hipGraphInstantiate(&s->exec[which], gobj, nullptr, nullptr, 0));
   }
   bool have_record = false;
   for (;;) {
@@ -646,9 +726,14 @@ extern "C" int gnpde_adjoint_adaptive_run(gnpde_adjoint_adaptive_t* s, const flo
       reach += step;
       ++batch;
     }
-    for (int b = 0; b < batch; ++b) GNPDE_HIP(hipGraphLaunch(s->exec[(s->n_launches + b) & 1], st));
+    for (int b = 0; b < batch;) {
+      const int par = (s->n_launches + b) & 1;
+      if (batch - b >= 2) { GNPDE_HIP(hipGraphLaunch(s->exec[2 + par], st)); b += 2; }
+      else { GNPDE_HIP(hipGraphLaunch(s->exec[par], st)); b += 1; }
+    }
     s->n_launches += batch;
-    GNPDE_HIP(hipMemcpyAsync(s->host_ctl, s->ctl, sizeof(HCtl), hipMemcpyDeviceToHost, st));
+    // (trial step k, parity k & 1, leaves the next record in slot (k + 1) & 1)
+    GNPDE_HIP(hipMemcpyAsync(s->host_ctl, s->ctl + (s->n_launches & 1), sizeof(HCtl), hipMemcpyDeviceToHost, st));
     GNPDE_HIP(hipStreamSynchronize(st));
     s->n_syncs += 1;
     have_record = true;
@@ -661,7 +746,7 @@ extern "C" int gnpde_adjoint_adaptive_run(gnpde_adjoint_adaptive_t* s, const flo
   }
   hipLaunchKernelGGL(adaptive_copy_rows_kernel, dim3(static_cast<unsigned>(cb)), dim3(kBlock), 0, st, s->AOUT, r.ld, a, ld_a, n, r.d);
   GNPDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adaptive_store_g_kernel, dim3(1), dim3(1), 0, st, s->ctl, g);
+  hipLaunchKernelGGL(adaptive_store_g_kernel, dim3(1), dim3(1), 0, st, s->ctl + (s->n_launches & 1), g);
   GNPDE_LAUNCH_CHECK();
   if (finished) *finished = 1;
   return 0;
@@ -680,7 +765,7 @@ extern "C" int gnpde_adjoint_adaptive_stats(const gnpde_adjoint_adaptive_t* s, i
 
 extern "C" int gnpde_adjoint_adaptive_destroy(gnpde_adjoint_adaptive_t* s) {
   if (!s) return 0;
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < 4; ++p) {
     if (s->exec[p]) (void)hipGraphExecDestroy(s->exec[p]);
     if (s->graph_obj[p]) (void)hipGraphDestroy(s->graph_obj[p]);
   }
