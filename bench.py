@@ -295,18 +295,25 @@ def secondary_kernels(G, block, x, E, n, ceiling):
   wqk, bqk = lay.qk_weights()
   A, h = lay.attention_dim, lay.h
   d = x.shape[1]
-  qk = ops.linear(x, wqk, bqk)
-  t_lin = timed_replay(lambda: ops.linear(x, wqk, bqk, out=qk), 16)
+  # (the layout the solver uses for this shape: two tables q, k [n, A] when a key row is shorter than a cache line, else rows [n, 2A])
+  split_ok = f.opt['attention_type'] == 'scaled_dot'
+  if split_ok:
+    q_, k_, ldqk, buf = ops.qk_tables(x, wqk, bqk, A)
+    t_lin = timed_replay(lambda: ops.qk_tables(x, wqk, bqk, A, out=buf), 16)
+  else:
+    buf = ops.linear(x, wqk, bqk)
+    q_, k_, ldqk = buf, buf[:, A:], 2 * A
+    t_lin = timed_replay(lambda: ops.linear(x, wqk, bqk, out=buf), 16)
   st = ops.attention_struct(_lib.ATT_TYPES[f.opt['attention_type']], h, A, f.opt['attention_norm_idx'], f.opt['square_plus'],
-                            q=qk, k=qk[:, A:], ldqk=2 * A)
+                            q=q_, k=k_, ldqk=ldqk)
   t_att = timed_replay(lambda: ops.edge_attention(graph, st, True, False, False, like=x), 16)
   b_lin = n * (4 * d + 4 * 2 * A)
   b_att = E * (4 + 4 * A + 4) + n * (16 + 4 * A)
   out = [{'kernel': 'row attention: scores + softmax over the row + head mean (row_attention_sd_kernel, one launch per degree '
                     'class with the hub phases riding)', 'bytes': b_att, 'avg_us': round(t_att * 1e6, 2),
           'gbs': round(b_att / t_att / 1e9, 1)},
-         {'kernel': 'q||k projection [n,d] x [d,2A] on the fp32 MFMA (linear_persistent_kernel / linear_lds_kernel)', 'bytes': b_lin,
-          'avg_us': round(t_lin * 1e6, 2), 'gbs': round(b_lin / t_lin / 1e9, 1)}]
+         {'kernel': 'q||k projection [n,d] x [d,2A] on the fp32 MFMA (linear_staged2_kernel / linear_lds_kernel)', 'bytes': b_lin,
+          'avg_us': round(t_lin * 1e6, 2), 'gbs': round(b_lin / t_lin / 1e9, 1), 'key_table': bool(ldqk == A)}]
   return out
 
 
@@ -417,9 +424,17 @@ def pmc_child(G, block, x, reps=3):
     lay = f.multihead_att_layer
     wqk, bqk = lay.qk_weights()
     A, h = lay.attention_dim, lay.h
-    qk = torch.empty(x.shape[0], 2 * A, dtype=torch.float32, device=dev)     # (filled by the loop: exactly `reps` projection launches)
+    qk = torch.empty(x.shape[0] * 2 * A, dtype=torch.float32, device=dev)     # (filled by the loop: exactly `reps` projection launches)
+    split_ok = f.opt['attention_type'] == 'scaled_dot' and bool(_lib.lib().gnpde_linear_split_supported(
+      _lib.ptr(x), x.shape[0], x.shape[1], x.stride(0), _lib.ptr(wqk), wqk.shape[0], wqk.stride(0), A))
+    if split_ok:      # the solver's layout for this shape: two tables
+      n_ = x.shape[0]
+      q_, k_, ldqk = qk[:n_ * A].view(n_, A), qk[n_ * A:].view(n_, A), A
+    else:
+      q_ = qk.view(x.shape[0], 2 * A)
+      k_, ldqk = q_[:, A:], 2 * A
     att = ops.attention_struct(_lib.ATT_TYPES[f.opt['attention_type']], h, A, f.opt['attention_norm_idx'], f.opt['square_plus'],
-                               q=qk, k=qk[:, A:], ldqk=2 * A)
+                               q=q_, k=k_, ldqk=ldqk)
   # as the solver issues them: EVERY aggregation is preceded by the projection and the row attention of its own stage input (they
   # sweep ~300 MB through the L2s in between: four aggregations back to back would find more of the state still cached than the
   # solve does -- 1.16 instead of 1.24 GB of L2 -> fabric traffic per launch, the difference the round-4 review found between the
@@ -429,7 +444,10 @@ def pmc_child(G, block, x, reps=3):
       kw = dict(st)
       u = kw.pop('u')
       if att is not None:
-        ops.linear(u, wqk, bqk, out=qk)
+        if split_ok:
+          ops.qk_tables(u, wqk, bqk, A, out=qk)
+        else:
+          ops.linear(u, wqk, bqk, out=qk.view(x.shape[0], 2 * A))
         ops.edge_attention(graph, att, True, False, False, like=x)
       ops.spmm_rhs(graph, w, u, alpha, beta, x0, True, dt=1.0, **kw)
   torch.cuda.synchronize()

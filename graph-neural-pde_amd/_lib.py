@@ -141,6 +141,9 @@ PROTOTYPES = {
   'gnpde_adjoint_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, c_vp, c_vp,
                                           ctypes.c_int32, c_float_p, ctypes.c_int32, c_vp, ctypes.c_size_t]),
   'gnpde_adjoint_run': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
+  'gnpde_linear_split_supported': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+  'gnpde_linear_split': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp,
+                                        ctypes.c_int32, c_vp]),
   'gnpde_adjoint_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_solver_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32, ctypes.c_int32]),
   'gnpde_solver_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),

@@ -568,12 +568,16 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   gnpde_attention_t at = r.att;
   const int A = at.att_dim, M = s->M;
   const float* qk = s->qk;
+  const float* kk = nl && !gat ? s->qk + A : s->qk;      // the key side of q||k and the row stride of both (interleaved unless recorded as two tables)
+  int ldq = M;
   const float* wfwd = s->w;
   if (nl && recorded != nullptr) {
     // the forward solve left this evaluation's q||k and weights on the tape: neither the projection nor the attention runs again
     qk = recorded->proj;
     wfwd = recorded->wmean;
-    at.q = qk; at.k = qk + A; at.ldqk = M;
+    if (rhs_key_table(r, uy)) { kk = qk + static_cast<size_t>(n) * A; ldq = A; }     // (as enqueue_rhs wrote them)
+    else { kk = qk + A; ldq = M; }
+    at.q = qk; at.k = kk; at.ldqk = ldq;
     w = wfwd;
   } else if (nl) {
     rc = launch_linear_any(uy, n, d, ld, r.proj_w, M, d, r.proj_b, s->qk, M, st);
@@ -634,15 +638,15 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     if (lanes) {
       // d q over the rows (unless the backward kernel formed it), d k over the rows of the transposed graph
       if (!dq_fused) {
-        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, qk + A, M, inv, s->dqk, M, s->hub_ws, st);
+        rc = launch_head_rowsum(g, nullptr, s->ds, h, dk, kk, ldq, inv, s->dqk, M, s->hub_ws, st);
         if (rc) return rc;
       }
-      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, qk, M, inv, s->dqk + A, M, s->hub_ws, st);
+      rc = launch_head_rowsum(gt, s->t_from_csr, s->ds, h, dk, qk, ldq, inv, s->dqk + A, M, s->hub_ws, st);
       if (rc) return rc;
     } else {
-      rc = gnpde_head_spmm(g, 0, s->ds, h, dk, qk + A, M, inv, s->dqk, M, st);
+      rc = gnpde_head_spmm(g, 0, s->ds, h, dk, kk, ldq, inv, s->dqk, M, st);
       if (rc) return rc;
-      rc = gnpde_head_spmm(g, 1, s->ds, h, dk, qk, M, inv, s->dqk + A, M, st);
+      rc = gnpde_head_spmm(g, 1, s->ds, h, dk, qk, ldq, inv, s->dqk + A, M, st);
       if (rc) return rc;
     }
     if (s->unit_heads) {         // through the normalisation: d (q||k) from the gradient of the unit vectors, in place

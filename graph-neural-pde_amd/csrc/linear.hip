@@ -385,7 +385,10 @@ template <int KB, bool PAIRC, bool DEPTH2, int DIAG = 0>
 __global__ __launch_bounds__(kBlock) void linear_staged2_kernel(const float* __restrict__ x, int n, int ldx,
                                                                 const float* __restrict__ W, int ldw,
                                                                 const float* __restrict__ b, float* __restrict__ out,
-                                                                int ldo, int col_base, int relu) {
+                                                                int ldo, int col_base, int relu, float* __restrict__ out2 = nullptr,
+                                                                int split = 0) {
+  // out2 / split (round 6): output columns >= split go to out2[row * ldo + col - split] -- the q||k projection as TWO tables [n, A] when a
+  // key row is shorter than a cache line (A <= 16: the attention's gathers of 64-byte k rows then fetch no q halves of 128-byte lines)
   // DIAG (A/B diagnostics, gnpde_tune(13, v)): 1 = no output stores (unless a result is NaN), 2 = no LDS / MFMA work (the loads alone)
   constexpr int diag = DIAG;
   constexpr int MT = 2;
@@ -464,10 +467,16 @@ __global__ __launch_bounds__(kBlock) void linear_staged2_kernel(const float* __r
       const long long orow = row0 + 4 * kq + i;
       if (orow < n && (diag != 1 || acc[0][i] != acc[0][i])) {
         if constexpr (PAIRC) {
-          *reinterpret_cast<float2*>(out + static_cast<size_t>(orow) * ldo + col_base + 2 * r) = make_float2(acc[0][i] + bias[0], acc[1][i] + bias[1]);
+          const int c0 = col_base + 2 * r;
+          float* dst = (split > 0 && c0 >= split) ? out2 + static_cast<size_t>(orow) * ldo + (c0 - split) : out + static_cast<size_t>(orow) * ldo + c0;
+          *reinterpret_cast<float2*>(dst) = make_float2(acc[0][i] + bias[0], acc[1][i] + bias[1]);
         } else {
 #pragma unroll
-          for (int t = 0; t < MT; ++t) out[static_cast<size_t>(orow) * ldo + wcol[t]] = acc[t][i] + bias[t];
+          for (int t = 0; t < MT; ++t) {
+            float* dst = (split > 0 && wcol[t] >= split) ? out2 + static_cast<size_t>(orow) * ldo + (wcol[t] - split)
+                                                         : out + static_cast<size_t>(orow) * ldo + wcol[t];
+            *dst = acc[t][i] + bias[t];
+          }
         }
       }
     }
@@ -634,6 +643,31 @@ void launch_linear(const float* x, int n, int d, int ldx, const float* W, int m,
 
 }  // namespace
 
+// The q||k projection as two tables (q [n, A], k [n, A]): offered where a key row is shorter than a 128-byte line and the launch would
+// take the staged kernel anyway (tall x, d = 64 / 128, 2A = 32 output columns, 16-byte aligned operands).
+bool linear_split_supported(const float* x, long long n, int d, int ldx, const float* W, int m, int ldw, int split) {
+  const long long tiles = (n + 15) / 16;
+  return m == 32 && split == 16 && (d == 64 || d == 128) && tiles > kSmallLinearTiles && ldx % 4 == 0 && ldw % 4 == 0 &&
+         reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0 && g_tune[GNPDE_TUNE_LINEAR_STREAMING] == 0 &&
+         g_tune[GNPDE_TUNE_KEY_TABLE] != 1;
+}
+
+int launch_linear_split(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out_q, float* out_k,
+                        int split, hipStream_t s) {
+  GNPDE_CHECK_ARG(x && W && out_q && out_k && linear_split_supported(x, n, d, ldx, W, m, ldw, split) &&
+                  reinterpret_cast<uintptr_t>(out_q) % 8 == 0 && reinterpret_cast<uintptr_t>(out_k) % 8 == 0, GNPDE_ESHAPE,
+                  "linear_split: shape without a two-table kernel (see linear_split_supported)");
+  const long long tiles = (static_cast<long long>(n) + 15) / 16;
+  long long blocks = 256LL * 4;
+  const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > need) blocks = need;
+  const unsigned g2 = static_cast<unsigned>(blocks);
+  if (d == 128) hipLaunchKernelGGL((linear_staged2_kernel<8, true, false>), dim3(g2), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out_q, split, 0, 0, out_k, split);
+  else hipLaunchKernelGGL((linear_staged2_kernel<4, true, false>), dim3(g2), dim3(kBlock), 0, s, x, n, ldx, W, ldw, b, out_q, split, 0, 0, out_k, split);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
                       int ldo, hipStream_t s, int relu) {
   GNPDE_CHECK_ARG(x && W && out, GNPDE_EINVAL, "linear: null pointer");
@@ -653,6 +687,15 @@ int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int
 extern "C" int gnpde_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,
                             const float* b, float* out, int32_t ldo, void* stream) {
   return gnpde::launch_linear_any(x, n, d, ldx, W, m, ldw, b, out, ldo, static_cast<hipStream_t>(stream), 0);
+}
+
+extern "C" int gnpde_linear_split_supported(const float* x, int64_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw, int32_t split) {
+  return gnpde::linear_split_supported(x, n, d, ldx, W, m, ldw, split) ? 1 : 0;
+}
+
+extern "C" int gnpde_linear_split(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw, const float* b,
+                                  float* out_q, float* out_k, int32_t split, void* stream) {
+  return gnpde::launch_linear_split(x, n, d, ldx, W, m, ldw, b, out_q, out_k, split, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnpde_relu_linear(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw,

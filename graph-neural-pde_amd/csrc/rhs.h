@@ -30,6 +30,16 @@ inline RhsRecord rhs_record_at(const gnpde_rhs_t& r, float* base, size_t eval) {
   return RhsRecord{p, p + align_up(static_cast<size_t>(r.graph->n) * r.proj_m * 4, 256) / 4};
 }
 
+// Where q and k of an evaluation's projection lie: interleaved rows [n, 2A] (q = base, k = base + A, stride 2A) or -- GRAND-nl with
+// scaled-dot scores and key rows shorter than a cache line, whole-graph descriptors -- two tables (q = base, k = base + n A, stride A).
+bool linear_split_supported(const float* x, long long n, int d, int ldx, const float* W, int m, int ldw, int split);
+int launch_linear_split(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out_q, float* out_k,
+                        int split, hipStream_t s);
+inline bool rhs_key_table(const gnpde_rhs_t& r, const float* u) {
+  return r.kind == GNPDE_RHS_TRANSFORMER && r.att.type == GNPDE_ATT_SCALED_DOT && r.proj_row_end == 0 && r.n_state_rows <= r.graph->n &&
+         r.proj_m == 2 * r.att.att_dim && linear_split_supported(u, r.graph->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.att.att_dim);
+}
+
 RhsLayout rhs_layout(const gnpde_rhs_t& r);
 int check_rhs(const gnpde_rhs_t* r);
 // Enqueue f(u) with the given epilogue; `ws` follows rhs_layout(r).

@@ -91,14 +91,17 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
       p0 = r.proj_row_begin;
       p1 = r.proj_row_end;
     }
-    int rc = p1 > p0 ? launch_linear_any(u + static_cast<size_t>(p0) * r.ld, p1 - p0, r.d, r.ld, r.proj_w, r.proj_m, r.d,
-                                         r.proj_b, proj + static_cast<size_t>(p0) * r.proj_m, r.proj_m, s)
-                     : 0;
+    const bool key_table = rhs_key_table(r, u);       // q and k as two tables: the k gathers of the attention fetch whole lines of keys
+    int rc = 0;
+    if (key_table) rc = launch_linear_split(u, g->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.proj_b, proj, proj + static_cast<size_t>(g->n) * r.att.att_dim,
+                                            r.att.att_dim, s);
+    else if (p1 > p0) rc = launch_linear_any(u + static_cast<size_t>(p0) * r.ld, p1 - p0, r.d, r.ld, r.proj_w, r.proj_m, r.d,
+                                             r.proj_b, proj + static_cast<size_t>(p0) * r.proj_m, r.proj_m, s);
     if (rc) return rc;
     gnpde_attention_t at = r.att;
-    at.ldqk = r.proj_m;
+    at.ldqk = key_table ? r.att.att_dim : r.proj_m;
     at.q = proj;
-    at.k = r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj;
+    at.k = key_table ? proj + static_cast<size_t>(g->n) * r.att.att_dim : (r.kind == GNPDE_RHS_TRANSFORMER ? proj + r.att.att_dim : proj);
     if (r.kind == GNPDE_RHS_TRANSFORMER && (at.type == GNPDE_ATT_COSINE || at.type == GNPDE_ATT_PEARSON) &&
         at.heads >= 1 && at.att_dim % at.heads == 0) {
       // cosine_sim / pearson (reference src/function_transformer_attention.py:198-206) = the scaled dot product of unit (mean-centred)

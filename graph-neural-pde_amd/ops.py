@@ -59,6 +59,27 @@ def linear(x, weight, bias=None, out=None, relu_input=False):
   return out
 
 
+def qk_tables(x, weight, bias, att_dim, out=None):
+  """(q, k, ldqk, buffer) of the q||k projection in the layout the SOLVERS use for this shape: two tables [n, A] when a key row is
+  shorter than a cache line and gnpde_linear_split_supported says so, else interleaved rows [n, 2A] (measurement aids: bench.py times
+  the projection and the attention on what the solver launches)."""
+  require_hip(x, weight, bias)
+  x, weight = _lib.f32rows(x, 'x'), f32c(weight, 'weight')
+  n, d = x.shape
+  m = weight.shape[0]
+  L = _lib.lib()
+  if out is None:
+    out = torch.empty(n * m, dtype=torch.float32, device=x.device)
+  flat = out.reshape(-1)
+  if m == 2 * att_dim and L.gnpde_linear_split_supported(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), att_dim):
+    q, k = flat[:n * att_dim].view(n, att_dim), flat[n * att_dim:].view(n, att_dim)
+    check(L.gnpde_linear_split(ptr(x), n, d, x.stride(0), ptr(weight), m, weight.stride(0), ptr(None if bias is None else f32c(bias, 'bias')),
+                               ptr(q), ptr(k), att_dim, stream_of(x)))
+    return q, k, att_dim, out
+  qk = linear(x, weight, bias, out=flat.view(n, m))
+  return qk, qk[:, att_dim:], m, out
+
+
 def edge_to_csr_mean(graph, src_edge, out=None):
   """w_csr[p] = mean over heads of src_edge[perm[p]]; src_edge is [E] or [E,h] in edge order."""
   require_hip(src_edge)

@@ -439,6 +439,15 @@ int gnpde_solver_run(gnpde_solver_t* s, float* y, int32_t use_graph, void* strea
 size_t gnpde_solver_tape_bytes(const gnpde_rhs_t* rhs, int32_t method, int32_t n_steps);
 int    gnpde_solver_set_tape(gnpde_solver_t* s, void* tape, size_t tape_bytes);
 
+/* The q||k projection of SpGraphTransAttentionLayer (nn.Linear Q and K, reference src/function_transformer_attention.py:174-175) as TWO
+ * tables q [n, A], k [n, A] instead of interleaved rows [n, 2A]: when a key row is shorter than a 128-byte cache line (A <= 16) the
+ * attention's gathers of k rows otherwise fetch the q half of every line.  Offered (gnpde_linear_split_supported != 0) for tall x,
+ * d = 64 / 128, m = 2A = 32, 16-byte aligned operands; the fixed-step / dopri5 solvers use it by themselves for whole-graph GRAND-nl
+ * descriptors with scaled-dot scores (gnpde_attention_t.q / k / ldqk already describe either layout). */
+int gnpde_linear_split_supported(const float* x, int64_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw, int32_t split);
+int gnpde_linear_split(const float* x, int32_t n, int32_t d, int32_t ldx, const float* W, int32_t m, int32_t ldw, const float* b,
+                       float* out_q, float* out_k, int32_t split, void* stream);
+
 /* One un-fused evaluation out = f(u) of the same descriptor (what ODEFunc.forward returns). */
 int gnpde_rhs_eval(const gnpde_rhs_t* rhs, const float* u, float* out, void* workspace,
                    size_t workspace_bytes, void* stream);

@@ -577,3 +577,46 @@ def test_source_term_copy_follows_the_callers_tensor(dev, mode):
   b.mul_(2.0)                                             # the same tensor, written in place
   zb2 = solve(block, b)
   assert torch.equal(zb2, solve(fresh, b)) and not torch.equal(zb2, zb)
+
+
+def test_key_table_layout_is_bit_identical_to_interleaved_rows(dev):
+  """Round 6: where a key row is shorter than a cache line (A = 16) the solvers write q and k of every evaluation as two tables [n, A]
+  (gnpde_linear_split) instead of interleaved rows [n, 2A].  Same MFMA sequence, same attention arithmetic: the inference solve, the
+  recorded training solve and its gradients are bitwise equal to the interleaved layout (gnpde_tune(14, 1))."""
+  from gnpde_amd import ops, _lib
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.25)
+  assert n > 32768
+  x = torch.randn(n, 128, generator=torch.Generator().manual_seed(4)).to(dev)
+  opt = dict(BASE, time=2.0)
+  c = torch.randn(n, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+
+  def run(knob):
+    ops.tune(14, knob)
+    try:
+      torch.manual_seed(11)        # (nn.Linear draws its default biases from the global generator: the same block both times)
+      block = _block(opt, ei.to(dev), n, x, dev)
+      lay = block.odefunc.multihead_att_layer
+      wqk, _ = lay.qk_weights()
+      split = bool(_lib.lib().gnpde_linear_split_supported(_lib.ptr(x), n, 128, x.stride(0), _lib.ptr(wqk), wqk.shape[0], wqk.stride(0),
+                                                           lay.attention_dim))
+      block.set_x0(x)
+      with torch.no_grad():
+        z = block(x)
+      block.train()
+      xin = x.clone().requires_grad_(True)
+      block.set_x0(xin)
+      zt = block(xin)
+      (zt * c).sum().backward()
+      grads = {k: p.grad.clone() for k, p in block.named_parameters() if p.grad is not None}
+      return split, z, zt.detach(), xin.grad.clone(), grads, str(block.odefunc._last_train_solve)
+    finally:
+      ops.tune(14, 0)
+  s1, z1, zt1, gx1, g1, path1 = run(0)
+  s0, z0, zt0, gx0, g0, path0 = run(1)
+  assert s1 and not s0, 'layout selection: %s / %s' % (s1, s0)
+  assert path1.startswith('native recorded fixed-grid') and path0.startswith('native recorded fixed-grid')
+  assert torch.equal(z1, z0) and torch.equal(zt1, zt0) and torch.equal(gx1, gx0)
+  assert set(g1) == set(g0) and all(torch.equal(g1[k], g0[k]) for k in g1)
+  # and against the oracle
+  torch.manual_seed(11)
+  assert_parity(z1, R.odeint_fixed(_oracle_rhs(_block(opt, ei.to(dev), n, x, dev), x.cpu()), x.cpu(), 2.0, 1.0, 'rk4'), what='key table solve')
