@@ -381,6 +381,49 @@ __global__ __launch_bounds__(kBlock) void gat_dwx_kernel(const float* __restrict
   }
 }
 
+// ---- exp kernel (reference src/function_transformer_attention.py:193-194): score_eh = ov^2 exp(-|q_ih - k_jh|^2 / (2 l^2)).  With
+// c_eh = dL/d(score) score from the normaliser backward, S1_ih = sum_row c, S2_jh = sum_col c, T_ih = sum_row c k_jh, U_jh = sum_col c q_ih:
+//     d q_ih = (T_ih - S1_ih q_ih) / l^2,   d k_jh = (U_jh - S2_jh k_jh) / l^2,
+//     d ov = 2 sum_ih S1_ih / ov,   d l = sum_e c_e |q_i - k_j|^2 / l^3 = sum_ih (S1_ih |q_ih|^2 - 2 q_ih . T_ih + S2_ih |k_ih|^2) / l^3.
+// In place on dqk = [T | U] (interleaved rows [n, 2A]); block b of the slab grid also leaves its share of (d ov, d l) in
+// partial[b][slot], partial[b][slot + 1].  One thread per column of the 2A-wide row, rows of the slab in order.
+__global__ __launch_bounds__(kBlock) void exp_node_bwd_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ q,
+                                                             const float* __restrict__ k, int ldq, float* __restrict__ dqk, int n, int A, int h,
+                                                             const float* __restrict__ lengthscale, const float* __restrict__ output_var,
+                                                             int rows_per_block, float* __restrict__ partial, int stride, int slot) {
+  __shared__ float red[2][kWavesPerBlock];
+  const int dk = A / h;
+  const int col = threadIdx.x;                 // [0, 2A): q side then k side
+  const int r0 = static_cast<int>(blockIdx.x) * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  const float l = *lengthscale, ov = *output_var;
+  const float inv_l2 = 1.0f / (l * l);
+  float acc_l = 0.f, acc_ov = 0.f;
+  if (col < 2 * A) {
+    const bool kside = col >= A;
+    const int c = kside ? col - A : col;
+    const int hh = c / dk;
+    for (int i = r0; i < r1; ++i) {
+      const float sv = (kside ? s2 : s1)[static_cast<size_t>(i) * h + hh];
+      const float v = (kside ? k : q)[static_cast<size_t>(i) * ldq + c];
+      const float t = dqk[static_cast<size_t>(i) * 2 * A + col];
+      acc_l += kside ? sv * v * v : sv * v * v - 2.0f * v * t;
+      if (!kside && c == hh * dk) acc_ov += sv;          // (one column per head carries S1_ih)
+      dqk[static_cast<size_t>(i) * 2 * A + col] = (t - sv * v) * inv_l2;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { acc_l += __shfl_xor(acc_l, off, kWave); acc_ov += __shfl_xor(acc_ov, off, kWave); }
+  if ((threadIdx.x & (kWave - 1)) == 0) { red[0][threadIdx.x >> 6] = acc_l; red[1][threadIdx.x >> 6] = acc_ov; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* out = partial + static_cast<size_t>(blockIdx.x) * stride + slot;
+    out[0] = 2.0f * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / ov;
+    out[1] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (l * l * l);
+  }
+}
+
 // partial[b][slot + {c, d_k + c}] = this slab's share of d a; the rest of the M slots behind `slot` (where the Gram kernels left the
 // column sums of d wx -- GAT's projection has no bias) is zeroed.  One thread per column of wx, rows of the slab in order.
 __global__ __launch_bounds__(kBlock) void gat_da_partial_kernel(const float* __restrict__ dts, const float* __restrict__ dtd, const float* __restrict__ wx,
@@ -434,6 +477,7 @@ struct gnpde_adjoint {
   size_t state_bytes;
   float *uy[2], *ua[2], *F[4], *V[3], *P, *qk, *dqk, *w, *w_t, *r, *ds, *partial, *one, *dots, *hub_ws, *qk_inv;
   float *gts = nullptr, *gtd = nullptr;      // GAT: [n, h] head sums of c over the rows / over the columns
+  int extra = 0;             // gradient slots behind the Gram block and the bias sums: 2 for the exp kernel (d output_var, d lengthscale)
   int unit_heads = 0;        // 1: cosine_sim, 2: pearson -- scores are the scaled dot product of normalised (mean-centred) head vectors
   int n_dots;
   char *ws_att, *ws_attbwd, *ws_spmm, *ws_spmm_t;
@@ -484,7 +528,10 @@ int check_adjoint(const gnpde_rhs_t* rhs, const gnpde_graph_t* gt, int method) {
     const gnpde_attention_t& at = rhs->att;
     const int a4 = at.att_dim / 4;
     const bool unit = at.type == GNPDE_ATT_COSINE || at.type == GNPDE_ATT_PEARSON;
-    GNPDE_CHECK_ARG(at.type == GNPDE_ATT_SCALED_DOT || unit, GNPDE_ESHAPE, "adjoint: scaled-dot, cosine_sim and pearson scores");
+    const bool expk = at.type == GNPDE_ATT_EXP_KERNEL;
+    GNPDE_CHECK_ARG(at.type == GNPDE_ATT_SCALED_DOT || unit || expk, GNPDE_ESHAPE, "adjoint: scaled-dot, cosine_sim, pearson and exp_kernel scores");
+    GNPDE_CHECK_ARG(!expk || (at.output_var && at.lengthscale && 2 * at.att_dim <= kBlock && at.heads <= kGatMaxHeads), GNPDE_ESHAPE,
+                    "adjoint (exp kernel): scalars missing, attention_dim > 128 or more than 8 heads");
     GNPDE_CHECK_ARG(!unit || (at.heads >= 1 && normalise_heads_bwd_supported(at.att_dim, at.heads)), GNPDE_ESHAPE,
                     "adjoint: cosine_sim / pearson need d_k in {4, 8, 16}");
     GNPDE_CHECK_ARG(at.att_dim % at.heads == 0 && (at.att_dim / at.heads) % 4 == 0 && a4 <= 64 && (a4 & (a4 - 1)) == 0, GNPDE_ESHAPE,
@@ -523,12 +570,13 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     o_hub = take((hub_f > hub_ft ? hub_f : hub_ft) * 4 + 256);
     att_b = attention_workspace_bytes(&g, r.att.heads, gat);
     attbwd_b = gnpde_attention_bwd_workspace_bytes(&g, &r.att);
-    if (gat) { o_dts = take(static_cast<size_t>(g.n) * r.att.heads * 4); o_dtd = take(static_cast<size_t>(g.n) * r.att.heads * 4); }
+    if (gat || r.att.type == GNPDE_ATT_EXP_KERNEL) { o_dts = take(static_cast<size_t>(g.n) * r.att.heads * 4); o_dtd = take(static_cast<size_t>(g.n) * r.att.heads * 4); }
   }
+  const int extra = (r.kind == GNPDE_RHS_TRANSFORMER && r.att.type == GNPDE_ATT_EXP_KERNEL) ? 2 : 0;
   const size_t o_att = take(att_b), o_attbwd = take(attbwd_b);
   const size_t spmm_b = gnpde_spmm_workspace_bytes(&g, r.d), spmm_t_b = gnpde_spmm_workspace_bytes(&gt, r.d);
   const size_t o_spmm = take(spmm_b), o_spmm_t = take(spmm_t_b);
-  const int stride = M * r.d + M + 2;
+  const int stride = M * r.d + M + extra + 2;
   const size_t o_part = take(static_cast<size_t>(kParamBlocks) * stride * 4);
   if (s) {
     char* b = s->ws;
@@ -542,7 +590,8 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     s->dots = f(o_dots); s->n_dots = n_dots;
     s->hub_ws = nl ? f(o_hub) : nullptr;
     s->qk_inv = nl ? f(o_inv) : nullptr;
-    s->gts = gat ? f(o_dts) : nullptr; s->gtd = gat ? f(o_dtd) : nullptr;
+    s->gts = (gat || extra) ? f(o_dts) : nullptr; s->gtd = (gat || extra) ? f(o_dtd) : nullptr;
+    s->extra = extra;
     s->ws_att = b + o_att; s->ws_attbwd = b + o_attbwd; s->ws_spmm = b + o_spmm; s->ws_spmm_t = b + o_spmm_t;
     s->att_bytes = att_b; s->attbwd_bytes = attbwd_b; s->spmm_bytes = spmm_b; s->spmm_t_bytes = spmm_t_b;
     s->partial = f(o_part);
@@ -604,7 +653,35 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   if (rc) return rc;
   const float* source = nullptr;
   const float* source_scale = nullptr;
-  if (gat) {
+  int rows_per_block = (n + kParamBlocks - 1) / kParamBlocks;      // slab grid of the parameter-gradient passes
+  if (rows_per_block < 4) rows_per_block = 4;
+  const int nb = (n + rows_per_block - 1) / rows_per_block;
+  if (nl && !gat && at.type == GNPDE_ATT_EXP_KERNEL) {
+    const int h = at.heads, dk = A / h;
+    rc = launch_edge_attention_bwd(g, &at, s->r, nullptr, 1, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
+    if (rc) return rc;
+    const unsigned gr = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(gat_head_sums_kernel, dim3(gr), dim3(kBlock), 0, st, g->rowptr, static_cast<const int*>(nullptr), s->ds, n, h, s->gts);
+    GNPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_head_sums_kernel, dim3(gr), dim3(kBlock), 0, st, gt->rowptr, s->t_from_csr, s->ds, n, h, s->gtd);
+    GNPDE_LAUNCH_CHECK();
+    rc = gnpde_head_spmm(g, 0, s->ds, h, dk, kk, ldq, 1.0f, s->dqk, M, st);            // T = sum_row c k
+    if (rc) return rc;
+    rc = gnpde_head_spmm(g, 1, s->ds, h, dk, qk, ldq, 1.0f, s->dqk + A, M, st);        // U = sum_col c q
+    if (rc) return rc;
+    hipLaunchKernelGGL(exp_node_bwd_kernel, dim3(nb), dim3(kBlock), 0, st, s->gts, s->gtd, qk, kk, ldq, s->dqk, n, A, h, at.lengthscale, at.output_var,
+                       rows_per_block, s->partial, s->stride, M * d + M);
+    GNPDE_LAUNCH_CHECK();
+    rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
+    if (rc) return rc;
+    if (g->e > 0) {
+      hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
+      GNPDE_LAUNCH_CHECK();
+    }
+    wt = s->w_t;
+    source = s->P;
+    source_scale = s->one;
+  } else if (gat) {
     const int h = at.heads;
     rc = launch_edge_attention_bwd(g, &at, s->r, nullptr, 2, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
     if (rc) return rc;
@@ -676,9 +753,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
   ParamArgs p{};
   p.dqk = nl ? s->dqk : nullptr; p.uy = uy; p.ua = ua; p.F = Fout; p.x0 = r.x0;
   p.n = n; p.d = d; p.ld = ld; p.M = M;
-  p.rows_per_block = (n + kParamBlocks - 1) / kParamBlocks;
-  if (p.rows_per_block < 4) p.rows_per_block = 4;
-  const int nb = (n + p.rows_per_block - 1) / p.rows_per_block;
+  p.rows_per_block = rows_per_block;
   p.stride = s->stride; p.partial = s->partial;
   const bool gram_mfma = nl && (M == 16 || M == 32 || M == 64) && d % 64 == 0 && d <= 256 && d * (M / 16) <= 512 && ld % 4 == 0 &&
                          reinterpret_cast<uintptr_t>(uy) % 16 == 0 && g_tune[GNPDE_TUNE_ADJOINT_GRAM] != 1;
@@ -702,9 +777,9 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     hipLaunchKernelGGL(gat_da_partial_kernel, dim3(nb), dim3(kBlock), 0, st, s->gts, s->gtd, qk, n, M, at.heads, p.rows_per_block, s->partial, s->stride, M * d);
     GNPDE_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, s->n_dots, nb, s->partial, s->stride, M * d + M);
+  hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, s->n_dots, nb, s->partial, s->stride, M * d + M + s->extra);
   GNPDE_LAUNCH_CHECK();
-  const int n_plain = M * d + M;
+  const int n_plain = M * d + M + s->extra;
   hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 31) / 32), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
                      pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, r.alpha_sigmoid, grads);
   GNPDE_LAUNCH_CHECK();
@@ -857,7 +932,8 @@ void drop_adjoint_graph(gnpde_adjoint* s) {
 extern "C" int gnpde_adjoint_grad_floats(const gnpde_rhs_t* rhs) {
   if (!rhs) return 0;
   const int M = rhs->kind != GNPDE_RHS_LAPLACIAN ? rhs->proj_m : 0;
-  return M * rhs->d + M + 2;
+  const int extra = (rhs->kind == GNPDE_RHS_TRANSFORMER && rhs->att.type == GNPDE_ATT_EXP_KERNEL) ? 2 : 0;
+  return M * rhs->d + M + extra + 2;
 }
 
 extern "C" size_t gnpde_adjoint_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, int32_t method) {

@@ -602,7 +602,7 @@ def _solve_dopri5_recorded(func, y0, t, rtol, atol):
 # --------------------------------------------------------------------------------------------------
 def _transformer_stage_native(func):
   """GRAND-nl per-evaluation attention the native VJP stage of csrc/adjoint.hip covers: scaled-dot scores, and (round 6) cosine_sim /
-  pearson -- the scaled dot product of unit (mean-centred) head vectors, d_k in {4, 8, 16} -- with any normaliser."""
+  pearson -- the scaled dot product of unit (mean-centred) head vectors, d_k in {4, 8, 16} -- and exp_kernel, with any normaliser."""
   lay, opt = func.multihead_att_layer, func.opt
   a4 = lay.attention_dim // 4
   if opt['mix_features'] or getattr(lay, 'split_kernel', False):
@@ -611,6 +611,8 @@ def _transformer_stage_native(func):
     return False
   if opt['attention_type'] == 'scaled_dot':
     return True
+  if opt['attention_type'] == 'exp_kernel':       # (round 6; the BLEND split kernel -- two exp kernels multiplied -- keeps the stage loop)
+    return lay.attention_dim <= 128 and lay.h <= 8
   return opt['attention_type'] in ('cosine_sim', 'pearson') and lay.d_k in (4, 8, 16)
 
 
@@ -671,6 +673,10 @@ def _grad_vector_by_param(func, g, d):
     gb = g[2 * A * d:2 * A * d + 2 * A]
     by_param = {id(lay.Q.weight): gram[:A], id(lay.K.weight): gram[A:], id(lay.Q.bias): gb[:A], id(lay.K.bias): gb[A:]}
     tail = 2 * A * d + 2 * A
+    if func.opt['attention_type'] == 'exp_kernel':      # two more slots: d output_var, d lengthscale
+      by_param[id(lay.output_var)] = g[tail].reshape(lay.output_var.shape)
+      by_param[id(lay.lengthscale)] = g[tail + 1].reshape(lay.lengthscale.shape)
+      tail += 2
   elif func.__class__.__name__ == 'ODEFuncAtt':      # d W^T [A, d], then d a in the first 2 d_k of the A slots behind it
     lay = func.multihead_att_layer
     A = lay.attention_dim

@@ -37,6 +37,10 @@ def _run(dev, opt, ei, x, seed, host):
     for f in (block.odefunc, block.reg_odefunc.odefunc):
       f.alpha_train.fill_(0.3)
       f.beta_train.fill_(0.2)
+      lay = getattr(f, 'multihead_att_layer', None)
+      if lay is not None and hasattr(lay, 'lengthscale'):       # exp kernel: scalars away from their initial 1
+        lay.lengthscale.fill_(1.7)
+        lay.output_var.fill_(0.8)
   block.train()
   xin = x.clone().requires_grad_(True)
   block.set_x0(xin)
@@ -73,6 +77,9 @@ CASES = {
   'nl_raw_alpha': dict(no_alpha_sigmoid=True),
   'nl_raw_alpha_cols_euler': dict(no_alpha_sigmoid=True, attention_norm_idx=1, adjoint_method='euler', adjoint_step_size=0.5),
   'l_raw_alpha': dict(function='laplacian', no_alpha_sigmoid=True),
+  # exp_kernel scores: d q / d k through the squared distance, d output_var and d lengthscale
+  'nl_exp_kernel': dict(attention_type='exp_kernel'),
+  'nl_exp_kernel_cols_squareplus': dict(attention_type='exp_kernel', attention_norm_idx=1, square_plus=True, attention_dim=32, heads=2, time=2.3),
   # the GAT function (reference src/function_GAT_attention.py) on the native stage
   'gat_rk4': dict(function='GAT'),
   'gat_cols_euler_h8': dict(function='GAT', attention_norm_idx=1, attention_dim=64, heads=8, adjoint_method='euler', adjoint_step_size=0.5),
@@ -86,7 +93,7 @@ CASES = {
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_native_adjoint_matches_stage_loop(dev, case):
   opt = _opt(**CASES[case])
-  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16', 'nl_d128_mfma', 'gat_rk4') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
+  hubs = 2 if case in ('nl_rk4', 'l_rk4', 'nl_d162_padded', 'nl_heads8_dk16', 'nl_d128_mfma', 'gat_rk4', 'nl_exp_kernel') else 0     # (d = 80 with hubs: the row-pair kernel's chunk and long-row paths)
   n = 21000 if case == 'nl_d128_mfma' else 700       # (21000 rows: 42-row slabs -- several K steps per wave, ragged last steps)
   ei = random_graph(n, 6, seed=11, hubs=hubs, hub_deg=700, isolated=3, dup=20).to(dev)
   x = (0.5 * torch.randn(n, opt['hidden_dim'], generator=torch.Generator().manual_seed(3))).to(dev)

@@ -311,6 +311,11 @@ def _fixed_block(dev, kind, block_kind, n, d, heads, A, seed, method, time, step
         p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
       else:
         p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(dev))
+    for f in (block.odefunc, block.reg_odefunc.odefunc):
+      lay = getattr(f, 'multihead_att_layer', None)
+      if lay is not None and hasattr(lay, 'lengthscale'):       # exp kernel: a length scale near zero would underflow every score
+        lay.lengthscale.fill_(1.7)
+        lay.output_var.fill_(0.8)
   return block, x
 
 
@@ -332,6 +337,7 @@ FIXED_CASES = {
   'nl_cosine_cols_euler': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=2, A=32, method='euler', time=2.0, step_size=0.5,
                                attention_type='cosine_sim', attention_norm_idx=1, square_plus=True),
   'nl_raw_alpha_rk4': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
+  'nl_exp_kernel_rk4': dict(kind='transformer', block_kind='constant', n=800, d=32, heads=4, A=16, method='rk4', time=2.3, attention_type='exp_kernel'),
   'gat_rk4_hubs': dict(kind='GAT', block_kind='constant', n=1500, d=32, heads=4, A=16, method='rk4', time=2.3, hubs=2, hub_deg=700),
   'gat_midpoint_cols': dict(kind='GAT', block_kind='constant', n=700, d=48, heads=2, A=32, method='midpoint', time=2.0, step_size=0.5, attention_norm_idx=1),
   'l_attention_raw_alpha_rk4': dict(kind='laplacian', block_kind='attention', n=800, d=32, heads=4, A=16, method='rk4', time=2.0, no_alpha_sigmoid=True),
