@@ -824,9 +824,33 @@ class _RecordedFixedGrid(torch.autograd.Function):
     return (dy0, dw, None, None, None) + tuple(gparams)
 
 
+_FIXED_TAPE_BUDGET_BYTES = 96 << 30     # a recorded fixed-grid solve that would need more than this (or more than 70 % of the free device memory) runs the host loop
+
+
+def _fixed_tape_estimate(func, y0, n_evals):
+  """Bytes of the record of a fixed-grid solve: n_evals + 1 stage inputs and, for GRAND-nl with scaled-dot scores, q||k and the weights
+  of every evaluation (csrc/solver.hip gnpde_solver_tape_bytes; an upper estimate without building the descriptor)."""
+  n, d = y0.shape
+  ld = (d + 3) // 4 * 4
+  total = (n_evals + 1) * n * ld * 4
+  lay = getattr(func, 'multihead_att_layer', None)
+  if func.__class__.__name__ == 'ODEFuncTransformerAtt' and lay is not None and func.edge_index is not None:
+    total += n_evals * (n * 2 * lay.attention_dim * 4 + int(func.edge_index.shape[1]) * 4)
+  return total
+
+
 def _solve_fixed_recorded(func, y0, t, method, step_size):
   grid = time_grid(t.detach().to('cpu'), step_size)
   dts = tuple((grid[1:] - grid[:-1]).tolist())
+  need = _fixed_tape_estimate(func, y0, len(dts) * _EVALS_PER_STEP[method])
+  try:
+    free = torch.cuda.mem_get_info(y0.device)[0]
+  except Exception:   # noqa: BLE001
+    free = _FIXED_TAPE_BUDGET_BYTES
+  cached = func.__dict__.get('_fixed_tape_state')          # (a tape of this shape that already exists is not allocated again)
+  if not cached and need > min(_FIXED_TAPE_BUDGET_BYTES, 0.7 * free):
+    func._last_train_solve = 'differentiable host loop (the record of %d evaluations would take %.1f GB)' % (len(dts) * _EVALS_PER_STEP[method], need / 1e9)
+    return _solve_fixed_host(func, y0, t, method, step_size)
   params = tuple(p for p in func.parameters() if p.requires_grad)
   edge_values = None
   if func.__class__.__name__ == 'LaplacianODEFunc':

@@ -399,3 +399,15 @@ def test_fixed_grid_backward_after_a_later_forward_fails_loudly(dev):
   zb.sum().backward()
   with pytest.raises(G.GnpdeError):
     za.sum().backward()
+
+
+def test_recorded_fixed_grid_falls_back_to_the_host_loop_beyond_its_memory_budget(dev, monkeypatch):
+  """A record that would not fit (budget: 96 GiB or 70 % of the free device memory) is never allocated: the differentiable host loop runs
+  instead and says so."""
+  monkeypatch.setattr(O, '_FIXED_TAPE_BUDGET_BYTES', 1 << 16)
+  block, x = _fixed_block(dev, seed=64, **FIXED_CASES['nl_d22_euler'])
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+  z, gx, g, nfe = _train_once(block, x, dev, c)
+  assert str(block.odefunc._last_train_solve).startswith('differentiable host loop'), block.odefunc._last_train_solve
+  assert not block.odefunc.__dict__.get('_fixed_tape_state')
+  assert torch.isfinite(gx).all()
