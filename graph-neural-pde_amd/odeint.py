@@ -470,6 +470,20 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
 # --------------------------------------------------------------------------------------------------
 # recorded dopri5: training WITHOUT the adjoint method (reference default opt['adjoint'] = False; best_params Cora / Citeseer)
 # --------------------------------------------------------------------------------------------------
+def _tape_busy(func, name):
+  """True while the record of an earlier forward pass of this function is still waiting for its backward (the autograd node of that pass
+  is alive and has not run): the next differentiated solve then takes the host loop instead of overwriting it -- two forwards before
+  one backward (siamese losses, gradient accumulation over two graphs) stay differentiable, as in the reference."""
+  ref = func.__dict__.get(name)
+  ctx = ref() if ref is not None else None
+  return ctx is not None and not getattr(ctx, 'gnpde_consumed', False)
+
+
+def _tape_claim(func, name, ctx):
+  import weakref
+  func.__dict__[name] = weakref.ref(ctx)
+
+
 _TAPE_BUDGET_BYTES = 8 << 30     # first tape allocation (it grows when a solve accepts more steps than it holds)
 
 
@@ -561,12 +575,14 @@ class _RecordedDopri5(torch.autograd.Function):
     ctx.heads = edge_values.shape[1] if edge_values.dim() == 2 else 0
     ctx.save_for_backward(w_t, alpha_train, beta_train)
     func._last_train_solve = 'native recorded-tape dopri5'
+    _tape_claim(func, '_tape_live_dopri5', ctx)
     return out
 
   @staticmethod
   def backward(ctx, grad_out):
     w_t, alpha_train, beta_train = ctx.saved_tensors
     sol, gt, E = ctx.sol, ctx.gt, ctx.e
+    ctx.gnpde_consumed = True
     if sol.handle is None or sol.tape_generation != ctx.gen:
       raise _lib.GnpdeError('recorded dopri5: the tape of this forward pass was overwritten by a later solve of the same function '
                             '(backward must run before the next training forward; opt["gnpde_host_dopri5_training"] = True keeps a tape per forward)')
@@ -591,6 +607,9 @@ class _RecordedDopri5(torch.autograd.Function):
 
 
 def _solve_dopri5_recorded(func, y0, t, rtol, atol):
+  if _tape_busy(func, '_tape_live_dopri5'):
+    func._last_train_solve = 'differentiable host loop (the record of an earlier forward pass still awaits its backward)'
+    return _solve_dopri5(func, y0, t, rtol, atol)
   return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, float(t[0]), float(t[-1]), float(rtol),
                                float(atol))
 
@@ -755,12 +774,14 @@ class _RecordedFixedGrid(torch.autograd.Function):
     ctx.heads = 0 if edge_values is None else (edge_values.shape[1] if edge_values.dim() == 2 else 0)
     ctx.has_edge_values = edge_values is not None
     func._last_train_solve = 'native recorded fixed-grid %s' % method
+    _tape_claim(func, '_tape_live_fixed', ctx)
     return out
 
   @staticmethod
   def backward(ctx, grad_out):
     from . import ops
     func, ent, graph, view, desc = ctx.func, ctx.ent, ctx.graph, ctx.view, ctx.desc
+    ctx.gnpde_consumed = True
     sol = ent['solver']
     if sol is None or sol.handle is None or sol.tape_generation != ctx.gen:
       raise _lib.GnpdeError('recorded fixed-grid solve: the tape of this forward pass was overwritten by a later solve of the same function '
@@ -847,6 +868,9 @@ def _solve_fixed_recorded(func, y0, t, method, step_size):
     free = torch.cuda.mem_get_info(y0.device)[0]
   except Exception:   # noqa: BLE001
     free = _FIXED_TAPE_BUDGET_BYTES
+  if _tape_busy(func, '_tape_live_fixed'):
+    func._last_train_solve = 'differentiable host loop (the record of an earlier forward pass still awaits its backward)'
+    return _solve_fixed_host(func, y0, t, method, step_size)
   cached = func.__dict__.get('_fixed_tape_state')          # (a tape of this shape that already exists is not allocated again)
   if not cached and need > min(_FIXED_TAPE_BUDGET_BYTES, 0.7 * free):
     func._last_train_solve = 'differentiable host loop (the record of %d evaluations would take %.1f GB)' % (len(dts) * _EVALS_PER_STEP[method], need / 1e9)

@@ -144,27 +144,47 @@ def test_tape_grows_when_a_solve_accepts_more_steps_than_it_holds(dev, monkeypat
   assert_parity(gx1, gx2, 2e-4, 'grad_x after the tape grew')
 
 
-def test_backward_after_a_later_forward_fails_loudly(dev):
+def test_two_forwards_before_one_backward_stay_differentiable(dev):
+  """Round 6 (advisor item): while the record of forward A awaits its backward, forward B of the same function takes the differentiable
+  host loop instead of overwriting it -- both backward passes run, as they do in the reference, and agree with a fresh single pass."""
   block, x, ei, opt = _cora_like(dev, n=300, d=16, heads=4, A=16, seed=51, time=2.0, tol_scale=100.0)
   block.train()
   xa = x.to(dev).clone().requires_grad_(True)
   block.set_x0(xa)
   za = block(xa)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded')
   xb = x.to(dev).clone().requires_grad_(True)
   block.set_x0(xb)
   zb = block(xb)
+  assert str(block.odefunc._last_train_solve).startswith('differentiable host loop')
   zb.sum().backward()
-  with pytest.raises(G.GnpdeError):
-    za.sum().backward()
+  za.sum().backward()
+  assert_parity(xa.grad, xb.grad, 2e-4, 'grad_x of the recorded pass vs the host-loop pass')
+  # the record is free again: the next pass is recorded
+  xc = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xc)
+  block(xc).sum().backward()
+  assert str(block.odefunc._last_train_solve).startswith('native recorded')
+  # an abandoned forward pass (output dropped, no backward) does not block the record either
+  xd = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xd)
+  zd = block(xd)
+  del zd
+  import gc
+  gc.collect()
+  xe = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xe)
+  block(xe)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded')
 
 
-def test_backward_after_a_later_forward_that_outgrew_the_tape_fails_loudly(dev, monkeypatch):
-  """The stale-tape stamp only ever grows: forward A (stamp g), then forward B on the same function that accepts more steps than the
-  tape holds (a new, longer tape) -- A's backward must raise instead of differentiating B's record (round-5 advisor item)."""
+def test_stale_tape_stamp_only_ever_grows(dev, monkeypatch):
+  """The safety net behind the live-record rule: the solver's tape stamp only ever grows (round-5 advisor item: `set_tape` used to reset
+  it, so a backward could pass the stale-tape check after a later solve outgrew the tape).  Forced here by clearing the live-record
+  marker: forward A, then a forward B that outgrows the 8-slot tape -- A's backward raises instead of differentiating B's record."""
   monkeypatch.setattr(O, '_TAPE_BUDGET_BYTES', 1)          # -> the smallest tape (8 slots)
   block, x, ei, opt = _cora_like(dev, n=400, d=16, heads=4, A=16, seed=41, time=30.0, tol_scale=1.0)
   block.train()
-  block.odefunc.opt['time'] = 1.0
   xa = x.to(dev).clone().requires_grad_(True)
   block.set_x0(xa)
   t_long = block.t.clone()
@@ -172,11 +192,14 @@ def test_backward_after_a_later_forward_that_outgrew_the_tape_fails_loudly(dev, 
   za = block(xa)
   sol = next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver']
   assert sol.tape_capacity == 8
-  block.t = t_long                                         # the long one outgrows them
+  gen_a = sol.tape_generation
+  block.odefunc.__dict__.pop('_tape_live_dopri5')          # (pretend A's pass is not waiting: the case the stamp exists for)
+  block.t = t_long                                         # the long one outgrows the tape
   xb = x.to(dev).clone().requires_grad_(True)
   block.set_x0(xb)
   zb = block(xb)
-  assert sol.tape_capacity > 8 or next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver'] is not sol
+  sol_b = next(iter(block.odefunc.__dict__['_tape_state'].values()))['solver']
+  assert sol_b.tape_capacity > 8 and sol_b.tape_generation > gen_a
   with pytest.raises(G.GnpdeError):
     za.sum().backward()
   zb.sum().backward()
@@ -387,7 +410,9 @@ def test_recorded_fixed_grid_on_the_relabelled_graph(dev):
   _module_scaled(g2, {k: v for k, v in g1.items() if v is not None}, 2e-5, 'relabelled')
 
 
-def test_fixed_grid_backward_after_a_later_forward_fails_loudly(dev):
+def test_fixed_grid_two_forwards_before_one_backward(dev):
+  """While the record of forward A awaits its backward, forward B takes the host loop; both backward passes run and agree.  With the
+  live-record marker cleared (the case the tape stamp exists for) A's backward after B's recorded forward raises."""
   block, x = _fixed_block(dev, seed=63, **FIXED_CASES['nl_d22_euler'])
   block.train()
   xa = x.to(dev).clone().requires_grad_(True)
@@ -396,9 +421,22 @@ def test_fixed_grid_backward_after_a_later_forward_fails_loudly(dev):
   xb = x.to(dev).clone().requires_grad_(True)
   block.set_x0(xb)
   zb = block(xb)
+  assert str(block.odefunc._last_train_solve).startswith('differentiable host loop')
   zb.sum().backward()
+  za.sum().backward()
+  assert_parity(xa.grad, xb.grad, 2e-4, 'grad_x recorded vs host loop')
+  xc = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xc)
+  zc = block(xc)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded fixed-grid')
+  block.odefunc.__dict__.pop('_tape_live_fixed')
+  xd = x.to(dev).clone().requires_grad_(True)
+  block.set_x0(xd)
+  zd = block(xd)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded fixed-grid')
+  zd.sum().backward()
   with pytest.raises(G.GnpdeError):
-    za.sum().backward()
+    zc.sum().backward()
 
 
 def test_recorded_fixed_grid_falls_back_to_the_host_loop_beyond_its_memory_budget(dev, monkeypatch):
