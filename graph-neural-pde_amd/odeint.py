@@ -28,6 +28,46 @@ def time_grid(t, step_size):
   return grid
 
 
+_GRID_CACHE = {}
+
+
+def step_sizes(t, step_size):
+  """The step sizes of torchdiffeq's fixed grid over `t` as host floats.  The blocks pass the SAME device tensor `block.t` on every forward
+  pass: reading it back costs a device -> host synchronisation per solve (~25 us of a 150-us Cora forward), so the result is kept per
+  (tensor object, version, storage address, dtype, step size); tensors without a version counter are read every time."""
+  try:
+    key = (id(t), t._version, t.data_ptr(), t.dtype, float(step_size))
+  except RuntimeError:
+    key = None
+  hit = _GRID_CACHE.get(key) if key is not None else None
+  if hit is not None and hit[0] is t:
+    return hit[1]
+  grid = time_grid(t.detach().to('cpu'), step_size)
+  dts = tuple((grid[1:] - grid[:-1]).tolist())
+  if key is not None:
+    if len(_GRID_CACHE) >= 64:
+      _GRID_CACHE.clear()
+    _GRID_CACHE[key] = (t, dts)        # (holds `t`: its id cannot be handed to another tensor while it is a key)
+  return dts
+
+
+def end_points(t):
+  """(float(t[0]), float(t[-1])) with the same cache as step_sizes: the adaptive device solves read them once per `block.t`."""
+  try:
+    key = (id(t), t._version, t.data_ptr(), t.dtype, 'ends')
+  except RuntimeError:
+    key = None
+  hit = _GRID_CACHE.get(key) if key is not None else None
+  if hit is not None and hit[0] is t:
+    return hit[1]
+  ends = (float(t[0]), float(t[-1]))
+  if key is not None:
+    if len(_GRID_CACHE) >= 64:
+      _GRID_CACHE.clear()
+    _GRID_CACHE[key] = (t, ends)
+  return ends
+
+
 # --------------------------------------------------------------------------------------------------
 # native fixed-step path
 # --------------------------------------------------------------------------------------------------
@@ -38,8 +78,7 @@ def _native_ok(func, y0, t):
 
 def _solve_native(func, y0, t, method, step_size, use_graph=True, evaluator=None):
   from . import ops
-  grid = time_grid(t.detach().to('cpu'), step_size)
-  dts = (grid[1:] - grid[:-1]).tolist()
+  dts = list(step_sizes(t, step_size))
   n_evals = len(dts) * _EVALS_PER_STEP[method]
   # NFE guard with the reference's semantics (raise at the first evaluation that finds nfe > max_nfe)
   room = func.opt['max_nfe'] + 1 - func.nfe
@@ -454,7 +493,8 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
       order32 = view.__dict__['order32'] = view.order.to(torch.int32).contiguous()
   if getattr(sol, '_row_order', None) is not order32:
     sol.set_row_order(order32)
-  finished = ent['solver'].run(y0c, float(t[0]), float(t[-1]), out[1], trials_per_sync=trials_per_sync, max_evals=room)
+  t0_, t1_ = end_points(t)
+  finished = ent['solver'].run(y0c, t0_, t1_, out[1], trials_per_sync=trials_per_sync, max_evals=room)
   spent = ent['solver'].stats()['evals']
   func._dopri5_stats = ent['solver'].stats()
   if not finished or spent > room:
@@ -610,7 +650,8 @@ def _solve_dopri5_recorded(func, y0, t, rtol, atol):
   if _tape_busy(func, '_tape_live_dopri5'):
     func._last_train_solve = 'differentiable host loop (the record of an earlier forward pass still awaits its backward)'
     return _solve_dopri5(func, y0, t, rtol, atol)
-  return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, float(t[0]), float(t[-1]), float(rtol),
+  t0_, t1_ = end_points(t)
+  return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, t0_, t1_, float(rtol),
                                float(atol))
 
 
@@ -861,8 +902,7 @@ def _fixed_tape_estimate(func, y0, n_evals):
 
 
 def _solve_fixed_recorded(func, y0, t, method, step_size):
-  grid = time_grid(t.detach().to('cpu'), step_size)
-  dts = tuple((grid[1:] - grid[:-1]).tolist())
+  dts = step_sizes(t, step_size)
   need = _fixed_tape_estimate(func, y0, len(dts) * _EVALS_PER_STEP[method])
   try:
     free = torch.cuda.mem_get_info(y0.device)[0]
