@@ -18,7 +18,7 @@ LONG_ROW = 512
 STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 STAGE_RK1C, STAGE_RK2C, STAGE_RK3C, STAGE_RK4C = range(6, 10)
 STAGE_LINCOMB = 10
-ABI_VERSION = 5      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
+ABI_VERSION = 6      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4, METHOD_MIDPOINT = range(3)
@@ -144,7 +144,8 @@ PROTOTYPES = {
   'gnpde_linear_split_supported': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
   'gnpde_linear_split': (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp,
                                         ctypes.c_int32, c_vp]),
-  'gnpde_adjoint_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_adjoint_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+  'gnpde_adjoint_tape_swapped': (ctypes.c_int, [c_vp]),
   'gnpde_solver_tape_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.c_int32, ctypes.c_int32]),
   'gnpde_solver_set_tape': (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),
   'gnpde_adjoint_num_rhs_evals': (ctypes.c_int, [c_vp]),

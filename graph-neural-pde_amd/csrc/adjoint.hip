@@ -241,11 +241,13 @@ __global__ __launch_bounds__(kBlock) void adjoint_gram_mfma_kernel(const ParamAr
 // (launch_adjoint_rows): first level of the fold of sum u_a . F and sum u_a . x0, fixed order
 __global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* __restrict__ dots, int n_dots, int nb, float* __restrict__ partial,
                                                                   int stride, int slot) {
-  __shared__ float red[kWavesPerBlock][2];
-  float d1 = 0.f, d2 = 0.f;
+  // (the per-row dots are sums of opposite signs -- <u, A v> against <u, v> -- and there are n of them: this level is summed in double,
+  //  round 6; the nb block results go on as floats)
+  __shared__ double red[kWavesPerBlock][2];
+  double d1 = 0.0, d2 = 0.0;
   for (long long w = static_cast<long long>(blockIdx.x) + static_cast<long long>(threadIdx.x) * nb; w < n_dots; w += static_cast<long long>(kBlock) * nb) {
-    d1 += dots[2 * w];
-    d2 += dots[2 * w + 1];
+    d1 += static_cast<double>(dots[2 * w]);
+    d2 += static_cast<double>(dots[2 * w + 1]);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* 
   __syncthreads();
   if (threadIdx.x == 0) {
     float* out = partial + static_cast<size_t>(blockIdx.x) * stride + slot;
-    out[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-    out[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    out[0] = static_cast<float>((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+    out[1] = static_cast<float>((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
   }
 }
 
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void adjoint_dots_fold_kernel(const float* 
 __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float* __restrict__ partial, int nb, int stride, int n_plain,
                                                                    float coef, const float* __restrict__ alpha,
                                                                    const float* __restrict__ beta, int has_source, int alpha_sigmoid,
-                                                                   float* __restrict__ grads) {
+                                                                   int source_in_s1, float* __restrict__ grads) {
   constexpr int OUTS = 32, SL = kBlock / OUTS;
   __shared__ float part[SL][OUTS][2];
   const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
@@ -314,7 +316,9 @@ __global__ __launch_bounds__(kBlock) void adjoint_param_fold_kernel(const float*
   }
   const float a = *alpha;
   const float sig = 1.0f / (1.0f + expf(-a));
-  const float b = has_source ? *beta : 0.f;
+  // (source_in_s1: the row kernel summed u_a . F with the source term inside F; the cotangent-side sweep sums u_y . S, which has none --
+  //  nothing to subtract, and no cancellation against beta <u_a, x0>)
+  const float b = (has_source && source_in_s1) ? *beta : 0.f;
   grads[n_plain] = fmaf(coef, (1.0f - sig) * (s1 - b * s2), grads[n_plain]);
   grads[n_plain + 1] = fmaf(coef, has_source ? s2 : 0.f, grads[n_plain + 1]);
 }
@@ -334,6 +338,55 @@ __global__ __launch_bounds__(kBlock) void permute_f32_kernel(const float* __rest
     for (long long i = base; i < n; ++i) dst[i] = src[idx[i]];
   }
 }
+
+// ---- reverse sweep over a recorded solve, cotangent side only (round 6).  The stage's row kernel runs on the TRANSPOSED graph with the
+// roles exchanged (gathered operand = the cotangent u_a, own row = the recorded stage input u_y): one pass over the gathered rows gives
+// S = alpha' (A^T u_a - u_a), the edge products r = u_y[row'] . u_a[col'] in the transposed order and <u_y, S> = alpha' <u_a, A u_y - u_y>
+// (the alpha gradient) -- the state side needs no gather of its own, because nothing integrates it.  GRAND-nl / GAT then need the
+// attention backward before the stage algebra can close: combine = stage algebra with k = S + P, and <u_a, x0> for d beta on the way.
+struct CombineArgs {
+  const float* S; const float* P;      // [n, ld]; P may be null
+  const float* ua;                     // the row's own stage input of the cotangent recursion
+  const float* x0;                     // or null
+  const float* beta;                   // device scalar (with x0)
+  int alpha_sigmoid;
+  long long n4;                        // float4s of a state buffer (n * ld / 4)
+  gnpde_epilogue_t ep;                 // stage, dt, y, k1, out_y / out_k
+  float* pairs;                        // [gridDim.x][2]: (0, <u_a, x0>) per block, appended to the row kernel's dots
+};
+
+__global__ __launch_bounds__(kBlock) void stage_combine_kernel(const CombineArgs a) {
+  __shared__ float red[kWavesPerBlock];
+  float t = 0.f;
+  for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < a.n4; i += static_cast<long long>(gridDim.x) * kBlock) {
+    const size_t off = static_cast<size_t>(i) * 4;
+    float k[4], ui[4];
+    load_vec<4>(a.S + off, k);
+    load_vec<4>(a.ua + off, ui);
+    if (a.P != nullptr) {
+      float pv[4];
+      load_vec<4>(a.P + off, pv);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) k[v] = k[v] + 1.0f * pv[v];          // (as the aggregation epilogue formed it: k + beta s with beta = 1)
+    }
+    if (a.x0 != nullptr) {
+      float xv[4];
+      load_vec<4>(a.x0 + off, xv);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t = fmaf(ui[v], xv[v], t);          // (padding columns hold zeros on both sides)
+    }
+    stage_store<4, false>(a.ep, off, k, ui);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.pairs[2 * static_cast<size_t>(blockIdx.x)] = 0.f;
+    a.pairs[2 * static_cast<size_t>(blockIdx.x) + 1] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+constexpr int kCombineBlocks = 1024;
 
 // ---- GAT (reference src/function_GAT_attention.py:105-115): score_eh = LeakyReLU(ts_ih + td_jh), ts_ih = sum_c a[c] wx[i, h, c],
 // td_jh = sum_c a[d_k + c] wx[j, h, c], wx = u W.  With c_eh = dL/d(score) LeakyReLU'(score) from the normaliser backward:
@@ -493,6 +546,10 @@ struct gnpde_adjoint {
   // recorded forward solve (gnpde_adjoint_set_tape): the stage inputs of the FORWARD solve in evaluation order; the run is then the
   // reverse sweep through those evaluations (what autograd does through torchdiffeq's fixed-grid loop when opt['adjoint'] is off)
   const float* tape = nullptr;
+  const int32_t* csr_from_t = nullptr;   // [e] position in graph_t of the entry at CSR position q (inverse of t_from_csr), or null
+  bool swapped = false;              // the sweep gathers cotangent rows only (see stage_combine_kernel)
+  float* r_t = nullptr;              // [e] edge products in the transposed graph's order
+  int dots_capacity = 0;
   const float* tape_rec = nullptr;   // one RhsRecord (q||k, head-mean weights) per forward evaluation, behind the stage inputs (rhs.h), or null
   float* r_acc = nullptr;    // [e] or null: sum over the evaluations of (b_j h) u_a[row] . u_y[col] in CSR order (GRAND-l weight gradients)
 };
@@ -558,7 +615,10 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
   size_t att_b = 0, attbwd_b = 0;
   o_r = take(e4);
   const int n_dots = adjoint_rows_dot_slots(&g, r.d);
-  const size_t o_dots = take(static_cast<size_t>(n_dots) * 8);
+  const int n_dots_t = adjoint_rows_dot_slots(&gt, r.d);
+  const int dots_cap = (n_dots > n_dots_t ? n_dots : n_dots_t) + kCombineBlocks;
+  const size_t o_dots = take(static_cast<size_t>(dots_cap) * 8);
+  const size_t o_rt = take(e4);
   if (nl) {
     o_P = take(state);
     o_qk = take(static_cast<size_t>(g.n) * M * 4);
@@ -587,7 +647,8 @@ size_t adjoint_layout(const gnpde_rhs_t& r, const gnpde_graph_t& gt, int method,
     s->one = f(o_one);
     s->P = nl ? f(o_P) : nullptr; s->qk = nl ? f(o_qk) : nullptr; s->dqk = nl ? f(o_dqk) : nullptr;
     s->w = nl ? f(o_w) : nullptr; s->w_t = nl ? f(o_wt) : nullptr; s->r = f(o_r); s->ds = nl ? f(o_ds) : nullptr;
-    s->dots = f(o_dots); s->n_dots = n_dots;
+    s->dots = f(o_dots); s->n_dots = n_dots; s->dots_capacity = dots_cap;
+    s->r_t = f(o_rt);
     s->hub_ws = nl ? f(o_hub) : nullptr;
     s->qk_inv = nl ? f(o_inv) : nullptr;
     s->gts = (gat || extra) ? f(o_dts) : nullptr; s->gtd = (gat || extra) ? f(o_dtd) : nullptr;
@@ -643,14 +704,55 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     if (rc) return rc;
     w = s->w;
   }
-  // F with the next stage input in its epilogue + r_e = ua[row] . uy[col] + the per-wave dots, one kernel over the gathered rows
-  eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
-  eF.out_k = Fout;
-  if (s->tape != nullptr && s->r_acc != nullptr && !nl)
-    rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r_acc, s->dots, s->ws_spmm, s->spmm_bytes, st, padded, true, pcoef);
-  else
-    rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
-  if (rc) return rc;
+  const bool swapped = s->tape != nullptr && s->swapped;
+  int n_pairs = s->n_dots;                     // (d1, d2) pairs the dots fold below has to sum
+  if (swapped) {
+    // Recorded solve, cotangent side only: the row kernel on the TRANSPOSED graph with the roles exchanged (gathered = u_a, own row = the
+    // recorded u_y): S = alpha' (A^T u_a - u_a), r in the transposed order, <u_y, S> -- see stage_combine_kernel.
+    const int n_dots_t = adjoint_rows_dot_slots(gt, d);
+    if (nl) {
+      if (g->e > 0) {
+        hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, w, s->t_from_csr, g->e, s->w_t);
+        GNPDE_LAUNCH_CHECK();
+      }
+      gnpde_epilogue_t eS{};
+      eS.stage = GNPDE_STAGE_LINCOMB; eS.alpha = r.alpha; eS.alpha_sigmoid = r.alpha_sigmoid; eS.out_k = s->uy[0];
+      rc = launch_adjoint_rows(gt, s->w_t, ua, uy, d, ld, &eS, s->r_t, s->dots, s->ws_spmm_t, s->spmm_t_bytes, st, padded);
+      if (rc) return rc;
+      if (g->e > 0) {       // the edge products in the order the attention backward walks them
+        hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, s->r_t, s->csr_from_t, g->e, s->r);
+        GNPDE_LAUNCH_CHECK();
+      }
+      n_pairs = n_dots_t + kCombineBlocks;       // (the combine pass appends its <u_a, x0> pairs)
+    } else {
+      // GRAND-l: nothing stands between the aggregation and the stage algebra -- the whole stage is this launch (+ the source dot)
+      gnpde_epilogue_t e2 = eV;
+      e2.alpha = r.alpha; e2.beta = nullptr; e2.x0 = nullptr; e2.alpha_sigmoid = r.alpha_sigmoid; e2.out_k = Vout;
+      rc = launch_adjoint_rows(gt, s->w_t_fixed, ua, uy, d, ld, &e2, s->r_acc != nullptr ? s->r_acc : s->r, s->dots, s->ws_spmm_t, s->spmm_t_bytes, st,
+                               padded, s->r_acc != nullptr, pcoef);
+      if (rc) return rc;
+      n_pairs = n_dots_t;
+      if (r.x0 != nullptr) {
+        CombineArgs ca{};
+        ca.S = ua; ca.P = nullptr; ca.ua = ua; ca.x0 = r.x0; ca.beta = r.beta; ca.alpha_sigmoid = r.alpha_sigmoid;
+        ca.n4 = static_cast<long long>(n) * ld / 4;
+        ca.ep.stage = -1;                          // (no stage output: the dot only)
+        ca.pairs = s->dots + 2 * static_cast<size_t>(n_dots_t);
+        hipLaunchKernelGGL(stage_combine_kernel, dim3(kCombineBlocks), dim3(kBlock), 0, st, ca);
+        GNPDE_LAUNCH_CHECK();
+        n_pairs += kCombineBlocks;
+      }
+    }
+  } else {
+    // F with the next stage input in its epilogue + r_e = ua[row] . uy[col] + the per-wave dots, one kernel over the gathered rows
+    eF.alpha = r.alpha; eF.beta = r.beta; eF.x0 = r.x0; eF.alpha_sigmoid = r.alpha_sigmoid;
+    eF.out_k = Fout;
+    if (s->tape != nullptr && s->r_acc != nullptr && !nl)
+      rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r_acc, s->dots, s->ws_spmm, s->spmm_bytes, st, padded, true, pcoef);
+    else
+      rc = launch_adjoint_rows(g, w, uy, ua, d, ld, &eF, s->r, s->dots, s->ws_spmm, s->spmm_bytes, st, padded);
+    if (rc) return rc;
+  }
   const float* source = nullptr;
   const float* source_scale = nullptr;
   int rows_per_block = (n + kParamBlocks - 1) / kParamBlocks;      // slab grid of the parameter-gradient passes
@@ -674,7 +776,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     GNPDE_LAUNCH_CHECK();
     rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
     if (rc) return rc;
-    if (g->e > 0) {
+    if (g->e > 0 && !swapped) {
       hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
       GNPDE_LAUNCH_CHECK();
     }
@@ -696,7 +798,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     GNPDE_LAUNCH_CHECK();
     rc = launch_linear_any(s->dqk, n, M, M, s->proj_wt, d, M, nullptr, s->P, ld, st);
     if (rc) return rc;
-    if (g->e > 0) {
+    if (g->e > 0 && !swapped) {
       hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
       GNPDE_LAUNCH_CHECK();
     }
@@ -736,7 +838,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     //  softmax backward -- 4- / 16-byte scattered stores cost more than these gathers, adjoint_rows +50 us, softmax backward +35 us against
     //  -25 / -30 us; and running this permutation + the NEXT stage's attention as a parallel hipGraph branch beside the backward chain --
     //  the overlapped kernels slow each other down by what the overlap hides, 0.82 ms per f + VJP either way)
-    if (g->e > 0) {
+    if (g->e > 0 && !swapped) {
       hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, wfwd, s->t_from_csr, g->e, s->w_t);
       GNPDE_LAUNCH_CHECK();
     }
@@ -744,11 +846,23 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     source = s->P;
     source_scale = s->one;
   }
-  // V = alpha (A^T ua - ua) [+ 1 * P]
-  eV.alpha = r.alpha; eV.beta = source_scale; eV.x0 = source; eV.alpha_sigmoid = r.alpha_sigmoid;
-  eV.out_k = Vout;
-  rc = launch_spmm_rhs(gt, wt, ua, d, ld, &eV, nullptr, s->ws_spmm_t, s->spmm_t_bytes, st, nullptr, padded);
-  if (rc) return rc;
+  if (swapped && nl) {
+    // V = S + P and the stage algebra of the cotangent recursion, one pass over the rows (+ the <u_a, x0> pairs)
+    CombineArgs ca{};
+    ca.S = s->uy[0]; ca.P = source; ca.ua = ua; ca.x0 = r.x0; ca.beta = r.beta; ca.alpha_sigmoid = r.alpha_sigmoid;
+    ca.n4 = static_cast<long long>(n) * ld / 4;
+    ca.ep = eV;
+    ca.ep.out_k = Vout;
+    ca.pairs = s->dots + 2 * static_cast<size_t>(n_pairs - kCombineBlocks);
+    hipLaunchKernelGGL(stage_combine_kernel, dim3(kCombineBlocks), dim3(kBlock), 0, st, ca);
+    GNPDE_LAUNCH_CHECK();
+  } else if (!swapped) {
+    // V = alpha (A^T ua - ua) [+ 1 * P]
+    eV.alpha = r.alpha; eV.beta = source_scale; eV.x0 = source; eV.alpha_sigmoid = r.alpha_sigmoid;
+    eV.out_k = Vout;
+    rc = launch_spmm_rhs(gt, wt, ua, d, ld, &eV, nullptr, s->ws_spmm_t, s->spmm_t_bytes, st, nullptr, padded);
+    if (rc) return rc;
+  }
   // parameter gradients
   ParamArgs p{};
   p.dqk = nl ? s->dqk : nullptr; p.uy = uy; p.ua = ua; p.F = Fout; p.x0 = r.x0;
@@ -777,11 +891,11 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     hipLaunchKernelGGL(gat_da_partial_kernel, dim3(nb), dim3(kBlock), 0, st, s->gts, s->gtd, qk, n, M, at.heads, p.rows_per_block, s->partial, s->stride, M * d);
     GNPDE_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, s->n_dots, nb, s->partial, s->stride, M * d + M + s->extra);
+  hipLaunchKernelGGL(adjoint_dots_fold_kernel, dim3(nb), dim3(kBlock), 0, st, s->dots, n_pairs, nb, s->partial, s->stride, M * d + M + s->extra);
   GNPDE_LAUNCH_CHECK();
   const int n_plain = M * d + M + s->extra;
   hipLaunchKernelGGL(adjoint_param_fold_kernel, dim3((n_plain + 1 + 31) / 32), dim3(kBlock), 0, st, s->partial, nb, s->stride, n_plain,
-                     pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, r.alpha_sigmoid, grads);
+                     pcoef, r.alpha, r.beta, r.x0 != nullptr ? 1 : 0, r.alpha_sigmoid, swapped ? 0 : 1, grads);
   GNPDE_LAUNCH_CHECK();
   return 0;
 }
@@ -1021,12 +1135,16 @@ extern "C" int gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* 
   return 0;
 }
 
-extern "C" int gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc) {
+extern "C" int gnpde_adjoint_tape_swapped(const gnpde_adjoint_t* s) { return s != nullptr && s->tape != nullptr && s->swapped ? 1 : 0; }
+
+extern "C" int gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc, const int32_t* csr_from_t) {
   GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "adjoint_set_tape: solver is null");
   drop_adjoint_graph(s);
   s->tape = nullptr;
   s->tape_rec = nullptr;
   s->r_acc = nullptr;
+  s->csr_from_t = nullptr;
+  s->swapped = false;
   if (tape == nullptr) return 0;
   const size_t per = s->method == GNPDE_METHOD_RK4 ? 4 : s->method == GNPDE_METHOD_MIDPOINT ? 2 : 1;
   const size_t rec_floats = rhs_record_stride(s->rhs);
@@ -1036,6 +1154,10 @@ extern "C" int gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size
                   tape_bytes, need);
   GNPDE_CHECK_ARG(r_acc == nullptr || s->rhs.kind == GNPDE_RHS_LAPLACIAN, GNPDE_EINVAL,
                   "adjoint_set_tape: edge-weight gradients are GRAND-l's (GRAND-nl forms its weights from the state)");
+  s->csr_from_t = csr_from_t;
+  // the cotangent-side form of the sweep: always for GRAND-l, for the functions with an attention per evaluation when the caller hands over
+  // the inverse position map (gnpde_tune(15, 1): the first form, which gathers the recorded state rows again)
+  s->swapped = g_tune[GNPDE_TUNE_SWEEP_UNSWAPPED] != 1 && (s->rhs.kind == GNPDE_RHS_LAPLACIAN || csr_from_t != nullptr);
   s->tape = static_cast<const float*>(tape);
   s->tape_rec = rec_floats > 0 ? s->tape + (per * s->dts.size() + 1) * (s->state_bytes / 4) : nullptr;
   s->r_acc = r_acc;

@@ -104,6 +104,7 @@ enum {
   GNPDE_TUNE_XCD_ROWS = 10,            // 0: as gnpde_graph_t.xcd_deal says; 1: contiguous eighths for every graph; 2: hashed blocks for every graph
   GNPDE_TUNE_HUB_FOLD = 11,            // 2: phase 1 of the hub-row attention folds the row's chunk partials straight from memory instead of staging them through LDS (default: staged)
   GNPDE_TUNE_ADJOINT_GRAM = 12,        // 1: weight-gradient Gram blocks of the adjoint stage on the VALU (scalar-operand kernel) instead of the matrix cores
+  GNPDE_TUNE_SWEEP_UNSWAPPED = 15,     // 1: the reverse sweep over a recorded solve gathers the STATE rows again (round-6 first form) instead of the cotangent rows only (A/B)
   GNPDE_TUNE_KEY_TABLE = 14,           // 1: keep q||k interleaved [n, 2A] where the solver would write two tables (A/B)
   GNPDE_TUNE_LINEAR_DIAG = 13,         // A/B diagnostics of the staged projection kernel (1: no stores, 2: loads alone); never set in production
   GNPDE_TUNE_COUNT = 16

@@ -65,14 +65,15 @@ __device__ __forceinline__ float alpha_of(const gnpde_epilogue_t& ep) {
   return ep.alpha_sigmoid ? 1.0f / (1.0f + expf(-a)) : a;
 }
 
+template <int VEC, bool NT>
+__device__ __forceinline__ void stage_store(const gnpde_epilogue_t& ep, size_t off, const float (&k)[VEC], const float (&ui)[VEC]);
+
 // k = alpha (ax - u_i) + beta x0_i, then the stage algebra in torchdiffeq's operation order.
 template <int VEC, bool NT>
 __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha, float beta, size_t off,
                                          const float (&ax)[VEC], const float (&ui)[VEC]) {
   // per-row streaming operands (y, k1..k3, x0 in; k, y out) are touched once per launch
   auto ld = [](const float* p, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(p, v); else load_vec<VEC>(p, v); };
-  auto st = [](float* p, const float (&v)[VEC]) { if constexpr (NT) store_vec_nt<VEC>(p, v); else store_vec<VEC>(p, v); };
-  constexpr float kThird = 1.0f / 3.0f;
   float k[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) k[v] = alpha * (ax[v] - ui[v]);
@@ -82,6 +83,15 @@ __device__ __forceinline__ void epilogue(const gnpde_epilogue_t& ep, float alpha
 #pragma unroll
     for (int v = 0; v < VEC; ++v) k[v] = k[v] + beta * s[v];
   }
+  stage_store<VEC, NT>(ep, off, k, ui);
+}
+
+// The stage algebra alone: k = the derivative of this row (however it was formed), u_i = the row's own stage input.
+template <int VEC, bool NT>
+__device__ __forceinline__ void stage_store(const gnpde_epilogue_t& ep, size_t off, const float (&k)[VEC], const float (&ui)[VEC]) {
+  auto ld = [](const float* p, float (&v)[VEC]) { if constexpr (NT) load_vec_nt<VEC>(p, v); else load_vec<VEC>(p, v); };
+  auto st = [](float* p, const float (&v)[VEC]) { if constexpr (NT) store_vec_nt<VEC>(p, v); else store_vec<VEC>(p, v); };
+  constexpr float kThird = 1.0f / 3.0f;
   const float dt = ep.dt;
   float y[VEC], a[VEC], b[VEC], c[VEC], o[VEC];
   switch (ep.stage) {

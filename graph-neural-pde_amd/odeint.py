@@ -851,7 +851,14 @@ class _RecordedFixedGrid(torch.autograd.Function):
         if ent['sweep'] is not None:
           ent['sweep'].close()
         ent['sweep'] = ops.AdjointSolver(desc, gt, t_from_csr if nl else None, proj_wt, w_t, ctx.method, ctx.dts, dev)
-        ent['sweep'].set_tape(sol.tape, ex['r_acc'] if want_dw else None)
+        csr_from_t = None
+        if nl and graph.e > 0:       # the inverse position map: lets the sweep gather the cotangent rows only (csrc/adjoint.hip)
+          csr_from_t = graph.__dict__.get('_csr_from_t')
+          if csr_from_t is None:
+            csr_from_t = torch.empty_like(t_from_csr)
+            csr_from_t[t_from_csr.long()] = torch.arange(graph.e, dtype=t_from_csr.dtype, device=dev)
+            graph.__dict__['_csr_from_t'] = csr_from_t
+        ent['sweep'].set_tape(sol.tape, ex['r_acc'] if want_dw else None, csr_from_t)
         ent['grads'] = torch.zeros(ent['sweep'].n_grad, dtype=torch.float32, device=dev)
         ent['sweep_sig'] = sweep_sig
       ab = ent['a']
@@ -876,7 +883,8 @@ class _RecordedFixedGrid(torch.autograd.Function):
           a = torch.sigmoid(a)
         E = graph.e
         dw_e = torch.empty(E, dtype=torch.float32, device=dev)
-        dw_e[graph.perm_long] = a * ex['r_acc'][:E]
+        order = gt.perm_long if ent['sweep'].swapped else graph.perm_long      # (the products lie in the order of the graph the row kernel ran on)
+        dw_e[order] = a * ex['r_acc'][:E]
         dw = (dw_e / ctx.heads).unsqueeze(1).expand(E, ctx.heads).contiguous() if ctx.heads else dw_e
       by_param = _grad_vector_by_param(func, ent['grads'], d)
       gparams = []

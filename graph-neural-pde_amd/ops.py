@@ -787,15 +787,19 @@ class AdjointSolver(object):
     self.handle = handle
     self.n_rhs_evals = L.gnpde_adjoint_num_rhs_evals(handle)
 
-  def set_tape(self, tape, r_acc=None):
+  def set_tape(self, tape, r_acc=None, csr_from_t=None):
     """Reverse sweep through the recorded forward solve whose stage inputs `tape` holds (FixedStepSolver.set_tape; same method and
-    grid): run() then maps a = dL/dy(T) to dL/dy0.  r_acc [e] (GRAND-l): receives the weighted edge products in CSR order."""
+    grid): run() then maps a = dL/dy(T) to dL/dy0.  r_acc [e] (GRAND-l): receives the weighted edge products -- in the order of the
+    TRANSPOSED graph when `swapped` (the cotangent-side form of the sweep: always for GRAND-l, with `csr_from_t` for the others), else in
+    CSR order.  csr_from_t [e] int32: the inverse of t_from_csr."""
+    L = _lib.lib()
     if tape is None:
-      check(_lib.lib().gnpde_adjoint_set_tape(self.handle, None, 0, None))
+      check(L.gnpde_adjoint_set_tape(self.handle, None, 0, None, None))
     else:
       require_hip(tape)
-      check(_lib.lib().gnpde_adjoint_set_tape(self.handle, ptr(tape), tape.numel(), ptr(r_acc)))
-    self.tape, self.r_acc = tape, r_acc
+      check(L.gnpde_adjoint_set_tape(self.handle, ptr(tape), tape.numel(), ptr(r_acc), ptr(csr_from_t)))
+    self.tape, self.r_acc, self.csr_from_t = tape, r_acc, csr_from_t
+    self.swapped = bool(L.gnpde_adjoint_tape_swapped(self.handle))
 
   def run(self, y, a, grads, use_graph=True):
     """y, a [n, ld] integrated backwards in place; grads [n_grad] receives the parameter gradients."""

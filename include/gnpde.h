@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 5   /* 5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 6   /* 6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -483,7 +483,13 @@ int    gnpde_adjoint_run(gnpde_adjoint_t* s, float* y, float* a, float* grads, i
  * a = dL/dy(T) to dL/dy0, grads as above.  r_acc (GRAND-l, nullable) [e]: receives sum over the evaluations of
  * (b_j h) u_a[row] . u_y[col] in the CSR order of rhs->graph -- times alpha' the gradient of the edge weights (attention block).
  * tape == NULL detaches. */
-int    gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc);
+int    gnpde_adjoint_set_tape(gnpde_adjoint_t* s, const void* tape, size_t tape_bytes, float* r_acc, const int32_t* csr_from_t);
+/* csr_from_t (nullable) [e] device: position in graph_t of the entry stored at CSR position q of rhs->graph (the inverse of t_from_csr).  With
+ * it -- and always for GRAND-l -- the sweep gathers the COTANGENT rows only: per recorded evaluation one row kernel on graph_t with the roles
+ * exchanged (S = alpha' (A^T u_a - u_a), the edge products in graph_t's order, <u_y, S>), the attention backward, and one pass that closes
+ * the stage algebra with S + P; the recorded state rows are read as own rows, never gathered.  gnpde_adjoint_tape_swapped: 1 when that
+ * form runs -- r_acc then holds the products in GRAPH_T's order. */
+int    gnpde_adjoint_tape_swapped(const gnpde_adjoint_t* s);
 int    gnpde_adjoint_num_rhs_evals(const gnpde_adjoint_t* s);
 int    gnpde_adjoint_destroy(gnpde_adjoint_t* s);
 

@@ -449,3 +449,32 @@ def test_recorded_fixed_grid_falls_back_to_the_host_loop_beyond_its_memory_budge
   assert str(block.odefunc._last_train_solve).startswith('differentiable host loop'), block.odefunc._last_train_solve
   assert not block.odefunc.__dict__.get('_fixed_tape_state')
   assert torch.isfinite(gx).all()
+
+
+@pytest.mark.parametrize('case', ['nl_hubs_rk4', 'nl_d22_euler', 'nl_midpoint', 'l_attention_rk4_hubs', 'gat_rk4_hubs', 'nl_pearson_rk4'])
+def test_cotangent_side_sweep_equals_the_first_form(dev, case):
+  """Round 6: the reverse sweep gathers the COTANGENT rows only (row kernel on the transposed graph with the roles exchanged, then one pass
+  that closes the stage algebra with S + P) instead of gathering the recorded state rows again and running a second aggregation.  The
+  same products; the row sums of A^T u_a come from another kernel (another grouping of a row's entries), so the two forms
+  (gnpde_tune(15, 1): the first) agree to rounding (2e-6 for dL/dx and the weight gradients' modules, 5e-5 for the scalars), not bit for bit."""
+  from gnpde_amd import ops
+  kw = dict(FIXED_CASES[case])
+  c = None
+  res = []
+  for knob in (0, 1):
+    ops.tune(15, knob)
+    try:
+      block, x = _fixed_block(dev, seed=66, **kw)
+      if c is None:
+        c = torch.randn(x.shape, generator=torch.Generator().manual_seed(10)).to(dev)
+      z, gx, g, nfe = _train_once(block, x, dev, c)
+      ent = next(iter(block.odefunc.__dict__['_fixed_tape_state'].values()))
+      res.append((z, gx, g, bool(ent['sweep'].swapped)))
+    finally:
+      ops.tune(15, 0)
+  (z1, gx1, g1, sw1), (z0, gx0, g0, sw0) = res
+  assert sw1 and not sw0, (sw1, sw0)
+  assert torch.equal(z1, z0)
+  assert_parity(gx1, gx0, 2e-6, case + ' grad_x')
+  refs = {k: v for k, v in g0.items() if v is not None}
+  _module_scaled(g1, refs, 5e-5, case)      # (the scalar gradients are sums over all rows: the first form subtracts beta <u_a, x0> back out of a float sum)
