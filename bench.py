@@ -1301,9 +1301,18 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
     host = {'error': repr(exc)[:300]}
   E = rec['E']
   agg = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n
-  # one VJP stage of the reverse sweep moves what an adjoint stage moves (train_main) less the state-side stage output
-  stage_bytes = (agg + 4 * E + 4 * d * n - 4 * d * n) + agg + n * (4 * d + 8 * A) + (E * (4 + 4 * A + 4) + n * (16 + 4 * A)) \
-      + (E * (4 + 4 + 4 * A + 4 * h) + n * (16 + 4 * A)) + (2 * (E * (4 + 4 * h + 4 * A) + n * (16 + 4 * A)) + E * 4) + n * (8 * A + 4 * d) + E * 12 + n * (8 * A + 4 * d)
+  # algorithmic bytes of ONE VJP stage of the cotangent-side sweep (gather model as SURVEY 8d): the row kernel on the
+  # transposed graph (an aggregation + the own recorded row + the edge products written), two 4-byte permutations (weights in, products
+  # back), the normaliser backward, d q / d k, P, the combine pass (S, P, u_a, x0 and on average 1.5 stage operands in, the next cotangent
+  # out), the Gram pass; neither the projection nor the attention forward (recorded) nor a second aggregation
+  b_rows = agg + 4 * E + 4 * d * n
+  b_perm = 2 * (E * 12)
+  b_attb = E * (4 + 4 + 4 * A + 4 * h) + n * (16 + 4 * A)
+  b_dqk = 2 * (E * (4 + 4 * h + 4 * A) + n * (16 + 4 * A)) + E * 4
+  b_pg = n * (8 * A + 4 * d)
+  b_comb = int(n * 4 * d * 6.5)
+  b_gram = n * (8 * A + 4 * d)
+  stage_bytes = b_rows + b_perm + b_attb + b_dqk + b_pg + b_comb + b_gram
   t_stage = rec['bw'] / (4 * K)
   parity = None
   if 'error' not in host:
@@ -1338,7 +1347,7 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
       'steps_per_s': round(K / (host['fw'] + host['bw']), 3)},
     'speedup_vs_host_loop': None if 'error' in host else round((host['fw'] + host['bw']) / (rec['fw'] + rec['bw']), 2),
     'parity_vs_host_loop': parity,
-    'roofline': {'kernel': 'one VJP stage of the reverse sweep (projection, row attention, adjoint row kernel, normaliser backward, d q / d k, P, transposed aggregation, Gram)',
+    'roofline': {'kernel': 'one VJP stage of the cotangent-side reverse sweep (permutation, row kernel on the transposed graph, permutation, normaliser backward, d q / d k, P, combine pass, Gram)',
                  'bound': 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                  'frac': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4), 'frac_algorithmic': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'algorithmic_bytes_per_stage': stage_bytes},
