@@ -85,6 +85,7 @@ def parse():
                        'solve, opt[adjoint] with adjoint_method rk4 / adjoint_step_size 1) of K steps each; prints its own JSON line')
   ap.add_argument('--no-adjoint', action='store_true',
                   help='with --train: opt[adjoint] off (run_GNN.py\'s default) -- recorded native solve + native reverse sweep, A/B against the host loop')
+  ap.add_argument('--no-host-loop', action='store_true', help='with --train --no-adjoint: skip the host-loop A/B (the child the PMC passes profile)')
   ap.add_argument('--replays', type=int, default=5, help='timed launches of the K-step solve (median reported)')
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--norm-idx', type=int, default=0, choices=[0, 1], help='attention_norm_idx (1: softmax over columns, general 3-pass path)')
@@ -1295,10 +1296,38 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
 
   rec = measure(False, args.replays)
   assert torch.isfinite(rec['gx']).all()
-  try:
-    host = measure(True, 1)
-  except Exception as exc:   # noqa: BLE001
-    host = {'error': repr(exc)[:300]}
+  if args.no_host_loop:
+    host = {'error': 'skipped (--no-host-loop)'}
+  else:
+    try:
+      host = measure(True, 1)
+    except Exception as exc:   # noqa: BLE001
+      host = {'error': repr(exc)[:300]}
+  # counter traffic of ONE VJP stage: two rocprofv3 --pmc passes over a short child run of this mode (no host-loop A/B in it); the kernels
+  # of the reverse sweep do not run in the forward solve, so their totals / the number of recorded evaluations is the stage's traffic
+  traffic, traffic_src = None, None
+  if not args.no_live_pmc and not args.no_host_loop:
+    kc, wc = 2, 2
+    pmc = mode_pmc_traffic(args, ['--train', '--no-adjoint', '--no-host-loop', '--steps', str(kc), '--warmup', str(wc), '--graph', args.graph,
+                                  '--function', args.function], 'train_no_adjoint')
+    if isinstance(pmc, dict) and 'error' not in pmc:
+      iters = max(wc, 2) + 1
+      S = float(iters * 4 * kc)
+      sweep = ('adjoint_rows', 'adjoint_long_reduce', 'permute_f32', 'attention_rows_bwd', 'attention_hub', 'head_rowsum', 'linear_lds', 'stage_combine',
+               'adjoint_gram', 'adjoint_dots_fold', 'adjoint_param_fold', 'normalise_heads_bwd', 'att_bwd', 'seg_dot', 'gat_', 'exp_node', 'head_spmm')
+      tot, by = 0.0, {}
+      for k, v in pmc.items():
+        if k.startswith('_') or 'bytes_per_launch' not in v or not any(t in k for t in sweep):
+          continue
+        by[k] = {'launches': v['launches'], 'bytes_per_launch': round(v['bytes_per_launch']), 'l2_hit_rate': v.get('l2_hit_rate')}
+        tot += v['fetch_bytes_total'] + v['write_bytes_total']
+      traffic = tot / S
+      traffic_src = {'how': 'measured in this run: rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes, --kernel-trace only) '
+                            'over a child `bench.py --train --no-adjoint --no-host-loop --steps %d` (%d iterations = %d recorded evaluations swept); bytes = '
+                            '(2 FETCH_SIZE + WRITE_SIZE) * 1024 over the kernels of the reverse sweep, per VJP stage' % (kc, iters, int(S)),
+                     'live': True, 'seconds': pmc.get('_seconds'), 'kernels': by}
+    elif isinstance(pmc, dict):
+      traffic_src = {'live_pmc_error': pmc.get('error')}
   E = rec['E']
   agg = E * (8 + 4 * d) + n * (4 + 8 * d) + 4 * d * n
   # algorithmic bytes of ONE VJP stage of the cotangent-side sweep (gather model as SURVEY 8d): the row kernel on the
@@ -1349,8 +1378,10 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
     'parity_vs_host_loop': parity,
     'roofline': {'kernel': 'one VJP stage of the cotangent-side reverse sweep (permutation, row kernel on the transposed graph, permutation, normaliser backward, d q / d k, P, combine pass, Gram)',
                  'bound': 'hbm', 'achieved': round(stage_bytes / t_stage / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                 'frac': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4), 'frac_algorithmic': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
-                 'traffic': None, 'algorithmic_bytes_per_stage': stage_bytes},
+                 'frac': round((traffic if traffic else stage_bytes) / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'frac_algorithmic': round(stage_bytes / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'frac_traffic': None if traffic is None else round(traffic / t_stage / 1e9 / HBM_PEAK_GBS, 4),
+                 'traffic': None if traffic is None else round(traffic), 'traffic_source': traffic_src, 'algorithmic_bytes_per_stage': stage_bytes},
     'cpu_baseline': None,
   }
   print(json.dumps(out))
