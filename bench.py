@@ -1407,7 +1407,7 @@ CONFIG_CHILDREN = (
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
    ['--train', '--steps', '10', '--warmup', '2'], 400),
   ('c3_training_iteration_adjoint_off', 'configs[2] shape, TRAINING as run_GNN.py runs rk4 by default (adjoint off): recorded solve + native reverse sweep, host-loop A/B',
-   ['--train', '--no-adjoint', '--steps', '10', '--warmup', '2'], 300),
+   ['--train', '--no-adjoint', '--steps', '10', '--warmup', '2', '--no-live-pmc'], 300),     # (its counter passes: profiles/r06_train_no_adjoint.json)
   ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
    ['--config', 'c4', '--warmup', '2'], 400),
   ('c3_normalised_over_columns_squareplus', 'configs[2] shape with attention_norm_idx 1 + squareplus (the reference\'s Cora / Citeseer normaliser at scale)',
