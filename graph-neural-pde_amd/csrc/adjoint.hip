@@ -711,13 +711,17 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     // recorded u_y): S = alpha' (A^T u_a - u_a), r in the transposed order, <u_y, S> -- see stage_combine_kernel.
     const int n_dots_t = adjoint_rows_dot_slots(gt, d);
     if (nl) {
-      if (g->e > 0) {
+      // (the weights stay in the order the attention wrote them: the row kernel takes w[t_from_csr[p]] itself -- the 4-byte gathers of the
+      //  26-us permutation pass now ride under the row gathers; gnpde_tune(15, 2): the separate pass, for A/B)
+      const bool fused_w = g_tune[GNPDE_TUNE_SWEEP_UNSWAPPED] != 2;
+      if (g->e > 0 && !fused_w) {
         hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, w, s->t_from_csr, g->e, s->w_t);
         GNPDE_LAUNCH_CHECK();
       }
       gnpde_epilogue_t eS{};
       eS.stage = GNPDE_STAGE_LINCOMB; eS.alpha = r.alpha; eS.alpha_sigmoid = r.alpha_sigmoid; eS.out_k = s->uy[0];
-      rc = launch_adjoint_rows(gt, s->w_t, ua, uy, d, ld, &eS, s->r_t, s->dots, s->ws_spmm_t, s->spmm_t_bytes, st, padded);
+      rc = launch_adjoint_rows(gt, fused_w ? w : s->w_t, ua, uy, d, ld, &eS, s->r_t, s->dots, s->ws_spmm_t, s->spmm_t_bytes, st, padded, false, 1.0f,
+                               fused_w ? s->t_from_csr : nullptr);
       if (rc) return rc;
       if (g->e > 0) {       // the edge products in the order the attention backward walks them
         hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, s->r_t, s->csr_from_t, g->e, s->r);

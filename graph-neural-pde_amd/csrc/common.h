@@ -148,7 +148,7 @@ int launch_spmm_rhs(const gnpde_graph_t* g, const float* w_csr, const float* u, 
 int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d);
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
-                        bool padded_rows, bool accumulate_r = false, float r_scale = 1.0f);
+                        bool padded_rows, bool accumulate_r = false, float r_scale = 1.0f, const int* wpos = nullptr);
 
 // head-wise weighted row sums with a lane per entry (backward.hip): the adjoint stage's d q (pos == nullptr) and d k (rows of the
 // transposed graph, pos = its positions -> CSR positions of ds); rows without entries are not written

@@ -1296,6 +1296,8 @@ struct AdjRowsArgs {
   int r_accumulate;                // != 0: r[e] += (every entry belongs to exactly one lane of one launch: no race); the recorded
                                    // dopri5 backward sums the edge products of all its evaluations this way
   float r_scale;                   // weight of this launch's products in the sum (the recorded fixed-grid backward: the stage's b_j h)
+  const int* __restrict__ wpos;    // or null: the weight of entry p is w[wpos[p]] (weights stored in ANOTHER graph's order: the cotangent-side
+                                   // sweep runs on the transposed graph with the weights as the attention wrote them, no permutation pass)
 };
 
 template <int N, int MASK>
@@ -1366,7 +1368,7 @@ __device__ __forceinline__ void adjoint_item(const AdjRowsArgs& fa, int row, int
     const int me = base + lane;
     const bool in = me < e1;
     const int cv = in ? a.colidx[me] : 0;          // one coalesced load of 64 column ids and weights per wave
-    const float wv = in ? a.w[me] : 0.0f;
+    const float wv = in ? a.w[fa.wpos != nullptr ? fa.wpos[me] : me] : 0.0f;
     const int cnt = (e1 - base) < kWave ? (e1 - base) : kWave;
     for (int t0 = 0; t0 < cnt; t0 += EPB) {
       float vals[U][VEC], ww[U], p[U];
@@ -1516,7 +1518,7 @@ int adjoint_rows_dot_slots(const gnpde_graph_t* g, int d) {
 
 int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float* u, const float* gvec, int d, int ld,
                         const gnpde_epilogue_t* epi, float* r_out, float* dots, void* ws, size_t ws_bytes, hipStream_t stream,
-                        bool padded_rows, bool accumulate_r, float r_scale) {
+                        bool padded_rows, bool accumulate_r, float r_scale, const int* wpos) {
   GNPDE_CHECK_ARG(g && u && gvec && epi && r_out && dots && (w_csr || g->e == 0), GNPDE_EINVAL, "adjoint_rows: null pointer");
   const int stg = epi->stage;
   GNPDE_CHECK_ARG((stg == GNPDE_STAGE_LINCOMB || stg == GNPDE_STAGE_EULER || (stg >= GNPDE_STAGE_RK1C && stg <= GNPDE_STAGE_RK4C)) &&
@@ -1549,7 +1551,7 @@ int launch_adjoint_rows(const gnpde_graph_t* g, const float* w_csr, const float*
   const void* ptrs[] = {u, gvec, ws, epi->x0, epi->y, epi->k1, epi->out_k, epi->out_y, stg == GNPDE_STAGE_LINCOMB ? epi->prev[0] : nullptr,
                         stg == GNPDE_STAGE_LINCOMB ? epi->prev[1] : nullptr, stg == GNPDE_STAGE_LINCOMB ? epi->prev[2] : nullptr};
   for (const void* p : ptrs) GNPDE_CHECK_ARG(aligned(p, 16), GNPDE_EINVAL, "adjoint_rows: operands must be 16-byte aligned");
-  fa.g = gvec; fa.r = r_out; fa.dots = dots; fa.r_accumulate = accumulate_r ? 1 : 0; fa.r_scale = r_scale;
+  fa.g = gvec; fa.r = r_out; fa.dots = dots; fa.r_accumulate = accumulate_r ? 1 : 0; fa.r_scale = r_scale; fa.wpos = wpos;
   const unsigned grid = adjoint_rows_grid(g);
   const int slots = (d + 3) / 4;
   if (slots <= 16) hipLaunchKernelGGL((adjoint_rows_kernel<16, 8>), dim3(grid), dim3(kWave), 0, stream, fa);
