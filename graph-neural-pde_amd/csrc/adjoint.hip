@@ -705,6 +705,7 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     w = s->w;
   }
   const bool swapped = s->tape != nullptr && s->swapped;
+  bool r_through_map = false;
   int n_pairs = s->n_dots;                     // (d1, d2) pairs the dots fold below has to sum
   if (swapped) {
     // Recorded solve, cotangent side only: the row kernel on the TRANSPOSED graph with the roles exchanged (gathered = u_a, own row = the
@@ -723,7 +724,10 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
       rc = launch_adjoint_rows(gt, fused_w ? w : s->w_t, ua, uy, d, ld, &eS, s->r_t, s->dots, s->ws_spmm_t, s->spmm_t_bytes, st, padded, false, 1.0f,
                                fused_w ? s->t_from_csr : nullptr);
       if (rc) return rc;
-      if (g->e > 0) {       // the edge products in the order the attention backward walks them
+      // the edge products in the order the attention backward walks them: the row-softmax kernels read r_t through the position map
+      // themselves (RRef, csrc/backward.hip); the general normaliser backward (columns / squareplus / GAT / exp kernel) takes a permuted copy
+      r_through_map = fused_w && s->rows_bwd && !gat && at.type == GNPDE_ATT_SCALED_DOT;
+      if (g->e > 0 && !r_through_map) {
         hipLaunchKernelGGL(permute_f32_kernel, dim3((g->e + 8 * kBlock - 1) / (8 * kBlock)), dim3(kBlock), 0, st, s->r_t, s->csr_from_t, g->e, s->r);
         GNPDE_LAUNCH_CHECK();
       }
@@ -815,7 +819,8 @@ int enqueue_stage(gnpde_adjoint* s, const float* uy, const float* ua, float* Fou
     const bool lanes = head_rowsum_supported(h, dk);            // lane-per-entry row sums (rows without entries stay zero)
     const bool dq_fused = s->rows_bwd && lanes && attention_rows_bwd_dq_supported(h, dk);
     if (lanes) GNPDE_HIP(hipMemsetAsync(s->dqk, 0, static_cast<size_t>(n) * M * 4, st));
-    if (s->rows_bwd) rc = launch_attention_rows_bwd_dq(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, dq_fused ? s->dqk : nullptr, M, s->hub_ws, st);
+    if (s->rows_bwd) rc = launch_attention_rows_bwd_dq(g, &at, r_through_map ? s->r_t : s->r, r.alpha, r.alpha_sigmoid, s->ds, dq_fused ? s->dqk : nullptr, M,
+                                                       s->hub_ws, st, r_through_map ? s->csr_from_t : nullptr);
     else rc = gnpde_edge_attention_bwd(g, &at, s->r, r.alpha, r.alpha_sigmoid, s->ds, s->ws_attbwd, s->attbwd_bytes, st);
     if (rc) return rc;
     if (lanes) {

@@ -12,6 +12,16 @@
 namespace gnpde {
 namespace {
 
+// The gradient of the head-mean weights per entry, read through an optional position map: r[p] = data[pos[p]] when the producer left it in
+// ANOTHER graph's order (the cotangent-side sweep of a recorded solve forms the products on the transposed graph: reading them through
+// the map here replaces a 26-us permutation pass; csrc/adjoint.hip).
+struct RRef {
+  const float* __restrict__ data;
+  const int* __restrict__ pos;
+  __device__ __forceinline__ float operator[](long long p) const { return pos != nullptr ? data[pos[p]] : data[p]; }
+};
+
+
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
@@ -252,7 +262,7 @@ template <int H, int DK, int GL, int PER, bool HUBS, bool DQ>
 __global__ __launch_bounds__(kBlock) void attention_rows_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                                    const int* __restrict__ bin_rows, int first_rec, int n_rec,
                                                                    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-                                                                   const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                   const RRef r, const float* __restrict__ edge_w,
                                                                    const float* __restrict__ scale_ptr, int scale_sigmoid,
                                                                    const int* __restrict__ long_rows, int n_long,
                                                                    float* __restrict__ ds, float* __restrict__ dq, int lddq) {
@@ -492,7 +502,7 @@ __device__ __forceinline__ float hub_block_max(float v, float* red) {
 template <int H, int DK, bool DQ>
 __global__ __launch_bounds__(kHubThreads) void attention_hub_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                                        const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-                                                                       const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                       const RRef r, const float* __restrict__ edge_w,
                                                                        const float* __restrict__ scale_ptr, int scale_sigmoid,
                                                                        const int* __restrict__ long_rows, float* __restrict__ ds,
                                                                        float* __restrict__ dq, int lddq) {
@@ -669,7 +679,7 @@ template <int H, int DK>
 __global__ __launch_bounds__(kBlock) void attention_hub_stats_kernel(const int* __restrict__ colidx, const int* __restrict__ lc_row,
                                                                     const int* __restrict__ lc_begin, const int* __restrict__ lc_end,
                                                                     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-                                                                    const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                    const RRef r, const float* __restrict__ edge_w,
                                                                     float* __restrict__ part) {
   constexpr int PER = GNPDE_LONG_ROW / kBlock;      // entries per thread
   __shared__ float red[kWavesPerBlock];
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void attention_hub_ds_kernel(const int* __r
                                                                  const int* __restrict__ lc_row, const int* __restrict__ lc_begin,
                                                                  const int* __restrict__ lc_end, const int* __restrict__ lc_first,
                                                                  const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-                                                                 const float* __restrict__ r, const float* __restrict__ edge_w,
+                                                                 const RRef r, const float* __restrict__ edge_w,
                                                                  const float* __restrict__ scale_ptr, int scale_sigmoid,
                                                                  const float* __restrict__ part, float* __restrict__ ds,
                                                                  float* __restrict__ dqpart) {
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(kWave) void hub_rowpart_fold_kernel(const int* __re
 
 template <int H, int DK, bool DQ>
 int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
+                                int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s, const int* rpos) {
   const int n16 = g->n_bin16, n64 = g->n_bin64, nl = g->n_long_rows;
   // second class (17..512 entries, longest first): its trailing n_bin_le64 records (17..64 entries) take a ONE-pass launch (an entry per
   // lane, 1/8 of the score registers: twice the waves per SIMD and no predicated dead passes), the leading ones the 8-pass launch
@@ -869,7 +879,7 @@ int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t*
     constexpr int rows_per_block = kWavesPerBlock * (kWave / 16);
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, 16, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
-                       g->bin_rows, 0, n16, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
+                       g->bin_rows, 0, n16, att->q, att->k, att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, 0,
                        ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
@@ -879,10 +889,10 @@ int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t*
     float* stats = hub_ws;
     float* dqpart = hub_ws + static_cast<size_t>(nc) * 3 * H;
     hipLaunchKernelGGL((attention_hub_stats_kernel<H, DK>), dim3(nc), dim3(kBlock), 0, s, g->colidx, g->long_chunk_row, g->long_chunk_begin,
-                       g->long_chunk_end, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, stats);
+                       g->long_chunk_end, att->q, att->k, att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, stats);
     GNPDE_LAUNCH_CHECK();
     hipLaunchKernelGGL((attention_hub_ds_kernel<H, DK, DQ>), dim3(nc), dim3(kBlock), 0, s, g->rowptr, g->colidx, g->long_chunk_row,
-                       g->long_chunk_begin, g->long_chunk_end, g->long_chunk_first, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
+                       g->long_chunk_begin, g->long_chunk_end, g->long_chunk_first, att->q, att->k, att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, scale,
                        scale_sigmoid, stats, ds_csr, dqpart);
     GNPDE_LAUNCH_CHECK();
     if constexpr (DQ) {
@@ -892,20 +902,20 @@ int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t*
     }
   } else if (nl > 0) {       // no scratch: one 1024-thread workgroup per hub
     hipLaunchKernelGGL((attention_hub_bwd_kernel<H, DK, DQ>), dim3(nl), dim3(kHubThreads), 0, s, g->rowptr, g->colidx, att->q, att->k,
-                       att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, ds_csr, dq, lddq);
+                       att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, scale, scale_sigmoid, g->long_rows, ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
   if (n_gt64 > 0) {
     const unsigned grid = static_cast<unsigned>((n_gt64 + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, GNPDE_LONG_ROW / kWave, false, DQ>), dim3(grid), dim3(kBlock), 0, s,
-                       g->rowptr, g->colidx, g->bin_rows, n16, n_gt64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale,
+                       g->rowptr, g->colidx, g->bin_rows, n16, n_gt64, att->q, att->k, att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, scale,
                        scale_sigmoid, g->long_rows, 0, ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
   if (n_le64 > 0) {
     const unsigned grid = static_cast<unsigned>((n_le64 + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL((attention_rows_bwd_kernel<H, DK, kWave, 1, false, DQ>), dim3(grid), dim3(kBlock), 0, s, g->rowptr, g->colidx,
-                       g->bin_rows, n16 + n_gt64, n_le64, att->q, att->k, att->ldqk, r_csr, att->edge_w_csr, scale, scale_sigmoid,
+                       g->bin_rows, n16 + n_gt64, n_le64, att->q, att->k, att->ldqk, RRef{r_csr, rpos}, att->edge_w_csr, scale, scale_sigmoid,
                        g->long_rows, 0, ds_csr, dq, lddq);
     GNPDE_LAUNCH_CHECK();
   }
@@ -914,11 +924,11 @@ int launch_attention_rows_bwd_v(const gnpde_graph_t* g, const gnpde_attention_t*
 
 template <int H, int DK>
 int launch_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                              int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
+                              int scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s, const int* rpos) {
   if constexpr (H * DK <= 32) {
-    if (dq != nullptr) return launch_attention_rows_bwd_v<H, DK, true>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s);
+    if (dq != nullptr) return launch_attention_rows_bwd_v<H, DK, true>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s, rpos);
   }
-  return launch_attention_rows_bwd_v<H, DK, false>(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, hub_ws, s);
+  return launch_attention_rows_bwd_v<H, DK, false>(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, hub_ws, s, rpos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,7 +1148,7 @@ bool attention_rows_bwd_dq_supported(int heads, int dk) {
 }
 
 int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s) {
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s, const int* rpos) {
   GNPDE_CHECK_ARG(g && att && r_csr && ds_csr && att->q && att->k, GNPDE_EINVAL, "attention_rows_bwd: null argument");
   GNPDE_CHECK_ARG(att->type == GNPDE_ATT_SCALED_DOT && att->norm_idx == 0 && !att->square_plus, GNPDE_ESHAPE,
                   "attention_rows_bwd: only scaled-dot attention with a softmax over the row");
@@ -1151,7 +1161,7 @@ int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t
   const int h = att->heads, dk = att->att_dim / att->heads;
   GNPDE_CHECK_ARG(dq == nullptr || attention_rows_bwd_dq_supported(h, dk), GNPDE_ESHAPE, "attention_rows_bwd: d q fusion needs heads * d_k <= 32");
 #define GNPDE_AB(HH, DD) \
-  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s);
+  if (h == HH && dk == DD) return launch_attention_rows_bwd<HH, DD>(g, att, r_csr, scale, scale_sigmoid, ds_csr, dq, lddq, hub_ws, s, rpos);
   GNPDE_AB(1, 4) GNPDE_AB(1, 8) GNPDE_AB(1, 16) GNPDE_AB(2, 4) GNPDE_AB(2, 8) GNPDE_AB(2, 16) GNPDE_AB(4, 4) GNPDE_AB(4, 8)
   GNPDE_AB(4, 16) GNPDE_AB(8, 4) GNPDE_AB(8, 8) GNPDE_AB(8, 16)
 #undef GNPDE_AB
@@ -1162,5 +1172,5 @@ int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t
 
 extern "C" int gnpde_attention_rows_bwd(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
                                         int32_t scale_sigmoid, float* ds_csr, void* stream) {
-  return gnpde::launch_attention_rows_bwd_dq(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
+  return gnpde::launch_attention_rows_bwd_dq(g, att, r_csr, scale, scale_sigmoid, ds_csr, nullptr, 0, nullptr, static_cast<hipStream_t>(stream), nullptr);
 }

@@ -162,7 +162,7 @@ size_t hub_bwd_workspace_floats(const gnpde_graph_t* g, int heads, int att_dim);
 // row softmax backward (ds) with the row-side head sum d q formed in the same kernel (backward.hip; heads * d_k <= 32)
 bool attention_rows_bwd_dq_supported(int heads, int dk);
 int launch_attention_rows_bwd_dq(const gnpde_graph_t* g, const gnpde_attention_t* att, const float* r_csr, const float* scale,
-                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s);
+                                 int32_t scale_sigmoid, float* ds_csr, float* dq, int lddq, float* hub_ws, hipStream_t s, const int* rpos = nullptr);
 
 // attention + aggregation of the short rows in one kernel (spmm.hip) and the hub-row weights it needs (attention.hip)
 bool attn_spmm_supported(const gnpde_graph_t* g, const gnpde_attention_t& at, int d, int ld, const float* u,
