@@ -524,6 +524,13 @@ def _tape_claim(func, name, ctx):
   func.__dict__[name] = weakref.ref(ctx)
 
 
+_TAPE_GROWTH_CAP_BYTES = 96 << 30     # a recorded dopri5 solve whose tape would outgrow this runs the host loop instead (round-5 advisor item)
+
+
+class _TapeTooLong(_lib.GnpdeError):
+  pass
+
+
 _TAPE_BUDGET_BYTES = 8 << 30     # first tape allocation (it grows when a solve accepts more steps than it holds)
 
 
@@ -597,6 +604,9 @@ class _RecordedDopri5(torch.autograd.Function):
         if 'do not fit the tape' not in str(exc):
           raise
         torch.cuda.synchronize(y0c.device)
+        state_bytes = max(n * desc.struct.ld * 4, 1)
+        if 2 * sol.tape_capacity * 6 * state_bytes > _TAPE_GROWTH_CAP_BYTES:
+          raise _TapeTooLong('recorded dopri5: %d accepted steps do not fit a tape of %.0f GB' % (sol.tape_capacity, _TAPE_GROWTH_CAP_BYTES / 1e9))
         sol.set_tape(2 * sol.tape_capacity)           # more accepted steps than slots: a longer tape, and the solve again
     stats = sol.stats()
     func._dopri5_stats = dict(stats, recorded=True)
@@ -651,8 +661,14 @@ def _solve_dopri5_recorded(func, y0, t, rtol, atol):
     func._last_train_solve = 'differentiable host loop (the record of an earlier forward pass still awaits its backward)'
     return _solve_dopri5(func, y0, t, rtol, atol)
   t0_, t1_ = end_points(t)
-  return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, t0_, t1_, float(rtol),
-                               float(atol))
+  nfe0 = func.nfe
+  try:
+    return _RecordedDopri5.apply(y0, func._edge_values(), func.alpha_train, func.beta_train, func, t0_, t1_, float(rtol),
+                                 float(atol))
+  except _TapeTooLong as exc:
+    func.nfe = nfe0
+    func._last_train_solve = 'differentiable host loop (%s)' % exc
+    return _solve_dopri5(func, y0, t, rtol, atol)
 
 
 # --------------------------------------------------------------------------------------------------

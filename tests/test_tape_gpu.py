@@ -478,3 +478,19 @@ def test_cotangent_side_sweep_equals_the_first_form(dev, case):
   assert_parity(gx1, gx0, 2e-6, case + ' grad_x')
   refs = {k: v for k, v in g0.items() if v is not None}
   _module_scaled(g1, refs, 5e-5, case)      # (the scalar gradients are sums over all rows: the first form subtracts beta <u_a, x0> back out of a float sum)
+
+
+def test_recorded_dopri5_tape_growth_is_capped(dev, monkeypatch):
+  """A solve whose accepted steps would need a tape beyond the cap runs the differentiable host loop instead of doubling without bound
+  (round-5 advisor item)."""
+  monkeypatch.setattr(O, '_TAPE_BUDGET_BYTES', 1)          # -> the smallest tape (8 slots)
+  monkeypatch.setattr(O, '_TAPE_GROWTH_CAP_BYTES', 1 << 10)
+  block, x, ei, opt = _cora_like(dev, n=400, d=16, heads=4, A=16, seed=41, time=30.0, tol_scale=1.0)
+  c = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+  z1, gx1, g1, nfe1 = _train_once(block, x, dev, c)
+  assert str(block.odefunc._last_train_solve).startswith('differentiable host loop'), block.odefunc._last_train_solve
+  monkeypatch.setattr(O, '_TAPE_GROWTH_CAP_BYTES', 96 << 30)
+  z2, gx2, g2, nfe2 = _train_once(block, x, dev, c)
+  assert str(block.odefunc._last_train_solve).startswith('native recorded')
+  assert nfe1 == nfe2
+  assert_parity(gx1, gx2, 2e-4, 'grad_x host loop vs recorded')
