@@ -18,7 +18,7 @@ LONG_ROW = 512
 STAGE_RHS, STAGE_EULER, STAGE_RK1, STAGE_RK2, STAGE_RK3, STAGE_RK4 = range(6)
 STAGE_RK1C, STAGE_RK2C, STAGE_RK3C, STAGE_RK4C = range(6, 10)
 STAGE_LINCOMB = 10
-ABI_VERSION = 6      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
+ABI_VERSION = 7      # GNPDE_ABI_VERSION of include/gnpde.h this package's struct layouts and prototypes were written for
 ATT_SCALED_DOT, ATT_COSINE, ATT_PEARSON, ATT_EXP_KERNEL, ATT_GAT = range(5)
 RHS_LAPLACIAN, RHS_TRANSFORMER, RHS_GAT = range(3)
 METHOD_EULER, METHOD_RK4, METHOD_MIDPOINT = range(3)
@@ -173,6 +173,9 @@ PROTOTYPES = {
   'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_dopri5_workspace_bytes': (ctypes.c_size_t, [c_vp]),
   'gnpde_dopri5_create': (ctypes.c_int, [c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t]),
+  'gnpde_dopri5_sharded_workspace_bytes': (ctypes.c_size_t, [c_vp]),
+  'gnpde_dopri5_create_sharded': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_int64, c_vp,
+                                                 ctypes.c_size_t]),
   'gnpde_dopri5_run': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, c_vp, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_dopri5_set_early_stop': (ctypes.c_int, [c_vp, ctypes.POINTER(DecoderStruct), c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32,

@@ -363,6 +363,11 @@ struct gnpde_dopri5 {
   float* host_h = nullptr;      // pinned copy of the accepted steps' sizes, read once behind a recorded solve
   int host_h_capacity = 0;
   const int* row_order = nullptr;   // gnpde_dopri5_set_row_order: solver row r <-> caller's row row_order[r]
+  // Row-partitioned solve (gnpde_dopri5_create_sharded): the evaluations go through the exchange engine (its stage buffers hold the four
+  // states that are ever an evaluation's input: Y[0], Y[1], u[0], u[1]), the error norms are summed over the ranks inside the stream
+  gnpde_sharded_solver_t* shard = nullptr;
+  long long n_rows = 0;             // rows the element-wise kernels of this rank cover (all rows / the owned rows)
+  double count = 0.0;               // elements of the WHOLE state: the mean of the error norm is over every rank's rows
   float last_x = 0.f;           // interpolation fraction of the last accepted step of the last run
   int tape_steps = 0;           // accepted steps of the last recorded run (0: nothing to differentiate)
 };
@@ -384,10 +389,19 @@ size_t dopri5_layout(const gnpde_rhs_t& r, gnpde_dopri5* s) {
   return off;
 }
 
+// one evaluation of f at u with the given epilogue: the whole graph, or -- partitioned -- exchange + interior + boundary rows
+int enqueue_f(gnpde_dopri5* s, float* u, const gnpde_epilogue_t& e, hipStream_t st) {
+  if (s->shard != nullptr) return sharded_enqueue_eval(s->shard, u, e, st);
+  return enqueue_rhs(s->rhs, u, e, s->ws + s->off_rhs, s->L, st);
+}
+
+__global__ void root_mean_kernel(const double* __restrict__ sum, double count, float* __restrict__ out) {
+  *out = static_cast<float>(sqrt(sum[0] / count));
+}
+
 int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   const gnpde_rhs_t& r = s->rhs;
-  const long long n = r.graph->n;
-  char* rws = s->ws + s->off_rhs;
+  const long long n = s->n_rows;
   const float* h = &s->ctl->h[parity];
   float* y = s->Y[parity];
   float* y1 = s->Y[1 - parity];
@@ -405,20 +419,24 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
     for (int j = 0; j < i; ++j) e.prev[j] = k[j];
     for (int j = 0; j <= i; ++j) e.coef[j] = static_cast<float>(kB[i][j]);
     e.coef_scale = h;
-    if (int rc = enqueue_rhs(r, ui[i - 1], e, rws, s->L, st)) return rc;
+    if (int rc = enqueue_f(s, ui[i - 1], e, st)) return rc;
   }
   {
     gnpde_epilogue_t e = base_epilogue(r);
     e.stage = GNPDE_STAGE_RHS;
     e.out_k = k[6];
-    if (int rc = enqueue_rhs(r, y1, e, rws, s->L, st)) return rc;
+    if (int rc = enqueue_f(s, y1, e, st)) return rc;
   }
   float ce[7];
   for (int j = 0; j < 7; ++j) ce[j] = static_cast<float>(kE[j]);
   int nblocks = 0;
   if (int rc = launch_rk_error_ratio(y, y1, k, ce, 7, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
     return rc;
-  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, reinterpret_cast<const double*>(s->err_ws), nblocks, static_cast<double>(n) * r.d, s->ctl, parity,
+  if (s->shard != nullptr) {      // the squares of every rank's rows: one double all-reduced inside the stream
+    if (int rc = sharded_enqueue_sum(s->shard, reinterpret_cast<double*>(s->err_ws), nblocks, st)) return rc;
+    nblocks = 1;
+  }
+  hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, reinterpret_cast<const double*>(s->err_ws), nblocks, s->count, s->ctl, parity,
                      s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
   GNPDE_LAUNCH_CHECK();
   if (s->tape != nullptr) {
@@ -461,7 +479,17 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
 // rms(sum_j c_j v_j / (atol + rtol |y|)) -> *out (device)
 int scaled_rms(gnpde_dopri5* s, const float* const* v, const float* c, int n_v, hipStream_t st, float* out) {
   const gnpde_rhs_t& r = s->rhs;
-  return launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, r.graph->n, r.d, r.ld, out, s->err_ws, st, nullptr,
+  if (s->shard != nullptr) {
+    int nblocks = 0;
+    if (int rc = launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, s->n_rows, r.d, r.ld, nullptr, s->err_ws, st, nullptr,
+                                       &nblocks))
+      return rc;
+    if (int rc = sharded_enqueue_sum(s->shard, reinterpret_cast<double*>(s->err_ws), nblocks, st)) return rc;
+    hipLaunchKernelGGL(root_mean_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<const double*>(s->err_ws), s->count, out);
+    GNPDE_LAUNCH_CHECK();
+    return 0;
+  }
+  return launch_rk_error_ratio(s->Y[0], s->Y[0], v, c, n_v, s->atol, s->rtol, s->n_rows, r.d, r.ld, out, s->err_ws, st, nullptr,
                                nullptr);
 }
 
@@ -507,8 +535,81 @@ extern "C" int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs,
   s->KA[0] = base + 4 * stride; s->KA[1] = base + 5 * stride;
   for (int j = 0; j < 5; ++j) s->km[j] = base + (6 + j) * stride;
   s->yout = base + 11 * stride;
+  s->n_rows = s->graph.n;
+  s->count = static_cast<double>(s->graph.n) * s->rhs.d;
   if (hipHostMalloc(reinterpret_cast<void**>(&s->host_ctl), sizeof(Ctl), hipHostMallocDefault) != hipSuccess) {
     set_error("dopri5_create: pinned allocation failed");
+    delete s;
+    return GNPDE_EINVAL;
+  }
+  *out = s;
+  return 0;
+}
+
+// Row-partitioned: [controller record | error partials | k0, k6, five k's, y_out of the owned rows]; the evaluation scratch is the engine's
+namespace {
+size_t dopri5_sharded_layout(const ShardedShape& h, gnpde_dopri5* s) {
+  const size_t state = align_up(static_cast<size_t>(h.n_own > 0 ? h.n_own : 1) * h.ld * 4, 256);
+  size_t off = 0;
+  const size_t off_ctl = off;   off += 256;
+  const size_t off_err = off;   off += 4096 * 4;
+  const size_t off_state = off; off += 8 * state;
+  if (s) {
+    s->state_bytes = state;
+    s->off_ctl = off_ctl; s->off_err = off_err; s->off_rhs = off_state; s->off_state = off_state;
+  }
+  return off;
+}
+}  // namespace
+
+extern "C" size_t gnpde_dopri5_sharded_workspace_bytes(gnpde_sharded_solver_t* engine) {
+  if (engine == nullptr) return 0;
+  return dopri5_sharded_layout(sharded_shape(engine), nullptr);
+}
+
+extern "C" int gnpde_dopri5_create_sharded(gnpde_dopri5_t** out, gnpde_sharded_solver_t* engine, float rtol, float atol,
+                                           int64_t n_rows_total, void* workspace, size_t workspace_bytes) {
+  GNPDE_CHECK_ARG(out != nullptr, GNPDE_EINVAL, "dopri5_create_sharded: out is null");
+  *out = nullptr;
+  GNPDE_CHECK_ARG(engine != nullptr, GNPDE_EINVAL, "dopri5_create_sharded: engine is null");
+  GNPDE_CHECK_ARG(rtol >= 0.f && atol >= 0.f && rtol + atol > 0.f, GNPDE_EINVAL, "dopri5_create_sharded: bad tolerances");
+  const ShardedShape h = sharded_shape(engine);
+  GNPDE_CHECK_ARG(h.p2p && h.n_buffers >= 4, GNPDE_ESTATE, "dopri5_create_sharded: the engine needs the P2P transport with 4 shared stage buffers");
+  GNPDE_CHECK_ARG(h.ld % 4 == 0, GNPDE_ESHAPE, "dopri5_create_sharded: the state row stride must be a multiple of 4");
+  GNPDE_CHECK_ARG(n_rows_total >= h.n_own && h.n_own >= 1, GNPDE_EINVAL, "dopri5_create_sharded: %lld rows in total, %d owned",
+                  static_cast<long long>(n_rows_total), h.n_own);
+  if (int rc = sharded_prepare_adaptive(engine)) return rc;
+  gnpde_dopri5* s = new gnpde_dopri5();
+  s->shard = engine;
+  s->rhs = *h.rhs;                 // alpha / beta / x0 / widths of the owned rows (the evaluations themselves are the engine's)
+  s->graph = *h.rhs->graph;
+  s->rhs.graph = &s->graph;
+  s->rhs.att.graph_t = nullptr;
+  s->rtol = rtol;
+  s->atol = atol;
+  s->n_rows = h.n_own;
+  s->count = static_cast<double>(n_rows_total) * h.d;
+  const size_t need = dopri5_sharded_layout(h, s);
+  if (!(workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0)) {
+    set_error("dopri5_create_sharded: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+    delete s;
+    return GNPDE_EWS;
+  }
+  s->ws = static_cast<char*>(workspace);
+  s->ws_bytes = workspace_bytes;
+  s->ctl = reinterpret_cast<Ctl*>(s->ws + s->off_ctl);
+  s->init = reinterpret_cast<Init*>(s->ws + s->off_ctl + 128);
+  s->err_ws = reinterpret_cast<float*>(s->ws + s->off_err);
+  // every state that is ever an evaluation's input lives in a shared stage buffer: the peers push their boundary rows into its halo rows
+  s->Y[0] = sharded_stage_buffer(engine, 0); s->Y[1] = sharded_stage_buffer(engine, 1);
+  s->u[0] = sharded_stage_buffer(engine, 2); s->u[1] = sharded_stage_buffer(engine, 3);
+  float* base = reinterpret_cast<float*>(s->ws + s->off_state);
+  const size_t stride = s->state_bytes / 4;
+  s->KA[0] = base; s->KA[1] = base + stride;
+  for (int j = 0; j < 5; ++j) s->km[j] = base + (2 + j) * stride;
+  s->yout = base + 7 * stride;
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->host_ctl), sizeof(Ctl), hipHostMallocDefault) != hipSuccess) {
+    set_error("dopri5_create_sharded: pinned allocation failed");
     delete s;
     return GNPDE_EINVAL;
   }
@@ -523,14 +624,14 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
   GNPDE_CHECK_ARG(ld_y0 >= r.d && ld_out >= r.d && t1 > t0, GNPDE_EINVAL, "dopri5_run: bad strides or time span");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (trials_per_sync < 1) trials_per_sync = 1;
-  const int n = r.graph->n;
+  const int n = static_cast<int>(s->n_rows);
   s->n_evals = s->n_accepted = s->n_rejected = s->n_launches = s->n_syncs = 0;
   s->tape_steps = 0;
   if (finished) *finished = 0;
   if (s->tape != nullptr) GNPDE_HIP(hipMemsetAsync(s->tape_overflow, 0, sizeof(int), st));
   if (s->early) GNPDE_HIP(hipMemsetAsync(s->early_state, 0, 8 * sizeof(int32_t), st));
   if (!s->padding_cleared) {   // once: the padding columns [d, ld) are never written with anything but what they hold
-    GNPDE_HIP(hipMemsetAsync(s->ws + s->off_state, 0, 12 * s->state_bytes, st));
+    GNPDE_HIP(hipMemsetAsync(s->ws + s->off_state, 0, (s->shard != nullptr ? 8 : 12) * s->state_bytes, st));
     s->padding_cleared = true;
   }
   long long copy_blocks = (static_cast<long long>(n) * r.d + kBlock - 1) / kBlock;
@@ -542,13 +643,12 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(copy_blocks)), dim3(kBlock), 0, st, y0, ld_y0, s->Y[0], r.ld,
                        static_cast<long long>(n), r.d);
   GNPDE_LAUNCH_CHECK();
-  char* rws = s->ws + s->off_rhs;
-  auto feval = [&](const float* src, float* dst) -> int {
+  auto feval = [&](float* src, float* dst) -> int {
     gnpde_epilogue_t e = base_epilogue(r);
     e.stage = GNPDE_STAGE_RHS;
     e.out_k = dst;
     s->n_evals += 1;
-    return enqueue_rhs(r, src, e, rws, s->L, st);
+    return enqueue_f(s, src, e, st);
   };
   if (int rc = feval(s->Y[0], s->KA[0])) return rc;
   // initial step size, entirely on the device (no read-back): see init_h0_kernel / init_dt_kernel
@@ -615,6 +715,11 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     s->n_evals = base_evals + 6 * hc.trials;
     s->n_accepted = hc.accepted;
     s->n_rejected = hc.rejected;
+    if (s->shard != nullptr) {    // a peer that never arrived: its share of the norms is missing, nothing behind this point means anything
+      int lost = 0;
+      if (int rc = sharded_lost_peer(s->shard, &lost)) return rc;
+      GNPDE_CHECK_ARG(!lost, GNPDE_ESTATE, "dopri5_run: a peer never published its rows or its share of the error norm (wait timed out)");
+    }
     if (hc.done) break;
     GNPDE_CHECK_ARG(hc.t + hc.dt > hc.t, GNPDE_EINVAL, "dopri5_run: underflow in dt %g at t %g", hc.dt, hc.t);
     if (max_evals > 0 && s->n_evals > max_evals) return 0;   // *finished stays 0
@@ -652,6 +757,7 @@ extern "C" int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decode
     s->early = false;
     return 0;
   }
+  GNPDE_CHECK_ARG(s->shard == nullptr, GNPDE_ESTATE, "dopri5_set_early_stop: not on a row-partitioned solve (the split counts are over all rows)");
   if (int rc = check_decoder(dec, s->rhs.d)) return rc;
   GNPDE_CHECK_ARG(state != nullptr && max_trial_steps >= 1, GNPDE_EINVAL, "dopri5_set_early_stop: state is null or no trial steps allowed");
   GNPDE_CHECK_ARG((trace != nullptr || trace_capacity == 0) && (times != nullptr || times_capacity == 0) && trace_capacity >= 0 &&
@@ -669,6 +775,7 @@ extern "C" int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decode
 
 extern "C" int gnpde_dopri5_set_row_order(gnpde_dopri5_t* s, const int32_t* order) {
   GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "dopri5_set_row_order: solver is null");
+  GNPDE_CHECK_ARG(order == nullptr || s->shard == nullptr, GNPDE_ESTATE, "dopri5_set_row_order: not on a row-partitioned solve");
   s->row_order = order;      // (read by the copy kernels of gnpde_dopri5_run only: the captured trial steps are untouched)
   return 0;
 }
@@ -722,6 +829,7 @@ extern "C" int gnpde_dopri5_set_tape(gnpde_dopri5_t* s, void* tape, size_t tape_
   s->tape = nullptr;
   s->tape_steps = 0;
   if (tape == nullptr) return 0;
+  GNPDE_CHECK_ARG(s->shard == nullptr, GNPDE_ESTATE, "dopri5_set_tape: not on a row-partitioned solve");
   GNPDE_CHECK_ARG(s->rhs.kind == GNPDE_RHS_LAPLACIAN, GNPDE_EINVAL, "dopri5_set_tape: the recorded solve covers the Laplacian function (f linear in the state)");
   GNPDE_CHECK_ARG(capacity_steps >= 1 && reinterpret_cast<uintptr_t>(tape) % 256 == 0, GNPDE_EINVAL, "dopri5_set_tape: bad capacity or alignment");
   const size_t need = gnpde_dopri5_tape_bytes(&s->rhs, capacity_steps);

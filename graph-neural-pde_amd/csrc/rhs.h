@@ -48,4 +48,21 @@ int enqueue_rhs(const gnpde_rhs_t& r, const float* u, const gnpde_epilogue_t& ep
 // epilogue with the descriptor's alpha / beta / x0 filled in
 gnpde_epilogue_t base_epilogue(const gnpde_rhs_t& r);
 
+// The exchange engine of the row-partitioned solvers (a gnpde_sharded_solver_t with the P2P transport, sharded.hip) as the adaptive
+// solver drives it (dopri5.hip, gnpde_dopri5_create_sharded): one evaluation = push of the boundary rows of `u` + interior pass +
+// wait + boundary pass; one sum = the all-reduce of a double over the ranks, inside the stream (no host, no library call).
+struct ShardedShape {
+  int n_own, n_local, d, ld, world, n_buffers;
+  bool p2p;
+  size_t buffer_bytes;
+  const gnpde_rhs_t* rhs;      // the interior descriptor: alpha / beta / x0 / widths of the owned rows
+};
+ShardedShape sharded_shape(gnpde_sharded_solver_t* s);
+float* sharded_stage_buffer(gnpde_sharded_solver_t* s, int b);
+int sharded_prepare_adaptive(gnpde_sharded_solver_t* s);        // no per-evaluation stamps, no chunked boundary pass
+int sharded_enqueue_eval(gnpde_sharded_solver_t* s, float* u, const gnpde_epilogue_t& e, hipStream_t st);
+// value[0] <- sum over the ranks (in rank order: the same bits on every rank) of (value[0] + ... + value[n_partials - 1])
+int sharded_enqueue_sum(gnpde_sharded_solver_t* s, double* value, int n_partials, hipStream_t st);
+int sharded_lost_peer(gnpde_sharded_solver_t* s, int* lost);    // synchronising read of the error word
+
 }  // namespace gnpde

@@ -104,7 +104,10 @@ struct gnpde_comm {
 // IPC-shared exchange memory of one rank.  data: n_buffers stage buffers (coarse-grained: read through L2 by the
 // kernels launched after the wait kernel; a kernel boundary invalidates stale lines).  ctl (fine-grained, never cached):
 // [0, 128) epoch flags written by the peers, [128] pushes done, [129] waits done, [130] push blocks finished, [131] error.
-constexpr int kCtlWords = 256, kCtlPush = 128, kCtlWait = 129, kCtlDone = 130, kCtlErr = 131, kMaxWorld = 128;
+// Behind them, the all-reduce of the adaptive solver's error norm (p2p_sum_kernel): [132] sums done, [256, 384) the peers' sum epochs,
+// [512, 1024) two banks (epoch parity) of one double per rank.
+constexpr int kCtlWords = 1024, kCtlPush = 128, kCtlWait = 129, kCtlDone = 130, kCtlErr = 131, kCtlSum = 132, kCtlSumFlags = 256,
+              kCtlSumVals = 512, kMaxWorld = 128;
 
 struct gnpde_p2p {
   int rank = 0, world = 1;
@@ -203,6 +206,64 @@ __global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, in
   __threadfence_system();
   __syncthreads();
   if (stamp != nullptr && threadIdx.x == 0) stamp[1] = wall_clock64();   // every peer's rows have landed
+}
+
+// All-reduce (sum) of one double over the ranks, one block: fold this rank's partials (the fold of dopri5.hip's control kernel), store
+// the result into bank (epoch & 1) of every peer, raise the epoch in every peer's flag array, wait for every peer's epoch, add the
+// bank in RANK order -- every rank adds the same numbers in the same order, so every rank's controller sees the same bits and takes
+// the same accept / reject decisions.  A bank is rewritten two sums later: by then every peer has passed the sum in between, which
+// needed this rank's contribution to it, which this rank made after reading the bank.  Bounded wait like wait_flags_kernel.
+__global__ __launch_bounds__(kBlock) void p2p_sum_kernel(double* __restrict__ value, int n_partials, uint32_t* ctl, uint32_t* const* peer_ctl,
+                                                        int rank, int world, long long max_spins) {
+  __shared__ double red[kBlock];
+  __shared__ unsigned epoch;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += kBlock) acc += value[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (world == 1) {
+    if (threadIdx.x == 0) value[0] = red[0];
+    return;
+  }
+  if (threadIdx.x == 0) {
+    epoch = __hip_atomic_load(ctl + kCtlSum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(ctl + kCtlSum, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const unsigned e = epoch;
+  const int bank = static_cast<int>(e & 1u) * kMaxWorld;
+  const unsigned long long mine = static_cast<unsigned long long>(__double_as_longlong(red[0]));
+  const int p = threadIdx.x;
+  const bool lost = __hip_atomic_load(ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+  if (p < world) {
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(peer_ctl[p] + kCtlSumVals) + bank + rank;
+    __hip_atomic_store(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (p != rank) __hip_atomic_store(peer_ctl[p] + kCtlSumFlags + rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (p < world && p != rank && !lost) {
+    long long n = 0;
+    while (static_cast<int>(__hip_atomic_load(ctl + kCtlSumFlags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++n > max_spins) {
+        __hip_atomic_store(ctl + kCtlErr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long* vals = reinterpret_cast<const unsigned long long*>(ctl + kCtlSumVals) + bank;
+    double total = 0.0;
+    for (int q = 0; q < world; ++q)
+      total += __longlong_as_double(static_cast<long long>(__hip_atomic_load(vals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)));
+    value[0] = total;
+  }
 }
 
 }  // namespace
@@ -917,6 +978,55 @@ extern "C" int gnpde_sharded_solver_timing(gnpde_sharded_solver_t* s, int64_t* s
   GNPDE_HIP(hipMemcpy(stamps, s->d_stamps, static_cast<size_t>(n) * 4 * sizeof(int64_t), hipMemcpyDeviceToHost));   // synchronises
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ the engine, for dopri5.hip (rhs.h)
+namespace gnpde {
+
+ShardedShape sharded_shape(gnpde_sharded_solver* s) {
+  ShardedShape h{};
+  h.n_own = s->n_own; h.n_local = s->n_own + s->n_halo; h.d = s->d; h.ld = s->ld;
+  h.world = s->p2p ? s->p2p->world : (s->comm ? s->comm->world : 1);
+  h.p2p = s->p2p != nullptr;
+  h.n_buffers = s->p2p ? s->p2p->n_buffers : 0;
+  h.buffer_bytes = s->p2p ? s->p2p->buffer_bytes : 0;
+  h.rhs = &s->rhs_int;
+  return h;
+}
+
+float* sharded_stage_buffer(gnpde_sharded_solver* s, int b) { return stage_buffer(s, b); }
+
+int sharded_prepare_adaptive(gnpde_sharded_solver* s) {
+  GNPDE_CHECK_ARG(s->p2p != nullptr, GNPDE_ESTATE, "adaptive partitioned solve: the P2P transport only");
+  GNPDE_CHECK_ARG(s->rhs_chunk.empty(), GNPDE_ESTATE, "adaptive partitioned solve: no chunked boundary pass");
+  drop_sharded_graph(s);
+  if (s->d_stamps) (void)hipFree(s->d_stamps);    // (per-evaluation stamps are sized by a fixed grid's evaluation count)
+  s->d_stamps = nullptr;
+  s->n_evals = 0;
+  s->eval_cursor = 0;
+  return 0;
+}
+
+int sharded_enqueue_eval(gnpde_sharded_solver* s, float* u, const gnpde_epilogue_t& e, hipStream_t st) {
+  s->eval_cursor = 0;      // (first / last only matter to the chunked boundary pass and the stamps, both off here)
+  return enqueue_eval(s, u, e, st);
+}
+
+int sharded_enqueue_sum(gnpde_sharded_solver* s, double* value, int n_partials, hipStream_t st) {
+  GNPDE_CHECK_ARG(s->p2p != nullptr && value != nullptr && n_partials >= 1, GNPDE_EINVAL, "sharded sum: bad arguments");
+  hipLaunchKernelGGL(p2p_sum_kernel, dim3(1), dim3(kBlock), 0, st, value, n_partials, s->p2p->ctl, s->d_peer_ctl, s->p2p->rank,
+                     s->p2p->world, s->max_spins);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+int sharded_lost_peer(gnpde_sharded_solver* s, int* lost) {
+  uint32_t w = 0;
+  if (s->p2p) GNPDE_HIP(hipMemcpy(&w, s->p2p->ctl + kCtlErr, sizeof(w), hipMemcpyDeviceToHost));
+  *lost = w != 0u;
+  return 0;
+}
+
+}  // namespace gnpde
 
 extern "C" int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins) {
   GNPDE_CHECK_ARG(s != nullptr && max_spins > 0, GNPDE_EINVAL, "sharded_solver_set_spin_limit: bad argument");

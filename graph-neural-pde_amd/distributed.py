@@ -729,8 +729,11 @@ class NativeShardedSolver(object):
     self.shard, self.be, self.transport = shard, backend, transport
     s = shard
     L = _lib.lib()
-    grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
-    dts = (grid[1:] - grid[:-1]).tolist()
+    if T is None:       # the exchange engine alone (NativeShardedDopri5 drives it): no time grid
+      dts = []
+    else:
+      grid = time_grid(torch.tensor([0.0, float(T)]), step_size)
+      dts = (grid[1:] - grid[:-1]).tolist()
     self.dts = tuple(dts)
     self.d_int = backend._descriptor(with_source, 'interior')
     self.d_bnd = backend._descriptor(with_source, 'boundary')
@@ -755,7 +758,7 @@ class NativeShardedSolver(object):
       both = max(L.gnpde_rhs_workspace_bytes(self.d_int.ref()), L.gnpde_rhs_workspace_bytes(self.d_bnd.ref()))
       slack = max(0, max(L.gnpde_rhs_workspace_bytes(dc.ref()) for dc in self.d_chunks) - both) + 256
     self.ws = torch.empty(int(need) + slack, dtype=torch.uint8, device=backend.dev)
-    arr = (ctypes.c_float * len(dts))(*dts)
+    arr = (ctypes.c_float * max(len(dts), 1))(*dts)
     handle = ctypes.c_void_p()
     self.ctx = self.comm = None
     self._own_ctx = False
@@ -874,6 +877,64 @@ class NativeShardedSolver(object):
     if self._own_ctx and self.ctx is not None:
       self.ctx.close()
       self.ctx = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+
+class NativeShardedDopri5(object):
+  """gnpde_dopri5_create_sharded over a NativeBackend's shard: dopri5 with the controller ON THE DEVICE of every rank.  A trial step
+  is one hipGraph replay per rank (six evaluations, each push + interior rows + wait + boundary rows; the error norm as one double
+  summed over the ranks inside the stream, csrc/sharded.hip p2p_sum_kernel); every rank's controller record holds the same bits,
+  so every rank reads the same record once per batch of trial steps and queues the same number of them -- no host read and no
+  torch.distributed call per trial step (ShardedSolver.integrate_adaptive: one all-to-all per evaluation and one all-reduce per
+  trial step from Python).  Reference call: src/block_constant.py:57-62 with opt['method'] = 'dopri5' (run_GNN.py's default)."""
+
+  def __init__(self, shard, backend, rtol, atol, n_rows_total, with_source=True, ctx=None, group=None):
+    import ctypes
+    self.shard, self.be = shard, backend
+    self.engine = NativeShardedSolver(shard, backend, None, method='rk4', with_source=with_source, ctx=ctx, group=group, boundary_chunks=1)
+    L = _lib.lib()
+    self.handle = None
+    try:
+      nbytes = int(L.gnpde_dopri5_sharded_workspace_bytes(self.engine.handle))
+      self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=backend.dev)
+      handle = ctypes.c_void_p()
+      _lib.check(L.gnpde_dopri5_create_sharded(ctypes.byref(handle), self.engine.handle, float(rtol), float(atol), int(n_rows_total),
+                                               _lib.ptr(self.ws), self.ws.numel()))
+      self.handle = handle
+    except Exception:
+      self.engine.close()
+      raise
+    self.out = backend.empty(shard.n_own)
+
+  def integrate(self, y_own, x0_own, t0, t1, trials_per_sync=1, max_evals=0):
+    """(owned rows of y(t1) -- a view of an internal buffer --, finished); x0_own refreshes the persistent source term in place."""
+    import ctypes
+    if x0_own is not None:
+      self.be.x0.copy_(x0_own)
+    y = _lib.f32rows(y_own, 'y0')
+    fin = ctypes.c_int32(0)
+    _lib.check(_lib.lib().gnpde_dopri5_run(self.handle, _lib.ptr(y), y.stride(0), float(t0), float(t1), _lib.ptr(self.out), self.out.stride(0),
+                                           int(trials_per_sync), int(max_evals), ctypes.byref(fin), _lib.stream_of(y)))
+    return self.out, bool(fin.value)
+
+  def stats(self):
+    import ctypes
+    v = [ctypes.c_int32(0) for _ in range(5)]
+    _lib.check(_lib.lib().gnpde_dopri5_stats(self.handle, *[ctypes.byref(x) for x in v]))
+    return dict(zip(('evals', 'accepted', 'rejected', 'launches', 'syncs'), [x.value for x in v]))
+
+  def close(self):
+    if getattr(self, 'handle', None) is not None and self.handle.value:
+      _lib.lib().gnpde_dopri5_destroy(self.handle)
+      self.handle = None
+    if getattr(self, 'engine', None) is not None:
+      self.engine.close()
+      self.engine = None
 
   def __del__(self):
     try:
@@ -1026,9 +1087,47 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
   with_source = bool(func.opt['add_source'])
   skey = (method, dts, with_source)
   sol = ent['solvers'].get(skey)
+  in_graph = (adaptive and method == 'dopri5' and ent['ctx'] is not None and d % 4 == 0 and t.dtype == torch.float32 and
+              os.environ.get('GNPDE_SHARDED_HOST_CONTROLLER', '0') != '1')
+  if in_graph:
+    # dopri5 with the controller on every rank's device: trial steps as per-rank hipGraphs, the error norm summed over the ranks
+    # inside the stream (NativeShardedDopri5) -- every rank holds the same controller record, reads it once per batch of trial steps
+    from .utils import MaxNFEException
+    from .odeint import end_points
+    room = func.opt['max_nfe'] + 1 - func.nfe
+    if room <= 0:
+      raise MaxNFEException
+    skey = (method, float(rtol), float(atol), with_source)
+    sol = ent['solvers'].get(skey)
+    if sol is None:
+      for old in ent['solvers'].values():     # one live solver per function: its stage buffers are the shared P2P block
+        if hasattr(old, 'close'):
+          old.close()
+      ent['solvers'].clear()
+      sol = NativeShardedDopri5(shard, be, rtol, atol, n, with_source=with_source, ctx=ent['ctx'], group=group)
+      ent['solvers'][skey] = sol
+    y_own = y0.detach()[ent['own_ids']]
+    x0_own = None
+    if with_source:
+      if func.x0 is None:
+        raise _lib.GnpdeError('add_source is set but x0 was never assigned (call ODEblock.set_x0)')
+      x0_own = func.x0.detach()[ent['own_ids']]
+    tps = 8 if n * d < (1 << 22) else 1        # (the same rule as on one GPU, over the WHOLE state: the same batches on every rank)
+    if os.environ.get('GNPDE_DOPRI5_TRIALS_PER_SYNC'):
+      tps = max(1, int(os.environ['GNPDE_DOPRI5_TRIALS_PER_SYNC']))
+    t0_, t1_ = end_points(t)
+    z_own, finished = sol.integrate(y_own, x0_own, t0_, t1_, trials_per_sync=tps, max_evals=room)
+    stats = sol.stats()
+    func._dopri5_stats = stats
+    spent = stats['evals']
+    if not finished or spent > room:
+      func.nfe += min(spent, room)
+      raise MaxNFEException
+    func.nfe += spent
+    return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, 0)
   if adaptive:
-    # dopri5 / adaptive_heun: the host controller over sharded evaluations (ShardedSolver.integrate_adaptive); the in-graph P2P
-    # solver is fixed-step
+    # adaptive_heun (and dopri5 where the in-graph solver does not apply): the host controller over sharded evaluations
+    # (ShardedSolver.integrate_adaptive), one all-reduce per trial step
     if sol is None:
       for old in ent['solvers'].values():
         if hasattr(old, 'close'):

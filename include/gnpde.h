@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 6   /* 6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition);  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -823,6 +823,20 @@ int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* timed_out, i
 int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins);
 int gnpde_sharded_solver_num_rhs_evals(const gnpde_sharded_solver_t* s);
 int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s);
+
+/* dopri5 over the row partition with the controller on the device  [replaces, per rank, the Python controller that ran over
+ * torch.distributed until ABI 6: reference src/block_constant.py:57-62 with opt['method'] = 'dopri5' on a graph no single GPU holds].
+ * `engine`: a gnpde_sharded_solver_t created with gnpde_sharded_solver_create_p2p (method GNPDE_METHOD_RK4 -- four shared stage
+ * buffers --, n_steps = 0): it stays the caller's, must outlive the dopri5 object and is used by nothing else meanwhile.  The trial
+ * step of gnpde_dopri5_create is captured per rank with every evaluation as push + interior rows + wait + boundary rows, and the
+ * error norm (and the three norms of the initial step size) as ONE double summed over the ranks inside the stream: every rank stores
+ * its partial into every peer's fine-grained flag block, waits for the peers' and adds them in rank order, so every rank's
+ * controller record holds the same bits and every rank takes the same accept / reject decisions and step sizes -- no host read per
+ * trial step, no collective call.  n_rows_total: rows of the WHOLE graph (the mean of the norm).  gnpde_dopri5_run then takes and
+ * returns the OWNED rows ([n_own, d]); early stopping, the tape and the row order are single-GPU features (GNPDE_ESTATE here). */
+size_t gnpde_dopri5_sharded_workspace_bytes(gnpde_sharded_solver_t* engine);
+int gnpde_dopri5_create_sharded(gnpde_dopri5_t** out, gnpde_sharded_solver_t* engine, float rtol, float atol, int64_t n_rows_total,
+                                void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

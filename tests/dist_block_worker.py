@@ -92,7 +92,9 @@ def main():
     dist.all_gather(allz, mine)
     res[name] = dict(rel_max=e_inf, rel_l2=e_2, nfe=nfe, ref_nfe=int(fx.arr['nfe']), replay_equal=bool(torch.equal(z, z2)),
                      ranks_agree=all(torch.equal(a, mine) for a in allz), own_rows=sh.n_own, halo_rows=sh.n_halo,
-                     world=world)
+                     world=world, solvers=sorted(type(v).__name__ for v in ent['solvers'].values()),
+                     syncs=(getattr(block.odefunc, '_dopri5_stats', None) or {}).get('syncs'),
+                     trials=sum((getattr(block.odefunc, '_dopri5_stats', None) or {}).get(k, 0) for k in ('accepted', 'rejected')))
     dist.barrier()
     for e in block.odefunc._shard_state.values():
       e['close']()

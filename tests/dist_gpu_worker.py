@@ -101,6 +101,34 @@ def main():
       z2 = solver.integrate_adaptive(x_own, x_own, tt.to(dev), rtol, atol, n, method=method).clone()
     assert torch.equal(z1, z2), 'rank %d: repeated adaptive solve differs' % rank
     full = D.gather_rows_all(z1.cpu(), plan, sh)
+    native = {}
+    if method == 'dopri5':
+      # the same solve with the controller on every rank's DEVICE (gnpde_dopri5_create_sharded): trial steps as per-rank hipGraphs, the
+      # error norm summed over the ranks inside the stream; the host reads the controller record once per batch of trial steps
+      ctx = D.P2PContext(sh, d, 4)
+      with torch.no_grad():
+        nat = D.NativeShardedDopri5(sh, be, rtol, atol, n, with_source=True, ctx=ctx)
+        nat.engine.set_spin_limit(1 << 22)
+        n1, fin1 = nat.integrate(x_own, x_own, 0.0, T, trials_per_sync=8)
+        n1 = n1.clone()
+        st1 = nat.stats()
+        n2, fin2 = nat.integrate(x_own, x_own, 0.0, T, trials_per_sync=1)
+        n2 = n2.clone()
+        st2 = nat.stats()
+        n3, fin3 = nat.integrate(x_own, x_own, 0.0, T, trials_per_sync=8, max_evals=8)     # the evaluation budget (opt['max_nfe'])
+        st3 = nat.stats()
+      assert fin1 and fin2 and not fin3, (fin1, fin2, fin3)
+      assert torch.equal(n1, n2), 'rank %d: the batch size of the record reads changed the solve' % rank
+      mine = torch.tensor([st1['evals'], st1['accepted'], st1['rejected'], st1['launches']], dtype=torch.int64)
+      allst = [torch.empty_like(mine) for _ in range(world)]
+      dist.all_gather(allst, mine)
+      assert all(torch.equal(a, mine) for a in allst), 'rank %d: the ranks took different decisions: %r' % (rank, allst)
+      nfull = D.gather_rows_all(n1.cpu(), plan, sh)
+      native = dict(native_evals=st1['evals'], native_syncs=st1['syncs'], native_trials=st1['accepted'] + st1['rejected'],
+                    native_syncs_per_trial_batch1=st2['syncs'], native_budget_evals=st3['evals'],
+                    native_vs_host_controller=float((nfull - full).abs().max() / full.abs().max()))
+      nat.close()
+      ctx.close()
     if rank == 0:
       calls = [0]
 
@@ -115,6 +143,11 @@ def main():
       e_inf, e_2 = parity(full, ref)
       json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
                  'interior_rows': sh.n_interior, 'own_rows': sh.n_own, 'evals': evals, 'ref_evals': calls[0]}, open(out_path, 'w'))
+      if native:
+        n_inf, n_2 = parity(nfull, ref)
+        r = json.load(open(out_path))
+        r.update(native, native_rel_max=n_inf, native_rel_l2=n_2)
+        json.dump(r, open(out_path, 'w'))
     dist.barrier()
     dist.destroy_process_group()
     return

@@ -132,6 +132,10 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
     assert e['rel_max'] < 1e-5 and e['rel_l2'] < 1e-5, (name, e)
     assert e['nfe'] == e['ref_nfe'] and e['replay_equal'] and e['ranks_agree'], (name, e)
     assert e.get('moved', 1.0) > 1e-3, (name, e)       # (self-checks: the solve did something)
+    if name.endswith('_dopri5'):
+      # the adaptive blocks take the device controller over the partition (gnpde_dopri5_create_sharded): fewer reads of the
+      # controller record than trial steps, none per trial step
+      assert e['solvers'] == ['NativeShardedDopri5'] and 0 < e['syncs'] < e['trials'], (name, e)
 
 
 @pytest.mark.parametrize('kind,method,T', [('laplacian', 'dopri5', 2.5), ('transformer', 'dopri5', 1.5), ('laplacian', 'adaptive_heun', 1.0)])
@@ -149,6 +153,14 @@ def test_adaptive_methods_run_partitioned(dev, tmp_path, kind, method, T):
   r = json.load(open(out))
   assert r['world'] == 3 and r['halo_rows'] > 0 and r['evals'] == r['ref_evals'], r
   assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
+  if method == 'dopri5':
+    # the controller on every rank's device (gnpde_dopri5_create_sharded, the path the operator surface takes): the same evaluation
+    # count and state as the reference's controller, the same decisions on every rank (asserted in the worker), and FEWER host reads
+    # than trial steps -- none per trial step: one per batch, batches as long as the end point allows
+    assert r['native_evals'] == r['ref_evals'] and r['native_trials'] * 6 + 2 == r['native_evals'], r
+    assert r['native_rel_max'] < 1e-5 and r['native_rel_l2'] < 1e-5 and r['native_vs_host_controller'] < 1e-5, r
+    assert r['native_syncs'] < r['native_trials'] and r['native_syncs_per_trial_batch1'] == r['native_trials'], r
+    assert 8 < r['native_budget_evals'] < r['native_evals'], r      # (the budget is looked at once per batch of trial steps)
 
 
 @pytest.mark.parametrize('kind,method', [('gat', 'rk4'), ('gat_n1', 'rk4'), ('gat', 'dopri5')])
