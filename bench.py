@@ -34,6 +34,9 @@ import time
 
 import torch
 
+T_PROCESS_START = time.perf_counter()
+DEFAULT_RUN_SECONDS = 310      # the default run (headline + every other configuration by child runs) is planned to end within this
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
@@ -78,7 +81,10 @@ def parse():
                        'adjoint method) on a Pubmed-shaped graph: ms per training iteration of the block, native stages vs the flat host loop')
   ap.add_argument('--no-configs', action='store_true',
                   help='default line only: skip the `configs` block (the other BASELINE configurations, each measured by a child process of this script)')
-  ap.add_argument('--configs-budget', type=float, default=1100.0, help='seconds the `configs` block may take in total (children past it are skipped, and say so)')
+  ap.add_argument('--configs-budget', type=float, default=None,
+                  help='seconds the `configs` block may take in total (children that would not fit are skipped, and say so); default: what is '
+                       'left of %d s since the start of this process, so that the default run ends within about five minutes' % DEFAULT_RUN_SECONDS)
+  ap.add_argument('--parity-only', action='store_true', help='one evaluation of the CPU oracle for the parity figure, no timed cpu_baseline leg')
   ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter_collection.csv files of the live PMC passes')
   ap.add_argument('--train', action='store_true',
                   help='training iteration instead of the inference solve: forward (tape-free native solver) + backward (native adjoint '
@@ -616,8 +622,10 @@ def cpu_baseline(block, x_cpu, evals):
   cands = sorted({c for c in (ncpu, 64, 32, 16, 8) if c <= ncpu}, reverse=True)
   trials = {}
   with torch.no_grad():
-    torch.set_num_threads(cands[0])
+    torch.set_num_threads(min(cands[0], 16) if evals == 0 else cands[0])
     out = rhs(x_cpu)  # warm-up, also the parity reference
+    if evals == 0:       # --parity-only
+      return None, out, {}
     for c in cands:
       torch.set_num_threads(c)
       ts = []
@@ -1388,36 +1396,37 @@ def train_no_adjoint_main(G, args, opt, cfg, ei, n, x, dev):
 
 
 CONFIG_CHILDREN = (
-  # (key, BASELINE.json reference, flags, timeout s).  Every child is this script in another mode and prints its own full JSON line;
-  # the parent keeps a summary.  Ordered so that the cheap ones are never starved by the expensive ones.
+  # (key, BASELINE.json reference, flags, timeout s, seconds it took in the last evidence run).  Every child is this script in another mode
+  # and prints its own full JSON line; the parent keeps a summary.  Ordered by what the line must not lose: the BASELINE configurations
+  # first, the variants DESIGN.md quotes last -- a child that would not fit what is left of the budget is skipped and says so.
   ('c1_cora_grand_l_euler_T4', 'configs[0] as named: Cora GRAND-l, euler, step_size 1, T = 4',
-   ['--graph', 'cora', '--function', 'laplacian', '--method', 'euler', '--steps', '4', '--warmup', '4', '--no-live-pmc', '--no-hbm-probe', '--replays', '21'], 120),
+   ['--graph', 'cora', '--function', 'laplacian', '--method', 'euler', '--steps', '4', '--warmup', '4', '--no-live-pmc', '--no-hbm-probe', '--replays', '21'], 120, 11),
   ('c1_cora_grand_l_rk4', 'configs[0] shape with rk4 (per-step time over 100 steps)',
-   ['--graph', 'cora', '--function', 'laplacian', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120),
+   ['--graph', 'cora', '--function', 'laplacian', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 11),
   ('c2_cora_grand_nl_rk4_row_softmax', 'configs[1]: Cora GRAND-nl scaled_dot, rk4 (A = 128, 8 heads), softmax over rows',
-   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120),
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 21),
   ('c2_cora_grand_nl_rk4_as_run_GNN_runs_it', 'configs[1] with best_params Cora normaliser: squareplus over columns',
-   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120),
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120, 22),
   ('cora_best_params_epoch', 'the reference\'s flagship run (best_params Cora: attention block, Laplacian, dopri5, adjoint=False): s per epoch',
-   ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240),
+   ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240, 4),
   ('pubmed_block_adaptive_heun_adjoint', 'best_params Pubmed\'s ODE block in training: dopri5 forward, adjoint_method adaptive_heun (the reference\'s default)',
-   ['--config', 'pubmed-adjoint'], 200),
+   ['--config', 'pubmed-adjoint'], 200, 5),
   ('coauthorcs_block_dopri5_adjoint', 'best_params CoauthorCS\'s ODE block in training: dopri5 forward, adjoint_method dopri5',
-   ['--config', 'coauthor-adjoint'], 200),
+   ['--config', 'coauthor-adjoint'], 200, 3),
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
-   ['--train', '--steps', '10', '--warmup', '2'], 400),
+   ['--train', '--steps', '10', '--warmup', '2'], 400, 15),
   ('c3_training_iteration_adjoint_off', 'configs[2] shape, TRAINING as run_GNN.py runs rk4 by default (adjoint off): recorded solve + native reverse sweep, host-loop A/B',
-   ['--train', '--no-adjoint', '--steps', '10', '--warmup', '2', '--no-live-pmc'], 300),     # (its counter passes: profiles/r06_train_no_adjoint.json)
+   ['--train', '--no-adjoint', '--steps', '10', '--warmup', '2', '--no-live-pmc'], 300, 5),     # (its counter passes: profiles/r06_train_no_adjoint.json)
   ('c4_arxiv_blend_dopri5', 'configs[3]: ogbn-arxiv BLEND, rewiring block, dopri5',
-   ['--config', 'c4', '--warmup', '2'], 400),
-  ('c3_normalised_over_columns_squareplus', 'configs[2] shape with attention_norm_idx 1 + squareplus (the reference\'s Cora / Citeseer normaliser at scale)',
-   ['--steps', '20', '--warmup', '5', '--norm-idx', '1', '--square-plus', '--no-live-pmc', '--no-hbm-probe', '--cpu-evals', '2'], 300),
-  ('c3_arxiv_flat_no_planted_communities', 'configs[2] shape on a graph WITHOUT community structure (what relabelling gains without planted locality)',
-   ['--graph', 'arxiv_flat', '--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--cpu-evals', '2'], 300),
-  ('c3_arxiv_relabelling_off', 'configs[2] with the node relabelling switched off (GNPDE_REORDER=0)',
-   ['--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--no-cpu-baseline'], 200),
+   ['--config', 'c4', '--warmup', '2'], 400, 34),
   ('c5_rmat_one_gpu', 'configs[4] shape on ONE GPU: R-MAT 2^21 nodes, d = 256 (the 8-GPU run is the driver\'s)',
-   ['--graph', 'rmat', '--steps', '4', '--warmup', '1', '--no-hbm-probe'], 900),
+   ['--graph', 'rmat', '--steps', '4', '--warmup', '1', '--no-hbm-probe'], 900, 72),
+  ('c3_normalised_over_columns_squareplus', 'configs[2] shape with attention_norm_idx 1 + squareplus (the reference\'s Cora / Citeseer normaliser at scale)',
+   ['--steps', '20', '--warmup', '5', '--norm-idx', '1', '--square-plus', '--no-live-pmc', '--no-hbm-probe', '--parity-only'], 300, 6),
+  ('c3_arxiv_relabelling_off', 'configs[2] with the node relabelling switched off (GNPDE_REORDER=0)',
+   ['--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--no-cpu-baseline'], 200, 3),
+  ('c3_arxiv_flat_no_planted_communities', 'configs[2] shape on a graph WITHOUT community structure (what relabelling gains without planted locality)',
+   ['--graph', 'arxiv_flat', '--steps', '20', '--warmup', '5', '--no-live-pmc', '--no-hbm-probe', '--parity-only'], 300, 6),
 )
 
 
@@ -1569,10 +1578,11 @@ def run_configs(args, budget_s):
   import subprocess
   t_start = time.perf_counter()
   out = {}
-  for key, what, flags, limit in CONFIG_CHILDREN:
+  for key, what, flags, limit, expect in CONFIG_CHILDREN:
     left = budget_s - (time.perf_counter() - t_start)
-    if left < 30:
-      out[key] = {'skipped': 'the configs block had used its %.0f s budget' % budget_s, 'what': what}
+    if left < 1.15 * expect + 5:      # (a child cut off by the budget would have spent its time for nothing)
+      out[key] = {'skipped': 'the configs block had %.0f s of its %.0f s budget left, this child takes about %d s: run `python bench.py %s`'
+                             % (max(left, 0.0), budget_s, expect, ' '.join(flags)), 'what': what}
       continue
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-configs', '--seed', str(args.seed)] + flags
     env = dict(os.environ)
@@ -1908,6 +1918,15 @@ def main():
       out['parity_vs_oracle_row_subset'] = subset_parity(main_block, x, x_cpu)
     except Exception as exc:   # noqa: BLE001
       out['parity_vs_oracle_row_subset'] = {'error': repr(exc)[:200]}
+  elif args.parity_only:
+    # (children of the default run: the timed baseline is the headline's; here only the parity figure of this configuration)
+    ref = cpu_baseline(main_block, x_cpu, 0)[1]
+    with torch.no_grad():
+      f.x0 = x
+      got = f(0.0, x)
+    from oracle import restate as R
+    e_inf, e_2 = R.parity_error(got, ref)
+    out['parity_vs_oracle_one_eval'] = {'rel_max': e_inf, 'rel_l2': e_2}
   elif not args.no_cpu_baseline:
     t_eval, ref, thread_trials = cpu_baseline(main_block, x_cpu, cpu_evals)
     with torch.no_grad():
@@ -1935,7 +1954,10 @@ def main():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    configs = run_configs(args, args.configs_budget)
+    budget = args.configs_budget
+    if budget is None:
+      budget = max(90.0, DEFAULT_RUN_SECONDS - (time.perf_counter() - T_PROCESS_START))
+    configs = run_configs(args, budget)
   else:
     configs = None
   emit(out, configs)
