@@ -72,7 +72,7 @@ def parse():
   ap.add_argument('--no-hbm-probe', action='store_true', help='skip roofline.hbm_bound_probe (a 2-GiB table, ~3 s)')
   ap.add_argument('--pmc-child', action='store_true',
                   help='internal: launch the kernels of one evaluation eagerly a few times and exit (the process the PMC passes profile)')
-  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch', 'pubmed-adjoint', 'coauthor-adjoint'],
+  ap.add_argument('--config', default=None, choices=['c4', 'cora-epoch', 'pubmed-adjoint', 'coauthor-adjoint', 'arxiv-adjoint'],
                   help='c4: BASELINE configs[3] -- ogbn-arxiv BLEND (beltrami split kernel, d = 64 + 98 = 162), block_transformer_rewiring in '
                        'evaluation mode, Laplacian function, dopri5 with tol_scale 11353, T = 3.676; prints its own JSON line (ms per forward).  '
                        'cora-epoch: the reference\'s flagship run -- best_params Cora (attention block, Laplacian function, dopri5, adjoint=False, '
@@ -1028,16 +1028,24 @@ def pubmed_adjoint_main(G, args, dev):
   (opt['gnpde_host_adjoint'])."""
   import numpy as np
   preset = getattr(args, 'config', 'pubmed-adjoint')
-  n, pairs, d = (19717, 44324, 128) if preset == 'pubmed-adjoint' else (18333, 81894, 16)
-  rng = np.random.default_rng(args.seed + 11)
-  a, b = rng.integers(0, n, 2 * pairs), rng.integers(0, n, 2 * pairs)
-  keep = a != b
-  key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
-  key = np.sort(rng.permutation(key)[:pairs])
-  lo, hi = key // n, key % n
-  row, col = np.concatenate([lo, hi]), np.concatenate([hi, lo])
-  order = np.lexsort((col, row))
-  ei = torch.from_numpy(np.stack([row[order], col[order]])).long().to(dev)
+  if preset == 'arxiv-adjoint':
+    # best_params ogbn-arxiv, the reference's largest flagship run, in TRAINING: hard-attention block (the strongest 81 % of the edges by
+    # head-mean attention carry the diffusion, reference src/block_transformer_hard_attention.py:48-66), Laplacian function, d = 162,
+    # dopri5 forward (tol_scale 11 353, T = 3.676), adjoint_method rk4 with adjoint_step_size 1
+    ei_cpu, n = G.synthetic.make_graph('arxiv', seed=args.seed, scale=args.scale)
+    d = 162
+    ei = ei_cpu.to(dev)
+  else:
+    n, pairs, d = (19717, 44324, 128) if preset == 'pubmed-adjoint' else (18333, 81894, 16)
+    rng = np.random.default_rng(args.seed + 11)
+    a, b = rng.integers(0, n, 2 * pairs), rng.integers(0, n, 2 * pairs)
+    keep = a != b
+    key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+    key = np.sort(rng.permutation(key)[:pairs])
+    lo, hi = key // n, key % n
+    row, col = np.concatenate([lo, hi]), np.concatenate([hi, lo])
+    order = np.lexsort((col, row))
+    ei = torch.from_numpy(np.stack([row[order], col[order]])).long().to(dev)
   x = (torch.randn(n, d, generator=torch.Generator().manual_seed(args.seed + 12)) * 0.5).to(dev)
   base = dict(heads=1, attention_dim=16, attention_type='cosine_sim', attention_norm_idx=0, square_plus=True, reweight_attention=False, beltrami=False,
               leaky_relu_slope=0.2, self_loop_weight=1, max_nfe=5000, add_source=True, no_alpha_sigmoid=False, mix_features=False, hidden_dim=d,
@@ -1051,12 +1059,19 @@ def pubmed_adjoint_main(G, args, dev):
     label = 'CoauthorCS'
     base.update(heads=4, attention_dim=8, attention_type='scaled_dot', attention_norm_idx=1, square_plus=True, add_source=False, self_loop_weight=0,
                 adjoint_method='dopri5', tol_scale=9348.983916372074, tol_scale_adjoint=6599.1250595331385, time=3.126400580172773, max_nfe=3000)
+  Block = G.AttODEblock
+  if preset == 'arxiv-adjoint':
+    label = 'ogbn-arxiv'
+    Block = G.HardAttODEblock
+    base.update(heads=2, attention_dim=32, attention_type='scaled_dot', attention_norm_idx=0, square_plus=False, add_source=False, self_loop_weight=1,
+                adjoint_method='rk4', adjoint_step_size=1, tol_scale=11353.558848254957, tol_scale_adjoint=1.0, time=3.6760155951687636, max_nfe=500,
+                block='hard_attention', att_samp_pct=0.8105268910037231, use_flux=False)
   data = _Data()
   data.x, data.edge_index, data.edge_attr, data.num_nodes = x, ei, None, n
   res = {}
   for host in (False, True):
     opt = dict(base, gnpde_host_adjoint=host)
-    block = G.AttODEblock(G.LaplacianODEFunc, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
+    block = Block(G.LaplacianODEFunc, [], opt, data, dev, t=torch.tensor([0, opt['time']])).to(dev)
     g = torch.Generator().manual_seed(args.seed + 13)
     with torch.no_grad():         # EVERY parameter from the seeded generator (nn.Linear's own bias init draws from the global RNG: two blocks would differ)
       for name, p in block.named_parameters():
@@ -1093,9 +1108,10 @@ def pubmed_adjoint_main(G, args, dev):
     'value': round(nat['forward_ms'] + nat['backward_ms'], 3), 'unit': 'ms', 'n_gpus': 1, 'steps': 1, 'warmup': 2,
     'ms_per_step': round(nat['forward_ms'] + nat['backward_ms'], 3), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
     'data': 'synthetic',
-    'config': {'workload': ('ODE block of best_params %s (attention block: %s, %d head(s), A = %d, squareplus; Laplacian function; dopri5 tol_scale %.0f, '
+    'config': {'workload': ('ODE block of best_params %s (%s block: %s, %d head(s), A = %d%s; Laplacian function; dopri5 tol_scale %.0f, '
                             'T = %.2f; adjoint=True, adjoint_method %s, tol_scale_adjoint %.0f) on a %s-shaped synthetic graph; one step = one training '
-                            'iteration of the block (loss = sum of the output)') % (label, base['attention_type'], base['heads'], base['attention_dim'],
+                            'iteration of the block (loss = sum of the output)') % (label, base['block'].replace('_', '-'), base['attention_type'], base['heads'], base['attention_dim'],
+                                                                                     ', squareplus' if base['square_plus'] else '',
                                                                                      base['tol_scale'], base['time'], base['adjoint_method'],
                                                                                      base['tol_scale_adjoint'], label),
                'nodes': n, 'edges_with_self_loops': int(ei.shape[1]) + (n if base['self_loop_weight'] else 0), 'd': d},
@@ -1106,7 +1122,8 @@ def pubmed_adjoint_main(G, args, dev):
     'parity_vs_flat_host_loop': {'grad_x_rel_max': e_inf, 'grad_x_rel_l2': e_2, 'z_bitwise_equal': bool(torch.equal(nat['z'], hst['z'])),
                                  'what': 'dL/dx of the same iteration (identical parameters) through torchdiffeq\'s flat-vector loop; the two take the same '
                                          'steps when `augmented_evals_backward` agree'},
-    'roofline': None, 'roofline_note': 'launch-bound (10-MB state, ~250 us of host work per augmented evaluation): no bandwidth roofline to quote',
+    'roofline': None, 'roofline_note': ('the aggregation kernels of the headline / C4 lines at this width (see c4_arxiv_blend_dopri5)' if preset == 'arxiv-adjoint' else
+                                        'launch-bound (10-MB state, ~250 us of host work per augmented evaluation): no bandwidth roofline to quote'),
     'cpu_baseline': None,
   }
   print(json.dumps(out))
@@ -1413,6 +1430,8 @@ CONFIG_CHILDREN = (
    ['--config', 'pubmed-adjoint'], 200, 5),
   ('coauthorcs_block_dopri5_adjoint', 'best_params CoauthorCS\'s ODE block in training: dopri5 forward, adjoint_method dopri5',
    ['--config', 'coauthor-adjoint'], 200, 3),
+  ('arxiv_block_rk4_adjoint', 'best_params ogbn-arxiv\'s ODE block in training (the reference\'s largest flagship run): hard-attention block, d = 162, dopri5 forward, adjoint_method rk4',
+   ['--config', 'arxiv-adjoint'], 300, 6),
   ('c3_training_iteration', 'configs[2] shape, TRAINING: forward + native adjoint backward (rk4 both ways)',
    ['--train', '--steps', '10', '--warmup', '2'], 400, 15),
   ('c3_training_iteration_adjoint_off', 'configs[2] shape, TRAINING as run_GNN.py runs rk4 by default (adjoint off): recorded solve + native reverse sweep, host-loop A/B',
@@ -1663,7 +1682,7 @@ def main():
     return c4_main(G, args, dev)
   if args.config == 'cora-epoch':
     return cora_epoch_main(G, args, dev)
-  if args.config in ('pubmed-adjoint', 'coauthor-adjoint'):
+  if args.config in ('pubmed-adjoint', 'coauthor-adjoint', 'arxiv-adjoint'):
     return pubmed_adjoint_main(G, args, dev)
   cfg = G.synthetic.CONFIGS[args.graph]
   ei_cpu, n = G.synthetic.make_graph(args.graph, seed=args.seed, scale=args.scale)
