@@ -26,6 +26,7 @@ namespace gnpde {
 namespace {
 
 constexpr int kGmaxSlots = 64;
+constexpr int kGmaxPartCap = 8192;      // waves of a "small" squareplus maximum sweep (AttArgs::gmax_part)
 
 struct AttArgs {
   int n, e, h, dk, type, norm_idx, square_plus;
@@ -67,6 +68,12 @@ struct AttArgs {
   const int* __restrict__ out_pos;   // nullptr, or position e of the walked graph -> position of the weight in w_mean (the walked graph
                                      // is the TRANSPOSED one when the normalisation runs over columns)
   int sp_mode;                       // 0 softmax; 1 squareplus with the global maximum in *gmax; 2 only form that maximum
+  // squareplus on a SMALL grid (at most kGmaxPartCap waves in the maximum sweep, no hub rows): every wave of the sweep stores its
+  // maximum in gmax_part[gmax_base + wave] (no atomic, nothing to clear beforehand) and every block of the second sweep folds the
+  // gmax_count entries itself (block 0 also publishes *gmax for the kernels behind) -- no memset node and no fold launch, two of
+  // the eight launches of such an evaluation (Cora as run_GNN.py runs it: ~4.5 us each)
+  unsigned* gmax_part;
+  int gmax_base, gmax_count;
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -806,6 +813,12 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
     mw = wave_max(mw);
     // one atomic per wave at most, and only while the wave's maximum beats the value it can see (a stale read only costs an atomic:
     // tens of thousands of waves hammering ONE address serialise -- 0.7 ms per sweep at the ogbn-arxiv shape when every wave did)
+    if (a.gmax_part != nullptr) {      // small grid: one plain store per wave (0 = below every encoded float)
+      if (lane == 0)
+        a.gmax_part[a.gmax_base + (static_cast<int>(blockIdx.x) - n_hub) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6)] =
+            mw > -INFINITY ? f2ord(mw) : 0u;
+      return;
+    }
     if (lane == 0 && mw > -INFINITY) {
       const unsigned mine = f2ord(mw);
       unsigned* tgt = a.gmax_slots != nullptr ? a.gmax_slots + 32 * (blockIdx.x % kGmaxSlots) : a.gmax;
@@ -815,7 +828,29 @@ __global__ __launch_bounds__(kBlock) void row_attention_sd_kernel(const AttArgs 
   }
   float l[RI];
   if constexpr (MODE == 1) {
-    const float gm = ord2f(*a.gmax);
+    float gm;
+    if (a.gmax_part != nullptr) {      // (block-uniform) fold the sweep's per-wave maxima: gmax_count / 256 coalesced loads per thread
+      __shared__ unsigned s_gmax[kWavesPerBlock];
+      unsigned v = 0u;
+      for (int i = threadIdx.x; i < a.gmax_count; i += kBlock) {
+        const unsigned w = a.gmax_part[i];
+        v = w > v ? w : v;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned w = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), o, kWave));
+        v = w > v ? w : v;
+      }
+      if (lane == 0) s_gmax[threadIdx.x >> 6] = v;
+      __syncthreads();
+      v = s_gmax[0];
+#pragma unroll
+      for (int w = 1; w < kWavesPerBlock; ++w) v = s_gmax[w] > v ? s_gmax[w] : v;
+      if (blockIdx.x == 0 && threadIdx.x == 0 && first_row == 0) *a.gmax = v;     // (for the kernels behind this launch: the backward passes)
+      gm = ord2f(v);
+    } else {
+      gm = ord2f(*a.gmax);
+    }
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
       l[r] = 0.f;
@@ -924,7 +959,8 @@ AttLayout att_layout(int n, int e, int h, bool gat, size_t long_slots, int key_r
   L.scores = off; off += align_up(static_cast<size_t>(e) * h * 4, 256);
   L.seg_m = off;  off += align_up(static_cast<size_t>(n) * h * 4, 256);
   L.seg_den = off; off += align_up(static_cast<size_t>(n) * h * 4, 256);
-  L.gmax = off; off += 256 + kGmaxSlots * 128;      // the maximum, then its partial slots (AttArgs::gmax_slots)
+  L.gmax = off; off += 256 + (kGmaxSlots * 128 > kGmaxPartCap * 4 ? kGmaxSlots * 128 : kGmaxPartCap * 4);   // the maximum, then its partial slots
+                                                                                                             // (AttArgs::gmax_slots / gmax_part)
   L.gat = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 2 * h * 4, 256);   // (halo rows of a partitioned graph)
   L.gat_table = off; if (gat) off += align_up(static_cast<size_t>(key_rows > n ? key_rows : n) * 8 * h * 4, 256);
   L.part = off; off += align_up(long_slots * 2 * h * 4, 256);
@@ -948,8 +984,23 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
   }
 }
 
+// rows per workgroup of the <= 16-entry class of row_attention_sd_kernel (launch_rows_sd_mode's first launch)
+constexpr int sd_rows_per_block16(int h, int dk4) {
+  const int gl16 = (16 * h < kWave) ? 16 * h : kWave;
+  const int p16 = (16 * h + gl16 - 1) / gl16;
+  const int ri16 = (dk4 == 1 && p16 == 1) ? 4 : (p16 == 1 ? 2 : 1);
+  return (kWave / gl16) * ri16 * kWavesPerBlock;
+}
+// waves of the two launches of a sweep without hub blocks: [0] the <= 16-entry class, [1] the others (AttArgs::gmax_part)
+inline void sd_sweep_waves(int h, int dk4, int n16, int n64, long long (&w)[2]) {
+  const long long rpb = sd_rows_per_block16(h, dk4);
+  w[0] = n16 > 0 ? (n16 + rpb - 1) / rpb * kWavesPerBlock : 0;
+  w[1] = n64 > 0 ? static_cast<long long>(n64 + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock : 0;
+}
+
 template <int H, int DK4, int MODE, bool SCATTER>
-void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int n_hub, float* part, const int* chunk_first) {
+void launch_rows_sd_mode(const AttArgs& a_in, int n16, int n64, hipStream_t s, int n_hub, float* part, const int* chunk_first) {
+  AttArgs a = a_in;
   constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
   constexpr int RPW16 = kWave / GL16;
@@ -960,9 +1011,11 @@ void launch_rows_sd_mode(const AttArgs& a, int n16, int n64, hipStream_t s, int 
   // squareplus, MODE 2, has no hub phase 1)
   if (n16 > 0 || n_hub > 0) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
+    static_assert(RPW16 * RI16 * kWavesPerBlock == sd_rows_per_block16(H, DK4), "sd_sweep_waves counts this launch's waves");
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block) + n_hub;
     hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, GL16, RI16, P16, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub,
                        0, part, chunk_first);
+    if (MODE == 2 && a.gmax_part != nullptr) a.gmax_base += static_cast<int>(grid - n_hub) * kWavesPerBlock;   // the second launch's waves follow
   }
   const int n_hub2 = MODE == 2 ? 0 : n_hub;
   if (n64 > 0 || n_hub2 > 0) {
@@ -1145,7 +1198,6 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
   a.hub_fold_lds = g_tune[GNPDE_TUNE_HUB_FOLD] == 2 ? 0 : 1;   // default since round 3 (bit-identical; -3.4 % on the R-MAT launch)
   float* part = reinterpret_cast<float*>(base + L.part);
 
-  if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, 256 + kGmaxSlots * 128, stream));
   // GAT's row softmax on the scaled-dot row kernels (gat_terms_kernel's table): the fused row path without edge weights
   const bool gat_sd = gat && !stats_only && pass_only == 0 && !hubs_only && a.norm_idx == 0 && !a.square_plus && att_edge == nullptr &&
                       prods_edge == nullptr && w_mean_csr != nullptr && g->bin_rows != nullptr && a.edge_w == nullptr &&
@@ -1250,12 +1302,24 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
       const int n_hub = sg->n_long_rows > 0 ? sg->n_long_chunks : 0;
       if (a.square_plus) {
         c.sp_mode = 2;
-        c.gmax_slots = a.gmax + 64;          // (256 bytes behind the maximum itself)
-        if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
-        GNPDE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gmax_fold_kernel, dim3(1), dim3(kWave), 0, stream, c.gmax_slots, a.gmax);
-        GNPDE_LAUNCH_CHECK();
-        c.gmax_slots = nullptr;
+        long long sw[2];
+        sd_sweep_waves(a.h, a.dk / 4, sg->n_bin16, sg->n_bin64, sw);
+        if (n_hub == 0 && sw[0] + sw[1] <= kGmaxPartCap && g_tune[GNPDE_TUNE_GMAX_SMALL] == 0) {
+          // small grid: per-wave maxima, folded by the blocks of the second sweep (AttArgs::gmax_part) -- nothing to clear, no fold launch
+          c.gmax_part = a.gmax + 64;
+          c.gmax_base = 0;
+          c.gmax_count = static_cast<int>(sw[0] + sw[1]);
+          if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
+          GNPDE_LAUNCH_CHECK();
+        } else {
+          GNPDE_HIP(hipMemsetAsync(a.gmax, 0, 256 + kGmaxSlots * 128, stream));
+          c.gmax_slots = a.gmax + 64;          // (256 bytes behind the maximum itself)
+          if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
+          GNPDE_LAUNCH_CHECK();
+          hipLaunchKernelGGL(gmax_fold_kernel, dim3(1), dim3(kWave), 0, stream, c.gmax_slots, a.gmax);
+          GNPDE_LAUNCH_CHECK();
+          c.gmax_slots = nullptr;
+        }
         c.sp_mode = 1;
       }
       if (!launch_sd_with_hubs(c, sg->n_bin16, sg->n_bin64, n_hub, part, sg->long_chunk_first, stream)) return GNPDE_ESHAPE;
@@ -1263,6 +1327,7 @@ static int edge_attention_impl(const gnpde_graph_t* g, const gnpde_attention_t* 
       return 0;
     }
   }
+  if (a.square_plus && pass_only <= 1) GNPDE_HIP(hipMemsetAsync(a.gmax, 0, 256 + kGmaxSlots * 128, stream));    // (scores_kernel: atomic maxima)
   if (pass_only == 0 || pass_only == 1) {
     launch_scores_any(a, vec4, stream_grid(static_cast<long long>(a.e) * a.h), stream);
     GNPDE_LAUNCH_CHECK();

@@ -107,7 +107,8 @@ enum {
   GNPDE_TUNE_SWEEP_UNSWAPPED = 15,     // 1: the reverse sweep over a recorded solve gathers the STATE rows again (round-6 first form) instead of the cotangent rows only (A/B)
   GNPDE_TUNE_KEY_TABLE = 14,           // 1: keep q||k interleaved [n, 2A] where the solver would write two tables (A/B)
   GNPDE_TUNE_LINEAR_DIAG = 13,         // A/B diagnostics of the staged projection kernel (1: no stores, 2: loads alone); never set in production
-  GNPDE_TUNE_COUNT = 16
+  GNPDE_TUNE_GMAX_SMALL = 16,          // 1: squareplus on a small grid keeps the slot atomics + memset + fold launch (A/B against the per-wave maxima folded by the second sweep)
+  GNPDE_TUNE_COUNT = 17
 };
 extern int g_tune[GNPDE_TUNE_COUNT];
 

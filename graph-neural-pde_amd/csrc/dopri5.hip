@@ -220,8 +220,17 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total4;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const f4 ya = reinterpret_cast<const f4*>(a.y)[i], yb = reinterpret_cast<const f4*>(a.y1)[i];
-    const f4 fa = reinterpret_cast<const f4*>(a.k[0])[i], fb = reinterpret_cast<const f4*>(a.k[6])[i];
+    // (accept / interp are the same for every thread of the grid: an accepted step that does not contain the end point -- the common
+    //  case -- reads y1 and k6 only, a rejected one y and k0 only; two of the four streams of the old unconditional form)
+    f4 ya = {0.f, 0.f, 0.f, 0.f}, yb = ya, fa = ya, fb = ya;
+    if (interp || !accept) {
+      ya = reinterpret_cast<const f4*>(a.y)[i];
+      fa = reinterpret_cast<const f4*>(a.k[0])[i];
+    }
+    if (interp || accept) {
+      yb = reinterpret_cast<const f4*>(a.y1)[i];
+      fb = reinterpret_cast<const f4*>(a.k[6])[i];
+    }
     if (interp) {
       f4 ym = ya;
 #pragma unroll

@@ -61,6 +61,37 @@ def test_cora_config_c2_as_run(dev):
   assert_parity(z, ref, what='C2 Cora squareplus/norm_idx=1 rk4 T=18.29')
 
 
+@pytest.mark.parametrize('norm_idx', [0, 1])
+def test_squareplus_maximum_of_a_small_grid_equals_the_slot_form_bitwise(dev, norm_idx):
+  """Squareplus needs the maximum over EVERY score of the evaluation.  On a grid of at most 8192 waves (Cora) the sweep stores one
+  maximum per wave and every block of the second sweep folds them (no memset node, no fold launch); larger grids keep the 64 atomic
+  slots + fold kernel, which gnpde_tune(16, 1) forces here: a maximum does not depend on the order, so the solves are equal BITWISE --
+  over the rows and over the columns (the transposed graph's segments), eager and replayed."""
+  from gnpde_amd import ops
+  ei, n = G.synthetic.make_graph('cora')
+  x = torch.randn(n, 80, generator=torch.Generator().manual_seed(31)) * 0.5
+  opt = dict(BASE, heads=8, attention_dim=128, hidden_dim=80, square_plus=True, attention_norm_idx=norm_idx, time=3.0)
+  outs = {}
+  for knob in (0, 1):
+    torch.manual_seed(11)
+    block = _block(opt, ei.to(dev), n, x.to(dev), dev)
+    block.set_x0(x.to(dev))
+    ops.tune(16, knob)
+    try:
+      with torch.no_grad():
+        z1 = block(x.to(dev)).clone()
+        z2 = block(x.to(dev)).clone()          # (the captured solve replayed: nothing of the first one may be left in the partials)
+        block.odefunc.x0 = x.to(dev)
+        f1 = block.odefunc(0.0, x.to(dev)).clone()
+    finally:
+      ops.tune(16, 0)
+    assert torch.equal(z1, z2)
+    outs[knob] = (z1, f1)
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+  ref = R.odeint_fixed(_oracle_rhs(block, x), x, opt['time'], 1.0, 'rk4')
+  assert_parity(outs[0][0], ref, what='Cora squareplus norm_idx=%d, per-wave maxima' % norm_idx)
+
+
 def test_cora_config_c1_laplacian_euler(dev):
   """BASELINE configs[0]: Cora GRAND-l, euler step 1, T=4."""
   ei, n = G.synthetic.make_graph('cora')
