@@ -182,6 +182,7 @@ PROTOTYPES = {
                                                  ctypes.c_int32]),
   'gnpde_dopri5_stats': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   'gnpde_dopri5_set_row_order': (ctypes.c_int, [c_vp, c_vp]),
+  'gnpde_dopri5_set_pair': (ctypes.c_int, [c_vp, ctypes.c_int32]),
   'gnpde_dopri5_destroy': (ctypes.c_int, [c_vp]),
   'gnpde_adjoint_adaptive_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), ctypes.c_int32]),
   'gnpde_adjoint_adaptive_create': (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(RhsStruct), ctypes.POINTER(GraphStruct), c_vp, ctypes.c_int32,

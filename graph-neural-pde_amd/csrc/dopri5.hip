@@ -62,7 +62,7 @@ static_assert(sizeof(Ctl) == 96, "controller record");
 // fold of the error partial sums (as rk_error_final_kernel of misc.hip) + torchdiffeq rk_common.py _adaptive_step /
 // _optimal_step_size: safety 0.9, ifactor 10, dfactor 0.2, order 5
 __global__ __launch_bounds__(kBlock) void control_kernel(const double* __restrict__ ws, int nblocks, double count, Ctl* c,
-                                                        int parity, double* __restrict__ times, int times_capacity) {
+                                                        int parity, double* __restrict__ times, int times_capacity, double inv_order) {
   __shared__ double red[kBlock];
   double acc = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += ws[i];      // block partials in double (misc.hip, rk_error_partial_kernel)
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void control_kernel(const double* __restric
     factor = 10.0;
   } else {
     const double lo = ratio < 1.0 ? 1.0 : 0.2;
-    factor = fmin(10.0, fmax(0.9 / pow(ratio, 0.2), lo));
+    factor = fmin(10.0, fmax(0.9 / pow(ratio, inv_order), lo));     // (1 / order: 0.2 for dopri5, 0.5 for the Heun pair)
   }
   c->dt = dt * factor;
   c->h[1 - parity] = static_cast<float>(c->dt);
@@ -145,7 +145,7 @@ __global__ void init_h0_kernel(Init* q) {
   q->h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6f : 0.01f * q->d0 / q->d1;
 }
 
-__global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1, int max_trials, double* times, int times_capacity) {
+__global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1, int max_trials, double* times, int times_capacity, float inv_order) {
   const double h0 = static_cast<double>(q->h0), d1 = static_cast<double>(q->d1);
   const double d2 = static_cast<double>(q->d2) / h0;
   double h1;
@@ -153,7 +153,7 @@ __global__ void init_dt_kernel(const Init* q, Ctl* c, double t0, double t1, int 
     h1 = fmax(1e-6, h0 * 1e-3);
   } else {
     const float big = static_cast<float>(fmax(d1, d2));
-    h1 = static_cast<double>(static_cast<float>(pow(static_cast<double>(0.01f / big), static_cast<double>(1.0f / 5.0f))));
+    h1 = static_cast<double>(static_cast<float>(pow(static_cast<double>(0.01f / big), static_cast<double>(inv_order))));
   }
   c->t = t0;
   c->t1 = t1;
@@ -202,6 +202,7 @@ struct FinishArgs {
   float* k[7];                    // written here only when this step was rejected
   float* yout; float* u1;
   float mid[7];                   // fl32(c_mid_j)
+  int n_k, last;                  // derivatives of the pair (7 / 2), index of the last one (the next step's first if accepted)
   float b10;
   long long n;
   int d, ld;
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
     }
     if (interp || accept) {
       yb = reinterpret_cast<const f4*>(a.y1)[i];
-      fb = reinterpret_cast<const f4*>(a.k[6])[i];
+      fb = reinterpret_cast<const f4*>(a.k[a.last])[i];
     }
     if (interp) {
       f4 ym = ya;
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
-        const float m = a.mid[j] * h;
+        const float m = j < a.n_k ? a.mid[j] * h : 0.0f;
         if (m != 0.0f) ym += reinterpret_cast<const f4*>(a.k[j])[i] * m;
       }
       const f4 ca = 2.0f * h * (fb - fa) - 8.0f * (yb + ya) + 16.0f * ym;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const FinishArgs a) {
     if (stopped) reinterpret_cast<f4*>(a.yout)[i] = yn;     // trial budget spent: the state where the integration stopped
     if (!accept) {
       reinterpret_cast<f4*>(a.y1)[i] = yn;
-      reinterpret_cast<f4*>(a.k[6])[i] = fn;
+      reinterpret_cast<f4*>(a.k[a.last])[i] = fn;
     }
     f4 u;
 #pragma unroll
@@ -374,6 +375,7 @@ struct gnpde_dopri5 {
   const int* row_order = nullptr;   // gnpde_dopri5_set_row_order: solver row r <-> caller's row row_order[r]
   // Row-partitioned solve (gnpde_dopri5_create_sharded): the evaluations go through the exchange engine (its stage buffers hold the four
   // states that are ever an evaluation's input: Y[0], Y[1], u[0], u[1]), the error norms are summed over the ranks inside the stream
+  int pair = GNPDE_ADAPTIVE_DOPRI5;   // gnpde_dopri5_set_pair: the embedded pair (Dormand-Prince 5(4) / torchdiffeq's adaptive_heun 2(1))
   gnpde_sharded_solver_t* shard = nullptr;
   long long n_rows = 0;             // rows the element-wise kernels of this rank cover (all rows / the owned rows)
   double count = 0.0;               // elements of the WHOLE state: the mean of the error norm is over every rank's rows
@@ -418,7 +420,30 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   // stage inputs u_1..u_5: two alternating buffers -- or, when the solve is recorded, five distinct ones that survive the trial step
   float* ui[5] = {s->u[0], s->u[1], s->u[0], s->u[1], s->u[0]};
   if (s->tape != nullptr) { ui[2] = s->tape_x[0]; ui[3] = s->tape_x[1]; ui[4] = s->tape_x[2]; }
-  for (int i = 1; i < 6; ++i) {       // (u_1 = y + (b10 h) k0 was written by the previous trial step's finish kernel)
+  const bool heun = s->pair == GNPDE_ADAPTIVE_HEUN;
+  int n_k = 7;
+  float ce[7], cmid[7];
+  for (int j = 0; j < 7; ++j) { ce[j] = static_cast<float>(kE[j]); cmid[j] = static_cast<float>(kMid[j]); }
+  if (heun) {
+    // torchdiffeq 0.2.1's adaptive_heun (adaptive_heun.py: alpha (1), beta ((1)), c_sol (1/2, 1/2), c_error (1/2, -1/2), c_mid (1/2, 0)):
+    // ONE evaluation per trial step, k1 = f(u_1) with u_1 = y + h k0, whose epilogue forms y1 = y + h (k0 + k1) / 2; the next step's
+    // first derivative is k1 (rk_common.py takes f1 = k[..., -1] for every pair, also this one, whose last stage is not the solution)
+    n_k = 2;
+    for (int j = 1; j < 7; ++j) k[j] = s->KA[1 - parity];
+    for (int j = 0; j < 7; ++j) { ce[j] = 0.f; cmid[j] = 0.f; }
+    ce[0] = 0.5f; ce[1] = -0.5f; cmid[0] = 0.5f;
+    gnpde_epilogue_t e = base_epilogue(r);
+    e.stage = GNPDE_STAGE_LINCOMB;
+    e.y = y;
+    e.out_k = k[1];
+    e.out_y = y1;
+    e.n_prev = 1;
+    e.prev[0] = k[0];
+    e.coef[0] = 0.5f; e.coef[1] = 0.5f;
+    e.coef_scale = h;
+    if (int rc = enqueue_f(s, s->u[0], e, st)) return rc;
+  }
+  for (int i = 1; i < 6 && !heun; ++i) {       // (u_1 = y + (b10 h) k0 was written by the previous trial step's finish kernel)
     gnpde_epilogue_t e = base_epilogue(r);
     e.stage = GNPDE_STAGE_LINCOMB;
     e.y = y;
@@ -430,23 +455,21 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
     e.coef_scale = h;
     if (int rc = enqueue_f(s, ui[i - 1], e, st)) return rc;
   }
-  {
+  if (!heun) {
     gnpde_epilogue_t e = base_epilogue(r);
     e.stage = GNPDE_STAGE_RHS;
     e.out_k = k[6];
     if (int rc = enqueue_f(s, y1, e, st)) return rc;
   }
-  float ce[7];
-  for (int j = 0; j < 7; ++j) ce[j] = static_cast<float>(kE[j]);
   int nblocks = 0;
-  if (int rc = launch_rk_error_ratio(y, y1, k, ce, 7, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
+  if (int rc = launch_rk_error_ratio(y, y1, k, ce, n_k, s->atol, s->rtol, n, r.d, r.ld, nullptr, s->err_ws, st, h, &nblocks))
     return rc;
   if (s->shard != nullptr) {      // the squares of every rank's rows: one double all-reduced inside the stream
     if (int rc = sharded_enqueue_sum(s->shard, reinterpret_cast<double*>(s->err_ws), nblocks, st)) return rc;
     nblocks = 1;
   }
   hipLaunchKernelGGL(control_kernel, dim3(1), dim3(kBlock), 0, st, reinterpret_cast<const double*>(s->err_ws), nblocks, s->count, s->ctl, parity,
-                     s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
+                     s->early ? s->times : nullptr, s->early ? s->times_capacity : 0, heun ? 0.5 : 0.2);
   GNPDE_LAUNCH_CHECK();
   if (s->tape != nullptr) {
     TapeArgs ta{};
@@ -466,9 +489,10 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
   fa.y = y; fa.y1 = y1; fa.yout = s->yout; fa.u1 = s->u[0];
   for (int j = 0; j < 7; ++j) {
     fa.k[j] = k[j];
-    fa.mid[j] = static_cast<float>(kMid[j]);
+    fa.mid[j] = cmid[j];
   }
-  fa.b10 = static_cast<float>(kB[0][0]);
+  fa.n_k = n_k; fa.last = n_k - 1;
+  fa.b10 = heun ? 1.0f : static_cast<float>(kB[0][0]);
   fa.n = n; fa.d = r.d; fa.ld = r.ld; fa.c = s->ctl; fa.parity = parity;
   long long blocks = (n * r.ld / 4 + kBlock - 1) / kBlock;
   if (blocks > 4096) blocks = 4096;
@@ -676,10 +700,10 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     const float cw[2] = {one, minus};
     if (int rc = scaled_rms(s, dk, cw, 2, st, &s->init->d2)) return rc;
     hipLaunchKernelGGL(init_dt_kernel, dim3(1), dim3(1), 0, st, s->init, s->ctl, t0, t1, s->early ? s->max_trials : 0,
-                       s->early ? s->times : nullptr, s->early ? s->times_capacity : 0);
+                       s->early ? s->times : nullptr, s->early ? s->times_capacity : 0, s->pair == GNPDE_ADAPTIVE_HEUN ? 1.0f / 2.0f : 1.0f / 5.0f);
     GNPDE_LAUNCH_CHECK();
     // first stage input of the first trial step (later ones come out of the finish kernel)
-    const float c[1] = {static_cast<float>(kB[0][0])};
+    const float c[1] = {s->pair == GNPDE_ADAPTIVE_HEUN ? 1.0f : static_cast<float>(kB[0][0])};
     if (int rc = launch_lincomb(s->Y[0], w, c, 1, flat, s->u[0], st, &s->ctl->h[0])) return rc;
   }
   for (int parity = 0; parity < 2; ++parity) {
@@ -721,7 +745,7 @@ extern "C" int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y
     GNPDE_HIP(hipStreamSynchronize(st));
     s->n_syncs += 1;
     have_record = true;
-    s->n_evals = base_evals + 6 * hc.trials;
+    s->n_evals = base_evals + (s->pair == GNPDE_ADAPTIVE_HEUN ? 1 : 6) * hc.trials;
     s->n_accepted = hc.accepted;
     s->n_rejected = hc.rejected;
     if (s->shard != nullptr) {    // a peer that never arrived: its share of the norms is missing, nothing behind this point means anything
@@ -782,6 +806,18 @@ extern "C" int gnpde_dopri5_set_early_stop(gnpde_dopri5_t* s, const gnpde_decode
   return 0;
 }
 
+extern "C" int gnpde_dopri5_set_pair(gnpde_dopri5_t* s, int32_t pair) {
+  GNPDE_CHECK_ARG(s != nullptr && (pair == GNPDE_ADAPTIVE_DOPRI5 || pair == GNPDE_ADAPTIVE_HEUN), GNPDE_EINVAL, "dopri5_set_pair: bad argument");
+  GNPDE_CHECK_ARG(pair == GNPDE_ADAPTIVE_DOPRI5 || s->tape == nullptr, GNPDE_ESTATE, "dopri5_set_pair: the recorded solve is Dormand-Prince's");
+  if (pair == s->pair) return 0;
+  for (int p = 0; p < 2; ++p) {      // the trial step is captured per pair
+    if (s->exec[p]) { (void)hipGraphExecDestroy(s->exec[p]); s->exec[p] = nullptr; }
+    if (s->graph_obj[p]) { (void)hipGraphDestroy(s->graph_obj[p]); s->graph_obj[p] = nullptr; }
+  }
+  s->pair = pair;
+  return 0;
+}
+
 extern "C" int gnpde_dopri5_set_row_order(gnpde_dopri5_t* s, const int32_t* order) {
   GNPDE_CHECK_ARG(s != nullptr, GNPDE_EINVAL, "dopri5_set_row_order: solver is null");
   GNPDE_CHECK_ARG(order == nullptr || s->shard == nullptr, GNPDE_ESTATE, "dopri5_set_row_order: not on a row-partitioned solve");
@@ -839,6 +875,7 @@ extern "C" int gnpde_dopri5_set_tape(gnpde_dopri5_t* s, void* tape, size_t tape_
   s->tape_steps = 0;
   if (tape == nullptr) return 0;
   GNPDE_CHECK_ARG(s->shard == nullptr, GNPDE_ESTATE, "dopri5_set_tape: not on a row-partitioned solve");
+  GNPDE_CHECK_ARG(s->pair == GNPDE_ADAPTIVE_DOPRI5, GNPDE_ESTATE, "dopri5_set_tape: the recorded solve is Dormand-Prince's");
   GNPDE_CHECK_ARG(s->rhs.kind == GNPDE_RHS_LAPLACIAN, GNPDE_EINVAL, "dopri5_set_tape: the recorded solve covers the Laplacian function (f linear in the state)");
   GNPDE_CHECK_ARG(capacity_steps >= 1 && reinterpret_cast<uintptr_t>(tape) % 256 == 0, GNPDE_EINVAL, "dopri5_set_tape: bad capacity or alignment");
   const size_t need = gnpde_dopri5_tape_bytes(&s->rhs, capacity_steps);

@@ -893,9 +893,9 @@ class NativeShardedDopri5(object):
   torch.distributed call per trial step (ShardedSolver.integrate_adaptive: one all-to-all per evaluation and one all-reduce per
   trial step from Python).  Reference call: src/block_constant.py:57-62 with opt['method'] = 'dopri5' (run_GNN.py's default)."""
 
-  def __init__(self, shard, backend, rtol, atol, n_rows_total, with_source=True, ctx=None, group=None):
+  def __init__(self, shard, backend, rtol, atol, n_rows_total, with_source=True, ctx=None, group=None, pair='dopri5'):
     import ctypes
-    self.shard, self.be = shard, backend
+    self.shard, self.be, self.pair = shard, backend, pair
     self.engine = NativeShardedSolver(shard, backend, None, method='rk4', with_source=with_source, ctx=ctx, group=group, boundary_chunks=1)
     L = _lib.lib()
     self.handle = None
@@ -906,7 +906,12 @@ class NativeShardedDopri5(object):
       _lib.check(L.gnpde_dopri5_create_sharded(ctypes.byref(handle), self.engine.handle, float(rtol), float(atol), int(n_rows_total),
                                                _lib.ptr(self.ws), self.ws.numel()))
       self.handle = handle
+      if pair != 'dopri5':      # torchdiffeq's adaptive_heun: the same controller, one evaluation per trial step (gnpde_dopri5_set_pair)
+        _lib.check(L.gnpde_dopri5_set_pair(handle, {'adaptive_heun': 0, 'dopri5': 1}[pair]))
     except Exception:
+      if self.handle is not None:
+        L.gnpde_dopri5_destroy(self.handle)
+        self.handle = None
       self.engine.close()
       raise
     self.out = backend.empty(shard.n_own)
@@ -1087,10 +1092,10 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
   with_source = bool(func.opt['add_source'])
   skey = (method, dts, with_source)
   sol = ent['solvers'].get(skey)
-  in_graph = (adaptive and method == 'dopri5' and ent['ctx'] is not None and d % 4 == 0 and t.dtype == torch.float32 and
+  in_graph = (adaptive and ent['ctx'] is not None and d % 4 == 0 and t.dtype == torch.float32 and
               os.environ.get('GNPDE_SHARDED_HOST_CONTROLLER', '0') != '1')
   if in_graph:
-    # dopri5 with the controller on every rank's device: trial steps as per-rank hipGraphs, the error norm summed over the ranks
+    # dopri5 / adaptive_heun with the controller on every rank's device: trial steps as per-rank hipGraphs, the error norm summed over the ranks
     # inside the stream (NativeShardedDopri5) -- every rank holds the same controller record, reads it once per batch of trial steps
     from .utils import MaxNFEException
     from .odeint import end_points
@@ -1104,7 +1109,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
         if hasattr(old, 'close'):
           old.close()
       ent['solvers'].clear()
-      sol = NativeShardedDopri5(shard, be, rtol, atol, n, with_source=with_source, ctx=ent['ctx'], group=group)
+      sol = NativeShardedDopri5(shard, be, rtol, atol, n, with_source=with_source, ctx=ent['ctx'], group=group, pair=method)
       ent['solvers'][skey] = sol
     y_own = y0.detach()[ent['own_ids']]
     x0_own = None
@@ -1126,8 +1131,8 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
     func.nfe += spent
     return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, 0)
   if adaptive:
-    # adaptive_heun (and dopri5 where the in-graph solver does not apply): the host controller over sharded evaluations
-    # (ShardedSolver.integrate_adaptive), one all-reduce per trial step
+    # where the in-graph solver does not apply (normalisers with exchanges between the attention passes, rows that are no multiple of
+    # 16 bytes): the host controller over sharded evaluations (ShardedSolver.integrate_adaptive), one all-reduce per trial step
     if sol is None:
       for old in ent['solvers'].values():
         if hasattr(old, 'close'):

@@ -417,7 +417,7 @@ def _solve_dopri5_native(func, y0, t, rtol, atol, safety=0.9, ifactor=10.0, dfac
   return out
 
 
-def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluator=None, stop_after=None):
+def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluator=None, stop_after=None, pair='dopri5'):
   """dopri5 with the controller on the device (csrc/dopri5.hip): a trial step is one hipGraph replay; accept / reject, the
   step-size update, the end-point interpolation and the commit are decided by kernels from a record in device memory, which the
   host reads once per `trials_per_sync` trial steps.  Same arithmetic as `_solve_dopri5_native` (which stays for callers that
@@ -471,6 +471,8 @@ def _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=None, evaluato
     ent['solver'] = ops.Dopri5Solver(desc, rtol, atol, y0.device)
     ent['sig'] = sig
   sol = ent['solver']
+  if getattr(sol, 'pair', 'dopri5') != pair:      # (`pair`: 'dopri5' or torchdiffeq's 'adaptive_heun' -- the same controller, another trial step)
+    sol.set_pair(pair)
   if evaluator is not None:
     if getattr(sol, 'evaluator', None) is not evaluator or getattr(sol, 'max_trial_steps', None) != int(stop_after):
       sol.set_early_stop(evaluator, int(stop_after))
@@ -1015,6 +1017,10 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, use_
       return _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=options.get('trials_per_sync'))
     return _solve_dopri5(func, y0, t, rtol, atol, norm=options.get('norm'))
   if method == 'adaptive_heun':
+    if (hasattr(func, '_descriptor') and _native_ok(func, y0, t) and t.dtype == torch.float32 and not options.get('host_controller', False)
+        and options.get('norm') is None):
+      # the device controller with the Heun pair's trial step (one evaluation per trial step; csrc/dopri5.hip, gnpde_dopri5_set_pair)
+      return _solve_dopri5_device(func, y0, t, rtol, atol, trials_per_sync=options.get('trials_per_sync'), pair='adaptive_heun')
     return _solve_dopri5(func, y0, t, rtol, atol, tableau='adaptive_heun', norm=options.get('norm'))
   raise ValueError('unsupported method %r (euler, midpoint, rk4, dopri5, adaptive_heun)' % (method,))
 

@@ -465,6 +465,11 @@ class Dopri5Solver(object):
                                         ptr(self.times), cap, int(max_trial_steps)))
     self.evaluator, self.max_trial_steps = evaluator, int(max_trial_steps)
 
+  def set_pair(self, name):
+    """The embedded pair of the following runs: 'dopri5' or 'adaptive_heun' (gnpde_dopri5_set_pair)."""
+    check(_lib.lib().gnpde_dopri5_set_pair(self.handle, {'adaptive_heun': 0, 'dopri5': 1}[name]))
+    self.pair = name
+
   def set_row_order(self, order32):
     """Fold a node relabelling into the solve's copies: solver row r <-> caller's row order32[r] (int32 device tensor or None)."""
     check(_lib.lib().gnpde_dopri5_set_row_order(self.handle, ptr(order32)))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition);  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition), gnpde_dopri5_set_pair;  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -577,6 +577,13 @@ typedef struct gnpde_dopri5 gnpde_dopri5_t;
 size_t gnpde_dopri5_workspace_bytes(const gnpde_rhs_t* rhs);
 int gnpde_dopri5_create(gnpde_dopri5_t** out, const gnpde_rhs_t* rhs, float rtol, float atol, void* workspace,
                         size_t workspace_bytes);
+enum { GNPDE_ADAPTIVE_HEUN = 0, GNPDE_ADAPTIVE_DOPRI5 = 1 };
+/* The embedded pair of the following runs: GNPDE_ADAPTIVE_DOPRI5 (default) or GNPDE_ADAPTIVE_HEUN -- torchdiffeq 0.2.1's
+ * `adaptive_heun` (adaptive_heun.py; reference `--method adaptive_heun`, src/run_GNN.py): one evaluation per trial step, k1 = f(y + h k0),
+ * y1 = y + h (k0 + k1) / 2, error h (k0 - k1) / 2, order 2 in the step-size rule and the initial step, the quartic end-point
+ * interpolant through y + h k0 / 2, and k1 as the next step's first derivative (rk_common.py takes f1 = k[..., -1] for every pair).
+ * Same controller record, batching and early stopping; the recorded solve (gnpde_dopri5_set_tape) is Dormand-Prince's only. */
+int gnpde_dopri5_set_pair(gnpde_dopri5_t* s, int32_t pair);
 int gnpde_dopri5_run(gnpde_dopri5_t* s, const float* y0, int32_t ld_y0, double t0, double t1, float* y_out, int32_t ld_out,
                      int32_t trials_per_sync, int32_t max_evals, int32_t* finished, void* stream);
 /* Early stopping on the device controller  [replaces EarlyStopDopri5.advance + evaluate, reference src/early_stop_solver.py:
@@ -647,7 +654,7 @@ int gnpde_dopri5_tape_backward(gnpde_dopri5_t* s, const gnpde_graph_t* graph_t, 
  *   g (device float[2]) in / out: accumulated (g_alpha, g_beta); integrates s from s0 to s1 > s0 (= -t) starting with step dt0 (the
  *   caller selects it: misc.py _select_initial_step, two evaluations).  max_evals / *finished as gnpde_dopri5_run.  Synchronises the stream
  *   while it runs (one read per batch); the final copies are queued behind. */
-enum { GNPDE_ADAPTIVE_HEUN = 0, GNPDE_ADAPTIVE_DOPRI5 = 1 };
+/* (GNPDE_ADAPTIVE_HEUN / GNPDE_ADAPTIVE_DOPRI5: declared with gnpde_dopri5_set_pair above) */
 typedef struct gnpde_adjoint_adaptive gnpde_adjoint_adaptive_t;
 size_t gnpde_adjoint_adaptive_workspace_bytes(const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, int32_t method);
 int gnpde_adjoint_adaptive_create(gnpde_adjoint_adaptive_t** out, const gnpde_rhs_t* rhs, const gnpde_graph_t* graph_t, const float* w_t,

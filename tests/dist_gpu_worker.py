@@ -102,12 +102,12 @@ def main():
     assert torch.equal(z1, z2), 'rank %d: repeated adaptive solve differs' % rank
     full = D.gather_rows_all(z1.cpu(), plan, sh)
     native = {}
-    if method == 'dopri5':
+    if method in ('dopri5', 'adaptive_heun'):
       # the same solve with the controller on every rank's DEVICE (gnpde_dopri5_create_sharded): trial steps as per-rank hipGraphs, the
       # error norm summed over the ranks inside the stream; the host reads the controller record once per batch of trial steps
       ctx = D.P2PContext(sh, d, 4)
       with torch.no_grad():
-        nat = D.NativeShardedDopri5(sh, be, rtol, atol, n, with_source=True, ctx=ctx)
+        nat = D.NativeShardedDopri5(sh, be, rtol, atol, n, with_source=True, ctx=ctx, pair=method)
         nat.engine.set_spin_limit(1 << 22)
         n1, fin1 = nat.integrate(x_own, x_own, 0.0, T, trials_per_sync=8)
         n1 = n1.clone()

@@ -350,6 +350,54 @@ def test_device_controlled_dopri5(dev, function, d):
     assert runs[label][2]['launches'] == trials, (label, runs[label][2], trials)
 
 
+@pytest.mark.parametrize('function,d', [('transformer', 64), ('laplacian', 64), ('laplacian', 81)])
+def test_device_controlled_adaptive_heun(dev, function, d):
+  """`--method adaptive_heun` (torchdiffeq 0.2.1's 2(1) pair) on the device controller (gnpde_dopri5_set_pair): one evaluation per trial
+  step.  Same evaluations of f and the same state as the controller of odeint._solve_dopri5 on the host (options host_controller) and as
+  the restated torchdiffeq of oracle/shims over the CPU oracle; the batch size of the record reads does not change a bit; switching the
+  same solver object back to dopri5 reproduces the dopri5 solve."""
+  ei, n = G.synthetic.make_graph('arxiv', scale=0.03)
+  xc = torch.randn(n, d, generator=torch.Generator().manual_seed(23)) * 0.5
+  x = xc.to(dev)
+  opt = dict(BASE, function=function, hidden_dim=d, method='adaptive_heun', time=2.0, tol_scale=2000.0)
+  block = _block(opt, ei.to(dev), n, x, dev)
+  f = block.odefunc
+  f.x0 = x
+  t = torch.tensor([0.0, 2.0], device=dev)
+  kw = dict(atol=2000.0 * 1e-7, rtol=2000.0 * 1e-9)
+  runs = {}
+  with torch.no_grad():
+    f.nfe = 0
+    z_dp = G.odeint(f, x, t, method='dopri5', **kw)[1].clone()
+    for label, options in [('host', {'host_controller': True}), ('k1', {'trials_per_sync': 1}), ('k8', {'trials_per_sync': 8})]:
+      f.nfe = 0
+      z = G.odeint(f, x, t, method='adaptive_heun', options=options, **kw)[1]
+      runs[label] = (z.clone(), f.nfe, dict(getattr(f, '_dopri5_stats', {})))
+    f.nfe = 0
+    z_dp2 = G.odeint(f, x, t, method='dopri5', **kw)[1].clone()
+  assert torch.equal(z_dp, z_dp2)
+  z_host, nfe_host, _ = runs['host']
+  assert nfe_host >= 8
+  for label in ('k1', 'k8'):
+    z, nfe, stats = runs[label]
+    assert nfe == nfe_host and stats['evals'] == nfe and (stats['accepted'] + stats['rejected']) + 2 == nfe, (label, nfe, nfe_host, stats)
+    assert_parity(z, z_host, tol=2e-6, what='adaptive_heun: device vs host controller (%s)' % label)
+  assert torch.equal(runs['k1'][0], runs['k8'][0]) and runs['k8'][2]['syncs'] < runs['k1'][2]['syncs']
+  calls = [0]
+  if function == 'laplacian':
+    cpu = lambda v: v.detach().cpu()
+    rhs0 = lambda tq, y: R.rhs_laplacian(y, cpu(f.edge_index), cpu(f.edge_weight), cpu(f.alpha_train), cpu(f.beta_train), xc, False, True)
+  else:
+    rhs0 = _oracle_rhs(block, xc)
+
+  def rhs(tq, y):
+    calls[0] += 1
+    return rhs0(tq, y)
+  ref = REF_TORCHDIFFEQ.odeint(rhs, xc, torch.tensor([0.0, 2.0]), method='adaptive_heun', options={}, **kw)[1]
+  assert calls[0] == nfe_host
+  assert_parity(runs['k8'][0], ref, tol=2e-5, what='adaptive_heun on the device vs the restated torchdiffeq over the oracle')
+
+
 @pytest.mark.parametrize('function', ['transformer', 'laplacian'])
 def test_device_controlled_dopri5_on_the_relabelled_graph(dev, function):
   """Device dopri5 on the relabelled graph -- on request only (opt['gnpde_reorder'] = 'parts' / 'degree'; 'auto' leaves dopri5
