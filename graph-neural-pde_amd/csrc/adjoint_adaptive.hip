@@ -373,10 +373,21 @@ __global__ __launch_bounds__(kBlock) void adaptive_finish2_kernel(const HCtlArgs
   typedef float f4 __attribute__((ext_vector_type(4)));
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < p.n4;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const f4 ya = reinterpret_cast<const f4*>(p.y)[i], yb = reinterpret_cast<const f4*>(p.y1)[i];
-    const f4 fa = reinterpret_cast<const f4*>(p.f)[i], fb = reinterpret_cast<const f4*>(p.f1)[i];
-    const f4 aa = reinterpret_cast<const f4*>(p.a)[i], ab = reinterpret_cast<const f4*>(p.a1)[i];
-    const f4 va = reinterpret_cast<const f4*>(p.v[0])[i], vb = reinterpret_cast<const f4*>(p.v[S])[i];
+    // (the decision is the same for every thread of the grid: an accepted step that does not contain the end point -- the common case --
+    //  needs the new state, adjoint and last derivatives only, a rejected one the old ones only: four of the eight streams)
+    f4 ya = {0.f, 0.f, 0.f, 0.f}, yb = ya, fa = ya, fb = ya, aa = ya, ab = ya, va = ya, vb = ya;
+    if (interp || !accept) {
+      ya = reinterpret_cast<const f4*>(p.y)[i];
+      fa = reinterpret_cast<const f4*>(p.f)[i];
+      aa = reinterpret_cast<const f4*>(p.a)[i];
+      va = reinterpret_cast<const f4*>(p.v[0])[i];
+    }
+    if (interp || accept) {
+      yb = reinterpret_cast<const f4*>(p.y1)[i];
+      fb = reinterpret_cast<const f4*>(p.f1)[i];
+      ab = reinterpret_cast<const f4*>(p.a1)[i];
+      vb = reinterpret_cast<const f4*>(p.v[S])[i];
+    }
     if (interp) {
       f4 am = aa;
 #pragma unroll
