@@ -1025,6 +1025,20 @@ void launch_pair(const SpmmArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((spmm_pair_kernel<VEC, U, BLK, true, false>), dim3(grid), dim3(BLK), 0, s, a);
 }
 
+// A/B (gnpde_tune(0, 135)): the same kernel with ordinary (cached) loads and stores of the per-row streaming operands
+template <int VEC, int U, int BLK>
+void launch_pair_cached(const SpmmArgs& a, hipStream_t s) {
+  constexpr int WPB = BLK / kWave;
+  const long long cn = a.chunk_end - a.chunk_begin, rn = a.row_end - a.row_begin;
+  const long long per = xcd_rows_per(static_cast<int>(rn), a.row_shift);
+  const long long per_xcd = (cn + kXcds - 1) / kXcds + (per + 1) / 2;
+  long long blocks = (per_xcd + WPB - 1) / WPB;
+  if (blocks < 1) blocks = 1;
+  const unsigned grid = static_cast<unsigned>(blocks * kXcds);
+  if (a.d == 32 * VEC) hipLaunchKernelGGL((spmm_pair_kernel<VEC, U, BLK, false, true>), dim3(grid), dim3(BLK), 0, s, a);
+  else hipLaunchKernelGGL((spmm_pair_kernel<VEC, U, BLK, false, false>), dim3(grid), dim3(BLK), 0, s, a);
+}
+
 // resident grid of the pipelined row-pair kernel: `waves_per_cu` waves on every CU, shrunk when there is less work than that
 template <int VEC, int U, int BLK>
 void launch_pair_pipe(const SpmmArgs& a, hipStream_t s, int waves_per_cu) {
@@ -1103,6 +1117,7 @@ int dispatch_rows(const SpmmArgs& a, hipStream_t s) {
         case 132: launch_pair<4, 4, 64>(a, s); return 0;
         case 133: launch_pair<4, 16, 64>(a, s); return 0;
         case 134: launch_pair<4, 4, 256>(a, s); return 0;
+        case 135: launch_pair_cached<4, 16, 64>(a, s); return 0;
         default: launch_pair<4, 16, 256>(a, s); return 0;
       }
     }
