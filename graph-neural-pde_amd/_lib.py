@@ -78,6 +78,14 @@ class HaloStruct(ctypes.Structure):
               ('send_idx', c_vp), ('send_counts', c_int_p), ('recv_counts', c_int_p)]
 
 
+class GeneralStruct(ctypes.Structure):
+  _fields_ = [('att_graph', ctypes.POINTER(GraphStruct)), ('spmm_graph', ctypes.POINTER(GraphStruct)), ('att', ctypes.POINTER(AttentionStruct)),
+              ('qk', c_vp), ('w', c_vp), ('stats_send', c_vp), ('att_ws', c_vp), ('att_ws_bytes', ctypes.c_size_t),
+              ('spmm_ws', c_vp), ('spmm_ws_bytes', ctypes.c_size_t), ('stats_buffer', ctypes.c_int32), ('in_offset', ctypes.c_int64),
+              ('peer_in_offset', ctypes.POINTER(ctypes.c_int64)), ('peer_buffer_bytes', ctypes.POINTER(ctypes.c_int64)),
+              ('peer_rev_row0', ctypes.POINTER(ctypes.c_int64))]
+
+
 XCD_CONTIGUOUS, XCD_HASHED = 0, 1
 COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 128
@@ -220,6 +228,7 @@ PROTOTYPES = {
                                                      ctypes.POINTER(RhsStruct), ctypes.POINTER(RhsStruct), ctypes.c_int32,
                                                      c_float_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
                                                      ctypes.POINTER(ctypes.c_int64), c_vp, ctypes.c_size_t]),
+  'gnpde_sharded_solver_set_general': (ctypes.c_int, [c_vp, ctypes.POINTER(GeneralStruct)]),
   'gnpde_sharded_solver_status': (ctypes.c_int, [c_vp, c_int_p, ctypes.POINTER(ctypes.c_int64)]),
   'gnpde_sharded_solver_timing': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_vp, c_vp]),
   'gnpde_sharded_solver_set_spin_limit': (ctypes.c_int, [c_vp, ctypes.c_int64]),

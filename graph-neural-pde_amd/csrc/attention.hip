@@ -21,6 +21,7 @@
 //   rows run the general passes restricted to their chunks.
 #include <cmath>
 #include "common.h"
+#include "rhs.h"
 
 namespace gnpde {
 namespace {
@@ -1617,6 +1618,13 @@ extern "C" int gnpde_edge_attention_pass(const gnpde_graph_t* g, const gnpde_att
                                          void* workspace, size_t workspace_bytes, void* stream) {
   return gnpde::launch_edge_attention_pass(g, a, pass, w_mean_csr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
+
+namespace gnpde {
+AttLayoutView att_layout_view(const gnpde_graph_t* g, const gnpde_attention_t* a) {
+  const AttLayout L = att_layout(g->n, g->e, a->heads, a->type == GNPDE_ATT_GAT, long_slots_of(g), a->n_key_rows);
+  return AttLayoutView{L.seg_m, L.seg_den, L.gmax, L.total};
+}
+}  // namespace gnpde
 
 extern "C" int gnpde_attention_workspace_regions(const gnpde_graph_t* g, const gnpde_attention_t* a, size_t* offsets) {
   GNPDE_CHECK_ARG(g && a && offsets && a->heads >= 1, GNPDE_EINVAL, "attention_workspace_regions: bad arguments");

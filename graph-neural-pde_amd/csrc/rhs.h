@@ -40,6 +40,10 @@ inline bool rhs_key_table(const gnpde_rhs_t& r, const float* u) {
          r.proj_m == 2 * r.att.att_dim && linear_split_supported(u, r.graph->n, r.d, r.ld, r.proj_w, r.proj_m, r.d, r.att.att_dim);
 }
 
+// where the segment statistics and the squareplus maximum of the attention passes lie inside their workspace (attention.hip)
+struct AttLayoutView { size_t seg_m, seg_den, gmax, total; };
+AttLayoutView att_layout_view(const gnpde_graph_t* g, const gnpde_attention_t* a);
+
 RhsLayout rhs_layout(const gnpde_rhs_t& r);
 int check_rhs(const gnpde_rhs_t* r);
 // Enqueue f(u) with the given epilogue; `ws` follows rhs_layout(r).

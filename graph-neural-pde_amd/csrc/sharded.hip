@@ -37,6 +37,10 @@
 #include "rhs.h"
 
 namespace gnpde {
+int launch_linear_any(const float* x, int n, int d, int ldx, const float* W, int m, int ldw, const float* b, float* out,
+                      int ldo, hipStream_t s, int relu = 0);
+int launch_edge_attention_pass(const gnpde_graph_t* g, const gnpde_attention_t* at, int pass, float* w_mean_csr, void* ws,
+                               size_t ws_bytes, hipStream_t stream);
 namespace {
 
 struct Rccl {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void push_rows_kernel(const PushArgs a) {
     const int i = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[a.w_begin + w]) : a.w_begin + w;
     int p = 0;
     while (p + 1 < a.world && i >= a.seg[p + 1]) ++p;
-    const float* src = a.src + static_cast<size_t>(a.send_idx[i]) * a.ld;
+    const float* src = a.src + static_cast<size_t>(a.send_idx != nullptr ? a.send_idx[i] : i) * a.ld;     // (NULL: the rows in list order)
     float* dst = a.dst[p] + static_cast<size_t>(a.dst_row0[p] + (i - a.seg[p])) * a.ld;
     if ((a.d & 3) == 0 && (a.ld & 3) == 0) {
       for (int c = lane * 4; c < a.d; c += kWave * 4)
@@ -213,10 +217,18 @@ __global__ __launch_bounds__(kMaxWorld) void wait_flags_kernel(uint32_t* ctl, in
 // bank in RANK order -- every rank adds the same numbers in the same order, so every rank's controller sees the same bits and takes
 // the same accept / reject decisions.  A bank is rewritten two sums later: by then every peer has passed the sum in between, which
 // needed this rank's contribution to it, which this rank made after reading the bank.  Bounded wait like wait_flags_kernel.
+// MAXWORD: the same exchange for the MAXIMUM of one unsigned word per rank (`value` points at it: the order-preserving encoding of
+// squareplus' global maximum score, csrc/attention.hip f2ord) -- exact, so no order to keep.
+template <bool MAXWORD>
 __global__ __launch_bounds__(kBlock) void p2p_sum_kernel(double* __restrict__ value, int n_partials, uint32_t* ctl, uint32_t* const* peer_ctl,
                                                         int rank, int world, long long max_spins) {
   __shared__ double red[kBlock];
   __shared__ unsigned epoch;
+  if constexpr (MAXWORD) {
+    if (world == 1) return;
+    if (threadIdx.x == 0) red[0] = __longlong_as_double(static_cast<long long>(*reinterpret_cast<const uint32_t*>(value)));
+    __syncthreads();
+  } else {
   double acc = 0.0;
   for (int i = threadIdx.x; i < n_partials; i += kBlock) acc += value[i];
   red[threadIdx.x] = acc;
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(kBlock) void p2p_sum_kernel(double* __restrict__ va
   if (world == 1) {
     if (threadIdx.x == 0) value[0] = red[0];
     return;
+  }
   }
   if (threadIdx.x == 0) {
     epoch = __hip_atomic_load(ctl + kCtlSum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -259,11 +272,57 @@ __global__ __launch_bounds__(kBlock) void p2p_sum_kernel(double* __restrict__ va
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long* vals = reinterpret_cast<const unsigned long long*>(ctl + kCtlSumVals) + bank;
-    double total = 0.0;
-    for (int q = 0; q < world; ++q)
-      total += __longlong_as_double(static_cast<long long>(__hip_atomic_load(vals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)));
-    value[0] = total;
+    if constexpr (MAXWORD) {
+      uint32_t best = 0u;
+      for (int q = 0; q < world; ++q) {
+        const uint32_t w = static_cast<uint32_t>(__hip_atomic_load(vals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        best = w > best ? w : best;
+      }
+      *reinterpret_cast<uint32_t*>(value) = best;
+    } else {
+      double total = 0.0;
+      for (int q = 0; q < world; ++q)
+        total += __longlong_as_double(static_cast<long long>(__hip_atomic_load(vals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)));
+      value[0] = total;
+    }
   }
+}
+
+// ---- statistics of the segments of a normaliser that is not row-local (attention_norm_idx = 1: the segments are the COLUMNS, and a
+// column's entries lie on every rank that holds a row pointing at it) between the tables of the attention passes ([n, h] maxima and
+// [n, h] sums) and the rows that travel ([.., 2 h]: maxima then sums)
+__global__ __launch_bounds__(kBlock) void stats_pack_kernel(const float* __restrict__ m, const float* __restrict__ den, int row0, int n_rows, int h,
+                                                           float* __restrict__ out) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<long long>(n_rows) * 2 * h) return;
+  const int i = static_cast<int>(idx / (2 * h)), c = static_cast<int>(idx % (2 * h));
+  const size_t o = static_cast<size_t>(row0 + i) * h;
+  out[idx] = c < h ? m[o + c] : den[o + c - h];
+}
+__global__ __launch_bounds__(kBlock) void stats_unpack_kernel(const float* __restrict__ in, int row0, int n_rows, int h, float* __restrict__ m,
+                                                             float* __restrict__ den) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<long long>(n_rows) * 2 * h) return;
+  const int i = static_cast<int>(idx / (2 * h)), c = static_cast<int>(idx % (2 * h));
+  const size_t o = static_cast<size_t>(row0 + i) * h;
+  if (c < h) m[o + c] = in[idx]; else den[o + c - h] = in[idx];
+}
+// (m, den)[rows[i]] <- (m, den)[rows[i]] (+) in[i]: the arithmetic of stats_merge_kernel (csrc/attention.hip) on travelling rows
+__global__ __launch_bounds__(kBlock) void stats_merge_rows_kernel(float* __restrict__ m, float* __restrict__ den, const int* __restrict__ rows,
+                                                                 int n_rows, int h, const float* __restrict__ in, int square_plus) {
+  const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<long long>(n_rows) * h) return;
+  const int i = static_cast<int>(idx / h), head = static_cast<int>(idx % h);
+  const size_t o = static_cast<size_t>(rows[i]) * h + head;
+  const float m_in = in[static_cast<size_t>(i) * 2 * h + head], den_in = in[static_cast<size_t>(i) * 2 * h + h + head];
+  if (square_plus) {
+    den[o] = den[o] + den_in;
+    return;
+  }
+  const float ma = m[o], mb = m_in;
+  const float mm = fmaxf(ma, mb);
+  den[o] = mm == -INFINITY ? den[o] + den_in : den[o] * expf(ma - mm) + den_in * expf(mb - mm);
+  m[o] = mm;
 }
 
 }  // namespace
@@ -306,6 +365,20 @@ struct gnpde_sharded_solver {
   std::vector<gnpde_graph_t> g_chunk;
   std::vector<RhsLayout> L_chunk;
   std::vector<int> push_chunk_ptr;  // [n_chunks + 1] into the walk order
+  // Normalisers that are not row-local (gnpde_sharded_solver_set_general): the evaluation is projection + the three attention passes
+  // with their exchanges in between + aggregation, all inside the stream
+  struct General {
+    bool on = false;
+    gnpde_graph_t g_att, g_spmm;
+    gnpde_attention_t att;
+    float* qk = nullptr; float* w = nullptr; float* stats_send = nullptr;
+    char* att_ws = nullptr; size_t att_ws_bytes = 0; char* spmm_ws = nullptr; size_t spmm_ws_bytes = 0;
+    size_t off_m = 0, off_den = 0, off_gmax = 0;
+    float* table = nullptr;          // this rank's [S: n_local x 2h | in_part: n_send x 2h] inside the shared block
+    float* in_part = nullptr;
+    char* dev = nullptr;             // device tables below (one allocation)
+    int32_t* d_rev_seg = nullptr; long long* d_rev_row0 = nullptr; float** d_rev_dst = nullptr; float** d_s_dst = nullptr;
+  } gen;
 };
 
 namespace {
@@ -406,8 +479,99 @@ int enqueue_exchange_p2p(gnpde_sharded_solver* s, float* u, hipStream_t st) {
   return enqueue_push_p2p(s, u, 0, s->n_send, true, s->eval_cursor, true, st);
 }
 
+// push of the rows of a [.., w] table (list order when idx is NULL) into the peers' copies + the epoch; joins the side stream back
+int enqueue_push_table(gnpde_sharded_solver* s, const float* src, int w, int n_send, const int32_t* idx, const int32_t* seg, float* const* dst,
+                       const long long* dst_row0, hipStream_t st) {
+  gnpde_p2p* x = s->p2p;
+  GNPDE_HIP(hipEventRecord(s->e_pack, st));
+  GNPDE_HIP(hipStreamWaitEvent(x->stream, s->e_pack, 0));
+  PushArgs a;
+  a.src = src; a.ld = w; a.d = w; a.n_send = n_send; a.rank = x->rank; a.world = x->world;
+  a.send_idx = idx; a.order = nullptr; a.seg = seg; a.dst = dst; a.dst_row0 = dst_row0;
+  a.peer_ctl = s->d_peer_ctl; a.ctl = x->ctl; a.w_begin = 0; a.publish = 1; a.stamp_start = nullptr; a.stamp_end = nullptr;
+  const unsigned grid = static_cast<unsigned>(n_send > 0 ? (n_send + kWavesPerBlock - 1) / kWavesPerBlock : 1);
+  hipLaunchKernelGGL(push_rows_kernel, dim3(grid), dim3(kBlock), 0, x->stream, a);
+  GNPDE_LAUNCH_CHECK();
+  GNPDE_HIP(hipEventRecord(s->e_recv, x->stream));
+  GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
+  hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, x->ctl, x->rank, x->world, s->max_spins, nullptr);
+  GNPDE_LAUNCH_CHECK();
+  return 0;
+}
+
+// One evaluation with a normaliser that is not row-local (reference src/function_transformer_attention.py:190-213 with
+// attention_norm_idx = 1 and / or squareplus, src/utils.py:179-208), everything inside the stream -- the sequence of
+// distributed.NativeBackend.rhs_stage_general, which drove it from Python with torch.distributed exchanges:
+//   state rows to the peers; projection of own + halo rows; pass 1 (scores + the local maximum) [squareplus: MAX over the ranks];
+//   pass 2 (statistics of every local segment) [over columns: the halo columns' partial statistics to their owners, merged there peer
+//   by peer in rank order, the totals back with the state's pattern]; pass 3 (normalise + head mean); aggregation with the stage.
+// Every rank issues the same pushes in the same order, so ONE epoch sequence orders all three exchanges.
+int enqueue_eval_general(gnpde_sharded_solver* s, float* u, const gnpde_epilogue_t& e, hipStream_t st) {
+  auto& G = s->gen;
+  gnpde_p2p* x = s->p2p;
+  const int n_local = s->n_own + s->n_halo, h = G.att.heads, A = G.att.att_dim;
+  const bool exch = s->exchanges;
+  if (exch) {
+    if (int rc = enqueue_exchange_p2p(s, u, st)) return rc;
+    GNPDE_HIP(hipStreamWaitEvent(st, s->e_recv, 0));
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(kMaxWorld), 0, st, x->ctl, x->rank, x->world, s->max_spins, nullptr);
+    GNPDE_LAUNCH_CHECK();
+  }
+  const gnpde_rhs_t& r = s->rhs_int;
+  if (int rc = launch_linear_any(u, n_local, s->d, s->ld, r.proj_w, r.proj_m, s->d, r.proj_b, G.qk, r.proj_m, st)) return rc;
+  gnpde_attention_t at = G.att;
+  at.q = G.qk;
+  at.k = r.kind == GNPDE_RHS_GAT ? G.qk : G.qk + A;
+  at.ldqk = r.proj_m;
+  float* m = reinterpret_cast<float*>(G.att_ws + G.off_m);
+  float* den = reinterpret_cast<float*>(G.att_ws + G.off_den);
+  if (int rc = launch_edge_attention_pass(&G.g_att, &at, 1, nullptr, G.att_ws, G.att_ws_bytes, st)) return rc;
+  if (at.square_plus && exch) {
+    hipLaunchKernelGGL(p2p_sum_kernel<true>, dim3(1), dim3(kBlock), 0, st, reinterpret_cast<double*>(G.att_ws + G.off_gmax), 1, x->ctl,
+                       s->d_peer_ctl, x->rank, x->world, s->max_spins);
+    GNPDE_LAUNCH_CHECK();
+  }
+  if (int rc = launch_edge_attention_pass(&G.g_att, &at, 2, nullptr, G.att_ws, G.att_ws_bytes, st)) return rc;
+  if (at.norm_idx == 1 && exch) {
+    auto blocks = [](long long items) { return dim3(static_cast<unsigned>(items > 0 ? (items + kBlock - 1) / kBlock : 1)); };
+    // (i) partial statistics of the halo columns -> their owners' in_part rows
+    if (s->n_halo > 0) {
+      hipLaunchKernelGGL(stats_pack_kernel, blocks(static_cast<long long>(s->n_halo) * 2 * h), dim3(kBlock), 0, st, m, den, s->n_own, s->n_halo, h, G.stats_send);
+      GNPDE_LAUNCH_CHECK();
+    }
+    if (int rc = enqueue_push_table(s, G.stats_send, 2 * h, s->n_halo, nullptr, G.d_rev_seg, G.d_rev_dst, G.d_rev_row0, st)) return rc;
+    // (ii) merge at the owner, peer by peer in rank order
+    int pos = 0;
+    for (int p = 0; p < x->world; ++p) {
+      const int cnt = s->send_counts[p];
+      if (cnt > 0) {
+        hipLaunchKernelGGL(stats_merge_rows_kernel, blocks(static_cast<long long>(cnt) * h), dim3(kBlock), 0, st, m, den, s->send_idx + pos, cnt, h,
+                           G.in_part + static_cast<size_t>(pos) * 2 * h, at.square_plus);
+        GNPDE_LAUNCH_CHECK();
+      }
+      pos += cnt;
+    }
+    // (iii) the totals travel back like the state's boundary rows (same send list, same halo rows on the peers)
+    if (s->n_own > 0) {
+      hipLaunchKernelGGL(stats_pack_kernel, blocks(static_cast<long long>(s->n_own) * 2 * h), dim3(kBlock), 0, st, m, den, 0, s->n_own, h, G.table);
+      GNPDE_LAUNCH_CHECK();
+    }
+    if (int rc = enqueue_push_table(s, G.table, 2 * h, s->n_send, s->send_idx, s->d_seg, G.d_s_dst, s->d_dst_row0, st)) return rc;
+    if (s->n_halo > 0) {
+      hipLaunchKernelGGL(stats_unpack_kernel, blocks(static_cast<long long>(s->n_halo) * 2 * h), dim3(kBlock), 0, st,
+                         G.table + static_cast<size_t>(s->n_own) * 2 * h, s->n_own, s->n_halo, h, m, den);
+      GNPDE_LAUNCH_CHECK();
+    }
+  }
+  if (int rc = launch_edge_attention_pass(&G.g_att, &at, 3, G.w, G.att_ws, G.att_ws_bytes, st)) return rc;
+  if (int rc = launch_spmm_rhs(&G.g_spmm, G.w, u, s->d, s->ld, &e, nullptr, G.spmm_ws, G.spmm_ws_bytes, st)) return rc;
+  ++s->eval_cursor;
+  return 0;
+}
+
 // exchange + f(u) with the fused stage: interior rows overlap the exchange, boundary rows follow it
 int enqueue_eval(gnpde_sharded_solver* s, float* u, gnpde_epilogue_t e, hipStream_t st) {
+  if (s->gen.on) return enqueue_eval_general(s, u, e, st);
   char* rws = s->ws + s->off_rhs;
   const bool exch = s->exchanges;
   const bool chunked = s->p2p != nullptr && exch && !s->rhs_chunk.empty();
@@ -690,7 +854,7 @@ extern "C" int gnpde_push_order(const int32_t* send_counts, int32_t world, int32
 
 // ------------------------------------------------------------------------------------------------ P2P shared memory
 extern "C" int gnpde_p2p_create(gnpde_p2p_t** out, int32_t rank, int32_t world, size_t buffer_bytes, int32_t n_buffers) {
-  GNPDE_CHECK_ARG(out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n_buffers >= 1 && n_buffers <= 4 &&
+  GNPDE_CHECK_ARG(out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n_buffers >= 1 && n_buffers <= 5 &&
                   buffer_bytes > 0, GNPDE_EINVAL, "p2p_create: bad arguments");
   *out = nullptr;
   static_assert(2 * sizeof(hipIpcMemHandle_t) <= GNPDE_P2P_HANDLE_BYTES, "IPC handles do not fit");
@@ -848,6 +1012,76 @@ extern "C" int gnpde_sharded_solver_create_p2p(gnpde_sharded_solver_t** out, gnp
     return static_cast<int>(e);
   }
   *out = s;
+  return 0;
+}
+
+extern "C" int gnpde_sharded_solver_set_general(gnpde_sharded_solver_t* s, const gnpde_general_t* g) {
+  GNPDE_CHECK_ARG(s != nullptr && g != nullptr, GNPDE_EINVAL, "sharded_solver_set_general: null argument");
+  GNPDE_CHECK_ARG(s->p2p != nullptr, GNPDE_ESTATE, "sharded_solver_set_general: the P2P transport only");
+  GNPDE_CHECK_ARG(s->rhs_chunk.empty(), GNPDE_ESTATE, "sharded_solver_set_general: no chunked boundary pass");
+  GNPDE_CHECK_ARG(g->att_graph && g->spmm_graph && g->att && g->qk && g->w && g->att_ws && g->peer_in_offset && g->peer_rev_row0 &&
+                  g->peer_buffer_bytes,
+                  GNPDE_EINVAL, "sharded_solver_set_general: null member");
+  GNPDE_CHECK_ARG(s->rhs_int.kind == GNPDE_RHS_TRANSFORMER || s->rhs_int.kind == GNPDE_RHS_GAT, GNPDE_EINVAL,
+                  "sharded_solver_set_general: an attention function");
+  const int n_local = s->n_own + s->n_halo, W = s->p2p->world, h = g->att->heads;
+  GNPDE_CHECK_ARG(g->att_graph->n == n_local && g->spmm_graph->n == s->n_own && g->spmm_graph->row_begin == 0, GNPDE_EINVAL,
+                  "sharded_solver_set_general: the attention graph has every local node as a segment, the aggregation graph the owned rows");
+  GNPDE_CHECK_ARG(h >= 1 && g->att->att_dim % h == 0 && (g->att->norm_idx == 0 || g->att->norm_idx == 1), GNPDE_EINVAL,
+                  "sharded_solver_set_general: bad attention description");
+  const bool columns = g->att->norm_idx == 1 && W > 1;
+  GNPDE_CHECK_ARG(!columns || (g->stats_send != nullptr && g->stats_buffer >= 0 && g->stats_buffer < s->p2p->n_buffers && g->stats_buffer >= 4),
+                  GNPDE_EINVAL, "sharded_solver_set_general: the column statistics need a shared buffer behind the four stage buffers");
+  const size_t row_bytes = static_cast<size_t>(2 * h) * 4;
+  const size_t in_off = static_cast<size_t>(g->in_offset);
+  GNPDE_CHECK_ARG(!columns || (in_off % 256 == 0 && in_off >= static_cast<size_t>(n_local) * row_bytes &&
+                               in_off + static_cast<size_t>(s->n_send) * row_bytes <= s->p2p->buffer_bytes),
+                  GNPDE_EWS, "sharded_solver_set_general: [S | in_part] does not fit the shared buffer (%zu + %zu of %zu bytes)", in_off,
+                  static_cast<size_t>(s->n_send) * row_bytes, s->p2p->buffer_bytes);
+  const gnpde::AttLayoutView lv = gnpde::att_layout_view(g->att_graph, g->att);
+  GNPDE_CHECK_ARG(g->att_ws_bytes >= lv.total, GNPDE_EWS, "sharded_solver_set_general: attention workspace %zu < %zu bytes", g->att_ws_bytes, lv.total);
+  drop_sharded_graph(s);
+  auto& G = s->gen;
+  if (G.dev) { (void)hipFree(G.dev); G.dev = nullptr; }
+  G.g_att = *g->att_graph; G.g_spmm = *g->spmm_graph; G.att = *g->att;
+  G.att.graph_t = nullptr; G.att.t_from_csr = nullptr;
+  G.qk = g->qk; G.w = g->w; G.stats_send = g->stats_send;
+  G.att_ws = static_cast<char*>(g->att_ws); G.att_ws_bytes = g->att_ws_bytes;
+  G.spmm_ws = static_cast<char*>(g->spmm_ws); G.spmm_ws_bytes = g->spmm_ws_bytes;
+  G.off_m = lv.seg_m; G.off_den = lv.seg_den; G.off_gmax = lv.gmax;
+  if (columns) {
+    G.table = reinterpret_cast<float*>(s->p2p->data + static_cast<size_t>(g->stats_buffer) * s->p2p->buffer_bytes);
+    G.in_part = reinterpret_cast<float*>(reinterpret_cast<char*>(G.table) + in_off);
+    const size_t seg_b = align_up(static_cast<size_t>(W + 1) * 4, 256), tab = align_up(static_cast<size_t>(W) * 8, 256);
+    if (hipMalloc(reinterpret_cast<void**>(&G.dev), seg_b + 3 * tab) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("sharded_solver_set_general: table allocation failed");
+      return GNPDE_EINVAL;
+    }
+    G.d_rev_seg = reinterpret_cast<int32_t*>(G.dev);
+    G.d_rev_row0 = reinterpret_cast<long long*>(G.dev + seg_b);
+    G.d_rev_dst = reinterpret_cast<float**>(G.dev + seg_b + tab);
+    G.d_s_dst = reinterpret_cast<float**>(G.dev + seg_b + 2 * tab);
+    std::vector<int32_t> seg(W + 1, 0);
+    std::vector<long long> row0(W);
+    std::vector<float*> rdst(W), sdst(W);
+    for (int p = 0; p < W; ++p) {
+      seg[p + 1] = seg[p] + s->recv_counts[p];
+      row0[p] = g->peer_rev_row0[p];
+      char* base = s->p2p->peer_data[p] + static_cast<size_t>(g->stats_buffer) * static_cast<size_t>(g->peer_buffer_bytes[p]);
+      sdst[p] = reinterpret_cast<float*>(base);
+      rdst[p] = reinterpret_cast<float*>(base + static_cast<size_t>(g->peer_in_offset[p]));
+    }
+    hipError_t e = hipMemcpy(G.d_rev_seg, seg.data(), (W + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(G.d_rev_row0, row0.data(), W * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(G.d_rev_dst, rdst.data(), W * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(G.d_s_dst, sdst.data(), W * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      set_error("sharded_solver_set_general: table upload failed: %s", hipGetErrorString(e));
+      return static_cast<int>(e);
+    }
+  }
+  G.on = true;
   return 0;
 }
 
@@ -1013,7 +1247,7 @@ int sharded_enqueue_eval(gnpde_sharded_solver* s, float* u, const gnpde_epilogue
 
 int sharded_enqueue_sum(gnpde_sharded_solver* s, double* value, int n_partials, hipStream_t st) {
   GNPDE_CHECK_ARG(s->p2p != nullptr && value != nullptr && n_partials >= 1, GNPDE_EINVAL, "sharded sum: bad arguments");
-  hipLaunchKernelGGL(p2p_sum_kernel, dim3(1), dim3(kBlock), 0, st, value, n_partials, s->p2p->ctl, s->d_peer_ctl, s->p2p->rank,
+  hipLaunchKernelGGL(p2p_sum_kernel<false>, dim3(1), dim3(kBlock), 0, st, value, n_partials, s->p2p->ctl, s->d_peer_ctl, s->p2p->rank,
                      s->p2p->world, s->max_spins);
   GNPDE_LAUNCH_CHECK();
   return 0;
@@ -1044,6 +1278,7 @@ extern "C" int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s) {
   if (s->e_pack) (void)hipEventDestroy(s->e_pack);
   if (s->e_recv) (void)hipEventDestroy(s->e_recv);
   if (s->d_stamps) (void)hipFree(s->d_stamps);
+  if (s->gen.dev) (void)hipFree(s->gen.dev);
   delete s;
   return 0;
 }

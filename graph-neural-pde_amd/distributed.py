@@ -700,6 +700,8 @@ class P2PContext(object):
     # where THIS rank's rows start inside peer p's stage buffers: after p's own rows and the rows p receives from lower ranks
     self.peer_row0 = [m['n_own'] + sum(m['recv_counts'][:s.rank]) for m in metas]
     self.peer_buffer_bytes = [m['buffer_bytes'] for m in metas]
+    self.n_buffers = int(n_buffers)
+    self.metas = [dict(n_own=m['n_own'], recv_counts=list(m['recv_counts'])) for m in metas]
     if s.world > 1:
       # every rank has mapped every peer before anyone pushes -- or every rank learns that one of them could not
       outcomes = [None] * s.world
@@ -788,6 +790,61 @@ class NativeShardedSolver(object):
       self.boundary_chunks = len(self.d_chunks)
     self.y = backend.empty(s.n_local)
     self.n_rhs_evals = L.gnpde_sharded_solver_num_rhs_evals(handle)
+    if getattr(backend, 'general', False):
+      try:
+        self._attach_general()
+      except Exception:
+        self.close()
+        raise
+
+  @staticmethod
+  def stats_layout(n_local, n_send, heads):
+    """(byte offset of in_part, bytes of [S | in_part]) inside the shared statistics buffer of a rank (gnpde_general_t)."""
+    row = 2 * int(heads) * 4
+    off = (int(n_local) * row + 255) // 256 * 256
+    return off, off + max(int(n_send), 1) * row
+
+  def _attach_general(self):
+    """gnpde_sharded_solver_set_general: the normalisers that are not row-local (attention_norm_idx 1, squareplus) with their exchanges
+    between the attention passes inside the per-rank graph -- what NativeBackend.rhs_stage_general drives from Python."""
+    import ctypes
+    be, s, L, ctx = self.be, self.shard, _lib.lib(), self.ctx
+    if self.transport != 'p2p' or ctx is None:
+      raise _lib.GnpdeError('normalisers with exchanges between the attention passes: the in-graph form needs the P2P transport')
+    h, A = be.heads, be.A
+    if be.kind == 'gat':
+      att = be.ops.attention_struct(_lib.ATT_GAT, h, A, be.norm_idx, False, leaky_slope=be.leaky_slope, gat_a=be.gat_a)
+      proj_m = A
+    else:
+      att = be.ops.attention_struct(be.att_code, h, A, be.norm_idx, be.square_plus, output_var=be.output_var, lengthscale=be.lengthscale,
+                                    edge_w_csr=be.reweight['att'] if be.reweight is not None else None)
+      proj_m = 2 * A
+    g_att, g_spmm, dev = be.g_att, be.graph, be.dev
+    columns = be.norm_idx == 1 and s.world > 1
+    in_off, need = self.stats_layout(s.n_local, int(sum(s.send_counts)), h)
+    if columns and (ctx.n_buffers < 5 or need > ctx.buffer_bytes):
+      raise _lib.GnpdeError('column statistics of %d bytes do not fit a fifth shared buffer of %d bytes' % (need, ctx.buffer_bytes))
+    keep = dict(att=att,
+                qk=torch.empty(max(s.n_local, 1), proj_m, dtype=torch.float32, device=dev),
+                w=torch.empty(max(g_att.e, 1), dtype=torch.float32, device=dev),
+                send=torch.empty(max(s.n_halo, 1), 2 * h, dtype=torch.float32, device=dev))
+    keep['att_ws'] = torch.empty(max(int(L.gnpde_attention_workspace_bytes(g_att.ref(), ctypes.byref(att))), 256), dtype=torch.uint8, device=dev)
+    keep['spmm_ws'] = torch.empty(max(int(L.gnpde_spmm_workspace_bytes(g_spmm.ref(), be.d)), 256), dtype=torch.uint8, device=dev)
+    W = s.world
+    metas = ctx.metas
+    peer_in = [self.stats_layout(m['n_own'] + sum(m['recv_counts']), 0, h)[0] for m in metas]
+    # peer p's send list is grouped by destination rank: my rows start behind what p sends to the ranks below me (= what they receive from p)
+    rev_row0 = [sum(metas[q]['recv_counts'][p] for q in range(s.rank)) for p in range(W)]
+    g = _lib.GeneralStruct()
+    g.att_graph, g.spmm_graph, g.att = ctypes.pointer(g_att.struct), ctypes.pointer(g_spmm.struct), ctypes.pointer(att)
+    g.qk, g.w, g.stats_send = keep['qk'].data_ptr(), keep['w'].data_ptr(), keep['send'].data_ptr()
+    g.att_ws, g.att_ws_bytes = keep['att_ws'].data_ptr(), keep['att_ws'].numel()
+    g.spmm_ws, g.spmm_ws_bytes = keep['spmm_ws'].data_ptr(), keep['spmm_ws'].numel()
+    g.stats_buffer, g.in_offset = 4, in_off
+    keep['tables'] = ((ctypes.c_int64 * W)(*peer_in), (ctypes.c_int64 * W)(*ctx.peer_buffer_bytes), (ctypes.c_int64 * W)(*rev_row0))
+    g.peer_in_offset, g.peer_buffer_bytes, g.peer_rev_row0 = keep['tables']
+    _lib.check(L.gnpde_sharded_solver_set_general(self.handle, ctypes.byref(g)))
+    self._general = keep      # (the library holds raw addresses of all of these)
 
   def _chunked_push_order(self, chunks):
     """(order, chunk_ptr): the send slots grouped by the boundary chunk that computes their row (interior rows that peers
@@ -1072,7 +1129,24 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
     be = NativeBackend(shard, d, dev, kind, local, func.alpha_train, func.beta_train, not func.opt['no_alpha_sigmoid'])
     # normalisers that are not row-local (attention_norm_idx 1, squareplus) exchange BETWEEN the attention passes: they run the
     # Python-driven loop over torch.distributed (ShardedSolver + NativeBackend.rhs_stage_general), not the in-graph P2P solver
-    ctx = None if getattr(be, 'general', False) else P2PContext(shard, d, 4, group=group)
+    # ... since round 6 inside the per-rank graph too (gnpde_sharded_solver_set_general) when the column statistics fit a fifth shared
+    # buffer on EVERY rank (the ranks agree: all or none); GNPDE_SHARDED_HOST_EXCHANGES=1 keeps the Python-driven loop (A/B, tests)
+    general = bool(getattr(be, 'general', False))
+    in_graph_general = False
+    if general and os.environ.get('GNPDE_SHARDED_HOST_EXCHANGES', '0') != '1':
+      buf_bytes = (max(shard.n_local, 1) * d * 4 + 255) // 256 * 256
+      fits = NativeShardedSolver.stats_layout(shard.n_local, int(sum(shard.send_counts)), be.heads)[1] <= buf_bytes
+      votes = [None] * world
+      if world > 1:
+        dist.all_gather_object(votes, bool(fits), group=group)
+      else:
+        votes = [bool(fits)]
+      in_graph_general = all(votes)
+    ctx = None
+    if not general:
+      ctx = P2PContext(shard, d, 4, group=group)
+    elif in_graph_general:
+      ctx = P2PContext(shard, d, 5, group=group)
     ent = dict(edge_index=ei, plan=plan, shard=shard, be=be, ctx=ctx, solvers={}, own_ids=shard.own_old_ids.to(dev))
 
     def close(ent=ent):
@@ -1148,7 +1222,7 @@ def solve_sharded(func, y0, t, method, step_size, use_graph=True, group=None, rt
       x0_own = func.x0.detach()[ent['own_ids']].contiguous()
     z_own = sol.integrate_adaptive(y_own, x0_own, t, rtol, atol, n, method=method, on_eval=func._check_nfe).clone()
     return _gather_full(z_own, y0, plan, shard, world, n, d, dev, group, func, 0)
-  if getattr(be, 'general', False):
+  if getattr(be, 'general', False) and ent['ctx'] is None:
     if sol is None:
       ent['solvers'].clear()
       sol = ShardedSolver(shard, be, group)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition), gnpde_dopri5_set_pair;  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition), gnpde_dopri5_set_pair, gnpde_sharded_solver_set_general;  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -755,7 +755,7 @@ typedef struct gnpde_halo {
  * in each peer's flag array, a one-block wait kernel in front of the boundary pass polls the flags (bounded spin).  No
  * library call and no host involvement per evaluation: the per-rank hipGraph holds kernel and memcpy nodes only.
  * Several ranks may share one device (the processes map each other's memory the same way).
- *   gnpde_p2p_create      allocates n_buffers (4 for rk4, 2 for euler) stage buffers of buffer_bytes >= (n_own + n_halo) * d * 4
+ *   gnpde_p2p_create      allocates n_buffers (4 for rk4, 2 for euler; a fifth for gnpde_sharded_solver_set_general) stage buffers of buffer_bytes >= (n_own + n_halo) * d * 4
  *                         and the flag array (fine-grained memory)
  *   gnpde_p2p_get_handle  -> GNPDE_P2P_HANDLE_BYTES to be all-gathered over the ranks by the host
  *   gnpde_p2p_connect     handles of ALL ranks, [world][GNPDE_P2P_HANDLE_BYTES]; maps the peers' memory */
@@ -830,6 +830,37 @@ int gnpde_sharded_solver_status(gnpde_sharded_solver_t* s, int32_t* timed_out, i
 int gnpde_sharded_solver_set_spin_limit(gnpde_sharded_solver_t* s, int64_t max_spins);
 int gnpde_sharded_solver_num_rhs_evals(const gnpde_sharded_solver_t* s);
 int gnpde_sharded_solver_destroy(gnpde_sharded_solver_t* s);
+
+/* Normalisers that are not row-local over the row partition, inside the per-rank graph  [replaces the Python-driven evaluation that ran
+ * until ABI 6: reference src/function_transformer_attention.py:190-213 with attention_norm_idx = 1 and / or squareplus
+ * (src/utils.py:179-208), src/function_GAT_attention.py with attention_norm_idx = 1].  After this call every evaluation of the solver is:
+ * push of the boundary rows; projection of own + halo rows into qk; pass 1 of gnpde_edge_attention_pass on att_graph (every local node
+ * a segment) [squareplus: the MAXIMUM of the global score maximum over the ranks, one word exchanged through the flag blocks];
+ * pass 2 [normalised over columns: the partial statistics of the halo columns are pushed into their owners' in_part rows, merged
+ * there peer by peer in rank order (the arithmetic of gnpde_segment_stats_merge), and the totals are pushed back with the state's
+ * pattern]; pass 3 into w; the aggregation over spmm_graph (the owned rows) with the solver's stage epilogue.  Every rank issues the
+ * same pushes in the same order, so the one epoch sequence of the transport orders all of them.
+ *   att: type / heads / att_dim / norm_idx / square_plus / leaky_slope / gat_a / output_var / lengthscale / edge_w_csr (att_graph's CSR
+ *        order); q, k, ldqk are filled per evaluation (transformer: q = qk, k = qk + att_dim, ldqk = 2 att_dim; GAT: q = k = qk).
+ *   qk [n_own + n_halo, proj_m], w [entries of att_graph], stats_send [n_halo, 2 heads], the two workspaces: device memory of the caller.
+ *   stats_buffer: index (>= 4) of the shared buffer of gnpde_p2p_create that holds [S: (n_own + n_halo) x 2 heads | in_part: n_send x
+ *        2 heads] on every rank; in_offset / peer_in_offset[p]: byte offset of in_part on this rank / on peer p (multiples of 256);
+ *        peer_buffer_bytes[p] as in gnpde_sharded_solver_create_p2p; peer_rev_row0[p]: row of peer p's in_part where THIS rank's rows
+ *        start (= the send counts of p for the ranks below this one).  Only read when att->norm_idx == 1 and world > 1. */
+typedef struct gnpde_general {
+  const gnpde_graph_t* att_graph;
+  const gnpde_graph_t* spmm_graph;
+  const gnpde_attention_t* att;
+  float* qk; float* w; float* stats_send;
+  void* att_ws; size_t att_ws_bytes;
+  void* spmm_ws; size_t spmm_ws_bytes;
+  int32_t stats_buffer;
+  int64_t in_offset;
+  const int64_t* peer_in_offset;
+  const int64_t* peer_buffer_bytes;
+  const int64_t* peer_rev_row0;
+} gnpde_general_t;
+int gnpde_sharded_solver_set_general(gnpde_sharded_solver_t* s, const gnpde_general_t* g);
 
 /* dopri5 over the row partition with the controller on the device  [replaces, per rank, the Python controller that ran over
  * torch.distributed until ABI 6: reference src/block_constant.py:57-62 with opt['method'] = 'dopri5' on a graph no single GPU holds].

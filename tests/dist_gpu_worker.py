@@ -74,6 +74,30 @@ def main():
     if not same:
       print('rank %d: repeated solve differs: max |d| %g, finite %s / %s' % (rank, float((z1 - z2).abs().max()), bool(torch.isfinite(z1).all()), bool(torch.isfinite(z2).all())), flush=True)
     full = D.gather_rows_all(z1.cpu(), plan, sh)
+    # the same solve with the exchanges between the attention passes INSIDE the per-rank graph (gnpde_sharded_solver_set_general): the
+    # same kernels in the same order, the merges peer by peer in rank order -- eager and as a replayed hipGraph
+    ctx = D.P2PContext(sh, d, 5)
+    native = {}
+    with torch.no_grad():
+      nat = D.NativeShardedSolver(sh, be, T, 1.0, method, ctx=ctx)
+      nat.set_spin_limit(1 << 22)
+      n_eager = nat.integrate(x_own, x_own, use_graph=False).clone()
+      nat.check()
+      n_g1 = nat.integrate(x_own, x_own, use_graph=True).clone()
+      n_g2 = nat.integrate(x_own, x_own, use_graph=True).clone()
+      nat.check()
+    native['native_replay_equal'] = bool(torch.equal(n_g1, n_g2)) and bool(torch.equal(n_eager, n_g1))
+    native['native_vs_loop_bitwise'] = bool(torch.equal(n_g1, z1))
+    native['native_vs_loop'] = float((n_g1 - z1).abs().max() / z1.abs().max())
+    flags = torch.tensor([int(native['native_replay_equal']), int(native['native_vs_loop_bitwise'])])
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    native['native_replay_equal'], native['native_vs_loop_bitwise'] = bool(flags[0]), bool(flags[1])
+    worst = torch.tensor([native['native_vs_loop']], dtype=torch.float64)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    native['native_vs_loop'] = float(worst[0])
+    nfull = D.gather_rows_all(n_g1.cpu(), plan, sh)
+    nat.close()
+    ctx.close()
     if rank == 0:
       rhs = lambda t, y: R.rhs_transformer(y, ei, params['Wq'], params['bq'], params['Wk'], params['bk'], h, alpha, beta,  # noqa: E731
                                            x, False, True, norm_idx=norm_idx, square_plus=square_plus)
@@ -82,8 +106,10 @@ def main():
       ref = R.odeint_fixed(rhs, x, T, 1.0, method)
       e_inf, e_2 = parity(full, ref)
       print('general %s: rel_max %g rel_l2 %g' % (kind, e_inf, e_2), flush=True)
-      json.dump({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
-                 'interior_rows': sh.n_interior, 'own_rows': sh.n_own}, open(out_path, 'w'))
+      n_inf, n_2 = parity(nfull, ref)
+      json.dump(dict({'rel_max': e_inf, 'rel_l2': e_2, 'world': world, 'edge_cut': plan.edge_cut(), 'halo_rows': sh.n_halo,
+                      'interior_rows': sh.n_interior, 'own_rows': sh.n_own, 'native_rel_max': n_inf, 'native_rel_l2': n_2}, **native),
+                open(out_path, 'w'))
     dist.barrier()
     dist.destroy_process_group()
     assert same, 'rank %d: repeated solve differs' % rank

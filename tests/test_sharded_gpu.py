@@ -132,6 +132,9 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
     assert e['rel_max'] < 1e-5 and e['rel_l2'] < 1e-5, (name, e)
     assert e['nfe'] == e['ref_nfe'] and e['replay_equal'] and e['ranks_agree'], (name, e)
     assert e.get('moved', 1.0) > 1e-3, (name, e)       # (self-checks: the solve did something)
+    if name == 'block_constant_transformer_sqp_n1_rk4':
+      # squareplus over columns: the exchanges between the attention passes ride in the per-rank graph (gnpde_sharded_solver_set_general)
+      assert e['solvers'] == ['NativeShardedSolver'], (name, e)
     if name.endswith('_dopri5'):
       # the adaptive blocks take the device controller over the partition (gnpde_dopri5_create_sharded): fewer reads of the
       # controller record than trial steps, none per trial step
@@ -228,6 +231,11 @@ def test_normalisers_that_are_not_row_local(dev, tmp_path, world, kind):
   r = json.load(open(out))
   assert r['world'] == world and r['halo_rows'] > 0
   assert r['rel_max'] < 1e-5 and r['rel_l2'] < 1e-5, r
+  # the same exchanges INSIDE the per-rank graph (gnpde_sharded_solver_set_general: the partial column statistics pushed to their owners,
+  # merged in rank order, pushed back; the squareplus maximum through the flag blocks): eager = replayed graph, and the same kernels in
+  # the same order as the Python-driven loop
+  assert r['native_replay_equal'] and r['native_vs_loop'] < 1e-6, r
+  assert r['native_rel_max'] < 1e-5 and r['native_rel_l2'] < 1e-5, r
 
 
 @pytest.mark.parametrize('kind', ['cosine_sim', 'pearson', 'exp_kernel'])
