@@ -179,6 +179,9 @@ PROTOTYPES = {
   'gnpde_stream_read': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp]),
   'gnpde_quantile_workspace_bytes': (ctypes.c_size_t, []),
   'gnpde_quantile': (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_graph_build_device_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),
+  'gnpde_graph_build_device': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int32] + [c_vp] * 8 + [c_vp, ctypes.c_size_t, c_vp]),
+  'gnpde_graph_build_device_long': (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int32] * 4 + [c_vp] * 8 + [c_vp, ctypes.c_size_t, c_vp]),
   'gnpde_dopri5_workspace_bytes': (ctypes.c_size_t, [c_vp]),
   'gnpde_dopri5_create': (ctypes.c_int, [c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t]),
   'gnpde_dopri5_sharded_workspace_bytes': (ctypes.c_size_t, [c_vp]),

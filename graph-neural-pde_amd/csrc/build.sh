@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I${ROOT}/include -I. -Wall -W
 mkdir -p build
 objs=""
 pids=""
-for f in error.cpp graph_prep.cpp spmm.hip linear.hip attention.hip fused_attn.hip backward.hip adjoint.hip solver.hip misc.hip early_stop.hip sharded.hip rewire.hip twohop.hip dopri5.hip adjoint_adaptive.hip; do
+for f in error.cpp graph_prep.cpp spmm.hip linear.hip attention.hip fused_attn.hip backward.hip adjoint.hip solver.hip misc.hip early_stop.hip sharded.hip rewire.hip twohop.hip dopri5.hip adjoint_adaptive.hip graph_device.hip; do
   o="build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ epilogue.h -nt "$o" ] || [ rhs.h -nt "$o" ] || [ "${ROOT}/include/gnpde.h" -nt "$o" ]; then
     rm -f "$o"

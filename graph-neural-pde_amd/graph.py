@@ -3,6 +3,7 @@
 edge_index tensor into CSR + permutation + CSC view + long-row chunk list by the native host code
 (csrc/graph_prep.cpp) and kept resident in HBM as int32 arrays."""
 import ctypes
+import os
 import numpy as np
 import torch
 
@@ -106,6 +107,45 @@ def build_arrays_on_device(edge_index, n):
   return out, counts
 
 
+_NATIVE_KEYS = ('rowptr', 'colidx', 'perm', 'rowidx', 'cscptr', 'cscpos', 'bin_rows')
+
+
+def build_arrays_native(edge_index, n):
+  """The same arrays and counts as build_arrays_on_device by the library's own device builder (csrc/graph_device.hip: two calls around
+  ONE host read of the counts, instead of ~60 torch launches and half a dozen reads).  Element for element equal
+  (tests/test_kernels_gpu.py::test_native_graph_builder_equals_the_other_two)."""
+  import ctypes
+  L = _lib.lib()
+  dev = edge_index.device
+  e = int(edge_index.shape[1])
+  ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.to(torch.int64).contiguous()
+  i32 = dict(dtype=torch.int32, device=dev)
+  out = {'rowptr': torch.empty(n + 1, **i32), 'cscptr': torch.empty(n + 1, **i32), 'bin_rows': torch.empty(4 * max(n, 1), **i32)}
+  for k in ('colidx', 'perm', 'rowidx', 'cscpos'):
+    out[k] = torch.zeros(max(e, 1), **i32) if e == 0 else torch.empty(e, **i32)
+  counts = torch.empty(16, **i32)
+  ws = torch.empty(max(int(L.gnpde_graph_build_device_workspace_bytes(e, n)), 256), dtype=torch.uint8, device=dev)
+  stream = _lib.stream_of(ei)
+  _lib.check(L.gnpde_graph_build_device(_lib.ptr(ei[0]) if e else None, _lib.ptr(ei[1]) if e else None, e, n, _lib.ptr(out['rowptr']), _lib.ptr(out['colidx']),
+                                        _lib.ptr(out['perm']), _lib.ptr(out['rowidx']), _lib.ptr(out['cscptr']), _lib.ptr(out['cscpos']),
+                                        _lib.ptr(out['bin_rows']), _lib.ptr(counts), _lib.ptr(ws), ws.numel(), stream))
+  c = counts.tolist()                       # the one host read
+  if c[0]:
+    raise _lib.GnpdeError('libgnpde_hip error -1: graph_build: edge index outside [0,%d)' % n)
+  n16, n64, nle, nlr, nlc, nch, max_row, max_col = c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]
+  for k, size in (('long_rows', nlr), ('long_chunk_row', nch), ('long_chunk_begin', nch), ('long_chunk_end', nch), ('long_cols', nlc),
+                  ('long_chunk_first', nch)):
+    out[k] = torch.zeros(max(size, 1), **i32)
+  out['long_chunk_ptr'] = torch.zeros(nlr + 1, **i32)
+  if nlr or nlc:
+    _lib.check(L.gnpde_graph_build_device_long(_lib.ptr(out['rowptr']), _lib.ptr(out['cscptr']), n, nlr, nch, nlc, _lib.ptr(out['long_rows']),
+                                               _lib.ptr(out['long_chunk_ptr']), _lib.ptr(out['long_chunk_row']), _lib.ptr(out['long_chunk_begin']),
+                                               _lib.ptr(out['long_chunk_end']), _lib.ptr(out['long_cols']), _lib.ptr(out['long_chunk_first']),
+                                               _lib.ptr(counts), _lib.ptr(ws), ws.numel(), stream))
+  counts_d = dict(n_long_rows=nlr, n_long_chunks=nch, n_long_cols=nlc, n_bin16=n16, n_bin64=n64, n_bin_le64=nle, max_row_len=max_row, max_col_len=max_col)
+  return out, counts_d
+
+
 class CSRGraph(object):
   """Device-resident CSR view of `edge_index` for a square N x N operator.
 
@@ -173,7 +213,9 @@ class CSRGraph(object):
     self.set_row_range(0, self.n, rowptr=torch.from_numpy(rp))
 
   def _init_on_device(self, edge_index):
-    self.t, c = build_arrays_on_device(edge_index, self.n)
+    # (GNPDE_GRAPH_BUILD=torch: the torch-op builder, kept as the second opinion of the tests)
+    native = os.environ.get('GNPDE_GRAPH_BUILD', 'native') != 'torch' and self.e < 2 ** 31
+    self.t, c = (build_arrays_native if native else build_arrays_on_device)(edge_index, self.n)
     self.n_long_rows, self.n_long_chunks, self.n_long_cols = c['n_long_rows'], c['n_long_chunks'], c['n_long_cols']
     self.n_bin16, self.n_bin64 = c['n_bin16'], c['n_bin64']
     self.n_bin_le64 = c['n_bin_le64']

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition), gnpde_dopri5_set_pair, gnpde_sharded_solver_set_general;  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
+#define GNPDE_ABI_VERSION 7   /* 7: gnpde_dopri5_create_sharded (device controller over the row partition), gnpde_dopri5_set_pair, gnpde_sharded_solver_set_general, gnpde_graph_build_device;  6: gnpde_adjoint_set_tape takes csr_from_t, gnpde_adjoint_tape_swapped, gnpde_linear_split;  5: gnpde_solver_set_tape / gnpde_adjoint_set_tape (recorded fixed-grid solve);  4: gnpde_dopri5_set_tape / _tape_backward, gnpde_adjoint_adaptive_*, GNPDE_METHOD_MIDPOINT;  2: gnpde_graph_t.xcd_deal appended, gnpde_xcd_row_map; 3: gnpde_attention_t.graph_t / t_from_csr appended,
                                  gnpde_adjoint_*, gnpde_stream_read; gnpde_graph_t.n_bin_le64 and gnpde_attention_t.n_key_rows in what was
                                  padding (struct sizes unchanged) */
 
@@ -78,6 +78,26 @@ int gnpde_graph_build(const int64_t* row, const int64_t* col, int64_t n_edges, i
                       int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* long_chunk_row,
                       int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols,
                       int32_t* bin_rows, int32_t* bin_counts, int32_t* long_chunk_first);
+
+/* The same arrays built ON THE DEVICE from an edge list that already lives there (blocks that hand over a new edge set every training
+ * forward: reference src/block_transformer_hard_attention.py:55-61, src/block_transformer_rewiring.py), element for element what
+ * gnpde_graph_build gives.  Two calls around ONE host read:
+ *   gnpde_graph_build_device       row / col: device int64 [E]; fills rowptr[n+1], colidx / perm / rowidx / cscpos [E], cscptr[n+1],
+ *                                  bin_rows[4n] and counts[16] (device): [0] != 0: an index outside [0, n); [1] rows with 1..16 entries,
+ *                                  [2] with 17..GNPDE_LONG_ROW, [3] of those with <= 64, [4] long rows, [5] long columns, [6] 512-entry
+ *                                  chunks of the long rows, [7] / [8] longest row / column.
+ *   gnpde_graph_build_device_long  (after the caller read counts and allocated the lists) long_rows[n_long_rows],
+ *                                  long_chunk_ptr[n_long_rows+1], long_chunk_row / begin / end / first[n_long_chunks],
+ *                                  long_cols[n_long_cols]; scratch_count: one device word.
+ * Workspace: gnpde_graph_build_device_workspace_bytes(E, n) device bytes, 256-byte aligned, the same block for both calls. */
+size_t gnpde_graph_build_device_workspace_bytes(int64_t n_edges, int32_t n_nodes);
+int gnpde_graph_build_device(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n_nodes, int32_t* rowptr, int32_t* colidx,
+                             int32_t* perm, int32_t* rowidx, int32_t* cscptr, int32_t* cscpos, int32_t* bin_rows, int32_t* counts,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int gnpde_graph_build_device_long(const int32_t* rowptr, const int32_t* cscptr, int32_t n_nodes, int32_t n_long_rows, int32_t n_long_chunks,
+                                  int32_t n_long_cols, int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* long_chunk_row,
+                                  int32_t* long_chunk_begin, int32_t* long_chunk_end, int32_t* long_cols, int32_t* long_chunk_first,
+                                  int32_t* scratch_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Balanced k-way row partition for the multi-GPU path (no METIS offline; no reference equivalent): size-capped
  * label-propagation clusters packed into parts, then node-level refinement under the balance constraint.  The parts are

@@ -360,3 +360,51 @@ def test_cosine_fused_path_agrees_with_the_generic_score_kernels_near_zero_norms
     f_generic = ops.spmm_rhs(graph, w, xd, func.alpha_train, func.beta_train, xd, True)
   assert torch.isfinite(f_fused).all() and torch.isfinite(att).all()
   assert_parity(f_fused, f_generic, 1e-5, '%s norm_idx %d squareplus %s' % (att_type, norm_idx, square_plus))
+
+
+@pytest.mark.parametrize('case', ['hubs', 'uniform', 'duplicates', 'isolated', 'empty', 'one_node', 'directed'])
+def test_native_graph_builder_equals_the_other_two(dev, case):
+  """The arrays of gnpde_graph_t three ways: the host builder (csrc/graph_prep.cpp, edge list on the CPU), the torch-op builder on
+  the device (graph.build_arrays_on_device) and the library's device builder (csrc/graph_device.hip, what a device edge list gets
+  since round 6: blocks that hand over a new edge set every training forward).  Element for element equal: stable orders, the row
+  records by class (longest first in the second class, ties in row order), long rows / columns and their chunks, every count."""
+  from gnpde_amd import graph as GR
+  g = torch.Generator().manual_seed(5)
+  if case == 'hubs':
+    n = 3000
+    ei = random_graph(n, 6, seed=3, hubs=3, hub_deg=1400)
+  elif case == 'uniform':
+    n = 5000
+    ei = random_graph(n, 20, seed=4)
+  elif case == 'duplicates':
+    n = 400
+    ei = torch.randint(0, n, (2, 9000), generator=g)
+    ei = torch.cat([ei, ei[:, :3000]], dim=1)                      # repeated entries keep their relative order
+  elif case == 'isolated':
+    n = 1000
+    ei = torch.randint(0, 300, (2, 5000), generator=g)             # rows / columns 300.. have no entries
+    ei[0, :700] = 7                                                # one long row ...
+    ei[1, 700:1500] = 11                                           # ... and one long column
+  elif case == 'empty':
+    n, ei = 17, torch.zeros(2, 0, dtype=torch.int64)
+  elif case == 'one_node':
+    n, ei = 1, torch.zeros(2, 5, dtype=torch.int64)
+  else:
+    n = 2000
+    ei = torch.stack([torch.randint(0, n, (30000,), generator=g), torch.randint(0, 50, (30000,), generator=g)])   # 50 long columns, no long row
+  host = GR.CSRGraph(ei, n, device=dev)                            # CPU edge list: the host builder
+  t_torch, c_torch = GR.build_arrays_on_device(ei.to(dev), n)
+  t_nat, c_nat = GR.build_arrays_native(ei.to(dev), n)
+  assert c_nat == c_torch, (c_nat, c_torch)
+  assert (host.n_long_rows, host.n_long_chunks, host.n_long_cols, host.n_bin16, host.n_bin64, host.n_bin_le64, host.max_row_len, host.max_col_len) == \
+         tuple(c_nat[k] for k in ('n_long_rows', 'n_long_chunks', 'n_long_cols', 'n_bin16', 'n_bin64', 'n_bin_le64', 'max_row_len', 'max_col_len'))
+  assert set(t_nat) == set(t_torch) == set(host.t)
+  for k in t_torch:
+    a, b, c = t_nat[k].cpu(), t_torch[k].cpu(), host.t[k].cpu()
+    assert a.dtype == torch.int32 and a.shape == b.shape == c.shape, (k, a.shape, b.shape, c.shape)
+    assert torch.equal(a, b), 'native vs torch builder: %s' % k
+    assert torch.equal(a, c), 'native vs host builder: %s' % k
+  with pytest.raises(G._lib.GnpdeError):
+    bad = torch.tensor([[0, n], [0, 0]], dtype=torch.int64, device=dev)
+    GR.build_arrays_native(bad, n)
+
