@@ -1010,6 +1010,32 @@ void launch_rows_sd_mode(const AttArgs& a_in, int n16, int n64, hipStream_t s, i
   constexpr int PB64 = (DK4 == 1) ? 4 : 2;
   // launch 1: hub phase 0 + rows with <= 16 entries; launch 2: hub phase 1 + rows with 17..512 entries (the maximum sweep of
   // squareplus, MODE 2, has no hub phase 1)
+  if constexpr (H == 4 && (DK4 == 1 || DK4 == 4) && MODE == 0 && !SCATTER) {
+    // Rows of <= 16 entries on a QUARTER of a wave each (round 6): 16 lanes = 4 entries x 4 heads per pass, four passes, two rows
+    // interleaved per group -- 8 rows per wave instead of 4 on whole waves, where a median row of 8 entries left half of the lanes without
+    // an entry.  Measured at the ogbn-arxiv shape: row attention 41.2 -> 37.3 us per evaluation (1074 -> 1089 steps/s at T = 100), R-MAT
+    // (d_k = 16) 4.48 -> 3.98 ms; the other packings tried (gnpde_tune(17, v): 1 / 2 half a wave x 2 passes with 8 / 4 rows per wave: 38.2;
+    // 3: a quarter with 16 rows per wave: 40.4; 5: half with 16 rows: 43.0; 6: a quarter with 4 rows: 37.3; 7 / 8: an eighth x 8 passes:
+    // 40.4 / 37.2) and the whole-wave form (9) stay behind the knob.
+    int v = g_tune[GNPDE_TUNE_ATT_ROWS16];
+    if (v == 0) v = 4;
+    if (v >= 1 && v <= 8 && (n16 > 0 || n_hub > 0)) {
+      const int rows_per_wave[9] = {0, 8, 4, 16, 8, 16, 4, 16, 8};
+      const long long rpb = rows_per_wave[v] * kWavesPerBlock;
+      const unsigned grid = static_cast<unsigned>((n16 + rpb - 1) / rpb) + n_hub;
+      if (v == 1) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 4, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 2) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 2, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 3) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 4, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 4) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 2, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 5) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 8, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 6) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 1, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else if (v == 7) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 8, 2, 8, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      else hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 8, 1, 8, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
+      n16 = -n16;      // (done: skip the default launch below)
+    }
+  }
+  if (n16 < 0) n16 = -n16;
+  else
   if (n16 > 0 || n_hub > 0) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
     static_assert(RPW16 * RI16 * kWavesPerBlock == sd_rows_per_block16(H, DK4), "sd_sweep_waves counts this launch's waves");
