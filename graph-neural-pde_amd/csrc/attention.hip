@@ -986,10 +986,12 @@ void launch_scores_any(const AttArgs& a, bool vec4, unsigned grid, hipStream_t s
 }
 
 // rows per workgroup of the <= 16-entry class of row_attention_sd_kernel (launch_rows_sd_mode's first launch)
+// (4 heads, d_k 4 or 16: a QUARTER of a wave per row, see launch_rows_sd_mode)
+constexpr bool sd_quarter_rows(int h, int dk4) { return h == 4 && (dk4 == 1 || dk4 == 4); }
 constexpr int sd_rows_per_block16(int h, int dk4) {
-  const int gl16 = (16 * h < kWave) ? 16 * h : kWave;
+  const int gl16 = sd_quarter_rows(h, dk4) ? 16 : ((16 * h < kWave) ? 16 * h : kWave);
   const int p16 = (16 * h + gl16 - 1) / gl16;
-  const int ri16 = (dk4 == 1 && p16 == 1) ? 4 : (p16 == 1 ? 2 : 1);
+  const int ri16 = sd_quarter_rows(h, dk4) ? 2 : ((dk4 == 1 && p16 == 1) ? 4 : (p16 == 1 ? 2 : 1));
   return (kWave / gl16) * ri16 * kWavesPerBlock;
 }
 // waves of the two launches of a sweep without hub blocks: [0] the <= 16-entry class, [1] the others (AttArgs::gmax_part)
@@ -1002,41 +1004,33 @@ inline void sd_sweep_waves(int h, int dk4, int n16, int n64, long long (&w)[2]) 
 template <int H, int DK4, int MODE, bool SCATTER>
 void launch_rows_sd_mode(const AttArgs& a_in, int n16, int n64, hipStream_t s, int n_hub, float* part, const int* chunk_first) {
   AttArgs a = a_in;
-  constexpr int GL16 = (16 * H < kWave) ? 16 * H : kWave;   // lanes per row for rows with <= 16 entries
+  // Rows of <= 16 entries.  4 heads (round 6): a QUARTER of a wave per row -- 16 lanes = 4 entries x 4 heads per pass, four passes, two
+  // rows interleaved per group: 8 rows per wave instead of 4 on whole waves, where a median row of 8 entries left half of the lanes without
+  // an entry.  Measured at the ogbn-arxiv shape: row attention 41.2 -> 37.3 us per evaluation (1074 -> 1089 steps/s at T = 100), R-MAT
+  // (d_k = 16) 4.48 -> 3.98 ms; the other packings tried on the row softmax (half a wave x 2 passes with 8 / 4 rows per wave: 38.2; a quarter
+  // with 16 rows per wave: 40.4, with 4: 37.3; half with 16 rows: 43.0; an eighth x 8 passes with 16 / 8 rows: 40.4 / 37.2) are in DESIGN.md,
+  // the whole-wave form stays behind gnpde_tune(17, 9) for the row softmax (A/B).  Other head counts: 16 H lanes (at most a wave) per row.
+  constexpr bool QUARTER = sd_quarter_rows(H, DK4);
+  constexpr int GL16 = QUARTER ? 16 : ((16 * H < kWave) ? 16 * H : kWave);   // lanes per row for rows with <= 16 entries
   constexpr int P16 = (16 * H + GL16 - 1) / GL16;           // passes to cover 16 entries
   constexpr int RPW16 = kWave / GL16;
-  constexpr int RI16 = (DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1);  // rows interleaved per group
+  constexpr int RI16 = QUARTER ? 2 : ((DK4 == 1 && P16 == 1) ? 4 : (P16 == 1 ? 2 : 1));  // rows interleaved per group
   constexpr int P64 = GNPDE_LONG_ROW / (kWave / H);         // passes to cover GNPDE_LONG_ROW entries
   constexpr int PB64 = (DK4 == 1) ? 4 : 2;
   // launch 1: hub phase 0 + rows with <= 16 entries; launch 2: hub phase 1 + rows with 17..512 entries (the maximum sweep of
   // squareplus, MODE 2, has no hub phase 1)
-  if constexpr (H == 4 && (DK4 == 1 || DK4 == 4) && MODE == 0 && !SCATTER) {
-    // Rows of <= 16 entries on a QUARTER of a wave each (round 6): 16 lanes = 4 entries x 4 heads per pass, four passes, two rows
-    // interleaved per group -- 8 rows per wave instead of 4 on whole waves, where a median row of 8 entries left half of the lanes without
-    // an entry.  Measured at the ogbn-arxiv shape: row attention 41.2 -> 37.3 us per evaluation (1074 -> 1089 steps/s at T = 100), R-MAT
-    // (d_k = 16) 4.48 -> 3.98 ms; the other packings tried (gnpde_tune(17, v): 1 / 2 half a wave x 2 passes with 8 / 4 rows per wave: 38.2;
-    // 3: a quarter with 16 rows per wave: 40.4; 5: half with 16 rows: 43.0; 6: a quarter with 4 rows: 37.3; 7 / 8: an eighth x 8 passes:
-    // 40.4 / 37.2) and the whole-wave form (9) stay behind the knob.
-    int v = g_tune[GNPDE_TUNE_ATT_ROWS16];
-    if (v == 0) v = 4;
-    if (v >= 1 && v <= 8 && (n16 > 0 || n_hub > 0)) {
-      const int rows_per_wave[9] = {0, 8, 4, 16, 8, 16, 4, 16, 8};
-      const long long rpb = rows_per_wave[v] * kWavesPerBlock;
+  bool first_done = false;
+  if constexpr (QUARTER && MODE == 0 && !SCATTER) {
+    if (g_tune[GNPDE_TUNE_ATT_ROWS16] == 9 && (n16 > 0 || n_hub > 0)) {      // A/B: a whole wave per row, four rows interleaved (until round 6)
+      constexpr int RIW = DK4 == 1 ? 4 : 2;
+      const long long rpb = static_cast<long long>(RIW) * kWavesPerBlock;
       const unsigned grid = static_cast<unsigned>((n16 + rpb - 1) / rpb) + n_hub;
-      if (v == 1) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 4, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 2) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 2, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 3) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 4, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 4) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 2, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 5) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 32, 8, 2, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 6) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 16, 1, 4, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else if (v == 7) hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 8, 2, 8, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      else hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, 8, 1, 8, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part, chunk_first);
-      n16 = -n16;      // (done: skip the default launch below)
+      hipLaunchKernelGGL((row_attention_sd_kernel<H, DK4, kWave, RIW, 1, 1, MODE, SCATTER>), dim3(grid), dim3(kBlock), 0, s, a, 0, n16, n_hub, 0, part,
+                         chunk_first);
+      first_done = true;
     }
   }
-  if (n16 < 0) n16 = -n16;
-  else
-  if (n16 > 0 || n_hub > 0) {
+  if (!first_done && (n16 > 0 || n_hub > 0)) {
     const long long rows_per_block = static_cast<long long>(RPW16) * RI16 * kWavesPerBlock;
     static_assert(RPW16 * RI16 * kWavesPerBlock == sd_rows_per_block16(H, DK4), "sd_sweep_waves counts this launch's waves");
     const unsigned grid = static_cast<unsigned>((n16 + rows_per_block - 1) / rows_per_block) + n_hub;

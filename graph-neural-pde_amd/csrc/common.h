@@ -108,7 +108,7 @@ enum {
   GNPDE_TUNE_KEY_TABLE = 14,           // 1: keep q||k interleaved [n, 2A] where the solver would write two tables (A/B)
   GNPDE_TUNE_LINEAR_DIAG = 13,         // A/B diagnostics of the staged projection kernel (1: no stores, 2: loads alone); never set in production
   GNPDE_TUNE_GMAX_SMALL = 16,          // 1: squareplus on a small grid keeps the slot atomics + memset + fold launch (A/B against the per-wave maxima folded by the second sweep)
-  GNPDE_TUNE_ATT_ROWS16 = 17,          // packing of the rows of <= 16 entries in the scaled-dot row kernel (4 heads): 0 = 4: a quarter wave per row, 4 passes, 8 rows per wave (default); 1..8: other packings; 9: a whole wave per row (until round 6)
+  GNPDE_TUNE_ATT_ROWS16 = 17,          // 9: the row softmax of the scaled-dot row kernel (4 heads) keeps a whole wave per row of <= 16 entries (A/B against the quarter-wave packing)
   GNPDE_TUNE_COUNT = 18
 };
 extern int g_tune[GNPDE_TUNE_COUNT];
