@@ -25,20 +25,25 @@ constexpr int kKeyNone = 1000;      // sort key of the rows that are not listed 
 
 __global__ __launch_bounds__(kBlock) void gd_convert_kernel(const long long* __restrict__ row, const long long* __restrict__ col, long long e, int n,
                                                            int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ iota,
-                                                           int* __restrict__ deg, int* __restrict__ cdeg, int* __restrict__ counts) {
+                                                           int* __restrict__ counts) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= e) return;
   const long long r = row[i], c = col[i];
-  if (r < 0 || r >= n || c < 0 || c >= n) {
-    atomicOr(counts + C_ERR, 1);
-    row32[i] = 0; col32[i] = 0; iota[i] = static_cast<int>(i);
-    return;
-  }
-  row32[i] = static_cast<int>(r);
-  col32[i] = static_cast<int>(c);
+  const bool bad = r < 0 || r >= n || c < 0 || c >= n;
+  if (bad) atomicOr(counts + C_ERR, 1);
+  row32[i] = bad ? 0 : static_cast<int>(r);
+  col32[i] = bad ? 0 : static_cast<int>(c);
   iota[i] = static_cast<int>(i);
-  atomicAdd(deg + r, 1);
-  atomicAdd(cdeg + c, 1);
+}
+
+// segment pointers from SORTED keys, no atomics (a hub row of 10^5 entries would serialise 10^5 atomic adds on one counter): position p
+// writes ptr[r] = p for every r in (key[p - 1], key[p]] -- the first position of key[p] and of the empty segments in front of it
+__global__ __launch_bounds__(kBlock) void gd_ptr_kernel(const int* __restrict__ sorted, long long e, int n, int* __restrict__ ptr) {
+  const long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p > e) return;
+  const int prev = p > 0 ? sorted[p - 1] : -1;
+  const int cur = p < e ? sorted[p] : n;
+  for (int r = prev + 1; r <= cur; ++r) ptr[r] = static_cast<int>(p);
 }
 
 __global__ __launch_bounds__(kBlock) void gd_gather_kernel(const int* __restrict__ src, const int* __restrict__ idx, long long e, int* __restrict__ out) {
@@ -46,12 +51,12 @@ __global__ __launch_bounds__(kBlock) void gd_gather_kernel(const int* __restrict
   if (i < e) out[i] = src[idx[i]];
 }
 
-__global__ __launch_bounds__(kBlock) void gd_classify_kernel(const int* __restrict__ deg, const int* __restrict__ cdeg, int n, int* __restrict__ keys,
+__global__ __launch_bounds__(kBlock) void gd_classify_kernel(const int* __restrict__ rowptr, const int* __restrict__ cscptr, int n, int* __restrict__ keys,
                                                             int* __restrict__ rows, int* __restrict__ counts) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   int n16 = 0, n64 = 0, nle = 0, nlr = 0, nlc = 0, nch = 0, mr = 0, mc = 0;
   if (r < n) {
-    const int d = deg[r], cd = cdeg[r];
+    const int d = rowptr[r + 1] - rowptr[r], cd = cscptr[r + 1] - cscptr[r];
     int key = kKeyNone;
     if (d >= 1 && d <= 16) { key = 0; n16 = 1; }
     else if (d > 16 && d <= GNPDE_LONG_ROW) { key = 1 + (GNPDE_LONG_ROW - d); n64 = 1; nle = d <= 64 ? 1 : 0; }
@@ -173,38 +178,35 @@ extern "C" int gnpde_graph_build_device(const int64_t* row, const int64_t* col, 
   char* ws = static_cast<char*>(workspace);
   int* row32 = reinterpret_cast<int*>(ws + L.row32); int* col32 = reinterpret_cast<int*>(ws + L.col32);
   int* iota = reinterpret_cast<int*>(ws + L.iota); int* keys_tmp = reinterpret_cast<int*>(ws + L.keys_tmp);
-  int* deg = reinterpret_cast<int*>(ws + L.deg); int* cdeg = reinterpret_cast<int*>(ws + L.cdeg);
   int* rkeys = reinterpret_cast<int*>(ws + L.rkeys); int* rkeys_out = reinterpret_cast<int*>(ws + L.rkeys_out);
   int* rows = reinterpret_cast<int*>(ws + L.rows); int* listed = reinterpret_cast<int*>(ws + L.listed);
   void* temp = ws + L.temp;
   size_t tb = L.temp_bytes;
   GNPDE_HIP(hipMemsetAsync(counts, 0, kCountWords * 4, st));
-  GNPDE_HIP(hipMemsetAsync(deg, 0, (static_cast<size_t>(n) + 1) * 4, st));
-  GNPDE_HIP(hipMemsetAsync(cdeg, 0, (static_cast<size_t>(n) + 1) * 4, st));
   auto grid = [](long long items) { return dim3(static_cast<unsigned>(items > 0 ? (items + kBlock - 1) / kBlock : 1)); };
   if (e > 0) {
     hipLaunchKernelGGL(gd_convert_kernel, grid(e), dim3(kBlock), 0, st, reinterpret_cast<const long long*>(row), reinterpret_cast<const long long*>(col),
-                       static_cast<long long>(e), n, row32, col32, iota, deg, cdeg, counts);
+                       static_cast<long long>(e), n, row32, col32, iota, counts);
     GNPDE_LAUNCH_CHECK();
-  }
-  // rowptr / cscptr: exclusive scans over n + 1 counts (the last one 0): element n is the total
-  tb = L.temp_bytes;
-  GNPDE_HIP(rocprim::exclusive_scan(temp, tb, deg, rowptr, 0, static_cast<size_t>(n) + 1, rocprim::plus<int>(), st));
-  tb = L.temp_bytes;
-  GNPDE_HIP(rocprim::exclusive_scan(temp, tb, cdeg, cscptr, 0, static_cast<size_t>(n) + 1, rocprim::plus<int>(), st));
-  if (e > 0) {
     const int bits = bits_for(n);
-    // CSR order: the stable sort of the edge list by row (radix sort is stable)
+    // CSR order: the stable sort of the edge list by row (radix sort is stable); the row pointers from the sorted rows
     tb = L.temp_bytes;
     GNPDE_HIP(rocprim::radix_sort_pairs(temp, tb, row32, rowidx, iota, perm, static_cast<size_t>(e), 0, bits, st));
+    hipLaunchKernelGGL(gd_ptr_kernel, grid(e + 1), dim3(kBlock), 0, st, rowidx, static_cast<long long>(e), n, rowptr);
+    GNPDE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gd_gather_kernel, grid(e), dim3(kBlock), 0, st, col32, perm, static_cast<long long>(e), colidx);
     GNPDE_LAUNCH_CHECK();
-    // CSC positions: the stable sort of the CSR positions by column
+    // CSC positions: the stable sort of the CSR positions by column; the column pointers from the sorted columns
     tb = L.temp_bytes;
     GNPDE_HIP(rocprim::radix_sort_pairs(temp, tb, colidx, keys_tmp, iota, cscpos, static_cast<size_t>(e), 0, bits, st));
+    hipLaunchKernelGGL(gd_ptr_kernel, grid(e + 1), dim3(kBlock), 0, st, keys_tmp, static_cast<long long>(e), n, cscptr);
+    GNPDE_LAUNCH_CHECK();
+  } else {
+    GNPDE_HIP(hipMemsetAsync(rowptr, 0, (static_cast<size_t>(n) + 1) * 4, st));
+    GNPDE_HIP(hipMemsetAsync(cscptr, 0, (static_cast<size_t>(n) + 1) * 4, st));
   }
   if (n > 0) {
-    hipLaunchKernelGGL(gd_classify_kernel, grid(n), dim3(kBlock), 0, st, deg, cdeg, n, rkeys, rows, counts);
+    hipLaunchKernelGGL(gd_classify_kernel, grid(n), dim3(kBlock), 0, st, rowptr, cscptr, n, rkeys, rows, counts);
     GNPDE_LAUNCH_CHECK();
     tb = L.temp_bytes;
     GNPDE_HIP(rocprim::radix_sort_pairs(temp, tb, rkeys, rkeys_out, rows, listed, static_cast<size_t>(n), 0, 10, st));
