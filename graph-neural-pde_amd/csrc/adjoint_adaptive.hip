@@ -505,11 +505,17 @@ int enqueue_eval(gnpde_adjoint_adaptive* s, const float* uy, const float* ua, fl
   eb.stage = GNPDE_STAGE_LINCOMB;
   eb.out_k = v_out;
   if (n_prev >= 0) {
-    e.y = y; e.out_y = dst_y; e.n_prev = n_prev; e.coef_scale = h;
-    eb.y = a; eb.out_y = dst_a; eb.n_prev = n_prev; eb.coef_scale = h;
-    for (int j = 0; j < n_prev; ++j) { e.prev[j] = pf[j]; e.coef[j] = -w[j]; eb.prev[j] = pv[j]; eb.coef[j] = w[j]; }
-    e.coef[n_prev] = -w[n_prev];
-    eb.coef[n_prev] = w[n_prev];
+    // (earlier derivatives with a zero weight -- the second stage in Dormand-Prince's solution row -- are not streamed)
+    int np = 0;
+    for (int j = 0; j < n_prev; ++j) {
+      if (w[j] == 0.0f) continue;
+      e.prev[np] = pf[j]; e.coef[np] = -w[j]; eb.prev[np] = pv[j]; eb.coef[np] = w[j];
+      ++np;
+    }
+    e.y = y; e.out_y = dst_y; e.n_prev = np; e.coef_scale = h;
+    eb.y = a; eb.out_y = dst_a; eb.n_prev = np; eb.coef_scale = h;
+    e.coef[np] = -w[n_prev];
+    eb.coef[np] = w[n_prev];
   }
   float* dots = s->dots + 2 * static_cast<size_t>(s->slots) * dots_region;
   if (int rc = launch_adjoint_rows(&s->graph, r.w_csr, uy, ua, r.d, r.ld, &e, s->r_dummy, dots, s->part_bytes ? s->ws + s->off_part : nullptr,

@@ -449,9 +449,17 @@ int enqueue_trial(gnpde_dopri5* s, int parity, hipStream_t st) {
     e.y = y;
     e.out_k = k[i];
     e.out_y = i == 5 ? y1 : ui[i];
-    e.n_prev = i;
-    for (int j = 0; j < i; ++j) e.prev[j] = k[j];
-    for (int j = 0; j <= i; ++j) e.coef[j] = static_cast<float>(kB[i][j]);
+    // (earlier derivatives with a zero weight -- k1 in the solution row -- are not streamed: fma(k, 0, o) = o for every finite k)
+    int np = 0;
+    for (int j = 0; j < i; ++j) {
+      const float c = static_cast<float>(kB[i][j]);
+      if (c == 0.0f) continue;
+      e.prev[np] = k[j];
+      e.coef[np] = c;
+      ++np;
+    }
+    e.n_prev = np;
+    e.coef[np] = static_cast<float>(kB[i][i]);
     e.coef_scale = h;
     if (int rc = enqueue_f(s, ui[i - 1], e, st)) return rc;
   }
