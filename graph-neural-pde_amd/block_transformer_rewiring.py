@@ -113,7 +113,10 @@ class RewireAttODEblock(ODEblock):
         threshold = ops.quantile(_device_f32(self.odefunc.edge_weight, 'rewiring quantile'), q)   # radix select, same float32 rank arithmetic as torch.quantile
         self.threshold_edges(x, threshold)
     self.odefunc.edge_index = self.data_edge_index
-    mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)
+    if not torch.is_grad_enabled() and self.opt['function'] not in {'GAT', 'transformer'}:
+      mean_att = self.multihead_att_layer.mean_attention(x, self.data_edge_index)     # (evaluation: the head mean alone, fused row kernels)
+    else:
+      mean_att = self.get_attention_weights(x).mean(dim=1, keepdim=False)
     self.odefunc.edge_weight = mean_att
     self.odefunc.attention_weights = mean_att
     self.reg_odefunc.odefunc.edge_index, self.reg_odefunc.odefunc.edge_weight = self.odefunc.edge_index, self.odefunc.edge_weight

@@ -187,6 +187,24 @@ class SpGraphTransAttentionLayer(nn.Module):
       v = v.view(-1, self.h, self.d_k).transpose(1, 2)
     return att, (v, prods)
 
+  def mean_attention(self, x, edge):
+    """forward(x, edge)[0].mean(dim=1) for callers without autograd that want nothing else (the attention / hard-attention / rewiring
+    blocks in evaluation mode, reference src/block_transformer_attention.py:36-40, src/block_transformer_rewiring.py:232-236): the head
+    mean comes straight out of the fused row kernels (no [E,h] attention and products, no generic three-pass path), then goes from the
+    CSR order to the order of `edge`."""
+    _lib.require_hip(x, edge)
+    with torch.no_grad():
+      xc = _lib.f32c(x)
+      graph = graph_of(edge, xc.shape[0], xc.device)
+      wqk, bqk = self.qk_weights()
+      qk = ops.linear(xc, wqk, bqk)
+      A = self.kernel_att_dim
+      st, keep = self.attention_struct(graph, q=qk, k=qk[:, A:], ldqk=2 * A)
+      w_csr, _, _ = ops.edge_attention(graph, st, want_w_mean=True, want_att=False, want_prods=False, like=xc)
+      out = torch.empty(graph.e, dtype=torch.float32, device=xc.device)
+      out[graph.perm_long] = w_csr[:graph.e]
+    return out
+
   def __repr__(self):
     return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
 
