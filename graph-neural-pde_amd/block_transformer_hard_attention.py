@@ -48,6 +48,15 @@ class HardAttODEblock(ODEblock):
       self.data_edge_index, score, thr, self.opt['attention_norm_idx'], self.num_nodes)
 
   def forward(self, x):
+    if not self.training and not torch.is_grad_enabled() and self._own_layer:
+      # evaluation: every edge carries the diffusion with the head-mean attention -- straight out of the fused row kernels
+      # (SpGraphTransAttentionLayer.mean_attention) instead of [E,h] attention and products that are only averaged
+      self.odefunc.edge_index = self.data_edge_index
+      self.odefunc.attention_weights = self.multihead_att_layer.mean_attention(x, self.data_edge_index)
+      twin = self.reg_odefunc.odefunc
+      twin.edge_index, twin.edge_weight, twin.attention_weights = (self.odefunc.edge_index, self.odefunc.edge_weight,
+                                                                   self.odefunc.attention_weights)
+      return self._integrate(x, {'step_size': self.opt['step_size']})
     attention = self.get_attention_weights(x)
     if self.training:
       with torch.no_grad():
