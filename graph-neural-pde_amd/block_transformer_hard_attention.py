@@ -57,11 +57,14 @@ class HardAttODEblock(ODEblock):
       twin.edge_index, twin.edge_weight, twin.attention_weights = (self.odefunc.edge_index, self.odefunc.edge_weight,
                                                                    self.odefunc.attention_weights)
       return self._integrate(x, {'step_size': self.opt['step_size']})
-    attention = self.get_attention_weights(x)
     if self.training:
+      # (the reference forms the attention with autograd history and then uses it under no_grad only, src/block_transformer_hard_
+      #  attention.py:48-66: no gradient reaches the layer either way; formed without the history it is the same values, bit for bit)
       with torch.no_grad():
+        attention = self.get_attention_weights(x)
         self._sample_edges(x, attention)
     else:
+      attention = self.get_attention_weights(x)
       self.odefunc.edge_index = self.data_edge_index
       self.odefunc.attention_weights = attention.mean(dim=1)
     twin = self.reg_odefunc.odefunc
