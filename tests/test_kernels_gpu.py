@@ -408,3 +408,26 @@ def test_native_graph_builder_equals_the_other_two(dev, case):
     bad = torch.tensor([[0, n], [0, 0]], dtype=torch.int64, device=dev)
     GR.build_arrays_native(bad, n)
 
+
+@pytest.mark.parametrize('att_type,beltrami,norm_idx,sqp', [('scaled_dot', False, 0, False), ('cosine_sim', False, 0, False), ('exp_kernel', False, 0, False),
+                                                            ('exp_kernel', True, 0, False), ('scaled_dot', False, 1, True)])
+def test_layer_mean_attention_is_the_head_mean_of_the_layer(dev, att_type, beltrami, norm_idx, sqp):
+  """SpGraphTransAttentionLayer.mean_attention (what the hard-attention and rewiring blocks take in evaluation mode: the head mean straight
+  out of the fused row kernels, in the order of the edge list) against forward(x, edge)[0].mean(dim=1) (the [E,h] attention of the
+  generic passes, which the reference-recorded layer fixtures pin) -- incl. BLEND's split feature x positional kernel and hub rows."""
+  n, d, h, A = 1500, 32, 4, 16
+  ei = random_graph(n, 7, seed=9, hubs=2, hub_deg=700, isolated=2, dup=10).to(dev)
+  g = torch.Generator().manual_seed(10)
+  x = (torch.randn(n, d, generator=g) * 0.5).to(dev)
+  opt = dict(heads=h, attention_dim=A, attention_type=att_type, attention_norm_idx=norm_idx, square_plus=sqp, reweight_attention=False,
+             beltrami=beltrami, feat_hidden_dim=20, pos_enc_hidden_dim=12, leaky_relu_slope=0.2, hidden_dim=d, mix_features=False)
+  layer = G.SpGraphTransAttentionLayer(d, d, opt, dev).to(dev)
+  with torch.no_grad():
+    for p in layer.parameters():
+      if p.dim() >= 2:
+        p.copy_((torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5).to(dev))
+    att, _ = layer(x, ei)
+    w = layer.mean_attention(x, ei)
+  assert w.shape == (ei.shape[1],) and torch.isfinite(w).all()
+  assert_parity(w, att.mean(dim=1), tol=1e-5, what='mean_attention vs the head mean of the layer (%s)' % att_type)
+
