@@ -27,12 +27,16 @@ def main():
   torch.cuda.set_device(dev)
   res = {}
   for name in names:
-    if name.startswith('selfcheck:') or name.startswith('selfcheck_rw:'):
+    if name.startswith('selfcheck:') or name.startswith('selfcheck_rw:') or name.startswith('selfcheck_dopri5:'):
       # a FUNCTION fixture (reference parameters, state and graph) integrated by the constant block: the partitioned solve against the
       # unpartitioned solve of this package (which the reference-recorded fixtures pin) -- for functions without a recorded block solve
       fx = Fixture(name.split(':', 1)[1])
       x = fx.t('x', dev)
       opt = dict(fx.opt, block='constant', method='rk4', time=2.3, step_size=1.0)
+      if name.startswith('selfcheck_dopri5:'):
+        # an adaptive solve of a function whose normaliser is NOT row-local: the device controller over the exchange engine in its
+        # general mode (gnpde_dopri5_create_sharded over gnpde_sharded_solver_set_general)
+        opt.update(method='dopri5', tol_scale=200.0, time=1.7)
       edge_attr = None
       if name.startswith('selfcheck_rw:'):
         # opt['reweight_attention'] with a weighted edge list (reference src/function_transformer_attention.py:208-209: the scores
@@ -64,7 +68,7 @@ def main():
       dist.all_gather(allz, mine)
       res[name] = dict(rel_max=e_inf, rel_l2=e_2, nfe=nfe, ref_nfe=nfe_one, replay_equal=bool(torch.equal(z, z2)),
                        ranks_agree=all(torch.equal(a, mine) for a in allz), own_rows=sh.n_own, halo_rows=sh.n_halo, world=world,
-                       moved=float((z_one - x).abs().max()))
+                       moved=float((z_one - x).abs().max()), solvers=sorted(type(v).__name__ for v in ent['solvers'].values()))
       dist.barrier()
       for e in block.odefunc._shard_state.values():
         e['close']()

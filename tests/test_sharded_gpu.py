@@ -119,7 +119,9 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
            # BLEND's split feature x positional kernel as a per-evaluation attention (no recorded block solve: against the one-GPU solve)
            'selfcheck:func_transformer_beltrami_expkernel,selfcheck:func_transformer_beltrami_expkernel_sqp,'
            # re-weighted attention (edge_attr data): row softmax in the in-graph solver, column softmax in the exchange loop
-           'selfcheck_rw:func_transformer_sd_softmax_n0,selfcheck_rw:func_transformer_sd_softmax_n1')
+           'selfcheck_rw:func_transformer_sd_softmax_n0,selfcheck_rw:func_transformer_sd_softmax_n1,'
+           # dopri5 of a function normalised over COLUMNS: the device controller over the engine's general mode (round 6)
+           'selfcheck_dopri5:func_transformer_sd_softmax_n1')
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
          '--master-port', str(29640 + world), os.path.join(root, 'tests', 'dist_block_worker.py'), out, names]
@@ -135,6 +137,8 @@ def test_blocks_run_sharded_from_the_operator_surface(dev, tmp_path, world):
     if name == 'block_constant_transformer_sqp_n1_rk4':
       # squareplus over columns: the exchanges between the attention passes ride in the per-rank graph (gnpde_sharded_solver_set_general)
       assert e['solvers'] == ['NativeShardedSolver'], (name, e)
+    if name.startswith('selfcheck_dopri5:'):
+      assert e['solvers'] == ['NativeShardedDopri5'], (name, e)
     if name.endswith('_dopri5'):
       # the adaptive blocks take the device controller over the partition (gnpde_dopri5_create_sharded): fewer reads of the
       # controller record than trial steps, none per trial step
