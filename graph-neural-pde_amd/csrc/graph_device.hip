@@ -73,15 +73,23 @@ __global__ __launch_bounds__(kBlock) void gd_classify_kernel(const int* __restri
     nlr += __shfl_xor(nlr, o, kWave); nlc += __shfl_xor(nlc, o, kWave); nch += __shfl_xor(nch, o, kWave);
     mr = max(mr, __shfl_xor(mr, o, kWave)); mc = max(mc, __shfl_xor(mc, o, kWave));
   }
+  // ... then the block's four waves through the LDS: one atomic per BLOCK and counter (thousands of waves on eight addresses serialise)
+  __shared__ int part[kWavesPerBlock][8];
   if ((threadIdx.x & (kWave - 1)) == 0) {
-    if (n16) atomicAdd(counts + C_N16, n16);
-    if (n64) atomicAdd(counts + C_N64, n64);
-    if (nle) atomicAdd(counts + C_NLE64, nle);
-    if (nlr) atomicAdd(counts + C_NLONGR, nlr);
-    if (nlc) atomicAdd(counts + C_NLONGC, nlc);
-    if (nch) atomicAdd(counts + C_NCHUNKS, nch);
-    if (mr) atomicMax(counts + C_MAXROW, mr);
-    if (mc) atomicMax(counts + C_MAXCOL, mc);
+    int* p = part[threadIdx.x >> 6];
+    p[0] = n16; p[1] = n64; p[2] = nle; p[3] = nlr; p[4] = nlc; p[5] = nch; p[6] = mr; p[7] = mc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int c = threadIdx.x;
+    int v = part[0][c];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) v = c < 6 ? v + part[w][c] : max(v, part[w][c]);
+    const int slot[8] = {C_N16, C_N64, C_NLE64, C_NLONGR, C_NLONGC, C_NCHUNKS, C_MAXROW, C_MAXCOL};
+    if (v != 0) {
+      if (c < 6) atomicAdd(counts + slot[c], v);
+      else atomicMax(counts + slot[c], v);
+    }
   }
 }
 
