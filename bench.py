@@ -35,7 +35,7 @@ import time
 import torch
 
 T_PROCESS_START = time.perf_counter()
-DEFAULT_RUN_SECONDS = 310      # the default run (headline + every other configuration by child runs) is planned to end within this
+DEFAULT_RUN_SECONDS = 290      # the default run (headline + every other configuration by child runs) is planned to end within this
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
