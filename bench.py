@@ -620,6 +620,10 @@ def cpu_baseline(block, x_cpu, evals):
   # three evaluations per candidate (one sample each made the choice -- 8 or 32 threads -- a coin toss, +-15 % on the baseline)
   ncpu = os.cpu_count() or 1
   cands = sorted({c for c in (ncpu, 64, 32, 16, 8) if c <= ncpu}, reverse=True)
+  if int(edge.shape[1]) * int(x_cpu.shape[1]) < 5_000_000:
+    # a graph this small (Cora: 13 k entries x 80 columns) is not worth a sweep over thread counts -- re-sizing the OpenMP pool five times
+    # cost the Cora children of the default run 9-19 s each, for a baseline that 8 threads give as well as 64
+    cands = [min(ncpu, 8)]
   trials = {}
   with torch.no_grad():
     torch.set_num_threads(min(cands[0], 16) if evals == 0 else cands[0])
@@ -1417,13 +1421,13 @@ CONFIG_CHILDREN = (
   # and prints its own full JSON line; the parent keeps a summary.  Ordered by what the line must not lose: the BASELINE configurations
   # first, the variants DESIGN.md quotes last -- a child that would not fit what is left of the budget is skipped and says so.
   ('c1_cora_grand_l_euler_T4', 'configs[0] as named: Cora GRAND-l, euler, step_size 1, T = 4',
-   ['--graph', 'cora', '--function', 'laplacian', '--method', 'euler', '--steps', '4', '--warmup', '4', '--no-live-pmc', '--no-hbm-probe', '--replays', '21'], 120, 11),
+   ['--graph', 'cora', '--function', 'laplacian', '--method', 'euler', '--steps', '4', '--warmup', '4', '--no-live-pmc', '--no-hbm-probe', '--replays', '21'], 120, 4),
   ('c1_cora_grand_l_rk4', 'configs[0] shape with rk4 (per-step time over 100 steps)',
-   ['--graph', 'cora', '--function', 'laplacian', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 11),
+   ['--graph', 'cora', '--function', 'laplacian', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 4),
   ('c2_cora_grand_nl_rk4_row_softmax', 'configs[1]: Cora GRAND-nl scaled_dot, rk4 (A = 128, 8 heads), softmax over rows',
-   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 21),
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--no-live-pmc', '--no-hbm-probe'], 120, 5),
   ('c2_cora_grand_nl_rk4_as_run_GNN_runs_it', 'configs[1] with best_params Cora normaliser: squareplus over columns',
-   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120, 22),
+   ['--graph', 'cora', '--steps', '100', '--warmup', '10', '--square-plus', '--norm-idx', '1', '--no-live-pmc', '--no-hbm-probe'], 120, 5),
   ('cora_best_params_epoch', 'the reference\'s flagship run (best_params Cora: attention block, Laplacian, dopri5, adjoint=False): s per epoch',
    ['--config', 'cora-epoch', '--steps', '20', '--warmup', '3'], 240, 4),
   ('pubmed_block_adaptive_heun_adjoint', 'best_params Pubmed\'s ODE block in training: dopri5 forward, adjoint_method adaptive_heun (the reference\'s default)',
